@@ -1,0 +1,264 @@
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/gen_golden.py [--only NAME]
+
+It imports the reference's own Python (`YOND_SIDD.py`, `utils/`, `archs/`) under the stub
+modules of `oracle/_refimport.py`, feeds it seeded synthetic inputs and procedurally seeded
+weights (`oracle/yond_oracle.procedural_state_dict`), and stores the reference's OUTPUTS
+(plus input checksums) as small .npz fixtures.  No reference source text is stored; the
+fixtures are data.  `tests/test_oracle_golden.py` replays them against the oracle on CPU and
+`tests/test_hip_*.py` against the HIP path on the GPU box (where /root/reference is absent).
+"""
+import argparse
+import hashlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refimport  # noqa: E402
+import yond_oracle as O  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+KSIG = [(0.72, 1.8), (4.37, 6.27), (22.65, 37.09), (39.2, 0.0)]     # (K, sigma) seen in the shipped log
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def checks(a):
+    a = np.asarray(a, np.float64)
+    return np.array([a.sum(), np.abs(a).sum(), (a * a).sum()])
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_pack(ref):
+    a = np.arange(6 * 8, dtype=np.float32).reshape(6, 8)
+    b = np.arange(4 * 6 * 4, dtype=np.float32).reshape(4, 6, 4)
+    save("pack", bayer=a, rggb=ref.bayer2rggb(a), rggb_in=b, bayer_out=ref.rggb2bayer(b))
+
+
+def gen_vst(ref):
+    x = np.linspace(-64, 1100, 2329).astype(np.float32)
+    out = {"x": x}
+    for i, (K, s) in enumerate(KSIG):
+        K, s = np.float64(K), np.float64(s)
+        v = ref.VST(x, s, gain=K)
+        out[f"vst_{i}"] = v
+        out[f"ivst_{i}"] = ref.inverse_VST(v.copy(), s, gain=K, exact=False)
+        out[f"ivst_exact_{i}"] = ref.inverse_VST(v.copy(), s, gain=K, exact=True)
+        z = np.linspace(-1.0, 80.0, 1621)
+        out[f"z_{i}"] = z
+        out[f"ivst_z_{i}"] = ref.inverse_VST(z.copy(), s, gain=K, exact=False)
+        out[f"ivst_exact_z_{i}"] = ref.inverse_VST(z.copy(), s, gain=K, exact=True)
+    out["ksig"] = np.array(KSIG)
+    save("vst", **out)
+
+
+def gen_bias(ref):
+    out = {"ksig": np.array(KSIG)}
+    for i, (K, s) in enumerate(KSIG):
+        for tag, mx in (("a", 959.7), ("b", 312.4), ("c", 41.3)):
+            f = ref.get_bias(np.float32(mx), np.float64(s), np.float64(K))
+            out[f"lams_{i}{tag}"] = np.asarray(f.x)
+            out[f"bias_{i}{tag}"] = np.asarray(f.y)
+            xq = np.linspace(0, np.ceil(mx) + 1, 777).astype(np.float32)
+            out[f"xq_{i}{tag}"] = xq
+            out[f"bq_{i}{tag}"] = f(xq)
+    out["max"] = np.array([959.7, 312.4, 41.3])
+    save("bias", **out)
+
+
+def gen_nle(ref):
+    out = {}
+    cases = [("s256", 256, 256, 4.0, 6.0, 0), ("s512", 512, 768, 4.0, 6.0, 1),
+             ("hi", 384, 512, 22.65, 37.09, 2), ("lo", 384, 512, 0.72, 1.8, 3)]
+    for tag, H, W, K, s, idx in cases:
+        noisy, clean = O.synth_noisy(H, W, K, s, idx)
+        out[f"{tag}_meta"] = np.array([H, W, K, s, idx])
+        out[f"{tag}_sha"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
+        rggb = ref.bayer2rggb(noisy)
+        k = 29
+        import cv2
+        lr_k = ref.stdfilt(rggb, k)
+        mean = cv2.blur(rggb, (k, k))
+        lap = ref.stdfilt(cv2.blur(rggb, (k // 3 * 2 + 1,) * 2), k)
+        th, pct = ref.get_threshold((lap, mean), step=5, mode='score3')
+        reg = ref.SimpleNLF(noisy, k=k, setting={'mode': 'self'})
+        out[f"{tag}_self"] = np.array([th, pct, reg[0], reg[1]])
+        out[f"{tag}_mean_crop"] = mean[:48, :48]
+        out[f"{tag}_std_crop"] = lr_k[:48, :48]
+        out[f"{tag}_lap_crop"] = lap[:48, :48]
+        out[f"{tag}_mean_chk"] = checks(mean)
+        out[f"{tag}_std_chk"] = checks(lr_k)
+        out[f"{tag}_lap_chk"] = checks(lap)
+        # collab: "denoised" stand-in = clean + small smooth error (deterministic)
+        dn = np.clip(clean + 0.002 * np.sin(np.arange(W)[None, :] / 37.0), 0, 1).astype(np.float32)
+        regc = ref.SimpleNLF(noisy, dn, k=k, setting={'mode': 'collab'})
+        hr = ref.bayer2rggb(dn)
+        hr_k = ref.stdfilt(hr, k)
+        thc, pctc = ref.get_threshold((hr_k, cv2.blur(hr, (k, k))), step=5, mode='score3')
+        out[f"{tag}_collab"] = np.array([thc, pctc, regc[0], regc[1]])
+    # SIDD_256 re-tiling: 256 x 8192 strip (packed 128 x 4096 -> 32 tiles of 128 x 128)
+    noisy, clean = O.synth_noisy(256, 8192, 4.0, 6.0, 7)
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(8192)[None, :] / 37.0), 0, 1).astype(np.float32)
+    out["strip_sha"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
+    r1 = ref.SimpleNLF(noisy, k=29, setting={'mode': 'self', 'SIDD_256': True})
+    r2 = ref.SimpleNLF(noisy, dn, k=29, setting={'mode': 'collab', 'SIDD_256': True})
+    r3 = ref.SimpleNLF(noisy, k=29, setting={'mode': 'self'})
+    out["strip_regs"] = np.array([r1, r2, r3])
+    save("nle", **out)
+
+
+ARCHS = {
+    "gru32": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+    "gru8": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
+    "gru32_nonorm": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=False, norm=False),
+    "snr32": dict(name='SNRnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+    "unet32": dict(name='UNetSeeInDark', in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+    "unet8": dict(name='UNetSeeInDark', in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
+}
+
+
+def ref_net(ref, arch, seed=0):
+    net = getattr(ref, arch['name'])(dict(arch))
+    sd = O.procedural_state_dict(arch, seed)
+    ref_keys = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    ours = {k: tuple(v.shape) for k, v in sd.items()}
+    assert ref_keys == ours, (set(ref_keys) ^ set(ours))
+    net = ref.load_weights(net, sd, by_name=False)
+    return net.eval(), sd
+
+
+def net_input(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g)
+
+
+def gen_net(ref):
+    out = {}
+    cases = [("gru32", (1, 4, 64, 96), 0.05), ("gru32", (2, 4, 32, 64), 0.1), ("gru8", (1, 4, 32, 32), 0.02),
+             ("gru32_nonorm", (1, 4, 32, 64), 0.08), ("snr32", (1, 4, 64, 64), 0.05),
+             ("unet32", (1, 4, 64, 96), None), ("unet8", (2, 4, 32, 32), None)]
+    for ci, (aname, shape, tval) in enumerate(cases):
+        arch = ARCHS[aname]
+        net, sd = ref_net(ref, arch, seed=ci)
+        x = net_input(shape, 100 + ci) * 0.9
+        with torch.no_grad():
+            if tval is not None:
+                if shape[0] == 1 and arch.get('norm', False):
+                    # 0-d, as YOND_SIDD.py:285 (the reference only accepts it when norm=True, where
+                    # t/(ub-lb) broadcasts it to (B,1,1,1); with norm=False conv2d rejects a 0-d t)
+                    t = torch.tensor(tval, dtype=torch.float32)
+                elif shape[0] == 1:
+                    t = torch.tensor([tval]).view(-1, 1, 1, 1)
+                else:
+                    t = torch.tensor([tval, 0.5 * tval]).view(-1, 1, 1, 1)   # as trainer_AWGN.py:362
+                y = net(x.clone(), t)
+                out[f"t_{ci}"] = t.numpy()
+            else:
+                y = net(x.clone())
+        out[f"meta_{ci}"] = np.array([ci, 100 + ci] + list(shape))
+        out[f"arch_{ci}"] = np.array(aname)
+        out[f"y_{ci}"] = y.numpy()
+        out[f"nparams_{ci}"] = np.array(sum(v.numel() for v in sd.values()))
+    save("net", **out)
+
+
+def fake_self(ref, arch, sd_seed, pipe):
+    obj = object.__new__(ref.YOND_SIDD)
+    obj.biaslut = None
+    obj.device = torch.device('cpu')
+    obj.arch = dict(arch)
+    net, sd = ref_net(ref, arch, sd_seed)
+    obj.net = net
+    obj.pipe = dict(pipe)
+    obj.dst = {'root_dir': '/nonexistent'}
+    obj.args = {}
+    obj.est_args = {}
+    obj.est_net = {}
+    obj.logfile = None
+    return obj, sd
+
+
+def gen_vst_denoiser(ref):
+    out = {}
+    pipe = {'vst_type': 'exact'}
+    for ci, (aname, H, W, K, s, bc) in enumerate([("gru32", 128, 192, 4.37, 6.27, 'pre'),
+                                                   ("gru32", 120, 136, 22.65, 37.09, 'pre'),
+                                                   ("gru32", 128, 128, 4.37, 6.27, None),
+                                                   ("unet32", 128, 192, 0.72, 1.8, 'pre')]):
+        arch = ARCHS[aname]
+        obj, sd = fake_self(ref, arch, 50 + ci, pipe)
+        noisy, _ = O.synth_noisy(H, W, K, s, 20 + ci)
+        p = {'wp': 1023, 'bl': 64, 'ratio': 1, 'scale': 959.0, 'gain': np.float64(K), 'sigma': np.float64(s)}
+        dn = ref.YOND_SIDD.VST_Denoiser(obj, noisy, None, bc, None, denoiser='gru32n', p=p)
+        out[f"meta_{ci}"] = np.array([H, W, K, s, 20 + ci, 50 + ci])
+        out[f"arch_{ci}"] = np.array(aname)
+        out[f"bias_corr_{ci}"] = np.array(str(bc))
+        out[f"sha_{ci}"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
+        out[f"dn_{ci}"] = np.asarray(dn)
+    save("vst_denoiser", **out)
+
+
+def gen_iter(ref):
+    out = {}
+    H, W = 256, 8192
+    noisy, clean = O.synth_noisy(H, W, 4.0, 6.0, 31)
+    full, _ = O.synth_noisy(512, 1024, 4.0, 6.0, 32)           # "full frame" used for round-1 NLE
+    tmp = tempfile.mkdtemp()
+    full_path = os.path.join(tmp, "full.npy")
+    np.save(full_path, full)
+    out["sha_noisy"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
+    out["sha_full"] = np.frombuffer(bytes.fromhex(sha(full)), np.uint8)
+    base_pipe = {'data_type': 'SIDD', 'full_est': True, 'est_type': 'simple+full', 'k': 29, 'vst_type': 'exact',
+                 'bias_corr': 'pre', 'denoiser_type': 'gru32n', 'iter': 'iter', 'max_iter': 1, 'clip': False}
+    for ci, (aname, full_dn) in enumerate([("gru8", False), ("gru8", True)]):
+        pipe = dict(base_pipe, full_dn=full_dn)
+        obj, sd = fake_self(ref, ARCHS[aname], 70 + ci, pipe)
+        p = dict(pipe)
+        p.update({'K': 8.74253, 'sigGs': 12.81, 'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0})
+        p['scale'] = (p['wp'] - p['bl']) / p['ratio']
+        data = {'lr_path_full': full_path, 'lr': np.array(np.split(noisy, 32, axis=-1)),
+                'hr': np.array(np.split(clean, 32, axis=-1)), 'meta': None, 'name': 'synthetic_000'}
+        res = obj.IterDenoise(data, {'p': p, 'img_id': 0})
+        regs = np.array([np.asarray(r, np.float64) for r in res['regs']])
+        out[f"regs_{ci}"] = regs
+        out[f"full_dn_{ci}"] = np.array(full_dn)
+        out[f"arch_{ci}"] = np.array(aname)
+        out[f"seed_{ci}"] = np.array(70 + ci)
+        for it, dn in enumerate(res['raw_dns']):
+            dn = np.asarray(dn)
+            out[f"dn_{ci}_{it}_crop"] = dn[:, :768].astype(np.float32)
+            out[f"dn_{ci}_{it}_chk"] = checks(dn)
+    save("iter", **out)
+
+
+GENS = dict(pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
+            vst_denoiser=gen_vst_denoiser, iter=gen_iter)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    ref = _refimport.import_reference()
+    for name, fn in GENS.items():
+        if a.only and a.only != name:
+            continue
+        print("==", name)
+        fn(ref)

@@ -1,0 +1,773 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of YOND's per-image hot path.
+
+This module is the checker, never the product:
+  * only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+    `bench.py` may import it;
+  * nothing under `yond_public_amd/` imports it, and the product path raises when
+    the HIP library is missing instead of falling back to anything in here.
+
+Every function restates one function of the reference (fenghansen/YOND_public @
+2025-02-22, paths relative to /root/reference) in NumPy / SciPy / PyTorch-CPU and
+cites the lines it follows.  dtypes are staged exactly as the reference stages
+them under NumPy 2 promotion rules (float32 image arrays, float64 NumPy scalars
+for the noise parameters, so the VST side is float64 and the network side is
+float32).
+
+Pinning: the reference ships no tests or golden vectors, so the
+oracle is pinned against outputs of the reference itself, generated in the build
+container by `oracle/gen_golden.py` (which imports /root/reference under stub
+modules) and committed as `tests/golden/*.npz`; `tests/test_oracle_golden.py`
+replays them.  One boundary stays UNPINNED: `cv2.blur` (OpenCV is absent from the
+image and from /root/reference); `box_blur` below restates its documented
+semantics and the golden vectors were produced with an independent restatement
+of the same semantics (`oracle/_refimport._cv2_blur`).  skimage's PSNR and the
+cv2-based SSIM are restated from their formulas and are unpinned as well.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------
+# Row A -- Bayer pack / unpack (utils/isp_ops.py:57-63).  Index permutation, bit exact.
+# ----------------------------------------------------------------------------------------
+
+def bayer2rggb(bayer):
+    """utils/isp_ops.py:57-59: out[i, j, 2*dy+dx] = in[2i+dy, 2j+dx]."""
+    H, W = bayer.shape
+    return bayer.reshape(H // 2, 2, W // 2, 2).transpose(0, 2, 1, 3).reshape(H // 2, W // 2, 4)
+
+
+def rggb2bayer(rggb):
+    """utils/isp_ops.py:61-63: inverse of bayer2rggb."""
+    H, W, _ = rggb.shape
+    return rggb.reshape(H, W, 2, 2).transpose(0, 2, 1, 3).reshape(H * 2, W * 2)
+
+
+# ----------------------------------------------------------------------------------------
+# Row B -- cv2.blur restatement + stdfilt (utils/isp_algos.py:234-242)
+# ----------------------------------------------------------------------------------------
+
+def _reflect101(idx, n):
+    """BORDER_REFLECT_101 index map: ... 2 1 | 0 1 2 ... n-1 | n-2 n-3 ..."""
+    if n == 1:
+        return np.zeros_like(idx)
+    period = 2 * (n - 1)
+    idx = np.mod(idx, period)
+    return np.where(idx >= n, period - idx, idx)
+
+
+def box_blur(img, k):
+    """cv2.blur(img, (k, k)) restated: normalised k x k box mean, anchor at the centre,
+    BORDER_REFLECT_101, each channel independently (img is HxW or HxWxC), window sums in
+    float64, result = float64 sum * (1/(k*k)) cast to the input dtype.
+    Called by the reference at utils/isp_algos.py:236,240 and YOND_SIDD.py:69,70,97."""
+    a = np.asarray(img)
+    r = k // 2
+    x = a.astype(np.float64)
+    H, W = x.shape[:2]
+    # horizontal pass
+    cols = _reflect101(np.arange(-r, W + r), W)
+    xp = x[:, cols]
+    cs = np.cumsum(xp, axis=1)
+    cs = np.concatenate([np.zeros_like(cs[:, :1]), cs], axis=1)
+    h = cs[:, k:k + W] - cs[:, 0:W]
+    # vertical pass
+    rows = _reflect101(np.arange(-r, H + r), H)
+    hp = h[rows]
+    cs = np.cumsum(hp, axis=0)
+    cs = np.concatenate([np.zeros_like(cs[:1]), cs], axis=0)
+    v = cs[k:k + H] - cs[0:H]
+    return (v * (1.0 / (k * k))).astype(a.dtype)
+
+
+def box_blur_direct(img, k):
+    """Same definition as `box_blur`, evaluated by direct summation of the k*k shifted images
+    (no cumulative-sum cancellation).  Slow; used by tests on small inputs."""
+    a = np.asarray(img)
+    r = k // 2
+    x = a.astype(np.float64)
+    H, W = x.shape[:2]
+    rows = _reflect101(np.arange(-r, H + r), H)
+    cols = _reflect101(np.arange(-r, W + r), W)
+    xp = x[rows][:, cols]
+    acc = np.zeros_like(x)
+    for dy in range(k):
+        for dx in range(k):
+            acc += xp[dy:dy + H, dx:dx + W]
+    return (acc * (1.0 / (k * k))).astype(a.dtype)
+
+
+def stdfilt(img, k=5, blur=box_blur):
+    """utils/isp_algos.py:234-242: sqrt(max(blur(img**2) - blur(img)**2, 0)); every
+    intermediate keeps the input dtype (float32 on the hot path)."""
+    img_blur = blur(img, k)
+    result_1 = img_blur ** 2
+    img_2 = img ** 2
+    result_2 = blur(img_2, k)
+    return np.sqrt(np.maximum(result_2 - result_1, 0))
+
+
+# ----------------------------------------------------------------------------------------
+# Row C -- adaptive threshold (YOND_SIDD.py:22-49, mode 'score3')
+# ----------------------------------------------------------------------------------------
+
+def percentile_linear(data, quants):
+    """np.percentile(data.reshape(-1), quants, method='linear') restated (NumPy 2.2
+    lib/_function_base_impl.py `_quantile` + `_lerp`): virtual index q/100*(n-1) in float64,
+    neighbours taken from the sorted data in the data dtype, diff = b - a in the data dtype,
+    result = a + diff*t (t < 0.5) or b - diff*(1-t) (t >= 0.5) in float64."""
+    a = np.sort(np.asarray(data).reshape(-1))
+    n = a.size
+    q = np.asarray(quants, dtype=np.float64) / 100.0
+    vidx = q * (n - 1)
+    lo = np.floor(vidx).astype(np.int64)
+    hi = np.minimum(lo + 1, n - 1)
+    t = vidx - lo
+    av, bv = a[lo], a[hi]
+    diff = bv - av                                  # data dtype (float32 on the hot path)
+    out = av + diff * t
+    out = np.where(t >= 0.5, bv - diff * (1 - t), out)
+    out = np.where(bv == av, av.astype(out.dtype), out)
+    return out
+
+
+def get_threshold_score3(data, mean, step=5, nbins=1000, full=False):
+    """YOND_SIDD.py:22-49.  data = img_lap, mean = local mean, both (h, w, C) float32."""
+    quants = np.linspace(step, 100, 100 // step, endpoint=True)
+    ths = percentile_linear(data, quants)
+    npeaks = np.ones_like(ths)
+    for i in range(len(ths)):
+        bucket = (mean[data <= ths[i]].clip(0, 1) * nbins).astype(int)       # :37
+        counts = np.bincount(bucket, minlength=nbins + 1)                      # :40
+        npeaks[i] = np.sum(counts > 0)                                         # :43
+    score = ths / (quants * npeaks)                                            # :45
+    i = int(np.argmin(score[1:]) + 1)                                          # :46-47
+    if full:
+        return ths[i], quants[i], dict(ths=ths, npeaks=npeaks, score=score, index=i)
+    return ths[i], quants[i]
+
+
+# ----------------------------------------------------------------------------------------
+# Row E -- polyfit (utils/isp_algos.py:345-365, ransac=False)
+# ----------------------------------------------------------------------------------------
+
+def polyfit(x, y):
+    """utils/isp_algos.py:345-365 (least-squares branch).  The reference calls
+    scipy.linalg.lstsq on X = [x, 1] (float64 after vstack with np.ones) -- the oracle calls
+    the same routine; the side effect setup_seed(2024) (:346) has no numerical effect."""
+    import scipy.linalg
+    nonsat = np.logical_and(x > 1e-4, x < 0.8)
+    if len(x[nonsat]) > 0.01 * len(x.reshape(-1)):
+        x, y = x[nonsat], y[nonsat]
+    X = np.vstack([x, np.ones(len(x))]).T
+    res, _, _, _ = scipy.linalg.lstsq(X, y)
+    return res
+
+
+def polyfit_moments(x, y):
+    """The same fit from the five moment sums (what the HIP path accumulates); float64."""
+    nonsat = np.logical_and(x > 1e-4, x < 0.8)
+    if np.count_nonzero(nonsat) > 0.01 * x.size:
+        x, y = x[nonsat], y[nonsat]
+    x = x.astype(np.float64)
+    y = y.astype(np.float64)
+    n, sx, sy, sxx, sxy = float(x.size), x.sum(), y.sum(), (x * x).sum(), (x * y).sum()
+    det = n * sxx - sx * sx
+    return np.array([(n * sxy - sx * sy) / det, (sxx * sy - sx * sxy) / det])
+
+
+# ----------------------------------------------------------------------------------------
+# Rows D, D', F -- SelfNLF / CollabNLF / SimpleNLF (YOND_SIDD.py:62-124)
+# ----------------------------------------------------------------------------------------
+
+def _sidd_256(rggb):
+    """YOND_SIDD.py:64-65 / :91-93: split into 32 along W, stack on the channel axis so
+    that box windows never straddle the 256x256 SIDD blocks."""
+    return np.concatenate(np.split(rggb, 32, axis=-2), axis=-1)
+
+
+def _select_and_fit(var, mean, img_lap, full=False):
+    th, percent, info = get_threshold_score3(img_lap, mean, step=5, full=True)
+    sel = img_lap < th
+    if np.count_nonzero(sel) > 0:                                              # :77 / :105
+        v, m = var[sel], mean[sel]
+    else:                                                                      # :79-84
+        th_backup = percentile_linear(img_lap, [25.0])[0]
+        v, m = var, mean
+        if th != th_backup:
+            th = th_backup
+            sel = img_lap < th
+            v, m = var[sel], mean[sel]
+    reg = polyfit(m.reshape(-1), v.reshape(-1))
+    if full:
+        info.update(th=th, percent=percent, nsel=int(np.count_nonzero(sel)))
+        return reg, info
+    return reg
+
+
+def SelfNLF(lr_rggb, k=29, SIDD_256=False, full=False, blur=box_blur):
+    """YOND_SIDD.py:62-87."""
+    if SIDD_256:
+        lr_rggb = _sidd_256(lr_rggb)
+    lr_k = stdfilt(lr_rggb, k, blur)
+    mean = blur(lr_rggb, k)
+    k2 = k // 3 * 2 + 1
+    img_lap = stdfilt(blur(lr_rggb, k2), k, blur)
+    var = lr_k ** 2
+    return _select_and_fit(var, mean, img_lap, full)
+
+
+def CollabNLF(lr_rggb, hr_rggb, k=29, SIDD_256=False, full=False, blur=box_blur):
+    """YOND_SIDD.py:89-115."""
+    if SIDD_256:
+        lr_rggb = _sidd_256(lr_rggb)
+        hr_rggb = _sidd_256(hr_rggb)
+    lr_k = stdfilt(lr_rggb, k, blur)
+    hr_k = stdfilt(hr_rggb, k, blur)
+    var = lr_k ** 2 - hr_k ** 2
+    mean = blur(hr_rggb, k)
+    img_lap = hr_k
+    return _select_and_fit(var, mean, img_lap, full)
+
+
+def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, blur=box_blur):
+    """YOND_SIDD.py:117-124."""
+    setting = setting or {'mode': 'self'}
+    lr_rggb = bayer2rggb(lr_raw)
+    sidd = bool(setting.get('SIDD_256', False))
+    if setting['mode'] == 'self':
+        return SelfNLF(lr_rggb, k, sidd, full, blur)
+    elif setting['mode'] == 'collab':
+        return CollabNLF(lr_rggb, bayer2rggb(hr_raw), k, sidd, full, blur)
+    raise NotImplementedError(setting['mode'])
+
+
+# ----------------------------------------------------------------------------------------
+# Rows G, G' -- VST / inverse VST (utils/isp_algos.py:5-33)
+# ----------------------------------------------------------------------------------------
+
+def VST(x, sigma, mu=0, gain=1.0):
+    """utils/isp_algos.py:5-14: 2/K * sqrt(max(K x + 3/8 K^2 + sigma^2 - K mu, 0))."""
+    fz = gain * x + (3 / 8) * gain ** 2 + sigma ** 2 - gain * mu
+    fz = np.maximum(fz, 0)
+    return 2 / gain * fz ** 0.5
+
+
+def inverse_VST(z, sigma, gain=1, exact=False):
+    """utils/isp_algos.py:17-33.  `exact=True` is the closed-form approximation of the exact
+    unbiased inverse (used only when bias_corr is None, YOND_SIDD.py:296); unlike the
+    reference it does not modify `z` in place."""
+    sigma = sigma / gain
+    if exact:
+        z = np.array(z, dtype=np.result_type(z, np.float32), copy=True)
+        pos = z > 0
+        zp = np.where(pos, z, 1.0)
+        fz = (zp / 2) ** 2 + (1 / 4) * ((3 / 2) ** 0.5) * zp ** (-1.0) - (11 / 8) * zp ** (-2.0) \
+            + (5 / 8) * ((3 / 2) ** 0.5) * zp ** (-3.0) - 1 / 8 - sigma ** 2
+        fz = np.where(pos, fz, 0.0)
+    else:
+        fz = (z / 2) ** 2 - 3.0 / 8.0 - sigma ** 2
+    fz = np.maximum(fz, 0)
+    return fz * gain
+
+
+# ----------------------------------------------------------------------------------------
+# Row H -- VST bias LUT (utils/isp_algos.py:49-140)
+# ----------------------------------------------------------------------------------------
+
+def bias_knots(ub):
+    """utils/isp_algos.py:101-108: the lambda grid for ub = ceil(max)+1."""
+    lb = 0
+    if ub < 50:
+        return np.linspace(lb, ub, int((ub - lb) / 0.1) + 2)
+    elif ub < 500:
+        return np.concatenate((np.linspace(lb, 50, int((50 - lb) / 0.1) + 1),
+                               np.linspace(50, ub, int(ub - 50) + 2)))
+    return np.concatenate((np.linspace(lb, 50, int((50 - lb) / 0.1) + 1),
+                           np.linspace(50, 500, 451),
+                           np.linspace(500, ub, int(ub - 500) // 10 + 2)))
+
+
+def getGsP(lam, K, sigGs, r=5, pho=1):
+    """utils/isp_algos.py:49-82 (clip=False, show=False): Poisson(lam/K) (*) N(0, sigGs/K)
+    sampled at 1/pho e- over [-r, r], renormalised so that sum(p)/pho == 1."""
+    from scipy.stats import poisson, norm
+    from scipy.signal import convolve
+    l = 2 * pho * r + 1
+    x = np.linspace(-r, r, l)
+    Ps = poisson.pmf(x, lam / K)
+    if sigGs > 0:
+        Gs = norm.pdf(x, loc=0, scale=sigGs / K)
+        conv = convolve(Ps, Gs, mode='same')
+    else:
+        conv = poisson.pmf(x, lam / K)
+    conv[conv < 0] = 0
+    conv = conv / (conv.sum() / pho)
+    return x, conv
+
+
+def close_form_bias(x, sigGs, K):
+    """utils/isp_algos.py:84-96 (Foi's closed-form bias of the generalized Anscombe VST)."""
+    y = x / K
+    sigma = sigGs / K
+    y_hat = y + 3 / 8 + sigma ** 2
+    m1 = (y + sigma ** 2) / y_hat ** 2
+    m2 = y / y_hat ** 3
+    m3 = (y + 3 * (y + sigma ** 2) ** 2) / y_hat ** 4
+    return 2 * y_hat ** 0.5 * (-1 / 8 * m1 + 1 / 16 * m2 - 5 / 128 * m3)
+
+
+def get_bias_table(img_max, sigGs, K, pho_min=1):
+    """utils/isp_algos.py:98-127 (close_form=True, clip=False): returns (lams float64,
+    bias float32) -- the knots the reference hands to interp1d."""
+    ub = np.ceil(img_max) + 1
+    lams = bias_knots(ub)
+    bias = np.zeros(len(lams), np.float32)
+    pho = np.maximum(int(K ** 0.5), pho_min)
+    th = 50 * K if K < 1 else 50 * K ** 0.5
+    bias[lams > th] = close_form_bias(lams[lams > th], sigGs, K)
+    for i, lam in enumerate(lams[lams <= th]):
+        x, p = getGsP(lam, K, sigGs, r=int(lam * (1 / K) * 2 + sigGs * 2 + lam + 10), pho=pho)
+        bias[i] = np.sum(p * VST(K * x, sigGs, gain=K) / pho) - VST(lam, sigGs, gain=K)
+    return lams, bias
+
+
+def interp_linear(xk, yk, xq):
+    """scipy.interpolate.interp1d(xk, yk) (kind='linear', bounds_error=True) restated
+    (scipy/interpolate/_interpolate.py `_call_linear`): hi = clip(searchsorted(xk, xq), 1, n-1),
+    lo = hi-1, slope = (y_hi - y_lo)/(x_hi - x_lo) with y_hi - y_lo evaluated in y's dtype
+    (float32: get_bias stores its knots as float32) and everything else in float64,
+    y = slope*(xq - x_lo) + y_lo."""
+    xk = np.asarray(xk)          # float64, except float32 when ub < 50 (np.linspace of a float32 ub)
+    yk = np.asarray(yk)
+    xq = np.asarray(xq)
+    if xq.size and (xq.min() < xk[0] or xq.max() > xk[-1]):
+        raise ValueError("A value in x_new is outside the interpolation range.")
+    hi = np.searchsorted(xk, xq).clip(1, len(xk) - 1).astype(int)
+    lo = hi - 1
+    x_lo, x_hi = xk[lo], xk[hi]
+    y_lo, y_hi = yk[lo], yk[hi]
+    slope = (y_hi - y_lo) / (x_hi - x_lo)
+    return slope * (xq - x_lo) + y_lo
+
+
+class BiasFunc:
+    """Callable with the behaviour of the interp1d object `get_bias` returns (:128)."""
+
+    def __init__(self, lams, bias):
+        self.x = np.asarray(lams)
+        self.y = np.asarray(bias, np.float32)
+
+    def __call__(self, xq):
+        return interp_linear(self.x, self.y, xq)
+
+
+def get_bias(img_max, sigGs, K):
+    return BiasFunc(*get_bias_table(img_max, sigGs, K))
+
+
+# ----------------------------------------------------------------------------------------
+# Row I -- padding helper (utils/utils.py:246-252)
+# ----------------------------------------------------------------------------------------
+
+def get_p2d(shape, base=16):
+    xb, xc, xh, xw = shape
+    yh, yw = ((xh - 1) // base + 1) * base, ((xw - 1) // base + 1) * base
+    diffY, diffX = yh - xh, yw - xw
+    return (diffX // 2, diffX - diffX // 2, diffY // 2, diffY - diffY // 2)
+
+
+# ----------------------------------------------------------------------------------------
+# Rows K-P -- denoiser forward passes on CPU (archs/Unet.py, archs/modules.py), written
+# functionally over a state_dict with the reference's keys.
+# ----------------------------------------------------------------------------------------
+
+def data_normalize(x):
+    """archs/modules.py:15-21: lower = 0, upper = per-item max over (C, H, W)."""
+    ub = torch.stack([x[b].max() for b in range(x.shape[0])]).view(-1, 1, 1, 1)
+    return x / ub, ub
+
+
+def _conv(sd, key, x, stride=1, padding=0):
+    return F.conv2d(x, sd[key + '.weight'], sd.get(key + '.bias'), stride=stride, padding=padding)
+
+
+def _guided_block(sd, pre, x, t, has_sc):
+    """archs/modules.py:186-196."""
+    if has_sc:
+        x = _conv(sd, pre + '.short_cut.0', x)
+    z = F.silu(x)
+    z = _conv(sd, pre + '.conv1', z, padding=1)
+    tk = _conv(sd, pre + '.gamma.2', F.silu(_conv(sd, pre + '.gamma.0', t)))
+    tb = _conv(sd, pre + '.beta.1', F.silu(tk))
+    z = z * tk + tb
+    z = F.silu(z)
+    z = _conv(sd, pre + '.conv2', z, padding=1)
+    return z + x
+
+
+def _snr_block(sd, pre, x, t, has_sc):
+    """archs/modules.py:221-233."""
+    if has_sc:
+        x = _conv(sd, pre + '.short_cut.0', x)
+    z = F.silu(x)
+    z = _conv(sd, pre + '.conv1', z, padding=1)
+    a1 = _conv(sd, pre + '.sfm1.2', F.silu(_conv(sd, pre + '.sfm1.0', t)))
+    z = z * a1
+    z = F.silu(z)
+    z = _conv(sd, pre + '.conv2', z, padding=1)
+    a2 = _conv(sd, pre + '.sfm2.2', F.silu(_conv(sd, pre + '.sfm2.0', t)))
+    z = z * a2
+    return z + x
+
+
+def _as_t(t, x):
+    t = torch.as_tensor(t, dtype=x.dtype)
+    if t.ndim == 0:
+        t = t.view(1, 1, 1, 1).expand(x.shape[0], 1, 1, 1)
+    return t.reshape(-1, 1, 1, 1)
+
+
+def guided_unet_forward(sd, x, t, block='guided', res=True, norm=True):
+    """GuidedResUnet.forward (archs/Unet.py:424-470) / SNRnet.forward (:332-378)."""
+    blk = _guided_block if block == 'guided' else _snr_block
+    t = _as_t(t, x)
+    if norm:
+        x, ub = data_normalize(x)
+        t = t / ub
+    conv_in = F.leaky_relu(_conv(sd, 'conv_in', x, padding=1), 0.01)
+    c1 = blk(sd, 'conv1', conv_in, t, False)
+    p1 = _conv(sd, 'pool1.conv', c1, stride=2, padding=1)       # no activation (dead ReLU)
+    c2 = blk(sd, 'conv2', p1, t, False)
+    p2 = _conv(sd, 'pool2.conv', c2, stride=2, padding=1)
+    c3 = blk(sd, 'conv3', p2, t, False)
+    p3 = _conv(sd, 'pool3.conv', c3, stride=2, padding=1)
+    c4 = blk(sd, 'conv4', p3, t, False)
+    p4 = _conv(sd, 'pool4.conv', c4, stride=2, padding=1)
+    c5 = blk(sd, 'conv5', p4, t, False)
+    up = F.conv_transpose2d(c5, sd['upv6.weight'], sd['upv6.bias'], stride=2)
+    c6 = blk(sd, 'conv6', torch.cat([up, c4], 1), t, True)
+    up = F.conv_transpose2d(c6, sd['upv7.weight'], sd['upv7.bias'], stride=2)
+    c7 = blk(sd, 'conv7', torch.cat([up, c3], 1), t, True)
+    up = F.conv_transpose2d(c7, sd['upv8.weight'], sd['upv8.bias'], stride=2)
+    c8 = blk(sd, 'conv8', torch.cat([up, c2], 1), t, True)
+    up = F.conv_transpose2d(c8, sd['upv9.weight'], sd['upv9.bias'], stride=2)
+    c9 = blk(sd, 'conv9', torch.cat([up, c1], 1), t, True)
+    out = _conv(sd, 'conv10', c9)
+    if res:
+        out = out + x[:, 0:4]
+    if norm:
+        out = out * ub
+    return out
+
+
+def unet_sid_forward(sd, x, res=True, norm=True):
+    """UNetSeeInDark.forward (archs/Unet.py:55-104): LeakyReLU(0.2), MaxPool2d(2)."""
+    act = lambda v: F.leaky_relu(v, 0.2)
+    if norm:
+        x, ub = data_normalize(x)
+    c1 = act(_conv(sd, 'conv1_2', act(_conv(sd, 'conv1_1', x, padding=1)), padding=1))
+    c2 = act(_conv(sd, 'conv2_2', act(_conv(sd, 'conv2_1', F.max_pool2d(c1, 2), padding=1)), padding=1))
+    c3 = act(_conv(sd, 'conv3_2', act(_conv(sd, 'conv3_1', F.max_pool2d(c2, 2), padding=1)), padding=1))
+    c4 = act(_conv(sd, 'conv4_2', act(_conv(sd, 'conv4_1', F.max_pool2d(c3, 2), padding=1)), padding=1))
+    c5 = act(_conv(sd, 'conv5_2', act(_conv(sd, 'conv5_1', F.max_pool2d(c4, 2), padding=1)), padding=1))
+    up = torch.cat([F.conv_transpose2d(c5, sd['upv6.weight'], sd['upv6.bias'], stride=2), c4], 1)
+    c6 = act(_conv(sd, 'conv6_2', act(_conv(sd, 'conv6_1', up, padding=1)), padding=1))
+    up = torch.cat([F.conv_transpose2d(c6, sd['upv7.weight'], sd['upv7.bias'], stride=2), c3], 1)
+    c7 = act(_conv(sd, 'conv7_2', act(_conv(sd, 'conv7_1', up, padding=1)), padding=1))
+    up = torch.cat([F.conv_transpose2d(c7, sd['upv8.weight'], sd['upv8.bias'], stride=2), c2], 1)
+    c8 = act(_conv(sd, 'conv8_2', act(_conv(sd, 'conv8_1', up, padding=1)), padding=1))
+    up = torch.cat([F.conv_transpose2d(c8, sd['upv9.weight'], sd['upv9.bias'], stride=2), c1], 1)
+    c9 = act(_conv(sd, 'conv9_2', act(_conv(sd, 'conv9_1', up, padding=1)), padding=1))
+    out = _conv(sd, 'conv10_1', c9)
+    if res:
+        out = out + x[:, 0:4]
+    if norm:
+        out = out * ub
+    return out
+
+
+def net_forward(arch, sd, x, t=None):
+    name = arch['name']
+    res, norm = bool(arch.get('res', True)), bool(arch.get('norm', False))
+    with torch.no_grad():
+        if name == 'GuidedResUnet':
+            return guided_unet_forward(sd, x, t, 'guided', res, norm)
+        if name == 'SNRnet':
+            return guided_unet_forward(sd, x, t, 'snr', res, norm)
+        if name == 'UNetSeeInDark':
+            return unet_sid_forward(sd, x, res, norm)
+    raise NotImplementedError(name)
+
+
+# ----------------------------------------------------------------------------------------
+# Procedural weights (defined by the build; loaded into the reference net by gen_golden.py
+# and into the HIP-backed modules by the tests, so both sides see identical parameters).
+# ----------------------------------------------------------------------------------------
+
+def arch_param_shapes(arch):
+    """state_dict keys -> shapes for the three hot-path architectures (archs/Unet.py:4-53,
+    288-330, 380-422; archs/modules.py:163-233)."""
+    nf, inc, outc = arch['nf'], arch['in_nc'] * arch.get('nframes', 1), arch['out_nc']
+    shapes = {}
+
+    def conv(key, cout, cin, k):
+        shapes[key + '.weight'] = (cout, cin, k, k)
+        shapes[key + '.bias'] = (cout,)
+
+    def convT(key, cin, cout):
+        shapes[key + '.weight'] = (cin, cout, 2, 2)
+        shapes[key + '.bias'] = (cout,)
+
+    name = arch['name']
+    if name == 'UNetSeeInDark':
+        chans = [nf, nf * 2, nf * 4, nf * 8, nf * 16]
+        cin = inc
+        for i, c in enumerate(chans, start=1):
+            conv(f'conv{i}_1', c, cin, 3)
+            conv(f'conv{i}_2', c, c, 3)
+            cin = c
+        for i, c in zip(range(6, 10), [nf * 8, nf * 4, nf * 2, nf]):
+            convT(f'upv{i}', c * 2, c)
+            conv(f'conv{i}_1', c, c * 2, 3)
+            conv(f'conv{i}_2', c, c, 3)
+        conv('conv10_1', outc, nf, 1)
+        return shapes
+
+    def block(pre, cin, c):
+        conv(pre + '.conv1', c, c, 3)
+        conv(pre + '.conv2', c, c, 3)
+        if name == 'GuidedResUnet':
+            conv(pre + '.gamma.0', c, 1, 1)
+            conv(pre + '.gamma.2', c, c, 1)
+            conv(pre + '.beta.1', c, c, 1)
+        else:
+            for s in ('sfm1', 'sfm2'):
+                conv(pre + f'.{s}.0', c, 1, 1)
+                conv(pre + f'.{s}.2', c, c, 1)
+        if cin != c:
+            conv(pre + '.short_cut.0', c, cin, 1)
+
+    conv('conv_in', nf, inc, 3)
+    c = nf
+    for i in range(1, 5):
+        block(f'conv{i}', c, c)
+        conv(f'pool{i}.conv', c * 2, c, 3)
+        c *= 2
+    block('conv5', c, c)
+    for i in range(6, 10):
+        convT(f'upv{i}', c, c // 2)
+        block(f'conv{i}', c, c // 2)
+        c //= 2
+    conv('conv10', outc, nf, 1)
+    return shapes
+
+
+def procedural_state_dict(arch, seed=0, gain=1.0):
+    """Deterministic weights: per-key seeded generator, fan-in-scaled normal weights
+    (std = gain*sqrt(1/fan_in) so activations stay O(1) through the 27-conv stack) and small
+    normal biases.  Keys are visited in sorted order so the result does not depend on dict order."""
+    import zlib
+    sd = {}
+    for key, shape in sorted(arch_param_shapes(arch).items()):
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(key.encode())) % (2 ** 31))
+        if key.endswith('.weight'):
+            if 'upv' in key:
+                fan_in = shape[0]                        # ConvT 2x2 s2: one tap per output pixel
+            else:
+                fan_in = shape[1] * shape[2] * shape[3]
+            std = gain * math.sqrt(1.0 / fan_in)
+            if '.gamma.0' in key or '.sfm1.0' in key or '.sfm2.0' in key:
+                std = 4.0                                # input is the scalar t ~ 0.01..0.2
+            sd[key] = torch.randn(shape, generator=g) * std
+        else:
+            sd[key] = torch.randn(shape, generator=g) * 0.05
+            if '.gamma.2' in key or '.sfm1.2' in key or '.sfm2.2' in key:
+                sd[key] = sd[key] + 1.0                  # FiLM scale around 1
+    return sd
+
+
+# ----------------------------------------------------------------------------------------
+# Row J -- VST_Denoiser (YOND_SIDD.py:250-299), Simple_Denoiser (:238-248)
+# ----------------------------------------------------------------------------------------
+
+def VST_Denoiser(lr_raw, p, arch, sd, bias_corr='pre', bias_func=None, vst_type='exact', full=False):
+    lr_rggb = bayer2rggb(lr_raw) * p['scale']
+    bias_base = np.maximum(lr_rggb, 0)
+    if bias_corr is not None:
+        if bias_func is None:
+            bias_func = get_bias(lr_rggb.max(), p['sigma'], p['gain'])
+        bias = bias_func(bias_base)
+    raw_vst = VST(lr_rggb, p['sigma'], gain=p['gain'])
+    if bias_corr == 'pre':
+        raw_vst = raw_vst - bias
+    lower = VST(0, p['sigma'], gain=p['gain'])
+    upper = VST(p['scale'], p['sigma'], gain=p['gain'])
+    nsr = 1 / (upper - lower)
+    raw_vst = (raw_vst - lower) / (upper - lower)
+    x = torch.from_numpy(np.ascontiguousarray(raw_vst)).float().permute(2, 0, 1)[None]
+    p2d = get_p2d(x.shape, base=32)
+    x = F.pad(x, p2d, mode='reflect')
+    net_in = x.clamp(0, 1)
+    if 'guided' in arch:
+        sigma_corr = 1.03 if bias_corr == 'pre' else 1.00
+        t = torch.tensor(nsr * sigma_corr, dtype=x.dtype)
+        y = net_forward(arch, sd, net_in, t).clamp(0, 1)
+    else:
+        t = None
+        y = net_forward(arch, sd, net_in).clamp(0, 1)
+    _, _, H, W = y.shape
+    yc = y[..., p2d[-2]:H - p2d[-1], p2d[0]:W - p2d[1]]
+    out = yc[0].permute(1, 2, 0).numpy()
+    out = out * (upper - lower) + lower
+    exact_inverse = bias_corr is None and vst_type == 'exact'
+    out = inverse_VST(out, p['sigma'], gain=p['gain'], exact=exact_inverse)
+    raw_dn = rggb2bayer(out) / p['scale']
+    if full:
+        return raw_dn, dict(net_in=net_in, net_out=y, t=t, lower=lower, upper=upper, p2d=p2d)
+    return raw_dn
+
+
+def Simple_Denoiser(lr_raw, arch, sd):
+    x = torch.from_numpy(np.ascontiguousarray(bayer2rggb(lr_raw))).float().permute(2, 0, 1)[None]
+    p2d = get_p2d(x.shape, base=32)
+    x = F.pad(x, p2d, mode='reflect')
+    y = net_forward(arch, sd, x.clamp(0, 1)).clamp(0, 1)
+    _, _, H, W = y.shape
+    y = y[..., p2d[-2]:H - p2d[-1], p2d[0]:W - p2d[1]]
+    return rggb2bayer(y[0].permute(1, 2, 0).numpy())
+
+
+# ----------------------------------------------------------------------------------------
+# Row Q -- IterDenoise control flow (YOND_SIDD.py:301-483) for est_type 'simple' pipelines.
+# ----------------------------------------------------------------------------------------
+
+def default_params():
+    """YOND_SIDD.py:503-505."""
+    p = {'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0}
+    p['scale'] = (p['wp'] - p['bl']) / p['ratio']
+    return p
+
+
+def IterDenoise(lr_raw, arch, sd, pipe, lr_full=None, p=None):
+    """lr_raw: (H, W) Bayer when pipe['full_dn'] else the SIDD layout (32, 256, 256).
+    Returns dict(raw_dns=[iter0, iter1...], regs=[...], params=[(K, sigma), ...])."""
+    p = dict(p or default_params())
+    k = pipe.get('k', 29)
+    bias_corr = pipe.get('bias_corr', 'pre')
+    if bias_corr == 'none':
+        bias_corr = None
+    full_dn = bool(pipe.get('full_dn', False))
+    sidd = not full_dn
+    vst_type = pipe.get('vst_type', 'exact')
+    regs, params = [], []
+    scale = p['wp'] - p['bl']
+
+    if sidd:
+        lr_cat = np.concatenate(lr_raw, axis=-1)                                  # :314
+        blocks = np.array(np.split(lr_cat, 32, axis=-1))                          # :353
+    else:
+        lr_cat = lr_raw
+    raw4est = lr_cat if lr_full is None else lr_full                              # :340
+    reg = SimpleNLF(raw4est, k=k, setting={'mode': 'self'})                       # :341
+    p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale       # :356
+    regs.append(reg)
+    params.append((p['gain'], p['sigma']))
+
+    def denoise_all(bias_func):
+        if full_dn:                                                               # :387-389
+            return VST_Denoiser(lr_cat, p, arch, sd, bias_corr, bias_func, vst_type).clip(0, 1)
+        out = np.empty((32, 256, 256), np.float32)                                # :391
+        for num in range(32):                                                     # :398-407
+            out[num] = VST_Denoiser(blocks[num], p, arch, sd, bias_corr, bias_func, vst_type).clip(0, 1)
+        return np.concatenate(out, axis=-1)
+
+    bias_func = None
+    if sidd and bias_corr is not None:
+        bias_func = get_bias(blocks.max() * scale, p['sigma'], p['gain'])         # :393-395
+    raw_dn = denoise_all(bias_func)
+    raw_dns = [raw_dn.copy()]
+
+    if pipe.get('iter', 'iter') == 'iter':
+        for epoch in range(1, pipe.get('max_iter', 1) + 1):
+            # :431 hard-codes SIDD_256=True (YOND_SIDD.py only handles SIDD); the full-frame
+            # drivers named in README.md:38-47 cannot (W/2 is not a multiple of 32), so the
+            # re-tiling follows the SIDD layout unless pipe['collab_sidd256'] overrides it.
+            reg = SimpleNLF(lr_cat, raw_dn, k=k,
+                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd))})
+            if reg[1] < 0:                                                        # :438-440
+                reg = (reg[0], reg[0] ** 2)
+            p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(reg[1]) * scale       # :442
+            if reg[0] < 0:                                                        # :445-447
+                break
+            upper_bound = (blocks.max() if sidd else lr_cat.max()) * scale        # :450
+            bias_func = get_bias(upper_bound, p['sigma'], p['gain'])              # :452
+            raw_dn = denoise_all(bias_func)
+            raw_dns.append(raw_dn.copy())
+            regs.append(reg)
+            params.append((p['gain'], p['sigma']))
+    return dict(raw_dns=raw_dns, regs=regs, params=params)
+
+
+# ----------------------------------------------------------------------------------------
+# Metrics (YOND_SIDD.py:651-652, 679-697).  skimage / cv2 are absent: restated from formulas.
+# ----------------------------------------------------------------------------------------
+
+def psnr(dn, hr, data_range=1.0):
+    """skimage.metrics.peak_signal_noise_ratio: 10 log10(R^2 / mean((a-b)^2)), float64."""
+    err = np.mean((np.asarray(dn, np.float64) - np.asarray(hr, np.float64)) ** 2)
+    return 10 * np.log10(data_range ** 2 / err)
+
+
+def _gauss_kernel(n=11, sigma=1.5):
+    """cv2.getGaussianKernel(11, 1.5): exp(-(i-(n-1)/2)^2 / (2 sigma^2)), normalised."""
+    i = np.arange(n) - (n - 1) / 2
+    g = np.exp(-(i ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def ssim(prediction, target):
+    """YOND_SIDD.py:679-697 on [0,255] images; filter2D + [5:-5] crop == 'valid' correlation."""
+    from scipy.signal import correlate2d
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    a, b = prediction.astype(np.float64), target.astype(np.float64)
+    g = _gauss_kernel()
+    win = np.outer(g, g)
+    f = lambda v: correlate2d(v, win, mode='valid')
+    mu1, mu2 = f(a), f(b)
+    s1, s2, s12 = f(a * a) - mu1 ** 2, f(b * b) - mu2 ** 2, f(a * b) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))
+    return m.mean()
+
+
+def sidd_block_metrics(dn, hr):
+    """YOND_SIDD.py:649-652: mean PSNR / SSIM over the 32 blocks split along the last axis."""
+    dns, hrs = np.split(dn, 32, axis=-1), np.split(hr, 32, axis=-1)
+    return (float(np.mean([psnr(a, b) for a, b in zip(dns, hrs)])),
+            float(np.mean([ssim(a * 255, b * 255) for a, b in zip(dns, hrs)])))
+
+
+# ----------------------------------------------------------------------------------------
+# Synthetic inputs shared by tests / smoke / bench
+# ----------------------------------------------------------------------------------------
+
+def synth_clean(H, W):
+    """Smooth ramp + 256-px checker + mild sinusoid in [0,1]: flat regions and edges."""
+    y, x = np.mgrid[0:H, 0:W].astype(np.float64)
+    ramp = 0.08 + 0.55 * (x / max(W - 1, 1)) * (0.6 + 0.4 * y / max(H - 1, 1))
+    checker = 0.12 * ((((x // 256) + (y // 256)) % 2) - 0.5)
+    wave = 0.04 * np.sin(2 * np.pi * x / 97.0) * np.cos(2 * np.pi * y / 131.0)
+    return np.clip(ramp + checker + wave, 0.0, 1.0)
+
+
+def synth_noisy(H, W, K=4.0, sigma=6.0, idx=0, clip=True, scale=959.0):
+    rng = np.random.default_rng(1997 + idx)
+    clean = synth_clean(H, W)
+    noisy = (rng.poisson(clean * scale / K) * K + rng.normal(0.0, sigma, (H, W))) / scale
+    if clip:
+        noisy = np.clip(noisy, 0, 1)
+    return noisy.astype(np.float32), clean.astype(np.float32)

@@ -1,0 +1,199 @@
+"""CPU: the oracle (oracle/yond_oracle.py) replayed against golden vectors produced by running
+the reference itself (oracle/gen_golden.py).  These pin the oracle; see its header for the one
+unpinned boundary (cv2.blur)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import yond_oracle as O
+
+ARCHS = {
+    "gru32": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+    "gru8": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
+    "gru32_nonorm": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=False, norm=False),
+    "snr32": dict(name='SNRnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+    "unet32": dict(name='UNetSeeInDark', in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+    "unet8": dict(name='UNetSeeInDark', in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
+}
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def test_pack_unpack_bit_exact(golden):
+    g = golden("pack")
+    assert np.array_equal(O.bayer2rggb(g["bayer"]), g["rggb"])
+    assert np.array_equal(O.rggb2bayer(g["rggb_in"]), g["bayer_out"])
+    a = np.random.default_rng(0).random((10, 14)).astype(np.float32)
+    assert np.array_equal(O.rggb2bayer(O.bayer2rggb(a)), a)
+
+
+def test_vst_and_inverse(golden):
+    g = golden("vst")
+    x = g["x"]
+    for i, (K, s) in enumerate(g["ksig"]):
+        K, s = np.float64(K), np.float64(s)
+        v = O.VST(x, s, gain=K)
+        assert v.dtype == np.float64
+        np.testing.assert_array_equal(v, g[f"vst_{i}"])
+        np.testing.assert_array_equal(O.inverse_VST(v, s, gain=K), g[f"ivst_{i}"])
+        np.testing.assert_allclose(O.inverse_VST(v, s, gain=K, exact=True), g[f"ivst_exact_{i}"], rtol=1e-14, atol=0)
+        z = g[f"z_{i}"]
+        np.testing.assert_array_equal(O.inverse_VST(z, s, gain=K), g[f"ivst_z_{i}"])
+        np.testing.assert_allclose(O.inverse_VST(z, s, gain=K, exact=True), g[f"ivst_exact_z_{i}"], rtol=1e-14, atol=0)
+
+
+def test_bias_lut_knots_and_interp(golden):
+    g = golden("bias")
+    for i, (K, s) in enumerate(g["ksig"]):
+        for tag, mx in zip("abc", g["max"]):
+            lams, bias = O.get_bias_table(np.float32(mx), np.float64(s), np.float64(K))
+            np.testing.assert_array_equal(lams, g[f"lams_{i}{tag}"])
+            np.testing.assert_array_equal(bias, g[f"bias_{i}{tag}"])
+            f = O.BiasFunc(lams, bias)
+            np.testing.assert_array_equal(f(g[f"xq_{i}{tag}"]), g[f"bq_{i}{tag}"])
+    with pytest.raises(ValueError):
+        O.BiasFunc(lams, bias)(np.array([lams[-1] + 1.0]))
+
+
+def test_box_blur_two_restatements_agree():
+    rng = np.random.default_rng(3)
+    a = rng.random((40, 52, 4)).astype(np.float32)
+    for k in (5, 19, 29):
+        b1, b2 = O.box_blur(a, k), O.box_blur_direct(a, k)
+        assert b1.dtype == np.float32
+        # the two summation orders may differ in the last float32 bit
+        assert np.max(np.abs(b1.astype(np.float64) - b2)) <= 6e-8
+
+
+def test_percentile_matches_numpy():
+    rng = np.random.default_rng(5)
+    for n in (7, 1000, 4097):
+        a = rng.random(n).astype(np.float32) ** 2
+        q = np.linspace(5, 100, 20)
+        np.testing.assert_array_equal(O.percentile_linear(a, q), np.percentile(a, q, method='linear'))
+    np.testing.assert_array_equal(O.percentile_linear(a, [25.0]), np.percentile(a, [25.0], method='linear'))
+
+
+@pytest.mark.parametrize("tag", ["s256", "s512", "hi", "lo"])
+def test_nle_self_and_collab(golden, tag):
+    g = golden("nle")
+    H, W, K, s, idx = g[f"{tag}_meta"]
+    noisy, clean = O.synth_noisy(int(H), int(W), K, s, int(idx))
+    assert np.array_equal(sha(noisy), g[f"{tag}_sha"]), "synthetic input is not reproducible on this box"
+    rggb = O.bayer2rggb(noisy)
+    mean = O.box_blur(rggb, 29)
+    std = O.stdfilt(rggb, 29)
+    lap = O.stdfilt(O.box_blur(rggb, 19), 29)
+    # float32 maps: the two cv2.blur restatements (cumsum vs ndimage) may differ in the last bit
+    np.testing.assert_allclose(mean[:48, :48], g[f"{tag}_mean_crop"], rtol=2e-7, atol=0)
+    np.testing.assert_allclose(std[:48, :48], g[f"{tag}_std_crop"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(lap[:48, :48], g[f"{tag}_lap_crop"], rtol=0, atol=2e-6)
+    reg, info = O.SimpleNLF(noisy, k=29, setting={'mode': 'self'}, full=True)
+    th, pct, b1, b2 = g[f"{tag}_self"]
+    assert info["percent"] == pct
+    np.testing.assert_allclose(info["th"], th, rtol=1e-5)
+    np.testing.assert_allclose(reg[0], b1, rtol=1e-5)
+    np.testing.assert_allclose(reg[1], b2, rtol=0, atol=1e-5 * abs(b1) + 1e-9)
+    # moment-sum fit == lstsq fit
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(int(W))[None, :] / 37.0), 0, 1).astype(np.float32)
+    regc, infoc = O.SimpleNLF(noisy, dn, k=29, setting={'mode': 'collab'}, full=True)
+    thc, pctc, c1, c2 = g[f"{tag}_collab"]
+    assert infoc["percent"] == pctc
+    np.testing.assert_allclose(infoc["th"], thc, rtol=1e-5)
+    np.testing.assert_allclose(regc[0], c1, rtol=1e-5)
+    np.testing.assert_allclose(regc[1], c2, rtol=0, atol=1e-5 * abs(c1) + 1e-9)
+
+
+def test_nle_sidd256_retiling(golden):
+    g = golden("nle")
+    noisy, clean = O.synth_noisy(256, 8192, 4.0, 6.0, 7)
+    assert np.array_equal(sha(noisy), g["strip_sha"])
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(8192)[None, :] / 37.0), 0, 1).astype(np.float32)
+    r1 = O.SimpleNLF(noisy, k=29, setting={'mode': 'self', 'SIDD_256': True})
+    r2 = O.SimpleNLF(noisy, dn, k=29, setting={'mode': 'collab', 'SIDD_256': True})
+    r3 = O.SimpleNLF(noisy, k=29, setting={'mode': 'self'})
+    for r, gr in zip((r1, r2, r3), g["strip_regs"]):
+        np.testing.assert_allclose(r[0], gr[0], rtol=1e-5)
+        np.testing.assert_allclose(r[1], gr[1], rtol=0, atol=1e-5 * abs(gr[0]) + 1e-9)
+
+
+def test_polyfit_moments_equals_lstsq():
+    rng = np.random.default_rng(11)
+    m = rng.random(20000).astype(np.float32)
+    v = (0.004 * m + 4e-5 + 1e-5 * rng.standard_normal(20000)).astype(np.float32)
+    a, b = O.polyfit(m, v), O.polyfit_moments(m, v)
+    np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("ci", range(7))
+def test_net_forward(golden, ci):
+    g = golden("net")
+    aname = str(g[f"arch_{ci}"])
+    arch = ARCHS[aname]
+    meta = g[f"meta_{ci}"]
+    shape = tuple(int(v) for v in meta[2:])
+    sd = O.procedural_state_dict(arch, seed=int(meta[0]))
+    assert sum(v.numel() for v in sd.values()) == int(g[f"nparams_{ci}"])
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(int(meta[1]))) * 0.9
+    t = torch.from_numpy(g[f"t_{ci}"]) if f"t_{ci}" in g.files else None
+    torch.set_num_threads(8)
+    y = O.net_forward(arch, sd, x, t).numpy()
+    ref = g[f"y_{ci}"]
+    assert y.shape == ref.shape
+    # same ATen CPU kernels, functional vs nn.Module call path
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6)
+
+
+def test_gru32_param_count():
+    sd = O.procedural_state_dict(ARCHS["gru32"])
+    assert sum(v.numel() for v in sd.values()) == 11173668          # logs/...log:3-4: 11.17 M
+    assert tuple(sd['conv1.gamma.0.weight'].shape) == (32, 1, 1, 1)
+    assert tuple(sd['upv6.weight'].shape) == (512, 256, 2, 2)
+    assert tuple(sd['conv6.short_cut.0.weight'].shape) == (256, 512, 1, 1)
+
+
+@pytest.mark.parametrize("ci", range(4))
+def test_vst_denoiser(golden, ci):
+    g = golden("vst_denoiser")
+    H, W, K, s, idx, seed = g[f"meta_{ci}"]
+    arch = ARCHS[str(g[f"arch_{ci}"])]
+    bc = str(g[f"bias_corr_{ci}"])
+    bc = None if bc == 'None' else bc
+    noisy, _ = O.synth_noisy(int(H), int(W), K, s, int(idx))
+    assert np.array_equal(sha(noisy), g[f"sha_{ci}"])
+    sd = O.procedural_state_dict(arch, int(seed))
+    p = {'wp': 1023, 'bl': 64, 'ratio': 1, 'scale': 959.0, 'gain': np.float64(K), 'sigma': np.float64(s)}
+    torch.set_num_threads(8)
+    dn = O.VST_Denoiser(noisy, p, arch, sd, bias_corr=bc)
+    ref = g[f"dn_{ci}"]
+    assert dn.dtype == ref.dtype and dn.shape == ref.shape
+    np.testing.assert_allclose(dn, ref, rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("ci", range(2))
+def test_iter_denoise(golden, ci):
+    g = golden("iter")
+    noisy, clean = O.synth_noisy(256, 8192, 4.0, 6.0, 31)
+    full, _ = O.synth_noisy(512, 1024, 4.0, 6.0, 32)
+    assert np.array_equal(sha(noisy), g["sha_noisy"]) and np.array_equal(sha(full), g["sha_full"])
+    arch = ARCHS[str(g[f"arch_{ci}"])]
+    sd = O.procedural_state_dict(arch, int(g[f"seed_{ci}"]))
+    full_dn = bool(g[f"full_dn_{ci}"])
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1,
+            'full_dn': full_dn, 'collab_sidd256': True}
+    lr = noisy if full_dn else np.array(np.split(noisy, 32, axis=-1))
+    torch.set_num_threads(8)
+    res = O.IterDenoise(lr, arch, sd, pipe, lr_full=full)
+    regs = g[f"regs_{ci}"]
+    assert len(res['regs']) == len(regs)
+    for r, gr in zip(res['regs'], regs):
+        np.testing.assert_allclose(r[0], gr[0], rtol=1e-5)
+        np.testing.assert_allclose(r[1], gr[1], rtol=0, atol=1e-5 * abs(gr[0]) + 1e-9)
+    for it, dn in enumerate(res['raw_dns']):
+        np.testing.assert_allclose(dn[:, :768], g[f"dn_{ci}_{it}_crop"], rtol=0, atol=2e-5)
+        chk = g[f"dn_{ci}_{it}_chk"]
+        np.testing.assert_allclose(np.asarray(dn, np.float64).sum(), chk[0], rtol=1e-6)

@@ -1,0 +1,197 @@
+/* yond_hip.h -- C ABI of libyond_hip.so: the MI355X (gfx950) kernels behind YOND's per-image hot path.
+ *
+ * The reference (fenghansen/YOND_public) has no FFI: its hot path is Python over NumPy / cv2 / SciPy /
+ * torch.nn.  The boundary a maintainer binds is therefore this C ABI, called through ctypes from the
+ * Python functions that keep the reference's names.  Every entry point
+ *   - takes plain device pointers (from torch.Tensor.data_ptr()), sizes and a hipStream_t (as void*),
+ *   - is asynchronous on that stream, allocates nothing, keeps no state and owns none of its arguments,
+ *   - returns 0 on success, a negative YOND_E* code for a rejected argument (nothing launched) or the
+ *     positive hipError_t of a failed launch.
+ * All images are float32.  "packed" means the 4-channel half-resolution view of a Bayer frame,
+ * channel = 2*dy+dx  (utils/isp_ops.py:57-63).  Each function cites the reference lines it replaces
+ * (paths relative to the reference root).
+ */
+#ifndef YOND_HIP_H
+#define YOND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YOND_OK 0
+#define YOND_EINVAL (-1)      /* bad pointer / size / flag */
+#define YOND_EUNSUPPORTED (-2) /* valid request the kernels do not cover (e.g. channel count) */
+
+/* Library / device probe.  Returns the ABI version (this header: 1). */
+int yond_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  pack + VST + bias + normalise + reflect-pad + clamp            (memory bound, 8 B / Bayer px)
+ * Replaces YOND_SIDD.py:251-269 (pack, *scale, bias LUT, VST, normalise), :281-282 (reflect pad to a
+ * multiple of 32), :286 (clamp to [0,1]), utils/isp_algos.py:5-14 (VST) and the per-pixel evaluation
+ * of the interp1d object returned by utils/isp_algos.py:128.  Also produces the per-image maximum that
+ * archs/modules.py:15-21 (data_normalize) needs.
+ *   bayer      [H][W]                      input frame (device)
+ *   out        [Hp][Wp][4]                 Hp = h+pad_t+pad_b, Wp = w+pad_l+pad_r, h=H/2, w=W/2
+ *   mode       0: identity (Simple_Denoiser, YOND_SIDD.py:238-243: pack, pad, clamp only)
+ *              1: u = (VST(x*scale) - bias(max(x*scale,0)) - lo) / (hi - lo)
+ *   lut_x/lut_y  knots of the bias LUT (float64 abscissae, float32 ordinates, device); lut_n = 0
+ *              disables the bias correction (bias_corr=None).
+ *   img_max    optional device float[1]: max over the clamped output (must be zeroed by the caller
+ *              -- the function issues the memset itself on `stream`).
+ * Arithmetic: float32 x*scale, then float64 exactly as NumPy stages it, rounded once to float32. */
+int yond_pack_vst_norm_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t,
+                           int pad_b, int mode, double scale, double gain, double sigma, double lo,
+                           double hi, const double* lut_x, const float* lut_y, int lut_n, float* img_max,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  clamp + crop + de-normalise + inverse VST + unpack (+ /scale, clip)          (8 B / Bayer px)
+ * Replaces YOND_SIDD.py:286 (output clamp), :289-299 and utils/isp_algos.py:17-33 (inverse_VST).
+ *   net_out  [Hp][Wp][4];  bayer_out [2h][2w];  crop origin (pad_t, pad_l)
+ *   mode 0: identity (Simple_Denoiser :244-248), 1: algebraic inverse, 2: closed-form exact inverse
+ *   clip01: apply the caller's .clip(0,1) (YOND_SIDD.py:389,407). */
+int yond_denorm_ivst_unpack_f32(const float* net_out, int Hp, int Wp, int pad_t, int pad_l, int h, int w,
+                                float* bayer_out, int mode, double scale, double gain, double sigma,
+                                double lo, double hi, int clip01, void* stream);
+
+/* Bayer <-> packed planar/NHWC4 copies (utils/isp_ops.py:57-63), bit exact. */
+int yond_bayer2rggb_f32(const float* bayer, int H, int W, float* rggb /*[H/2][W/2][4]*/, void* stream);
+int yond_rggb2bayer_f32(const float* rggb, int h, int w, float* bayer /*[2h][2w]*/, void* stream);
+
+/* Layout helpers for the archs plugin surface (NCHW tensors in, NCHW out; C == 4). */
+int yond_nchw4_to_nhwc4_f32(const float* src, float* dst, int N, int H, int W, void* stream);
+int yond_nhwc4_to_nchw4_f32(const float* src, float* dst, int N, int H, int W, void* stream);
+
+/* Per-image maximum (archs/modules.py:18-19).  x: [N][elems]; partial: workspace float[N*256];
+ * out: float[N].  Two launches, deterministic. */
+int yond_image_max_f32(const float* x, int N, size_t elems, float* partial, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  convolutions of the denoiser as fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32).
+ * Activations are NHWC float32.  One descriptor covers: 3x3 stride 1 / stride 2 and 1x1 convolutions,
+ * an input that is the channel concatenation of two tensors (torch.cat([up, skip], 1) is never
+ * materialised), 2x2 stride-2 transposed convolution (as a 1x1 GEMM with a pixel-shuffle store), an
+ * optional SiLU on the staged input, and the epilogue  v = acc*escale + eshift ; act(v) ; v += res.
+ * Replaces nn.Conv2d / nn.ConvTranspose2d / SiLU / FiLM / residual at archs/modules.py:117-125,
+ * 186-196, 221-233 and archs/Unet.py:55-104, 332-378, 424-470.
+ * Weights must be packed by yond_pack_conv_weight_f32 (host side) for the same (taps, TN, KC). */
+typedef struct YondConvDesc {
+    const float* src0;    /* [N][H][W][C0] */
+    const float* src1;    /* [N][H][W][C1] or NULL */
+    int C0, C1;           /* Cin = C0 + C1; each a multiple of kc */
+    int N, H, W;          /* input extent */
+    int Ho, Wo;           /* GEMM-M extent: H/stride, W/stride (convT: H, W) */
+    int Cout;             /* GEMM-N extent (convT: 4 * real Cout), multiple of 32 */
+    int ksize;            /* 1 or 3 */
+    int stride;           /* 1 or 2 (2 only with ksize 3) */
+    int shuffle;          /* 1: convT 2x2 s2 store, dst is [N][2Ho][2Wo][Cout/4] */
+    int pre_act;          /* 0 none, 1 SiLU applied to the staged input */
+    int post_act;         /* 0 none, 1 SiLU, 2 LeakyReLU(slope) */
+    float slope;
+    const float* wpk;     /* packed weights */
+    const float* escale;  /* [ebatch ? N : 1][Cout'] or NULL (=1) ; Cout' = real Cout */
+    const float* eshift;  /* [ebatch ? N : 1][Cout'] or NULL (=0) */
+    int ebatch;
+    const float* res;     /* residual, same shape as dst, or NULL */
+    float* dst;           /* [N][Ho][Wo][Cout]  (shuffle: see above) */
+} YondConvDesc;
+
+/* Tile configuration the library would use for a descriptor (needed to pack weights). */
+int yond_conv_config(int ksize, int stride, int cin, int cout, int shuffle, int* tn, int* kc);
+/* Host-side weight packing: w is OIHW [cout][cin][k][k] (Conv2d) -- for a transposed conv pass the
+ * already re-indexed [4*cout][cin][1][1] matrix.  dst has cout*cin*k*k floats. */
+int yond_pack_conv_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int kc, float* dst);
+int yond_conv2d_f32(const YondConvDesc* desc, void* stream);
+
+/* First layer: 3x3, Cin=4 -> Cout=32k, input NHWC4, optional division by the per-image maximum
+ * (data_normalize, archs/Unet.py:427-431) and LeakyReLU(slope).  wpk from yond_pack_conv_in_weight_f32. */
+int yond_conv_in_f32(const float* x, const float* ub /*[N] or NULL*/, int N, int H, int W, int Cout,
+                     const float* wpk, const float* bias, float slope, float* dst, void* stream);
+int yond_pack_conv_in_weight_f32(const float* w /*[cout][4][3][3]*/, int cout, float* dst /*cout*40*/);
+
+/* Last layer: 1x1 Cin -> 4, + x/ub residual, * ub (archs/Unet.py:463-468). */
+int yond_conv_out_f32(const float* feat /*[N][H][W][Cin]*/, int Cin, const float* w /*[4][Cin]*/,
+                      const float* bias /*[4]*/, const float* x /*[N][H][W][4] or NULL*/,
+                      const float* ub /*[N] or NULL*/, int N, int H, int W, float* dst /*[N][H][W][4]*/,
+                      void* stream);
+
+/* 2x2 max pooling, NHWC (UNetSeeInDark, archs/Unet.py:60-72). */
+int yond_maxpool2_f32(const float* src, int N, int H, int W, int C, float* dst, void* stream);
+
+/* sigma-conditioning vectors for one GuidedResidualBlock / SNR_Block (archs/modules.py:170-178,190-193
+ * / 205-214, 225-231), folded with the conv biases into the epilogue (scale, shift) pairs of conv1 and
+ * conv2.  t: [N] (already divided by ub when ub != NULL is NOT assumed: the kernel divides).
+ *   kind 0 GuidedResidualBlock: m1 = gamma (w_a0,b_a0,w_a2,b_a2), m2 = beta (w_b,b_b)
+ *   kind 1 SNR_Block:           m1 = sfm1, m2 = sfm2 (w_b0,b_b0 used as second first-layer)
+ * Outputs s1,t1,s2,t2: [N][ld], only the first C entries of a row are written (channel padding stays 0).
+ * `descs` is a DEVICE array of nblocks descriptors. */
+typedef struct YondFilmDesc {
+    int kind, C, ld;                           /* C <= 1024 real channels; ld = row stride of the outputs */
+    const float *w_a0, *b_a0, *w_a2, *b_a2;   /* first MLP: 1->C, C->C */
+    const float *w_b0, *b_b0;                  /* SNR only: second MLP first layer 1->C */
+    const float *w_b, *b_b;                    /* guided: beta C->C ; SNR: sfm2 second layer C->C */
+    const float *cb1, *cb2;                    /* conv1 / conv2 biases [C] */
+    float *s1, *t1, *s2, *t2;                  /* [N][ld] */
+} YondFilmDesc;
+int yond_film_f32(const YondFilmDesc* descs, int nblocks, const float* t /*[N]*/, const float* ub /*[N] or NULL*/,
+                  int N, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5  local statistics for the noise-level estimator (box means in float64, cv2.blur semantics:
+ * normalised k x k window, BORDER_REFLECT_101, result rounded to float32).
+ * Replaces utils/isp_algos.py:234-242 (stdfilt) and the cv2.blur calls at YOND_SIDD.py:67-71, 95-98.
+ * All maps are planar packed [4][h][w]; `tile_w` > 0 makes every tile_w columns an independent image
+ * (the SIDD_256 re-tiling of YOND_SIDD.py:64-65, 91-93), 0 means the whole width.
+ *   stage 1 (self):   from Bayer: mean = B_k(x), var = stdfilt(x,k)^2, blur2 = B_k2(x)
+ *   stage 2 (self):   from blur2: lap = stdfilt(blur2, k)
+ *   collab:           from noisy & denoised Bayer: var = stdfilt(lr)^2 - stdfilt(hr)^2,
+ *                     mean = B_k(hr), lap = stdfilt(hr) */
+int yond_box_stats_self1_f32(const float* bayer, int H, int W, int k, int k2, int tile_w, float* mean,
+                             float* var, float* blur2, void* stream);
+int yond_box_stats_self2_f32(const float* blur2, int h, int w, int k, int tile_w, float* lap, void* stream);
+int yond_box_stats_collab_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,
+                              float* mean, float* var, float* lap, void* stream);
+
+/* K6  exact order statistics of a non-negative float32 map (np.percentile's two neighbours).
+ * ranks: nr 0-based ranks (device int64); out: nr float values (device).  ws: workspace of
+ * yond_select_ws_bytes(nr) bytes.  Replaces the sort inside np.percentile at YOND_SIDD.py:26,80. */
+size_t yond_select_ws_bytes(int nr);
+int yond_select_ranks_f32(const float* data, size_t n, const int64_t* ranks_host, int nr, float* out, void* ws,
+                          void* stream);
+/* np.percentile(data, q, method='linear') (YOND_SIDD.py:26,80): q_host[nq] in percent (host array, nq <= 32),
+ * out: nq float64 values (device).  Same workspace as yond_select_ranks_f32. */
+int yond_percentiles_f32(const float* data, size_t n, const double* q_host, int nq, double* out, void* ws,
+                         void* stream);
+
+/* K7  one pass over (lap, mean, var): for thresholds ths[0..nt) (ascending, float64, device)
+ *   occ  [nt][1024] uint32 flags: bin floor(clip(mean,0,1)*1000) occupied among {lap <= ths[i]} and not
+ *        among {lap <= ths[i-1]}     (YOND_SIDD.py:37-43; prefix-OR on the host gives npeaks)
+ *   mom  [nt+1][2][5] float64: {n, sum m, sum v, sum m^2, sum m v} over {ths[i-1] <= lap < ths[i]}
+ *        (bucket nt: lap >= ths[nt-1]), [.][0] all pixels, [.][1] only 1e-4 < mean < 0.8
+ *        (utils/isp_algos.py:348-350, 352-364 as moment sums)
+ * ws: workspace of yond_nlf_ws_bytes(nt) bytes. */
+size_t yond_nlf_ws_bytes(int nt);
+int yond_nlf_accumulate_f32(const float* lap, const float* mean, const float* var, size_t n, const double* ths,
+                            int nt, uint32_t* occ, double* mom, void* ws, void* stream);
+
+/* Row H  bias LUT construction on the device (utils/isp_algos.py:49-140): for every knot lam <= th the
+ * Poisson (*) Gaussian expectation of the VST, above th Foi's closed form.  lams: float64[n] (device),
+ * bias: float32[n] (device out). */
+int yond_bias_lut_f64(const double* lams, int n, double gain, double sigma, float* bias, void* stream);
+
+/* N1  per-block PSNR / SSIM partial sums (YOND_SIDD.py:649-652, 679-697).  dn, hr: Bayer [H][W]; blocks of
+ * bh x bw (row-major block order); out: [nblocks][ntiles][2] float64 = {sum of squared error, sum of SSIM
+ * over the 'valid' map} per 32x32 tile, ntiles = yond_block_metrics_tiles(bh, bw); the host adds the tiles:
+ * psnr = 10 log10(1 / (sum_se / (bh*bw))), ssim = sum_ssim / ((bh-10)*(bw-10)). */
+int yond_block_metrics_tiles(int bh, int bw);
+int yond_block_metrics_f32(const float* dn, const float* hr, int H, int W, int bh, int bw, double* out,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOND_HIP_H */

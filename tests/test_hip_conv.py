@@ -1,0 +1,159 @@
+"""GPU: every variant of the fp32-MFMA convolution kernels against torch CPU convolutions
+(float64 reference of the same op), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_common import report
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def run_conv(w, b, ksize, stride, splits, xs, N, H, W, shuffle=False, **kw):
+    from yond_public_amd.engine import _PackedConv, DenoiserPlan
+    pc = _PackedConv(torch.device(DEV), w, b, ksize, stride, splits, shuffle=shuffle)
+    plan = DenoiserPlan.__new__(DenoiserPlan)
+    from yond_public_amd import _lib as L
+    plan.lib = L.load()
+    plan.dev = torch.device(DEV)
+    if shuffle:
+        dst = torch.full((N, 2 * H, 2 * W, pc.cout_real_p), float('nan'), device=DEV)
+    elif stride == 2:
+        dst = torch.full((N, (H + 1) // 2, (W + 1) // 2, pc.coutp), float('nan'), device=DEV)
+    else:
+        dst = torch.full((N, H, W, pc.coutp), float('nan'), device=DEV)
+    plan._conv(pc, xs[0], xs[1] if len(xs) > 1 else None, N, H, W, dst, **kw)
+    torch.cuda.synchronize()
+    return dst.cpu()
+
+
+@pytest.mark.parametrize("C,Co,N,H,W", [(32, 32, 1, 24, 40), (64, 64, 2, 16, 32), (32, 64, 1, 9, 33), (128, 128, 1, 8, 32)])
+def test_conv3x3_s1_plain(C, Co, N, H, W):
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(Co, generator=g)
+    got = nchw(run_conv(w, b, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert report(f"conv3x3 s1 C{C}->{Co} {H}x{W}", got, ref) < 2e-5
+
+
+def test_conv3x3_s1_fused_film_silu_residual():
+    g = torch.Generator().manual_seed(7)
+    N, C, H, W = 2, 64, 16, 48
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    es, et = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
+    res = torch.randn(N, C, H, W, generator=g)
+    got = nchw(run_conv(w, None, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, escale=es.to(DEV), eshift=et.to(DEV), ebatch=1,
+                        res=nhwc(res).to(DEV), pre_act=1, post_act=1))
+    z = F.conv2d(F.silu(x.double()), w.double(), padding=1)
+    z = F.silu(z * es.double()[:, :, None, None] + et.double()[:, :, None, None]) + res.double()
+    assert report("conv3x3 fused", got, z) < 2e-5
+
+
+def test_conv3x3_two_source_leaky():
+    g = torch.Generator().manual_seed(9)
+    N, C, H, W = 1, 32, 16, 32
+    a, b2 = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 2 * C, 3, 3, generator=g) / (3 * (2 * C) ** 0.5)
+    b = torch.randn(C, generator=g)
+    got = nchw(run_conv(w, b, 3, 1, [C, C], [nhwc(a).to(DEV), nhwc(b2).to(DEV)], N, H, W, post_act=2, slope=0.2))
+    ref = F.leaky_relu(F.conv2d(torch.cat([a, b2], 1).double(), w.double(), b.double(), padding=1), 0.2)
+    assert report("conv3x3 two-source", got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("C,N,H,W", [(32, 1, 16, 64), (64, 2, 32, 32), (32, 1, 18, 34)])
+def test_conv3x3_s2(C, N, H, W):
+    g = torch.Generator().manual_seed(C + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(2 * C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(2 * C, generator=g)
+    got = nchw(run_conv(w, b, 3, 2, [C], [nhwc(x).to(DEV)], N, H, W))
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    assert report(f"conv3x3 s2 C{C} {H}x{W}", got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("C", [32, 128])
+def test_conv1x1_two_source(C):
+    g = torch.Generator().manual_seed(C)
+    N, H, W = 2, 8, 40
+    a, b2 = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 2 * C, 1, 1, generator=g) / (2 * C) ** 0.5
+    b = torch.randn(C, generator=g)
+    got = nchw(run_conv(w, b, 1, 1, [C, C], [nhwc(a).to(DEV), nhwc(b2).to(DEV)], N, H, W))
+    ref = F.conv2d(torch.cat([a, b2], 1).double(), w.double(), b.double())
+    assert report(f"conv1x1 two-source C{C}", got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("Ci,Co", [(64, 32), (256, 128)])
+def test_conv_transpose_2x2(Ci, Co):
+    g = torch.Generator().manual_seed(Ci)
+    N, H, W = 2, 8, 24
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5
+    b = torch.randn(Co, generator=g)
+    got = nchw(run_conv(w, b, 1, 1, [Ci], [nhwc(x).to(DEV)], N, H, W, shuffle=True))
+    ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
+    assert report(f"convT {Ci}->{Co}", got, ref) < 2e-5
+
+
+def test_channel_padding_small_nf():
+    """nf=8 style channel counts are zero-padded to 32 inside the engine."""
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W = 1, 8, 16, 32
+    x = torch.randn(N, C, H, W, generator=g)
+    xp = torch.zeros(N, 32, H, W)
+    xp[:, :C] = x
+    w = torch.randn(16, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(16, generator=g)
+    got = nchw(run_conv(w, b, 3, 1, [C], [nhwc(xp).to(DEV)], N, H, W))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert report("padded conv", got[:, :16], ref) < 2e-5
+    assert float(got[:, 16:].abs().max()) == 0.0
+
+
+def test_conv_in_and_out_and_maxpool_and_film():
+    import ctypes as C
+    from yond_public_amd import _lib as L
+    from yond_public_amd.engine import DenoiserPlan
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    N, H, W = 2, 24, 40
+    x = torch.rand(N, 4, H, W, generator=g)
+    ub = x.reshape(N, -1).max(dim=1).values
+    w = torch.randn(32, 4, 3, 3, generator=g) / 6
+    b = torch.randn(32, generator=g)
+    plan = DenoiserPlan.__new__(DenoiserPlan)
+    plan.lib, plan.dev = lib, torch.device(DEV)
+    wp, bp = plan._pack_conv_in(w, b)
+    x4 = nhwc(x).to(DEV)
+    ubd = plan.image_max(x4, N)
+    torch.cuda.synchronize()
+    assert torch.equal(ubd.cpu(), ub)
+    dst = torch.empty(N, H, W, 32, device=DEV)
+    L.check(lib.yond_conv_in_f32(L.ptr(x4), L.ptr(ubd), N, H, W, 32, L.ptr(wp), L.ptr(bp), 0.01, L.ptr(dst), L.stream()), "conv_in")
+    ref = F.leaky_relu(F.conv2d((x / ub.view(-1, 1, 1, 1)).double(), w.double(), b.double(), padding=1), 0.01)
+    assert report("conv_in", nchw(dst.cpu()), ref) < 1e-5
+    # conv_out
+    feat = torch.randn(N, 32, H, W, generator=g)
+    w10, b10 = torch.randn(4, 32, 1, 1, generator=g) / 6, torch.randn(4, generator=g)
+    out = torch.empty(N, H, W, 4, device=DEV)
+    L.check(lib.yond_conv_out_f32(L.ptr(nhwc(feat).to(DEV)), 32, L.ptr(w10.reshape(4, 32).contiguous().to(DEV)), L.ptr(b10.to(DEV)),
+                                  L.ptr(x4), L.ptr(ubd), N, H, W, L.ptr(out), L.stream()), "conv_out")
+    refo = (F.conv2d(feat.double(), w10.double(), b10.double()) + (x / ub.view(-1, 1, 1, 1)).double()) * ub.view(-1, 1, 1, 1).double()
+    assert report("conv_out", nchw(out.cpu()), refo) < 1e-5
+    # maxpool
+    mp = torch.empty(N, H // 2, W // 2, 32, device=DEV)
+    L.check(lib.yond_maxpool2_f32(L.ptr(dst), N, H, W, 32, L.ptr(mp), L.stream()), "maxpool")
+    assert torch.equal(nchw(mp.cpu()), F.max_pool2d(nchw(dst.cpu()), 2))

@@ -1,0 +1,181 @@
+"""GPU: noise-level estimation kernels (K5 box statistics, K6 percentiles, K7 accumulation) and the
+assembled SimpleNLF against the oracle and the reference's golden vectors.
+Tolerances: th, beta1 rel <= 1e-5; beta2 abs <= 1e-5*beta1 + 1e-9."""
+import numpy as np
+import pytest
+import torch
+
+from hip_common import report, sha
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def planes(a):
+    """oracle HWC (h, w, 4) -> planar (4, h, w)"""
+    return np.ascontiguousarray(np.transpose(a, (2, 0, 1)))
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (200, 328), (62, 70)])
+def test_box_stats_self(H, W):
+    import yond_oracle as O
+    from yond_public_amd import _lib as L
+    lib = L.load()
+    noisy, _ = O.synth_noisy(H, W, 4.0, 6.0, 11)
+    rggb = O.bayer2rggb(noisy)
+    mean = O.box_blur(rggb, 29)
+    var = O.stdfilt(rggb, 29) ** 2
+    b2 = O.box_blur(rggb, 19)
+    lap = O.stdfilt(b2, 29)
+    h, w = H // 2, W // 2
+    t = torch.from_numpy(noisy).to(DEV)
+    o = [torch.empty((4, h, w), device=DEV) for _ in range(4)]
+    L.check(lib.yond_box_stats_self1_f32(L.ptr(t), H, W, 29, 19, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.stream()), "self1")
+    L.check(lib.yond_box_stats_self2_f32(L.ptr(o[2]), h, w, 29, 0, L.ptr(o[3]), L.stream()), "self2")
+    got = [x.cpu().numpy() for x in o]
+    # window sums of float32 data are exact in float64, so the maps agree to the bit except where the
+    # oracle's cumulative-sum order flips a float32 rounding (<= 1 ulp)
+    assert report("mean", got[0], planes(mean)) <= 6e-8
+    assert report("blur19", got[2], planes(b2)) <= 6e-8
+    assert report("var", got[1], planes(var)) <= 2e-8
+    assert report("lap", got[3], planes(lap)) <= 2e-6
+    frac = np.mean(got[0] == planes(mean))
+    print("bit-identical mean fraction", frac)
+    assert frac > 0.99
+
+
+def test_box_stats_collab_and_sidd_tiling():
+    import yond_oracle as O
+    from yond_public_amd import _lib as L
+    lib = L.load()
+    H, W = 256, 2048
+    noisy, clean = O.synth_noisy(H, W, 4.0, 6.0, 12)
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(W)[None, :] / 37.0), 0, 1).astype(np.float32)
+    for tile_w in (0, 64):
+        lr, hr = O.bayer2rggb(noisy), O.bayer2rggb(dn)
+        if tile_w:
+            nt = (W // 2) // tile_w
+            lr = np.concatenate(np.split(lr, nt, axis=-2), axis=-1)
+            hr = np.concatenate(np.split(hr, nt, axis=-2), axis=-1)
+        lr_k, hr_k = O.stdfilt(lr, 29), O.stdfilt(hr, 29)
+        var, mean, lap = lr_k ** 2 - hr_k ** 2, O.box_blur(hr, 29), hr_k
+        if tile_w:  # back to (h, w, 4)
+            un = lambda a: np.concatenate(np.split(a, nt, axis=-1), axis=-2)
+            var, mean, lap = un(var), un(mean), un(lap)
+        h, w = H // 2, W // 2
+        o = [torch.empty((4, h, w), device=DEV) for _ in range(3)]
+        L.check(lib.yond_box_stats_collab_f32(L.ptr(torch.from_numpy(noisy).to(DEV)), L.ptr(torch.from_numpy(dn).to(DEV)), H, W, 29,
+                                              tile_w, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.stream()), "collab")
+        got = [x.cpu().numpy() for x in o]
+        assert report(f"collab mean tile_w={tile_w}", got[0], planes(mean)) <= 6e-8
+        assert report(f"collab var tile_w={tile_w}", got[1], planes(var)) <= 3e-8
+        assert report(f"collab lap tile_w={tile_w}", got[2], planes(lap)) <= 2e-6
+
+
+@pytest.mark.parametrize("n", [1, 5, 1000, 65537, 3_000_001])
+def test_percentiles_exact(n):
+    from yond_public_amd import pipeline as P
+    rng = np.random.default_rng(n)
+    a = (rng.random(n).astype(np.float32) ** 3) * 0.1
+    if n > 100:
+        a[:: 7] = a[3]                      # heavy duplicates
+    q = np.linspace(5, 100, 20)
+    got = P._percentiles(torch.from_numpy(a).to(DEV), q).cpu().numpy()
+    ref = np.percentile(a, q, method='linear')
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+    got25 = P._percentiles(torch.from_numpy(a).to(DEV), [25.0]).cpu().numpy()
+    assert np.array_equal(got25, np.percentile(a, [25.0], method='linear'))
+
+
+def test_select_handles_negative_and_zero_values():
+    from yond_public_amd import pipeline as P
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal(10007).astype(np.float32)
+    a[:50] = 0.0
+    a[50:60] = -0.0
+    q = [0.0, 12.5, 50.0, 99.9, 100.0]
+    got = P._percentiles(torch.from_numpy(a).to(DEV), q).cpu().numpy()
+    assert np.array_equal(got, np.percentile(a, q, method='linear'))
+
+
+def test_accumulate_matches_numpy():
+    from yond_public_amd import pipeline as P
+    rng = np.random.default_rng(4)
+    n = 1_000_003
+    lap = (rng.random(n).astype(np.float32) ** 2) * 0.05
+    mean = np.clip(rng.random(n).astype(np.float32) * 1.1 - 0.05, -0.02, 1.05).astype(np.float32)
+    var = (0.004 * mean + 1e-4 * rng.standard_normal(n)).astype(np.float32)
+    q = np.linspace(5, 100, 20)
+    ths = np.percentile(lap, q, method='linear')
+    pad = (-n) % 4
+    occ, mom = P._accumulate(torch.from_numpy(lap).to(DEV), torch.from_numpy(mean).to(DEV), torch.from_numpy(var).to(DEV),
+                             torch.from_numpy(ths).to(DEV))
+    occ, mom = occ.cpu().numpy(), mom.cpu().numpy()
+    seen = np.logical_or.accumulate(occ.astype(bool), axis=0).sum(axis=1)
+    for i in range(20):
+        b = (mean[lap <= ths[i]].clip(0, 1) * 1000).astype(int)
+        assert seen[i] == np.sum(np.bincount(b, minlength=1001) > 0), i
+    for i in (0, 5, 19):
+        sel = lap < ths[i]
+        m, v = mean[sel].astype(np.float64), var[sel].astype(np.float64)
+        ref = np.array([m.size, m.sum(), v.sum(), (m * m).sum(), (m * v).sum()])
+        got = mom[:i + 1, 0].sum(axis=0)
+        np.testing.assert_allclose(got, ref, rtol=1e-11)
+        ns = sel & (mean > np.float32(1e-4)) & (mean < np.float32(0.8))
+        m, v = mean[ns].astype(np.float64), var[ns].astype(np.float64)
+        ref = np.array([m.size, m.sum(), v.sum(), (m * m).sum(), (m * v).sum()])
+        np.testing.assert_allclose(mom[:i + 1, 1].sum(axis=0), ref, rtol=1e-11)
+    assert mom[:, 0, 0].sum() == n
+
+
+@pytest.mark.parametrize("tag", ["s256", "s512", "hi", "lo"])
+def test_simple_nlf_matches_reference(golden, tag):
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    g = golden("nle")
+    H, W, K, s, idx = g[f"{tag}_meta"]
+    noisy, clean = O.synth_noisy(int(H), int(W), K, s, int(idx))
+    assert np.array_equal(sha(noisy), g[f"{tag}_sha"])
+    reg, info = P.SimpleNLF(noisy, k=29, setting={'mode': 'self'}, full=True, device=DEV)
+    th, pct, b1, b2 = g[f"{tag}_self"]
+    print(f"[parity] NLE self {tag}: th {info['th']:.6e} vs {th:.6e}; b1 {reg[0]:.6e} vs {b1:.6e}; b2 {reg[1]:.6e} vs {b2:.6e}")
+    assert info['percent'] == pct
+    np.testing.assert_allclose(info['th'], th, rtol=1e-5)
+    np.testing.assert_allclose(reg[0], b1, rtol=1e-5)
+    np.testing.assert_allclose(reg[1], b2, rtol=0, atol=1e-5 * abs(b1) + 1e-9)
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(int(W))[None, :] / 37.0), 0, 1).astype(np.float32)
+    regc, infoc = P.SimpleNLF(noisy, dn, k=29, setting={'mode': 'collab'}, full=True, device=DEV)
+    thc, pctc, c1, c2 = g[f"{tag}_collab"]
+    assert infoc['percent'] == pctc
+    np.testing.assert_allclose(infoc['th'], thc, rtol=1e-5)
+    np.testing.assert_allclose(regc[0], c1, rtol=1e-5)
+    np.testing.assert_allclose(regc[1], c2, rtol=0, atol=1e-5 * abs(c1) + 1e-9)
+
+
+def test_simple_nlf_sidd256(golden):
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    g = golden("nle")
+    noisy, clean = O.synth_noisy(256, 8192, 4.0, 6.0, 7)
+    assert np.array_equal(sha(noisy), g["strip_sha"])
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(8192)[None, :] / 37.0), 0, 1).astype(np.float32)
+    r1 = P.SimpleNLF(noisy, k=29, setting={'mode': 'self', 'SIDD_256': True}, device=DEV)
+    r2 = P.SimpleNLF(noisy, dn, k=29, setting={'mode': 'collab', 'SIDD_256': True}, device=DEV)
+    r3 = P.SimpleNLF(noisy, k=29, setting={'mode': 'self'}, device=DEV)
+    for r, gr in zip((r1, r2, r3), g["strip_regs"]):
+        np.testing.assert_allclose(r[0], gr[0], rtol=1e-5)
+        np.testing.assert_allclose(r[1], gr[1], rtol=0, atol=1e-5 * abs(gr[0]) + 1e-9)
+
+
+def test_nlf_full_frame_size_properties():
+    """BASELINE cfg-2 size (3000 x 4000): size-independent checks -- percentiles are sorted and bracket the
+    data, bucket counts add up to the pixel count, the estimate recovers the synthetic (K, sigma)."""
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    noisy, _ = O.synth_noisy(3000, 4000, 4.0, 6.0, 0)
+    reg, info = P.SimpleNLF(noisy, k=29, setting={'mode': 'self'}, full=True, device=DEV)
+    ths = info['ths']
+    assert np.all(np.diff(ths) >= 0)
+    K, sig = reg[0] * 959, np.sqrt(max(reg[1], 0)) * 959
+    print(f"[cfg2] estimated K={K:.4f} sigma={sig:.4f} (synthetic 4.0 / 6.0), percent={info['percent']}")
+    assert abs(K - 4.0) < 0.2 and abs(sig - 6.0) < 1.0

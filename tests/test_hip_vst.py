@@ -1,0 +1,114 @@
+"""GPU: K1 / K4 / pack / bias LUT against the oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from hip_common import report
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_pack_unpack_bit_exact(golden):
+    from yond_public_amd import pipeline as P
+    g = golden("pack")
+    assert np.array_equal(P.bayer2rggb(g["bayer"], DEV).cpu().numpy(), g["rggb"])
+    assert np.array_equal(P.rggb2bayer(g["rggb_in"], DEV).cpu().numpy(), g["bayer_out"])
+    a = np.random.default_rng(0).random((3000, 4000)).astype(np.float32)       # BASELINE cfg-2 size: round trip
+    t = torch.from_numpy(a).to(DEV)
+    assert torch.equal(P.rggb2bayer(P.bayer2rggb(t)), t)
+
+
+def test_bias_lut_matches_reference_knots(golden):
+    from yond_public_amd import pipeline as P
+    g = golden("bias")
+    worst = 0.0
+    for i, (K, s) in enumerate(g["ksig"]):
+        for tag, mx in zip("abc", g["max"]):
+            lut = P.get_bias(np.float32(mx), np.float64(s), np.float64(K), device=DEV)
+            np.testing.assert_array_equal(lut.lams, g[f"lams_{i}{tag}"])
+            got = lut.y.cpu().numpy()
+            ref = g[f"bias_{i}{tag}"]
+            worst = max(worst, report(f"bias LUT K={K} s={s} max={mx}", got, ref))
+            # float32 knots: a few ulp of float32 at |bias| <= 0.2 (different exp/lgamma/summation order)
+            np.testing.assert_allclose(got, ref, rtol=0, atol=3e-7)
+    print("worst bias knot error", worst)
+
+
+@pytest.mark.parametrize("H,W,K,s,bc", [(128, 192, 4.37, 6.27, True), (120, 136, 22.65, 37.09, True), (64, 96, 0.72, 1.8, True),
+                                        (128, 128, 4.37, 6.27, False)])
+def test_k1_pack_vst_norm(H, W, K, s, bc):
+    import yond_oracle as O
+    import torch.nn.functional as F
+    from yond_public_amd import pipeline as P, _lib as L
+    lib = L.load()
+    noisy, _ = O.synth_noisy(H, W, K, s, 3)
+    K, s = np.float64(K), np.float64(s)
+    # oracle staging (YOND_SIDD.py:251-269, 281-286)
+    lr = O.bayer2rggb(noisy) * 959.0
+    v = O.VST(lr, s, gain=K)
+    if bc:
+        f = O.get_bias(lr.max(), s, K)
+        v = v - f(np.maximum(lr, 0))
+    lo, hi = O.VST(0, s, gain=K), O.VST(959.0, s, gain=K)
+    u = torch.from_numpy(np.ascontiguousarray((v - lo) / (hi - lo))).float().permute(2, 0, 1)[None]
+    p2d = O.get_p2d(u.shape, 32)
+    ref = F.pad(u, p2d, mode='reflect').clamp(0, 1)[0].permute(1, 2, 0).numpy()
+    # HIP
+    t = torch.from_numpy(noisy).to(DEV)
+    h, w = H // 2, W // 2
+    Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
+    x4 = torch.empty((Hp, Wp, 4), device=DEV)
+    mx = torch.empty(1, device=DEV)
+    lut = P.get_bias(lr.max(), s, K, device=DEV) if bc else None
+    L.check(lib.yond_pack_vst_norm_f32(L.ptr(t), H, W, L.ptr(x4), *p2d, 1, 959.0, float(K), float(s), float(lo), float(hi),
+                                       L.ptr(lut.x) if bc else None, L.ptr(lut.y) if bc else None, len(lut) if bc else 0,
+                                       L.ptr(mx), L.stream()), "k1")
+    got = x4.cpu().numpy()
+    err = report(f"K1 {H}x{W} K={K}", got, ref)
+    assert err <= 3e-7          # <= 2-3 ulp of float32 on [0,1] (LUT knots differ by float32 ulps)
+    assert float(mx.item()) == float(got.max())
+
+
+def test_k4_denorm_ivst_unpack():
+    import yond_oracle as O
+    from yond_public_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    Hp, Wp, h, w, pt, pl = 64, 96, 60, 90, 2, 3
+    y = (rng.random((Hp, Wp, 4)) * 1.2 - 0.1).astype(np.float32)
+    K, s = np.float64(4.37), np.float64(6.27)
+    lo, hi = O.VST(0, s, gain=K), O.VST(959.0, s, gain=K)
+    for mode, exact in ((1, False), (2, True)):
+        yc = np.clip(y, 0, 1)[pt:pt + h, pl:pl + w]
+        z = yc * (hi - lo) + lo
+        ref = O.rggb2bayer(O.inverse_VST(z, s, gain=K, exact=exact)) / 959.0
+        out = torch.empty((2 * h, 2 * w), device=DEV)
+        L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(torch.from_numpy(y).to(DEV)), Hp, Wp, pt, pl, h, w, L.ptr(out), mode, 959.0,
+                                                float(K), float(s), float(lo), float(hi), 0, L.stream()), "k4")
+        got = out.cpu().numpy()
+        err = np.abs(got.astype(np.float64) - ref)
+        rel = err / np.maximum(np.abs(ref), 1e-6)
+        print(f"[parity] K4 mode {mode}: max_abs={err.max():.3e} max_rel={rel.max():.3e}")
+        assert rel.max() <= 2 ** -23        # one rounding to float32
+
+
+@pytest.mark.parametrize("ci", range(4))
+def test_vst_denoiser_matches_reference(golden, ci):
+    """End-to-end row J against the reference's own output (tests/golden/vst_denoiser.npz)."""
+    import yond_oracle as O
+    from hip_common import ARCHS, make_net, sha
+    from yond_public_amd import pipeline as P
+    g = golden("vst_denoiser")
+    H, W, K, s, idx, seed = g[f"meta_{ci}"]
+    arch = ARCHS[str(g[f"arch_{ci}"])]
+    bc = str(g[f"bias_corr_{ci}"])
+    bc = None if bc == 'None' else bc
+    noisy, _ = O.synth_noisy(int(H), int(W), K, s, int(idx))
+    assert np.array_equal(sha(noisy), g[f"sha_{ci}"])
+    net, sd = make_net(arch, int(seed))
+    p = {'wp': 1023, 'bl': 64, 'ratio': 1, 'scale': 959.0, 'gain': np.float64(K), 'sigma': np.float64(s)}
+    dn = P.VST_Denoiser(torch.from_numpy(noisy).to(DEV), p, net, arch, bias_corr=bc).cpu().numpy()
+    ref = g[f"dn_{ci}"]
+    err = report(f"VST_Denoiser case {ci}", dn, ref)
+    assert err <= 1e-4

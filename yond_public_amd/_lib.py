@@ -1,0 +1,109 @@
+"""ctypes binding of libyond_hip.so (C ABI declared in include/yond_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a tensor is not
+on a ROCm device, the callers raise.  `load()` is lazy so that importing the package (and
+the host-side logic) works on a CPU-only box; the first kernel call needs the library.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyond_hip.so")
+_lib = None
+
+vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+
+class YondConvDesc(C.Structure):
+    _fields_ = [("src0", vp), ("src1", vp), ("C0", i32), ("C1", i32), ("N", i32), ("H", i32), ("W", i32),
+                ("Ho", i32), ("Wo", i32), ("Cout", i32), ("ksize", i32), ("stride", i32), ("shuffle", i32),
+                ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
+                ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp)]
+
+
+class YondFilmDesc(C.Structure):
+    _fields_ = [("kind", i32), ("C", i32), ("ld", i32),
+                ("w_a0", vp), ("b_a0", vp), ("w_a2", vp), ("b_a2", vp), ("w_b0", vp), ("b_b0", vp),
+                ("w_b", vp), ("b_b", vp), ("cb1", vp), ("cb2", vp),
+                ("s1", vp), ("t1", vp), ("s2", vp), ("t2", vp)]
+
+
+# name -> argtypes, in the order of include/yond_hip.h (tests check every name is exported)
+PROTOTYPES = {
+    "yond_abi_version": [],
+    "yond_pack_vst_norm_f32": [vp, i32, i32, vp, i32, i32, i32, i32, i32, f64, f64, f64, f64, f64, vp, vp, i32, vp, vp],
+    "yond_denorm_ivst_unpack_f32": [vp, i32, i32, i32, i32, i32, i32, vp, i32, f64, f64, f64, f64, f64, i32, vp],
+    "yond_bayer2rggb_f32": [vp, i32, i32, vp, vp],
+    "yond_rggb2bayer_f32": [vp, i32, i32, vp, vp],
+    "yond_nchw4_to_nhwc4_f32": [vp, vp, i32, i32, i32, vp],
+    "yond_nhwc4_to_nchw4_f32": [vp, vp, i32, i32, i32, vp],
+    "yond_image_max_f32": [vp, i32, sz, vp, vp, vp],
+    "yond_conv_config": [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
+    "yond_pack_conv_weight_f32": [vp, i32, i32, i32, i32, i32, vp],
+    "yond_conv2d_f32": [C.POINTER(YondConvDesc), vp],
+    "yond_conv_in_f32": [vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp],
+    "yond_pack_conv_in_weight_f32": [vp, i32, vp],
+    "yond_conv_out_f32": [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp],
+    "yond_maxpool2_f32": [vp, i32, i32, i32, i32, vp, vp],
+    "yond_film_f32": [vp, i32, vp, vp, i32, vp],
+    "yond_box_stats_self1_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
+    "yond_box_stats_self2_f32": [vp, i32, i32, i32, i32, vp, vp],
+    "yond_box_stats_collab_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp],
+    "yond_select_ws_bytes": [i32],
+    "yond_select_ranks_f32": [vp, sz, vp, i32, vp, vp, vp],
+    "yond_percentiles_f32": [vp, sz, vp, i32, vp, vp, vp],
+    "yond_nlf_ws_bytes": [i32],
+    "yond_nlf_accumulate_f32": [vp, vp, vp, sz, vp, i32, vp, vp, vp, vp],
+    "yond_bias_lut_f64": [vp, i32, f64, f64, vp, vp],
+    "yond_block_metrics_tiles": [i32, i32],
+    "yond_block_metrics_f32": [vp, vp, i32, i32, i32, i32, vp, vp],
+}
+_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nlf_ws_bytes"}
+
+
+class YondHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libyond_hip.so (once).  Raises if it is missing -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YondHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  yond_public_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_size_t if name in _SIZE_T_RET else C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "YOND_EINVAL", -2: "YOND_EUNSUPPORTED"}.get(rc, f"hipError {rc}")
+        raise YondHipError(f"{what} failed: {kind}")
+
+
+def require_cuda(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise YondHipError(f"{name} must be a float32 tensor on a ROCm device (the HIP path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise YondHipError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise YondHipError(f"{name} must be contiguous")
+    return t
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

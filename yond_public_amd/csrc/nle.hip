@@ -1,0 +1,475 @@
+// K5-K7: the noise-level estimator's data passes (YOND_SIDD.py:13-115, utils/isp_algos.py:234-242, 345-365).
+//   K5  box statistics: cv2.blur semantics (normalised k x k window, BORDER_REFLECT_101), window sums in
+//       float64 (the float32 inputs make them exact), every intermediate rounded to float32 exactly where
+//       NumPy / OpenCV round (no fused multiply-adds across those points).
+//   K6  exact order statistics by 4-pass radix select (8 bits per pass, LDS-privatised histograms, all
+//       requested ranks at once) + np.percentile's linear interpolation.
+//   K7  one pass over (lap, mean, var): occupancy of the 1/1000 mean bins per threshold bucket and the five
+//       moment sums of the least-squares line per bucket.
+// All of it is integer / streaming work bound by HBM and LDS, not MFMA.
+#include "common.h"
+
+// =====================================================================================================
+// K5
+// =====================================================================================================
+#define BX_TH 32
+#define BX_TW 64
+#define BX_R 14
+#define BX_RH (BX_TH + 2 * BX_R)
+#define BX_RW (BX_TW + 2 * BX_R)
+
+// Window sums of one quantity for this thread's 8 outputs: rows (tid>>6) + 4*i, column tid&63.
+// s_src: float [BX_RH][BX_RW] (tile with halo BX_R), s_h: double [BX_RH][BX_TW] scratch.
+__device__ __forceinline__ void window_sums(const float* s_src, bool square, int k, double* s_h, double out[8]) {
+    const int tid = threadIdx.x;
+    const int rk = k / 2;
+    const int off = BX_R - rk;                       // first tile row/col that the window of output 0 touches
+    const int nrows = BX_TH + 2 * rk;
+    __syncthreads();                                 // previous user of s_h is done
+    for (int it = tid; it < nrows * BX_TW; it += 256) {
+        const int row = it / BX_TW + off, col = it % BX_TW;
+        const float* p = s_src + row * BX_RW + col + off;
+        double s = 0.0;
+        if (square) {
+            for (int d = 0; d < k; ++d) { const float v = p[d]; s += (double)__fmul_rn(v, v); }
+        } else {
+            for (int d = 0; d < k; ++d) s += (double)p[d];
+        }
+        s_h[row * BX_TW + col] = s;
+    }
+    __syncthreads();
+    const int col = tid & 63, rg = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = rg + 4 * i + off;
+        double s = 0.0;
+        for (int d = 0; d < k; ++d) s += s_h[(row + d) * BX_TW + col];
+        out[i] = s;
+    }
+}
+
+__device__ __forceinline__ float blur_round(double s, int k) { return (float)(s * (1.0 / (double)(k * k))); }
+
+// std = sqrt(max(B(x^2) - B(x)^2, 0)) in float32 steps (utils/isp_algos.py:236-241)
+__device__ __forceinline__ float std_from(float b1, float b2) {
+    const float d = __fsub_rn(b2, __fmul_rn(b1, b1));
+    return __fsqrt_rn(fmaxf(d, 0.0f));
+}
+
+struct BoxSrc {
+    const float* p;     // base pointer
+    int bayer;          // 1: Bayer frame [2h][2w], plane = blockIdx.z ; 0: planar [4][h][w]
+};
+
+__device__ __forceinline__ void load_tile(float* s_src, BoxSrc src, int h, int w, int tile_w, int oy0, int ox0, int plane) {
+    // reflect inside [0,h) x [bx0, bx0+bw): bw = tile_w (SIDD_256 re-tiling) or the whole width
+    const int bw = tile_w > 0 ? tile_w : w;
+    const int bx0 = tile_w > 0 ? (ox0 / tile_w) * tile_w : 0;
+    const int dy = plane >> 1, dx = plane & 1;
+    for (int it = threadIdx.x; it < BX_RH * BX_RW; it += 256) {
+        const int ty = it / BX_RW, tx = it % BX_RW;
+        const int gy = reflect101(oy0 - BX_R + ty, h);
+        const int gx = bx0 + reflect101(ox0 - BX_R + tx - bx0, bw);
+        float v;
+        if (src.bayer) v = src.p[(size_t)(2 * gy + dy) * (2 * w) + 2 * gx + dx];
+        else v = src.p[((size_t)plane * h + gy) * w + gx];
+        s_src[it] = v;
+    }
+}
+
+// mode 0: self stage 1 (mean, var, blur2 from the Bayer frame); 1: self stage 2 (lap from blur2);
+// 2: collab (mean, var, lap from noisy + denoised Bayer frames)
+template <int MODE>
+__global__ __launch_bounds__(256) void box_stats_kernel(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_w,
+                                                        float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* s_h = (double*)smem_raw;                                   // [BX_RH][BX_TW]
+    float* s_a = (float*)(smem_raw + sizeof(double) * BX_RH * BX_TW);  // [BX_RH][BX_RW]
+    float* s_b = s_a + BX_RH * BX_RW;
+    const int plane = blockIdx.z;
+    const int ox0 = blockIdx.x * BX_TW, oy0 = blockIdx.y * BX_TH;
+    load_tile(s_a, a, h, w, tile_w, oy0, ox0, plane);
+    if (MODE == 2) load_tile(s_b, b, h, w, tile_w, oy0, ox0, plane);
+    double q0[8], q1[8], q2[8], q3[8];
+    if (MODE == 0) {
+        window_sums(s_a, false, k, s_h, q0);
+        window_sums(s_a, true, k, s_h, q1);
+        window_sums(s_a, false, k2, s_h, q2);
+    } else if (MODE == 1) {
+        window_sums(s_a, false, k, s_h, q0);
+        window_sums(s_a, true, k, s_h, q1);
+    } else {
+        window_sums(s_a, false, k, s_h, q0);
+        window_sums(s_a, true, k, s_h, q1);
+        window_sums(s_b, false, k, s_h, q2);
+        window_sums(s_b, true, k, s_h, q3);
+    }
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int ox = ox0 + col;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int oy = oy0 + rg + 4 * i;
+        if (oy >= h || ox >= w) continue;
+        const size_t idx = ((size_t)plane * h + oy) * w + ox;
+        if (MODE == 0) {
+            const float m = blur_round(q0[i], k);
+            const float sd = std_from(m, blur_round(q1[i], k));
+            o0[idx] = m;
+            o1[idx] = __fmul_rn(sd, sd);                              // var = lr_rggb_k**2 (YOND_SIDD.py:72)
+            o2[idx] = blur_round(q2[i], k2);
+        } else if (MODE == 1) {
+            o0[idx] = std_from(blur_round(q0[i], k), blur_round(q1[i], k));
+        } else {
+            const float sl = std_from(blur_round(q0[i], k), blur_round(q1[i], k));
+            const float mh = blur_round(q2[i], k);
+            const float sh = std_from(mh, blur_round(q3[i], k));
+            o0[idx] = mh;                                              // mean = blur(hr) (YOND_SIDD.py:97)
+            o1[idx] = __fsub_rn(__fmul_rn(sl, sl), __fmul_rn(sh, sh));  // var = lr_k**2 - hr_k**2 (:96)
+            o2[idx] = sh;                                              // img_lap = hr_k (:98)
+        }
+    }
+}
+
+static int box_args_ok(int h, int w, int k, int tile_w) {
+    if (h < 1 || w < 1) return YOND_EINVAL;
+    if (k < 1 || !(k & 1)) return YOND_EINVAL;
+    if (k > 2 * BX_R + 1) return YOND_EUNSUPPORTED;
+    if (tile_w < 0) return YOND_EINVAL;
+    if (tile_w > 0 && (tile_w % BX_TW != 0 || w % tile_w != 0)) return YOND_EUNSUPPORTED;
+    return YOND_OK;
+}
+
+template <int MODE>
+static int launch_box(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_w, float* o0, float* o1, float* o2, hipStream_t st) {
+    const size_t smem = sizeof(double) * BX_RH * BX_TW + sizeof(float) * BX_RH * BX_RW * (MODE == 2 ? 2 : 1);
+    static bool attr = false;
+    auto kern = box_stats_kernel<MODE>;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    dim3 grid((w + BX_TW - 1) / BX_TW, (h + BX_TH - 1) / BX_TH, 4);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a, b, h, w, k, k2, tile_w, o0, o1, o2);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_box_stats_self1_f32(const float* bayer, int H, int W, int k, int k2, int tile_w, float* mean,
+                                        float* var, float* blur2, void* stream) {
+    if (!bayer || !mean || !var || !blur2 || (H & 1) || (W & 1)) return YOND_EINVAL;
+    int rc = box_args_ok(H / 2, W / 2, k, tile_w);
+    if (rc) return rc;
+    rc = box_args_ok(H / 2, W / 2, k2, tile_w);
+    if (rc) return rc;
+    BoxSrc a{bayer, 1}, b{nullptr, 0};
+    return launch_box<0>(a, b, H / 2, W / 2, k, k2, tile_w, mean, var, blur2, (hipStream_t)stream);
+}
+
+extern "C" int yond_box_stats_self2_f32(const float* blur2, int h, int w, int k, int tile_w, float* lap, void* stream) {
+    if (!blur2 || !lap) return YOND_EINVAL;
+    const int rc = box_args_ok(h, w, k, tile_w);
+    if (rc) return rc;
+    BoxSrc a{blur2, 0}, b{nullptr, 0};
+    return launch_box<1>(a, b, h, w, k, k, tile_w, lap, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int yond_box_stats_collab_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,
+                                         float* mean, float* var, float* lap, void* stream) {
+    if (!bayer_lr || !bayer_hr || !mean || !var || !lap || (H & 1) || (W & 1)) return YOND_EINVAL;
+    const int rc = box_args_ok(H / 2, W / 2, k, tile_w);
+    if (rc) return rc;
+    BoxSrc a{bayer_lr, 1}, b{bayer_hr, 1};
+    return launch_box<2>(a, b, H / 2, W / 2, k, k, tile_w, mean, var, lap, (hipStream_t)stream);
+}
+
+// =====================================================================================================
+// K6: multi-rank radix select + np.percentile(method='linear')
+// =====================================================================================================
+#define SEL_MAXT 64          // max number of order statistics per call
+
+struct SelState {
+    unsigned int tgt_prefix[SEL_MAXT];
+    long long tgt_rank[SEL_MAXT];      // remaining rank inside the target's prefix group
+    int tgt_slot[SEL_MAXT];
+    unsigned int slot_prefix[SEL_MAXT];
+    int nslots;
+    int nt;
+    unsigned int hist[SEL_MAXT * 256];
+};
+
+__device__ __forceinline__ unsigned int f2key(float f) {
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);       // total order of floats as unsigned
+}
+__device__ __forceinline__ float key2f(unsigned int k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+struct SelRanks { long long r[SEL_MAXT]; };
+
+__global__ void sel_init_kernel(SelState* st, SelRanks ranks, int nt) {
+    const int t = threadIdx.x;
+    if (t < nt) { st->tgt_prefix[t] = 0; st->tgt_rank[t] = ranks.r[t]; st->tgt_slot[t] = 0; }
+    if (t == 0) { st->nslots = 1; st->slot_prefix[0] = 0; st->nt = nt; }
+    for (int i = t; i < SEL_MAXT * 256; i += blockDim.x) st->hist[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__ data, size_t n, SelState* st, int pass) {
+    extern __shared__ unsigned int s_hist[];                 // [nslots][256]
+    __shared__ unsigned int s_pref[SEL_MAXT];
+    const int nslots = st->nslots;
+    for (int i = threadIdx.x; i < nslots * 256; i += 256) s_hist[i] = 0;
+    if (threadIdx.x < nslots) s_pref[threadIdx.x] = st->slot_prefix[threadIdx.x];
+    __syncthreads();
+    const int shift = 24 - 8 * pass;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned int key = f2key(data[i]);
+        int slot = 0;
+        if (pass > 0) {
+            const unsigned int pre = key >> (shift + 8);
+            int lo = 0, hi = nslots;                          // first index with s_pref >= pre
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid] < pre) lo = mid + 1; else hi = mid; }
+            slot = (lo < nslots && s_pref[lo] == pre) ? lo : -1;
+        }
+        if (slot >= 0) atomicAdd(&s_hist[slot * 256 + ((key >> shift) & 255u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nslots * 256; i += 256) {
+        const unsigned int c = s_hist[i];
+        if (c) atomicAdd(&st->hist[i], c);
+    }
+}
+
+__global__ void sel_resolve_kernel(SelState* st, int pass, float* out_vals) {
+    __shared__ unsigned int s_newp[SEL_MAXT];
+    const int t = threadIdx.x;
+    const int nt = st->nt;
+    if (t < nt) {
+        const unsigned int* h = st->hist + st->tgt_slot[t] * 256;
+        long long rank = st->tgt_rank[t];
+        int d = 0;
+        long long cum = 0;
+        for (; d < 255; ++d) {
+            const long long c = (long long)h[d];
+            if (rank < cum + c) break;
+            cum += c;
+        }
+        st->tgt_rank[t] = rank - cum;
+        const unsigned int np = (st->tgt_prefix[t] << 8) | (unsigned int)d;
+        st->tgt_prefix[t] = np;
+        s_newp[t] = np;
+        if (pass == 3) out_vals[t] = key2f(np);
+    }
+    __syncthreads();
+    if (t == 0 && pass < 3) {
+        // sorted distinct prefixes -> slots
+        int ns = 0;
+        for (int i = 0; i < nt; ++i) {
+            const unsigned int p = s_newp[i];
+            int pos = 0;
+            while (pos < ns && st->slot_prefix[pos] < p) ++pos;
+            if (pos < ns && st->slot_prefix[pos] == p) continue;
+            for (int j = ns; j > pos; --j) st->slot_prefix[j] = st->slot_prefix[j - 1];
+            st->slot_prefix[pos] = p;
+            ++ns;
+        }
+        st->nslots = ns;
+        for (int i = 0; i < nt; ++i) {
+            int pos = 0;
+            while (st->slot_prefix[pos] != s_newp[i]) ++pos;
+            st->tgt_slot[i] = pos;
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < SEL_MAXT * 256; i += blockDim.x) st->hist[i] = 0;
+}
+
+struct LerpArgs { double t[SEL_MAXT / 2]; };
+
+__global__ void percentile_lerp_kernel(const float* __restrict__ vals, LerpArgs a, int nq, double* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i >= nq) return;
+    // numpy _lerp: diff = b - a in the data dtype; a + diff*t (t < 0.5) or b - diff*(1-t) (t >= 0.5); b == a -> a
+    const float av = vals[2 * i], bv = vals[2 * i + 1];
+    const float diff = __fsub_rn(bv, av);
+    const double t = a.t[i];
+    double r = (t >= 0.5) ? __dsub_rn((double)bv, __dmul_rn((double)diff, 1.0 - t)) : __dadd_rn((double)av, __dmul_rn((double)diff, t));
+    if (bv == av) r = (double)av;
+    out[i] = r;
+}
+
+extern "C" size_t yond_select_ws_bytes(int nr) {
+    (void)nr;
+    return sizeof(SelState) + SEL_MAXT * sizeof(float) + 64;
+}
+
+static int select_ranks(const float* data, size_t n, const long long* ranks, int nr, float* out, void* ws, hipStream_t st) {
+    SelState* state = (SelState*)ws;
+    SelRanks rk;
+    for (int i = 0; i < nr; ++i) {
+        if (ranks[i] < 0 || (size_t)ranks[i] >= n) return YOND_EINVAL;
+        rk.r[i] = ranks[i];
+    }
+    hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(256), 0, st, state, rk, nr);
+    YOND_LAUNCH_CHECK();
+    size_t nb = (n + 256 * 8 - 1) / (256 * 8);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)sel_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_MAXT * 256 * 4);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    for (int pass = 0; pass < 4; ++pass) {
+        hipLaunchKernelGGL(sel_hist_kernel, dim3((unsigned)nb), dim3(256), SEL_MAXT * 256 * 4, st, data, n, state, pass);
+        YOND_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sel_resolve_kernel, dim3(1), dim3(256), 0, st, state, pass, out);
+        YOND_LAUNCH_CHECK();
+    }
+    return YOND_OK;
+}
+
+extern "C" int yond_select_ranks_f32(const float* data, size_t n, const int64_t* ranks_host, int nr, float* out, void* ws,
+                                     void* stream) {
+    if (!data || !ranks_host || !out || !ws || n == 0 || nr <= 0 || nr > SEL_MAXT) return YOND_EINVAL;
+    long long r[SEL_MAXT];
+    for (int i = 0; i < nr; ++i) r[i] = (long long)ranks_host[i];
+    return select_ranks(data, n, r, nr, out, ws, (hipStream_t)stream);
+}
+
+extern "C" int yond_percentiles_f32(const float* data, size_t n, const double* q_host, int nq, double* out, void* ws,
+                                    void* stream) {
+    if (!data || !q_host || !out || !ws || n == 0 || nq <= 0 || nq > SEL_MAXT / 2) return YOND_EINVAL;
+    long long r[SEL_MAXT];
+    LerpArgs la;
+    for (int i = 0; i < nq; ++i) {
+        if (!(q_host[i] >= 0.0 && q_host[i] <= 100.0)) return YOND_EINVAL;
+        // numpy: virtual index = q/100 * (n-1); previous = floor, next = previous+1 clipped, gamma = frac
+        const double vidx = (q_host[i] / 100.0) * (double)(n - 1);
+        long long lo = (long long)floor(vidx);
+        if (lo > (long long)n - 1) lo = (long long)n - 1;
+        long long hi = lo + 1;
+        if (hi > (long long)n - 1) hi = (long long)n - 1;
+        r[2 * i] = lo;
+        r[2 * i + 1] = hi;
+        la.t[i] = vidx - (double)lo;
+    }
+    float* vals = (float*)((unsigned char*)ws + sizeof(SelState));
+    const int rc = select_ranks(data, n, r, 2 * nq, vals, ws, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(percentile_lerp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vals, la, nq, out);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// =====================================================================================================
+// K7: occupancy bitmap + bucketed moment sums
+// =====================================================================================================
+#define NLF_MAXT 32
+#define NLF_BINS 1024        // 1001 used (np.bincount(minlength=nbins+1))
+
+__global__ __launch_bounds__(256) void nlf_accumulate_kernel(const float* __restrict__ lap, const float* __restrict__ mean,
+                                                             const float* __restrict__ var, size_t n,
+                                                             const double* __restrict__ ths, int nt,
+                                                             unsigned int* __restrict__ occ, double* __restrict__ mom) {
+    __shared__ double s_ths[NLF_MAXT];
+    __shared__ unsigned int s_occ[NLF_MAXT * (NLF_BINS / 32)];
+    __shared__ double s_mom[(NLF_MAXT + 1) * 10];
+    for (int i = threadIdx.x; i < nt; i += 256) s_ths[i] = ths[i];
+    for (int i = threadIdx.x; i < NLF_MAXT * (NLF_BINS / 32); i += 256) s_occ[i] = 0;
+    for (int i = threadIdx.x; i < (NLF_MAXT + 1) * 10; i += 256) s_mom[i] = 0.0;
+    __syncthreads();
+    // each thread walks a contiguous run of elements so that consecutive elements mostly share a bucket
+    const size_t per = (n + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
+    const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // interleave runs of 4 elements across the lanes of a wave: lane l handles elements base + 4*l .. +3
+    // (coalesced 16-byte accesses), the wave then moves on by 256 elements
+    (void)per; (void)gtid;
+    int cur = -1;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;        // all pixels
+    double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;        // non-saturated pixels only
+    auto flush = [&]() {
+        if (cur >= 0) {
+            double* m = s_mom + cur * 10;
+            if (a0 != 0.0) { atomicAdd(m + 0, a0); atomicAdd(m + 1, a1); atomicAdd(m + 2, a2); atomicAdd(m + 3, a3); atomicAdd(m + 4, a4); }
+            if (b0 != 0.0) { atomicAdd(m + 5, b0); atomicAdd(m + 6, b1); atomicAdd(m + 7, b2); atomicAdd(m + 8, b3); atomicAdd(m + 9, b4); }
+        }
+        a0 = a1 = a2 = a3 = a4 = 0.0;
+        b0 = b1 = b2 = b3 = b4 = 0.0;
+    };
+    const size_t nvec = n / 4;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec + 1; v += (size_t)gridDim.x * 256) {
+        float l4[4], m4[4], v4[4];
+        int cnt;
+        if (v < nvec) {
+            const f32x4 L = *(const f32x4*)(lap + v * 4), M = *(const f32x4*)(mean + v * 4), V = *(const f32x4*)(var + v * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { l4[e] = L[e]; m4[e] = M[e]; v4[e] = V[e]; }
+            cnt = 4;
+        } else {
+            cnt = (int)(n - nvec * 4);                       // tail (n % 4 elements), handled by one thread
+            for (int e = 0; e < 4; ++e) {
+                const size_t i = nvec * 4 + e;
+                l4[e] = i < n ? lap[i] : 0.f; m4[e] = i < n ? mean[i] : 0.f; v4[e] = i < n ? var[i] : 0.f;
+            }
+        }
+        for (int e = 0; e < cnt; ++e) {
+            const double ld = (double)l4[e];
+            int i_le = 0;
+            while (i_le < nt && !(ld <= s_ths[i_le])) ++i_le;   // first i with lap <= ths[i]   (YOND_SIDD.py:37)
+            int i_lt = i_le;
+            while (i_lt < nt && !(ld < s_ths[i_lt])) ++i_lt;    // first i with lap <  ths[i]   (YOND_SIDD.py:77)
+            const float mf = m4[e];
+            if (i_le < nt) {
+                const int bin = (int)__fmul_rn(fminf(fmaxf(mf, 0.0f), 1.0f), 1000.0f);   // (mean.clip(0,1)*nbins).astype(int)
+                const unsigned int bit = 1u << (bin & 31);
+                unsigned int* w = &s_occ[i_le * (NLF_BINS / 32) + (bin >> 5)];
+                if (!(*w & bit)) atomicOr(w, bit);
+            }
+            if (i_lt != cur) { flush(); cur = i_lt; }
+            const double md = (double)mf, vd = (double)v4[e];
+            a0 += 1.0; a1 += md; a2 += vd; a3 += md * md; a4 += md * vd;
+            if (mf > 1e-4f && mf < 0.8f) { b0 += 1.0; b1 += md; b2 += vd; b3 += md * md; b4 += md * vd; }
+        }
+    }
+    flush();
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * (NLF_BINS / 32); i += 256) {
+        unsigned int wv = s_occ[i];
+        const int t = i / (NLF_BINS / 32), wb = i % (NLF_BINS / 32);
+        while (wv) {
+            const int bpos = __ffs(wv) - 1;
+            wv &= wv - 1;
+            occ[(size_t)t * NLF_BINS + wb * 32 + bpos] = 1u;
+        }
+    }
+    for (int i = threadIdx.x; i < (nt + 1) * 10; i += 256) {
+        const double s = s_mom[i];
+        if (s != 0.0) atomicAdd(mom + i, s);
+    }
+}
+
+extern "C" size_t yond_nlf_ws_bytes(int nt) {
+    (void)nt;
+    return 64;
+}
+
+extern "C" int yond_nlf_accumulate_f32(const float* lap, const float* mean, const float* var, size_t n, const double* ths,
+                                       int nt, uint32_t* occ, double* mom, void* ws, void* stream) {
+    (void)ws;
+    if (!lap || !mean || !var || !ths || !occ || !mom || n == 0 || nt <= 0 || nt > NLF_MAXT) return YOND_EINVAL;
+    if (((uintptr_t)lap | (uintptr_t)mean | (uintptr_t)var) & 15) return YOND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(occ, 0, sizeof(uint32_t) * nt * NLF_BINS, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(mom, 0, sizeof(double) * (nt + 1) * 10, st);
+    if (e != hipSuccess) return (int)e;
+    size_t nb = (n / 4 + 1 + 256 * 4 - 1) / (256 * 4);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(nlf_accumulate_kernel, dim3((unsigned)nb), dim3(256), 0, st, lap, mean, var, n, ths, nt, occ, mom);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}

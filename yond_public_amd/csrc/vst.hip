@@ -1,0 +1,280 @@
+// K1 / K4 and the small layout kernels around the denoiser: pure streaming, HBM bound.
+//   K1  Bayer -> pack -> *scale -> bias LUT -> VST -> normalise -> reflect pad -> clamp -> NHWC4 (+ image max)
+//   K4  NHWC4 -> clamp -> crop -> de-normalise -> inverse VST -> unpack -> /scale -> clip -> Bayer
+// One thread per packed pixel: it reads/writes one 2x2 Bayer quad (two 8-byte accesses on adjacent rows,
+// coalesced across the wave) and one 16-byte NHWC4 slot.  Arithmetic follows the dtype staging of the
+// reference under NumPy 2: float32 x*scale, float64 for everything up to the single rounding to float32
+// (YOND_SIDD.py:251-269, 292-299; utils/isp_algos.py:5-33).
+#include "common.h"
+
+#define LUT_MAX 4096
+
+__device__ __forceinline__ double lut_eval(const double* __restrict__ sx, const float* __restrict__ sy, int n, float xq) {
+    // scipy interp1d(kind='linear')._call_linear: hi = clip(searchsorted(x, xq, 'left'), 1, n-1)
+    const double x = (double)xq;
+    int lo = 0, hi = n;                     // first index with sx[idx] >= x
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sx[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    int ih = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    const int il = ih - 1;
+    const float dy = sy[ih] - sy[il];       // float32 difference, as interp1d does with float32 knots
+    const double slope = (double)dy / (sx[ih] - sx[il]);
+    return slope * (x - sx[il]) + (double)sy[il];
+}
+
+__global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restrict__ bayer, int H, int W,
+                                                            float* __restrict__ out, int pad_l, int pad_t, int Hp,
+                                                            int Wp, int mode, float scale_f, double gain, double sigma,
+                                                            double lo, double hi, const double* __restrict__ lut_x,
+                                                            const float* __restrict__ lut_y, int lut_n,
+                                                            unsigned int* __restrict__ img_max) {
+    __shared__ double s_x[LUT_MAX];
+    __shared__ float s_y[LUT_MAX];
+    __shared__ float s_red[4];
+    for (int i = threadIdx.x; i < lut_n; i += 256) { s_x[i] = lut_x[i]; s_y[i] = lut_y[i]; }
+    __syncthreads();
+    const int h = H / 2, w = W / 2;
+    const size_t total = (size_t)Hp * Wp;
+    const double c0 = 0.375 * gain * gain;       // (3/8)*gain**2
+    const double s2 = sigma * sigma;
+    const double two_over_gain = 2.0 / gain;
+    const double span = hi - lo;
+    float vmax = 0.0f;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        const int yp = (int)(p / Wp), xp = (int)(p % Wp);
+        const int sy = reflect101(yp - pad_t, h), sx = reflect101(xp - pad_l, w);
+        const f32x2 r0 = *(const f32x2*)(bayer + (size_t)(2 * sy) * W + 2 * sx);
+        const f32x2 r1 = *(const f32x2*)(bayer + (size_t)(2 * sy + 1) * W + 2 * sx);
+        float q[4] = {r0[0], r0[1], r1[0], r1[1]};
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float u;
+            if (mode == 0) {
+                u = q[c];
+            } else {
+                const float x32 = q[c] * scale_f;                       // float32 * python float -> float32
+                double fz = gain * (double)x32 + c0 + s2;               // gain*x + (3/8)gain^2 + sigma^2 (- gain*0)
+                fz = fz > 0.0 ? fz : 0.0;
+                double v = two_over_gain * sqrt(fz);
+                if (lut_n > 0) v -= lut_eval(s_x, s_y, lut_n, fmaxf(x32, 0.0f));
+                u = (float)((v - lo) / span);
+            }
+            u = fminf(fmaxf(u, 0.0f), 1.0f);
+            o[c] = u;
+            vmax = fmaxf(vmax, u);
+        }
+        *(f32x4*)(out + p * 4) = o;
+    }
+    if (img_max) {
+        vmax = wave_max(vmax);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+            atomicMax(img_max, __float_as_uint(m));                      // values are >= 0: uint order == float order
+        }
+    }
+}
+
+extern "C" int yond_pack_vst_norm_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t,
+                                      int pad_b, int mode, double scale, double gain, double sigma, double lo,
+                                      double hi, const double* lut_x, const float* lut_y, int lut_n, float* img_max,
+                                      void* stream) {
+    if (!bayer || !out || H < 2 || W < 2 || (H & 1) || (W & 1)) return YOND_EINVAL;
+    if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0) return YOND_EINVAL;
+    if (mode != 0 && mode != 1) return YOND_EINVAL;
+    if (lut_n < 0 || lut_n > LUT_MAX || lut_n == 1 || (lut_n > 0 && (!lut_x || !lut_y))) return YOND_EINVAL;
+    if (mode == 1 && !(gain > 0.0) ) return YOND_EINVAL;
+    if (mode == 1 && !(hi > lo)) return YOND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int Hp = H / 2 + pad_t + pad_b, Wp = W / 2 + pad_l + pad_r;
+    if (img_max) {
+        hipError_t e = hipMemsetAsync(img_max, 0, sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t total = (size_t)Hp * Wp;
+    size_t nb = (total + 255) / 256;
+    if (nb > 256 * 16) nb = 256 * 16;
+    hipLaunchKernelGGL(pack_vst_norm_kernel, dim3((unsigned)nb), dim3(256), 0, st, bayer, H, W, out, pad_l, pad_t, Hp, Wp,
+                       mode, (float)scale, gain, sigma, lo, hi, lut_x, lut_y, mode == 1 ? lut_n : 0, (unsigned int*)img_max);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+__global__ __launch_bounds__(256) void denorm_ivst_unpack_kernel(const float* __restrict__ net_out, int Wp, int pad_t,
+                                                                 int pad_l, int h, int w, float* __restrict__ bayer,
+                                                                 int mode, double scale, double gain, double sigma,
+                                                                 double lo, double hi, int clip01) {
+    const size_t total = (size_t)h * w;
+    const double span = hi - lo;
+    const double sg = sigma / gain;                 // inverse_VST: sigma = sigma / gain
+    const double sg2 = sg * sg;
+    const double r32 = sqrt(1.5);                   // (3/2)**0.5
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        const int y = (int)(p / w), x = (int)(p % w);
+        const f32x4 v = *(const f32x4*)(net_out + ((size_t)(y + pad_t) * Wp + x + pad_l) * 4);
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float yc = fminf(fmaxf(v[c], 0.0f), 1.0f);
+            if (mode == 0) { o[c] = yc; continue; }
+            const double z = (double)yc * span + lo;
+            double fz;
+            if (mode == 2) {
+                if (z > 0.0) {
+                    const double iz = 1.0 / z;
+                    fz = (z / 2) * (z / 2) + 0.25 * r32 * iz - 1.375 * (iz * iz) + 0.625 * r32 * (iz * iz * iz) - 0.125 - sg2;
+                } else fz = 0.0;
+            } else {
+                fz = (z / 2) * (z / 2) - 0.375 - sg2;
+            }
+            fz = fz > 0.0 ? fz : 0.0;
+            double r = fz * gain / scale;
+            if (clip01) r = r < 0.0 ? 0.0 : (r > 1.0 ? 1.0 : r);
+            o[c] = (float)r;
+        }
+        f32x2 r0 = {o[0], o[1]}, r1 = {o[2], o[3]};
+        *(f32x2*)(bayer + (size_t)(2 * y) * (2 * w) + 2 * x) = r0;
+        *(f32x2*)(bayer + (size_t)(2 * y + 1) * (2 * w) + 2 * x) = r1;
+    }
+}
+
+extern "C" int yond_denorm_ivst_unpack_f32(const float* net_out, int Hp, int Wp, int pad_t, int pad_l, int h, int w,
+                                           float* bayer_out, int mode, double scale, double gain, double sigma,
+                                           double lo, double hi, int clip01, void* stream) {
+    if (!net_out || !bayer_out || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0) return YOND_EINVAL;
+    if (pad_t + h > Hp || pad_l + w > Wp) return YOND_EINVAL;
+    if (mode < 0 || mode > 2) return YOND_EINVAL;
+    if (mode != 0 && (!(gain > 0.0) || !(scale > 0.0))) return YOND_EINVAL;
+    const size_t total = (size_t)h * w;
+    size_t nb = (total + 255) / 256;
+    if (nb > 256 * 16) nb = 256 * 16;
+    hipLaunchKernelGGL(denorm_ivst_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, net_out, Wp, pad_t,
+                       pad_l, h, w, bayer_out, mode, scale, gain, sigma, lo, hi, clip01);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// ---- bit-exact pack / unpack (utils/isp_ops.py:57-63) ----
+__global__ __launch_bounds__(256) void bayer2rggb_kernel(const float* __restrict__ bayer, int W, int w, size_t total,
+                                                         float* __restrict__ rggb) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        const size_t y = p / w, x = p % w;
+        const f32x2 r0 = *(const f32x2*)(bayer + (2 * y) * W + 2 * x);
+        const f32x2 r1 = *(const f32x2*)(bayer + (2 * y + 1) * W + 2 * x);
+        f32x4 o = {r0[0], r0[1], r1[0], r1[1]};
+        *(f32x4*)(rggb + p * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void rggb2bayer_kernel(const float* __restrict__ rggb, int w, size_t total,
+                                                         float* __restrict__ bayer) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        const size_t y = p / w, x = p % w;
+        const f32x4 v = *(const f32x4*)(rggb + p * 4);
+        f32x2 r0 = {v[0], v[1]}, r1 = {v[2], v[3]};
+        *(f32x2*)(bayer + (2 * y) * (2 * (size_t)w) + 2 * x) = r0;
+        *(f32x2*)(bayer + (2 * y + 1) * (2 * (size_t)w) + 2 * x) = r1;
+    }
+}
+
+static unsigned stream_grid(size_t total) {
+    size_t nb = (total + 255) / 256;
+    if (nb > 256 * 16) nb = 256 * 16;
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+extern "C" int yond_bayer2rggb_f32(const float* bayer, int H, int W, float* rggb, void* stream) {
+    if (!bayer || !rggb || H < 2 || W < 2 || (H & 1) || (W & 1)) return YOND_EINVAL;
+    const size_t total = (size_t)(H / 2) * (W / 2);
+    hipLaunchKernelGGL(bayer2rggb_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, bayer, W, W / 2, total, rggb);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_rggb2bayer_f32(const float* rggb, int h, int w, float* bayer, void* stream) {
+    if (!bayer || !rggb || h < 1 || w < 1) return YOND_EINVAL;
+    const size_t total = (size_t)h * w;
+    hipLaunchKernelGGL(rggb2bayer_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, rggb, w, total, bayer);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// ---- NCHW(4) <-> NHWC4 for the archs plugin surface ----
+__global__ __launch_bounds__(256) void nchw4_to_nhwc4_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             size_t hw, size_t total) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        const size_t n = p / hw, i = p % hw;
+        const float* s = src + n * 4 * hw + i;
+        f32x4 o = {s[0], s[hw], s[2 * hw], s[3 * hw]};
+        *(f32x4*)(dst + p * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc4_to_nchw4_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             size_t hw, size_t total) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        const size_t n = p / hw, i = p % hw;
+        const f32x4 v = *(const f32x4*)(src + p * 4);
+        float* d = dst + n * 4 * hw + i;
+        d[0] = v[0]; d[hw] = v[1]; d[2 * hw] = v[2]; d[3 * hw] = v[3];
+    }
+}
+
+extern "C" int yond_nchw4_to_nhwc4_f32(const float* src, float* dst, int N, int H, int W, void* stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0) return YOND_EINVAL;
+    const size_t hw = (size_t)H * W, total = hw * N;
+    hipLaunchKernelGGL(nchw4_to_nhwc4_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, hw, total);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_nhwc4_to_nchw4_f32(const float* src, float* dst, int N, int H, int W, void* stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0) return YOND_EINVAL;
+    const size_t hw = (size_t)H * W, total = hw * N;
+    hipLaunchKernelGGL(nhwc4_to_nchw4_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, hw, total);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// ---- per-image maximum, two deterministic stages (archs/modules.py:18-19) ----
+__global__ __launch_bounds__(256) void image_max_stage1(const float* __restrict__ x, size_t elems, float* __restrict__ partial) {
+    __shared__ float s_red[4];
+    const int n = blockIdx.y;
+    const float* p = x + (size_t)n * elems;
+    float m = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < elems; i += (size_t)gridDim.x * 256) m = fmaxf(m, p[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)n * gridDim.x + blockIdx.x] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+}
+
+__global__ __launch_bounds__(256) void image_max_stage2(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+    __shared__ float s_red[4];
+    const int n = blockIdx.x;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < nb; i += 256) m = fmaxf(m, partial[(size_t)n * nb + i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[n] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+}
+
+extern "C" int yond_image_max_f32(const float* x, int N, size_t elems, float* partial, float* out, void* stream) {
+    if (!x || !partial || !out || N <= 0 || N > 65535 || elems == 0) return YOND_EINVAL;
+    size_t nb = (elems + 256 * 16 - 1) / (256 * 16);
+    if (nb > 256) nb = 256;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(image_max_stage1, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, x, elems, partial);
+    YOND_LAUNCH_CHECK();
+    hipLaunchKernelGGL(image_max_stage2, dim3(N), dim3(256), 0, (hipStream_t)stream, partial, (int)nb, out);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_abi_version(void) { return 1; }

@@ -1,0 +1,326 @@
+"""Device-side execution plan of the AWGN raw denoisers (SNR-Net = GuidedResUnet, SNRnet,
+UNetSeeInDark) on the HIP kernels of libyond_hip.so.
+
+The reference runs these nets through torch.nn / cuDNN in NCHW (archs/Unet.py:55-104, 332-378,
+424-470).  Here a forward pass is a fixed sequence of launches of the fp32-MFMA implicit-GEMM
+kernels over NHWC float32 activations:
+
+    [data_normalize max] -> sigma-MLPs (one launch) -> conv_in -> 9 x (conv1, conv2) with fused
+    SiLU / FiLM / residual -> 4 stride-2 convs -> 4 x (convT as GEMM + pixel-shuffle store,
+    two-source 1x1 shortcut: torch.cat is never materialised) -> conv_out (+x, *ub)
+
+Weights are taken from the owning nn.Module's state_dict (reference key names / OIHW layout),
+zero-padded so every channel count is a multiple of 32, re-ordered once into the LDS image order
+of the kernels (`yond_pack_conv_weight_f32`) and cached on the device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _rup(c, m=32):
+    return (c + m - 1) // m * m
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class _PackedConv:
+    """One convolution's device-side constants."""
+
+    def __init__(self, dev, weight, bias, ksize, stride, splits, shuffle=False):
+        """weight: OIHW float32 CPU tensor (for shuffle: ConvTranspose2d weight [Cin][Cout][2][2]);
+        splits: real channel counts of the concatenated inputs (cin = sum)."""
+        lib = L.load()
+        w = weight.detach().to('cpu', torch.float32).numpy()
+        if shuffle:
+            cin, cout = w.shape[0], w.shape[1]
+            # GEMM-N index n = sp*Coutp + co, sp = 2*dy+dx  <-  W[ci][co][dy][dx]
+            coutp = _rup(cout)
+            m = np.zeros((4, coutp, cin), np.float32)
+            m[:, :cout, :] = w.transpose(2, 3, 1, 0).reshape(4, cout, cin)
+            w = m.reshape(4 * coutp, cin, 1, 1)
+            self.cout_real_p = coutp
+            gemm_n = 4 * coutp
+        else:
+            cout = w.shape[0]
+            coutp = _rup(cout)
+            gemm_n = coutp
+            self.cout_real_p = coutp
+        assert sum(splits) == w.shape[1], (splits, w.shape)
+        # pad every input split to a multiple of 32 (zero weights) and cout to a multiple of 32
+        psplits = [_rup(s) for s in splits]
+        cinp = sum(psplits)
+        wp = np.zeros((gemm_n, cinp, ksize, ksize), np.float32)
+        so, do = 0, 0
+        for s, ps in zip(splits, psplits):
+            wp[:w.shape[0], do:do + s] = w[:, so:so + s]
+            so += s
+            do += ps
+        tn, kc = C.c_int(), C.c_int()
+        L.check(lib.yond_conv_config(ksize, stride, cinp, gemm_n, int(shuffle), C.byref(tn), C.byref(kc)), "yond_conv_config")
+        packed = np.empty(wp.size, np.float32)
+        L.check(lib.yond_pack_conv_weight_f32(_np_ptr(np.ascontiguousarray(wp)), gemm_n, cinp, ksize, tn.value, kc.value,
+                                              _np_ptr(packed)), "yond_pack_conv_weight_f32")
+        self.wpk = torch.from_numpy(packed).to(dev)
+        b = torch.zeros(coutp, dtype=torch.float32)
+        if bias is not None:
+            b[:cout] = bias.detach().to('cpu', torch.float32)
+        self.bias = b.to(dev)
+        self.ksize, self.stride, self.shuffle = ksize, stride, shuffle
+        self.psplits, self.gemm_n, self.coutp = psplits, gemm_n, coutp
+
+
+class DenoiserPlan:
+    """Packs a module's parameters once and runs forwards on NHWC4 device tensors."""
+
+    def __init__(self, module, device):
+        self.lib = L.load()
+        self.dev = torch.device(device)
+        self.kind = type(module).__name__          # GuidedResUnet | SNRnet | UNetSeeInDark
+        self.res = bool(module.res)
+        self.norm = bool(module.norm)
+        sd = {k: v.detach() for k, v in module.state_dict().items()}
+        self.sd = sd
+        self.guided = self.kind in ('GuidedResUnet', 'SNRnet')
+        dev = self.dev
+        if self.guided:
+            nf = sd['conv_in.weight'].shape[0]
+            self.nf = nf
+            self.conv_in_w, self.conv_in_b = self._pack_conv_in(sd['conv_in.weight'], sd['conv_in.bias'])
+            self.blocks = {}
+            chans = [nf, nf * 2, nf * 4, nf * 8, nf * 16, nf * 8, nf * 4, nf * 2, nf]
+            film = []
+            for i, c in enumerate(chans, start=1):
+                pre = f'conv{i}'
+                blk = {'C': c, 'Cp': _rup(c)}
+                blk['conv1'] = _PackedConv(dev, sd[pre + '.conv1.weight'], None, 3, 1, [c])
+                blk['conv2'] = _PackedConv(dev, sd[pre + '.conv2.weight'], None, 3, 1, [c])
+                if i >= 6:
+                    blk['sc'] = _PackedConv(dev, sd[pre + '.short_cut.0.weight'], sd[pre + '.short_cut.0.bias'], 1, 1, [c, c])
+                    blk['up'] = _PackedConv(dev, sd[f'upv{i}.weight'], sd[f'upv{i}.bias'], 1, 1, [2 * c], shuffle=True)
+                if i <= 4:
+                    blk['pool'] = _PackedConv(dev, sd[f'pool{i}.conv.weight'], sd[f'pool{i}.conv.bias'], 3, 2, [c])
+                self.blocks[i] = blk
+                film.append((pre, c))
+            self._film_spec = film
+            self._film_cache = {}
+            self.w_out = self._pad_out_w(sd['conv10.weight'])
+            self.b_out = sd['conv10.bias'].to(dev, torch.float32).contiguous()
+            self._film_params = {k: v.to(dev, torch.float32).contiguous() for k, v in sd.items()
+                                 if any(s in k for s in ('.gamma.', '.beta.', '.sfm1.', '.sfm2.', '.conv1.bias', '.conv2.bias'))}
+        else:
+            nf = sd['conv1_1.weight'].shape[0]
+            self.nf = nf
+            self.conv_in_w, self.conv_in_b = self._pack_conv_in(sd['conv1_1.weight'], sd['conv1_1.bias'])
+            self.convs = {}
+            c = nf
+            self.convs['conv1_2'] = _PackedConv(dev, sd['conv1_2.weight'], sd['conv1_2.bias'], 3, 1, [c])
+            for i in range(2, 6):
+                self.convs[f'conv{i}_1'] = _PackedConv(dev, sd[f'conv{i}_1.weight'], sd[f'conv{i}_1.bias'], 3, 1, [c])
+                c *= 2
+                self.convs[f'conv{i}_2'] = _PackedConv(dev, sd[f'conv{i}_2.weight'], sd[f'conv{i}_2.bias'], 3, 1, [c])
+            for i in range(6, 10):
+                self.convs[f'upv{i}'] = _PackedConv(dev, sd[f'upv{i}.weight'], sd[f'upv{i}.bias'], 1, 1, [c], shuffle=True)
+                c //= 2
+                self.convs[f'conv{i}_1'] = _PackedConv(dev, sd[f'conv{i}_1.weight'], sd[f'conv{i}_1.bias'], 3, 1, [c, c])
+                self.convs[f'conv{i}_2'] = _PackedConv(dev, sd[f'conv{i}_2.weight'], sd[f'conv{i}_2.bias'], 3, 1, [c])
+            self.w_out = self._pad_out_w(sd['conv10_1.weight'])
+            self.b_out = sd['conv10_1.bias'].to(dev, torch.float32).contiguous()
+
+    # -- packing helpers -------------------------------------------------------------------
+    def _pack_conv_in(self, w, b):
+        w = w.detach().to('cpu', torch.float32).numpy()
+        cout = w.shape[0]
+        if w.shape[1] != 4:
+            raise L.YondHipError(f"first layer must have 4 input channels (packed Bayer), got {w.shape[1]}")
+        coutp = _rup(cout)
+        wp = np.zeros((coutp, 4, 3, 3), np.float32)
+        wp[:cout] = w
+        packed = np.empty(coutp * 40, np.float32)
+        L.check(self.lib.yond_pack_conv_in_weight_f32(_np_ptr(wp), coutp, _np_ptr(packed)), "yond_pack_conv_in_weight_f32")
+        bp = torch.zeros(coutp, dtype=torch.float32)
+        bp[:cout] = b.detach().to('cpu', torch.float32)
+        return torch.from_numpy(packed).to(self.dev), bp.to(self.dev)
+
+    def _pad_out_w(self, w):
+        w = w.detach().to('cpu', torch.float32).reshape(w.shape[0], -1)
+        if w.shape[0] != 4:
+            raise L.YondHipError(f"last layer must have 4 output channels, got {w.shape[0]}")
+        wp = torch.zeros(4, _rup(w.shape[1]), dtype=torch.float32)
+        wp[:, :w.shape[1]] = w
+        return wp.to(self.dev).contiguous()
+
+    # -- launches ----------------------------------------------------------------------------
+    def _conv(self, pc, src0, src1, N, H, W, dst, escale=None, eshift=None, ebatch=0, res=None, pre_act=0, post_act=0,
+              slope=0.0):
+        d = L.YondConvDesc()
+        d.src0 = src0.data_ptr()
+        d.src1 = src1.data_ptr() if src1 is not None else None
+        d.C0 = pc.psplits[0]
+        d.C1 = pc.psplits[1] if len(pc.psplits) > 1 else 0
+        d.N, d.H, d.W = N, H, W
+        if pc.stride == 2:
+            d.Ho, d.Wo = (H + 1) // 2, (W + 1) // 2
+        else:
+            d.Ho, d.Wo = H, W
+        d.Cout = pc.gemm_n
+        d.ksize, d.stride, d.shuffle = pc.ksize, pc.stride, int(pc.shuffle)
+        d.pre_act, d.post_act, d.slope = pre_act, post_act, slope
+        d.wpk = pc.wpk.data_ptr()
+        d.escale = escale.data_ptr() if escale is not None else None
+        d.eshift = (eshift if eshift is not None else pc.bias).data_ptr()
+        d.ebatch = ebatch
+        d.res = res.data_ptr() if res is not None else None
+        d.dst = dst.data_ptr()
+        L.check(self.lib.yond_conv2d_f32(C.byref(d), L.stream()), "yond_conv2d_f32")
+        return dst
+
+    def _film(self, t_dev, ub, N):
+        """All nine blocks' (scale, shift) epilogue vectors in one launch."""
+        key = N
+        if key not in self._film_cache:
+            fp = self._film_params
+            outs, descs = {}, (L.YondFilmDesc * len(self._film_spec))()
+            for bi, (pre, c) in enumerate(self._film_spec):
+                cp = _rup(c)
+                o = torch.zeros(4, N, cp, dtype=torch.float32, device=self.dev)
+                outs[pre] = o
+                d = descs[bi]
+                d.C, d.ld = c, cp
+                if self.kind == 'GuidedResUnet':
+                    d.kind = 0
+                    d.w_a0, d.b_a0 = fp[pre + '.gamma.0.weight'].data_ptr(), fp[pre + '.gamma.0.bias'].data_ptr()
+                    d.w_a2, d.b_a2 = fp[pre + '.gamma.2.weight'].data_ptr(), fp[pre + '.gamma.2.bias'].data_ptr()
+                    d.w_b0 = d.b_b0 = None
+                    d.w_b, d.b_b = fp[pre + '.beta.1.weight'].data_ptr(), fp[pre + '.beta.1.bias'].data_ptr()
+                else:
+                    d.kind = 1
+                    d.w_a0, d.b_a0 = fp[pre + '.sfm1.0.weight'].data_ptr(), fp[pre + '.sfm1.0.bias'].data_ptr()
+                    d.w_a2, d.b_a2 = fp[pre + '.sfm1.2.weight'].data_ptr(), fp[pre + '.sfm1.2.bias'].data_ptr()
+                    d.w_b0, d.b_b0 = fp[pre + '.sfm2.0.weight'].data_ptr(), fp[pre + '.sfm2.0.bias'].data_ptr()
+                    d.w_b, d.b_b = fp[pre + '.sfm2.2.weight'].data_ptr(), fp[pre + '.sfm2.2.bias'].data_ptr()
+                d.cb1, d.cb2 = fp[pre + '.conv1.bias'].data_ptr(), fp[pre + '.conv2.bias'].data_ptr()
+                d.s1, d.t1, d.s2, d.t2 = (o[j].data_ptr() for j in range(4))
+            raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
+            self._film_cache[key] = (outs, raw, len(self._film_spec))
+        outs, raw, nb = self._film_cache[key]
+        L.check(self.lib.yond_film_f32(L.ptr(raw), nb, L.ptr(t_dev), L.ptr(ub), N, L.stream()), "yond_film_f32")
+        return outs
+
+    def image_max(self, x4, N):
+        elems = x4.numel() // N
+        partial = torch.empty(N * 256, dtype=torch.float32, device=self.dev)
+        ub = torch.empty(N, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.yond_image_max_f32(L.ptr(x4), N, elems, L.ptr(partial), L.ptr(ub), L.stream()), "yond_image_max_f32")
+        return ub
+
+    def _new(self, N, H, W, Cc):
+        return torch.empty((N, H, W, Cc), dtype=torch.float32, device=self.dev)
+
+    def forward_nhwc4(self, x4, t_dev=None, ub=None):
+        """x4: [N][H][W][4] float32 device tensor (H, W multiples of 16); t_dev: [N] float32 (guided
+        nets); ub: optional precomputed per-image maximum [N] (K1 provides it).  Returns [N][H][W][4]."""
+        L.require_cuda(x4, "x")
+        N, H, W, c4 = x4.shape
+        if c4 != 4 or H % 16 or W % 16:
+            raise L.YondHipError(f"input must be [N][H][W][4] with H, W multiples of 16, got {tuple(x4.shape)}")
+        if self.norm and ub is None:
+            ub = self.image_max(x4, N)
+        if not self.norm:
+            ub = None
+        st = L.stream()
+        lib = self.lib
+        nfp = _rup(self.nf)
+        if self.guided:
+            if t_dev is None:
+                raise L.YondHipError(f"{self.kind}.forward needs the noise level t")
+            film = self._film(t_dev, ub, N)
+            a = self._new(N, H, W, nfp)
+            L.check(lib.yond_conv_in_f32(L.ptr(x4), L.ptr(ub), N, H, W, nfp, L.ptr(self.conv_in_w), L.ptr(self.conv_in_b),
+                                         0.01, L.ptr(a), st), "yond_conv_in_f32")
+            skips = {}
+            h, w = H, W
+            cur = a
+            for i in range(1, 10):
+                blk = self.blocks[i]
+                cp = blk['Cp']
+                f = film[f'conv{i}']
+                if i >= 6:
+                    # ConvT 2x2 s2 (GEMM + pixel shuffle), then the block's 1x1 shortcut over [up, skip]
+                    up = self._new(N, 2 * h, 2 * w, cp)
+                    self._conv(blk['up'], cur, None, N, h, w, up)
+                    h, w = 2 * h, 2 * w
+                    xs = self._new(N, h, w, cp)
+                    self._conv(blk['sc'], up, skips[10 - i], N, h, w, xs)
+                    cur = xs
+                tmp = self._new(N, h, w, cp)
+                self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1, post_act=1)
+                out = self._new(N, h, w, cp)
+                self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur)
+                cur = out
+                if i <= 4:
+                    skips[i] = cur
+                    nxt = self._new(N, h // 2, w // 2, blk['pool'].coutp)
+                    self._conv(blk['pool'], cur, None, N, h, w, nxt)
+                    h, w = h // 2, w // 2
+                    cur = nxt
+            feat = cur
+        else:
+            a = self._new(N, H, W, nfp)
+            L.check(lib.yond_conv_in_f32(L.ptr(x4), L.ptr(ub), N, H, W, nfp, L.ptr(self.conv_in_w), L.ptr(self.conv_in_b),
+                                         0.2, L.ptr(a), st), "yond_conv_in_f32")
+            cv = self.convs
+            h, w = H, W
+            cur = self._conv(cv['conv1_2'], a, None, N, h, w, self._new(N, h, w, cv['conv1_2'].coutp), post_act=2, slope=0.2)
+            skips = {1: cur}
+            for i in range(2, 6):
+                cpv = cur.shape[-1]
+                pooled = self._new(N, h // 2, w // 2, cpv)
+                L.check(lib.yond_maxpool2_f32(L.ptr(cur), N, h, w, cpv, L.ptr(pooled), st), "yond_maxpool2_f32")
+                h, w = h // 2, w // 2
+                c1 = cv[f'conv{i}_1']
+                cur = self._conv(c1, pooled, None, N, h, w, self._new(N, h, w, c1.coutp), post_act=2, slope=0.2)
+                c2 = cv[f'conv{i}_2']
+                cur = self._conv(c2, cur, None, N, h, w, self._new(N, h, w, c2.coutp), post_act=2, slope=0.2)
+                if i < 5:
+                    skips[i] = cur
+            for i in range(6, 10):
+                upc = cv[f'upv{i}']
+                up = self._new(N, 2 * h, 2 * w, upc.cout_real_p)
+                self._conv(upc, cur, None, N, h, w, up)
+                h, w = 2 * h, 2 * w
+                c1 = cv[f'conv{i}_1']
+                cur = self._conv(c1, up, skips[10 - i], N, h, w, self._new(N, h, w, c1.coutp), post_act=2, slope=0.2)
+                c2 = cv[f'conv{i}_2']
+                cur = self._conv(c2, cur, None, N, h, w, self._new(N, h, w, c2.coutp), post_act=2, slope=0.2)
+            feat = cur
+        out4 = self._new(N, H, W, 4)
+        L.check(lib.yond_conv_out_f32(L.ptr(feat), feat.shape[-1], L.ptr(self.w_out), L.ptr(self.b_out),
+                                      L.ptr(x4) if self.res else None, L.ptr(ub), N, H, W, L.ptr(out4), st), "yond_conv_out_f32")
+        return out4
+
+    def forward_nchw(self, x, t=None):
+        """Plugin-surface call: x [N][4][H][W] -> [N][4][H][W]."""
+        L.require_cuda(x, "x")
+        N, c, H, W = x.shape
+        if c != 4:
+            raise L.YondHipError(f"expected 4 input channels, got {c}")
+        x4 = torch.empty((N, H, W, 4), dtype=torch.float32, device=x.device)
+        L.check(self.lib.yond_nchw4_to_nhwc4_f32(L.ptr(x), L.ptr(x4), N, H, W, L.stream()), "yond_nchw4_to_nhwc4_f32")
+        t_dev = None
+        if self.guided:
+            t_dev = torch.as_tensor(t, dtype=torch.float32, device=x.device).reshape(-1)
+            if t_dev.numel() == 1 and N > 1:
+                t_dev = t_dev.expand(N)
+            if t_dev.numel() != N:
+                raise L.YondHipError(f"t must have 1 or {N} elements, got {t_dev.numel()}")
+            t_dev = t_dev.contiguous()
+        y4 = self.forward_nhwc4(x4, t_dev)
+        y = torch.empty_like(x)
+        L.check(self.lib.yond_nhwc4_to_nchw4_f32(L.ptr(y4), L.ptr(y), N, H, W, L.stream()), "yond_nhwc4_to_nchw4_f32")
+        return y

@@ -1,0 +1,405 @@
+"""Device-side counterparts of the reference's per-image pipeline functions, same names and argument
+meaning, running on the HIP kernels (no CPU compute path):
+
+    SimpleNLF / SelfNLF / CollabNLF / get_threshold   YOND_SIDD.py:13-124
+    get_bias (LUT object)                              utils/isp_algos.py:98-140
+    VST_Denoiser / Simple_Denoiser                     YOND_SIDD.py:238-299
+    IterDenoise                                        YOND_SIDD.py:301-483 (est_type 'simple' pipelines)
+
+Images are float32 torch tensors on a ROCm device (NumPy arrays are uploaded).  Host code here is only
+control flow and O(20)-element arithmetic (threshold score, 2x2 normal equations, LUT knot grid); every
+pass over pixels is a kernel launch through the C ABI of libyond_hip.so.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+NBINS = 1024
+
+
+def _dev(x, device=None):
+    if isinstance(x, torch.Tensor):
+        if not x.is_cuda:
+            if device is None:
+                raise L.YondHipError("CPU tensor given and no device specified; the HIP path has no CPU fallback")
+            x = x.to(device)
+        return x.contiguous().float()
+    dev = torch.device(device if device is not None else 'cuda')
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------
+# pack / unpack (utils/isp_ops.py:57-63)
+# ------------------------------------------------------------------------------------------------
+def bayer2rggb(bayer, device=None):
+    b = _dev(bayer, device)
+    H, W = b.shape
+    out = torch.empty((H // 2, W // 2, 4), dtype=torch.float32, device=b.device)
+    L.check(L.load().yond_bayer2rggb_f32(L.ptr(b), H, W, L.ptr(out), L.stream()), "yond_bayer2rggb_f32")
+    return out
+
+
+def rggb2bayer(rggb, device=None):
+    r = _dev(rggb, device)
+    h, w, c = r.shape
+    if c != 4:
+        raise L.YondHipError("rggb2bayer expects (h, w, 4)")
+    out = torch.empty((2 * h, 2 * w), dtype=torch.float32, device=r.device)
+    L.check(L.load().yond_rggb2bayer_f32(L.ptr(r), h, w, L.ptr(out), L.stream()), "yond_rggb2bayer_f32")
+    return out
+
+
+def get_p2d(shape, base=16):
+    """utils/utils.py:246-252."""
+    xb, xc, xh, xw = shape
+    yh, yw = ((xh - 1) // base + 1) * base, ((xw - 1) // base + 1) * base
+    dY, dX = yh - xh, yw - xw
+    return (dX // 2, dX - dX // 2, dY // 2, dY - dY // 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# scalar VST helpers (host float64; the per-pixel transforms are fused into K1 / K4)
+# ------------------------------------------------------------------------------------------------
+def vst_scalar(x, sigma, gain):
+    """utils/isp_algos.py:5-14 for a scalar x (the reference evaluates lower = VST(0), upper = VST(scale))."""
+    fz = np.float64(gain) * x + (3 / 8) * np.float64(gain) ** 2 + np.float64(sigma) ** 2
+    fz = np.maximum(fz, 0)
+    return 2 / np.float64(gain) * fz ** 0.5
+
+
+# ------------------------------------------------------------------------------------------------
+# bias LUT (utils/isp_algos.py:98-140): knot grid on the host, expectation integrals on the device
+# ------------------------------------------------------------------------------------------------
+def _bias_knots(ub):
+    """utils/isp_algos.py:101-108 (same np.linspace calls, so the knots are bit-identical)."""
+    lb = 0
+    if ub < 50:
+        return np.linspace(lb, ub, int((ub - lb) / 0.1) + 2)
+    elif ub < 500:
+        return np.concatenate((np.linspace(lb, 50, int((50 - lb) / 0.1) + 1), np.linspace(50, ub, int(ub - 50) + 2)))
+    return np.concatenate((np.linspace(lb, 50, int((50 - lb) / 0.1) + 1), np.linspace(50, 500, 451),
+                           np.linspace(500, ub, int(ub - 500) // 10 + 2)))
+
+
+class DeviceBiasLUT:
+    """What `get_bias` returns: the interp1d knots, resident on the device.  K1 evaluates it per pixel."""
+
+    def __init__(self, lams, x_dev, y_dev):
+        self.lams = lams
+        self.x = x_dev          # float64 [n]
+        self.y = y_dev          # float32 [n]
+
+    def __len__(self):
+        return int(self.x.numel())
+
+    def __call__(self, *a, **k):
+        raise L.YondHipError("the bias LUT is evaluated per pixel inside yond_pack_vst_norm_f32 (VST_Denoiser); "
+                             "use .x / .y for the knots")
+
+
+def get_bias(img=None, sigGs=25.853043, K=24.48128, device=None):
+    """utils/isp_algos.py:98-140 (close_form=True, clip=False, pho_min=1).  `img`: anything with .max()
+    or a scalar upper bound (the reference only uses img.max())."""
+    if isinstance(img, torch.Tensor):
+        device = img.device if img.is_cuda else device
+        mx = np.float32(img.max().item())
+    else:
+        mx = np.max(img)
+    ub = np.ceil(mx) + 1
+    lams = _bias_knots(ub)
+    dev = torch.device(device if device is not None else 'cuda')
+    x_dev = torch.from_numpy(np.ascontiguousarray(lams, dtype=np.float64)).to(dev)
+    y_dev = torch.empty(len(lams), dtype=torch.float32, device=dev)
+    if len(lams) > 4096:
+        raise L.YondHipError(f"bias LUT with {len(lams)} knots exceeds the kernel's 4096-knot LDS table")
+    L.check(L.load().yond_bias_lut_f64(L.ptr(x_dev), len(lams), float(K), float(sigGs), L.ptr(y_dev), L.stream()),
+            "yond_bias_lut_f64")
+    return DeviceBiasLUT(lams, x_dev, y_dev)
+
+
+# ------------------------------------------------------------------------------------------------
+# noise-level estimation
+# ------------------------------------------------------------------------------------------------
+def _percentiles(data_flat, quants):
+    lib = L.load()
+    n = data_flat.numel()
+    q = np.ascontiguousarray(quants, dtype=np.float64)
+    ws = torch.empty(int(lib.yond_select_ws_bytes(2 * len(q))), dtype=torch.uint8, device=data_flat.device)
+    out = torch.empty(len(q), dtype=torch.float64, device=data_flat.device)
+    L.check(lib.yond_percentiles_f32(L.ptr(data_flat), n, C.c_void_p(q.ctypes.data), len(q), L.ptr(out), L.ptr(ws), L.stream()),
+            "yond_percentiles_f32")
+    return out
+
+
+def _accumulate(lap, mean, var, ths_dev):
+    lib = L.load()
+    nt = ths_dev.numel()
+    occ = torch.empty((nt, NBINS), dtype=torch.int32, device=lap.device)
+    mom = torch.empty((nt + 1, 2, 5), dtype=torch.float64, device=lap.device)
+    ws = torch.empty(64, dtype=torch.uint8, device=lap.device)
+    L.check(lib.yond_nlf_accumulate_f32(L.ptr(lap), L.ptr(mean), L.ptr(var), lap.numel(), L.ptr(ths_dev), nt, L.ptr(occ),
+                                        L.ptr(mom), L.ptr(ws), L.stream()), "yond_nlf_accumulate_f32")
+    return occ, mom
+
+
+def _fit_from_moments(m_all, m_ns):
+    """utils/isp_algos.py:345-365 on moment sums {n, Sm, Sv, Smm, Smv}: keep the non-saturated set if it
+    holds more than 1 % of the points (:349), then the 2x2 normal equations of [m, 1].[b1, b2] = v."""
+    use = m_ns if m_ns[0] > 0.01 * m_all[0] else m_all
+    n, sx, sy, sxx, sxy = (float(v) for v in use)
+    det = n * sxx - sx * sx
+    return np.array([(n * sxy - sx * sy) / det, (sxx * sy - sx * sxy) / det])
+
+
+def get_threshold(data, step=5, mode='score3', print_log=False, scale=1023 - 64, _full=False):
+    """YOND_SIDD.py:13-52, mode 'score3': data = (img_lap, mean) device maps (any shape, same numel).
+    Returns (th, percent) like the reference; `_full` adds the internals (used by SimpleNLF)."""
+    if mode != 'score3':
+        raise NotImplementedError(mode)
+    lap, mean = data
+    lap, mean = lap.reshape(-1), mean.reshape(-1)
+    quants = np.linspace(step, 100, 100 // step, endpoint=True)
+    ths_dev = _percentiles(lap, quants)
+    var_dummy = mean
+    occ, mom = _accumulate(lap, mean, var_dummy, ths_dev)
+    ths = ths_dev.cpu().numpy()
+    th, pct, info = _score3(ths, quants, occ.cpu().numpy())
+    if _full:
+        return th, pct, info
+    return th, pct
+
+
+def _score3(ths, quants, occ):
+    seen = np.logical_or.accumulate(occ.astype(bool), axis=0)
+    npeaks = seen.sum(axis=1).astype(np.float64)                 # YOND_SIDD.py:37-43
+    score = ths / (quants * npeaks)                              # :45
+    i = int(np.argmin(score[1:]) + 1)                            # :46-47
+    return ths[i], quants[i], dict(ths=ths, npeaks=npeaks, score=score, index=i)
+
+
+def _nlf_from_maps(lap, mean, var, full=False):
+    """Shared tail of SelfNLF / CollabNLF (YOND_SIDD.py:75-87 / 103-115)."""
+    lap, mean, var = lap.reshape(-1), mean.reshape(-1), var.reshape(-1)
+    quants = np.linspace(5, 100, 20, endpoint=True)
+    ths_dev = _percentiles(lap, quants)
+    occ, mom = _accumulate(lap, mean, var, ths_dev)
+    ths = ths_dev.cpu().numpy()                                  # one sync for the three small results
+    occ_h, mom_h = occ.cpu().numpy(), mom.cpu().numpy()
+    th, pct, info = _score3(ths, quants, occ_h)
+    i = info['index']
+    sel = mom_h[:i + 1].sum(axis=0)                              # pixels with lap < ths[i]
+    if sel[0, 0] > 0:
+        reg = _fit_from_moments(sel[0], sel[1])
+    else:                                                        # :79-84 'no flat area'
+        th_b = _percentiles(lap, [25.0])
+        th_backup = float(th_b.cpu().numpy()[0])
+        if th != th_backup:
+            th = th_backup
+            occ2, mom2 = _accumulate(lap, mean, var, th_b)
+            sel = mom2.cpu().numpy()[0]
+        else:
+            sel = mom_h.sum(axis=0)
+        reg = _fit_from_moments(sel[0], sel[1])
+    if full:
+        info.update(th=th, percent=pct, nsel=int(sel[0, 0]))
+        return reg, info
+    return reg
+
+
+def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None):
+    """YOND_SIDD.py:117-124 (+ SelfNLF :62-87, CollabNLF :89-115): Bayer frame(s) -> (beta1, beta2)."""
+    setting = setting or {'mode': 'self'}
+    lib = L.load()
+    lr = _dev(lr_raw, device)
+    H, W = lr.shape
+    h, w = H // 2, W // 2
+    tile_w = w // 32 if setting.get('SIDD_256', False) else 0
+    if tile_w and w % 32:
+        raise L.YondHipError("SIDD_256 needs a packed width that splits into 32 tiles")
+    new = lambda: torch.empty((4, h, w), dtype=torch.float32, device=lr.device)
+    mean, var, lap = new(), new(), new()
+    st = L.stream()
+    if setting['mode'] == 'self':
+        blur2 = new()
+        k2 = k // 3 * 2 + 1
+        L.check(lib.yond_box_stats_self1_f32(L.ptr(lr), H, W, k, k2, tile_w, L.ptr(mean), L.ptr(var), L.ptr(blur2), st),
+                "yond_box_stats_self1_f32")
+        L.check(lib.yond_box_stats_self2_f32(L.ptr(blur2), h, w, k, tile_w, L.ptr(lap), st), "yond_box_stats_self2_f32")
+    elif setting['mode'] == 'collab':
+        hr = _dev(hr_raw, lr.device)
+        if hr.shape != lr.shape:
+            raise L.YondHipError("collab NLF needs noisy and denoised frames of the same shape")
+        L.check(lib.yond_box_stats_collab_f32(L.ptr(lr), L.ptr(hr), H, W, k, tile_w, L.ptr(mean), L.ptr(var), L.ptr(lap), st),
+                "yond_box_stats_collab_f32")
+    else:
+        raise NotImplementedError(setting['mode'])
+    return _nlf_from_maps(lap, mean, var, full)
+
+
+# ------------------------------------------------------------------------------------------------
+# VST -> denoiser -> inverse VST  (YOND_SIDD.py:238-299)
+# ------------------------------------------------------------------------------------------------
+def _plan_of(net, device):
+    mod = net.module if hasattr(net, 'module') else net           # nn.DataParallel wrapper
+    if not hasattr(mod, '_get_plan'):
+        raise L.YondHipError(f"{type(mod).__name__} is not a yond_public_amd.archs denoiser")
+    return mod._get_plan(device)
+
+
+def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type='exact', clip01=False, device=None):
+    """YOND_SIDD.py:250-299 for the network denoisers.  lr_raw: Bayer [H][W]; p: dict with scale, gain,
+    sigma; returns the denoised Bayer frame (device tensor).  `clip01` folds the caller's .clip(0,1)."""
+    lib = L.load()
+    lr = _dev(lr_raw, device)
+    H, W = lr.shape
+    h, w = H // 2, W // 2
+    scale, gain, sigma = float(p['scale']), np.float64(p['gain']), np.float64(p['sigma'])
+    if bias_corr not in (None, 'pre'):
+        raise NotImplementedError(f"bias_corr={bias_corr!r} (the reference's 'post' branch is commented out)")
+    if bias_corr is not None and bias_func is None:
+        mx = np.float32(lr.max().item()) * np.float32(scale)      # lr_rggb.max() of the float32 product
+        bias_func = get_bias(mx, sigma, gain, device=lr.device)
+    lower, upper = vst_scalar(0, sigma, gain), vst_scalar(scale, sigma, gain)
+    nsr = 1 / (upper - lower)
+    p2d = get_p2d((1, 4, h, w), base=32)
+    Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
+    x4 = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=lr.device)
+    img_max = torch.empty(1, dtype=torch.float32, device=lr.device)
+    st = L.stream()
+    lut_n = len(bias_func) if bias_corr is not None else 0
+    L.check(lib.yond_pack_vst_norm_f32(L.ptr(lr), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], 1, scale, float(gain),
+                                       float(sigma), float(lower), float(upper),
+                                       L.ptr(bias_func.x) if lut_n else None, L.ptr(bias_func.y) if lut_n else None, lut_n,
+                                       L.ptr(img_max), st), "yond_pack_vst_norm_f32")
+    plan = _plan_of(net, lr.device)
+    t_dev = None
+    if 'guided' in arch:
+        sigma_corr = 1.03 if bias_corr == 'pre' else 1.00
+        t_dev = torch.full((1,), float(np.float32(nsr * sigma_corr)), dtype=torch.float32, device=lr.device)
+    y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
+    out = torch.empty((H, W), dtype=torch.float32, device=lr.device)
+    exact_inverse = bias_corr is None and vst_type == 'exact'
+    L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 2 if exact_inverse else 1,
+                                            scale, float(gain), float(sigma), float(lower), float(upper), int(clip01), st),
+            "yond_denorm_ivst_unpack_f32")
+    return out
+
+
+def Simple_Denoiser(lr_raw, net, device=None):
+    """YOND_SIDD.py:238-248: pack, reflect-pad, clamp, net(x), clamp, crop, unpack (no VST)."""
+    lib = L.load()
+    lr = _dev(lr_raw, device)
+    H, W = lr.shape
+    h, w = H // 2, W // 2
+    p2d = get_p2d((1, 4, h, w), base=32)
+    Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
+    x4 = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=lr.device)
+    img_max = torch.empty(1, dtype=torch.float32, device=lr.device)
+    st = L.stream()
+    L.check(lib.yond_pack_vst_norm_f32(L.ptr(lr), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], 0, 1.0, 1.0, 0.0, 0.0, 1.0,
+                                       None, None, 0, L.ptr(img_max), st), "yond_pack_vst_norm_f32")
+    plan = _plan_of(net, lr.device)
+    if plan.guided:
+        raise L.YondHipError("Simple_Denoiser calls net(x) without a noise level (YOND_SIDD.py:244)")
+    y4 = plan.forward_nhwc4(x4, None, ub=img_max)
+    out = torch.empty((H, W), dtype=torch.float32, device=lr.device)
+    L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 0, 1.0, 1.0, 0.0, 0.0, 1.0, 0, st),
+            "yond_denorm_ivst_unpack_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# IterDenoise (YOND_SIDD.py:301-483)
+# ------------------------------------------------------------------------------------------------
+def default_params():
+    """YOND_SIDD.py:503-505."""
+    p = {'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0}
+    p['scale'] = (p['wp'] - p['bl']) / p['ratio']
+    return p
+
+
+def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=None):
+    """Round 1: self-calibrated NLE -> VST -> denoise -> inverse VST; round 2 (pipe['iter']=='iter'):
+    collaborative NLE from (noisy, denoised) -> guards -> second pass.  lr_raw: Bayer [H][W] when
+    pipe['full_dn'], else the SIDD layout [32][256][256].  Returns dict(raw_dns, regs, params) with
+    device tensors in raw_dns (each [H][W], for SIDD the 256 x 8192 concatenation as in the reference)."""
+    p = dict(p or default_params())
+    k = pipe.get('k', 29)
+    bias_corr = pipe.get('bias_corr', 'pre')
+    if bias_corr == 'none':
+        bias_corr = None
+    full_dn = bool(pipe.get('full_dn', False))
+    sidd = not full_dn
+    vst_type = pipe.get('vst_type', 'exact')
+    scale = p['wp'] - p['bl']
+    regs, params = [], []
+    lr = _dev(lr_raw, device)
+    if sidd:
+        if lr.dim() != 3 or lr.shape[0] != 32:
+            raise L.YondHipError("SIDD layout expects [32][256][256] blocks")
+        lr_cat = torch.cat(list(lr), dim=-1).contiguous()                              # :314
+        blocks = lr
+    else:
+        lr_cat = lr
+    raw4est = lr_cat if lr_full is None else _dev(lr_full, lr.device)                  # :340
+    reg = SimpleNLF(raw4est, k=k, setting={'mode': 'self'})                            # :341
+    p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale            # :356
+    if log:
+        log(f"Self Est: K={p['gain']:.4f}, b={p['sigma']:.4f} (beta1={reg[0]:.3e}, beta2={reg[1]:.3e})")
+    regs.append(reg)
+    params.append((p['gain'], p['sigma']))
+    lr_max = np.float32(lr_cat.max().item())
+
+    def denoise_all(bias_func):
+        if full_dn:                                                                    # :387-389
+            return VST_Denoiser(lr_cat, p, net, arch, bias_corr, bias_func, vst_type, clip01=True)
+        outs = [VST_Denoiser(blocks[num], p, net, arch, bias_corr, bias_func, vst_type, clip01=True) for num in range(32)]
+        return torch.cat(outs, dim=-1).contiguous()                                    # :398-408
+
+    bias_func = None
+    if sidd and bias_corr is not None:
+        bias_func = get_bias(lr_max * scale, p['sigma'], p['gain'], device=lr.device)  # :393-395
+    raw_dn = denoise_all(bias_func)
+    raw_dns = [raw_dn]
+
+    if pipe.get('iter', 'iter') == 'iter':
+        for epoch in range(1, pipe.get('max_iter', 1) + 1):
+            reg = SimpleNLF(lr_cat, raw_dn, k=k,
+                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd))})   # :431
+            if reg[1] < 0:                                                             # :438-440
+                reg = (reg[0], reg[0] ** 2)
+            p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(reg[1]) * scale            # :442
+            if log:
+                log(f"Iter {epoch} Est: K={p['gain']:.4f}, sigma={p['sigma']:.4f} (beta1={reg[0]:.3e}, beta2={reg[1]:.3e})")
+            if reg[0] < 0:                                                             # :445-447
+                break
+            bias_func = get_bias(lr_max * scale, p['sigma'], p['gain'], device=lr.device)   # :450-452
+            raw_dn = denoise_all(bias_func)
+            raw_dns.append(raw_dn)
+            regs.append(reg)
+            params.append((p['gain'], p['sigma']))
+    return dict(raw_dns=raw_dns, regs=regs, params=params)
+
+
+# ------------------------------------------------------------------------------------------------
+# metrics (YOND_SIDD.py:649-652, 679-697)
+# ------------------------------------------------------------------------------------------------
+def block_metrics(dn, hr, bh=256, bw=256):
+    """Per-block PSNR (data_range 1) and SSIM (x255, 11x11 Gaussian, valid) -> two float64 arrays."""
+    lib = L.load()
+    dn, hr = _dev(dn), _dev(hr, dn.device if isinstance(dn, torch.Tensor) else None)
+    H, W = dn.shape
+    nblk = (H // bh) * (W // bw)
+    nt = lib.yond_block_metrics_tiles(bh, bw)
+    out = torch.empty((nblk, nt, 2), dtype=torch.float64, device=dn.device)
+    L.check(lib.yond_block_metrics_f32(L.ptr(dn), L.ptr(hr), H, W, bh, bw, L.ptr(out), L.stream()), "yond_block_metrics_f32")
+    s = out.sum(dim=1).cpu().numpy()
+    mse = s[:, 0] / (bh * bw)
+    with np.errstate(divide='ignore'):
+        psnr = 10 * np.log10(1.0 / mse)
+    ssim = s[:, 1] / ((bh - 10) * (bw - 10))
+    return psnr, ssim

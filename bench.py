@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""bench.py -- YOND hot path on MI355X: Bayer megapixels/s end-to-end (NLE + VST + denoise + iVST).
+
+    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+
+A step is one pass of the whole per-image path over one synthetic 3000 x 4000 Bayer frame that is already
+resident in HBM (BASELINE.json configs[1]): self-calibrated noise-level estimation, bias-LUT build,
+pack+VST, SNR-Net (GuidedResUnet nf=32, fp32 MFMA) forward, inverse VST+unpack.  Frames are sharded one
+per GPU (image parallel, weak scaling); there is no data-path collective, the only RCCL traffic is the
+barrier / max-over-ranks of the timing and the final PSNR reduction.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from yond_public_amd import distributed as D          # noqa: E402
+from yond_public_amd import pipeline as P             # noqa: E402
+from yond_public_amd import synthetic as S            # noqa: E402
+from yond_public_amd import archs as A                # noqa: E402
+from yond_public_amd import _lib as L                 # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+PEAK_HBM_GBPS = 8000.0
+
+ARCHS = {
+    'GuidedResUnet': dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+    'UNetSeeInDark': dict(name='UNetSeeInDark', in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+}
+
+
+def cpu_baseline(arch, mode, seed, threads):
+    """The oracle (CPU restatement of the reference path) timed on the host, on a bounded sample of the
+    same workload.  Test infrastructure used ONLY as the reported baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import yond_oracle as O
+    H, W = 768, 1024
+    noisy, _ = O.synth_noisy(H, W, 4.0, 6.0, 0)
+    sd = O.procedural_state_dict(arch, seed)
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': mode, 'max_iter': 1, 'full_dn': True,
+            'collab_sidd256': False}
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    O.IterDenoise(noisy, arch, sd, pipe)
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(old)
+    return {"value": H * W / 1e6 / dt, "unit": "Bayer MP/s", "cores": threads, "kind": "port",
+            "sample": f"one {H}x{W} synthetic Bayer frame, same pipeline ('{mode}'), oracle/yond_oracle.py "
+                      f"(NumPy/SciPy + PyTorch-CPU), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", default="once", choices=["once", "iter"])
+    ap.add_argument("--arch", default="GuidedResUnet", choices=list(ARCHS))
+    ap.add_argument("--height", type=int, default=3000)
+    ap.add_argument("--width", type=int, default=4000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank, local, world = D.init()
+    if world != a.gpus and rank == 0:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    L.load()
+
+    arch = ARCHS[a.arch]
+    net = getattr(A, arch['name'])(dict(arch))
+    net.load_state_dict(S.procedural_state_dict(net, 0))
+    net = net.to(dev).eval()
+    H, W = a.height, a.width
+    noisy, clean = S.synth_noisy(H, W, 4.0, 6.0, rank)
+    frame = torch.from_numpy(noisy).to(dev)
+    clean_d = torch.from_numpy(clean).to(dev)
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': a.mode, 'max_iter': 1, 'full_dn': True,
+            'collab_sidd256': False}
+
+    def step():
+        return P.IterDenoise(frame, net, arch, pipe)
+
+    for _ in range(a.warmup):
+        res = step()
+    plan = P._plan_of(net, dev)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    plan.prof = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    prof, plan.prof = plan.prof, None
+
+    # dominant kernel: the 3x3 stride-1 fp32-MFMA convolution (18 launches per forward, 91 % of the MACs)
+    per = {}
+    for tag, flops, e0, e1 in prof:
+        ms = e0.elapsed_time(e1)
+        k = per.setdefault(tag, [0, 0.0, 0.0])
+        k[0] += 1
+        k[1] += ms
+        k[2] += flops
+    dom = max((t for t in per if t.startswith("conv_mfma_kernel<3,1")), key=lambda t: per[t][1], default=None)
+    roof = None
+    if dom:
+        n, ms, fl = per[dom]
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "launches": n,
+                "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
+    conv_ms = sum(v[1] for v in per.values()) / max(a.steps, 1)
+    conv_fl = sum(v[2] for v in per.values()) / max(a.steps, 1)
+
+    # final metric reduction (the only collective of the eval path): PSNR of the last output vs the clean frame
+    dn = res['raw_dns'][-1]
+    mse = torch.mean((dn.double() - clean_d.double()) ** 2).item()
+    sums = D.MetricSums(1)
+    sums.update([10 * np.log10(1.0 / mse)], [0.0])
+    red = sums.reduce(dev)
+
+    if rank == 0:
+        mp = H * W / 1e6
+        out = {
+            "metric": "Bayer megapixels/sec end-to-end (NLE+VST+denoise+iVST)",
+            "value": round(world * a.steps * mp / elapsed, 2), "unit": "Bayer MP/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: one {H}x{W} synthetic Poisson-Gaussian Bayer frame per GPU, full "
+                                   f"NLE+VST+{a.arch}(nf=32)+iVST, pipeline '{a.mode}', bias_corr=pre, k=29",
+                       "frames_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}"},
+            "roofline": roof,
+            "conv_stack": {"ms_per_step": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
+                           "share_of_step": round(conv_ms / (elapsed / a.steps * 1e3), 3) if conv_ms else None},
+            "psnr_vs_clean_db": round(red["psnr_last"], 3),
+            "estimated_K_sigma": [round(float(v), 4) for v in res['params'][-1]],
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(arch, a.mode, 0, 1)
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -760,7 +760,7 @@ def synth_clean(H, W):
     y, x = np.mgrid[0:H, 0:W].astype(np.float64)
     ramp = 0.08 + 0.55 * (x / max(W - 1, 1)) * (0.6 + 0.4 * y / max(H - 1, 1))
     checker = 0.12 * ((((x // 256) + (y // 256)) % 2) - 0.5)
-    wave = 0.04 * np.sin(2 * np.pi * x / 97.0) * np.cos(2 * np.pi * y / 131.0)
+    wave = 0.004 * np.sin(2 * np.pi * x / 97.0) * np.cos(2 * np.pi * y / 131.0)
     return np.clip(ramp + checker + wave, 0.0, 1.0)
 
 

@@ -149,7 +149,8 @@ def test_conv_in_and_out_and_maxpool_and_film():
     feat = torch.randn(N, 32, H, W, generator=g)
     w10, b10 = torch.randn(4, 32, 1, 1, generator=g) / 6, torch.randn(4, generator=g)
     out = torch.empty(N, H, W, 4, device=DEV)
-    L.check(lib.yond_conv_out_f32(L.ptr(nhwc(feat).to(DEV)), 32, L.ptr(w10.reshape(4, 32).contiguous().to(DEV)), L.ptr(b10.to(DEV)),
+    featd, w10d, b10d = nhwc(feat).to(DEV), w10.reshape(4, 32).contiguous().to(DEV), b10.to(DEV)   # keep alive across the launch
+    L.check(lib.yond_conv_out_f32(L.ptr(featd), 32, L.ptr(w10d), L.ptr(b10d),
                                   L.ptr(x4), L.ptr(ubd), N, H, W, L.ptr(out), L.stream()), "conv_out")
     refo = (F.conv2d(feat.double(), w10.double(), b10.double()) + (x / ub.view(-1, 1, 1, 1)).double()) * ub.view(-1, 1, 1, 1).double()
     assert report("conv_out", nchw(out.cpu()), refo) < 1e-5

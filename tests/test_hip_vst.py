@@ -84,7 +84,8 @@ def test_k4_denorm_ivst_unpack():
         z = yc * (hi - lo) + lo
         ref = O.rggb2bayer(O.inverse_VST(z, s, gain=K, exact=exact)) / 959.0
         out = torch.empty((2 * h, 2 * w), device=DEV)
-        L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(torch.from_numpy(y).to(DEV)), Hp, Wp, pt, pl, h, w, L.ptr(out), mode, 959.0,
+        yd = torch.from_numpy(y).to(DEV)
+        L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(yd), Hp, Wp, pt, pl, h, w, L.ptr(out), mode, 959.0,
                                                 float(K), float(s), float(lo), float(hi), 0, L.stream()), "k4")
         got = out.cpu().numpy()
         err = np.abs(got.astype(np.float64) - ref)

@@ -73,6 +73,10 @@ class _PackedConv:
         self.bias = b.to(dev)
         self.ksize, self.stride, self.shuffle = ksize, stride, shuffle
         self.psplits, self.gemm_n, self.coutp = psplits, gemm_n, coutp
+        self.tn, self.kc = tn.value, kc.value
+        self.cin_real, self.cout_real = sum(splits), cout
+        # algorithmic MACs per GEMM-M pixel (SURVEY.md section 8d counts real, unpadded channels)
+        self.macs_per_pixel = self.cin_real * self.cout_real * (4 if shuffle else ksize * ksize)
 
 
 class DenoiserPlan:
@@ -81,6 +85,7 @@ class DenoiserPlan:
     def __init__(self, module, device):
         self.lib = L.load()
         self.dev = torch.device(device)
+        self.prof = None                           # list -> record (kernel tag, flops, start, end) HIP events per conv launch
         self.kind = type(module).__name__          # GuidedResUnet | SNRnet | UNetSeeInDark
         self.res = bool(module.res)
         self.norm = bool(module.norm)
@@ -177,7 +182,16 @@ class DenoiserPlan:
         d.ebatch = ebatch
         d.res = res.data_ptr() if res is not None else None
         d.dst = dst.data_ptr()
+        prof = getattr(self, 'prof', None)
+        if prof is not None:
+            # events on the stream the kernel is launched on (torch's current stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.check(self.lib.yond_conv2d_f32(C.byref(d), L.stream()), "yond_conv2d_f32")
+        if prof is not None:
+            e1.record()
+            tag = f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{pc.tn},{pc.kc}>"
+            prof.append((tag, 2.0 * pc.macs_per_pixel * N * d.Ho * d.Wo, e0, e1))
         return dst
 
     def _film(self, t_dev, ub, N):

@@ -98,10 +98,12 @@ typedef struct YondConvDesc {
     int ebatch;
     const float* res;     /* residual, same shape as dst, or NULL */
     float* dst;           /* [N][Ho][Wo][Cout]  (shuffle: see above) */
+    int tn;               /* channel-tile width the weights were packed for (32 or 64, from yond_conv_config) */
 } YondConvDesc;
 
-/* Tile configuration the library would use for a descriptor (needed to pack weights). */
-int yond_conv_config(int ksize, int stride, int cin, int cout, int shuffle, int* tn, int* kc);
+/* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.
+ * N, Ho, Wo (GEMM-M extent; 0 = unknown) let the library pick the tn that fills its persistent grid best. */
+int yond_conv_config(int ksize, int stride, int cin, int cout, int shuffle, int N, int Ho, int Wo, int* tn, int* kc);
 /* Host-side weight packing: w is OIHW [cout][cin][k][k] (Conv2d) -- for a transposed conv pass the
  * already re-indexed [4*cout][cin][1][1] matrix.  dst has cout*cin*k*k floats. */
 int yond_pack_conv_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int kc, float* dst);

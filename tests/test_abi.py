@@ -35,11 +35,14 @@ def test_host_side_argument_checks_without_gpu():
     from yond_public_amd import _lib
     lib = _lib.load()
     tn, kc = ctypes.c_int(), ctypes.c_int()
-    assert lib.yond_conv_config(3, 1, 64, 64, 0, ctypes.byref(tn), ctypes.byref(kc)) == 0 and (tn.value, kc.value) == (64, 16)
-    assert lib.yond_conv_config(3, 2, 32, 64, 0, ctypes.byref(tn), ctypes.byref(kc)) == 0 and (tn.value, kc.value) == (64, 8)
-    assert lib.yond_conv_config(1, 1, 64, 128, 1, ctypes.byref(tn), ctypes.byref(kc)) == 0 and tn.value == 32
-    assert lib.yond_conv_config(5, 1, 64, 64, 0, ctypes.byref(tn), ctypes.byref(kc)) == -2
-    assert lib.yond_conv_config(3, 1, 24, 64, 0, ctypes.byref(tn), ctypes.byref(kc)) == -2
+    assert lib.yond_conv_config(3, 1, 64, 64, 0, 0, 0, 0, ctypes.byref(tn), ctypes.byref(kc)) == 0 and (tn.value, kc.value) == (64, 16)
+    assert lib.yond_conv_config(3, 2, 32, 64, 0, 0, 0, 0, ctypes.byref(tn), ctypes.byref(kc)) == 0 and (tn.value, kc.value) == (64, 8)
+    assert lib.yond_conv_config(1, 1, 64, 128, 1, 0, 0, 0, ctypes.byref(tn), ctypes.byref(kc)) == 0 and tn.value == 32
+    assert lib.yond_conv_config(5, 1, 64, 64, 0, 0, 0, 0, ctypes.byref(tn), ctypes.byref(kc)) == -2
+    assert lib.yond_conv_config(3, 1, 24, 64, 0, 0, 0, 0, ctypes.byref(tn), ctypes.byref(kc)) == -2
+    # deepest level of cfg 2 (94 x 126, 512 ch): 384 tiles of width 64 would leave half the last round idle
+    assert lib.yond_conv_config(3, 1, 512, 512, 0, 1, 94, 126, ctypes.byref(tn), ctypes.byref(kc)) == 0 and tn.value == 32
+    assert lib.yond_conv_config(3, 1, 256, 256, 0, 1, 188, 252, ctypes.byref(tn), ctypes.byref(kc)) == 0 and tn.value == 64
     # null pointers are rejected before any launch
     assert lib.yond_pack_vst_norm_f32(None, 4, 4, None, 0, 0, 0, 0, 1, 1.0, 1.0, 0.0, 0.0, 1.0, None, None, 0, None, None) == -1
     assert lib.yond_conv2d_f32(None, None) == -1

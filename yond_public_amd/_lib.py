@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyond_hip.so")
+LIB_PATH = os.environ.get("YOND_HIP_LIB", os.path.join(_HERE, "libyond_hip.so"))   # override: experiments only
 _lib = None
 
 vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
@@ -20,7 +20,7 @@ class YondConvDesc(C.Structure):
     _fields_ = [("src0", vp), ("src1", vp), ("C0", i32), ("C1", i32), ("N", i32), ("H", i32), ("W", i32),
                 ("Ho", i32), ("Wo", i32), ("Cout", i32), ("ksize", i32), ("stride", i32), ("shuffle", i32),
                 ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
-                ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp)]
+                ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32)]
 
 
 class YondFilmDesc(C.Structure):
@@ -40,7 +40,7 @@ PROTOTYPES = {
     "yond_nchw4_to_nhwc4_f32": [vp, vp, i32, i32, i32, vp],
     "yond_nhwc4_to_nchw4_f32": [vp, vp, i32, i32, i32, vp],
     "yond_image_max_f32": [vp, i32, sz, vp, vp, vp],
-    "yond_conv_config": [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
+    "yond_conv_config": [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
     "yond_pack_conv_weight_f32": [vp, i32, i32, i32, i32, i32, vp],
     "yond_conv2d_f32": [C.POINTER(YondConvDesc), vp],
     "yond_conv_in_f32": [vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp],

@@ -36,3 +36,16 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+
+// compile-time loop: f(IntC<B>{}), ..., f(IntC<E-1>{}) -- the index is usable in constant expressions
+template <int I>
+struct IntC {
+    static constexpr int value = I;
+};
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(IntC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}

@@ -1,23 +1,34 @@
 // K2: the denoiser's convolutions as fp32 MFMA implicit GEMM on gfx950 (v_mfma_f32_32x32x2_f32).
 //
 // GEMM view per launch:  M = output pixels (32 consecutive x per MFMA tile), N = output channels,
-// K = taps * Cin, iterated as (channel chunk of KC) x (tap) x (group of 8 channels) x (4 k-steps).
-// One 256-thread workgroup (4 waves, one per SIMD; two workgroups per CU) owns TH x 32 output pixels x
-// TN output channels; wave w owns rows [w*MW, (w+1)*MW) x all TN channels = MW x NW accumulators of
-// 32x32 (16 VGPRs each).
+// K = taps * Cin, walked as (channel chunk of KC) x (tap) x (group of 8 channels) x (4 k-steps).
 //
-// LDS images (single-buffered, all in one dynamic array):
+// Structure (v2): PERSISTENT workgroups, one per CU (256 threads = one wave per SIMD), each walking a
+// flat list of (tile, chunk) steps; a tile is TH x 32 output pixels x TN output channels, wave w owns rows
+// [w*MW, (w+1)*MW) x TN channels = MW x NW accumulators of 32x32.  Per step, in ONE instruction stream:
+//     issue the global loads of step s+1 (registers)  ->  MFMAs of step s on LDS buffer s&1, with the
+//     (SiLU +) ds_write of step s+1 into buffer (s+1)&1 placed in their middle  ->  ONE barrier.
+// So HBM/L2 latency, the activation prologue and the LDS writes hide under the wave's own MFMAs and do not
+// depend on what a co-resident workgroup happens to be doing (v1: two single-buffered workgroups per CU ran
+// in lockstep -- rocprof showed the MFMA pipe 46 % busy on the 32-channel layers).  The loads of the next
+// tile's first chunk are issued during the current tile's last chunk, the residual is prefetched into
+// registers during that chunk, and the epilogue only issues stores.
+//
+// LDS images (double-buffered, one dynamic array):
 //   input  [IH][TWP] pixels x (KC+4) floats -- the +4 pad makes the pixel stride an odd multiple of 16 B,
 //          so the 16 lanes of a ds_read_b128 group (consecutive pixels, same 4 channels) hit 16 different
 //          16-byte bank groups; tap offsets are compile-time immediates.  For stride 2 the even and odd
 //          input columns are stored in separate halves of each row so a tap still reads consecutive pixels.
 //   weights [tap][KC/8][half][TN][4] -- lane (j = lane&31, half = lane>>5) reads its 4 k-steps with one
-//          conflict-free ds_read_b128.  The same order is produced on the host by
-//          yond_pack_conv_weight_f32, so staging is a linear copy.
+//          conflict-free ds_read_b128; produced in this order on the host by yond_pack_conv_weight_f32.
 // MFMA operand map (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
-// for k-step t of group q the half h = l>>5 contributes channel q*8 + h*4 + t.  D: col = l&31 (channel),
-// row = (r&3) + 8*(r>>2) + 4*(l>>5) (pixel).
+// for k-step t of group q the half h = l>>5 contributes channel q*8 + h*4 + t.  A = weights (i = output channel),
+// B = pixels (j = pixel), so D: col = l&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(l>>5) (output channel).
 #include "common.h"
+
+#ifndef YOND_ABL
+#define YOND_ABL 0      // timing-only ablations (bit 0: no weight DMA, bit 1: no input staging, bit 2: no epilogue stores)
+#endif
 
 template <int KS, int STRIDE, int TH, int TN, int KC>
 struct ConvCfg {
@@ -32,17 +43,28 @@ struct ConvCfg {
     static constexpr int IN_FLOATS = IH * TWP * PS;
     static constexpr int Q = KC / 8;
     static constexpr int W_FLOATS = TAPS * Q * 2 * TN * 4;
+    static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
     static constexpr int NW = TN / 32;
     static constexpr int MW = TH / 4;
-    static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS) * 4;
+    static constexpr int SMEM_BYTES = 2 * BUF_FLOATS * 4;
+    static constexpr int SL = KC / 4;
+    static constexpr int NITEM = IH * IW * SL;
+    static constexpr int NIN = (NITEM + 255) / 256;
+    static constexpr int NWV = W_FLOATS / 4;
+    static constexpr int NWT = (NWV + 255) / 256;
 };
 
-template <int KS, int STRIDE, int TH, int TN, int KC>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const YondConvDesc d) {
+// x * sigmoid(x) with the hardware exp2 / rcp (about 1 ulp each; relative error < 4e-7)
+__device__ __forceinline__ float silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+
+// 3x3: one workgroup per CU (its own MFMAs hide its memory traffic); 1x1 / transposed convolutions are memory
+// bound (K = Cin only), so they run two workgroups per CU for more loads in flight.
+template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE>
+__global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const YondConvDesc d) {
     using C = ConvCfg<KS, STRIDE, TH, TN, KC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_in = smem;
-    float* s_w = smem + C::IN_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -50,193 +72,309 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const YondConvDesc d) {
     const int li = lane & 31;
     const int lh = lane >> 5;
 
-    // block -> (channel tile, pixel tile): XCD-aware bijective remap so that the blocks that share an
-    // input tile / weight slice run on one XCD (speed only).
     const int nct = d.Cout / TN;
     const int ntx = (d.Wo + 31) / 32;
-    const int nblk = gridDim.x;
-    int b = blockIdx.x;
-    {
-        const int q8 = nblk / 8, r8 = nblk % 8, xcd = b % 8;
-        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    }
-    const int ct = b % nct;
-    const int t2 = b / nct;
-    const int tx = t2 % ntx;
-    const int ty = t2 / ntx;
-    const int n = blockIdx.y;
-    const int ox0 = tx * 32, oy0 = ty * TH;
-    const int ix0 = ox0 * STRIDE - C::PADK, iy0 = oy0 * STRIDE - C::PADK;
-
-    f32x16 acc[C::MW][C::NW];
-#pragma unroll
-    for (int m = 0; m < C::MW; ++m)
-#pragma unroll
-        for (int nn = 0; nn < C::NW; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
+    const int nty = (d.Ho + TH - 1) / TH;
+    const int tiles_per_img = nct * ntx * nty;
+    const int total = tiles_per_img * d.N;
+    const int G = gridDim.x;
+    // round r handles logical tiles [r*G, (r+1)*G); inside a round the workgroups of one XCD (blockIdx % 8
+    // equal) take a contiguous run of logical tiles so halos / weight slices are shared in that XCD's L2.
+    const int lslot = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
 
     const int Cin = d.C0 + d.C1;
     const int nchunk = Cin / KC;
-    const float* a_base = s_in + ((wave * C::MW * STRIDE) * C::TWP + li) * C::PS + lh * 4;
-    const float* b_base = s_w + (lh * TN + li) * 4;
+    const int Cr = d.shuffle ? d.Cout / 4 : d.Cout;
+    const int my_sl = (tid % C::SL) * 4;       // 256 % SL == 0: a thread keeps the same 16-byte slot in every item
 
-    // Register staging, split issue-early / write-late: the global loads of chunk ch+1 are issued before
-    // the MFMA block of chunk ch and written to LDS after it, so their latency hides under the MFMAs.
-    constexpr int SL = KC / 4;
-    constexpr int NITEM = C::IH * C::IW * SL;
-    constexpr int NIN = (NITEM + 255) / 256;
-    constexpr int NWV = C::W_FLOATS / 4;
-    constexpr int NWT = (NWV + 255) / 256;
-    f32x4 vin[NIN], vw[NWT];
-    int in_lds[NIN];            // LDS float offset of each staged slot (-1: none), chunk independent
-    int in_goff[NIN];           // pixel offset into the NHWC source (-1: outside the image -> zeros)
+    int in_lds[C::NIN];                        // LDS float offset of each staged slot, tile independent; items past the
+                                               // end of the tile go to pixel 0's pad slot (never read): no branch
 #pragma unroll
-    for (int k = 0; k < NIN; ++k) {
+    for (int k = 0; k < C::NIN; ++k) {
         const int it = tid + k * 256;
-        const int pix = it / SL, sl = it % SL;
+        const int pix = it / C::SL, sl = it % C::SL;
         const int py = pix / C::IW, px = pix % C::IW;
-        const int gy = iy0 + py, gx = ix0 + px;
         const int lp = (STRIDE == 2) ? py * C::TWP + (px & 1) * C::HALF + (px >> 1) : py * C::TWP + px;
-        in_lds[k] = it < NITEM ? lp * C::PS + sl * 4 : -1;
-        in_goff[k] = (it < NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) ? (gy * d.W + gx) : -1;
+        in_lds[k] = it < C::NITEM ? lp * C::PS + sl * 4 : KC;
     }
-    const size_t img_pix0 = (size_t)n * d.H * d.W;
-    const int my_sl = (tid % SL) * 4;     // 256 % SL == 0: a thread keeps the same slot in every item
 
-    auto issue_loads = [&](int ch) {
+    struct Tile {
+        int ct, n, ox0, oy0;
+        int goff[C::NIN];                      // pixel offset into the NHWC source (-1: outside the image -> zeros)
+    };
+    auto decode = [&](int t, Tile& T) {
+        const int n = t / tiles_per_img;
+        int b = t - n * tiles_per_img;
+        T.n = n;
+        T.ct = b % nct;
+        b /= nct;
+        const int tx = b % ntx, ty = b / ntx;
+        T.ox0 = tx * 32;
+        T.oy0 = ty * TH;
+        const int ix0 = T.ox0 * STRIDE - C::PADK, iy0 = T.oy0 * STRIDE - C::PADK;
+#pragma unroll
+        for (int k = 0; k < C::NIN; ++k) {
+            const int it = tid + k * 256;
+            const int pix = it / C::SL;
+            const int py = pix / C::IW, px = pix % C::IW;
+            const int gy = iy0 + py, gx = ix0 + px;
+            T.goff[k] = (it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) ? ((n * d.H + gy) * d.W + gx) : -1;
+        }
+    };
+
+    f32x4 vin[C::NIN];
+    unsigned vin_ok = 0;                       // bit k: staged item k lies inside the image
+    auto issue_loads = [&](const Tile& T, int ch, float* obuf) {
         const int c0 = ch * KC;
         const float* src;
         int Cs, cc;
         if (c0 < d.C0) { src = d.src0; Cs = d.C0; cc = c0; }
         else { src = d.src1; Cs = d.C1; cc = c0 - d.C0; }
+        vin_ok = 0;
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) {
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (in_goff[k] >= 0) v = *(const f32x4*)(src + (img_pix0 + in_goff[k]) * Cs + cc + my_sl);
-            vin[k] = v;
+        for (int k = 0; k < C::NIN; ++k) {
+            // outside the image: read pixel 0 (valid memory); the value is zeroed when it is written to LDS, so
+            // nothing touches the loaded registers (and waits for them) before the middle of the MFMA stream
+            const bool ok = T.goff[k] >= 0;
+            if ((YOND_ABL & 2) == 0) vin[k] = *(const f32x4*)(src + (size_t)(ok ? T.goff[k] : 0) * Cs + cc + my_sl);
+            vin_ok |= (ok ? 1u : 0u) << k;
         }
-        const float* wsrc = d.wpk + ((size_t)ct * nchunk + ch) * C::W_FLOATS;
+        // weight slice: already in LDS order on the host side -> linear copy by LDS-DMA (no VGPRs, no ds_write);
+        // one wave-instruction moves 64 lanes x 16 B = 1 KiB to (wave-uniform base + lane*16)
+        const float* wsrc = d.wpk + ((size_t)T.ct * nchunk + ch) * C::W_FLOATS;
 #pragma unroll
-        for (int k = 0; k < NWT; ++k) {
+        for (int k = 0; k < C::NWT; ++k) {
             const int it = tid + k * 256;
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (NWV % 256 == 0 || it < NWV) v = *(const f32x4*)(wsrc + it * 4);
-            vw[k] = v;
+            if ((YOND_ABL & 1) == 0 && (C::NWV % 256 == 0 || it < C::NWV))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + it * 4),
+                                                 (__attribute__((address_space(3))) void*)(obuf + C::IN_FLOATS + (it - lane) * 4),
+                                                 16, 0, 0);
         }
     };
-    auto write_lds = [&]() {
+    auto write_item = [&](float* buf, int k) {
+        f32x4 v = vin[k];
+        if (PRE) { v[0] = silu_fast(v[0]); v[1] = silu_fast(v[1]); v[2] = silu_fast(v[2]); v[3] = silu_fast(v[3]); }
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        if ((YOND_ABL & 2) == 0) *(f32x4*)(buf + in_lds[k]) = ((vin_ok >> k) & 1u) ? v : z;      // conv zero padding
+    };
+    auto write_lds = [&](float* buf) {
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) {
-            f32x4 v = vin[k];
-            if (d.pre_act == 1) {
-                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
-            }
-            if (in_lds[k] >= 0) *(f32x4*)(s_in + in_lds[k]) = v;
-        }
-#pragma unroll
-        for (int k = 0; k < NWT; ++k) {
-            const int it = tid + k * 256;
-            if (NWV % 256 == 0 || it < NWV) *(f32x4*)(s_w + it * 4) = vw[k];
-        }
+        for (int k = 0; k < C::NIN; ++k) write_item(buf, k);
     };
 
-    issue_loads(0);
-    for (int ch = 0; ch < nchunk; ++ch) {
-        write_lds();
-        __syncthreads();
-        if (ch + 1 < nchunk) issue_loads(ch + 1);
-
-        // ---- MFMA over taps x channel groups ----
+    f32x16 acc[C::MW][C::NW];
+    auto zero_acc = [&]() {
 #pragma unroll
-        for (int tap = 0; tap < C::TAPS; ++tap) {
+        for (int m = 0; m < C::MW; ++m)
+#pragma unroll
+            for (int nn = 0; nn < C::NW; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
+    };
+    // One step: MFMA groups g = (tap, q) of 4*MW*NW instructions each.  The fragments of group g+1 are read
+    // from LDS before the MFMAs of group g are issued (one wave per SIMD: nothing else hides the LDS latency),
+    // and the staged items of the NEXT step are converted / written to the other buffer a few groups in.
+    constexpr int NG = C::TAPS * C::Q;
+    // first group that carries a staged item: late enough for the global loads (issued after group 0, latency
+    // 2-4 us with every CU streaming) to have landed -- rocprof showed 20 % of the wave time in s_waitcnt with
+    // the items placed after group 3
+    constexpr int G0 = (NG * 5) / 9 > 0 ? (NG * 5) / 9 : 0;
+    constexpr int IPG = (C::NIN + (NG - G0) - 1) / (NG - G0);             // items per group
+    auto mfma_step = [&](const float* buf, float* obuf, const Tile& Tl, int lch) {
+        const float* a_base = buf + ((wave * C::MW * STRIDE) * C::TWP + li) * C::PS + lh * 4;
+        const float* b_base = buf + C::IN_FLOATS + (lh * TN + li) * 4;
+        f32x4 a[2][C::MW], bb[2][C::NW];
+        auto load_frag = [&](int g, f32x4* af, f32x4* bf) {
+            const int tap = g / C::Q, q = g % C::Q;
             const int dy = tap / KS, dx = tap % KS;
             const int xo = (STRIDE == 2) ? (dx & 1) * C::HALF + (dx >> 1) : dx;
 #pragma unroll
-            for (int q = 0; q < C::Q; ++q) {
-                f32x4 a[C::MW], bb[C::NW];
+            for (int m = 0; m < C::MW; ++m) af[m] = *(const f32x4*)(a_base + ((m * STRIDE + dy) * C::TWP + xo) * C::PS + q * 8);
+#pragma unroll
+            for (int nn = 0; nn < C::NW; ++nn) bf[nn] = *(const f32x4*)(b_base + (g * 2 * TN + nn * 32) * 4);
+        };
+        load_frag(0, a[0], bb[0]);
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int k0 = (g - G0) * IPG;
+            constexpr int nitem = (g < G0 || k0 >= C::NIN) ? 0 : (C::NIN - k0 < IPG ? C::NIN - k0 : IPG);
+            if constexpr (g + 1 < NG) load_frag(g + 1, a[(g + 1) & 1], bb[(g + 1) & 1]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int m = 0; m < C::MW; ++m)
-                    a[m] = *(const f32x4*)(a_base + ((m * STRIDE + dy) * C::TWP + xo) * C::PS + q * 8);
 #pragma unroll
-                for (int nn = 0; nn < C::NW; ++nn)
-                    bb[nn] = *(const f32x4*)(b_base + ((tap * C::Q + q) * 2 * TN + nn * 32) * 4);
+                    for (int nn = 0; nn < C::NW; ++nn)
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[g & 1][nn][t], a[g & 1][m][t], acc[m][nn], 0, 0, 0);   // D = W . X^T
+            // the address arithmetic and the issue of the next step's global loads ride in the shadow of group 0
+            if constexpr (g == 0) issue_loads(Tl, lch, obuf);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+            for (int j = 0; j < nitem; ++j) write_item(obuf, k0 + j);
+            // Scheduling pipeline of this group (hipcc otherwise sinks the LDS reads to one MFMA before their use
+            // and reuses the fragment registers, exposing the LDS latency on every group): first the reads of
+            // group g+1, then the MFMAs of group g with the staging VALU work in their shadow, then the ds_writes.
+            if constexpr (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, C::MW + C::NW, 0);
 #pragma unroll
-                    for (int m = 0; m < C::MW; ++m)
-#pragma unroll
-                        for (int nn = 0; nn < C::NW; ++nn)
-                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], bb[nn][t], acc[m][nn], 0, 0, 0);
+            for (int i = 0; i < 4 * C::MW * C::NW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (nitem > 0) __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 4 : 1, 0);
             }
-        }
-        __syncthreads();
-    }
+            if constexpr (nitem > 0) __builtin_amdgcn_sched_group_barrier(0x200, nitem, 0);
+        });
+    };
 
-    // ---- epilogue: v = acc*escale + eshift ; act ; + residual ; store (coalesced: 32 lanes = 128 B) ----
-    const int Cr = d.shuffle ? d.Cout / 4 : d.Cout;
+    // Output side.  The MFMAs are issued with the WEIGHT fragment as the A operand and the pixel fragment as
+    // B, so D = W . X^T: a lane owns ONE pixel (column = lane&31) and, in its 16 registers, the channels
+    // (r&3) + 8*(r>>2) + 4*(lane>>5) of the 32-channel tile -- four runs of 4 consecutive channels.  The epilogue
+    // therefore moves 16 bytes per lane and instruction (4 stores per 32x32 tile instead of 16; rocprof: the
+    // dword-per-lane epilogue was store-ISSUE bound, ~350 cycles per store instruction, 29 % of the 32-channel
+    // layers), and FiLM vectors / the residual are read as float4 too.
+    // Address of run g of element block (m, nn): dst[ubase(m, nn) + 8*g + lane_off]; ubase is wave-uniform.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int pstride = d.shuffle ? 2 * Cr : d.Cout;            // elements between horizontally adjacent pixels
+    const int lane_off = li * pstride + 4 * lh;
+    auto out_ubase = [&](const Tile& T, int m, int nn) -> long long {
+        const int oy = T.oy0 + wave_u * C::MW + m;
+        const int cu = T.ct * TN + nn * 32;                     // a channel tile never straddles two sub-positions
+        if (d.shuffle) {
+            const int sp = cu / Cr, pcu = cu % Cr;
+            return ((long long)(T.n * 2 * d.Ho + 2 * oy + (sp >> 1)) * (2 * d.Wo) + 2 * T.ox0 + (sp & 1)) * Cr + pcu;
+        }
+        return ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cu;
+    };
+    constexpr bool RESPF = true;       // prefetch the residual into registers during the tile's last step
+    f32x4 rres[C::MW][C::NW][4];
+    auto prefetch_res = [&](const Tile& T) {
+        const bool col_ok = T.ox0 + li < d.Wo;
 #pragma unroll
-    for (int nn = 0; nn < C::NW; ++nn) {
-        const int co = ct * TN + nn * 32 + li;
-        const int pc = d.shuffle ? co % Cr : co;
-        const int sp = d.shuffle ? co / Cr : 0;
-        const int eoff = (d.ebatch ? n * Cr : 0) + pc;
-        const float es = d.escale ? d.escale[eoff] : 1.0f;
-        const float et = d.eshift ? d.eshift[eoff] : 0.0f;
+        for (int nn = 0; nn < C::NW; ++nn)
 #pragma unroll
-        for (int m = 0; m < C::MW; ++m) {
-            const int oy = oy0 + wave * C::MW + m;
+            for (int m = 0; m < C::MW; ++m) {
+                const bool ok = col_ok && (T.oy0 + wave_u * C::MW + m < d.Ho);
+                const long long base = ok ? out_ubase(T, m, nn) + lane_off : 0;      // invalid lanes read element 0..27
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (oy < d.Ho && ox < d.Wo) {
-                    float v = fmaf(acc[m][nn][r], es, et);
-                    if (d.post_act == 1) v = silu_f(v);
-                    else if (d.post_act == 2) v = v > 0.0f ? v : v * d.slope;
-                    size_t idx;
-                    if (d.shuffle)
-                        idx = ((size_t)(n * 2 * d.Ho + 2 * oy + (sp >> 1)) * (2 * d.Wo) + 2 * ox + (sp & 1)) * Cr + pc;
-                    else
-                        idx = ((size_t)(n * d.Ho + oy) * d.Wo + ox) * d.Cout + co;
-                    if (d.res) v += d.res[idx];
-                    d.dst[idx] = v;
+                for (int g = 0; g < 4; ++g) rres[m][nn][g] = *(const f32x4*)(d.res + base + (ok ? 8 * g : 0));
+            }
+    };
+    // epilogue: v = acc*escale + eshift ; act ; + residual ; 16-byte stores
+    auto epilogue = [&](const Tile& T) {
+        const bool col_ok = T.ox0 + li < d.Wo;
+#pragma unroll
+        for (int nn = 0; nn < C::NW; ++nn) {
+            const int cu = T.ct * TN + nn * 32;
+            const int eoff = (d.ebatch ? T.n * Cr : 0) + (d.shuffle ? cu % Cr : cu) + 4 * lh;
+            f32x4 es[4], et[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                es[g] = d.escale ? *(const f32x4*)(d.escale + eoff + 8 * g) : one;
+                et[g] = d.eshift ? *(const f32x4*)(d.eshift + eoff + 8 * g) : zero;
+            }
+#pragma unroll
+            for (int m = 0; m < C::MW; ++m) {
+                const bool ok = col_ok && (T.oy0 + wave_u * C::MW + m < d.Ho);
+                float* op = d.dst + out_ubase(T, m, nn) + lane_off;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = fmaf(acc[m][nn][4 * g + e], es[g][e], et[g][e]);
+                        if (d.post_act == 1) x = silu_fast(x);
+                        else if (d.post_act == 2) x = x > 0.0f ? x : x * d.slope;
+                        if (RESPF && d.res) x += rres[m][nn][g][e];
+                        v[e] = x;
+                    }
+                    if (ok) {
+                        if (!RESPF && d.res) { const f32x4 rv = *(const f32x4*)(d.res + (op - d.dst) + 8 * g); v += rv; }
+                        *(f32x4*)(op + 8 * g) = v;
+                    }
                 }
             }
         }
+    };
+
+    int tile = lslot;                            // logical tile of round 0 (the launch guarantees tile < total)
+    if (tile >= total) return;
+    Tile cur, ld;                                // tile being computed / tile whose chunks are being loaded
+    decode(tile, cur);
+    ld = cur;
+    int ch = 0, pb = 0;
+    zero_acc();
+    issue_loads(cur, 0, smem);
+    write_lds(smem);
+    __syncthreads();                             // (the barrier's fence also drains the LDS-DMA of the weights)
+    while (true) {
+        const bool last_ch = (ch + 1 == nchunk);
+        const int ntile = last_ch ? tile + G : tile;
+        const int nch = last_ch ? 0 : ch + 1;
+        const bool has_next = ntile < total;
+        float* buf = smem + pb * C::BUF_FLOATS;
+        float* obuf = smem + (pb ^ 1) * C::BUF_FLOATS;      // all waves left obuf at the previous barrier
+        // The loads of the next step are always issued (on the very last step they harmlessly re-read the first
+        // chunk of the current tile), so the step body has no data-dependent branch.
+        if (last_ch) {
+            if (has_next) decode(ntile, ld);
+            if (RESPF && d.res) prefetch_res(cur);
+        }
+        mfma_step(buf, obuf, ld, nch);
+        __syncthreads();
+        if (last_ch) {
+            if ((YOND_ABL & 4) == 0 && ((YOND_ABL & 8) == 0 || d.N < 0)) epilogue(cur);
+            zero_acc();
+            cur = ld;
+        }
+        if (!has_next) break;
+        tile = ntile;
+        ch = nch;
+        pb ^= 1;
     }
 }
 
-template <int KS, int STRIDE, int TH, int TN, int KC>
+template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE>
 static int launch_conv(const YondConvDesc& d, hipStream_t st) {
     using C = ConvCfg<KS, STRIDE, TH, TN, KC>;
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<KS, STRIDE, TH, TN, KC>;
+    auto kern = conv_mfma_kernel<KS, STRIDE, TH, TN, KC, PRE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int nct = d.Cout / TN;
-    const int ntx = (d.Wo + 31) / 32, nty = (d.Ho + TH - 1) / TH;
-    dim3 grid(nct * ntx * nty, d.N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM_BYTES, st, d);
+    const long long total = (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
+    if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
+    const int slots = 256 * (KS == 1 ? 2 : 1);                 // persistent workgroups: one (3x3) or two (1x1) per CU
+    const int grid = total < slots ? (int)total : slots;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::SMEM_BYTES, st, d);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
 
-extern "C" int yond_conv_config(int ksize, int stride, int cin, int cout, int shuffle, int* tn, int* kc) {
+static int conv_kc(int ksize, int stride) { return (ksize == 3 && stride == 2) ? 8 : 16; }
+
+extern "C" int yond_conv_config(int ksize, int stride, int cin, int cout, int shuffle, int N, int Ho, int Wo, int* tn,
+                                int* kc) {
     if (!((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1))) return YOND_EUNSUPPORTED;
-    const int k = (ksize == 3 && stride == 2) ? 8 : 16;
+    const int k = conv_kc(ksize, stride);
     if (cout % 32 != 0 || cin % k != 0 || cin <= 0 || cout <= 0) return YOND_EUNSUPPORTED;
     if (shuffle && (ksize != 1 || cout % 128 != 0)) return YOND_EUNSUPPORTED;
     const int ntile = shuffle ? cout / 4 : cout;      // a channel tile must not straddle two sub-positions
-    if (tn) *tn = (ntile % 64 == 0) ? 64 : 32;
+    int t = (ntile % 64 == 0) ? 64 : 32;
+    if (t == 64 && N > 0 && Ho > 0 && Wo > 0) {
+        // persistent grid of 256 workgroups: prefer the tile width that fills the last round
+        const long long px = (long long)N * ((Ho + 7) / 8) * ((Wo + 31) / 32);
+        const long long t64 = px * (cout / 64), t32 = px * (cout / 32);
+        const double e64 = (double)t64 / (double)(((t64 + 255) / 256) * 256);
+        const double e32 = (double)t32 / (double)(((t32 + 255) / 256) * 256);
+        if (e64 < 0.85 && e32 > e64 + 0.1) t = 32;
+    }
+    if (tn) *tn = t;
     if (kc) *kc = k;
     return YOND_OK;
 }
 
 extern "C" int yond_pack_conv_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int kc, float* dst) {
-    if (!w || !dst || cout % tn != 0 || cin % kc != 0 || kc % 8 != 0) return YOND_EINVAL;
+    if (!w || !dst || (tn != 32 && tn != 64) || cout % tn != 0 || cin % kc != 0 || kc % 8 != 0) return YOND_EINVAL;
     const int taps = ksize * ksize, Q = kc / 8;
     size_t o = 0;
     for (int ct = 0; ct < cout / tn; ++ct)
@@ -258,255 +396,24 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!d.src0 || !d.dst || !d.wpk || d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Ho <= 0 || d.Wo <= 0) return YOND_EINVAL;
     if (d.C1 > 0 && !d.src1) return YOND_EINVAL;
-    if (d.N > 65535) return YOND_EUNSUPPORTED;
+    if (d.tn != 32 && d.tn != 64) return YOND_EINVAL;
     int tn, kc;
-    const int rc = yond_conv_config(d.ksize, d.stride, d.C0 + d.C1, d.Cout, d.shuffle, &tn, &kc);
+    const int rc = yond_conv_config(d.ksize, d.stride, d.C0 + d.C1, d.Cout, d.shuffle, 0, 0, 0, &tn, &kc);
     if (rc != YOND_OK) return rc;
-    if (d.C0 % kc != 0 || d.C1 % kc != 0) return YOND_EUNSUPPORTED;
+    tn = d.tn;                                           // the width the weights were packed for
+    if (d.C0 % kc != 0 || d.C1 % kc != 0 || d.Cout % tn != 0) return YOND_EUNSUPPORTED;
     if (d.shuffle && (d.ksize != 1 || (d.Cout / 4) % tn != 0)) return YOND_EUNSUPPORTED;
+    if ((long long)d.N * d.H * d.W > 0x7fffffffLL) return YOND_EUNSUPPORTED;    // 32-bit pixel offsets
     if (d.stride == 2) {
         if (d.Ho != (d.H + 1) / 2 || d.Wo != (d.W + 1) / 2) return YOND_EINVAL;
     } else if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
-    if (d.ksize == 3 && d.stride == 1) return tn == 64 ? launch_conv<3, 1, 8, 64, 16>(d, st) : launch_conv<3, 1, 8, 32, 16>(d, st);
-    if (d.ksize == 3 && d.stride == 2) return tn == 64 ? launch_conv<3, 2, 8, 64, 8>(d, st) : launch_conv<3, 2, 8, 32, 8>(d, st);
-    return tn == 64 ? launch_conv<1, 1, 8, 64, 16>(d, st) : launch_conv<1, 1, 8, 32, 16>(d, st);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// First layer (archs/Unet.py:431): 3x3, Cin = 4 (one 16-byte slot per pixel), Cout = 32*k.
-// K = 9 taps x 4 channels is walked as 5 tap PAIRS: half h of the wave takes tap 2u+h, so one MFMA
-// k-step covers channel t of both taps.  Tap 9 does not exist: its weights are zero and its A operand
-// re-reads tap 8.  Memory bound (16 B in, 4*Cout B out per pixel).
-// ------------------------------------------------------------------------------------------------------
-template <int TH>
-__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ ub,
-                                                      int H, int W, int Cout, const float* __restrict__ wpk,
-                                                      const float* __restrict__ bias, float slope,
-                                                      float* __restrict__ dst) {
-    constexpr int IH = TH + 2, IW = 34, MW = TH / 4;
-    __shared__ __attribute__((aligned(16))) float s_in[IH * IW * 4];
-    __shared__ __attribute__((aligned(16))) float s_w[5 * 2 * 32 * 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int nct = Cout / 32;
-    const int ntx = (W + 31) / 32;
-    int b = blockIdx.x;
-    const int ct = b % nct;
-    b /= nct;
-    const int tx = b % ntx, ty = b / ntx;
-    const int n = blockIdx.y;
-    const int ox0 = tx * 32, oy0 = ty * TH;
-    const float u = ub ? ub[n] : 1.0f;
-    for (int it = tid; it < IH * IW; it += 256) {
-        const int py = it / IW, px = it % IW;
-        const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            v = *(const f32x4*)(x + ((size_t)(n * H + gy) * W + gx) * 4);
-            if (ub) { v[0] /= u; v[1] /= u; v[2] /= u; v[3] /= u; }
-        }
-        *(f32x4*)(s_in + it * 4) = v;
+    if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;
+    if (d.pre_act == 1 && !(d.ksize == 3 && d.stride == 1)) return YOND_EUNSUPPORTED;
+    if (d.ksize == 3 && d.stride == 1) {
+        if (d.pre_act) return tn == 64 ? launch_conv<3, 1, 8, 64, 16, true>(d, st) : launch_conv<3, 1, 8, 32, 16, true>(d, st);
+        return tn == 64 ? launch_conv<3, 1, 8, 64, 16, false>(d, st) : launch_conv<3, 1, 8, 32, 16, false>(d, st);
     }
-    for (int it = tid; it < 5 * 2 * 32; it += 256)
-        *(f32x4*)(s_w + it * 4) = *(const f32x4*)(wpk + (size_t)ct * 1280 + it * 4);
-    __syncthreads();
-
-    f32x16 acc[MW];
-#pragma unroll
-    for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
-#pragma unroll
-    for (int up = 0; up < 5; ++up) {
-        int tap = 2 * up + lh;
-        if (tap > 8) tap = 8;
-        const int dy = tap / 3, dx = tap % 3;
-        const f32x4 bb = *(const f32x4*)(s_w + ((up * 2 + lh) * 32 + li) * 4);
-#pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            const f32x4 a = *(const f32x4*)(s_in + ((wave * MW + m + dy) * IW + li + dx) * 4);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bb[t], acc[m], 0, 0, 0);
-        }
-    }
-    const int co = ct * 32 + li;
-    const float bv = bias ? bias[co] : 0.0f;
-#pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int oy = oy0 + wave * MW + m;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (oy < H && ox < W) {
-                float v = acc[m][r] + bv;
-                v = v > 0.0f ? v : v * slope;
-                dst[((size_t)(n * H + oy) * W + ox) * Cout + co] = v;
-            }
-        }
-    }
-}
-
-extern "C" int yond_pack_conv_in_weight_f32(const float* w, int cout, float* dst) {
-    if (!w || !dst || cout % 32 != 0) return YOND_EINVAL;
-    size_t o = 0;
-    for (int ct = 0; ct < cout / 32; ++ct)
-        for (int up = 0; up < 5; ++up)
-            for (int h = 0; h < 2; ++h)
-                for (int j = 0; j < 32; ++j)
-                    for (int e = 0; e < 4; ++e) {
-                        const int tap = 2 * up + h, co = ct * 32 + j;
-                        dst[o++] = tap < 9 ? w[((size_t)co * 4 + e) * 9 + tap] : 0.0f;
-                    }
-    return YOND_OK;
-}
-
-extern "C" int yond_conv_in_f32(const float* x, const float* ub, int N, int H, int W, int Cout, const float* wpk,
-                                const float* bias, float slope, float* dst, void* stream) {
-    if (!x || !wpk || !dst || N <= 0 || H <= 0 || W <= 0 || N > 65535) return YOND_EINVAL;
-    if (Cout % 32 != 0) return YOND_EUNSUPPORTED;
-    constexpr int TH = 8;
-    dim3 grid((Cout / 32) * ((W + 31) / 32) * ((H + TH - 1) / TH), N);
-    hipLaunchKernelGGL(conv_in_kernel<TH>, grid, dim3(256), 0, (hipStream_t)stream, x, ub, H, W, Cout, wpk, bias, slope, dst);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Last layer (archs/Unet.py:463-468): out = (W10 . feat + b10 + x/ub) * ub, Cout = 4.  One pixel per
-// thread, weights through the scalar cache (uniform index).  Memory bound (4*Cin + 32 B per pixel).
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__ feat, int Cin,
-                                                       const float* __restrict__ w, const float* __restrict__ bias,
-                                                       const float* __restrict__ x, const float* __restrict__ ub,
-                                                       size_t npix_per_image, float* __restrict__ dst) {
-    const int n = blockIdx.y;
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npix_per_image) return;
-    const size_t gp = (size_t)n * npix_per_image + p;
-    const float* f = feat + gp * Cin;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    for (int c = 0; c < Cin; c += 4) {
-        const f32x4 v = *(const f32x4*)(f + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o0 = fmaf(v[e], w[0 * Cin + c + e], o0);
-            o1 = fmaf(v[e], w[1 * Cin + c + e], o1);
-            o2 = fmaf(v[e], w[2 * Cin + c + e], o2);
-            o3 = fmaf(v[e], w[3 * Cin + c + e], o3);
-        }
-    }
-    if (bias) { o0 += bias[0]; o1 += bias[1]; o2 += bias[2]; o3 += bias[3]; }
-    const float u = ub ? ub[n] : 1.0f;
-    if (x) {
-        f32x4 xv = *(const f32x4*)(x + gp * 4);
-        if (ub) { xv[0] /= u; xv[1] /= u; xv[2] /= u; xv[3] /= u; }
-        o0 += xv[0]; o1 += xv[1]; o2 += xv[2]; o3 += xv[3];
-    }
-    if (ub) { o0 *= u; o1 *= u; o2 *= u; o3 *= u; }
-    f32x4 o = {o0, o1, o2, o3};
-    *(f32x4*)(dst + gp * 4) = o;
-}
-
-extern "C" int yond_conv_out_f32(const float* feat, int Cin, const float* w, const float* bias, const float* x,
-                                 const float* ub, int N, int H, int W, float* dst, void* stream) {
-    if (!feat || !w || !dst || N <= 0 || H <= 0 || W <= 0 || N > 65535) return YOND_EINVAL;
-    if (Cin % 4 != 0) return YOND_EUNSUPPORTED;
-    const size_t npix = (size_t)H * W;
-    dim3 grid((unsigned)((npix + 255) / 256), N);
-    hipLaunchKernelGGL(conv_out_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, Cin, w, bias, x, ub, npix, dst);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
-}
-
-// 2x2 max pooling, NHWC, 4 channels per thread.
-__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ src, int H, int W, int C,
-                                                       float* __restrict__ dst, size_t total4) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const int c4 = C / 4;
-    const int Ho = H / 2, Wo = W / 2;
-    const int c = (int)(i % c4);
-    size_t p = i / c4;
-    const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int n = (int)(p / Ho);
-    const float* s = src + (((size_t)(n * H + 2 * oy) * W + 2 * ox) * C) + c * 4;
-    const f32x4 a = *(const f32x4*)s, b2 = *(const f32x4*)(s + C);
-    const f32x4 c2 = *(const f32x4*)(s + (size_t)W * C), d2 = *(const f32x4*)(s + (size_t)W * C + C);
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaxf(a[e], b2[e]), fmaxf(c2[e], d2[e]));
-    *(f32x4*)(dst + i * 4) = o;
-}
-
-extern "C" int yond_maxpool2_f32(const float* src, int N, int H, int W, int C, float* dst, void* stream) {
-    if (!src || !dst || N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C % 4 != 0) return YOND_EINVAL;
-    const size_t total4 = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, H, W, C, dst, total4);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// sigma-conditioning MLPs (archs/modules.py:170-178, 190-193 / 205-214, 225-231): one workgroup per
-// (block, image).  h = SiLU(w_a0*t + b_a0); m1 = W_a2 h + b_a2; then
-//   guided: tb = W_b SiLU(m1) + b_b;  (s1,t1) = (m1, cb1*m1 + tb);  (s2,t2) = (1, cb2)
-//   snr:    g = SiLU(w_b0*t + b_b0); m2 = W_b g + b_b;  (s1,t1) = (m1, cb1*m1);  (s2,t2) = (m2, cb2*m2)
-// Rows are reduced wave-per-row with shuffles (coalesced weight reads).  ~1.5 MFLOP total: negligible.
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void film_kernel(const YondFilmDesc* __restrict__ descs, const float* __restrict__ t,
-                                                   const float* __restrict__ ub) {
-    __shared__ float s_h[1024];
-    __shared__ float s_m[1024];
-    const YondFilmDesc d = descs[blockIdx.x];
-    const int n = blockIdx.y;
-    const int C = d.C;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float tv = t[n];
-    if (ub) tv = tv / ub[n];
-    for (int c = tid; c < C; c += 256) s_h[c] = silu_f(fmaf(d.w_a0[c], tv, d.b_a0[c]));
-    __syncthreads();
-    for (int row = wave; row < C; row += 4) {
-        float s = 0.0f;
-        for (int j = lane; j < C; j += 64) s = fmaf(d.w_a2[(size_t)row * C + j], s_h[j], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) s_m[row] = s + d.b_a2[row];
-    }
-    __syncthreads();
-    if (d.kind == 0) {
-        for (int c = tid; c < C; c += 256) s_h[c] = silu_f(s_m[c]);
-    } else {
-        for (int c = tid; c < C; c += 256) s_h[c] = silu_f(fmaf(d.w_b0[c], tv, d.b_b0[c]));
-    }
-    __syncthreads();
-    for (int row = wave; row < C; row += 4) {
-        float s = 0.0f;
-        for (int j = lane; j < C; j += 64) s = fmaf(d.w_b[(size_t)row * C + j], s_h[j], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) {
-            const float m2 = s + d.b_b[row];
-            const float m1 = s_m[row];
-            const size_t o = (size_t)n * d.ld + row;
-            if (d.kind == 0) {
-                d.s1[o] = m1;
-                d.t1[o] = fmaf(d.cb1[row], m1, m2);
-                d.s2[o] = 1.0f;
-                d.t2[o] = d.cb2[row];
-            } else {
-                d.s1[o] = m1;
-                d.t1[o] = d.cb1[row] * m1;
-                d.s2[o] = m2;
-                d.t2[o] = d.cb2[row] * m2;
-            }
-        }
-    }
-}
-
-extern "C" int yond_film_f32(const YondFilmDesc* descs, int nblocks, const float* t, const float* ub, int N, void* stream) {
-    if (!descs || !t || nblocks <= 0 || N <= 0 || N > 65535) return YOND_EINVAL;
-    hipLaunchKernelGGL(film_kernel, dim3(nblocks, N), dim3(256), 0, (hipStream_t)stream, descs, t, ub);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
+    if (d.ksize == 3 && d.stride == 2)
+        return tn == 64 ? launch_conv<3, 2, 8, 64, 8, false>(d, st) : launch_conv<3, 2, 8, 32, 8, false>(d, st);
+    return tn == 64 ? launch_conv<1, 1, 8, 64, 16, false>(d, st) : launch_conv<1, 1, 8, 32, 16, false>(d, st);
 }

@@ -241,28 +241,45 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__
     }
 }
 
-__global__ void sel_resolve_kernel(SelState* st, int pass, float* out_vals) {
+__global__ __launch_bounds__(256) void sel_resolve_kernel(SelState* st, int pass, float* out_vals) {
     __shared__ unsigned int s_newp[SEL_MAXT];
-    const int t = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = st->nt;
-    if (t < nt) {
-        const unsigned int* h = st->hist + st->tgt_slot[t] * 256;
-        long long rank = st->tgt_rank[t];
-        int d = 0;
-        long long cum = 0;
-        for (; d < 255; ++d) {
-            const long long c = (long long)h[d];
-            if (rank < cum + c) break;
-            cum += c;
+    // one wave per target: lane l holds bins 4l..4l+3, wave-wide exclusive scan, first bin whose cumulative
+    // count exceeds the remaining rank
+    for (int t = wave; t < nt; t += 4) {
+        const unsigned int* h = st->hist + st->tgt_slot[t] * 256 + lane * 4;
+        const long long c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
+        const long long mine = c0 + c1 + c2 + c3;
+        long long incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
         }
-        st->tgt_rank[t] = rank - cum;
-        const unsigned int np = (st->tgt_prefix[t] << 8) | (unsigned int)d;
-        st->tgt_prefix[t] = np;
-        s_newp[t] = np;
-        if (pass == 3) out_vals[t] = key2f(np);
+        const long long excl = incl - mine;
+        const long long rank = st->tgt_rank[t];
+        const bool here = rank >= excl && rank < incl;          // exactly one lane unless the data ran out
+        const unsigned long long m = __ballot(here);
+        const int src = m ? (__ffsll((long long)m) - 1) : 63;
+        int d;
+        long long cum;
+        if (rank < excl + c0) { d = 0; cum = excl; }
+        else if (rank < excl + c0 + c1) { d = 1; cum = excl + c0; }
+        else if (rank < excl + c0 + c1 + c2) { d = 2; cum = excl + c0 + c1; }
+        else { d = 3; cum = excl + c0 + c1 + c2; }
+        d = __shfl(d, src);
+        cum = __shfl(cum, src);
+        if (lane == 0) {
+            const unsigned int np = (st->tgt_prefix[t] << 8) | (unsigned int)(src * 4 + d);
+            st->tgt_rank[t] = rank - cum;
+            st->tgt_prefix[t] = np;
+            s_newp[t] = np;
+            if (pass == 3) out_vals[t] = key2f(np);
+        }
     }
     __syncthreads();
-    if (t == 0 && pass < 3) {
+    if (tid == 0 && pass < 3) {
         // sorted distinct prefixes -> slots
         int ns = 0;
         for (int i = 0; i < nt; ++i) {
@@ -282,7 +299,7 @@ __global__ void sel_resolve_kernel(SelState* st, int pass, float* out_vals) {
         }
     }
     __syncthreads();
-    for (int i = t; i < SEL_MAXT * 256; i += blockDim.x) st->hist[i] = 0;
+    for (int i = tid; i < SEL_MAXT * 256; i += blockDim.x) st->hist[i] = 0;
 }
 
 struct LerpArgs { double t[SEL_MAXT / 2]; };

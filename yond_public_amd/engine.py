@@ -61,22 +61,32 @@ class _PackedConv:
             wp[:w.shape[0], do:do + s] = w[:, so:so + s]
             so += s
             do += ps
-        tn, kc = C.c_int(), C.c_int()
-        L.check(lib.yond_conv_config(ksize, stride, cinp, gemm_n, int(shuffle), C.byref(tn), C.byref(kc)), "yond_conv_config")
-        packed = np.empty(wp.size, np.float32)
-        L.check(lib.yond_pack_conv_weight_f32(_np_ptr(np.ascontiguousarray(wp)), gemm_n, cinp, ksize, tn.value, kc.value,
-                                              _np_ptr(packed)), "yond_pack_conv_weight_f32")
-        self.wpk = torch.from_numpy(packed).to(dev)
+        self._wp = np.ascontiguousarray(wp)        # padded OIHW weights (host); packed per tile width on demand
+        self._packed = {}
+        self._dev = dev
         b = torch.zeros(coutp, dtype=torch.float32)
         if bias is not None:
             b[:cout] = bias.detach().to('cpu', torch.float32)
         self.bias = b.to(dev)
         self.ksize, self.stride, self.shuffle = ksize, stride, shuffle
-        self.psplits, self.gemm_n, self.coutp = psplits, gemm_n, coutp
-        self.tn, self.kc = tn.value, kc.value
+        self.psplits, self.gemm_n, self.coutp, self.cinp = psplits, gemm_n, coutp, cinp
         self.cin_real, self.cout_real = sum(splits), cout
+        self.config(0, 0, 0)                       # validates the shape and packs the default layout
         # algorithmic MACs per GEMM-M pixel (SURVEY.md section 8d counts real, unpadded channels)
         self.macs_per_pixel = self.cin_real * self.cout_real * (4 if shuffle else ksize * ksize)
+
+    def config(self, N, Ho, Wo):
+        """(tn, kc, packed weights on the device) for a GEMM-M extent; the packing is cached per tile width."""
+        lib = L.load()
+        tn, kc = C.c_int(), C.c_int()
+        L.check(lib.yond_conv_config(self.ksize, self.stride, self.cinp, self.gemm_n, int(self.shuffle), N, Ho, Wo,
+                                     C.byref(tn), C.byref(kc)), "yond_conv_config")
+        if tn.value not in self._packed:
+            packed = np.empty(self._wp.size, np.float32)
+            L.check(lib.yond_pack_conv_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn.value, kc.value,
+                                                  _np_ptr(packed)), "yond_pack_conv_weight_f32")
+            self._packed[tn.value] = torch.from_numpy(packed).to(self._dev)
+        return tn.value, kc.value, self._packed[tn.value]
 
 
 class DenoiserPlan:
@@ -176,7 +186,9 @@ class DenoiserPlan:
         d.Cout = pc.gemm_n
         d.ksize, d.stride, d.shuffle = pc.ksize, pc.stride, int(pc.shuffle)
         d.pre_act, d.post_act, d.slope = pre_act, post_act, slope
-        d.wpk = pc.wpk.data_ptr()
+        tn, kc, wpk = pc.config(N, d.Ho, d.Wo)
+        d.wpk = wpk.data_ptr()
+        d.tn = tn
         d.escale = escale.data_ptr() if escale is not None else None
         d.eshift = (eshift if eshift is not None else pc.bias).data_ptr()
         d.ebatch = ebatch
@@ -190,7 +202,7 @@ class DenoiserPlan:
         L.check(self.lib.yond_conv2d_f32(C.byref(d), L.stream()), "yond_conv2d_f32")
         if prof is not None:
             e1.record()
-            tag = f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{pc.tn},{pc.kc}>"
+            tag = f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{tn},{kc}>"
             prof.append((tag, 2.0 * pc.macs_per_pixel * N * d.Ho * d.Wo, e0, e1))
         return dst
 
@@ -273,9 +285,11 @@ class DenoiserPlan:
                     self._conv(blk['sc'], up, skips[10 - i], N, h, w, xs)
                     cur = xs
                 tmp = self._new(N, h, w, cp)
-                self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1, post_act=1)
+                # z = conv2(SiLU(FiLM(conv1(SiLU(x))))) + x : both SiLUs run in the consumers' staging (hidden under
+                # the MFMAs), the epilogues only scale/shift (+ residual)
+                self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1)
                 out = self._new(N, h, w, cp)
-                self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur)
+                self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=1)
                 cur = out
                 if i <= 4:
                     skips[i] = cur

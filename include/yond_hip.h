@@ -58,6 +58,12 @@ int yond_denorm_ivst_unpack_f32(const float* net_out, int Hp, int Wp, int pad_t,
                                 float* bayer_out, int mode, double scale, double gain, double sigma,
                                 double lo, double hi, int clip01, void* stream);
 
+/* Stand-alone elementwise VST / inverse VST on flat arrays (utils/isp_algos.py:5-14, 17-33) for the function
+ * seam; the hot path uses the fused K1 / K4 above.  float32 -> float64 and float64 -> float64 as NumPy stages
+ * them with np.float64 noise parameters. */
+int yond_vst_elem_f32(const float* x, size_t n, double sigma, double mu, double gain, double* out, void* stream);
+int yond_ivst_elem_f64(const double* z, size_t n, double sigma, double gain, int exact, double* out, void* stream);
+
 /* Bayer <-> packed planar/NHWC4 copies (utils/isp_ops.py:57-63), bit exact. */
 int yond_bayer2rggb_f32(const float* bayer, int H, int W, float* rggb /*[H/2][W/2][4]*/, void* stream);
 int yond_rggb2bayer_f32(const float* rggb, int h, int w, float* bayer /*[2h][2w]*/, void* stream);

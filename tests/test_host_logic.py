@@ -1,0 +1,78 @@
+"""CPU: host-side logic of the product (no kernels): threshold score, moment fit, LUT knot grid, padding,
+image sharding -- against the oracle's restatements of the same reference lines."""
+import numpy as np
+import pytest
+
+import yond_oracle as O
+from yond_public_amd import pipeline as P
+from yond_public_amd import distributed as D
+
+
+def test_get_p2d_matches_reference_formula():
+    for shape in [(1, 4, 1500, 2000), (1, 4, 128, 128), (1, 4, 60, 68), (2, 4, 33, 95)]:
+        assert P.get_p2d(shape, 32) == O.get_p2d(shape, 32)
+    assert P.get_p2d((1, 4, 1500, 2000), 32) == (8, 8, 2, 2)
+
+
+def test_bias_knots_bit_identical():
+    for mx in (959.7, 312.4, 41.3, 50.0, 499.2, 500.0, 3.2):
+        ub = np.ceil(np.float32(mx)) + 1
+        a, b = P._bias_knots(ub), O.bias_knots(ub)
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+
+
+def test_score3_and_fit_from_moments():
+    rng = np.random.default_rng(0)
+    n = 50000
+    lap = (rng.random(n).astype(np.float32) ** 2) * 0.05
+    mean = rng.random(n).astype(np.float32)
+    var = (0.004 * mean + 5e-5 + 1e-5 * rng.standard_normal(n)).astype(np.float32)
+    th, pct, info = O.get_threshold_score3(lap, mean, step=5, full=True)
+    quants = np.linspace(5, 100, 20)
+    ths = info['ths']
+    # emulate what the accumulate kernel returns
+    occ = np.zeros((20, P.NBINS), np.int32)
+    mom = np.zeros((21, 2, 5))
+    i_le = np.searchsorted(ths, lap.astype(np.float64), side='left')
+    i_lt = np.searchsorted(ths, lap.astype(np.float64), side='right')
+    bins = (mean.clip(0, 1) * 1000).astype(int)
+    for i, b in zip(i_le, bins):
+        if i < 20:
+            occ[i, b] = 1
+    ns = (mean > np.float32(1e-4)) & (mean < np.float32(0.8))
+    for k in range(21):
+        for j, sel in enumerate((i_lt == k, (i_lt == k) & ns)):
+            m, v = mean[sel].astype(np.float64), var[sel].astype(np.float64)
+            mom[k, j] = [m.size, m.sum(), v.sum(), (m * m).sum(), (m * v).sum()]
+    th2, pct2, info2 = P._score3(ths, quants, occ)
+    assert th2 == th and pct2 == pct
+    np.testing.assert_array_equal(info2['npeaks'], info['npeaks'])
+    sel = mom[:info2['index'] + 1].sum(axis=0)
+    reg = P._fit_from_moments(sel[0], sel[1])
+    ref = O.polyfit(mean[lap < th], var[lap < th])
+    np.testing.assert_allclose(reg, ref, rtol=1e-8)
+
+
+def test_vst_scalar_matches_oracle():
+    for K, s in [(0.72, 1.8), (4.37, 6.27), (22.65, 37.09)]:
+        for x in (0, 959.0, 12.5):
+            assert P.vst_scalar(x, np.float64(s), np.float64(K)) == O.VST(x, np.float64(s), gain=np.float64(K))
+
+
+def test_shard_indices():
+    assert D.shard_indices(40, 3, 8) == [3, 11, 19, 27, 35]
+    allidx = sorted(i for r in range(8) for i in D.shard_indices(40, r, 8))
+    assert allidx == list(range(40))
+    sizes = [3000 * 5328] * 8 + [2000 * 3000] * 8 + [4000 * 3000] * 8 + [1000 * 1000] * 16
+    parts = [D.shard_indices(40, r, 8, sizes) for r in range(8)]
+    assert sorted(i for p in parts for i in p) == list(range(40))
+    loads = [sum(sizes[i] for i in p) for p in parts]
+    assert max(loads) / (sum(loads) / 8) < 1.2
+
+
+def test_metric_sums_single_process():
+    m = D.MetricSums(2)
+    m.update([50.0, 51.0], [0.98, 0.99])
+    m.update([48.0, -1.0], [0.97, -1.0])
+    r = m.reduce()
+    assert r['count'] == 2 and r['psnr_iter0'] == 49.0 and r['psnr_iter1'] == 25.0 and abs(r['ssim_last'] + 0.005) < 1e-12

@@ -1,0 +1,203 @@
+"""Evaluation entry point with the reference's surface (YOND_SIDD.py:136-236, 485-570, 723-744):
+
+    python YOND_SIDD.py -f runfiles/YOND/SIDD_simple+full_pre_grumix.yml -m eval
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 YOND_SIDD.py -f ... -m eval
+
+Same runfile schema (`pipeline`, `dst*`, `arch`), same class / method names (`YOND_SIDD.eval`, `IterDenoise`,
+`VST_Denoiser`, `Simple_Denoiser`), same model lookup by name and checkpoint search order.  Differences that
+are the point of this build: every per-pixel pass runs on the MI355X HIP kernels; images are sharded one per
+GPU process (image k -> rank k mod world) instead of nn.DataParallel over batch 1; per-block PSNR/SSIM are
+computed on the device and reduced with ONE all-reduce at the end.
+
+Datasets: SIDD validation blocks are read from `<root_dir>/npy/{noisy,gt}_{k:03d}.npy` ((32,256,256) float32 in
+[0,1], plus optional `full_{k:03d}.npy`) when present; `.mat` / DNG ingestion is the reference's
+data_process/ (out of scope).  Without data the driver evaluates seeded synthetic
+stand-ins so the whole control flow can be exercised and timed.
+"""
+import argparse
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import yaml
+
+from . import archs as _archs
+from . import distributed as D
+from . import pipeline as P
+from . import synthetic as S
+
+
+def log(string, log=None, notime=False):
+    s = f'{time.strftime("%Y-%m-%d %H:%M:%S")} >>  {string}' if not notime else string
+    print(s, flush=True)
+    if log is not None:
+        with open(log, 'a+') as f:
+            f.write(s + '\n')
+
+
+class SyntheticSIDD:
+    """Stand-in for SIDD_Dataset (data_process/yond_datasets.py:767-868): items with 'lr', 'hr' of shape
+    (32, 256, 256), 'lr_full' (the frame used for the round-1 estimate), 'name'."""
+
+    def __init__(self, n=8, K=4.0, sigma=6.0):
+        self.n, self.K, self.sigma = n, K, sigma
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, k):
+        noisy, clean = S.synth_noisy(256, 8192, self.K, self.sigma, 100 + k)
+        full, _ = S.synth_noisy(1024, 1536, self.K, self.sigma, 500 + k)
+        return {'lr': np.array(np.split(noisy, 32, axis=-1)), 'hr': np.array(np.split(clean, 32, axis=-1)),
+                'lr_full': full, 'name': f'synthetic_{k:03d}', 'meta': None, 'cfa': 'rggb'}
+
+
+class NpySIDD:
+    def __init__(self, root):
+        self.root = root
+        self.ids = sorted(int(p.stem.split('_')[1]) for p in Path(root).glob('noisy_*.npy'))
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i):
+        k = self.ids[i]
+        d = {'lr': np.load(f'{self.root}/noisy_{k:03d}.npy').astype(np.float32), 'name': f'sidd_{k:03d}', 'meta': None, 'cfa': 'rggb'}
+        if os.path.exists(f'{self.root}/gt_{k:03d}.npy'):
+            d['hr'] = np.load(f'{self.root}/gt_{k:03d}.npy').astype(np.float32)
+        d['lr_full'] = np.load(f'{self.root}/full_{k:03d}.npy').astype(np.float32) if os.path.exists(f'{self.root}/full_{k:03d}.npy') else None
+        return d
+
+
+class YOND_SIDD:
+    def __init__(self, args=None):
+        self.parser = YONDParser().parse(args)
+        self.initialization()
+
+    def initialization(self):
+        with open(self.parser.runfile, 'r', encoding='utf-8') as f:
+            self.args = yaml.load(f.read(), Loader=yaml.FullLoader)
+        self.mode = self.args['mode'] if self.parser.mode is None else self.parser.mode
+        self.rank, self.local_rank, self.world = D.init()
+        if not torch.cuda.is_available():
+            raise SystemExit("YOND_SIDD needs an MI355X: the HIP path has no CPU fallback")
+        self.device = torch.device('cuda', self.local_rank)
+        torch.cuda.set_device(self.device)
+        self.dst, self.arch, self.pipe = self.args['dst'], self.args['arch'], self.args['pipeline']
+        if self.pipe['bias_corr'] == 'none':
+            self.pipe['bias_corr'] = None
+        self.model_name, self.method_name = self.args['model_name'], self.args['method_name']
+        self.fast_ckpt = self.args['fast_ckpt']
+        os.makedirs('./logs', exist_ok=True)
+        self.logfile = f'./logs/log_{self.method_name}.log' if self.rank == 0 else None
+        # model: looked up by name, checkpoint search order best -> last -> plain (YOND_SIDD.py:177-184)
+        self.net = getattr(_archs, self.arch['name'])(self.arch)
+        for suffix in ('_best_model.pth', '_last_model.pth', '.pth'):
+            model_path = f'{self.fast_ckpt}/{self.model_name}{suffix}'
+            if os.path.exists(model_path):
+                state = torch.load(model_path, map_location='cpu')
+                self.net.load_state_dict(state)
+                break
+        else:
+            model_path = None
+            self.net.load_state_dict(S.procedural_state_dict(self.net, 0))
+        self.net = self.net.to(self.device).eval()
+        if self.rank == 0:
+            nparam = sum(p.numel() for p in self.net.parameters())
+            log(f'Method Name:\t{self.method_name}', self.logfile, notime=True)
+            log(f'Architecture:\t{self.arch["name"]}', self.logfile, notime=True)
+            log(f'Parameters:\t{nparam / 1e6:.2f}M', self.logfile, notime=True)
+            log(f'Checkpoint:\t{model_path or "none found -> procedural weights (timing / parity only)"}', self.logfile, notime=True)
+            log(f"Let's use {self.world} GPUs (one process each, image-parallel)!", self.logfile, notime=True)
+        self.change_eval_dst('eval')
+
+    def change_eval_dst(self, mode='eval'):
+        self.dst = self.args[f'dst_{mode}']
+        root = os.path.join(self.dst['root_dir'], 'npy')
+        if os.path.isdir(root) and list(Path(root).glob('noisy_*.npy')):
+            self.dst_eval = NpySIDD(root)
+        else:
+            self.dst_eval = SyntheticSIDD(self.parser.synthetic)
+
+    # -- reference method names -----------------------------------------------------------------
+    def Simple_Denoiser(self, lr_raw):
+        return P.Simple_Denoiser(lr_raw, self.net, device=self.device)
+
+    def VST_Denoiser(self, lr_raw, hr_raw=None, bias_corr='pre', bias_func=None, denoiser='gru32n', p=None):
+        return P.VST_Denoiser(lr_raw, p, self.net, self.arch, bias_corr, bias_func, self.pipe.get('vst_type', 'exact'),
+                              device=self.device)
+
+    def IterDenoise(self, data, params):
+        res = P.IterDenoise(data['lr'], self.net, self.arch, self.pipe, lr_full=data.get('lr_full'), p=params['p'],
+                            device=self.device, log=(lambda s: log(s, self.logfile)) if self.parser.verbose else None)
+        res['lr_raw'] = np.concatenate(data['lr'], axis=-1)
+        res['hr_raw'] = np.concatenate(data['hr'], axis=-1) if 'hr' in data else None
+        return res
+
+    def eval(self, epoch=-1):
+        n_it = self.pipe['max_iter'] + 1 if self.pipe.get('iter') == 'iter' else 1
+        sums = D.MetricSums(n_it)
+        p = dict(self.pipe)
+        p.update({'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0})          # YOND_SIDD.py:504
+        p['scale'] = (p['wp'] - p['bl']) / p['ratio']
+        mine = D.shard_indices(len(self.dst_eval), self.rank, self.world)
+        self.metrics = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in mine:
+            data = self.dst_eval[k]
+            res = self.IterDenoise(data, {'p': p, 'img_id': k})
+            psnrs, ssims = [], []
+            if res['hr_raw'] is not None:
+                hr = torch.from_numpy(res['hr_raw']).to(self.device)
+                for dn in res['raw_dns']:
+                    ps, ss = P.block_metrics(dn, hr)                                   # :649-652 per 256x256 block
+                    psnrs.append(float(np.mean(ps)))
+                    ssims.append(float(np.mean(ss)))
+                while len(psnrs) < n_it:                                              # failed iteration (:644-647)
+                    psnrs.append(-1.0)
+                    ssims.append(-1.0)
+                sums.update(psnrs, ssims)
+            self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
+            log(f"[rank {self.rank}] {data['name']}: PSNR={psnrs[-1] if psnrs else float('nan'):.2f}, "
+                f"SSIM={ssims[-1] if ssims else float('nan'):.4f}", self.logfile)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        red = sums.reduce(self.device)                 # the ONE collective of the eval path (RCCL over xGMI)
+        dt = D.max_over_ranks(dt, self.device)
+        if self.rank == 0:
+            log(f'{self.method_name}:', self.logfile)
+            for it in range(n_it):
+                log(f"Iter{it}: PSNR={red[f'psnr_iter{it}']:.2f}, SSIM={red[f'ssim_iter{it}']:.4f}", self.logfile)
+            log(f"Iter_last: PSNR={red['psnr_last']:.2f}, SSIM={red['ssim_last']:.4f}", self.logfile)
+            log(f"{red['count']} images on {self.world} GPU(s) in {dt:.2f} s", self.logfile)
+        return red
+
+
+class YONDParser:
+    def __init__(self):
+        self.parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+
+    def parse(self, args=None):
+        a = self.parser
+        a.add_argument('--runfile', '-f', default="runfiles/YOND/SIDD_simple+full_pre_grumix.yml", type=Path, help="path to config")
+        a.add_argument('--mode', '-m', default='eval', type=str, help="eval or test")
+        a.add_argument('--debug', action='store_true', default=False)
+        a.add_argument('--nofig', action='store_true', default=True, help="don't save plots (no sRGB rendering in this build)")
+        a.add_argument('--nohost', action='store_true', default=False)
+        a.add_argument('--gpu', default="0", help="kept for CLI compatibility; ranks pick their device from LOCAL_RANK")
+        a.add_argument('--synthetic', type=int, default=8, help="number of synthetic stand-in images when no dataset is found")
+        a.add_argument('--verbose', action='store_true', default=False)
+        return a.parse_args(args)
+
+
+def main(argv=None):
+    trainer = YOND_SIDD(argv)
+    if 'eval' in trainer.mode or 'test' in trainer.mode:
+        return trainer.eval(-1)
+
+
+if __name__ == '__main__':
+    main()

@@ -46,7 +46,8 @@ struct ConvCfg {
     static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
     static constexpr int NW = TN / 32;
     static constexpr int MW = TH / 4;
-    static constexpr int SMEM_BYTES = 2 * BUF_FLOATS * 4;
+    static constexpr int EP_FLOATS = 2 * TN;              // epilogue scale / shift vectors of the current tile
+    static constexpr int SMEM_BYTES = (2 * BUF_FLOATS + EP_FLOATS) * 4;
     static constexpr int SL = KC / 4;
     static constexpr int NITEM = IH * IW * SL;
     static constexpr int NIN = (NITEM + 255) / 256;
@@ -256,19 +257,32 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
                 for (int g = 0; g < 4; ++g) rres[m][nn][g] = *(const f32x4*)(d.res + base + (ok ? 8 * g : 0));
             }
     };
+    // FiLM / bias vectors of the tile being finished -> LDS (issued at the start of its last step; the global
+    // latency hides under that step's MFMAs, the step-end barrier publishes the values to the epilogue)
+    float* s_ep = smem + 2 * C::BUF_FLOATS;
+    auto stage_ep = [&](const Tile& T) {
+        if (tid < 2 * TN) {
+            const int c = tid < TN ? tid : tid - TN;
+            const int cu = T.ct * TN + c;
+            const int eoff = (d.ebatch ? T.n * Cr : 0) + (d.shuffle ? cu % Cr : cu);
+            float v;
+            if (tid < TN) v = d.escale ? d.escale[eoff] : 1.0f;
+            else v = d.eshift ? d.eshift[eoff] : 0.0f;
+            s_ep[tid] = v;
+        }
+    };
     // epilogue: v = acc*escale + eshift ; act ; + residual ; 16-byte stores
     auto epilogue = [&](const Tile& T) {
         const bool col_ok = T.ox0 + li < d.Wo;
 #pragma unroll
         for (int nn = 0; nn < C::NW; ++nn) {
             const int cu = T.ct * TN + nn * 32;
-            const int eoff = (d.ebatch ? T.n * Cr : 0) + (d.shuffle ? cu % Cr : cu) + 4 * lh;
+            // scale / shift of this tile's channels were staged in LDS during the last step (stage_ep)
             f32x4 es[4], et[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero = {0.0f, 0.0f, 0.0f, 0.0f};
-                es[g] = d.escale ? *(const f32x4*)(d.escale + eoff + 8 * g) : one;
-                et[g] = d.eshift ? *(const f32x4*)(d.eshift + eoff + 8 * g) : zero;
+                es[g] = *(const f32x4*)(s_ep + nn * 32 + 8 * g + 4 * lh);
+                et[g] = *(const f32x4*)(s_ep + TN + nn * 32 + 8 * g + 4 * lh);
             }
 #pragma unroll
             for (int m = 0; m < C::MW; ++m) {
@@ -316,6 +330,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
         if (last_ch) {
             if (has_next) decode(ntile, ld);
             if (RESPF && d.res) prefetch_res(cur);
+            stage_ep(cur);
         }
         mfma_step(buf, obuf, ld, nch);
         __syncthreads();

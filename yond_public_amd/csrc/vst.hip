@@ -277,4 +277,51 @@ extern "C" int yond_image_max_f32(const float* x, int N, size_t elems, float* pa
     return YOND_OK;
 }
 
+// ---- stand-alone elementwise VST / inverse VST for the function seam (utils/isp_algos.py:5-33) ----
+// The hot path uses the fused K1 / K4; these exist so that `VST(x, sigma, mu, gain)` / `inverse_VST(z, ...)`
+// keep working on arbitrary arrays.  float32 in -> float64 out (NumPy promotes to float64 with np.float64
+// parameters), float64 in -> float64 out for the inverse.
+__global__ __launch_bounds__(256) void vst_elem_kernel(const float* __restrict__ x, size_t n, double sigma, double mu,
+                                                       double gain, double* __restrict__ out) {
+    const double c0 = 0.375 * gain * gain, s2 = sigma * sigma, gm = gain * mu, tg = 2.0 / gain;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double fz = gain * (double)x[i] + c0 + s2 - gm;
+        fz = fz > 0.0 ? fz : 0.0;
+        out[i] = tg * sqrt(fz);
+    }
+}
+
+__global__ __launch_bounds__(256) void ivst_elem_kernel(const double* __restrict__ z, size_t n, double sigma, double gain,
+                                                        int exact, double* __restrict__ out) {
+    const double sg = sigma / gain, sg2 = sg * sg, r32 = sqrt(1.5);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = z[i];
+        double fz;
+        if (exact) {
+            if (v > 0.0) {
+                const double iz = 1.0 / v;
+                fz = (v / 2) * (v / 2) + 0.25 * r32 * iz - 1.375 * (iz * iz) + 0.625 * r32 * (iz * iz * iz) - 0.125 - sg2;
+            } else fz = 0.0;
+        } else {
+            fz = (v / 2) * (v / 2) - 0.375 - sg2;
+        }
+        fz = fz > 0.0 ? fz : 0.0;
+        out[i] = fz * gain;
+    }
+}
+
+extern "C" int yond_vst_elem_f32(const float* x, size_t n, double sigma, double mu, double gain, double* out, void* stream) {
+    if (!x || !out || n == 0 || !(gain > 0.0)) return YOND_EINVAL;
+    hipLaunchKernelGGL(vst_elem_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, sigma, mu, gain, out);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_ivst_elem_f64(const double* z, size_t n, double sigma, double gain, int exact, double* out, void* stream) {
+    if (!z || !out || n == 0 || !(gain > 0.0)) return YOND_EINVAL;
+    hipLaunchKernelGGL(ivst_elem_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, z, n, sigma, gain, exact, out);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
 extern "C" int yond_abi_version(void) { return 1; }

@@ -41,7 +41,7 @@ def cpu_baseline(arch, mode, seed, threads):
     same workload.  Test infrastructure used ONLY as the reported baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import yond_oracle as O
-    H, W = 768, 1024
+    H, W = 2048, 3072
     noisy, _ = O.synth_noisy(H, W, 4.0, 6.0, 0)
     sd = O.procedural_state_dict(arch, seed)
     pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': mode, 'max_iter': 1, 'full_dn': True,
@@ -55,6 +55,19 @@ def cpu_baseline(arch, mode, seed, threads):
     return {"value": H * W / 1e6 / dt, "unit": "Bayer MP/s", "cores": threads, "kind": "port",
             "sample": f"one {H}x{W} synthetic Bayer frame, same pipeline ('{mode}'), oracle/yond_oracle.py "
                       f"(NumPy/SciPy + PyTorch-CPU), {dt:.1f} s"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected separately, gfx950 corrections applied by tools/pmc_traffic.py); None if not collected."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path)).get(kernel)
+        return t and {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "unit": "B", "source": "profiles/r01_pmc_traffic.json"}
+    except Exception:
+        return None
 
 
 def main():
@@ -122,7 +135,7 @@ def main():
         n, ms, fl = per[dom]
         ach = fl / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "launches": n,
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom), "launches": n,
                 "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
     conv_ms = sum(v[1] for v in per.values()) / max(a.steps, 1)
     conv_fl = sum(v[2] for v in per.values()) / max(a.steps, 1)

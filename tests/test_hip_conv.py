@@ -56,9 +56,9 @@ def test_conv3x3_s1_fused_film_silu_residual():
     es, et = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
     res = torch.randn(N, C, H, W, generator=g)
     got = nchw(run_conv(w, None, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, escale=es.to(DEV), eshift=et.to(DEV), ebatch=1,
-                        res=nhwc(res).to(DEV), pre_act=1, post_act=1))
+                        res=nhwc(res).to(DEV), pre_act=1, post_act=2, slope=0.3))
     z = F.conv2d(F.silu(x.double()), w.double(), padding=1)
-    z = F.silu(z * es.double()[:, :, None, None] + et.double()[:, :, None, None]) + res.double()
+    z = F.leaky_relu(z * es.double()[:, :, None, None] + et.double()[:, :, None, None], 0.3) + res.double()
     assert report("conv3x3 fused", got, z) < 2e-5
 
 

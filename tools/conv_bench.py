@@ -26,8 +26,8 @@ def main():
     layers = []
     for lvl, C in enumerate([32, 64, 128, 256, 512]):
         h, w = H0 >> lvl, W0 >> lvl
-        layers.append((f"3x3s1 C{C} L{lvl} film+silu", 3, 1, [C], C, h, w, dict(pre_act=1, post_act=1, film=True), False))
-        layers.append((f"3x3s1 C{C} L{lvl} +res", 3, 1, [C], C, h, w, dict(res=True), False))
+        layers.append((f"3x3s1 C{C} L{lvl} silu+film", 3, 1, [C], C, h, w, dict(pre_act=1, film=True), False))
+        layers.append((f"3x3s1 C{C} L{lvl} silu+res", 3, 1, [C], C, h, w, dict(pre_act=1, res=True), False))
         if lvl < 4:
             layers.append((f"3x3s2 C{C}->{2*C} L{lvl}", 3, 2, [C], 2 * C, h, w, {}, False))
             layers.append((f"convT C{2*C}->{C} L{lvl+1}->L{lvl}", 1, 1, [2 * C], C, h // 2, w // 2, {}, True))

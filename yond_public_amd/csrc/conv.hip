@@ -25,6 +25,7 @@
 // for k-step t of group q the half h = l>>5 contributes channel q*8 + h*4 + t.  A = weights (i = output channel),
 // B = pixels (j = pixel), so D: col = l&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(l>>5) (output channel).
 #include "common.h"
+#include <cstdlib>
 
 #ifndef YOND_ABL
 #define YOND_ABL 0      // timing-only ablations (bit 0: no weight DMA, bit 1: no input staging, bit 2: no epilogue stores)
@@ -172,16 +173,108 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
     };
+    // ---------------------------------------------------------------------------------------------------
+    // Output side.  The MFMAs are issued with the WEIGHT fragment as the A operand and the pixel fragment as
+    // B, so D = W . X^T: a lane owns ONE pixel (column = lane&31) and, in its 16 registers, the channels
+    // (r&3) + 8*(r>>2) + 4*(lane>>5) of the 32-channel tile -- four runs of 4 consecutive channels.  The epilogue
+    // therefore moves 16 bytes per lane and instruction (4 stores per 32x32 tile instead of 16), and the FiLM
+    // vectors / the residual are read as float4 too.
+    // Address of run g of element block (m, nn): dst[ubase(m, nn) + 8*g + lane_off]; ubase is wave-uniform.
+    // The epilogue of a finished tile is DEFERRED into the first step of the next tile (accumulators parked in
+    // `eacc`): its residual loads, FiLM arithmetic and stores then run in the shadow of that step's MFMAs
+    // (rocprof / ablation: an exposed epilogue cost 17-29 % on the 32- and 64-channel layers).
+    // ---------------------------------------------------------------------------------------------------
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int pstride = d.shuffle ? 2 * Cr : d.Cout;            // elements between horizontally adjacent pixels
+    const int lane_off = li * pstride + 4 * lh;
+    const float slope_eff = d.post_act == 2 ? d.slope : 1.0f;   // LeakyReLU(slope); slope 1 = identity
+    auto out_ubase = [&](const Tile& T, int m, int nn) -> long long {
+        const int oy = T.oy0 + wave_u * C::MW + m;
+        const int cu = T.ct * TN + nn * 32;                     // a channel tile never straddles two sub-positions
+        if (d.shuffle) {
+            const int sp = cu / Cr, pcu = cu % Cr;
+            return ((long long)(T.n * 2 * d.Ho + 2 * oy + (sp >> 1)) * (2 * d.Wo) + 2 * T.ox0 + (sp & 1)) * Cr + pcu;
+        }
+        return ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cu;
+    };
+    f32x4 rres[C::MW][C::NW][4];                                // residual of the pending tile (zeros when there is none)
+#pragma unroll
+    for (int m = 0; m < C::MW; ++m)
+#pragma unroll
+        for (int nn = 0; nn < C::NW; ++nn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f}; rres[m][nn][g] = z; }
+    auto load_res = [&](const Tile& T) {
+        const bool col_ok = T.ox0 + li < d.Wo;
+#pragma unroll
+        for (int nn = 0; nn < C::NW; ++nn)
+#pragma unroll
+            for (int m = 0; m < C::MW; ++m) {
+                const bool ok = col_ok && (T.oy0 + wave_u * C::MW + m < d.Ho);
+                const long long base = ok ? out_ubase(T, m, nn) + lane_off : 0;      // invalid lanes read element 0..27
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rres[m][nn][g] = *(const f32x4*)(d.res + base + (ok ? 8 * g : 0));
+            }
+    };
+    // FiLM / bias vectors of a tile -> LDS (issued at the start of the tile's last step; the global latency hides
+    // under that step's MFMAs, the step-end barrier publishes them).  Double-buffered by tile parity because the
+    // deferred epilogue of tile i reads them while tile i+1 may already stage its own.
+    float* s_ep = smem + 2 * C::BUF_FLOATS;
+    auto stage_ep = [&](const Tile& T, int par) {
+        if (tid < 2 * TN) {
+            const int c = tid < TN ? tid : tid - TN;
+            const int cu = T.ct * TN + c;
+            const int eoff = (d.ebatch ? T.n * Cr : 0) + (d.shuffle ? cu % Cr : cu);
+            float v;
+            if (tid < TN) v = d.escale ? d.escale[eoff] : 1.0f;
+            else v = d.eshift ? d.eshift[eoff] : 0.0f;
+            s_ep[par * 2 * TN + tid] = v;
+        }
+    };
+    // v = A*escale + eshift ; LeakyReLU ; + residual ; 16-byte stores.  Branch-free apart from the store mask.
+    auto epilogue_from = [&](const Tile& T, f32x16 (&A)[C::MW][C::NW], int par) {
+        const bool col_ok = T.ox0 + li < d.Wo;
+        const float* ep = s_ep + par * 2 * TN;
+#pragma unroll
+        for (int nn = 0; nn < C::NW; ++nn) {
+            f32x4 es[4], et[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                es[g] = *(const f32x4*)(ep + nn * 32 + 8 * g + 4 * lh);
+                et[g] = *(const f32x4*)(ep + TN + nn * 32 + 8 * g + 4 * lh);
+            }
+#pragma unroll
+            for (int m = 0; m < C::MW; ++m) {
+                const bool ok = col_ok && (T.oy0 + wave_u * C::MW + m < d.Ho);
+                float* op = d.dst + out_ubase(T, m, nn) + lane_off;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = fmaf(A[m][nn][4 * g + e], es[g][e], et[g][e]);
+                        x = x > 0.0f ? x : x * slope_eff;
+                        v[e] = x + rres[m][nn][g][e];
+                    }
+                    if (ok && ((YOND_ABL & 16) == 0 || d.N < 0)) *(f32x4*)(op + 8 * g) = v;
+                }
+            }
+        }
+    };
+
     // One step: MFMA groups g = (tap, q) of 4*MW*NW instructions each.  The fragments of group g+1 are read
     // from LDS before the MFMAs of group g are issued (one wave per SIMD: nothing else hides the LDS latency),
     // and the staged items of the NEXT step are converted / written to the other buffer a few groups in.
     constexpr int NG = C::TAPS * C::Q;
     // first group that carries a staged item: late enough for the global loads (issued after group 0, latency
-    // 2-4 us with every CU streaming) to have landed -- rocprof showed 20 % of the wave time in s_waitcnt with
-    // the items placed after group 3
+    // 2-4 us with every CU streaming) to have landed
     constexpr int G0 = (NG * 5) / 9 > 0 ? (NG * 5) / 9 : 0;
     constexpr int IPG = (C::NIN + (NG - G0) - 1) / (NG - G0);             // items per group
-    auto mfma_step = [&](const float* buf, float* obuf, const Tile& Tl, int lch) {
+    constexpr int GE = NG >= 9 ? 1 : NG - 1;                              // group that carries a pending epilogue (early:
+                                                                          // its stores must retire before the step-end barrier)
+    f32x16 eacc[C::MW][C::NW];                                            // accumulators of the pending tile
+    auto mfma_step = [&](auto epi_tag, const float* buf, float* obuf, const Tile& Tl, int lch, const Tile& Tp, int ppar) {
+        constexpr bool EPI = decltype(epi_tag)::value != 0;
         const float* a_base = buf + ((wave * C::MW * STRIDE) * C::TWP + li) * C::PS + lh * 4;
         const float* b_base = buf + C::IN_FLOATS + (lh * TN + li) * 4;
         f32x4 a[2][C::MW], bb[2][C::NW];
@@ -207,8 +300,12 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
 #pragma unroll
                     for (int nn = 0; nn < C::NW; ++nn)
                         acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[g & 1][nn][t], a[g & 1][m][t], acc[m][nn], 0, 0, 0);   // D = W . X^T
-            // the address arithmetic and the issue of the next step's global loads ride in the shadow of group 0
-            if constexpr (g == 0) issue_loads(Tl, lch, obuf);
+            // the address arithmetic and the issue of the next step's global loads (and of the pending tile's
+            // residual) ride in the shadow of group 0
+            if constexpr (g == 0) {
+                issue_loads(Tl, lch, obuf);
+            }
+            if constexpr (EPI && g == GE) epilogue_from(Tp, eacc, ppar);
 #pragma unroll
             for (int j = 0; j < nitem; ++j) write_item(obuf, k0 + j);
             // Scheduling pipeline of this group (hipcc otherwise sinks the LDS reads to one MFMA before their use
@@ -218,102 +315,23 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
 #pragma unroll
             for (int i = 0; i < 4 * C::MW * C::NW; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (nitem > 0) __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 4 : 1, 0);
+                if constexpr (nitem > 0 || (EPI && g >= GE && g < GE + 4)) __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 4 : 2, 0);
             }
             if constexpr (nitem > 0) __builtin_amdgcn_sched_group_barrier(0x200, nitem, 0);
         });
     };
 
-    // Output side.  The MFMAs are issued with the WEIGHT fragment as the A operand and the pixel fragment as
-    // B, so D = W . X^T: a lane owns ONE pixel (column = lane&31) and, in its 16 registers, the channels
-    // (r&3) + 8*(r>>2) + 4*(lane>>5) of the 32-channel tile -- four runs of 4 consecutive channels.  The epilogue
-    // therefore moves 16 bytes per lane and instruction (4 stores per 32x32 tile instead of 16; rocprof: the
-    // dword-per-lane epilogue was store-ISSUE bound, ~350 cycles per store instruction, 29 % of the 32-channel
-    // layers), and FiLM vectors / the residual are read as float4 too.
-    // Address of run g of element block (m, nn): dst[ubase(m, nn) + 8*g + lane_off]; ubase is wave-uniform.
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int pstride = d.shuffle ? 2 * Cr : d.Cout;            // elements between horizontally adjacent pixels
-    const int lane_off = li * pstride + 4 * lh;
-    auto out_ubase = [&](const Tile& T, int m, int nn) -> long long {
-        const int oy = T.oy0 + wave_u * C::MW + m;
-        const int cu = T.ct * TN + nn * 32;                     // a channel tile never straddles two sub-positions
-        if (d.shuffle) {
-            const int sp = cu / Cr, pcu = cu % Cr;
-            return ((long long)(T.n * 2 * d.Ho + 2 * oy + (sp >> 1)) * (2 * d.Wo) + 2 * T.ox0 + (sp & 1)) * Cr + pcu;
-        }
-        return ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cu;
-    };
-    constexpr bool RESPF = true;       // prefetch the residual into registers during the tile's last step
-    f32x4 rres[C::MW][C::NW][4];
-    auto prefetch_res = [&](const Tile& T) {
-        const bool col_ok = T.ox0 + li < d.Wo;
-#pragma unroll
-        for (int nn = 0; nn < C::NW; ++nn)
-#pragma unroll
-            for (int m = 0; m < C::MW; ++m) {
-                const bool ok = col_ok && (T.oy0 + wave_u * C::MW + m < d.Ho);
-                const long long base = ok ? out_ubase(T, m, nn) + lane_off : 0;      // invalid lanes read element 0..27
-#pragma unroll
-                for (int g = 0; g < 4; ++g) rres[m][nn][g] = *(const f32x4*)(d.res + base + (ok ? 8 * g : 0));
-            }
-    };
-    // FiLM / bias vectors of the tile being finished -> LDS (issued at the start of its last step; the global
-    // latency hides under that step's MFMAs, the step-end barrier publishes the values to the epilogue)
-    float* s_ep = smem + 2 * C::BUF_FLOATS;
-    auto stage_ep = [&](const Tile& T) {
-        if (tid < 2 * TN) {
-            const int c = tid < TN ? tid : tid - TN;
-            const int cu = T.ct * TN + c;
-            const int eoff = (d.ebatch ? T.n * Cr : 0) + (d.shuffle ? cu % Cr : cu);
-            float v;
-            if (tid < TN) v = d.escale ? d.escale[eoff] : 1.0f;
-            else v = d.eshift ? d.eshift[eoff] : 0.0f;
-            s_ep[tid] = v;
-        }
-    };
-    // epilogue: v = acc*escale + eshift ; act ; + residual ; 16-byte stores
-    auto epilogue = [&](const Tile& T) {
-        const bool col_ok = T.ox0 + li < d.Wo;
-#pragma unroll
-        for (int nn = 0; nn < C::NW; ++nn) {
-            const int cu = T.ct * TN + nn * 32;
-            // scale / shift of this tile's channels were staged in LDS during the last step (stage_ep)
-            f32x4 es[4], et[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                es[g] = *(const f32x4*)(s_ep + nn * 32 + 8 * g + 4 * lh);
-                et[g] = *(const f32x4*)(s_ep + TN + nn * 32 + 8 * g + 4 * lh);
-            }
-#pragma unroll
-            for (int m = 0; m < C::MW; ++m) {
-                const bool ok = col_ok && (T.oy0 + wave_u * C::MW + m < d.Ho);
-                float* op = d.dst + out_ubase(T, m, nn) + lane_off;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = fmaf(acc[m][nn][4 * g + e], es[g][e], et[g][e]);
-                        if (d.post_act == 1) x = silu_fast(x);
-                        else if (d.post_act == 2) x = x > 0.0f ? x : x * d.slope;
-                        if (RESPF && d.res) x += rres[m][nn][g][e];
-                        v[e] = x;
-                    }
-                    if (ok) {
-                        if (!RESPF && d.res) { const f32x4 rv = *(const f32x4*)(d.res + (op - d.dst) + 8 * g); v += rv; }
-                        *(f32x4*)(op + 8 * g) = v;
-                    }
-                }
-            }
-        }
-    };
-
     int tile = lslot;                            // logical tile of round 0 (the launch guarantees tile < total)
     if (tile >= total) return;
-    Tile cur, ld;                                // tile being computed / tile whose chunks are being loaded
+    Tile cur, ld, prev;                          // tile being computed / being loaded / awaiting its epilogue
     decode(tile, cur);
     ld = cur;
-    int ch = 0, pb = 0;
+    prev = cur;
+    int ch = 0, pb = 0, par = 0, ppar = 0;
+    bool pend = false;
+    // single-step tiles finish their epilogue at once; the memory-bound 1x1 kernels (two workgroups per CU, half the
+    // register budget) never defer
+    const bool defer = KS != 1 && nchunk >= 2;
     zero_acc();
     issue_loads(cur, 0, smem);
     write_lds(smem);
@@ -329,13 +347,33 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
         // chunk of the current tile), so the step body has no data-dependent branch.
         if (last_ch) {
             if (has_next) decode(ntile, ld);
-            if (RESPF && d.res) prefetch_res(cur);
-            stage_ep(cur);
+            stage_ep(cur, par);
+            if (KS != 1 && defer && d.res) load_res(cur);      // residual of this tile: needed by its (deferred) epilogue
         }
-        mfma_step(buf, obuf, ld, nch);
+        if constexpr (KS != 1) {
+            if (pend) mfma_step(IntC<1>{}, buf, obuf, ld, nch, prev, ppar);
+            else mfma_step(IntC<0>{}, buf, obuf, ld, nch, prev, ppar);
+        } else {
+            mfma_step(IntC<0>{}, buf, obuf, ld, nch, prev, ppar);
+        }
+        pend = false;
         __syncthreads();
         if (last_ch) {
-            if ((YOND_ABL & 4) == 0 && ((YOND_ABL & 8) == 0 || d.N < 0)) epilogue(cur);
+            if (KS != 1 && defer) {
+                if constexpr (KS != 1) {
+#pragma unroll
+                    for (int m = 0; m < C::MW; ++m)
+#pragma unroll
+                        for (int nn = 0; nn < C::NW; ++nn) eacc[m][nn] = acc[m][nn];
+                }
+                prev = cur;
+                ppar = par;
+                pend = true;
+            } else {
+                if (d.res) load_res(cur);
+                if ((YOND_ABL & 4) == 0) epilogue_from(cur, acc, par);
+            }
+            par ^= 1;
             zero_acc();
             cur = ld;
         }
@@ -343,6 +381,11 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
         tile = ntile;
         ch = nch;
         pb ^= 1;
+    }
+    if constexpr (KS != 1) {
+        if (pend) {                              // the last tile's epilogue has no next step to hide in
+            if ((YOND_ABL & 4) == 0) epilogue_from(prev, eacc, ppar);
+        }
     }
 }
 
@@ -423,6 +466,7 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
         if (d.Ho != (d.H + 1) / 2 || d.Wo != (d.W + 1) / 2) return YOND_EINVAL;
     } else if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
     if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;
+    if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;      // SiLU runs in the consumer's prologue (pre_act)
     if (d.pre_act == 1 && !(d.ksize == 3 && d.stride == 1)) return YOND_EUNSUPPORTED;
     if (d.ksize == 3 && d.stride == 1) {
         if (d.pre_act) return tn == 64 ? launch_conv<3, 1, 8, 64, 16, true>(d, st) : launch_conv<3, 1, 8, 32, 16, true>(d, st);

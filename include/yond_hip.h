@@ -105,6 +105,7 @@ typedef struct YondConvDesc {
     const float* res;     /* residual, same shape as dst, or NULL */
     float* dst;           /* [N][Ho][Wo][Cout]  (shuffle: see above) */
     int tn;               /* channel-tile width the weights were packed for (32 or 64, from yond_conv_config) */
+    int kc;               /* channel chunk the weights were packed for (8 or 16, from yond_conv_config; 0 = default) */
 } YondConvDesc;
 
 /* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.

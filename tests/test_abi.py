@@ -42,7 +42,11 @@ def test_host_side_argument_checks_without_gpu():
     assert lib.yond_conv_config(3, 1, 24, 64, 0, 0, 0, 0, ctypes.byref(tn), ctypes.byref(kc)) == -2
     # deepest level of cfg 2 (94 x 126, 512 ch): 384 tiles of width 64 would leave half the last round idle
     assert lib.yond_conv_config(3, 1, 512, 512, 0, 1, 94, 126, ctypes.byref(tn), ctypes.byref(kc)) == 0 and tn.value == 32
-    assert lib.yond_conv_config(3, 1, 256, 256, 0, 1, 188, 252, ctypes.byref(tn), ctypes.byref(kc)) == 0 and tn.value == 64
+    assert (tn.value, kc.value) == (32, 16)            # config A: one persistent workgroup per CU, 768 tiles = 3 rounds
+    # level 3 (188 x 252, 256 ch): 1536 tiles of width 32 fill the 512 slots of config B (two workgroups per CU) exactly
+    assert lib.yond_conv_config(3, 1, 256, 256, 0, 1, 188, 252, ctypes.byref(tn), ctypes.byref(kc)) == 0
+    assert (tn.value, kc.value) == (32, 8)
+    assert lib.yond_conv_config(3, 1, 32, 32, 0, 1, 1504, 2016, ctypes.byref(tn), ctypes.byref(kc)) == 0 and (tn.value, kc.value) == (32, 8)
     # null pointers are rejected before any launch
     assert lib.yond_pack_vst_norm_f32(None, 4, 4, None, 0, 0, 0, 0, 1, 1.0, 1.0, 0.0, 0.0, 1.0, None, None, 0, None, None) == -1
     assert lib.yond_conv2d_f32(None, None) == -1

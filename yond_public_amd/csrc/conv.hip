@@ -63,8 +63,12 @@ __device__ __forceinline__ float silu_fast(float x) {
 
 // 3x3: one workgroup per CU (its own MFMAs hide its memory traffic); 1x1 / transposed convolutions are memory
 // bound (K = Cin only), so they run two workgroups per CU for more loads in flight.
+template <int KS, int STRIDE, int KC>
+constexpr int conv_wgs_per_cu() { return (KS == 1 || (KS == 3 && STRIDE == 1 && KC == 8)) ? 2 : 1; }
+
 template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE>
-__global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const YondConvDesc d) {
+__global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC>())) void conv_mfma_kernel(const YondConvDesc d) {
+    constexpr bool CAN_DEFER = conv_wgs_per_cu<KS, STRIDE, KC>() == 1;     // two workgroups per CU cover each other's epilogues
     using C = ConvCfg<KS, STRIDE, TH, TN, KC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
     bool pend = false;
     // single-step tiles finish their epilogue at once; the memory-bound 1x1 kernels (two workgroups per CU, half the
     // register budget) never defer
-    const bool defer = KS != 1 && nchunk >= 2;
+    const bool defer = CAN_DEFER && nchunk >= 2;
     zero_acc();
     issue_loads(cur, 0, smem);
     write_lds(smem);
@@ -348,9 +352,9 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
         if (last_ch) {
             if (has_next) decode(ntile, ld);
             stage_ep(cur, par);
-            if (KS != 1 && defer && d.res) load_res(cur);      // residual of this tile: needed by its (deferred) epilogue
+            if (CAN_DEFER && defer && d.res) load_res(cur);      // residual of this tile: needed by its (deferred) epilogue
         }
-        if constexpr (KS != 1) {
+        if constexpr (CAN_DEFER) {
             if (pend) mfma_step(IntC<1>{}, buf, obuf, ld, nch, prev, ppar);
             else mfma_step(IntC<0>{}, buf, obuf, ld, nch, prev, ppar);
         } else {
@@ -359,8 +363,8 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
         pend = false;
         __syncthreads();
         if (last_ch) {
-            if (KS != 1 && defer) {
-                if constexpr (KS != 1) {
+            if (CAN_DEFER && defer) {
+                if constexpr (CAN_DEFER) {
 #pragma unroll
                     for (int m = 0; m < C::MW; ++m)
 #pragma unroll
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void conv_mfma_kernel(const Y
         ch = nch;
         pb ^= 1;
     }
-    if constexpr (KS != 1) {
+    if constexpr (CAN_DEFER) {
         if (pend) {                              // the last tile's epilogue has no next step to hide in
             if ((YOND_ABL & 4) == 0) epilogue_from(prev, eacc, ppar);
         }
@@ -401,31 +405,51 @@ static int launch_conv(const YondConvDesc& d, hipStream_t st) {
     }
     const long long total = (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
     if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
-    const int slots = 256 * (KS == 1 ? 2 : 1);                 // persistent workgroups: one (3x3) or two (1x1) per CU
+    const int slots = 256 * conv_wgs_per_cu<KS, STRIDE, KC>();   // persistent workgroups per CU: see conv_wgs_per_cu
     const int grid = total < slots ? (int)total : slots;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::SMEM_BYTES, st, d);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
 
-static int conv_kc(int ksize, int stride) { return (ksize == 3 && stride == 2) ? 8 : 16; }
-
+// Tile configuration.  3x3 stride-1 layers choose between
+//   A: 16-channel chunks, one persistent workgroup per CU, deferred epilogue   (long K loops)
+//   B:  8-channel chunks, two workgroups per CU covering each other's bubbles   (measured +8 % where it fits)
+// and between 32- / 64-wide channel tiles, by how well the tile count fills the last round of the persistent
+// grid (256 or 512 slots).  The factors are measured relative throughputs on MI355X (tools/conv_bench.py).
 extern "C" int yond_conv_config(int ksize, int stride, int cin, int cout, int shuffle, int N, int Ho, int Wo, int* tn,
                                 int* kc) {
     if (!((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1))) return YOND_EUNSUPPORTED;
-    const int k = conv_kc(ksize, stride);
-    if (cout % 32 != 0 || cin % k != 0 || cin <= 0 || cout <= 0) return YOND_EUNSUPPORTED;
+    int k = (ksize == 3 && stride == 2) ? 8 : 16;
+    if (cout % 32 != 0 || cin % 16 != 0 || cin <= 0 || cout <= 0) return YOND_EUNSUPPORTED;
     if (shuffle && (ksize != 1 || cout % 128 != 0)) return YOND_EUNSUPPORTED;
     const int ntile = shuffle ? cout / 4 : cout;      // a channel tile must not straddle two sub-positions
     int t = (ntile % 64 == 0) ? 64 : 32;
-    if (t == 64 && N > 0 && Ho > 0 && Wo > 0) {
-        // persistent grid of 256 workgroups: prefer the tile width that fills the last round
+    if (N > 0 && Ho > 0 && Wo > 0) {
         const long long px = (long long)N * ((Ho + 7) / 8) * ((Wo + 31) / 32);
-        const long long t64 = px * (cout / 64), t32 = px * (cout / 32);
-        const double e64 = (double)t64 / (double)(((t64 + 255) / 256) * 256);
-        const double e32 = (double)t32 / (double)(((t32 + 255) / 256) * 256);
-        if (e64 < 0.85 && e32 > e64 + 0.1) t = 32;
+        auto fill = [&](int tw, int slots) {
+            const long long tiles = px * (cout / tw);
+            return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots);
+        };
+        if (ksize == 3 && stride == 1) {
+            double best = -1.0;
+            const int tws[2] = {64, 32};
+            for (int i = 0; i < 2; ++i) {
+                if (ntile % tws[i] != 0) continue;
+                const double sa = fill(tws[i], 256) * (tws[i] == 64 ? 1.00 : 0.97);
+                const double sb = fill(tws[i], 512) * (tws[i] == 64 ? 1.08 : 1.05);
+                if (sa > best) { best = sa; t = tws[i]; k = 16; }
+                if (sb > best) { best = sb; t = tws[i]; k = 8; }
+            }
+        } else if (t == 64) {
+            const int slots = ksize == 1 ? 512 : 256;
+            if (fill(64, slots) < 0.85 && fill(32, slots) > fill(64, slots) + 0.1) t = 32;
+        }
     }
+    static const char* ekc = getenv("YOND_CONV_KC");            // experiments only
+    static const char* etn = getenv("YOND_CONV_TN");
+    if (ekc && ksize == 3 && stride == 1) k = atoi(ekc) == 8 ? 8 : 16;
+    if (etn && ksize == 3 && stride == 1 && ntile % 64 == 0) t = atoi(etn) == 32 ? 32 : 64;
     if (tn) *tn = t;
     if (kc) *kc = k;
     return YOND_OK;
@@ -458,7 +482,11 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     int tn, kc;
     const int rc = yond_conv_config(d.ksize, d.stride, d.C0 + d.C1, d.Cout, d.shuffle, 0, 0, 0, &tn, &kc);
     if (rc != YOND_OK) return rc;
-    tn = d.tn;                                           // the width the weights were packed for
+    tn = d.tn;                                           // the layout the weights were packed for
+    if (d.kc != 0) kc = d.kc;
+    if (kc != 8 && kc != 16) return YOND_EINVAL;
+    if (kc == 8 && d.ksize != 3) return YOND_EINVAL;
+    if (d.ksize == 3 && d.stride == 2 && kc != 8) return YOND_EINVAL;
     if (d.C0 % kc != 0 || d.C1 % kc != 0 || d.Cout % tn != 0) return YOND_EUNSUPPORTED;
     if (d.shuffle && (d.ksize != 1 || (d.Cout / 4) % tn != 0)) return YOND_EUNSUPPORTED;
     if ((long long)d.N * d.H * d.W > 0x7fffffffLL) return YOND_EUNSUPPORTED;    // 32-bit pixel offsets
@@ -468,6 +496,10 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;
     if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;      // SiLU runs in the consumer's prologue (pre_act)
     if (d.pre_act == 1 && !(d.ksize == 3 && d.stride == 1)) return YOND_EUNSUPPORTED;
+    if (d.ksize == 3 && d.stride == 1 && kc == 8) {
+        if (d.pre_act) return tn == 64 ? launch_conv<3, 1, 8, 64, 8, true>(d, st) : launch_conv<3, 1, 8, 32, 8, true>(d, st);
+        return tn == 64 ? launch_conv<3, 1, 8, 64, 8, false>(d, st) : launch_conv<3, 1, 8, 32, 8, false>(d, st);
+    }
     if (d.ksize == 3 && d.stride == 1) {
         if (d.pre_act) return tn == 64 ? launch_conv<3, 1, 8, 64, 16, true>(d, st) : launch_conv<3, 1, 8, 32, 16, true>(d, st);
         return tn == 64 ? launch_conv<3, 1, 8, 64, 16, false>(d, st) : launch_conv<3, 1, 8, 32, 16, false>(d, st);

@@ -81,12 +81,13 @@ class _PackedConv:
         tn, kc = C.c_int(), C.c_int()
         L.check(lib.yond_conv_config(self.ksize, self.stride, self.cinp, self.gemm_n, int(self.shuffle), N, Ho, Wo,
                                      C.byref(tn), C.byref(kc)), "yond_conv_config")
-        if tn.value not in self._packed:
+        key = (tn.value, kc.value)
+        if key not in self._packed:
             packed = np.empty(self._wp.size, np.float32)
             L.check(lib.yond_pack_conv_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn.value, kc.value,
                                                   _np_ptr(packed)), "yond_pack_conv_weight_f32")
-            self._packed[tn.value] = torch.from_numpy(packed).to(self._dev)
-        return tn.value, kc.value, self._packed[tn.value]
+            self._packed[key] = torch.from_numpy(packed).to(self._dev)
+        return tn.value, kc.value, self._packed[key]
 
 
 class DenoiserPlan:
@@ -189,6 +190,7 @@ class DenoiserPlan:
         tn, kc, wpk = pc.config(N, d.Ho, d.Wo)
         d.wpk = wpk.data_ptr()
         d.tn = tn
+        d.kc = kc
         d.escale = escale.data_ptr() if escale is not None else None
         d.eshift = (eshift if eshift is not None else pc.bias).data_ptr()
         d.ebatch = ebatch

@@ -18,34 +18,46 @@
 #define BX_RH (BX_TH + 2 * BX_R)
 #define BX_RW (BX_TW + 2 * BX_R)
 
-// Window sums of one quantity for this thread's 8 outputs: rows (tid>>6) + 4*i, column tid&63.
+// Window sums of one quantity for this thread's 8 outputs: rows 8*(tid>>6) + i (i = 0..7), column tid&63.
 // s_src: float [BX_RH][BX_RW] (tile with halo BX_R), s_h: double [BX_RH][BX_TW] scratch.
+// Both passes slide the window (sum += entering - leaving) over runs of 8 outputs: 29+14 LDS reads per run
+// instead of 8*29.  float32 data summed in float64: the window sums are exact (or differ from a direct sum
+// by ~1e-16 relative for the squares), far below the float32 rounding that follows.
 __device__ __forceinline__ void window_sums(const float* s_src, bool square, int k, double* s_h, double out[8]) {
     const int tid = threadIdx.x;
     const int rk = k / 2;
     const int off = BX_R - rk;                       // first tile row/col that the window of output 0 touches
     const int nrows = BX_TH + 2 * rk;
     __syncthreads();                                 // previous user of s_h is done
-    for (int it = tid; it < nrows * BX_TW; it += 256) {
-        const int row = it / BX_TW + off, col = it % BX_TW;
-        const float* p = s_src + row * BX_RW + col + off;
+    for (int it = tid; it < nrows * (BX_TW / 8); it += 256) {
+        const int row = it / (BX_TW / 8) + off, c0 = (it % (BX_TW / 8)) * 8;
+        const float* p = s_src + row * BX_RW + c0 + off;
+        double* o = s_h + row * BX_TW + c0;
         double s = 0.0;
         if (square) {
             for (int d = 0; d < k; ++d) { const float v = p[d]; s += (double)__fmul_rn(v, v); }
+            o[0] = s;
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                const float vn = p[j + k - 1], vo = p[j - 1];
+                s += (double)__fmul_rn(vn, vn) - (double)__fmul_rn(vo, vo);
+                o[j] = s;
+            }
         } else {
             for (int d = 0; d < k; ++d) s += (double)p[d];
+            o[0] = s;
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { s += (double)p[j + k - 1] - (double)p[j - 1]; o[j] = s; }
         }
-        s_h[row * BX_TW + col] = s;
     }
     __syncthreads();
     const int col = tid & 63, rg = tid >> 6;
+    const double* q = s_h + (rg * 8 + off) * BX_TW + col;
+    double s = 0.0;
+    for (int d = 0; d < k; ++d) s += q[d * BX_TW];
+    out[0] = s;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = rg + 4 * i + off;
-        double s = 0.0;
-        for (int d = 0; d < k; ++d) s += s_h[(row + d) * BX_TW + col];
-        out[i] = s;
-    }
+    for (int i = 1; i < 8; ++i) { s += q[(i + k - 1) * BX_TW] - q[(i - 1) * BX_TW]; out[i] = s; }
 }
 
 __device__ __forceinline__ float blur_round(double s, int k) { return (float)(s * (1.0 / (double)(k * k))); }
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(256) void box_stats_kernel(BoxSrc a, BoxSrc b, int 
     const int ox = ox0 + col;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int oy = oy0 + rg + 4 * i;
+        const int oy = oy0 + rg * 8 + i;
         if (oy >= h || ox >= w) continue;
         const size_t idx = ((size_t)plane * h + oy) * w + ox;
         if (MODE == 0) {
@@ -212,7 +224,6 @@ __global__ void sel_init_kernel(SelState* st, SelRanks ranks, int nt) {
     const int t = threadIdx.x;
     if (t < nt) { st->tgt_prefix[t] = 0; st->tgt_rank[t] = ranks.r[t]; st->tgt_slot[t] = 0; }
     if (t == 0) { st->nslots = 1; st->slot_prefix[0] = 0; st->nt = nt; }
-    for (int i = t; i < SEL_MAXT * 256; i += blockDim.x) st->hist[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__ data, size_t n, SelState* st, int pass) {
@@ -279,27 +290,34 @@ __global__ __launch_bounds__(256) void sel_resolve_kernel(SelState* st, int pass
         }
     }
     __syncthreads();
+    __shared__ unsigned int s_slot[SEL_MAXT];
+    __shared__ int s_ns;
     if (tid == 0 && pass < 3) {
-        // sorted distinct prefixes -> slots
+        // sorted distinct prefixes -> slots (in LDS; <= 64 entries)
         int ns = 0;
         for (int i = 0; i < nt; ++i) {
             const unsigned int p = s_newp[i];
             int pos = 0;
-            while (pos < ns && st->slot_prefix[pos] < p) ++pos;
-            if (pos < ns && st->slot_prefix[pos] == p) continue;
-            for (int j = ns; j > pos; --j) st->slot_prefix[j] = st->slot_prefix[j - 1];
-            st->slot_prefix[pos] = p;
+            while (pos < ns && s_slot[pos] < p) ++pos;
+            if (pos < ns && s_slot[pos] == p) continue;
+            for (int j = ns; j > pos; --j) s_slot[j] = s_slot[j - 1];
+            s_slot[pos] = p;
             ++ns;
         }
-        st->nslots = ns;
-        for (int i = 0; i < nt; ++i) {
-            int pos = 0;
-            while (st->slot_prefix[pos] != s_newp[i]) ++pos;
-            st->tgt_slot[i] = pos;
-        }
+        s_ns = ns;
     }
     __syncthreads();
-    for (int i = tid; i < SEL_MAXT * 256; i += blockDim.x) st->hist[i] = 0;
+    if (pass < 3) {
+        const int ns = s_ns;
+        if (tid == 0) st->nslots = ns;
+        if (tid < ns) st->slot_prefix[tid] = s_slot[tid];
+        if (tid < nt) {
+            int pos = 0;
+            while (s_slot[pos] != s_newp[tid]) ++pos;
+            st->tgt_slot[tid] = pos;
+        }
+    }
+    // the histograms are cleared by the memset that the host function queues before the next pass
 }
 
 struct LerpArgs { double t[SEL_MAXT / 2]; };
@@ -340,6 +358,8 @@ static int select_ranks(const float* data, size_t n, const long long* ranks, int
         attr = true;
     }
     for (int pass = 0; pass < 4; ++pass) {
+        hipError_t me = hipMemsetAsync(state->hist, 0, sizeof(unsigned int) * SEL_MAXT * 256, st);
+        if (me != hipSuccess) return (int)me;
         hipLaunchKernelGGL(sel_hist_kernel, dim3((unsigned)nb), dim3(256), SEL_MAXT * 256 * 4, st, data, n, state, pass);
         YOND_LAUNCH_CHECK();
         hipLaunchKernelGGL(sel_resolve_kernel, dim3(1), dim3(256), 0, st, state, pass, out);

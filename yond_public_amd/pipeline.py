@@ -251,42 +251,51 @@ def _plan_of(net, device):
 
 
 def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type='exact', clip01=False, device=None):
-    """YOND_SIDD.py:250-299 for the network denoisers.  lr_raw: Bayer [H][W]; p: dict with scale, gain,
-    sigma; returns the denoised Bayer frame (device tensor).  `clip01` folds the caller's .clip(0,1)."""
+    """YOND_SIDD.py:250-299 for the network denoisers.  lr_raw: Bayer [H][W] -- or a stack [B][H][W] of equally
+    sized frames that share (gain, sigma) and the bias LUT, e.g. the 32 blocks of a SIDD image, which then go
+    through ONE batched forward instead of the reference's 32 batch-1 calls (:398-407).  p: dict with scale,
+    gain, sigma; returns the denoised frame(s) as a device tensor.  `clip01` folds the caller's .clip(0,1)."""
     lib = L.load()
     lr = _dev(lr_raw, device)
-    H, W = lr.shape
+    single = lr.dim() == 2
+    if single:
+        lr = lr[None]
+    B, H, W = lr.shape
     h, w = H // 2, W // 2
     scale, gain, sigma = float(p['scale']), np.float64(p['gain']), np.float64(p['sigma'])
     if bias_corr not in (None, 'pre'):
         raise NotImplementedError(f"bias_corr={bias_corr!r} (the reference's 'post' branch is commented out)")
     if bias_corr is not None and bias_func is None:
+        if not single:
+            raise L.YondHipError("a stack of frames needs the shared bias LUT (the reference builds one per image, :392-397)")
         mx = np.float32(lr.max().item()) * np.float32(scale)      # lr_rggb.max() of the float32 product
         bias_func = get_bias(mx, sigma, gain, device=lr.device)
     lower, upper = vst_scalar(0, sigma, gain), vst_scalar(scale, sigma, gain)
     nsr = 1 / (upper - lower)
     p2d = get_p2d((1, 4, h, w), base=32)
     Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
-    x4 = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=lr.device)
-    img_max = torch.empty(1, dtype=torch.float32, device=lr.device)
+    x4 = torch.empty((B, Hp, Wp, 4), dtype=torch.float32, device=lr.device)
+    img_max = torch.empty(B, dtype=torch.float32, device=lr.device)
     st = L.stream()
     lut_n = len(bias_func) if bias_corr is not None else 0
-    L.check(lib.yond_pack_vst_norm_f32(L.ptr(lr), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], 1, scale, float(gain),
-                                       float(sigma), float(lower), float(upper),
-                                       L.ptr(bias_func.x) if lut_n else None, L.ptr(bias_func.y) if lut_n else None, lut_n,
-                                       L.ptr(img_max), st), "yond_pack_vst_norm_f32")
+    for i in range(B):
+        L.check(lib.yond_pack_vst_norm_f32(L.ptr(lr[i]), H, W, L.ptr(x4[i]), p2d[0], p2d[1], p2d[2], p2d[3], 1, scale, float(gain),
+                                           float(sigma), float(lower), float(upper),
+                                           L.ptr(bias_func.x) if lut_n else None, L.ptr(bias_func.y) if lut_n else None, lut_n,
+                                           L.ptr(img_max[i:i + 1]), st), "yond_pack_vst_norm_f32")
     plan = _plan_of(net, lr.device)
     t_dev = None
     if 'guided' in arch:
         sigma_corr = 1.03 if bias_corr == 'pre' else 1.00
-        t_dev = torch.full((1,), float(np.float32(nsr * sigma_corr)), dtype=torch.float32, device=lr.device)
+        t_dev = torch.full((B,), float(np.float32(nsr * sigma_corr)), dtype=torch.float32, device=lr.device)
     y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
-    out = torch.empty((H, W), dtype=torch.float32, device=lr.device)
+    out = torch.empty((B, H, W), dtype=torch.float32, device=lr.device)
     exact_inverse = bias_corr is None and vst_type == 'exact'
-    L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 2 if exact_inverse else 1,
-                                            scale, float(gain), float(sigma), float(lower), float(upper), int(clip01), st),
-            "yond_denorm_ivst_unpack_f32")
-    return out
+    for i in range(B):
+        L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4[i]), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out[i]), 2 if exact_inverse else 1,
+                                                scale, float(gain), float(sigma), float(lower), float(upper), int(clip01), st),
+                "yond_denorm_ivst_unpack_f32")
+    return out[0] if single else out
 
 
 def Simple_Denoiser(lr_raw, net, device=None):
@@ -357,8 +366,11 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     def denoise_all(bias_func):
         if full_dn:                                                                    # :387-389
             return VST_Denoiser(lr_cat, p, net, arch, bias_corr, bias_func, vst_type, clip01=True)
-        outs = [VST_Denoiser(blocks[num], p, net, arch, bias_corr, bias_func, vst_type, clip01=True) for num in range(32)]
-        return torch.cat(outs, dim=-1).contiguous()                                    # :398-408
+        if bias_corr is not None:
+            outs = VST_Denoiser(blocks, p, net, arch, bias_corr, bias_func, vst_type, clip01=True)   # one batch-32 forward
+        else:                                  # no shared LUT: per-block calls as the reference does (:398-407)
+            outs = [VST_Denoiser(blocks[num], p, net, arch, bias_corr, bias_func, vst_type, clip01=True) for num in range(32)]
+        return torch.cat(list(outs), dim=-1).contiguous()                              # :408
 
     bias_func = None
     if sidd and bias_corr is not None:

@@ -27,6 +27,9 @@
 #include "common.h"
 #include <cstdlib>
 
+#ifndef YOND_B32_WGS
+#define YOND_B32_WGS 2      // workgroups per CU of the (tn 32, kc 8) 3x3 configuration
+#endif
 #ifndef YOND_ABL
 #define YOND_ABL 0      // timing-only ablations (bit 0: no weight DMA, bit 1: no input staging, bit 2: no epilogue stores)
 #endif
@@ -63,12 +66,15 @@ __device__ __forceinline__ float silu_fast(float x) {
 
 // 3x3: one workgroup per CU (its own MFMAs hide its memory traffic); 1x1 / transposed convolutions are memory
 // bound (K = Cin only), so they run two workgroups per CU for more loads in flight.
-template <int KS, int STRIDE, int KC>
-constexpr int conv_wgs_per_cu() { return (KS == 1 || (KS == 3 && STRIDE == 1 && KC == 8)) ? 2 : 1; }
+template <int KS, int STRIDE, int KC, int TN>
+constexpr int conv_wgs_per_cu() {
+    if (KS == 3 && STRIDE == 1 && KC == 8) return TN == 32 ? YOND_B32_WGS : 2;
+    return KS == 1 ? 2 : 1;
+}
 
 template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE>
-__global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC>())) void conv_mfma_kernel(const YondConvDesc d) {
-    constexpr bool CAN_DEFER = conv_wgs_per_cu<KS, STRIDE, KC>() == 1;     // two workgroups per CU cover each other's epilogues
+__global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void conv_mfma_kernel(const YondConvDesc d) {
+    constexpr bool CAN_DEFER = conv_wgs_per_cu<KS, STRIDE, KC, TN>() == 1;     // two workgroups per CU cover each other's epilogues
     using C = ConvCfg<KS, STRIDE, TH, TN, KC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -405,7 +411,7 @@ static int launch_conv(const YondConvDesc& d, hipStream_t st) {
     }
     const long long total = (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
     if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
-    const int slots = 256 * conv_wgs_per_cu<KS, STRIDE, KC>();   // persistent workgroups per CU: see conv_wgs_per_cu
+    const int slots = 256 * conv_wgs_per_cu<KS, STRIDE, KC, TN>();   // persistent workgroups per CU: see conv_wgs_per_cu
     const int grid = total < slots ? (int)total : slots;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::SMEM_BYTES, st, d);
     YOND_LAUNCH_CHECK();

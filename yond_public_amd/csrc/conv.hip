@@ -50,7 +50,7 @@ struct ConvCfg {
     static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
     static constexpr int NW = TN / 32;
     static constexpr int MW = TH / 4;
-    static constexpr int EP_FLOATS = 2 * TN;              // epilogue scale / shift vectors of the current tile
+    static constexpr int EP_FLOATS = 4 * TN;              // epilogue scale / shift vectors, double-buffered by tile parity
     static constexpr int SMEM_BYTES = (2 * BUF_FLOATS + EP_FLOATS) * 4;
     static constexpr int SL = KC / 4;
     static constexpr int NITEM = IH * IW * SL;

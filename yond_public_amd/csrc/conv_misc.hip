@@ -54,21 +54,27 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
         for (int m = 0; m < MW; ++m) {
             const f32x4 a = *(const f32x4*)(s_in + ((wave * MW + m + dy) * IW + li + dx) * 4);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bb[t], acc[m], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[t], a[t], acc[m], 0, 0, 0);   // D = W . X^T
         }
     }
-    const int co = ct * 32 + li;
-    const float bv = bias ? bias[co] : 0.0f;
+    // D rows = output channels (r&3) + 8*(r>>2) + 4*lh, column = pixel li: four 16-byte stores per lane
+    const int ox = ox0 + li;
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int oy = oy0 + wave * MW + m;
+        if (oy < H && ox < W) {
+            float* op = dst + ((size_t)(n * H + oy) * W + ox) * Cout + ct * 32 + 4 * lh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (oy < H && ox < W) {
-                float v = acc[m][r] + bv;
-                v = v > 0.0f ? v : v * slope;
-                dst[((size_t)(n * H + oy) * W + ox) * Cout + co] = v;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4 bv = bias ? *(const f32x4*)(bias + ct * 32 + 4 * lh + 8 * g) : zero;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = acc[m][4 * g + e] + bv[e];
+                    v[e] = x > 0.0f ? x : x * slope;
+                }
+                *(f32x4*)(op + 8 * g) = v;
             }
         }
     }

@@ -99,6 +99,25 @@ def test_select_handles_negative_and_zero_values():
     assert np.array_equal(got, np.percentile(a, q, method='linear'))
 
 
+@pytest.mark.parametrize("off", [0, 1, 2, 3])
+def test_select_unaligned_large_and_constant(off):
+    """Edge cases of the three-level select: a data pointer that is not 16-byte aligned, values outside the
+    [0, 2) LDS window (negative, large), and constant data (every element in one bin)."""
+    from yond_public_amd import pipeline as P
+    rng = np.random.default_rng(30 + off)
+    n = 70001
+    a = (rng.standard_normal(n + off) * np.float32(3.0)).astype(np.float32)
+    a[100:200] = 1e6
+    a[200:260] = -1e-30
+    t = torch.from_numpy(a).to(DEV)[off:]
+    q = [0.0, 1.0, 33.3, 50.0, 75.0, 99.99, 100.0]
+    got = P._percentiles(t, q).cpu().numpy()
+    assert np.array_equal(got, np.percentile(a[off:], q, method='linear'))
+    c = torch.full((50003 + off,), 0.0123, device=DEV)[off:]
+    got = P._percentiles(c, q).cpu().numpy()
+    assert np.array_equal(got, np.full(len(q), np.float64(np.float32(0.0123))))
+
+
 def test_accumulate_matches_numpy():
     from yond_public_amd import pipeline as P
     rng = np.random.default_rng(4)

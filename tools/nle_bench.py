@@ -20,3 +20,17 @@ for k2 in (19, 29, 9):
     print("self1 k2=%d: %.1f us" % (k2, t(lambda: lib.yond_box_stats_self1_f32(L.ptr(x), H, W, 29, k2, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.stream()))))
 print("self2: %.1f us" % t(lambda: lib.yond_box_stats_self2_f32(L.ptr(o[2]), h, w, 29, 0, L.ptr(o[3]), L.stream())))
 print("collab: %.1f us" % t(lambda: lib.yond_box_stats_collab_f32(L.ptr(x), L.ptr(x), H, W, 29, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.stream())))
+
+import numpy as np
+from yond_public_amd import pipeline as P
+import yond_public_amd.synthetic as S
+noisy = S.synth_noisy(H, W, 4.0, 6.0, 0)[0] if hasattr(S, 'synth_noisy') else None
+if noisy is not None:
+    xb = torch.from_numpy(noisy).cuda()
+    lib.yond_box_stats_self1_f32(L.ptr(xb), H, W, 29, 19, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.stream())
+    lib.yond_box_stats_self2_f32(L.ptr(o[2]), h, w, 29, 0, L.ptr(o[3]), L.stream())
+lap, mean, var = o[3].reshape(-1), o[0].reshape(-1), o[1].reshape(-1)
+q = np.linspace(5, 100, 20)
+print("percentiles(20): %.1f us" % t(lambda: P._percentiles(lap, q)))
+ths = P._percentiles(lap, q)
+print("accumulate: %.1f us" % t(lambda: P._accumulate(lap, mean, var, ths)))

@@ -2,8 +2,7 @@
 //   K5  box statistics: cv2.blur semantics (normalised k x k window, BORDER_REFLECT_101), window sums in
 //       float64 (the float32 inputs make them exact), every intermediate rounded to float32 exactly where
 //       NumPy / OpenCV round (no fused multiply-adds across those points).
-//   K6  exact order statistics by 4-pass radix select (8 bits per pass, LDS-privatised histograms, all
-//       requested ranks at once) + np.percentile's linear interpolation.
+//   K6  exact order statistics + np.percentile's linear interpolation: nle_select.hip.
 //   K7  one pass over (lap, mean, var): occupancy of the 1/1000 mean bins per threshold bucket and the five
 //       moment sums of the least-squares line per bucket.
 // All of it is integer / streaming work bound by HBM and LDS, not MFMA.
@@ -193,212 +192,6 @@ extern "C" int yond_box_stats_collab_f32(const float* bayer_lr, const float* bay
     if (rc) return rc;
     BoxSrc a{bayer_lr, 1}, b{bayer_hr, 1};
     return launch_box<2>(a, b, H / 2, W / 2, k, k, tile_w, mean, var, lap, (hipStream_t)stream);
-}
-
-// =====================================================================================================
-// K6: multi-rank radix select + np.percentile(method='linear')
-// =====================================================================================================
-#define SEL_MAXT 64          // max number of order statistics per call
-
-struct SelState {
-    unsigned int tgt_prefix[SEL_MAXT];
-    long long tgt_rank[SEL_MAXT];      // remaining rank inside the target's prefix group
-    int tgt_slot[SEL_MAXT];
-    unsigned int slot_prefix[SEL_MAXT];
-    int nslots;
-    int nt;
-    unsigned int hist[SEL_MAXT * 256];
-};
-
-__device__ __forceinline__ unsigned int f2key(float f) {
-    const unsigned int b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);       // total order of floats as unsigned
-}
-__device__ __forceinline__ float key2f(unsigned int k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
-}
-
-struct SelRanks { long long r[SEL_MAXT]; };
-
-__global__ void sel_init_kernel(SelState* st, SelRanks ranks, int nt) {
-    const int t = threadIdx.x;
-    if (t < nt) { st->tgt_prefix[t] = 0; st->tgt_rank[t] = ranks.r[t]; st->tgt_slot[t] = 0; }
-    if (t == 0) { st->nslots = 1; st->slot_prefix[0] = 0; st->nt = nt; }
-}
-
-__global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__ data, size_t n, SelState* st, int pass) {
-    extern __shared__ unsigned int s_hist[];                 // [nslots][256]
-    __shared__ unsigned int s_pref[SEL_MAXT];
-    const int nslots = st->nslots;
-    for (int i = threadIdx.x; i < nslots * 256; i += 256) s_hist[i] = 0;
-    if (threadIdx.x < nslots) s_pref[threadIdx.x] = st->slot_prefix[threadIdx.x];
-    __syncthreads();
-    const int shift = 24 - 8 * pass;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const unsigned int key = f2key(data[i]);
-        int slot = 0;
-        if (pass > 0) {
-            const unsigned int pre = key >> (shift + 8);
-            int lo = 0, hi = nslots;                          // first index with s_pref >= pre
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid] < pre) lo = mid + 1; else hi = mid; }
-            slot = (lo < nslots && s_pref[lo] == pre) ? lo : -1;
-        }
-        if (slot >= 0) atomicAdd(&s_hist[slot * 256 + ((key >> shift) & 255u)], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nslots * 256; i += 256) {
-        const unsigned int c = s_hist[i];
-        if (c) atomicAdd(&st->hist[i], c);
-    }
-}
-
-__global__ __launch_bounds__(256) void sel_resolve_kernel(SelState* st, int pass, float* out_vals) {
-    __shared__ unsigned int s_newp[SEL_MAXT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = st->nt;
-    // one wave per target: lane l holds bins 4l..4l+3, wave-wide exclusive scan, first bin whose cumulative
-    // count exceeds the remaining rank
-    for (int t = wave; t < nt; t += 4) {
-        const unsigned int* h = st->hist + st->tgt_slot[t] * 256 + lane * 4;
-        const long long c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
-        const long long mine = c0 + c1 + c2 + c3;
-        long long incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const long long up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
-        }
-        const long long excl = incl - mine;
-        const long long rank = st->tgt_rank[t];
-        const bool here = rank >= excl && rank < incl;          // exactly one lane unless the data ran out
-        const unsigned long long m = __ballot(here);
-        const int src = m ? (__ffsll((long long)m) - 1) : 63;
-        int d;
-        long long cum;
-        if (rank < excl + c0) { d = 0; cum = excl; }
-        else if (rank < excl + c0 + c1) { d = 1; cum = excl + c0; }
-        else if (rank < excl + c0 + c1 + c2) { d = 2; cum = excl + c0 + c1; }
-        else { d = 3; cum = excl + c0 + c1 + c2; }
-        d = __shfl(d, src);
-        cum = __shfl(cum, src);
-        if (lane == 0) {
-            const unsigned int np = (st->tgt_prefix[t] << 8) | (unsigned int)(src * 4 + d);
-            st->tgt_rank[t] = rank - cum;
-            st->tgt_prefix[t] = np;
-            s_newp[t] = np;
-            if (pass == 3) out_vals[t] = key2f(np);
-        }
-    }
-    __syncthreads();
-    __shared__ unsigned int s_slot[SEL_MAXT];
-    __shared__ int s_ns;
-    if (tid == 0 && pass < 3) {
-        // sorted distinct prefixes -> slots (in LDS; <= 64 entries)
-        int ns = 0;
-        for (int i = 0; i < nt; ++i) {
-            const unsigned int p = s_newp[i];
-            int pos = 0;
-            while (pos < ns && s_slot[pos] < p) ++pos;
-            if (pos < ns && s_slot[pos] == p) continue;
-            for (int j = ns; j > pos; --j) s_slot[j] = s_slot[j - 1];
-            s_slot[pos] = p;
-            ++ns;
-        }
-        s_ns = ns;
-    }
-    __syncthreads();
-    if (pass < 3) {
-        const int ns = s_ns;
-        if (tid == 0) st->nslots = ns;
-        if (tid < ns) st->slot_prefix[tid] = s_slot[tid];
-        if (tid < nt) {
-            int pos = 0;
-            while (s_slot[pos] != s_newp[tid]) ++pos;
-            st->tgt_slot[tid] = pos;
-        }
-    }
-    // the histograms are cleared by the memset that the host function queues before the next pass
-}
-
-struct LerpArgs { double t[SEL_MAXT / 2]; };
-
-__global__ void percentile_lerp_kernel(const float* __restrict__ vals, LerpArgs a, int nq, double* __restrict__ out) {
-    const int i = threadIdx.x;
-    if (i >= nq) return;
-    // numpy _lerp: diff = b - a in the data dtype; a + diff*t (t < 0.5) or b - diff*(1-t) (t >= 0.5); b == a -> a
-    const float av = vals[2 * i], bv = vals[2 * i + 1];
-    const float diff = __fsub_rn(bv, av);
-    const double t = a.t[i];
-    double r = (t >= 0.5) ? __dsub_rn((double)bv, __dmul_rn((double)diff, 1.0 - t)) : __dadd_rn((double)av, __dmul_rn((double)diff, t));
-    if (bv == av) r = (double)av;
-    out[i] = r;
-}
-
-extern "C" size_t yond_select_ws_bytes(int nr) {
-    (void)nr;
-    return sizeof(SelState) + SEL_MAXT * sizeof(float) + 64;
-}
-
-static int select_ranks(const float* data, size_t n, const long long* ranks, int nr, float* out, void* ws, hipStream_t st) {
-    SelState* state = (SelState*)ws;
-    SelRanks rk;
-    for (int i = 0; i < nr; ++i) {
-        if (ranks[i] < 0 || (size_t)ranks[i] >= n) return YOND_EINVAL;
-        rk.r[i] = ranks[i];
-    }
-    hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(256), 0, st, state, rk, nr);
-    YOND_LAUNCH_CHECK();
-    size_t nb = (n + 256 * 8 - 1) / (256 * 8);
-    if (nb > 1024) nb = 1024;
-    if (nb < 1) nb = 1;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)sel_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_MAXT * 256 * 4);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
-    for (int pass = 0; pass < 4; ++pass) {
-        hipError_t me = hipMemsetAsync(state->hist, 0, sizeof(unsigned int) * SEL_MAXT * 256, st);
-        if (me != hipSuccess) return (int)me;
-        hipLaunchKernelGGL(sel_hist_kernel, dim3((unsigned)nb), dim3(256), SEL_MAXT * 256 * 4, st, data, n, state, pass);
-        YOND_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sel_resolve_kernel, dim3(1), dim3(256), 0, st, state, pass, out);
-        YOND_LAUNCH_CHECK();
-    }
-    return YOND_OK;
-}
-
-extern "C" int yond_select_ranks_f32(const float* data, size_t n, const int64_t* ranks_host, int nr, float* out, void* ws,
-                                     void* stream) {
-    if (!data || !ranks_host || !out || !ws || n == 0 || nr <= 0 || nr > SEL_MAXT) return YOND_EINVAL;
-    long long r[SEL_MAXT];
-    for (int i = 0; i < nr; ++i) r[i] = (long long)ranks_host[i];
-    return select_ranks(data, n, r, nr, out, ws, (hipStream_t)stream);
-}
-
-extern "C" int yond_percentiles_f32(const float* data, size_t n, const double* q_host, int nq, double* out, void* ws,
-                                    void* stream) {
-    if (!data || !q_host || !out || !ws || n == 0 || nq <= 0 || nq > SEL_MAXT / 2) return YOND_EINVAL;
-    long long r[SEL_MAXT];
-    LerpArgs la;
-    for (int i = 0; i < nq; ++i) {
-        if (!(q_host[i] >= 0.0 && q_host[i] <= 100.0)) return YOND_EINVAL;
-        // numpy: virtual index = q/100 * (n-1); previous = floor, next = previous+1 clipped, gamma = frac
-        const double vidx = (q_host[i] / 100.0) * (double)(n - 1);
-        long long lo = (long long)floor(vidx);
-        if (lo > (long long)n - 1) lo = (long long)n - 1;
-        long long hi = lo + 1;
-        if (hi > (long long)n - 1) hi = (long long)n - 1;
-        r[2 * i] = lo;
-        r[2 * i + 1] = hi;
-        la.t[i] = vidx - (double)lo;
-    }
-    float* vals = (float*)((unsigned char*)ws + sizeof(SelState));
-    const int rc = select_ranks(data, n, r, 2 * nq, vals, ws, (hipStream_t)stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(percentile_lerp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vals, la, nq, out);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
 }
 
 // =====================================================================================================

@@ -176,16 +176,26 @@ int yond_select_ranks_f32(const float* data, size_t n, const int64_t* ranks_host
 int yond_percentiles_f32(const float* data, size_t n, const double* q_host, int nq, double* out, void* ws,
                          void* stream);
 
-/* K7  one pass over (lap, mean, var): for thresholds ths[0..nt) (ascending, float64, device)
- *   occ  [nt][1024] uint32 flags: bin floor(clip(mean,0,1)*1000) occupied among {lap <= ths[i]} and not
- *        among {lap <= ths[i-1]}     (YOND_SIDD.py:37-43; prefix-OR on the host gives npeaks)
- *   mom  [nt+1][2][5] float64: {n, sum m, sum v, sum m^2, sum m v} over {ths[i-1] <= lap < ths[i]}
- *        (bucket nt: lap >= ths[nt-1]), [.][0] all pixels, [.][1] only 1e-4 < mean < 0.8
- *        (utils/isp_algos.py:348-350, 352-364 as moment sums)
- * ws: workspace of yond_nlf_ws_bytes(nt) bytes. */
-size_t yond_nlf_ws_bytes(int nt);
-int yond_nlf_accumulate_f32(const float* lap, const float* mean, const float* var, size_t n, const double* ths,
-                            int nt, uint32_t* occ, double* mom, void* ws, void* stream);
+/* K7a occupancy: one pass over (lap, mean), n elements laid out as rows of `width` (n % width == 0; pass the
+ *   image row length so that a lane can walk down a column of the smooth maps; any width is correct):
+ *   for thresholds ths[0..nt) (ascending, float64, device)
+ *   occ  [nt][32] uint32 bitmap: bit (bin & 31) of word bin >> 5 set when bin floor(clip(mean,0,1)*1000) is
+ *        occupied among {ths[i-1] < lap <= ths[i]}   (YOND_SIDD.py:37-43; prefix-OR over i gives npeaks) */
+int yond_nlf_occupancy_f32(const float* lap, const float* mean, size_t n, int width, const double* ths, int nt,
+                           uint32_t* occ, void* stream);
+
+/* K7s score3 on the device (YOND_SIDD.py:37-47): npeaks[i] = number of bins occupied among lap <= ths[i],
+ *   score = ths / (quants * npeaks) in float64, i* = argmin(score[1:]) + 1.
+ *   quants_host: nt float64 on the host.  sel (device, 4 float64): {i*, ths[i*], quants[i*], score[i*]};
+ *   npeaks (device, nt int32). */
+int yond_nlf_score3_f64(const uint32_t* occ, const double* ths, const double* quants_host, int nt, double* sel,
+                        int32_t* npeaks, void* stream);
+
+/* K7b moments: one pass over (lap, mean, var): mom [2][5] float64 = {n, sum m, sum v, sum m^2, sum m v} over
+ *   {lap < *th}, [0] all pixels, [1] only 1e-4 < mean < 0.8 (YOND_SIDD.py:77, 105; utils/isp_algos.py:348-350,
+ *   352-364 as moment sums).  th: one float64 on the device (e.g. sel + 1 of yond_nlf_score3_f64). */
+int yond_nlf_moments_f32(const float* lap, const float* mean, const float* var, size_t n, const double* th,
+                         double* mom, void* stream);
 
 /* Row H  bias LUT construction on the device (utils/isp_algos.py:49-140): for every knot lam <= th the
  * Poisson (*) Gaussian expectation of the VST, above th Foi's closed form.  lams: float64[n] (device),

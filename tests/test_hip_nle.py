@@ -118,34 +118,44 @@ def test_select_unaligned_large_and_constant(off):
     assert np.array_equal(got, np.full(len(q), np.float64(np.float32(0.0123))))
 
 
-def test_accumulate_matches_numpy():
+@pytest.mark.parametrize("shape", [(1_000_003,), (750, 1336), (333, 1001)])
+def test_occupancy_score3_moments_match_numpy(shape):
+    """K7a / K7s / K7b against NumPy: 1-D data (one row), a width that is a multiple of 4 (vector path) and an
+    odd width (scalar path)."""
     from yond_public_amd import pipeline as P
     rng = np.random.default_rng(4)
-    n = 1_000_003
+    n = int(np.prod(shape))
     lap = (rng.random(n).astype(np.float32) ** 2) * 0.05
     mean = np.clip(rng.random(n).astype(np.float32) * 1.1 - 0.05, -0.02, 1.05).astype(np.float32)
     var = (0.004 * mean + 1e-4 * rng.standard_normal(n)).astype(np.float32)
     q = np.linspace(5, 100, 20)
     ths = np.percentile(lap, q, method='linear')
-    pad = (-n) % 4
-    occ, mom = P._accumulate(torch.from_numpy(lap).to(DEV), torch.from_numpy(mean).to(DEV), torch.from_numpy(var).to(DEV),
-                             torch.from_numpy(ths).to(DEV))
-    occ, mom = occ.cpu().numpy(), mom.cpu().numpy()
-    seen = np.logical_or.accumulate(occ.astype(bool), axis=0).sum(axis=1)
+    lap[:3] = ths[4].astype(np.float32)                   # values exactly on / next to a threshold
+    width = shape[-1] if len(shape) > 1 else None
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    ths_dev = d(ths)
+    occ = P._occupancy(d(lap), d(mean), ths_dev, width)
+    seen = np.logical_or.accumulate(P._occ_unpack(occ.cpu().numpy()), axis=0).sum(axis=1)
+    ref_np = np.zeros(20, np.int64)
     for i in range(20):
         b = (mean[lap <= ths[i]].clip(0, 1) * 1000).astype(int)
-        assert seen[i] == np.sum(np.bincount(b, minlength=1001) > 0), i
-    for i in (0, 5, 19):
-        sel = lap < ths[i]
-        m, v = mean[sel].astype(np.float64), var[sel].astype(np.float64)
-        ref = np.array([m.size, m.sum(), v.sum(), (m * m).sum(), (m * v).sum()])
-        got = mom[:i + 1, 0].sum(axis=0)
-        np.testing.assert_allclose(got, ref, rtol=1e-11)
-        ns = sel & (mean > np.float32(1e-4)) & (mean < np.float32(0.8))
-        m, v = mean[ns].astype(np.float64), var[ns].astype(np.float64)
-        ref = np.array([m.size, m.sum(), v.sum(), (m * m).sum(), (m * v).sum()])
-        np.testing.assert_allclose(mom[:i + 1, 1].sum(axis=0), ref, rtol=1e-11)
-    assert mom[:, 0, 0].sum() == n
+        ref_np[i] = np.sum(np.bincount(b, minlength=1001) > 0)
+    assert np.array_equal(seen, ref_np)
+    sel, npk = P._score3_device(occ, ths_dev, q)
+    sel, npk = sel.cpu().numpy(), npk.cpu().numpy()
+    assert np.array_equal(npk, ref_np)
+    score = ths / (q * ref_np.astype(np.float64))
+    i = int(np.argmin(score[1:]) + 1)
+    assert int(sel[0]) == i and sel[1] == ths[i] and sel[2] == q[i] and sel[3] == score[i]
+    for i in (0, 4, 5, 19):
+        mom = P._moments(d(lap), d(mean), d(var), ths_dev[i:i + 1]).cpu().numpy()
+        pick = lap < ths[i]
+        for j, s_ in enumerate((pick, pick & (mean > np.float32(1e-4)) & (mean < np.float32(0.8)))):
+            m, v = mean[s_].astype(np.float64), var[s_].astype(np.float64)
+            ref = np.array([m.size, m.sum(), v.sum(), (m * m).sum(), (m * v).sum()])
+            np.testing.assert_allclose(mom[j], ref, rtol=1e-11)
+    inf = torch.full((1,), float('inf'), dtype=torch.float64, device=DEV)
+    assert P._moments(d(lap), d(mean), d(var), inf).cpu().numpy()[0, 0] == n
 
 
 @pytest.mark.parametrize("tag", ["s256", "s512", "hi", "lo"])

@@ -31,20 +31,20 @@ def test_score3_and_fit_from_moments():
     quants = np.linspace(5, 100, 20)
     ths = info['ths']
     # emulate what the accumulate kernel returns
-    occ = np.zeros((20, P.NBINS), np.int32)
+    occ = np.zeros((20, P.NBINS // 32), np.uint32)      # bitmap words, as the kernel writes them
     mom = np.zeros((21, 2, 5))
     i_le = np.searchsorted(ths, lap.astype(np.float64), side='left')
     i_lt = np.searchsorted(ths, lap.astype(np.float64), side='right')
     bins = (mean.clip(0, 1) * 1000).astype(int)
     for i, b in zip(i_le, bins):
         if i < 20:
-            occ[i, b] = 1
+            occ[i, b >> 5] |= np.uint32(1) << np.uint32(b & 31)
     ns = (mean > np.float32(1e-4)) & (mean < np.float32(0.8))
     for k in range(21):
         for j, sel in enumerate((i_lt == k, (i_lt == k) & ns)):
             m, v = mean[sel].astype(np.float64), var[sel].astype(np.float64)
             mom[k, j] = [m.size, m.sum(), v.sum(), (m * m).sum(), (m * v).sum()]
-    th2, pct2, info2 = P._score3(ths, quants, occ)
+    th2, pct2, info2 = P._score3(ths, quants, occ.view(np.int32))
     assert th2 == th and pct2 == pct
     np.testing.assert_array_equal(info2['npeaks'], info['npeaks'])
     sel = mom[:info2['index'] + 1].sum(axis=0)

@@ -33,4 +33,8 @@ lap, mean, var = o[3].reshape(-1), o[0].reshape(-1), o[1].reshape(-1)
 q = np.linspace(5, 100, 20)
 print("percentiles(20): %.1f us" % t(lambda: P._percentiles(lap, q)))
 ths = P._percentiles(lap, q)
-print("accumulate: %.1f us" % t(lambda: P._accumulate(lap, mean, var, ths)))
+def nlf_tail():
+    occ = P._occupancy(lap, mean, ths, w)
+    sel, npk = P._score3_device(occ, ths, q)
+    return P._moments(lap, mean, var, sel[1:2])
+print("occupancy+score3+moments: %.1f us" % t(nlf_tail))

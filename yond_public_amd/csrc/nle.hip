@@ -3,8 +3,8 @@
 //       float64 (the float32 inputs make them exact), every intermediate rounded to float32 exactly where
 //       NumPy / OpenCV round (no fused multiply-adds across those points).
 //   K6  exact order statistics + np.percentile's linear interpolation: nle_select.hip.
-//   K7  one pass over (lap, mean, var): occupancy of the 1/1000 mean bins per threshold bucket and the five
-//       moment sums of the least-squares line per bucket.
+//   K7  occupancy of the 1/1000 mean bins per threshold bucket (one sweep), score-3 selection on the device,
+//       and the five moment sums of the least-squares line below the selected threshold (one sweep).
 // All of it is integer / streaming work bound by HBM and LDS, not MFMA.
 #include "common.h"
 
@@ -195,111 +195,241 @@ extern "C" int yond_box_stats_collab_f32(const float* bayer_lr, const float* bay
 }
 
 // =====================================================================================================
-// K7: occupancy bitmap + bucketed moment sums
+// K7: score-3 threshold selection and the moment sums of the least-squares line
 // =====================================================================================================
+// K7a  occupancy: one sweep over (lap, mean), seen as a [rows][width] matrix (the planar maps are [4*h][w]):
+//      which of the 1/1000 mean bins are occupied among {lap <= ths[i]} for each of the nt thresholds.
+//      A lane owns VEC adjacent columns and walks a segment of rows (adjacent lanes read adjacent 16-byte
+//      vectors, NLF_BATCH rows ahead).  The thresholds live in scalar registers as float32
+//      (x <= T  <=>  x <= floor32(T) for float32 x and float64 T) and the bucket index is a branch-free count
+//      of compares; `mean` is a smooth map, so a lane remembers which buckets it has already marked for its
+//      current bin and only new (bucket, bin) pairs reach the LDS bitmap (no-return atomic OR).
+// K7s  score3 on the device (one wave): npeaks by prefix-OR + popcount, score = ths / (quants * npeaks),
+//      first minimum over i >= 1 (YOND_SIDD.py:37-47) -> the selected threshold stays on the device.
+// K7b  moments: one streaming sweep over (lap, mean, var), sums {n, Sm, Sv, Smm, Smv} over lap < th in
+//      float64 registers (all pixels / 1e-4 < mean < 0.8 only), wave + workgroup reduction, 10 atomics per
+//      workgroup.  (A single bucketed pass was tried first: on real frames lap changes bucket every 2-3
+//      pixels, and the float64 LDS atomics of the per-bucket sums cost 3x the whole sweep.)
 #define NLF_MAXT 32
 #define NLF_BINS 1024        // 1001 used (np.bincount(minlength=nbins+1))
+#define NLF_WORDS (NLF_BINS / 32)
+#define NLF_SEG 16           // rows per lane segment
+#define NLF_BATCH 4          // rows loaded ahead
 
-__global__ __launch_bounds__(256) void nlf_accumulate_kernel(const float* __restrict__ lap, const float* __restrict__ mean,
-                                                             const float* __restrict__ var, size_t n,
-                                                             const double* __restrict__ ths, int nt,
-                                                             unsigned int* __restrict__ occ, double* __restrict__ mom) {
-    __shared__ double s_ths[NLF_MAXT];
-    __shared__ unsigned int s_occ[NLF_MAXT * (NLF_BINS / 32)];
-    __shared__ double s_mom[(NLF_MAXT + 1) * 10];
-    for (int i = threadIdx.x; i < nt; i += 256) s_ths[i] = ths[i];
-    for (int i = threadIdx.x; i < NLF_MAXT * (NLF_BINS / 32); i += 256) s_occ[i] = 0;
-    for (int i = threadIdx.x; i < (NLF_MAXT + 1) * 10; i += 256) s_mom[i] = 0.0;
-    __syncthreads();
-    // each thread walks a contiguous run of elements so that consecutive elements mostly share a bucket
-    const size_t per = (n + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
-    const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    // interleave runs of 4 elements across the lanes of a wave: lane l handles elements base + 4*l .. +3
-    // (coalesced 16-byte accesses), the wave then moves on by 256 elements
-    (void)per; (void)gtid;
-    int cur = -1;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;        // all pixels
-    double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;        // non-saturated pixels only
-    auto flush = [&]() {
-        if (cur >= 0) {
-            double* m = s_mom + cur * 10;
-            if (a0 != 0.0) { atomicAdd(m + 0, a0); atomicAdd(m + 1, a1); atomicAdd(m + 2, a2); atomicAdd(m + 3, a3); atomicAdd(m + 4, a4); }
-            if (b0 != 0.0) { atomicAdd(m + 5, b0); atomicAdd(m + 6, b1); atomicAdd(m + 7, b2); atomicAdd(m + 8, b3); atomicAdd(m + 9, b4); }
-        }
-        a0 = a1 = a2 = a3 = a4 = 0.0;
-        b0 = b1 = b2 = b3 = b4 = 0.0;
-    };
-    const size_t nvec = n / 4;
-    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec + 1; v += (size_t)gridDim.x * 256) {
-        float l4[4], m4[4], v4[4];
-        int cnt;
-        if (v < nvec) {
-            const f32x4 L = *(const f32x4*)(lap + v * 4), M = *(const f32x4*)(mean + v * 4), V = *(const f32x4*)(var + v * 4);
+template <int VEC, int MAXT>
+__global__ __launch_bounds__(256) void nlf_occupancy_kernel(const float* __restrict__ lap, const float* __restrict__ mean,
+                                                            int rows, int width, const double* __restrict__ ths, int nt,
+                                                            unsigned int* __restrict__ occ) {
+    __shared__ unsigned int s_occ[NLF_MAXT * NLF_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    float te = INFINITY;                                       // padding: never below a finite value
+    if (lane < nt) {
+        const double T = ths[lane];
+        const float f = (float)T;
+        te = ((double)f > T) ? nextafterf(f, -INFINITY) : f;   // largest float32 <= T
+    }
+    float tle[MAXT];                                           // wave-uniform -> scalar registers
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { l4[e] = L[e]; m4[e] = M[e]; v4[e] = V[e]; }
-            cnt = 4;
-        } else {
-            cnt = (int)(n - nvec * 4);                       // tail (n % 4 elements), handled by one thread
-            for (int e = 0; e < 4; ++e) {
-                const size_t i = nvec * 4 + e;
-                l4[e] = i < n ? lap[i] : 0.f; m4[e] = i < n ? mean[i] : 0.f; v4[e] = i < n ? var[i] : 0.f;
-            }
-        }
-        for (int e = 0; e < cnt; ++e) {
-            const double ld = (double)l4[e];
-            int i_le = 0;
-            while (i_le < nt && !(ld <= s_ths[i_le])) ++i_le;   // first i with lap <= ths[i]   (YOND_SIDD.py:37)
-            int i_lt = i_le;
-            while (i_lt < nt && !(ld < s_ths[i_lt])) ++i_lt;    // first i with lap <  ths[i]   (YOND_SIDD.py:77)
-            const float mf = m4[e];
-            if (i_le < nt) {
-                const int bin = (int)__fmul_rn(fminf(fmaxf(mf, 0.0f), 1.0f), 1000.0f);   // (mean.clip(0,1)*nbins).astype(int)
-                const unsigned int bit = 1u << (bin & 31);
-                unsigned int* w = &s_occ[i_le * (NLF_BINS / 32) + (bin >> 5)];
-                if (!(*w & bit)) atomicOr(w, bit);
-            }
-            if (i_lt != cur) { flush(); cur = i_lt; }
-            const double md = (double)mf, vd = (double)v4[e];
-            a0 += 1.0; a1 += md; a2 += vd; a3 += md * md; a4 += md * vd;
-            if (mf > 1e-4f && mf < 0.8f) { b0 += 1.0; b1 += md; b2 += vd; b3 += md * md; b4 += md * vd; }
-        }
-    }
-    flush();
+    for (int i = 0; i < MAXT; ++i) tle[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(te), i));
+    for (int i = tid; i < NLF_MAXT * NLF_WORDS; i += 256) s_occ[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < nt * (NLF_BINS / 32); i += 256) {
-        unsigned int wv = s_occ[i];
-        const int t = i / (NLF_BINS / 32), wb = i % (NLF_BINS / 32);
-        while (wv) {
-            const int bpos = __ffs(wv) - 1;
-            wv &= wv - 1;
-            occ[(size_t)t * NLF_BINS + wb * 32 + bpos] = 1u;
+    const int G = (width + VEC - 1) / VEC;
+    const int nseg = (rows + NLF_SEG - 1) / NLF_SEG;
+    const size_t nitems = (size_t)G * nseg;
+    for (size_t item = (size_t)blockIdx.x * 256 + tid; item < nitems; item += (size_t)gridDim.x * 256) {
+        const int sgm = (int)(item / G), g = (int)(item % G);
+        const int r0 = sgm * NLF_SEG, r1 = min(rows, r0 + NLF_SEG);
+        const int c0 = g * VEC;
+        int cbin[VEC];
+        unsigned int cmask[VEC];                               // buckets already marked for the column's current bin
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { cbin[e] = -1; cmask[e] = 0; }
+        for (int rb = r0; rb < r1; rb += NLF_BATCH) {
+            f32x4 Lb[NLF_BATCH], Mb[NLF_BATCH];
+#pragma unroll
+            for (int j = 0; j < NLF_BATCH; ++j) {
+                const int r = min(rb + j, r1 - 1);
+                const size_t base = (size_t)r * width + c0;
+                if (VEC == 4) { Lb[j] = *(const f32x4*)(lap + base); Mb[j] = *(const f32x4*)(mean + base); }
+                else { Lb[j][0] = lap[base]; Mb[j][0] = mean[base]; }
+            }
+#pragma unroll
+            for (int j = 0; j < NLF_BATCH; ++j) {
+                if (rb + j >= r1) break;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float l = Lb[j][e], mf = Mb[j][e];
+                    int ce = 0;
+#pragma unroll
+                    for (int i = 0; i < MAXT; ++i) ce += (l <= tle[i]) ? 1 : 0;
+                    const int ile = min(MAXT - ce, nt);                  // first i with lap <= ths[i] (YOND_SIDD.py:37); NaN -> nt
+                    const int bin = (int)__fmul_rn(fminf(fmaxf(mf, 0.0f), 1.0f), 1000.0f);   // (mean.clip(0,1)*nbins).astype(int)
+                    if (bin != cbin[e]) { cbin[e] = bin; cmask[e] = 0; }
+                    const unsigned int bit = ile < nt ? (1u << ile) : 0u;
+                    if (bit & ~cmask[e]) {
+                        cmask[e] |= bit;
+                        atomicOr(&s_occ[ile * NLF_WORDS + (bin >> 5)], 1u << (bin & 31));
+                    }
+                }
+            }
         }
     }
-    for (int i = threadIdx.x; i < (nt + 1) * 10; i += 256) {
-        const double s = s_mom[i];
-        if (s != 0.0) atomicAdd(mom + i, s);
+    __syncthreads();
+    for (int i = tid; i < nt * NLF_WORDS; i += 256) {
+        const unsigned int wv = s_occ[i];
+        if (wv) atomicOr(occ + i, wv);
     }
 }
 
-extern "C" size_t yond_nlf_ws_bytes(int nt) {
-    (void)nt;
-    return 64;
+struct ScoreArgs { double quants[NLF_MAXT]; };
+
+__global__ __launch_bounds__(64) void nlf_score3_kernel(const unsigned int* __restrict__ occ, const double* __restrict__ ths,
+                                                        ScoreArgs qa, int nt, double* __restrict__ sel, int* __restrict__ npeaks) {
+    __shared__ unsigned int s_occ[NLF_MAXT * NLF_WORDS];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < nt * NLF_WORDS; i += 64) s_occ[i] = occ[i];
+    __syncthreads();
+    // lane w < 32 owns bitmap word w: running OR over the buckets, popcount, sum over the words
+    int np = 0;
+    unsigned int acc = 0;
+    for (int j = 0; j < nt; ++j) {
+        if (lane < NLF_WORDS) acc |= s_occ[j * NLF_WORDS + lane];           // bins seen among lap <= ths[j]
+        int c = lane < NLF_WORDS ? __popc(acc) : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == j) np = c;
+    }
+    double score = INFINITY;
+    if (lane < nt) {
+        npeaks[lane] = np;
+        score = __ddiv_rn(ths[lane], __dmul_rn(qa.quants[lane], (double)np));   // YOND_SIDD.py:45
+    }
+    // first minimum over 1 <= i < nt (np.argmin(score[1:]) + 1)
+    double best = (lane >= 1 && lane < nt) ? score : INFINITY;
+    int bi = (lane >= 1 && lane < nt) ? lane : 0x7FFFFFFF;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (bi == 0x7FFFFFFF) bi = 0;                              // nt == 1 (or no finite score): first threshold
+    if (lane == 0) {
+        sel[0] = (double)bi;
+        sel[1] = ths[bi];
+        sel[2] = qa.quants[bi];
+        sel[3] = best;
+    }
 }
 
-extern "C" int yond_nlf_accumulate_f32(const float* lap, const float* mean, const float* var, size_t n, const double* ths,
-                                       int nt, uint32_t* occ, double* mom, void* ws, void* stream) {
-    (void)ws;
-    if (!lap || !mean || !var || !ths || !occ || !mom || n == 0 || nt <= 0 || nt > NLF_MAXT) return YOND_EINVAL;
-    if (((uintptr_t)lap | (uintptr_t)mean | (uintptr_t)var) & 15) return YOND_EINVAL;
+#define MOM_UNROLL 4
+
+__global__ __launch_bounds__(256) void nlf_moments_kernel(const float* __restrict__ lap, const float* __restrict__ mean,
+                                                          const float* __restrict__ var, size_t n, int vec_ok,
+                                                          const double* __restrict__ th_ptr, double* __restrict__ mom) {
+    __shared__ double s_red[4][10];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double T = *th_ptr;
+    const float f = (float)T;
+    const float tl = ((double)f < T) ? nextafterf(f, INFINITY) : f;        // lap < T  <=>  lap < ceil32(T)
+    double a[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a[i] = 0.0;
+    auto add = [&](float l, float mf, float vf) {
+        if (l < tl) {                                                       // YOND_SIDD.py:77 / :105
+            const double md = (double)mf, vd = (double)vf;
+            const double mm = md * md, mv = md * vd;
+            a[0] += 1.0; a[1] += md; a[2] += vd; a[3] += mm; a[4] += mv;
+            if (mf > 1e-4f && mf < 0.8f) { a[5] += 1.0; a[6] += md; a[7] += vd; a[8] += mm; a[9] += mv; }   // utils/isp_algos.py:348
+        }
+    };
+    const size_t nvec = vec_ok ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t v = (size_t)blockIdx.x * 256 + tid; v < nvec; v += stride * MOM_UNROLL) {
+        f32x4 L[MOM_UNROLL], M[MOM_UNROLL], V[MOM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < MOM_UNROLL; ++u) {
+            const size_t vu = v + u * stride;
+            const size_t idx = (vu < nvec ? vu : v) * 4;
+            L[u] = *(const f32x4*)(lap + idx); M[u] = *(const f32x4*)(mean + idx); V[u] = *(const f32x4*)(var + idx);
+        }
+#pragma unroll
+        for (int u = 0; u < MOM_UNROLL; ++u) {
+            if (v + u * stride < nvec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) add(L[u][e], M[u][e], V[u][e]);
+            }
+        }
+    }
+    for (size_t i = nvec * 4 + (size_t)blockIdx.x * 256 + tid; i < n; i += stride) add(lap[i], mean[i], var[i]);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a[i] = wave_sum(a[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) s_red[wave][i] = a[i];
+    }
+    __syncthreads();
+    if (tid < 10) {
+        const double t = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+        if (t != 0.0) atomicAdd(mom + tid, t);
+    }
+}
+
+template <int VEC, int MAXT>
+static void launch_occupancy(unsigned nb, hipStream_t st, const float* lap, const float* mean, int rows, int width,
+                             const double* ths, int nt, uint32_t* occ) {
+    hipLaunchKernelGGL((nlf_occupancy_kernel<VEC, MAXT>), dim3(nb), dim3(256), 0, st, lap, mean, rows, width, ths, nt, occ);
+}
+
+extern "C" int yond_nlf_occupancy_f32(const float* lap, const float* mean, size_t n, int width, const double* ths, int nt,
+                                      uint32_t* occ, void* stream) {
+    if (!lap || !mean || !ths || !occ || n == 0 || nt <= 0 || nt > NLF_MAXT) return YOND_EINVAL;
+    if (width <= 0 || n % (size_t)width != 0 || n / (size_t)width > 0x7FFFFFFFull) return YOND_EINVAL;
+    const int rows = (int)(n / (size_t)width);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(occ, 0, sizeof(uint32_t) * nt * NLF_BINS, st);
+    hipError_t e = hipMemsetAsync(occ, 0, sizeof(uint32_t) * nt * NLF_WORDS, st);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(mom, 0, sizeof(double) * (nt + 1) * 10, st);
+    const bool vec = (width % 4 == 0) && !(((uintptr_t)lap | (uintptr_t)mean) & 15);
+    const int G = vec ? width / 4 : width;
+    const size_t nitems = (size_t)G * ((rows + NLF_SEG - 1) / NLF_SEG);
+    size_t nbs = (nitems + 255) / 256;
+    if (nbs > 4096) nbs = 4096;
+    if (nbs < 1) nbs = 1;
+    const unsigned nb = (unsigned)nbs;
+    if (vec) {
+        if (nt <= 8) launch_occupancy<4, 8>(nb, st, lap, mean, rows, width, ths, nt, occ);
+        else if (nt <= 24) launch_occupancy<4, 24>(nb, st, lap, mean, rows, width, ths, nt, occ);
+        else launch_occupancy<4, 32>(nb, st, lap, mean, rows, width, ths, nt, occ);
+    } else {
+        if (nt <= 8) launch_occupancy<1, 8>(nb, st, lap, mean, rows, width, ths, nt, occ);
+        else if (nt <= 24) launch_occupancy<1, 24>(nb, st, lap, mean, rows, width, ths, nt, occ);
+        else launch_occupancy<1, 32>(nb, st, lap, mean, rows, width, ths, nt, occ);
+    }
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_nlf_score3_f64(const uint32_t* occ, const double* ths, const double* quants_host, int nt, double* sel,
+                                   int32_t* npeaks, void* stream) {
+    if (!occ || !ths || !quants_host || !sel || !npeaks || nt <= 0 || nt > NLF_MAXT) return YOND_EINVAL;
+    ScoreArgs qa;
+    for (int i = 0; i < NLF_MAXT; ++i) qa.quants[i] = i < nt ? quants_host[i] : 1.0;
+    hipLaunchKernelGGL(nlf_score3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, occ, ths, qa, nt, sel, npeaks);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_nlf_moments_f32(const float* lap, const float* mean, const float* var, size_t n, const double* th,
+                                    double* mom, void* stream) {
+    if (!lap || !mean || !var || !th || !mom || n == 0) return YOND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(mom, 0, sizeof(double) * 10, st);
     if (e != hipSuccess) return (int)e;
-    size_t nb = (n / 4 + 1 + 256 * 4 - 1) / (256 * 4);
+    const int vec_ok = !(((uintptr_t)lap | (uintptr_t)mean | (uintptr_t)var) & 15);
+    size_t nb = (n / 4 + 256 * MOM_UNROLL - 1) / (256 * MOM_UNROLL);
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(nlf_accumulate_kernel, dim3((unsigned)nb), dim3(256), 0, st, lap, mean, var, n, ths, nt, occ, mom);
+    hipLaunchKernelGGL(nlf_moments_kernel, dim3((unsigned)nb), dim3(256), 0, st, lap, mean, var, n, vec_ok, th, mom);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

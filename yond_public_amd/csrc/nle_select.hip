@@ -20,6 +20,7 @@
 #define SEL_WIN_N 16384              // keys 0x8000 .. 0xBFFF: 0 <= x < 2
 #define SEL_THREADS 1024
 #define SEL_NONE 255
+#define SEL_UNROLL 4                 // vectors in flight per thread in the sweeps
 
 struct SelState {
     long long tgt_rank[SEL_MAXT];        // remaining rank inside the target's prefix group
@@ -45,12 +46,6 @@ __device__ __forceinline__ float key2f(unsigned int k) {
 
 struct SelRanks { long long r[SEL_MAXT]; };
 
-__global__ void sel_init_kernel(SelState* st, SelRanks ranks, int nt) {
-    const int t = threadIdx.x;
-    if (t < nt) { st->tgt_prefix[t] = 0; st->tgt_rank[t] = ranks.r[t]; st->tgt_slot[t] = 0; }
-    if (t == 0) { st->nslots = 0; st->nl1 = 0; st->nt = nt; }
-}
-
 // The sweeps read data[head .. head + 4*nvec) as 16-byte vectors; the (at most 6) elements before and after
 // that aligned body are "edge" elements handled by the first threads of workgroup 0.
 struct SelSpan { size_t head, nvec, n; };
@@ -71,11 +66,7 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist1_kernel(const float* __r
     const f32x4* vec = (const f32x4*)(data + sp.head);
     const size_t nchunk = (sp.nvec + 63) / 64;               // a wave takes 64 vectors at a time (uniform trip count)
     const size_t wstride = (size_t)gridDim.x * (SEL_THREADS / 64);
-    for (size_t c = (size_t)blockIdx.x * (SEL_THREADS / 64) + wave; c < nchunk; c += wstride) {
-        const size_t v = c * 64 + lane;
-        const bool valid = v < sp.nvec;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (valid) x = vec[v];
+    auto count4 = [&](const f32x4 x, bool valid) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             // invalid lanes carry ids that differ from every neighbour and never count
@@ -91,6 +82,22 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist1_kernel(const float* __r
                 else atomicAdd(&st->hist1[id], len);
             }
         }
+    };
+    // SEL_UNROLL chunks per trip: their loads are all in flight before the first one is counted
+    for (size_t c = (size_t)blockIdx.x * (SEL_THREADS / 64) + wave; c < nchunk; c += wstride * SEL_UNROLL) {
+        f32x4 x[SEL_UNROLL];
+        bool valid[SEL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SEL_UNROLL; ++u) {
+            const size_t v = (c + u * wstride) * 64 + lane;
+            valid[u] = (c + u * wstride) < nchunk && v < sp.nvec;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            x[u] = valid[u] ? vec[v] : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_UNROLL; ++u) {
+            if ((c + u * wstride) < nchunk) count4(x[u], valid[u]);      // wave-uniform condition
+        }
     }
     size_t ei;
     if (blockIdx.x == 0 && tid < 8 && edge_index(sp, tid, &ei)) atomicAdd(&st->hist1[f2key(data[ei]) >> 16], 1u);
@@ -101,8 +108,9 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist1_kernel(const float* __r
     }
 }
 
-// sorted distinct values of s_newp[0..nt) -> slots; returns the number of slots (all threads), nt <= SEL_MAXT
-__device__ __forceinline__ int assign_slots(const unsigned int* s_newp, int nt, unsigned int* slot_prefix, int* tgt_slot) {
+// sorted distinct values of s_newp[0..nt) -> slots (s_slotp sorted, s_tslot per target), all in LDS;
+// returns the number of slots (all threads), nt <= SEL_MAXT <= blockDim.x
+__device__ __forceinline__ int assign_slots(const unsigned int* s_newp, int nt, unsigned int* s_slotp, int* s_tslot) {
     __shared__ int s_ns;
     __shared__ int s_isfirst[SEL_MAXT];
     const int t = threadIdx.x;
@@ -117,51 +125,76 @@ __device__ __forceinline__ int assign_slots(const unsigned int* s_newp, int nt, 
         const unsigned int p = s_newp[t];
         int pos = 0;                                           // number of distinct prefixes below p
         for (int u = 0; u < nt; ++u) pos += (s_isfirst[u] && s_newp[u] < p) ? 1 : 0;
-        tgt_slot[t] = pos;
-        if (s_isfirst[t]) { slot_prefix[pos] = p; atomicAdd(&s_ns, 1); }
+        s_tslot[t] = pos;
+        if (s_isfirst[t]) { s_slotp[pos] = p; atomicAdd(&s_ns, 1); }
     }
     __syncthreads();
     return s_ns;
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void sel_resolve1_kernel(SelState* st) {
-    __shared__ unsigned long long s_cum[SEL_THREADS];        // inclusive sums of 64-bin chunks
-    __shared__ unsigned int s_newp[SEL_MAXT];
-    const int tid = threadIdx.x;
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long up = __shfl_up(v, o);
+        if (lane >= o) v += up;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void sel_resolve1_kernel(SelState* st, SelRanks ranks, int nt) {
+    __shared__ unsigned long long s_wtot[SEL_THREADS / 64];
+    __shared__ unsigned int s_newp[SEL_MAXT], s_slotp[SEL_MAXT];
+    __shared__ int s_tslot[SEL_MAXT], s_owner[SEL_MAXT];
+    __shared__ long long s_rank[SEL_MAXT];
+    __shared__ unsigned long long s_before[SEL_MAXT];
+    __shared__ __attribute__((aligned(16))) unsigned int s_bins[SEL_MAXT][64];
+    constexpr int NW = SEL_THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < nt) s_rank[tid] = ranks.r[tid];
+    // thread tid owns bins 64*tid .. 64*tid+63 and keeps them in registers
     const unsigned int* h = st->hist1 + tid * 64;
+    uint4 q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = *(const uint4*)(h + 4 * i);
     unsigned long long mine = 0;
-#pragma unroll 4
-    for (int i = 0; i < 64; i += 4) {
-        const uint4 q = *(const uint4*)(h + i);
-        mine += (unsigned long long)q.x + q.y + q.z + q.w;
-    }
-    s_cum[tid] = mine;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mine += (unsigned long long)q[i].x + q[i].y + q[i].z + q[i].w;
+    unsigned long long incl = wave_incl_scan_u64(mine, lane);
+    if (lane == 63) s_wtot[wave] = incl;
     __syncthreads();
-    for (int o = 1; o < SEL_THREADS; o <<= 1) {
-        const unsigned long long add = tid >= o ? s_cum[tid - o] : 0ull;
-        __syncthreads();
-        s_cum[tid] += add;
-        __syncthreads();
-    }
-    const int nt = st->nt;
-    if (tid < nt) {
-        const unsigned long long rank = (unsigned long long)st->tgt_rank[tid];
-        int lo = 0, hi = SEL_THREADS - 1;                     // first chunk whose inclusive sum exceeds the rank
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cum[mid] > rank) hi = mid; else lo = mid + 1; }
-        unsigned long long cum = lo ? s_cum[lo - 1] : 0ull;
-        const unsigned int* b = st->hist1 + lo * 64;
-        int d = 0;
-        while (d < 63 && cum + b[d] <= rank) { cum += b[d]; ++d; }
-        const unsigned int np = (unsigned int)(lo * 64 + d);
-        st->tgt_rank[tid] = (long long)(rank - cum);
-        st->tgt_prefix[tid] = np;
-        s_newp[tid] = np;
+    for (int w = 0; w < wave; ++w) incl += s_wtot[w];
+    const unsigned long long excl = incl - mine;
+    // the owner of the chunk that holds a rank publishes its 64 bins
+    for (int t = 0; t < nt; ++t) {
+        const unsigned long long rank = (unsigned long long)s_rank[t];
+        if (rank >= excl && rank < incl) {
+            s_owner[t] = tid;
+            s_before[t] = excl;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) *(uint4*)(&s_bins[t][4 * i]) = q[i];
+        }
     }
     __syncthreads();
-    const int ns = assign_slots(s_newp, nt, st->slot_prefix, st->tgt_slot);
-    if (tid == 0) { st->nslots = ns; st->nl1 = ns; }
+    // one wave per target: the chunk's 64 bins across the lanes
+    for (int t = wave; t < nt; t += NW) {
+        const unsigned long long rank = (unsigned long long)s_rank[t];
+        const unsigned long long c = s_bins[t][lane];
+        const unsigned long long bi = wave_incl_scan_u64(c, lane) + s_before[t];
+        const unsigned long long m = __ballot(bi > rank);
+        const int d = m ? (__ffsll((long long)m) - 1) : 63;
+        const unsigned long long cum = __shfl(bi - c, d);
+        if (lane == 0) {
+            const unsigned int np = (unsigned int)(s_owner[t] * 64 + d);
+            st->tgt_rank[t] = (long long)(rank - cum);
+            st->tgt_prefix[t] = np;
+            s_newp[t] = np;
+        }
+    }
     __syncthreads();
-    if (tid < ns) st->l1_prefix[tid] = st->slot_prefix[tid];
+    const int ns = assign_slots(s_newp, nt, s_slotp, s_tslot);
+    if (tid == 0) { st->nslots = ns; st->nl1 = ns; st->nt = nt; }
+    if (tid < nt) st->tgt_slot[tid] = s_tslot[tid];
+    if (tid < ns) { st->slot_prefix[tid] = s_slotp[tid]; st->l1_prefix[tid] = s_slotp[tid]; }
 }
 
 // LEVEL 2: count bits 15..8 under the level-1 slots; LEVEL 3: bits 7..0 under the level-2 slots
@@ -208,10 +241,21 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist23_kernel(const float* __
         }
     };
     const f32x4* vec = (const f32x4*)(data + sp.head);
-    for (size_t v = (size_t)blockIdx.x * SEL_THREADS + tid; v < sp.nvec; v += (size_t)gridDim.x * SEL_THREADS) {
-        const f32x4 x = vec[v];
+    const size_t vstride = (size_t)gridDim.x * SEL_THREADS;
+    for (size_t v = (size_t)blockIdx.x * SEL_THREADS + tid; v < sp.nvec; v += vstride * SEL_UNROLL) {
+        f32x4 x[SEL_UNROLL];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) count(x[e]);
+        for (int u = 0; u < SEL_UNROLL; ++u) {
+            const size_t vu = v + u * vstride;
+            x[u] = vec[vu < sp.nvec ? vu : v];
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_UNROLL; ++u) {
+            if (v + u * vstride < sp.nvec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) count(x[u][e]);
+            }
+        }
     }
     size_t ei;
     if (blockIdx.x == 0 && tid < 8 && edge_index(sp, tid, &ei)) count(data[ei]);
@@ -223,26 +267,40 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist23_kernel(const float* __
     }
 }
 
+struct LerpArgs { double t[SEL_MAXT / 2]; int nq; };
+
+// LEVEL 3 also writes the order statistics (out_vals, float32) and, when la.nq > 0, np.percentile's linear
+// interpolation between each pair of them (out_q, float64).
 template <int LEVEL>
-__global__ __launch_bounds__(256) void sel_resolve23_kernel(SelState* st, float* out_vals) {
-    __shared__ unsigned int s_newp[SEL_MAXT];
+__global__ __launch_bounds__(SEL_THREADS) void sel_resolve23_kernel(SelState* st, float* out_vals, LerpArgs la, double* out_q) {
+    __shared__ unsigned int s_newp[SEL_MAXT], s_slotp[SEL_MAXT], s_pref[SEL_MAXT], s_l1p[SEL_MAXT];
+    __shared__ int s_tslot[SEL_MAXT], s_slot[SEL_MAXT];
+    __shared__ long long s_rank[SEL_MAXT];
+    constexpr int NW = SEL_THREADS / 64, PER = SEL_MAXT / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = st->nt;
+    const int nl1 = st->nl1;
+    if (tid < nt) { s_rank[tid] = st->tgt_rank[tid]; s_slot[tid] = st->tgt_slot[tid]; s_pref[tid] = st->tgt_prefix[tid]; }
+    if (tid < nl1) s_l1p[tid] = st->l1_prefix[tid];
+    __syncthreads();
     const unsigned int* gh = LEVEL == 2 ? st->hist2 : st->hist3;
-    // one wave per target: lane l holds bins 4l..4l+3, wave-wide inclusive scan, first bin whose cumulative
-    // count exceeds the remaining rank
-    for (int t = wave; t < nt; t += 4) {
-        const unsigned int* h = gh + st->tgt_slot[t] * 256 + lane * 4;
-        const long long c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
-        const long long mine = c0 + c1 + c2 + c3;
-        long long incl = mine;
+    // one wave per target (targets wave, wave + NW, ...): lane l holds bins 4l..4l+3; all loads first
+    uint4 hv[PER];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const long long up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
-        }
+    for (int j = 0; j < PER; ++j) {
+        const int t = wave + j * NW;
+        const uint4 z = {0u, 0u, 0u, 0u};
+        hv[j] = t < nt ? *(const uint4*)(gh + s_slot[t] * 256 + lane * 4) : z;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int t = wave + j * NW;
+        if (t >= nt) break;
+        const long long c0 = hv[j].x, c1 = hv[j].y, c2 = hv[j].z, c3 = hv[j].w;
+        const long long mine = c0 + c1 + c2 + c3;
+        const long long incl = (long long)wave_incl_scan_u64((unsigned long long)mine, lane);
         const long long excl = incl - mine;
-        const long long rank = st->tgt_rank[t];
+        const long long rank = s_rank[t];
         const bool here = rank >= excl && rank < incl;          // exactly one lane unless the data ran out
         const unsigned long long m = __ballot(here);
         const int src = m ? (__ffsll((long long)m) - 1) : 63;
@@ -255,43 +313,40 @@ __global__ __launch_bounds__(256) void sel_resolve23_kernel(SelState* st, float*
         d = __shfl(d, src);
         cum = __shfl(cum, src);
         if (lane == 0) {
-            const unsigned int np = (st->tgt_prefix[t] << 8) | (unsigned int)(src * 4 + d);
-            st->tgt_rank[t] = rank - cum;
-            st->tgt_prefix[t] = np;
+            const unsigned int np = (s_pref[t] << 8) | (unsigned int)(src * 4 + d);
             s_newp[t] = np;
-            if (LEVEL == 3) out_vals[t] = key2f(np);
+            if (LEVEL == 3) {
+                out_vals[t] = key2f(np);
+            } else {
+                st->tgt_rank[t] = rank - cum;
+                st->tgt_prefix[t] = np;
+            }
         }
     }
     __syncthreads();
     if (LEVEL == 2) {
-        const int ns = assign_slots(s_newp, nt, st->slot_prefix, st->tgt_slot);
+        const int ns = assign_slots(s_newp, nt, s_slotp, s_tslot);
         if (tid == 0) st->nslots = ns;
-        __syncthreads();
-        const int nl1 = st->nl1;
+        if (tid < nt) st->tgt_slot[tid] = s_tslot[tid];
+        if (tid < ns) st->slot_prefix[tid] = s_slotp[tid];
         if (tid < nl1) {                                       // level-2 slots are sorted, so each level-1 slot owns a range
-            const unsigned int p16 = st->l1_prefix[tid];
+            const unsigned int p16 = s_l1p[tid];
             int first = 0, cnt = 0;
             for (int i = 0; i < ns; ++i) {
-                if ((st->slot_prefix[i] >> 8) == p16) { if (!cnt) first = i; ++cnt; }
+                if ((s_slotp[i] >> 8) == p16) { if (!cnt) first = i; ++cnt; }
             }
             st->l1_first[tid] = first;
             st->l1_count[tid] = cnt;
         }
+    } else if (tid < la.nq) {
+        // numpy _lerp: diff = b - a in the data dtype; a + diff*t (t < 0.5) or b - diff*(1-t) (t >= 0.5); b == a -> a
+        const float av = key2f(s_newp[2 * tid]), bv = key2f(s_newp[2 * tid + 1]);
+        const float diff = __fsub_rn(bv, av);
+        const double t = la.t[tid];
+        double r = (t >= 0.5) ? __dsub_rn((double)bv, __dmul_rn((double)diff, 1.0 - t)) : __dadd_rn((double)av, __dmul_rn((double)diff, t));
+        if (bv == av) r = (double)av;
+        out_q[tid] = r;
     }
-}
-
-struct LerpArgs { double t[SEL_MAXT / 2]; };
-
-__global__ void percentile_lerp_kernel(const float* __restrict__ vals, LerpArgs a, int nq, double* __restrict__ out) {
-    const int i = threadIdx.x;
-    if (i >= nq) return;
-    // numpy _lerp: diff = b - a in the data dtype; a + diff*t (t < 0.5) or b - diff*(1-t) (t >= 0.5); b == a -> a
-    const float av = vals[2 * i], bv = vals[2 * i + 1];
-    const float diff = __fsub_rn(bv, av);
-    const double t = a.t[i];
-    double r = (t >= 0.5) ? __dsub_rn((double)bv, __dmul_rn((double)diff, 1.0 - t)) : __dadd_rn((double)av, __dmul_rn((double)diff, t));
-    if (bv == av) r = (double)av;
-    out[i] = r;
 }
 
 extern "C" size_t yond_select_ws_bytes(int nr) {
@@ -299,7 +354,8 @@ extern "C" size_t yond_select_ws_bytes(int nr) {
     return sizeof(SelState) + SEL_MAXT * sizeof(float) + 64;
 }
 
-static int select_ranks(const float* data, size_t n, const long long* ranks, int nr, float* out, void* ws, hipStream_t st) {
+static int select_ranks(const float* data, size_t n, const long long* ranks, int nr, float* out, void* ws, hipStream_t st,
+                        const LerpArgs* lerp, double* out_q) {
     if (n > 0xFFFFFFFFull) return YOND_EUNSUPPORTED;          // 32-bit bin counters
     if (((uintptr_t)data & 3) || ((uintptr_t)ws & 15)) return YOND_EINVAL;
     SelState* state = (SelState*)ws;
@@ -308,6 +364,9 @@ static int select_ranks(const float* data, size_t n, const long long* ranks, int
         if (ranks[i] < 0 || (size_t)ranks[i] >= n) return YOND_EINVAL;
         rk.r[i] = ranks[i];
     }
+    LerpArgs la;
+    la.nq = 0;
+    if (lerp) la = *lerp;
     SelSpan sp;
     sp.n = n;
     sp.head = ((16 - ((uintptr_t)data & 15)) & 15) / 4;
@@ -324,24 +383,22 @@ static int select_ranks(const float* data, size_t n, const long long* ranks, int
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(64), 0, st, state, rk, nr);
-    YOND_LAUNCH_CHECK();
     hipError_t me = hipMemsetAsync(state->hist2, 0, sizeof(unsigned int) * (2 * SEL_MAXT * 256 + SEL_L1_BINS), st);
     if (me != hipSuccess) return (int)me;
-    size_t nb = (sp.nvec + SEL_THREADS * 4 - 1) / (SEL_THREADS * 4);
+    size_t nb = (sp.nvec + SEL_THREADS * SEL_UNROLL - 1) / (SEL_THREADS * SEL_UNROLL);
     if (nb < 1) nb = 1;
     const size_t nb1 = nb > 512 ? 512 : nb, nb23 = nb > 256 ? 256 : nb;
     hipLaunchKernelGGL(sel_hist1_kernel, dim3((unsigned)nb1), dim3(SEL_THREADS), SEL_WIN_N * 4, st, data, sp, state);
     YOND_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sel_resolve1_kernel, dim3(1), dim3(SEL_THREADS), 0, st, state);
+    hipLaunchKernelGGL(sel_resolve1_kernel, dim3(1), dim3(SEL_THREADS), 0, st, state, rk, nr);
     YOND_LAUNCH_CHECK();
     hipLaunchKernelGGL(sel_hist23_kernel<2>, dim3((unsigned)nb23), dim3(SEL_THREADS), lds23, st, data, sp, state);
     YOND_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sel_resolve23_kernel<2>, dim3(1), dim3(256), 0, st, state, out);
+    hipLaunchKernelGGL(sel_resolve23_kernel<2>, dim3(1), dim3(SEL_THREADS), 0, st, state, out, la, out_q);
     YOND_LAUNCH_CHECK();
     hipLaunchKernelGGL(sel_hist23_kernel<3>, dim3((unsigned)nb23), dim3(SEL_THREADS), lds23, st, data, sp, state);
     YOND_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sel_resolve23_kernel<3>, dim3(1), dim3(256), 0, st, state, out);
+    hipLaunchKernelGGL(sel_resolve23_kernel<3>, dim3(1), dim3(SEL_THREADS), 0, st, state, out, la, out_q);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -351,7 +408,7 @@ extern "C" int yond_select_ranks_f32(const float* data, size_t n, const int64_t*
     if (!data || !ranks_host || !out || !ws || n == 0 || nr <= 0 || nr > SEL_MAXT) return YOND_EINVAL;
     long long r[SEL_MAXT];
     for (int i = 0; i < nr; ++i) r[i] = (long long)ranks_host[i];
-    return select_ranks(data, n, r, nr, out, ws, (hipStream_t)stream);
+    return select_ranks(data, n, r, nr, out, ws, (hipStream_t)stream, nullptr, nullptr);
 }
 
 extern "C" int yond_percentiles_f32(const float* data, size_t n, const double* q_host, int nq, double* out, void* ws,
@@ -371,10 +428,7 @@ extern "C" int yond_percentiles_f32(const float* data, size_t n, const double* q
         r[2 * i + 1] = hi;
         la.t[i] = vidx - (double)lo;
     }
+    la.nq = nq;
     float* vals = (float*)((unsigned char*)ws + sizeof(SelState));
-    const int rc = select_ranks(data, n, r, 2 * nq, vals, ws, (hipStream_t)stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(percentile_lerp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vals, la, nq, out);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
+    return select_ranks(data, n, r, 2 * nq, vals, ws, (hipStream_t)stream, &la, out);
 }

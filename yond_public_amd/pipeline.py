@@ -135,15 +135,44 @@ def _percentiles(data_flat, quants):
     return out
 
 
-def _accumulate(lap, mean, var, ths_dev):
+def _occupancy(lap, mean, ths_dev, width=None):
+    """K7a over flat maps; `width` = row length of the maps (lets a lane walk down a column of the smooth maps).
+    Returns the occupancy bitmap [nt][32] int32 on the device; see _occ_unpack."""
     lib = L.load()
     nt = ths_dev.numel()
-    occ = torch.empty((nt, NBINS), dtype=torch.int32, device=lap.device)
-    mom = torch.empty((nt + 1, 2, 5), dtype=torch.float64, device=lap.device)
-    ws = torch.empty(64, dtype=torch.uint8, device=lap.device)
-    L.check(lib.yond_nlf_accumulate_f32(L.ptr(lap), L.ptr(mean), L.ptr(var), lap.numel(), L.ptr(ths_dev), nt, L.ptr(occ),
-                                        L.ptr(mom), L.ptr(ws), L.stream()), "yond_nlf_accumulate_f32")
-    return occ, mom
+    n = lap.numel()
+    width = int(width) if width and n % int(width) == 0 else n
+    occ = torch.empty((nt, NBINS // 32), dtype=torch.int32, device=lap.device)
+    L.check(lib.yond_nlf_occupancy_f32(L.ptr(lap), L.ptr(mean), n, width, L.ptr(ths_dev), nt, L.ptr(occ), L.stream()),
+            "yond_nlf_occupancy_f32")
+    return occ
+
+
+def _score3_device(occ, ths_dev, quants):
+    """K7s: (sel = [i*, ths[i*], quants[i*], score[i*]] float64, npeaks int32) on the device."""
+    lib = L.load()
+    nt = ths_dev.numel()
+    q = np.ascontiguousarray(quants, dtype=np.float64)
+    sel = torch.empty(4, dtype=torch.float64, device=occ.device)
+    npeaks = torch.empty(nt, dtype=torch.int32, device=occ.device)
+    L.check(lib.yond_nlf_score3_f64(L.ptr(occ), L.ptr(ths_dev), C.c_void_p(q.ctypes.data), nt, L.ptr(sel), L.ptr(npeaks),
+                                    L.stream()), "yond_nlf_score3_f64")
+    return sel, npeaks
+
+
+def _moments(lap, mean, var, th_dev):
+    """K7b: [2][5] float64 sums {n, Sm, Sv, Smm, Smv} over lap < th (th: float64 device scalar / 1-element view)."""
+    lib = L.load()
+    mom = torch.empty((2, 5), dtype=torch.float64, device=lap.device)
+    L.check(lib.yond_nlf_moments_f32(L.ptr(lap), L.ptr(mean), L.ptr(var), lap.numel(), L.ptr(th_dev), L.ptr(mom), L.stream()),
+            "yond_nlf_moments_f32")
+    return mom
+
+
+def _occ_unpack(occ_words):
+    """[nt][32] bitmap words (host array) -> [nt][1024] booleans."""
+    w = np.ascontiguousarray(occ_words).view(np.uint32)
+    return ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool).reshape(w.shape[0], -1)
 
 
 def _fit_from_moments(m_all, m_ns):
@@ -161,11 +190,11 @@ def get_threshold(data, step=5, mode='score3', print_log=False, scale=1023 - 64,
     if mode != 'score3':
         raise NotImplementedError(mode)
     lap, mean = data
+    width = lap.shape[-1] if lap.dim() > 1 else None
     lap, mean = lap.reshape(-1), mean.reshape(-1)
     quants = np.linspace(step, 100, 100 // step, endpoint=True)
     ths_dev = _percentiles(lap, quants)
-    var_dummy = mean
-    occ, mom = _accumulate(lap, mean, var_dummy, ths_dev)
+    occ = _occupancy(lap, mean, ths_dev, width)
     ths = ths_dev.cpu().numpy()
     th, pct, info = _score3(ths, quants, occ.cpu().numpy())
     if _full:
@@ -173,25 +202,34 @@ def get_threshold(data, step=5, mode='score3', print_log=False, scale=1023 - 64,
     return th, pct
 
 
-def _score3(ths, quants, occ):
-    seen = np.logical_or.accumulate(occ.astype(bool), axis=0)
-    npeaks = seen.sum(axis=1).astype(np.float64)                 # YOND_SIDD.py:37-43
+def _score3(ths, quants, occ=None, npeaks=None):
+    """YOND_SIDD.py:37-47 from the occupancy bitmap (or from npeaks already counted on the device)."""
+    if npeaks is None:
+        seen = np.logical_or.accumulate(_occ_unpack(occ), axis=0)
+        npeaks = seen.sum(axis=1)
+    npeaks = np.asarray(npeaks).astype(np.float64)               # YOND_SIDD.py:37-43
     score = ths / (quants * npeaks)                              # :45
     i = int(np.argmin(score[1:]) + 1)                            # :46-47
     return ths[i], quants[i], dict(ths=ths, npeaks=npeaks, score=score, index=i)
 
 
 def _nlf_from_maps(lap, mean, var, full=False):
-    """Shared tail of SelfNLF / CollabNLF (YOND_SIDD.py:75-87 / 103-115)."""
+    """Shared tail of SelfNLF / CollabNLF (YOND_SIDD.py:75-87 / 103-115).  Percentiles, occupancy, score3 and
+    the moment sums below the selected threshold all run on the device; one host sync at the end."""
+    width = lap.shape[-1] if lap.dim() > 1 else None
     lap, mean, var = lap.reshape(-1), mean.reshape(-1), var.reshape(-1)
     quants = np.linspace(5, 100, 20, endpoint=True)
     ths_dev = _percentiles(lap, quants)
-    occ, mom = _accumulate(lap, mean, var, ths_dev)
-    ths = ths_dev.cpu().numpy()                                  # one sync for the three small results
-    occ_h, mom_h = occ.cpu().numpy(), mom.cpu().numpy()
-    th, pct, info = _score3(ths, quants, occ_h)
-    i = info['index']
-    sel = mom_h[:i + 1].sum(axis=0)                              # pixels with lap < ths[i]
+    occ = _occupancy(lap, mean, ths_dev, width)
+    sel_dev, npeaks_dev = _score3_device(occ, ths_dev, quants)
+    mom = _moments(lap, mean, var, sel_dev[1:2])
+    small = torch.cat([ths_dev, sel_dev, mom.reshape(-1), npeaks_dev.to(torch.float64)]).cpu().numpy()   # the one sync
+    nq = len(quants)
+    ths, sel_h, mom_h, npeaks = small[:nq], small[nq:nq + 4], small[nq + 4:nq + 14].reshape(2, 5), small[nq + 14:]
+    th, pct, info = _score3(ths, quants, npeaks=npeaks)
+    if info['index'] != int(sel_h[0]) or th != sel_h[1]:          # host and device run the same float64 formula
+        raise L.YondHipError(f"score3 mismatch: device picked {sel_h[0]:.0f}/{sel_h[1]!r}, host {info['index']}/{th!r}")
+    sel = mom_h                                                  # pixels with lap < ths[i]
     if sel[0, 0] > 0:
         reg = _fit_from_moments(sel[0], sel[1])
     else:                                                        # :79-84 'no flat area'
@@ -199,10 +237,9 @@ def _nlf_from_maps(lap, mean, var, full=False):
         th_backup = float(th_b.cpu().numpy()[0])
         if th != th_backup:
             th = th_backup
-            occ2, mom2 = _accumulate(lap, mean, var, th_b)
-            sel = mom2.cpu().numpy()[0]
-        else:
-            sel = mom_h.sum(axis=0)
+            sel = _moments(lap, mean, var, th_b).cpu().numpy()
+        else:                                                    # same threshold: the empty selection falls back to all
+            sel = _moments(lap, mean, var, torch.full((1,), float('inf'), dtype=torch.float64, device=lap.device)).cpu().numpy()
         reg = _fit_from_moments(sel[0], sel[1])
     if full:
         info.update(th=th, percent=pct, nsel=int(sel[0, 0]))

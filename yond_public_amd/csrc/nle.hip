@@ -1,7 +1,7 @@
 // K5-K7: the noise-level estimator's data passes (YOND_SIDD.py:13-115, utils/isp_algos.py:234-242, 345-365).
 //   K5  box statistics: cv2.blur semantics (normalised k x k window, BORDER_REFLECT_101), window sums in
-//       float64 (the float32 inputs make them exact), every intermediate rounded to float32 exactly where
-//       NumPy / OpenCV round (no fused multiply-adds across those points).
+//       float64, every intermediate rounded to float32 exactly where NumPy / OpenCV round (no fused
+//       multiply-adds across those points).
 //   K6  exact order statistics + np.percentile's linear interpolation: nle_select.hip.
 //   K7  occupancy of the 1/1000 mean bins per threshold bucket (one sweep), score-3 selection on the device,
 //       and the five moment sums of the least-squares line below the selected threshold (one sweep).
@@ -9,54 +9,58 @@
 #include "common.h"
 
 // =====================================================================================================
-// K5
+// K5: box statistics, streamed down the rows
 // =====================================================================================================
-#define BX_TH 32
-#define BX_TW 64
-#define BX_R 14
-#define BX_RH (BX_TH + 2 * BX_R)
-#define BX_RW (BX_TW + 2 * BX_R)
+// A workgroup owns one plane, a strip of <= 256 - 2R "virtual" columns (outputs plus the reflected halo of
+// R = k/2 on either side, one column per thread) and a segment of rows.  It walks down the rows:
+//   vertical   every thread keeps the running k-row sums of its column in float64 registers
+//              (S += entering - leaving; the leaving row is read again from L2) -- float32 data summed in
+//              float64 is exact, so add/subtract leaves no drift;
+//   horizontal the k-column window sum is a difference of two prefix sums across the strip: a DPP
+//              inclusive scan inside each wave (row_shr 1/2/4/8, row_bcast 15/31), wave totals through LDS,
+//              then out[c] = Q[c + R] - Q[c - R - 1].  The prefix over <= 256 columns costs a relative
+//              error of ~1e-15 on the window sum, far below the float32 rounding that follows.
+// BS_B rows are processed per barrier pair.  Every intermediate is rounded to float32 exactly where NumPy /
+// OpenCV round (cv2.blur returns float32; stdfilt squares and subtracts in float32; no FMA contraction).
+#define BS_T 256
+#define BS_B 4
+#define BS_MAXR 14
+#define BS_MAXOH 256         // rows per segment (row table in LDS)
 
-// Window sums of one quantity for this thread's 8 outputs: rows 8*(tid>>6) + i (i = 0..7), column tid&63.
-// s_src: float [BX_RH][BX_RW] (tile with halo BX_R), s_h: double [BX_RH][BX_TW] scratch.
-// Both passes slide the window (sum += entering - leaving) over runs of 8 outputs: 29+14 LDS reads per run
-// instead of 8*29.  float32 data summed in float64: the window sums are exact (or differ from a direct sum
-// by ~1e-16 relative for the squares), far below the float32 rounding that follows.
-__device__ __forceinline__ void window_sums(const float* s_src, bool square, int k, double* s_h, double out[8]) {
-    const int tid = threadIdx.x;
-    const int rk = k / 2;
-    const int off = BX_R - rk;                       // first tile row/col that the window of output 0 touches
-    const int nrows = BX_TH + 2 * rk;
-    __syncthreads();                                 // previous user of s_h is done
-    for (int it = tid; it < nrows * (BX_TW / 8); it += 256) {
-        const int row = it / (BX_TW / 8) + off, c0 = (it % (BX_TW / 8)) * 8;
-        const float* p = s_src + row * BX_RW + c0 + off;
-        double* o = s_h + row * BX_TW + c0;
-        double s = 0.0;
-        if (square) {
-            for (int d = 0; d < k; ++d) { const float v = p[d]; s += (double)__fmul_rn(v, v); }
-            o[0] = s;
+struct BoxSrc {
+    const float* p;     // base pointer
+    int bayer;          // 1: Bayer frame [2h][2w], plane = blockIdx.z ; 0: planar [4][h][w]
+};
+
+struct BoxGeom {
+    int h, w, k, k2, tile_w;
+    int ow_nom, nstrip, oh;     // outputs per strip, strips per (tile_w-wide) block, rows per segment
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+    // lanes without a source (or masked rows) receive +0.0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// inclusive prefix sums across the 64 lanes of N independent values, step by step over all of them so that the
+// dependent DPP -> add chains of different values overlap
+template <int N>
+__device__ __forceinline__ void wave_incl_scan_f64(double (&v)[N]) {
 #pragma unroll
-            for (int j = 1; j < 8; ++j) {
-                const float vn = p[j + k - 1], vo = p[j - 1];
-                s += (double)__fmul_rn(vn, vn) - (double)__fmul_rn(vo, vo);
-                o[j] = s;
-            }
-        } else {
-            for (int d = 0; d < k; ++d) s += (double)p[d];
-            o[0] = s;
+    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x111, 0xf>(v[i]);       // row_shr:1
 #pragma unroll
-            for (int j = 1; j < 8; ++j) { s += (double)p[j + k - 1] - (double)p[j - 1]; o[j] = s; }
-        }
-    }
-    __syncthreads();
-    const int col = tid & 63, rg = tid >> 6;
-    const double* q = s_h + (rg * 8 + off) * BX_TW + col;
-    double s = 0.0;
-    for (int d = 0; d < k; ++d) s += q[d * BX_TW];
-    out[0] = s;
+    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x112, 0xf>(v[i]);       // row_shr:2
 #pragma unroll
-    for (int i = 1; i < 8; ++i) { s += q[(i + k - 1) * BX_TW] - q[(i - 1) * BX_TW]; out[i] = s; }
+    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x114, 0xf>(v[i]);       // row_shr:4
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x118, 0xf>(v[i]);       // row_shr:8
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x142, 0xa>(v[i]);       // row_bcast:15 into rows 1, 3
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x143, 0xc>(v[i]);       // row_bcast:31 into rows 2, 3
 }
 
 __device__ __forceinline__ float blur_round(double s, int k) { return (float)(s * (1.0 / (double)(k * k))); }
@@ -67,101 +71,184 @@ __device__ __forceinline__ float std_from(float b1, float b2) {
     return __fsqrt_rn(fmaxf(d, 0.0f));
 }
 
-struct BoxSrc {
-    const float* p;     // base pointer
-    int bayer;          // 1: Bayer frame [2h][2w], plane = blockIdx.z ; 0: planar [4][h][w]
-};
-
-__device__ __forceinline__ void load_tile(float* s_src, BoxSrc src, int h, int w, int tile_w, int oy0, int ox0, int plane) {
-    // reflect inside [0,h) x [bx0, bx0+bw): bw = tile_w (SIDD_256 re-tiling) or the whole width
-    const int bw = tile_w > 0 ? tile_w : w;
-    const int bx0 = tile_w > 0 ? (ox0 / tile_w) * tile_w : 0;
-    const int dy = plane >> 1, dx = plane & 1;
-    for (int it = threadIdx.x; it < BX_RH * BX_RW; it += 256) {
-        const int ty = it / BX_RW, tx = it % BX_RW;
-        const int gy = reflect101(oy0 - BX_R + ty, h);
-        const int gx = bx0 + reflect101(ox0 - BX_R + tx - bx0, bw);
-        float v;
-        if (src.bayer) v = src.p[(size_t)(2 * gy + dy) * (2 * w) + 2 * gx + dx];
-        else v = src.p[((size_t)plane * h + gy) * w + gx];
-        s_src[it] = v;
-    }
-}
-
 // mode 0: self stage 1 (mean, var, blur2 from the Bayer frame); 1: self stage 2 (lap from blur2);
 // 2: collab (mean, var, lap from noisy + denoised Bayer frames)
 template <int MODE>
-__global__ __launch_bounds__(256) void box_stats_kernel(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_w,
-                                                        float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* s_h = (double*)smem_raw;                                   // [BX_RH][BX_TW]
-    float* s_a = (float*)(smem_raw + sizeof(double) * BX_RH * BX_TW);  // [BX_RH][BX_RW]
-    float* s_b = s_a + BX_RH * BX_RW;
+__global__ __launch_bounds__(BS_T) void box_stream_kernel(BoxSrc a, BoxSrc b, BoxGeom g, float* __restrict__ o0,
+                                                         float* __restrict__ o1, float* __restrict__ o2) {
+    constexpr int NQ = MODE == 0 ? 3 : (MODE == 1 ? 2 : 4);      // running sums per column
+    constexpr int NI = MODE == 2 ? 2 : 1;                        // input frames
+    constexpr int NL = MODE == 0 ? 3 : 2;                        // loads per input and row: entering, leaving (k), leaving (k2)
+    __shared__ double s_p[NQ][BS_B][BS_T];
+    __shared__ double s_tot[NQ][BS_B][BS_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int plane = blockIdx.z;
-    const int ox0 = blockIdx.x * BX_TW, oy0 = blockIdx.y * BX_TH;
-    load_tile(s_a, a, h, w, tile_w, oy0, ox0, plane);
-    if (MODE == 2) load_tile(s_b, b, h, w, tile_w, oy0, ox0, plane);
-    double q0[8], q1[8], q2[8], q3[8];
-    if (MODE == 0) {
-        window_sums(s_a, false, k, s_h, q0);
-        window_sums(s_a, true, k, s_h, q1);
-        window_sums(s_a, false, k2, s_h, q2);
-    } else if (MODE == 1) {
-        window_sums(s_a, false, k, s_h, q0);
-        window_sums(s_a, true, k, s_h, q1);
-    } else {
-        window_sums(s_a, false, k, s_h, q0);
-        window_sums(s_a, true, k, s_h, q1);
-        window_sums(s_b, false, k, s_h, q2);
-        window_sums(s_b, true, k, s_h, q3);
-    }
-    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int ox = ox0 + col;
+    const int h = g.h, w = g.w, k = g.k, k2 = g.k2;
+    const int R = k / 2, R2 = k2 / 2;
+    // columns: reflect inside [bx0, bx0 + bw) -- bw = tile_w (SIDD_256 re-tiling) or the whole width
+    const int bw = g.tile_w > 0 ? g.tile_w : w;
+    const int blk = blockIdx.x / g.nstrip, strip = blockIdx.x % g.nstrip;
+    const int bx0 = blk * bw;
+    const int ox0 = bx0 + strip * g.ow_nom;
+    const int ow = min(g.ow_nom, bx0 + bw - ox0);
+    const bool live = tid < ow + 2 * R;
+    const int rc = bx0 + reflect101(ox0 - R + tid - bx0, bw);
+    const bool writer = tid >= R && tid < R + ow;
+    const int ox = ox0 + tid - R;
+    // rows
+    const int oy0 = blockIdx.y * g.oh;
+    const int ohe = min(g.oh, h - oy0);
+    const int nsteps = ohe + 2 * R;
+    const float* base[NI];
+    size_t rstride[NI];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int oy = oy0 + rg * 8 + i;
-        if (oy >= h || ox >= w) continue;
-        const size_t idx = ((size_t)plane * h + oy) * w + ox;
-        if (MODE == 0) {
-            const float m = blur_round(q0[i], k);
-            const float sd = std_from(m, blur_round(q1[i], k));
-            o0[idx] = m;
-            o1[idx] = __fmul_rn(sd, sd);                              // var = lr_rggb_k**2 (YOND_SIDD.py:72)
-            o2[idx] = blur_round(q2[i], k2);
-        } else if (MODE == 1) {
-            o0[idx] = std_from(blur_round(q0[i], k), blur_round(q1[i], k));
-        } else {
-            const float sl = std_from(blur_round(q0[i], k), blur_round(q1[i], k));
-            const float mh = blur_round(q2[i], k);
-            const float sh = std_from(mh, blur_round(q3[i], k));
-            o0[idx] = mh;                                              // mean = blur(hr) (YOND_SIDD.py:97)
-            o1[idx] = __fsub_rn(__fmul_rn(sl, sl), __fmul_rn(sh, sh));  // var = lr_k**2 - hr_k**2 (:96)
-            o2[idx] = sh;                                              // img_lap = hr_k (:98)
+    for (int i = 0; i < NI; ++i) {
+        const BoxSrc src = i == 0 ? a : b;
+        if (src.bayer) { base[i] = src.p + (size_t)(plane >> 1) * (2 * w) + 2 * rc + (plane & 1); rstride[i] = (size_t)4 * w; }
+        else { base[i] = src.p + (size_t)plane * h * w + rc; rstride[i] = (size_t)w; }
+    }
+    // image row of every local row l (reflect(oy0 - R + l)), once per workgroup
+    __shared__ int s_row[BS_MAXOH + 2 * BS_MAXR];
+    for (int l = tid; l < nsteps; l += BS_T) s_row[l] = reflect101(oy0 - R + l, h);
+    __syncthreads();
+    // value of local row l, l clamped into [0, nsteps).  Nothing depends on the loaded value until the batch is
+    // consumed, so the loads of a batch stay in flight together.  Idle columns and rows past the end read valid
+    // addresses: what they add only reaches prefix positions / rows that are never emitted.  Rows before the
+    // start (the "leaving" row of the first k steps) are zeroed by a 0/1 factor when the batch is consumed.
+    auto ld = [&](int i, int l) -> float {
+        const int gy = s_row[min(max(l, 0), nsteps - 1)];
+        return base[i][(size_t)gy * rstride[i]];
+    };
+    float cur[NI][NL][BS_B], nxt[NI][NL][BS_B];
+    auto load_batch = [&](float (&dst)[NI][NL][BS_B], int l0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int r = 0; r < BS_B; ++r) {
+                dst[i][0][r] = ld(i, l0 + r);
+                dst[i][1][r] = ld(i, l0 + r - k);
+                if (NL == 3) dst[i][2][r] = ld(i, l0 + r - k2);
+            }
         }
+    };
+    double S[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) S[q] = 0.0;
+    load_batch(nxt, 0);
+    for (int l0 = 0; l0 < nsteps; l0 += BS_B) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+#pragma unroll
+                for (int r = 0; r < BS_B; ++r) cur[i][j][r] = nxt[i][j][r];
+            }
+        }
+        if (l0 + BS_B < nsteps) load_batch(nxt, l0 + BS_B);
+        double P[NQ * BS_B];
+#pragma unroll
+        for (int r = 0; r < BS_B; ++r) {
+            const float mk = (l0 + r >= k) ? 1.0f : 0.0f, mk2 = (l0 + r >= k2) ? 1.0f : 0.0f;   // leaving row exists
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float xn = cur[i][0][r], xo = __fmul_rn(cur[i][1][r], mk);
+                S[2 * i] += (double)xn - (double)xo;
+                S[2 * i + 1] += (double)__fmul_rn(xn, xn) - (double)__fmul_rn(xo, xo);
+            }
+            if (MODE == 0) S[2] += (double)cur[0][0][r] - (double)__fmul_rn(cur[0][2][r], mk2);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) P[q * BS_B + r] = S[q];
+        }
+        // warm-up rows (no window complete yet) only feed the vertical sums: uniform skip of the horizontal pass
+        if (l0 + BS_B <= (MODE == 0 ? R + R2 : 2 * R)) continue;
+        wave_incl_scan_f64(P);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int r = 0; r < BS_B; ++r) {
+                s_p[q][r][tid] = P[q * BS_B + r];
+                if (lane == 63) s_tot[q][r][wave] = P[q * BS_B + r];
+            }
+        }
+        __syncthreads();
+        if (writer) {
+#pragma unroll
+            for (int r = 0; r < BS_B; ++r) {
+                const int l = l0 + r;
+                // window sum of quantity q with radius rad around this thread's column
+                auto win = [&](int q, int rad) -> double {
+                    // Q[hi] - Q[lo] with Q = in-wave prefix + totals of the waves before: hi and lo are at most
+                    // one wave apart (2 * rad + 1 <= 29 < 64), so the totals cancel except for the wave of lo
+                    const int hi = tid + rad, lo = tid - rad - 1;
+                    double d = s_p[q][r][hi];
+                    if (lo >= 0) {
+                        d -= s_p[q][r][lo];
+                        if ((hi >> 6) != (lo >> 6)) d += s_tot[q][r][lo >> 6];
+                    }
+                    return d;
+                };
+                const int oy = oy0 + l - 2 * R;                                   // k-window centred here is complete
+                if (l >= 2 * R && l < nsteps) {
+                    const size_t idx = ((size_t)plane * h + oy) * w + ox;
+                    if (MODE == 0) {
+                        const float m = blur_round(win(0, R), k);
+                        const float sd = std_from(m, blur_round(win(1, R), k));
+                        o0[idx] = m;
+                        o1[idx] = __fmul_rn(sd, sd);                              // var = lr_rggb_k**2 (YOND_SIDD.py:72)
+                    } else if (MODE == 1) {
+                        o0[idx] = std_from(blur_round(win(0, R), k), blur_round(win(1, R), k));
+                    } else {
+                        const float sl = std_from(blur_round(win(0, R), k), blur_round(win(1, R), k));
+                        const float mh = blur_round(win(2, R), k);
+                        const float sh = std_from(mh, blur_round(win(3, R), k));
+                        o0[idx] = mh;                                              // mean = blur(hr) (YOND_SIDD.py:97)
+                        o1[idx] = __fsub_rn(__fmul_rn(sl, sl), __fmul_rn(sh, sh));  // var = lr_k**2 - hr_k**2 (:96)
+                        o2[idx] = sh;                                              // img_lap = hr_k (:98)
+                    }
+                }
+                if (MODE == 0) {
+                    const int oy2 = oy0 + l - R - R2;                             // k2-window centred here is complete
+                    if (l >= R + R2 && oy2 < oy0 + ohe)
+                        o2[((size_t)plane * h + oy2) * w + ox] = blur_round(win(2, R2), k2);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
 static int box_args_ok(int h, int w, int k, int tile_w) {
     if (h < 1 || w < 1) return YOND_EINVAL;
     if (k < 1 || !(k & 1)) return YOND_EINVAL;
-    if (k > 2 * BX_R + 1) return YOND_EUNSUPPORTED;
+    if (k > 2 * BS_MAXR + 1) return YOND_EUNSUPPORTED;
     if (tile_w < 0) return YOND_EINVAL;
-    if (tile_w > 0 && (tile_w % BX_TW != 0 || w % tile_w != 0)) return YOND_EUNSUPPORTED;
+    if (tile_w > 0 && w % tile_w != 0) return YOND_EUNSUPPORTED;
     return YOND_OK;
 }
 
 template <int MODE>
 static int launch_box(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_w, float* o0, float* o1, float* o2, hipStream_t st) {
-    const size_t smem = sizeof(double) * BX_RH * BX_TW + sizeof(float) * BX_RH * BX_RW * (MODE == 2 ? 2 : 1);
-    static bool attr = false;
-    auto kern = box_stats_kernel<MODE>;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
-    dim3 grid((w + BX_TW - 1) / BX_TW, (h + BX_TH - 1) / BX_TH, 4);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a, b, h, w, k, k2, tile_w, o0, o1, o2);
+    if (k2 > k) return YOND_EUNSUPPORTED;
+    BoxGeom g;
+    g.h = h; g.w = w; g.k = k; g.k2 = k2; g.tile_w = tile_w;
+    const int bw = tile_w > 0 ? tile_w : w;
+    const int nblk = w / bw;
+    const int maxow = BS_T - 2 * (k / 2);
+    g.nstrip = (bw + maxow - 1) / maxow;
+    g.ow_nom = (bw + g.nstrip - 1) / g.nstrip;
+    // row segments: about four workgroups per CU in one round; longer segments re-read fewer halo rows
+    long target = 1024;
+    if (const char* e = getenv("YOND_BOX_WGS")) target = atol(e);        // experiments only
+    const long cols = 4L * nblk * g.nstrip;
+    long nseg = (target + cols / 2) / cols;
+    if (nseg < 1) nseg = 1;
+    g.oh = (int)((h + nseg - 1) / nseg);
+    if (g.oh < 16) g.oh = 16;
+    if (g.oh > BS_MAXOH) g.oh = BS_MAXOH;
+    if (g.oh > h) g.oh = h;
+    const int nsy = (h + g.oh - 1) / g.oh;
+    dim3 grid((unsigned)(nblk * g.nstrip), (unsigned)nsy, 4);
+    hipLaunchKernelGGL(box_stream_kernel<MODE>, grid, dim3(BS_T), 0, st, a, b, g, o0, o1, o2);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -9,19 +9,86 @@
 
 #define LUT_MAX 4096
 
-__device__ __forceinline__ double lut_eval(const double* __restrict__ sx, const float* __restrict__ sy, int n, float xq) {
+#define LUT_MAXSEG 8
+
+// The bias LUT's knots (utils/isp_algos.py:103-108) are runs of evenly spaced values (step 0.1, 1, 10): the
+// kernel finds the runs once per workgroup, guesses the knot index of a query with one multiply and repairs the
+// guess against the knots themselves, so the result is exactly searchsorted's whatever the spacing is
+// (irregular knots only cost more repair steps; more than LUT_MAXSEG runs fall back to bisection).
+struct LutLds {
+    double* x;                   // [n]  knots          (dynamic LDS: 20 bytes per knot)
+    double* slope;               // [n]  slope of the interval that ends at knot i (i >= 1)
+    float* y;                    // [n]
+    double seg_x[LUT_MAXSEG], seg_inv[LUT_MAXSEG];
+    int seg_i[LUT_MAXSEG + 1];
+    int nseg;                    // 0: bisection
+    int nbreak;
+};
+
+__device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict__ lut_x, const float* __restrict__ lut_y, int n) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 256) { L.x[i] = lut_x[i]; L.y[i] = lut_y[i]; }
+    if (tid == 0) { L.nbreak = 0; L.nseg = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        if (i >= 1) {
+            const float dy = L.y[i] - L.y[i - 1];                 // float32 difference, as interp1d does with float32 knots
+            L.slope[i] = (double)dy / (L.x[i] - L.x[i - 1]);
+        }
+        if (i >= 1 && i + 1 < n) {
+            const double d0 = L.x[i] - L.x[i - 1], d1 = L.x[i + 1] - L.x[i];
+            if (fabs(d1 - d0) > 1e-3 * fabs(d0)) {                 // the spacing changes at knot i
+                const int slot = atomicAdd(&L.nbreak, 1);
+                if (slot < LUT_MAXSEG - 1) L.seg_i[slot + 1] = i;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int nb = L.nbreak;
+        if (nb <= LUT_MAXSEG - 1 && n >= 2) {
+            L.seg_i[0] = 0;
+            for (int a = 2; a <= nb; ++a) {                        // insertion sort of <= 7 break indices
+                const int v = L.seg_i[a];
+                int j = a - 1;
+                while (j >= 1 && L.seg_i[j] > v) { L.seg_i[j + 1] = L.seg_i[j]; --j; }
+                L.seg_i[j + 1] = v;
+            }
+            L.seg_i[nb + 1] = n - 1;
+            for (int sgm = 0; sgm <= nb; ++sgm) {
+                const int i0 = L.seg_i[sgm];
+                L.seg_x[sgm] = L.x[i0];
+                L.seg_inv[sgm] = 1.0 / (L.x[i0 + 1] - L.x[i0]);
+            }
+            L.nseg = nb + 1;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double lut_eval(const LutLds& L, int n, float xq) {
     // scipy interp1d(kind='linear')._call_linear: hi = clip(searchsorted(x, xq, 'left'), 1, n-1)
     const double x = (double)xq;
-    int lo = 0, hi = n;                     // first index with sx[idx] >= x
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (sx[mid] < x) lo = mid + 1; else hi = mid;
+    int g;
+    const int nseg = L.nseg;
+    if (nseg > 0) {
+        int sgm = 0;
+        for (int i = 1; i < nseg; ++i) sgm += (x >= L.seg_x[i]) ? 1 : 0;
+        const double t = (x - L.seg_x[sgm]) * L.seg_inv[sgm];
+        const int i0 = L.seg_i[sgm], i1 = L.seg_i[sgm + 1];
+        int off = t > 0.0 ? (t < 1e9 ? (int)ceil(t) : 1000000000) : 0;
+        g = i0 + off;
+        g = g > i1 ? i1 : g;
+        while (g > 0 && L.x[g - 1] >= x) --g;                      // repair: first index with x[idx] >= xq
+        while (g < n && L.x[g] < x) ++g;
+    } else {
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.x[mid] < x) lo = mid + 1; else hi = mid; }
+        g = lo;
     }
-    int ih = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    const int ih = g < 1 ? 1 : (g > n - 1 ? n - 1 : g);
     const int il = ih - 1;
-    const float dy = sy[ih] - sy[il];       // float32 difference, as interp1d does with float32 knots
-    const double slope = (double)dy / (sx[ih] - sx[il]);
-    return slope * (x - sx[il]) + (double)sy[il];
+    return L.slope[ih] * (x - L.x[il]) + (double)L.y[il];
 }
 
 __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restrict__ bayer, int H, int W,
@@ -30,11 +97,16 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
                                                             double lo, double hi, const double* __restrict__ lut_x,
                                                             const float* __restrict__ lut_y, int lut_n,
                                                             unsigned int* __restrict__ img_max) {
-    __shared__ double s_x[LUT_MAX];
-    __shared__ float s_y[LUT_MAX];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lut_raw[];
+    __shared__ LutLds L;
     __shared__ float s_red[4];
-    for (int i = threadIdx.x; i < lut_n; i += 256) { s_x[i] = lut_x[i]; s_y[i] = lut_y[i]; }
+    if (threadIdx.x == 0) {
+        L.x = (double*)lut_raw;
+        L.slope = L.x + lut_n;
+        L.y = (float*)(L.slope + lut_n);
+    }
     __syncthreads();
+    if (lut_n > 0) lut_prepare(L, lut_x, lut_y, lut_n);
     const int h = H / 2, w = W / 2;
     const size_t total = (size_t)Hp * Wp;
     const double c0 = 0.375 * gain * gain;       // (3/8)*gain**2
@@ -59,7 +131,7 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
                 double fz = gain * (double)x32 + c0 + s2;               // gain*x + (3/8)gain^2 + sigma^2 (- gain*0)
                 fz = fz > 0.0 ? fz : 0.0;
                 double v = two_over_gain * sqrt(fz);
-                if (lut_n > 0) v -= lut_eval(s_x, s_y, lut_n, fmaxf(x32, 0.0f));
+                if (lut_n > 0) v -= lut_eval(L, lut_n, fmaxf(x32, 0.0f));
                 u = (float)((v - lo) / span);
             }
             u = fminf(fmaxf(u, 0.0f), 1.0f);
@@ -97,9 +169,16 @@ extern "C" int yond_pack_vst_norm_f32(const float* bayer, int H, int W, float* o
     }
     const size_t total = (size_t)Hp * Wp;
     size_t nb = (total + 255) / 256;
-    if (nb > 256 * 16) nb = 256 * 16;
-    hipLaunchKernelGGL(pack_vst_norm_kernel, dim3((unsigned)nb), dim3(256), 0, st, bayer, H, W, out, pad_l, pad_t, Hp, Wp,
-                       mode, (float)scale, gain, sigma, lo, hi, lut_x, lut_y, mode == 1 ? lut_n : 0, (unsigned int*)img_max);
+    if (nb > 256 * 4) nb = 256 * 4;          // every workgroup prepares the LUT once: keep them few and long-lived
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)pack_vst_norm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_MAX * 20);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    const int use_lut = mode == 1 ? lut_n : 0;
+    hipLaunchKernelGGL(pack_vst_norm_kernel, dim3((unsigned)nb), dim3(256), (size_t)use_lut * 20, st, bayer, H, W, out,
+                       pad_l, pad_t, Hp, Wp, mode, (float)scale, gain, sigma, lo, hi, lut_x, lut_y, use_lut, (unsigned int*)img_max);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -67,8 +67,19 @@ class _HipDenoiser(nn.Module):
         self._plan = None
         self._plan_key = None
 
+    def _apply(self, fn, *a, **k):
+        # .to() / .float() / .cuda() replace the parameter storage: drop the packed plan and the cached list
+        self._plan = None
+        self._plist = None
+        return super()._apply(fn, *a, **k)
+
     def _get_plan(self, device):
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """Packed weights + launch plan, rebuilt when a parameter was written to (in-place updates bump
+        `_version`; storage replacement goes through `_apply`)."""
+        plist = getattr(self, '_plist', None)
+        if plist is None:
+            plist = self._plist = list(self.parameters())
+        key = (str(device), tuple([p._version for p in plist]))
         if self._plan is None or self._plan_key != key:
             self._plan = DenoiserPlan(self, device)
             self._plan_key = key

@@ -85,6 +85,23 @@ def _bias_knots(ub):
                            np.linspace(500, ub, int(ub - 500) // 10 + 2)))
 
 
+_KNOT_CACHE = {}
+
+
+def _knots_on_device(ub, dev):
+    """The knot grid depends only on ceil(max)+1: keep the last few grids resident (host array + float64 device
+    copy) so that consecutive frames of a dataset skip the host linspace and the H2D copy."""
+    key = (float(ub), str(np.asarray(ub).dtype), str(dev))       # a float32 max gives float32 knots below 50 (NumPy 2)
+    hit = _KNOT_CACHE.get(key)
+    if hit is None:
+        lams = _bias_knots(ub)
+        hit = (lams, torch.from_numpy(np.ascontiguousarray(lams, dtype=np.float64)).to(dev))
+        if len(_KNOT_CACHE) >= 8:
+            _KNOT_CACHE.pop(next(iter(_KNOT_CACHE)))
+        _KNOT_CACHE[key] = hit
+    return hit
+
+
 class DeviceBiasLUT:
     """What `get_bias` returns: the interp1d knots, resident on the device.  K1 evaluates it per pixel."""
 
@@ -110,9 +127,8 @@ def get_bias(img=None, sigGs=25.853043, K=24.48128, device=None):
     else:
         mx = np.max(img)
     ub = np.ceil(mx) + 1
-    lams = _bias_knots(ub)
     dev = torch.device(device if device is not None else 'cuda')
-    x_dev = torch.from_numpy(np.ascontiguousarray(lams, dtype=np.float64)).to(dev)
+    lams, x_dev = _knots_on_device(ub, dev)
     y_dev = torch.empty(len(lams), dtype=torch.float32, device=dev)
     if len(lams) > 4096:
         raise L.YondHipError(f"bias LUT with {len(lams)} knots exceeds the kernel's 4096-knot LDS table")
@@ -287,11 +303,13 @@ def _plan_of(net, device):
     return mod._get_plan(device)
 
 
-def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type='exact', clip01=False, device=None):
+def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type='exact', clip01=False, device=None,
+                 lr_max=None):
     """YOND_SIDD.py:250-299 for the network denoisers.  lr_raw: Bayer [H][W] -- or a stack [B][H][W] of equally
     sized frames that share (gain, sigma) and the bias LUT, e.g. the 32 blocks of a SIDD image, which then go
     through ONE batched forward instead of the reference's 32 batch-1 calls (:398-407).  p: dict with scale,
-    gain, sigma; returns the denoised frame(s) as a device tensor.  `clip01` folds the caller's .clip(0,1)."""
+    gain, sigma; returns the denoised frame(s) as a device tensor.  `clip01` folds the caller's .clip(0,1);
+    `lr_max` (float32 max of the frame) spares the device reduction + sync when the caller already has it."""
     lib = L.load()
     lr = _dev(lr_raw, device)
     single = lr.dim() == 2
@@ -305,7 +323,9 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
     if bias_corr is not None and bias_func is None:
         if not single:
             raise L.YondHipError("a stack of frames needs the shared bias LUT (the reference builds one per image, :392-397)")
-        mx = np.float32(lr.max().item()) * np.float32(scale)      # lr_rggb.max() of the float32 product
+        if lr_max is None:
+            lr_max = lr.max().item()
+        mx = np.float32(lr_max) * np.float32(scale)                # lr_rggb.max() of the float32 product
         bias_func = get_bias(mx, sigma, gain, device=lr.device)
     lower, upper = vst_scalar(0, sigma, gain), vst_scalar(scale, sigma, gain)
     nsr = 1 / (upper - lower)
@@ -392,17 +412,18 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     else:
         lr_cat = lr
     raw4est = lr_cat if lr_full is None else _dev(lr_full, lr.device)                  # :340
+    lr_max_dev = lr_cat.max()                  # queued ahead of the NLE; read after the NLE's own host sync
     reg = SimpleNLF(raw4est, k=k, setting={'mode': 'self'})                            # :341
     p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale            # :356
     if log:
         log(f"Self Est: K={p['gain']:.4f}, b={p['sigma']:.4f} (beta1={reg[0]:.3e}, beta2={reg[1]:.3e})")
     regs.append(reg)
     params.append((p['gain'], p['sigma']))
-    lr_max = np.float32(lr_cat.max().item())
+    lr_max = np.float32(lr_max_dev.item())
 
     def denoise_all(bias_func):
         if full_dn:                                                                    # :387-389
-            return VST_Denoiser(lr_cat, p, net, arch, bias_corr, bias_func, vst_type, clip01=True)
+            return VST_Denoiser(lr_cat, p, net, arch, bias_corr, bias_func, vst_type, clip01=True, lr_max=lr_max)
         if bias_corr is not None:
             outs = VST_Denoiser(blocks, p, net, arch, bias_corr, bias_func, vst_type, clip01=True)   # one batch-32 forward
         else:                                  # no shared LUT: per-block calls as the reference does (:398-407)

@@ -94,10 +94,7 @@ def polyfit(x, y, ransac=False, clip=False):
     if ransac:
         raise NotImplementedError("RANSAC fit (unused by YOND_SIDD.py:86)")
     xd, yd = _P._dev(x).reshape(-1), _P._dev(y).reshape(-1)
-    n = xd.numel()
-    pad = (-n) % 4
-    lap = torch.zeros(n, dtype=torch.float32, device=xd.device)
-    ths = torch.full((1,), float('inf'), dtype=torch.float64, device=xd.device)
-    occ, mom = _P._accumulate(lap, xd.contiguous(), yd.contiguous(), ths)
-    m = mom.cpu().numpy()[0]
+    lap = torch.zeros(xd.numel(), dtype=torch.float32, device=xd.device)          # every point is below th = inf
+    th = torch.full((1,), float('inf'), dtype=torch.float64, device=xd.device)
+    m = _P._moments(lap, xd.contiguous(), yd.contiguous(), th).cpu().numpy()
     return _P._fit_from_moments(m[0], m[1])

@@ -106,6 +106,8 @@ typedef struct YondConvDesc {
     float* dst;           /* [N][Ho][Wo][Cout]  (shuffle: see above) */
     int tn;               /* channel-tile width the weights were packed for (32 or 64, from yond_conv_config) */
     int kc;               /* channel chunk the weights were packed for (8 or 16, from yond_conv_config; 0 = default) */
+    int algo;             /* 0 direct implicit GEMM; 1 Winograd F(2x2,3x3) (3x3 stride 1 only; wpk from
+                             yond_pack_conv_wino_weight_f32, tn = 64, see yond_conv_wino_supported) */
 } YondConvDesc;
 
 /* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.
@@ -115,6 +117,13 @@ int yond_conv_config(int ksize, int stride, int cin, int cout, int shuffle, int 
  * already re-indexed [4*cout][cin][1][1] matrix.  dst has cout*cin*k*k floats. */
 int yond_pack_conv_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int kc, float* dst);
 int yond_conv2d_f32(const YondConvDesc* desc, void* stream);
+
+/* Winograd F(2x2,3x3) variant of the 3x3 stride-1 convolution (same descriptor, algo = 1): 16 instead of 36
+ * multiplications per output patch, fp32 throughout; the result differs from the direct kernel by rounding order
+ * only.  yond_conv_wino_supported: 1 when (cin, cout) fit its tiles (cin % 8 == 0, cout % 64 == 0).
+ * Weights: w OIHW [cout][cin][3][3] -> dst, 16*cout*cin floats (U = G g G^T in float64, rounded once). */
+int yond_conv_wino_supported(int cin, int cout);
+int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, float* dst);
 
 /* First layer: 3x3, Cin=4 -> Cout=32k, input NHWC4, optional division by the per-image maximum
  * (data_normalize, archs/Unet.py:427-431) and LeakyReLU(slope).  wpk from yond_pack_conv_in_weight_f32. */

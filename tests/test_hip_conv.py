@@ -73,6 +73,34 @@ def test_conv3x3_two_source_leaky():
     assert report("conv3x3 two-source", got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("C,Co,N,H,W", [(64, 64, 1, 8, 32), (64, 64, 2, 16, 64), (32, 64, 1, 9, 33), (128, 128, 1, 24, 40),
+                                        (256, 64, 1, 94, 126)])
+def test_conv3x3_winograd_plain(C, Co, N, H, W):
+    """Winograd F(2x2,3x3) kernel (algo 1) against the float64 direct convolution: same tolerance as the direct
+    kernel; partial tiles, odd extents, several tiles per workgroup."""
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(Co, generator=g)
+    got = nchw(run_conv(w, b, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, algo=1))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert report(f"winograd conv3x3 C{C}->{Co} {H}x{W}", got, ref) < 2e-5
+
+
+def test_conv3x3_winograd_fused_two_source():
+    g = torch.Generator().manual_seed(17)
+    N, C, H, W = 2, 64, 20, 72
+    a, b2 = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 2 * C, 3, 3, generator=g) / (3 * (2 * C) ** 0.5)
+    es, et = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
+    res = torch.randn(N, C, H, W, generator=g)
+    got = nchw(run_conv(w, None, 3, 1, [C, C], [nhwc(a).to(DEV), nhwc(b2).to(DEV)], N, H, W, escale=es.to(DEV), eshift=et.to(DEV),
+                        ebatch=1, res=nhwc(res).to(DEV), pre_act=1, post_act=2, slope=0.3, algo=1))
+    z = F.conv2d(F.silu(torch.cat([a, b2], 1).double()), w.double(), padding=1)
+    z = F.leaky_relu(z * es.double()[:, :, None, None] + et.double()[:, :, None, None], 0.3) + res.double()
+    assert report("winograd conv3x3 fused two-source", got, z) < 2e-5
+
+
 @pytest.mark.parametrize("C,N,H,W", [(32, 1, 16, 64), (64, 2, 32, 32), (32, 1, 18, 34)])
 def test_conv3x3_s2(C, N, H, W):
     g = torch.Generator().manual_seed(C + W)

@@ -20,7 +20,7 @@ class YondConvDesc(C.Structure):
     _fields_ = [("src0", vp), ("src1", vp), ("C0", i32), ("C1", i32), ("N", i32), ("H", i32), ("W", i32),
                 ("Ho", i32), ("Wo", i32), ("Cout", i32), ("ksize", i32), ("stride", i32), ("shuffle", i32),
                 ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
-                ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32)]
+                ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32)]
 
 
 class YondFilmDesc(C.Structure):
@@ -45,6 +45,8 @@ PROTOTYPES = {
     "yond_conv_config": [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
     "yond_pack_conv_weight_f32": [vp, i32, i32, i32, i32, i32, vp],
     "yond_conv2d_f32": [C.POINTER(YondConvDesc), vp],
+    "yond_conv_wino_supported": [i32, i32],
+    "yond_pack_conv_wino_weight_f32": [vp, i32, i32, i32, vp],
     "yond_conv_in_f32": [vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp],
     "yond_pack_conv_in_weight_f32": [vp, i32, vp],
     "yond_conv_out_f32": [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp],

@@ -478,12 +478,18 @@ extern "C" int yond_pack_conv_weight_f32(const float* w, int cout, int cin, int 
     return YOND_OK;
 }
 
+int yond_conv_wino_dispatch(const YondConvDesc& d, hipStream_t st);      // conv_wino.hip
+
 extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     if (!dp) return YOND_EINVAL;
     const YondConvDesc& d = *dp;
     hipStream_t st = (hipStream_t)stream;
     if (!d.src0 || !d.dst || !d.wpk || d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Ho <= 0 || d.Wo <= 0) return YOND_EINVAL;
     if (d.C1 > 0 && !d.src1) return YOND_EINVAL;
+    if ((long long)d.N * d.H * d.W > 0x7fffffffLL) return YOND_EUNSUPPORTED;    // 32-bit pixel offsets
+    if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;
+    if (d.algo == 1) return yond_conv_wino_dispatch(d, st);
+    if (d.algo != 0) return YOND_EINVAL;
     if (d.tn != 32 && d.tn != 64) return YOND_EINVAL;
     int tn, kc;
     const int rc = yond_conv_config(d.ksize, d.stride, d.C0 + d.C1, d.Cout, d.shuffle, 0, 0, 0, &tn, &kc);

@@ -14,6 +14,7 @@ zero-padded so every channel count is a multiple of 32, re-ordered once into the
 of the kernels (`yond_pack_conv_weight_f32`) and cached on the device.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -27,6 +28,10 @@ def _rup(c, m=32):
 
 def _np_ptr(a):
     return C.c_void_p(a.ctypes.data)
+
+
+# 3x3 stride-1 layers: 1 = Winograd F(2x2,3x3) where the layer fits it, 0 = direct implicit GEMM everywhere
+WINO_DEFAULT = int(os.environ.get('YOND_CONV_WINO', '0'))
 
 
 class _PackedConv:
@@ -88,6 +93,18 @@ class _PackedConv:
                                                   _np_ptr(packed)), "yond_pack_conv_weight_f32")
             self._packed[key] = torch.from_numpy(packed).to(self._dev)
         return tn.value, kc.value, self._packed[key]
+
+    def wino(self):
+        """Packed Winograd F(2x2,3x3) weights (tn 64) or None when the layer does not fit that kernel."""
+        lib = L.load()
+        if self.ksize != 3 or self.stride != 1 or self.shuffle or not lib.yond_conv_wino_supported(self.cinp, self.gemm_n):
+            return None
+        if 'wino' not in self._packed:
+            packed = np.empty(16 * self.gemm_n * self.cinp, np.float32)
+            L.check(lib.yond_pack_conv_wino_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, 64, _np_ptr(packed)),
+                    "yond_pack_conv_wino_weight_f32")
+            self._packed['wino'] = torch.from_numpy(packed).to(self._dev)
+        return self._packed['wino']
 
 
 class DenoiserPlan:
@@ -173,7 +190,7 @@ class DenoiserPlan:
 
     # -- launches ----------------------------------------------------------------------------
     def _conv(self, pc, src0, src1, N, H, W, dst, escale=None, eshift=None, ebatch=0, res=None, pre_act=0, post_act=0,
-              slope=0.0):
+              slope=0.0, algo=None):
         d = L.YondConvDesc()
         d.src0 = src0.data_ptr()
         d.src1 = src1.data_ptr() if src1 is not None else None
@@ -187,7 +204,15 @@ class DenoiserPlan:
         d.Cout = pc.gemm_n
         d.ksize, d.stride, d.shuffle = pc.ksize, pc.stride, int(pc.shuffle)
         d.pre_act, d.post_act, d.slope = pre_act, post_act, slope
-        tn, kc, wpk = pc.config(N, d.Ho, d.Wo)
+        if algo is None:
+            algo = getattr(self, 'conv_algo', WINO_DEFAULT)
+        wino = pc.wino() if algo == 1 else None
+        if wino is not None:
+            tn, kc, wpk = 64, 8, wino
+            d.algo = 1
+        else:
+            tn, kc, wpk = pc.config(N, d.Ho, d.Wo)
+            d.algo = 0
         d.wpk = wpk.data_ptr()
         d.tn = tn
         d.kc = kc
@@ -204,7 +229,7 @@ class DenoiserPlan:
         L.check(self.lib.yond_conv2d_f32(C.byref(d), L.stream()), "yond_conv2d_f32")
         if prof is not None:
             e1.record()
-            tag = f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{tn},{kc}>"
+            tag = f"conv_wino_kernel<{tn}>" if d.algo == 1 else f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{tn},{kc}>"
             prof.append((tag, 2.0 * pc.macs_per_pixel * N * d.Ho * d.Wo, e0, e1))
         return dst
 

@@ -15,18 +15,23 @@
 // registers), so the output transform is lane-local: lane = patch (lane & 15), its 4 registers = 4 consecutive
 // channels (weights are the A operand as in conv.hip).  With two waves per SIMD the transforms, the staging and
 // the epilogue of one wave run under the MFMAs of the other.
-// Per step, in one instruction stream:
-//     planes 0..7  of step s   ||  (SiLU +) ds_write of the raw 10 x 34 input tile of step s+1      -> barrier
-//     planes 8..15 of step s   ||  global loads of step s+2, input transform raw -> V[(s+1)&1]      -> barrier
-// The transformed weights U of step s+1 arrive by LDS-DMA (packed in LDS order by yond_pack_conv_wino_weight_f32).
+// Per step, in one instruction stream with ONE barrier at its end:
+//     64 MFMAs of step s on V[s&1], U[s&1]
+//     || input transform raw[(s+1)&1] -> V[(s+1)&1]   || (SiLU +) ds_write of the registers loaded a step ago -> raw[s&1]
+//     || issue of the global loads of step s+3         || LDS-DMA of the transformed weights U of step s+1
+// (U is packed in LDS order by yond_pack_conv_wino_weight_f32.)
 //
 // LDS images:
-//   raw [kh][10 rows][parity][17][4]   kh = 4-channel half of the chunk; even / odd columns apart, so the sixteen
+//   raw [2][kh][10 rows][parity][17][4]  kh = 4-channel half of the chunk; even / odd columns apart, so the sixteen
 //                                      lanes of a ds_read_b128 (consecutive patches, column stride 2) are contiguous
 //   V   [2][16 planes][kh][64 patches][4]      U   [2][16 planes][kh][TN][4]
 // MFMA kk (0, 1) of a chunk takes channel 2*kq + kk from lane group kq = lane>>4, i.e. float2 (kq & 1) of the
 // 16-byte slot of half kh = kq >> 1 (any pairing works as long as U and V agree).
 #include "common.h"
+
+#ifndef WINO_ABL
+#define WINO_ABL 0      // timing-only ablations: 1 no input loads, 2 no weight DMA, 4 no epilogue, 8 no transform, 16 no MFMA
+#endif
 
 template <int TN>
 struct WinoCfg {
@@ -42,7 +47,8 @@ struct WinoCfg {
     static constexpr int NIN = (NITEM + NT - 1) / NT;
     static constexpr int NUT = U_FLOATS / 4 / NT;                // LDS-DMA instructions per thread and weight slice
     static constexpr int EP_FLOATS = 4 * TN;
-    static constexpr int SMEM_BYTES = (2 * V_FLOATS + 2 * U_FLOATS + RAW_FLOATS + EP_FLOATS) * 4;
+    static constexpr int RAWB_FLOATS = RAW_FLOATS + 4;           // + a dummy slot for items past the end of the tile
+    static constexpr int SMEM_BYTES = (2 * V_FLOATS + 2 * U_FLOATS + 2 * RAWB_FLOATS + EP_FLOATS) * 4;
 };
 
 __device__ __forceinline__ float wino_silu(float x) {
@@ -50,7 +56,10 @@ __device__ __forceinline__ float wino_silu(float x) {
 }
 
 // wait for this wave's LDS traffic only (not for global loads still in flight), then the workgroup barrier
-__device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void barrier_lds_only() { if (!(WINO_ABL & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... and for all but the N most recent vector-memory operations (the loads issued last stay in flight)
+template <int N>
+__device__ __forceinline__ void barrier_lds_keep_loads() { if (!(WINO_ABL & 32)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
 
 template <int TN, bool PRE>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     float* s_v = smem;
     float* s_u = smem + 2 * C::V_FLOATS;
     float* s_raw = s_u + 2 * C::U_FLOATS;
-    float* s_ep = s_raw + C::RAW_FLOATS;
+    float* s_ep = s_raw + 2 * C::RAWB_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 15, kq = lane >> 4;
@@ -83,7 +92,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         const int it = tid + k * C::NT;
         const int pix = it >> 1;
         const int py = pix / C::IW, px = pix % C::IW;
-        raw_lds[k] = it < C::NITEM ? ((((my_kh * C::IH + py) * 2 + (px & 1)) * C::HALF + (px >> 1)) * 4) : -1;
+        // items past the end of the tile go to a dummy slot behind the image (never read): no branch in the step body
+        raw_lds[k] = it < C::NITEM ? ((((my_kh * C::IH + py) * 2 + (px & 1)) * C::HALF + (px >> 1)) * 4) : C::RAW_FLOATS;
     }
 
     struct Tile {
@@ -110,6 +120,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     };
 
     f32x4 vin[C::NIN];
+    if (WINO_ABL & 1) {
+#pragma unroll
+        for (int k = 0; k < C::NIN; ++k) { const f32x4 z = {0.5f, 0.5f, 0.5f, 0.5f}; vin[k] = z; }
+    }
     unsigned vin_ok = 0;
     auto issue_loads = [&](const Tile& T, int ch) {
         const int c0 = ch * 8;
@@ -121,51 +135,60 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
 #pragma unroll
         for (int k = 0; k < C::NIN; ++k) {
             const bool ok = T.goff[k] >= 0;                    // outside the image: read pixel 0, zeroed at the LDS write
-            vin[k] = *(const f32x4*)(src + (size_t)(ok ? T.goff[k] : 0) * Cs + cc + my_kh * 4);
+            if (!(WINO_ABL & 1)) vin[k] = *(const f32x4*)(src + (size_t)(ok ? T.goff[k] : 0) * Cs + cc + my_kh * 4);
             vin_ok |= (ok ? 1u : 0u) << k;
         }
     };
+    // The weight slice goes global -> LDS by LDS-DMA, written as inline assembly: the compiler orders every later
+    // LDS access behind a builtin DMA with s_waitcnt vmcnt(0), i.e. it would expose the whole L2 latency once per
+    // step.  Completion is awaited explicitly by the end-of-step barrier (barrier_lds_keep_loads).
     auto issue_weights = [&](const Tile& T, int ch, float* ubuf) {
-        const float* wsrc = d.wpk + ((size_t)T.ct * nchunk + ch) * C::U_FLOATS;
+        const float* wsrc = d.wpk + ((size_t)T.ct * nchunk + ch) * C::U_FLOATS;        // wave-uniform
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ubuf;
 #pragma unroll
         for (int k = 0; k < C::NUT; ++k) {
             const int it = tid + k * C::NT;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + it * 4),
-                                             (__attribute__((address_space(3))) void*)(ubuf + (it - lane) * 4), 16, 0, 0);
+            const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(it - lane) * 16u);
+            const unsigned voff = (unsigned)it * 16u;
+            if (!(WINO_ABL & 2))
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(wsrc) : "memory");
         }
     };
-    auto write_raw = [&](int k) {
+    auto write_raw = [&](float* rawbuf, int k) {
         f32x4 v = vin[k];
         if (PRE) { v[0] = wino_silu(v[0]); v[1] = wino_silu(v[1]); v[2] = wino_silu(v[2]); v[3] = wino_silu(v[3]); }
         const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (raw_lds[k] >= 0) *(f32x4*)(s_raw + raw_lds[k]) = ((vin_ok >> k) & 1u) ? v : z;       // conv zero padding
+        *(f32x4*)(rawbuf + raw_lds[k]) = ((vin_ok >> k) & 1u) ? v : z;                            // conv zero padding
     };
-    // input transform of one (patch, kh) task per lane of waves 0 (kh 0) and 1 (kh 1); the other six waves skip it
-    const int t_kh = wave & 1;
-    const int t_patch = lane;
-    const int t_pr = t_patch >> 4, t_pc = t_patch & 15;
-    auto transform = [&](float* vbuf) {
-        if (wave < 2) {
-            f32x4 w[4][4];
+    // input transform: one (patch, kh, channel) scalar task per thread -- wave w takes patch row w & 3 of half
+    // kh = w >> 2, lane = 4 * patch column + channel: every LDS access is 256 contiguous bytes per wave
+    const int t_kh = wave >> 2, t_pr = wave & 3, t_pc = lane >> 2, t_e = lane & 3;
+    const int t_src = (((t_kh * C::IH + 2 * t_pr) * 2) * C::HALF + t_pc) * 4 + t_e;
+    const int t_dst = ((t_kh * C::NP) + t_pr * 16 + t_pc) * 4 + t_e;
+    float traw[4][4];
+    auto transform_load = [&](const float* rawbuf) {
+        const float* src = rawbuf + t_src;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 dd[4];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    dd[r] = *(const f32x4*)(s_raw + ((((t_kh * C::IH + 2 * t_pr + r) * 2 + (c & 1)) * C::HALF + t_pc + (c >> 1)) * 4));
-                w[0][c] = dd[0] - dd[2];                       // B^T d (rows)
-                w[1][c] = dd[1] + dd[2];
-                w[2][c] = dd[2] - dd[1];
-                w[3][c] = dd[1] - dd[3];
-            }
+            for (int c = 0; c < 4; ++c) traw[r][c] = src[((r * 2 + (c & 1)) * C::HALF + (c >> 1)) * 4];
+    };
+    auto transform_store = [&](float* vbuf) {
+        float w[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                      // (B^T d) B (columns)
-                float* o = vbuf + (((i * 4) * 2 + t_kh) * C::NP + t_patch) * 4;
-                *(f32x4*)(o + 0 * 2 * C::NP * 4) = w[i][0] - w[i][2];
-                *(f32x4*)(o + 1 * 2 * C::NP * 4) = w[i][1] + w[i][2];
-                *(f32x4*)(o + 2 * 2 * C::NP * 4) = w[i][2] - w[i][1];
-                *(f32x4*)(o + 3 * 2 * C::NP * 4) = w[i][1] - w[i][3];
-            }
+        for (int c = 0; c < 4; ++c) {                          // B^T d (rows)
+            w[0][c] = traw[0][c] - traw[2][c];
+            w[1][c] = traw[1][c] + traw[2][c];
+            w[2][c] = traw[2][c] - traw[1][c];
+            w[3][c] = traw[1][c] - traw[3][c];
+        }
+        float* o = vbuf + t_dst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                          // (B^T d) B (columns)
+            o[(i * 4 + 0) * 2 * C::NP * 4] = w[i][0] - w[i][2];
+            o[(i * 4 + 1) * 2 * C::NP * 4] = w[i][1] + w[i][2];
+            o[(i * 4 + 2) * 2 * C::NP * 4] = w[i][2] - w[i][1];
+            o[(i * 4 + 3) * 2 * C::NP * 4] = w[i][1] - w[i][3];
         }
     };
 
@@ -176,19 +199,43 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) { const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f}; acc[p][t] = z; }
     };
-    auto mfma_planes = [&](auto p0c, const float* vbuf, const float* ubuf) {
+    // eight planes = 32 MFMAs; `side` is straight-line vector / LDS work that the scheduling hints below spread
+    // between them (this wave's MFMA slots alternate with the co-resident wave's: about 60 issue cycles each)
+    auto mfma_planes = [&](auto p0c, const float* vbuf, const float* ubuf, auto&& side) {
         constexpr int P0 = decltype(p0c)::value;
         const float* ub = ubuf + ((kq >> 1) * TN + cq * 16 + lj) * 4 + (kq & 1) * 2;
         const float* vb = vbuf + ((kq >> 1) * C::NP + mb * 32 + lj) * 4 + (kq & 1) * 2;
+        f32x2_t uf[8], v0[8], v1[8];
 #pragma unroll
-        for (int p = P0; p < P0 + 8; ++p) {
-            const f32x2_t uf = *(const f32x2_t*)(ub + p * 2 * TN * 4);
-            const f32x2_t v0 = *(const f32x2_t*)(vb + p * 2 * C::NP * 4);
-            const f32x2_t v1 = *(const f32x2_t*)(vb + p * 2 * C::NP * 4 + 16 * 4);
-            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[0], v0[0], acc[p][0], 0, 0, 0);   // D = U . V^T
-            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[0], v1[0], acc[p][1], 0, 0, 0);
-            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[1], v0[1], acc[p][0], 0, 0, 0);
-            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[1], v1[1], acc[p][1], 0, 0, 0);
+        for (int q = 0; q < 8; ++q) {
+            const int p = P0 + q;
+            if (WINO_ABL & 64) { const f32x2_t c = {1.0f + p, 0.5f}; uf[q] = c; v0[q] = c; v1[q] = c; continue; }
+            // volatile: keeps these as single ds_read_b64 (2 LDS cycles, banks mod 64, conflict-free here); merged
+            // into ds_read2_b64 they cost 8 cycles and, with that instruction's mod-32 banking, conflict 2-way
+            typedef const volatile __attribute__((address_space(3))) f32x2_t* lds_v2;
+            uf[q] = *(lds_v2)(__attribute__((address_space(3))) float*)(ub + p * 2 * TN * 4);
+            v0[q] = *(lds_v2)(__attribute__((address_space(3))) float*)(vb + p * 2 * C::NP * 4);
+            v1[q] = *(lds_v2)(__attribute__((address_space(3))) float*)(vb + p * 2 * C::NP * 4 + 16 * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = P0 + q;
+            if (WINO_ABL & 16) continue;
+            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[q][0], v0[q][0], acc[p][0], 0, 0, 0);   // D = U . V^T
+            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[q][0], v1[q][0], acc[p][1], 0, 0, 0);
+            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[q][1], v0[q][1], acc[p][0], 0, 0, 0);
+            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[q][1], v1[q][1], acc[p][1], 0, 0, 0);
+        }
+        side();
+        // pipeline: fragment reads of the first planes up front, then per MFMA one slot of VALU work and one LDS
+        // access of the side work / the later planes' fragments
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
     };
 
@@ -210,10 +257,23 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         const f32x4 es = *(const f32x4*)(ep + cq * 16 + 4 * kq);
         const f32x4 et = *(const f32x4*)(ep + TN + cq * 16 + 4 * kq);
         const int ox = T.ox0 + 2 * lj;
+        const int oyb = T.oy0 + 4 * mb;
+        const long long pbase = ((long long)(T.n * d.Ho + oyb) * d.Wo + ox) * d.Cout + T.ct * TN + cq * 16 + 4 * kq;
+        // the eight residual vectors first (all in flight together; masked lanes read element 0), then the arithmetic
+        f32x4 rr[2][2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const bool ok = (oyb + 2 * t + a < d.Ho) && (ox + b < d.Wo);
+                    const long long off = pbase + ((long long)(2 * t + a) * d.Wo + b) * d.Cout;
+                    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                    rr[t][a][b] = d.res ? *(const f32x4*)(d.res + (ok ? off : 0)) : z;
+                }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int oy = T.oy0 + 2 * (2 * mb + t);
-            const long long pbase = ((long long)(T.n * d.Ho + oy) * d.Wo + ox) * d.Cout + T.ct * TN + cq * 16 + 4 * kq;
             f32x4 t0[4], t1[4];
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {                    // A^T M
@@ -229,83 +289,105 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const bool ok = (oy + a < d.Ho) && (ox + b < d.Wo);
-                    const long long off = pbase + ((long long)a * d.Wo + b) * d.Cout;
-                    f32x4 rr = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (d.res && ok) rr = *(const f32x4*)(d.res + off);
+                    const bool ok = (oyb + 2 * t + a < d.Ho) && (ox + b < d.Wo);
+                    const long long off = pbase + ((long long)(2 * t + a) * d.Wo + b) * d.Cout;
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float x = fmaf(y[a][b][e], es[e], et[e]);
                         x = x > 0.0f ? x : x * slope_eff;
-                        v[e] = x + rr[e];
+                        v[e] = x + rr[t][a][b][e];
                     }
                     if (ok) *(f32x4*)(d.dst + off) = v;
                 }
         }
     };
 
-    int tile = lslot;
-    if (tile >= total) return;
-    Tile cur, ld;
-    decode(tile, cur);
-    ld = cur;
-    int ch = 0, b = 0, par = 0;
+    // ---- the step pipeline: ONE barrier per step ----
+    //   step s computes on V(s), U(s); meanwhile it transforms raw(s+1) -> V(s+1), writes the registers loaded one
+    //   step ago as raw(s+2), issues the global loads of step s+3 and the LDS-DMA of U(s+1).
+    struct Cur { int tile, ch; };
+    auto adv = [&](Cur c) {
+        Cur n;
+        const bool last = c.ch + 1 == nchunk;
+        n.tile = last ? c.tile + G : c.tile;
+        n.ch = last ? 0 : c.ch + 1;
+        return n;
+    };
+    auto tile_ct = [&](int t) { return (t % tiles_per_img) % nct; };
+    if (lslot >= total) return;
+    Cur cs = {lslot, 0};                       // step being computed
+    Tile cur;                                   // its tile (epilogue)
+    Tile lt;                                    // tile of the load cursor
+    int lt_tile = -1;
+    auto loads_for = [&](Cur c) {               // steps past the end re-read the last decoded tile (harmless)
+        if (c.tile < total && c.tile != lt_tile) { decode(c.tile, lt); lt_tile = c.tile; }
+        issue_loads(lt, c.ch);
+    };
+    decode(cs.tile, cur);
+    const Cur c1 = adv(cs), c2 = adv(c1);
+    Cur cl = adv(c2);                           // next loads to issue: step s+3
+    int par = 0;
     zero_acc();
-    // prologue: raw + U of step 0, transform, then the loads of step 1
-    issue_loads(cur, 0);
-    issue_weights(cur, 0, s_u);
-#pragma unroll
-    for (int k = 0; k < C::NIN; ++k) write_raw(k);
-    __syncthreads();
-    transform(s_v);
+    float* rawA = s_raw;                        // raw(s+1) at the top of step s
+    float* rawB = s_raw + C::RAWB_FLOATS;       // receives raw(s+2) during step s
+    float* vb = s_v;
+    float* vn = s_v + C::V_FLOATS;
+    float* ubf = s_u;
+    float* un = s_u + C::U_FLOATS;
+    // prologue: V(0), U(0), raw(1) in LDS; the loads of step 2 in flight
+    loads_for(cs);
     {
-        const bool last0 = nchunk == 1;
-        if (last0 && tile + G < total) decode(tile + G, ld);
-        issue_loads(ld, last0 ? 0 : 1);
+        Tile t0 = cur;
+        issue_weights(t0, 0, ubf);
     }
+#pragma unroll
+    for (int k = 0; k < C::NIN; ++k) write_raw(rawB, k);
+    loads_for(c1);
+    __syncthreads();
+    transform_load(rawB);
+    transform_store(vb);
+#pragma unroll
+    for (int k = 0; k < C::NIN; ++k) write_raw(rawA, k);
+    loads_for(c2);
     __syncthreads();
     while (true) {
-        const bool last_ch = (ch + 1 == nchunk);
-        const int ntile = last_ch ? tile + G : tile;
-        const int nch = last_ch ? 0 : ch + 1;
-        const bool has_next = ntile < total;
-        // step after next (its raw loads are issued in the second half of this step)
-        const bool nlast = (nch + 1 == nchunk);
-        const int n2tile = nlast ? ntile + G : ntile;
-        const int n2ch = nlast ? 0 : nch + 1;
-        float* vb = s_v + b * C::V_FLOATS;
-        float* ubf = s_u + b * C::U_FLOATS;
-        float* vnext = s_v + (b ^ 1) * C::V_FLOATS;
-        float* unext = s_u + (b ^ 1) * C::U_FLOATS;
-        // `ld` is the tile of step s+1 here (decoded one step ahead)
-        issue_weights(ld, nch, unext);
+        const bool last_ch = (cs.ch + 1 == nchunk);
+        const Cur cn = adv(cs);
         if (last_ch) stage_ep(cur, par);
-        mfma_planes(IntC<0>{}, vb, ubf);
-#pragma unroll
-        for (int k = 0; k < C::NIN; ++k) write_raw(k);
-        __syncthreads();                                        // raw(s+1) and U(s+1) are in LDS
-        // tile of step s+2
-        Tile* l2 = &ld;
-        Tile ld2;
-        if (nlast) {
-            if (n2tile < total) { decode(n2tile, ld2); l2 = &ld2; }
+        {
+            Tile tw = cur;                                      // only .ct is used
+            tw.ct = cn.tile < total ? tile_ct(cn.tile) : cur.ct;
+            issue_weights(tw, cn.ch, un);                       // U(s+1): a whole step to arrive
         }
-        issue_loads(*l2, n2ch);
-        mfma_planes(IntC<8>{}, vb, ubf);
-        transform(vnext);
-        barrier_lds_only();                                     // V(s+1) complete; the loads of s+2 stay in flight
+        if (!(WINO_ABL & 8)) transform_load(rawA);
+        mfma_planes(IntC<0>{}, vb, ubf, [&]() { if (!(WINO_ABL & 8)) transform_store(vn); });
+        mfma_planes(IntC<8>{}, vb, ubf, [&]() {
+#pragma unroll
+            for (int k = 0; k < C::NIN; ++k) if (!(WINO_ABL & 128)) write_raw(rawB, k);
+        });
+        loads_for(cl);                                          // step s+3 (after the registers were written out)
+        barrier_lds_keep_loads<C::NIN>();                       // V(s+1), U(s+1), raw(s+2) complete; those loads stay in flight
         if (last_ch) {
-            epilogue(cur, par);
+            if (!(WINO_ABL & 4) || d.N < 0) epilogue(cur, par);
             par ^= 1;
             zero_acc();
-            cur = ld;
+            if (cn.tile < total) {
+                const int n = cn.tile / tiles_per_img;
+                int bq = cn.tile - n * tiles_per_img;
+                cur.n = n;
+                cur.ct = bq % nct;
+                bq /= nct;
+                cur.ox0 = (bq % ntx) * 32;
+                cur.oy0 = (bq / ntx) * 8;
+            }
         }
-        if (nlast && n2tile < total) ld = ld2;
-        if (!has_next) break;
-        tile = ntile;
-        ch = nch;
-        b ^= 1;
+        if (cn.tile >= total) break;
+        cs = cn;
+        cl = adv(cl);
+        { float* t = rawA; rawA = rawB; rawB = t; }
+        { float* t = vb; vb = vn; vn = t; }
+        { float* t = ubf; ubf = un; un = t; }
     }
 }
 

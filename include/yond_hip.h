@@ -120,8 +120,9 @@ int yond_conv2d_f32(const YondConvDesc* desc, void* stream);
 
 /* Winograd F(2x2,3x3) variant of the 3x3 stride-1 convolution (same descriptor, algo = 1): 16 instead of 36
  * multiplications per output patch, fp32 throughout; the result differs from the direct kernel by rounding order
- * only.  yond_conv_wino_supported: 1 when (cin, cout) fit its tiles (cin % 8 == 0, cout % 64 == 0).
- * Weights: w OIHW [cout][cin][3][3] -> dst, 16*cout*cin floats (U = G g G^T in float64, rounded once). */
+ * only.  yond_conv_wino_supported: 1 when (cin, cout) fit its tiles (cin % 8 == 0, cout % 64 == 0 or
+ * cout == 32).  Weights: w OIHW [cout][cin][3][3] -> dst, 16*roundup(cout,64)*cin floats (U = G g G^T in float64,
+ * rounded once; a 32-channel layer occupies half a 64-channel tile). */
 int yond_conv_wino_supported(int cin, int cout);
 int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, float* dst);
 

@@ -21,6 +21,7 @@ def nchw(t):
 
 def run_conv(w, b, ksize, stride, splits, xs, N, H, W, shuffle=False, **kw):
     from yond_public_amd.engine import _PackedConv, DenoiserPlan
+    kw.setdefault('algo', 0)        # the direct kernels unless a test asks for Winograd (algo=2)
     pc = _PackedConv(torch.device(DEV), w, b, ksize, stride, splits, shuffle=shuffle)
     plan = DenoiserPlan.__new__(DenoiserPlan)
     from yond_public_amd import _lib as L
@@ -74,7 +75,7 @@ def test_conv3x3_two_source_leaky():
 
 
 @pytest.mark.parametrize("C,Co,N,H,W", [(64, 64, 1, 8, 32), (64, 64, 2, 16, 64), (32, 64, 1, 9, 33), (128, 128, 1, 24, 40),
-                                        (256, 64, 1, 94, 126)])
+                                        (256, 64, 1, 94, 126), (32, 32, 2, 24, 72), (64, 32, 1, 17, 40)])
 def test_conv3x3_winograd_plain(C, Co, N, H, W):
     """Winograd F(2x2,3x3) kernel (algo 1) against the float64 direct convolution: same tolerance as the direct
     kernel; partial tiles, odd extents, several tiles per workgroup."""
@@ -82,7 +83,7 @@ def test_conv3x3_winograd_plain(C, Co, N, H, W):
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
     b = torch.randn(Co, generator=g)
-    got = nchw(run_conv(w, b, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, algo=1))
+    got = nchw(run_conv(w, b, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, algo=2))
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     assert report(f"winograd conv3x3 C{C}->{Co} {H}x{W}", got, ref) < 2e-5
 
@@ -95,7 +96,7 @@ def test_conv3x3_winograd_fused_two_source():
     es, et = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
     res = torch.randn(N, C, H, W, generator=g)
     got = nchw(run_conv(w, None, 3, 1, [C, C], [nhwc(a).to(DEV), nhwc(b2).to(DEV)], N, H, W, escale=es.to(DEV), eshift=et.to(DEV),
-                        ebatch=1, res=nhwc(res).to(DEV), pre_act=1, post_act=2, slope=0.3, algo=1))
+                        ebatch=1, res=nhwc(res).to(DEV), pre_act=1, post_act=2, slope=0.3, algo=2))
     z = F.conv2d(F.silu(torch.cat([a, b2], 1).double()), w.double(), padding=1)
     z = F.leaky_relu(z * es.double()[:, :, None, None] + et.double()[:, :, None, None], 0.3) + res.double()
     assert report("winograd conv3x3 fused two-source", got, z) < 2e-5

@@ -13,8 +13,8 @@
 // 8 x 32 output pixels = 4 x 16 patches x 64 output channels; wave (mb, cq) owns patches [32 mb, 32 mb + 32) x
 // channels [16 cq, 16 cq + 16) of ALL sixteen planes as 16 x 2 accumulators of v_mfma_f32_16x16x4_f32 (128
 // registers), so the output transform is lane-local: lane = patch (lane & 15), its 4 registers = 4 consecutive
-// channels (weights are the A operand as in conv.hip).  With two waves per SIMD the transforms, the staging and
-// the epilogue of one wave run under the MFMAs of the other.
+// channels (weights are the A operand as in conv.hip).  The two waves of a SIMD run the two halves of a step --
+// the 64 MFMAs, and everything else -- in opposite order, so the matrix pipe always has one of them.
 // Per step, in one instruction stream with ONE barrier at its end:
 //     64 MFMAs of step s on V[s&1], U[s&1]
 //     || input transform raw[(s+1)&1] -> V[(s+1)&1]   || (SiLU +) ds_write of the registers loaded a step ago -> raw[s&1]
@@ -29,6 +29,22 @@
 // 16-byte slot of half kh = kq >> 1 (any pairing works as long as U and V agree).
 #include "common.h"
 
+#ifndef WINO_DBG
+#define WINO_DBG 0      // 1: timestamps of workgroup 0, waves 0 and 4 -> g_wino_dbg (read with yond_wino_debug_read)
+#endif
+#if WINO_DBG
+__device__ unsigned long long g_wino_dbg[2][64][8];
+extern "C" int yond_wino_debug_read(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_dbg), sizeof(g_wino_dbg));
+}
+#define WDBG(slot)                                                                                  \
+    do {                                                                                            \
+        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && dbg_step < 64)              \
+            g_wino_dbg[wave >> 2][dbg_step][slot] = __builtin_readcyclecounter();                   \
+    } while (0)
+#else
+#define WDBG(slot) do {} while (0)
+#endif
 #ifndef WINO_ABL
 #define WINO_ABL 0      // timing-only ablations: 1 no input loads, 2 no weight DMA, 4 no epilogue, 8 no transform, 16 no MFMA
 #endif
@@ -76,7 +92,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     const int lj = lane & 15, kq = lane >> 4;
     const int mb = wave & 1, cq = wave >> 1;
 
-    const int nct = d.Cout / TN;
+    const int nct = (d.Cout + TN - 1) / TN;                  // Cout 32: one half-empty channel tile (U zero-padded)
+    const bool computes = cq * 16 < d.Cout;                  // the waves of the empty half only stage / transform
     const int ntx = (d.Wo + 31) / 32, nty = (d.Ho + 7) / 8;
     const int tiles_per_img = nct * ntx * nty;
     const int total = tiles_per_img * d.N;
@@ -119,24 +136,27 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         }
     };
 
-    f32x4 vin[C::NIN];
+    // Two register sets for the raw loads: set s & 1 is written out as raw(s+2) in step s and refilled at once with
+    // the loads of step s+4, so a load has two steps to arrive.
+    f32x4 vin[2][C::NIN];
     if (WINO_ABL & 1) {
 #pragma unroll
-        for (int k = 0; k < C::NIN; ++k) { const f32x4 z = {0.5f, 0.5f, 0.5f, 0.5f}; vin[k] = z; }
+        for (int k = 0; k < C::NIN; ++k) { const f32x4 z = {0.5f, 0.5f, 0.5f, 0.5f}; vin[0][k] = z; vin[1][k] = z; }
     }
-    unsigned vin_ok = 0;
-    auto issue_loads = [&](const Tile& T, int ch) {
+    unsigned vin_ok[2] = {0, 0};
+    auto issue_loads = [&](auto pc, const Tile& T, int ch) {
+        constexpr int P = decltype(pc)::value;
         const int c0 = ch * 8;
         const float* src;
         int Cs, cc;
         if (c0 < d.C0) { src = d.src0; Cs = d.C0; cc = c0; }
         else { src = d.src1; Cs = d.C1; cc = c0 - d.C0; }
-        vin_ok = 0;
+        vin_ok[P] = 0;
 #pragma unroll
         for (int k = 0; k < C::NIN; ++k) {
             const bool ok = T.goff[k] >= 0;                    // outside the image: read pixel 0, zeroed at the LDS write
-            if (!(WINO_ABL & 1)) vin[k] = *(const f32x4*)(src + (size_t)(ok ? T.goff[k] : 0) * Cs + cc + my_kh * 4);
-            vin_ok |= (ok ? 1u : 0u) << k;
+            if (!(WINO_ABL & 1)) vin[P][k] = *(const f32x4*)(src + (size_t)(ok ? T.goff[k] : 0) * Cs + cc + my_kh * 4);
+            vin_ok[P] |= (ok ? 1u : 0u) << k;
         }
     };
     // The weight slice goes global -> LDS by LDS-DMA, written as inline assembly: the compiler orders every later
@@ -154,11 +174,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(wsrc) : "memory");
         }
     };
-    auto write_raw = [&](float* rawbuf, int k) {
-        f32x4 v = vin[k];
-        if (PRE) { v[0] = wino_silu(v[0]); v[1] = wino_silu(v[1]); v[2] = wino_silu(v[2]); v[3] = wino_silu(v[3]); }
-        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        *(f32x4*)(rawbuf + raw_lds[k]) = ((vin_ok >> k) & 1u) ? v : z;                            // conv zero padding
+    auto write_raw = [&](auto pc, float* rawbuf) {
+        constexpr int P = decltype(pc)::value;
+#pragma unroll
+        for (int k = 0; k < C::NIN; ++k) {
+            f32x4 v = vin[P][k];
+            if (PRE) { v[0] = wino_silu(v[0]); v[1] = wino_silu(v[1]); v[2] = wino_silu(v[2]); v[3] = wino_silu(v[3]); }
+            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            *(f32x4*)(rawbuf + raw_lds[k]) = ((vin_ok[P] >> k) & 1u) ? v : z;                     // conv zero padding
+        }
     };
     // input transform: one (patch, kh, channel) scalar task per thread -- wave w takes patch row w & 3 of half
     // kh = w >> 2, lane = 4 * patch column + channel: every LDS access is 256 contiguous bytes per wave
@@ -199,63 +223,61 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) { const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f}; acc[p][t] = z; }
     };
-    // eight planes = 32 MFMAs; `side` is straight-line vector / LDS work that the scheduling hints below spread
-    // between them (this wave's MFMA slots alternate with the co-resident wave's: about 60 issue cycles each)
-    auto mfma_planes = [&](auto p0c, const float* vbuf, const float* ubuf, auto&& side) {
-        constexpr int P0 = decltype(p0c)::value;
-        const float* ub = ubuf + ((kq >> 1) * TN + cq * 16 + lj) * 4 + (kq & 1) * 2;
-        const float* vb = vbuf + ((kq >> 1) * C::NP + mb * 32 + lj) * 4 + (kq & 1) * 2;
-        f32x2_t uf[8], v0[8], v1[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int p = P0 + q;
-            if (WINO_ABL & 64) { const f32x2_t c = {1.0f + p, 0.5f}; uf[q] = c; v0[q] = c; v1[q] = c; continue; }
-            // volatile: keeps these as single ds_read_b64 (2 LDS cycles, banks mod 64, conflict-free here); merged
-            // into ds_read2_b64 they cost 8 cycles and, with that instruction's mod-32 banking, conflict 2-way
-            typedef const volatile __attribute__((address_space(3))) f32x2_t* lds_v2;
-            uf[q] = *(lds_v2)(__attribute__((address_space(3))) float*)(ub + p * 2 * TN * 4);
-            v0[q] = *(lds_v2)(__attribute__((address_space(3))) float*)(vb + p * 2 * C::NP * 4);
-            v1[q] = *(lds_v2)(__attribute__((address_space(3))) float*)(vb + p * 2 * C::NP * 4 + 16 * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int p = P0 + q;
-            if (WINO_ABL & 16) continue;
-            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[q][0], v0[q][0], acc[p][0], 0, 0, 0);   // D = U . V^T
-            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[q][0], v1[q][0], acc[p][1], 0, 0, 0);
-            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[q][1], v0[q][1], acc[p][0], 0, 0, 0);
-            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[q][1], v1[q][1], acc[p][1], 0, 0, 0);
-        }
-        side();
-        // pipeline: fragment reads of the first planes up front, then per MFMA one slot of VALU work and one LDS
-        // access of the side work / the later planes' fragments
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
+    // All 64 MFMAs of a step as one tight stretch (the wave that shares the SIMD does its vector / LDS work meanwhile:
+    // see the step loop).  The fragment loads are volatile so that they stay single ds_read_b64 (2 LDS cycles, banks
+    // mod 64, conflict-free here; merged into ds_read2_b64 they cost 8 cycles and conflict 2-way) -- and therefore in
+    // program order: the loop is software-pipelined by hand, plane p + FD is requested before plane p is multiplied.
+    constexpr int FD = 4;
+    const int u_off = ((kq >> 1) * TN + cq * 16 + lj) * 4 + (kq & 1) * 2;
+    const int v_off = ((kq >> 1) * C::NP + mb * 32 + lj) * 4 + (kq & 1) * 2;
+    auto mfma_all = [&](const float* vbuf, const float* ubuf) {
+        typedef const volatile __attribute__((address_space(3))) f32x2_t* lds_v2;
+        const __attribute__((address_space(3))) float* ub = (__attribute__((address_space(3))) float*)(ubuf + u_off);
+        const __attribute__((address_space(3))) float* vb = (__attribute__((address_space(3))) float*)(vbuf + v_off);
+        f32x2_t uf[FD + 2], v0[FD + 2], v1[FD + 2];
+        auto load = [&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int sl = p % (FD + 2);
+            if (WINO_ABL & 64) { const f32x2_t c = {1.0f + p, 0.5f}; uf[sl] = c; v0[sl] = c; v1[sl] = c; return; }
+            uf[sl] = *(lds_v2)(ub + p * 2 * TN * 4);
+            v0[sl] = *(lds_v2)(vb + p * 2 * C::NP * 4);
+            v1[sl] = *(lds_v2)(vb + p * 2 * C::NP * 4 + 16 * 4);
+        };
+        static_for<0, FD>([&](auto pc) { load(pc); });
+        __builtin_amdgcn_sched_barrier(0);
+        // planes in pairs: the second MFMA into an accumulator is issued four instructions (128 cycles) after the first
+        // -- back to back they would wait for the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 (32-cycle issue)
+        static_for<0, 8>([&](auto qc) {
+            constexpr int p = 2 * decltype(qc)::value;
+            constexpr int s0 = p % (FD + 2), s1 = (p + 1) % (FD + 2);
+            if constexpr (p + FD < 16) load(IntC<p + FD>{});
+            if constexpr (p + FD + 1 < 16) load(IntC<p + FD + 1>{});
+            __builtin_amdgcn_sched_barrier(0);                 // the machine scheduler would sink the loads to their uses
+            if (!(WINO_ABL & 16)) {
+                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s0][0], v0[s0][0], acc[p][0], 0, 0, 0);           // D = U . V^T
+                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s0][0], v1[s0][0], acc[p][1], 0, 0, 0);
+                acc[p + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][0], v0[s1][0], acc[p + 1][0], 0, 0, 0);
+                acc[p + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][0], v1[s1][0], acc[p + 1][1], 0, 0, 0);
+                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s0][1], v0[s0][1], acc[p][0], 0, 0, 0);
+                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s0][1], v1[s0][1], acc[p][1], 0, 0, 0);
+                acc[p + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][1], v0[s1][1], acc[p + 1][0], 0, 0, 0);
+                acc[p + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][1], v1[s1][1], acc[p + 1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
     // ---- output side: lane = patch (row 2 mb + t, column lj), its registers = channels 16 cq + 4 kq + (0..3) ----
     const float slope_eff = d.post_act == 2 ? d.slope : 1.0f;
-    auto stage_ep = [&](const Tile& T, int par) {
-        if (tid < 2 * TN) {
-            const int c = tid < TN ? tid : tid - TN;
-            const int cu = T.ct * TN + c;
-            const int eoff = (d.ebatch ? T.n * d.Cout : 0) + cu;
-            float v;
-            if (tid < TN) v = d.escale ? d.escale[eoff] : 1.0f;
-            else v = d.eshift ? d.eshift[eoff] : 0.0f;
-            s_ep[par * 2 * TN + tid] = v;
-        }
-    };
+    // (FiLM / bias vectors straight from global memory: a load inside a conditional block earlier in the step makes the
+    // compiler fall back to s_waitcnt vmcnt(0) for the staged input, which exposes the memory latency every step)
     auto epilogue = [&](const Tile& T, int par) {
-        const float* ep = s_ep + par * 2 * TN;
-        const f32x4 es = *(const f32x4*)(ep + cq * 16 + 4 * kq);
-        const f32x4 et = *(const f32x4*)(ep + TN + cq * 16 + 4 * kq);
+        (void)par;
+        const int cbase = T.ct * TN + cq * 16 + 4 * kq;
+        const int eoff = (d.ebatch ? T.n * d.Cout : 0) + cbase;
+        const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const f32x4 es = d.escale ? *(const f32x4*)(d.escale + eoff) : one;
+        const f32x4 et = d.eshift ? *(const f32x4*)(d.eshift + eoff) : zero4;
         const int ox = T.ox0 + 2 * lj;
         const int oyb = T.oy0 + 4 * mb;
         const long long pbase = ((long long)(T.n * d.Ho + oyb) * d.Wo + ox) * d.Cout + T.ct * TN + cq * 16 + 4 * kq;
@@ -304,8 +326,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     };
 
     // ---- the step pipeline: ONE barrier per step ----
-    //   step s computes on V(s), U(s); meanwhile it transforms raw(s+1) -> V(s+1), writes the registers loaded one
-    //   step ago as raw(s+2), issues the global loads of step s+3 and the LDS-DMA of U(s+1).
+    //   step s computes on V(s), U(s); meanwhile it transforms raw(s+1) -> V(s+1), writes register set s & 1 (loaded
+    //   two steps ago) as raw(s+2), refills it with the global loads of step s+4 and issues the LDS-DMA of U(s+1).
     struct Cur { int tile, ch; };
     auto adv = [&](Cur c) {
         Cur n;
@@ -314,19 +336,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         n.ch = last ? 0 : c.ch + 1;
         return n;
     };
-    auto tile_ct = [&](int t) { return (t % tiles_per_img) % nct; };
     if (lslot >= total) return;
     Cur cs = {lslot, 0};                       // step being computed
     Tile cur;                                   // its tile (epilogue)
     Tile lt;                                    // tile of the load cursor
     int lt_tile = -1;
-    auto loads_for = [&](Cur c) {               // steps past the end re-read the last decoded tile (harmless)
+    auto loads_for = [&](auto pc, Cur c) {      // steps past the end re-read the last decoded tile (harmless)
         if (c.tile < total && c.tile != lt_tile) { decode(c.tile, lt); lt_tile = c.tile; }
-        issue_loads(lt, c.ch);
+        issue_loads(pc, lt, c.ch);
     };
     decode(cs.tile, cur);
-    const Cur c1 = adv(cs), c2 = adv(c1);
-    Cur cl = adv(c2);                           // next loads to issue: step s+3
+    int next_ct = cur.ct;                       // channel tile of step s+1
+    const Cur c1 = adv(cs), c2 = adv(c1), c3 = adv(c2);
+    Cur cl = adv(c3);                           // next loads to issue: step s+4
     int par = 0;
     zero_acc();
     float* rawA = s_raw;                        // raw(s+1) at the top of step s
@@ -335,41 +357,66 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     float* vn = s_v + C::V_FLOATS;
     float* ubf = s_u;
     float* un = s_u + C::U_FLOATS;
-    // prologue: V(0), U(0), raw(1) in LDS; the loads of step 2 in flight
-    loads_for(cs);
-    {
-        Tile t0 = cur;
-        issue_weights(t0, 0, ubf);
-    }
-#pragma unroll
-    for (int k = 0; k < C::NIN; ++k) write_raw(rawB, k);
-    loads_for(c1);
+    // prologue: V(0), U(0), raw(1) in LDS; the loads of steps 2 and 3 in flight (register sets 0 and 1)
+    loads_for(IntC<0>{}, cs);
+    issue_weights(cur, 0, ubf);
+    loads_for(IntC<1>{}, c1);
+    write_raw(IntC<0>{}, rawB);
     __syncthreads();
     transform_load(rawB);
     transform_store(vb);
-#pragma unroll
-    for (int k = 0; k < C::NIN; ++k) write_raw(rawA, k);
-    loads_for(c2);
+    write_raw(IntC<1>{}, rawA);
+    loads_for(IntC<0>{}, c2);
+    loads_for(IntC<1>{}, c3);
     __syncthreads();
-    while (true) {
+    // VALU issue between the two waves of a SIMD is arbitrated by priority, then age: without this the younger half
+    // (waves 4-7) only gets the slots the older half leaves, and its vector work crawls while the older half is in its
+    // MFMA stretch (measured 3850 vs 1200 cycles for the same instructions).
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
+    // one step; P = s & 1 selects the register set.  Returns false after the last step.
+    int dbg_step = 0;
+    (void)dbg_step;
+    auto step = [&](auto pc) -> bool {
+        WDBG(0);
         const bool last_ch = (cs.ch + 1 == nchunk);
         const Cur cn = adv(cs);
-        if (last_ch) stage_ep(cur, par);
-        {
+        if (last_ch && cn.tile < total) next_ct = (cn.tile % tiles_per_img) % nct;
+        // U(s+1) by LDS-DMA.  The compiler does not see these (inline assembly) in its vmcnt bookkeeping: a wait for
+        // OLDER loads placed after them also waits for them, so a wave issues them where no such wait follows
+        // closely -- after the side work in the side-first waves (measured: 2500 cycles per step otherwise).
+        auto dma = [&]() {
             Tile tw = cur;                                      // only .ct is used
-            tw.ct = cn.tile < total ? tile_ct(cn.tile) : cur.ct;
-            issue_weights(tw, cn.ch, un);                       // U(s+1): a whole step to arrive
+            tw.ct = next_ct;
+            issue_weights(tw, cn.ch, un);
+        };
+        // The two waves of a SIMD (w and w + 4) take the halves of the step -- the 64 MFMAs, and the vector / LDS /
+        // memory work (independent of this step's MFMAs) -- in opposite order, so one of them is always in its MFMA
+        // stretch: barrier-synchronised waves running the same order leave the matrix pipe idle during the ~450
+        // other instructions of every step (measured: 50 % MFMA busy).  In both orders the DMA is issued before the
+        // step's global loads, which is what the end-of-step wait relies on.
+        WDBG(1);
+        if (wave < 4) {
+            dma();
+            if (computes) mfma_all(vb, ubf);
+            WDBG(2);
+            if (!(WINO_ABL & 8)) { transform_load(rawA); transform_store(vn); }
+            if (!(WINO_ABL & 128)) write_raw(pc, rawB);
+            loads_for(pc, cl);                                  // step s+4, into the set that was just written out
+        } else {
+            if (!(WINO_ABL & 8)) { transform_load(rawA); transform_store(vn); }
+            if (!(WINO_ABL & 128)) write_raw(pc, rawB);
+            dma();
+            loads_for(pc, cl);
+            WDBG(2);
+            if (computes) mfma_all(vb, ubf);
         }
-        if (!(WINO_ABL & 8)) transform_load(rawA);
-        mfma_planes(IntC<0>{}, vb, ubf, [&]() { if (!(WINO_ABL & 8)) transform_store(vn); });
-        mfma_planes(IntC<8>{}, vb, ubf, [&]() {
-#pragma unroll
-            for (int k = 0; k < C::NIN; ++k) if (!(WINO_ABL & 128)) write_raw(rawB, k);
-        });
-        loads_for(cl);                                          // step s+3 (after the registers were written out)
-        barrier_lds_keep_loads<C::NIN>();                       // V(s+1), U(s+1), raw(s+2) complete; those loads stay in flight
+        WDBG(3);
+        // V(s+1), U(s+1), raw(s+2) complete.  The DMA is older than this step's loads only: the loads of the previous
+        // step (other register set) are waited for as well -- they have had a whole step.
+        barrier_lds_keep_loads<C::NIN>();
+        WDBG(4);
         if (last_ch) {
-            if (!(WINO_ABL & 4) || d.N < 0) epilogue(cur, par);
+            if (computes && (!(WINO_ABL & 4) || d.N < 0)) epilogue(cur, par);
             par ^= 1;
             zero_acc();
             if (cn.tile < total) {
@@ -382,12 +429,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
                 cur.oy0 = (bq / ntx) * 8;
             }
         }
-        if (cn.tile >= total) break;
+        WDBG(5);
+        ++dbg_step;
+        if (cn.tile >= total) return false;
         cs = cn;
         cl = adv(cl);
         { float* t = rawA; rawA = rawB; rawB = t; }
         { float* t = vb; vb = vn; vn = t; }
         { float* t = ubf; ubf = un; un = t; }
+        return true;
+    };
+    while (true) {
+        if (!step(IntC<0>{})) break;
+        if (!step(IntC<1>{})) break;
     }
 }
 
@@ -401,7 +455,7 @@ static int launch_wino(const YondConvDesc& d, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const long long total = (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + 7) / 8) * d.N;
+    const long long total = (long long)((d.Cout + TN - 1) / TN) * ((d.Wo + 31) / 32) * ((d.Ho + 7) / 8) * d.N;
     if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
     const int grid = total < 256 ? (int)total : 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::SMEM_BYTES, st, d);
@@ -411,16 +465,17 @@ static int launch_wino(const YondConvDesc& d, hipStream_t st) {
 
 // U = G g G^T in float64, rounded once to float32, in the LDS order [ct][chunk][plane][kh][TN][4]
 extern "C" int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, float* dst) {
-    if (!w || !dst || tn != 64 || cout % tn != 0 || cin % 8 != 0) return YOND_EINVAL;
+    if (!w || !dst || tn != 64 || (cout % tn != 0 && cout != 32) || cin % 8 != 0) return YOND_EINVAL;
     static const double Gm[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
     size_t o = 0;
-    for (int ct = 0; ct < cout / tn; ++ct)
+    for (int ct = 0; ct < (cout + tn - 1) / tn; ++ct)
         for (int ch = 0; ch < cin / 8; ++ch)
             for (int p = 0; p < 16; ++p)
                 for (int kh = 0; kh < 2; ++kh)
                     for (int j = 0; j < tn; ++j)
                         for (int e = 0; e < 4; ++e) {
                             const int co = ct * tn + j, ci = ch * 8 + kh * 4 + e;
+                            if (co >= cout) { dst[o++] = 0.0f; continue; }      // cout 32: upper half of the tile is empty
                             const float* g = w + ((size_t)co * cin + ci) * 9;
                             const int xi = p >> 2, nu = p & 3;
                             double s = 0.0;
@@ -431,7 +486,9 @@ extern "C" int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin,
     return YOND_OK;
 }
 
-extern "C" int yond_conv_wino_supported(int cin, int cout) { return (cin > 0 && cin % 8 == 0 && cout > 0 && cout % 64 == 0) ? 1 : 0; }
+extern "C" int yond_conv_wino_supported(int cin, int cout) {
+    return (cin > 0 && cin % 8 == 0 && cout > 0 && (cout % 64 == 0 || cout == 32)) ? 1 : 0;
+}
 
 // called by yond_conv2d_f32 (conv.hip) for desc.algo == 1
 int yond_conv_wino_dispatch(const YondConvDesc& d, hipStream_t st) {

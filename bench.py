@@ -112,6 +112,7 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     plan.prof = []
+    P.PROF = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
@@ -120,8 +121,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     prof, plan.prof = plan.prof, None
+    stage_prof, P.PROF = P.PROF, None
 
-    # dominant kernel: the 3x3 stride-1 fp32-MFMA convolution (18 launches per forward, 91 % of the MACs)
+    # dominant kernel: the 3x3 stride-1 fp32-MFMA convolution that takes the most time (18 launches per forward, 91 % of
+    # the MACs: the Winograd kernel on the 64..512-channel layers, the direct kernel on the 32-channel ones)
     per = {}
     for tag, flops, e0, e1 in prof:
         ms = e0.elapsed_time(e1)
@@ -129,7 +132,8 @@ def main():
         k[0] += 1
         k[1] += ms
         k[2] += flops
-    dom = max((t for t in per if t.startswith("conv_mfma_kernel<3,1")), key=lambda t: per[t][1], default=None)
+    dom = max((t for t in per if t.startswith("conv_mfma_kernel<3,1") or t.startswith("conv_wino_kernel")),
+              key=lambda t: per[t][1], default=None)
     roof = None
     if dom:
         n, ms, fl = per[dom]
@@ -137,6 +141,31 @@ def main():
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom), "launches": n,
                 "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
+        if dom.startswith("conv_wino_kernel"):
+            # Winograd F(2x2,3x3) issues 16 multiplications per patch where the direct algorithm has 36: `achieved`
+            # counts the ALGORITHMIC flops of the convolution (it can exceed the matrix-core peak); the flops the MFMA
+            # unit really executes are 16/36 of that
+            roof["algorithm"] = "winograd F(2x2,3x3): 16/36 of the direct multiplications, fp32 throughout"
+            roof["mfma_issued_tflops"] = round(ach * 16.0 / 36.0, 2)
+            roof["mfma_issued_frac"] = round(ach * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS, 4)
+        others = {t: {"launches": v[0], "avg_launch_ms": round(v[1] / v[0], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
+                  for t, v in per.items() if t != dom and (t.startswith("conv_mfma_kernel<3,1") or t.startswith("conv_wino_kernel"))}
+        if others:
+            roof["other_3x3_kernels"] = others
+    # VST + NLE stages against the HBM roofline: algorithmic bytes of SURVEY section 8(d) (24 B per Bayer pixel for a
+    # 'once' pass: K1 8 + K4 8 + self-NLE 8; 'iter' adds a second K1/K4 pass and the collab NLE: 56 B) over the summed
+    # stage times (HIP events on the launch stream; the host gaps between the kernels of a stage are inside)
+    stage_ms = {}
+    for tag, e0, e1 in stage_prof:
+        stage_ms[tag] = stage_ms.get(tag, 0.0) + e0.elapsed_time(e1)
+    roof_hbm = None
+    if stage_ms:
+        tot_ms = sum(stage_ms.values()) / max(a.steps, 1)
+        bpp = 24.0 if a.mode == "once" else 56.0
+        gbs = bpp * H * W / (tot_ms * 1e-3) / 1e9
+        roof_hbm = {"stage": "VST+NLE (K1, K4, K5-K7)", "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(gbs / 8000.0, 4), "algorithmic_bytes_per_bayer_px": bpp, "ms_per_step": round(tot_ms, 4),
+                    "stage_ms_per_step": {k: round(v / max(a.steps, 1), 4) for k, v in stage_ms.items()}}
     conv_ms = sum(v[1] for v in per.values()) / max(a.steps, 1)
     conv_fl = sum(v[2] for v in per.values()) / max(a.steps, 1)
 
@@ -159,6 +188,7 @@ def main():
                                    f"NLE+VST+{a.arch}(nf=32)+iVST, pipeline '{a.mode}', bias_corr=pre, k=29",
                        "frames_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}"},
             "roofline": roof,
+            "roofline_vst_nle": roof_hbm,
             "conv_stack": {"ms_per_step": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
                            "share_of_step": round(conv_ms / (elapsed / a.steps * 1e3), 3) if conv_ms else None},
             "psnr_vs_clean_db": round(red["psnr_last"], 3),

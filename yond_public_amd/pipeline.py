@@ -20,6 +20,27 @@ from . import _lib as L
 
 NBINS = 1024
 
+# bench.py sets this to a list to collect (tag, start event, end event) of the VST / NLE stages, recorded on the
+# stream the kernels are launched on (torch's current stream)
+PROF = None
+
+
+class _stage:
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if PROF is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROF.append((self.tag, self.e0, e1))
+        return False
+
 
 def _dev(x, device=None):
     if isinstance(x, torch.Tensor):
@@ -235,10 +256,11 @@ def _nlf_from_maps(lap, mean, var, full=False):
     width = lap.shape[-1] if lap.dim() > 1 else None
     lap, mean, var = lap.reshape(-1), mean.reshape(-1), var.reshape(-1)
     quants = np.linspace(5, 100, 20, endpoint=True)
-    ths_dev = _percentiles(lap, quants)
-    occ = _occupancy(lap, mean, ths_dev, width)
-    sel_dev, npeaks_dev = _score3_device(occ, ths_dev, quants)
-    mom = _moments(lap, mean, var, sel_dev[1:2])
+    with _stage("nle_select_score_moments"):
+        ths_dev = _percentiles(lap, quants)
+        occ = _occupancy(lap, mean, ths_dev, width)
+        sel_dev, npeaks_dev = _score3_device(occ, ths_dev, quants)
+        mom = _moments(lap, mean, var, sel_dev[1:2])
     small = torch.cat([ths_dev, sel_dev, mom.reshape(-1), npeaks_dev.to(torch.float64)]).cpu().numpy()   # the one sync
     nq = len(quants)
     ths, sel_h, mom_h, npeaks = small[:nq], small[nq:nq + 4], small[nq + 4:nq + 14].reshape(2, 5), small[nq + 14:]
@@ -279,15 +301,17 @@ def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None):
     if setting['mode'] == 'self':
         blur2 = new()
         k2 = k // 3 * 2 + 1
-        L.check(lib.yond_box_stats_self1_f32(L.ptr(lr), H, W, k, k2, tile_w, L.ptr(mean), L.ptr(var), L.ptr(blur2), st),
-                "yond_box_stats_self1_f32")
-        L.check(lib.yond_box_stats_self2_f32(L.ptr(blur2), h, w, k, tile_w, L.ptr(lap), st), "yond_box_stats_self2_f32")
+        with _stage("nle_box_self"):
+            L.check(lib.yond_box_stats_self1_f32(L.ptr(lr), H, W, k, k2, tile_w, L.ptr(mean), L.ptr(var), L.ptr(blur2), st),
+                    "yond_box_stats_self1_f32")
+            L.check(lib.yond_box_stats_self2_f32(L.ptr(blur2), h, w, k, tile_w, L.ptr(lap), st), "yond_box_stats_self2_f32")
     elif setting['mode'] == 'collab':
         hr = _dev(hr_raw, lr.device)
         if hr.shape != lr.shape:
             raise L.YondHipError("collab NLF needs noisy and denoised frames of the same shape")
-        L.check(lib.yond_box_stats_collab_f32(L.ptr(lr), L.ptr(hr), H, W, k, tile_w, L.ptr(mean), L.ptr(var), L.ptr(lap), st),
-                "yond_box_stats_collab_f32")
+        with _stage("nle_box_collab"):
+            L.check(lib.yond_box_stats_collab_f32(L.ptr(lr), L.ptr(hr), H, W, k, tile_w, L.ptr(mean), L.ptr(var), L.ptr(lap), st),
+                    "yond_box_stats_collab_f32")
     else:
         raise NotImplementedError(setting['mode'])
     return _nlf_from_maps(lap, mean, var, full)
@@ -335,11 +359,12 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
     img_max = torch.empty(B, dtype=torch.float32, device=lr.device)
     st = L.stream()
     lut_n = len(bias_func) if bias_corr is not None else 0
-    for i in range(B):
-        L.check(lib.yond_pack_vst_norm_f32(L.ptr(lr[i]), H, W, L.ptr(x4[i]), p2d[0], p2d[1], p2d[2], p2d[3], 1, scale, float(gain),
-                                           float(sigma), float(lower), float(upper),
-                                           L.ptr(bias_func.x) if lut_n else None, L.ptr(bias_func.y) if lut_n else None, lut_n,
-                                           L.ptr(img_max[i:i + 1]), st), "yond_pack_vst_norm_f32")
+    with _stage("vst_pack"):
+        for i in range(B):
+            L.check(lib.yond_pack_vst_norm_f32(L.ptr(lr[i]), H, W, L.ptr(x4[i]), p2d[0], p2d[1], p2d[2], p2d[3], 1, scale,
+                                               float(gain), float(sigma), float(lower), float(upper),
+                                               L.ptr(bias_func.x) if lut_n else None, L.ptr(bias_func.y) if lut_n else None, lut_n,
+                                               L.ptr(img_max[i:i + 1]), st), "yond_pack_vst_norm_f32")
     plan = _plan_of(net, lr.device)
     t_dev = None
     if 'guided' in arch:
@@ -348,10 +373,11 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
     y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
     out = torch.empty((B, H, W), dtype=torch.float32, device=lr.device)
     exact_inverse = bias_corr is None and vst_type == 'exact'
-    for i in range(B):
-        L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4[i]), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out[i]), 2 if exact_inverse else 1,
-                                                scale, float(gain), float(sigma), float(lower), float(upper), int(clip01), st),
-                "yond_denorm_ivst_unpack_f32")
+    with _stage("ivst_unpack"):
+        for i in range(B):
+            L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4[i]), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out[i]),
+                                                    2 if exact_inverse else 1, scale, float(gain), float(sigma), float(lower),
+                                                    float(upper), int(clip01), st), "yond_denorm_ivst_unpack_f32")
     return out[0] if single else out
 
 

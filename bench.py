@@ -27,6 +27,7 @@ from yond_public_amd import synthetic as S            # noqa: E402
 from yond_public_amd import archs as A                # noqa: E402
 from yond_public_amd import _lib as L                 # noqa: E402
 
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
 PEAK_HBM_GBPS = 8000.0
 
@@ -80,6 +81,8 @@ def main():
     ap.add_argument("--height", type=int, default=3000)
     ap.add_argument("--width", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+                    help="fp16: BASELINE cfg 5, convolutions on the fp16 MFMA path (not the headline configuration)")
     a = ap.parse_args()
 
     rank, local, world = D.init()
@@ -92,7 +95,7 @@ def main():
     L.load()
 
     arch = ARCHS[a.arch]
-    net = getattr(A, arch['name'])(dict(arch))
+    net = getattr(A, arch['name'])(dict(arch, precision=a.precision))
     net.load_state_dict(S.procedural_state_dict(net, 0))
     net = net.to(dev).eval()
     H, W = a.height, a.width
@@ -132,14 +135,18 @@ def main():
         k[0] += 1
         k[1] += ms
         k[2] += flops
+    if a.precision == "fp16":
+        PEAK = PEAK_F16_MFMA_TFLOPS
+    else:
+        PEAK = PEAK_F32_MFMA_TFLOPS
     dom = max((t for t in per if t.startswith("conv_mfma_kernel<3,1") or t.startswith("conv_wino_kernel")),
               key=lambda t: per[t][1], default=None)
     roof = None
     if dom:
         n, ms, fl = per[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom), "launches": n,
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK, 4), "traffic": pmc_traffic(dom), "launches": n,
                 "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
         if dom.startswith("conv_wino_kernel"):
             # Winograd F(2x2,3x3) issues 16 multiplications per patch where the direct algorithm has 36: `achieved`
@@ -183,8 +190,9 @@ def main():
             "value": round(world * a.steps * mp / elapsed, 2), "unit": "Bayer MP/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: one {H}x{W} synthetic Poisson-Gaussian Bayer frame per GPU, full "
+            "vs_baseline": None, "dtype": "f32" if a.precision == "fp32" else "f16 MFMA operands, f32 accumulate and tensors (cfg 5)",
+            "data": "synthetic",
+            "config": {"workload": f"configs[{1 if a.precision == 'fp32' else 4}]: one {H}x{W} synthetic Poisson-Gaussian Bayer frame per GPU, full "
                                    f"NLE+VST+{a.arch}(nf=32)+iVST, pipeline '{a.mode}', bias_corr=pre, k=29",
                        "frames_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}"},
             "roofline": roof,

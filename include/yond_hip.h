@@ -106,8 +106,10 @@ typedef struct YondConvDesc {
     float* dst;           /* [N][Ho][Wo][Cout]  (shuffle: see above) */
     int tn;               /* channel-tile width the weights were packed for (32 or 64, from yond_conv_config) */
     int kc;               /* channel chunk the weights were packed for (8 or 16, from yond_conv_config; 0 = default) */
-    int algo;             /* 0 direct implicit GEMM; 1 Winograd F(2x2,3x3) (3x3 stride 1 only; wpk from
-                             yond_pack_conv_wino_weight_f32, tn = 64, see yond_conv_wino_supported) */
+    int algo;             /* 0 direct implicit GEMM, fp32 MFMA; 1 Winograd F(2x2,3x3), fp32 MFMA (3x3 stride 1 only; wpk from
+                             yond_pack_conv_wino_weight_f32, tn = 64, see yond_conv_wino_supported); 2 direct implicit GEMM
+                             on the fp16 MFMA (operands rounded to half at the matrix core, fp32 accumulate, fp32 tensors:
+                             BASELINE cfg 5; same packed weights as algo 0) */
 } YondConvDesc;
 
 /* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.

@@ -102,6 +102,25 @@ def test_conv3x3_winograd_fused_two_source():
     assert report("winograd conv3x3 fused two-source", got, z) < 2e-5
 
 
+@pytest.mark.parametrize("ks,st,C,Co", [(3, 1, 64, 64), (3, 1, 32, 32), (3, 2, 32, 64), (1, 1, 64, 32)])
+def test_conv_fp16_mfma_path(ks, st, C, Co):
+    """algo 'fp16' (descriptor algo 2, BASELINE cfg 5): operands rounded to half at the matrix core, fp32 accumulate.
+    Against the float64 convolution of the half-rounded operands the error is accumulation order only; against the
+    unrounded one it is the half rounding (relative 2^-11 per operand)."""
+    g = torch.Generator().manual_seed(ks * 10 + st + C)
+    N, H, W = 1, 24, 40
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, ks, ks, generator=g) / (ks * C ** 0.5)
+    b = torch.randn(Co, generator=g)
+    got = nchw(run_conv(w, b, ks, st, [C], [nhwc(x).to(DEV)], N, H, W, algo='fp16'))
+    pad = ks // 2
+    xh, wh = x.half().double(), w.half().double()
+    ref_h = F.conv2d(xh, wh, b.double(), stride=st, padding=pad)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=pad)
+    assert report(f"fp16-mfma conv {ks}x{ks} s{st} C{C}->{Co} vs half-rounded operands", got, ref_h) < 2e-5
+    assert report(f"fp16-mfma conv {ks}x{ks} s{st} C{C}->{Co} vs fp32 operands", got, ref) < 5e-3
+
+
 @pytest.mark.parametrize("C,N,H,W", [(32, 1, 16, 64), (64, 2, 32, 32), (32, 1, 18, 34)])
 def test_conv3x3_s2(C, N, H, W):
     g = torch.Generator().manual_seed(C + W)

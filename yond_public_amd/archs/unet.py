@@ -61,6 +61,11 @@ class _HipDenoiser(nn.Module):
         self.nframes = args['nframes'] if 'nframes' in args else 1
         self.cf = 0
         self.res = args['res']
+        # 'fp32' (default, the reference's precision) or 'fp16': convolutions on the fp16 MFMA path with fp32 accumulation and
+        # fp32 tensors (BASELINE cfg 5); not a reference key -- absent means fp32
+        self.precision = args.get('precision', 'fp32')
+        if self.precision not in ('fp32', 'fp16'):
+            raise ValueError(f"precision must be 'fp32' or 'fp16', got {self.precision!r}")
         self.norm = args['norm'] if 'norm' in args else False
         if args['in_nc'] * self.nframes != 4 or args['out_nc'] != 4:
             raise L.YondHipError("the HIP denoisers take packed Bayer input/output (in_nc*nframes == out_nc == 4)")
@@ -79,7 +84,7 @@ class _HipDenoiser(nn.Module):
         plist = getattr(self, '_plist', None)
         if plist is None:
             plist = self._plist = list(self.parameters())
-        key = (str(device), tuple([p._version for p in plist]))
+        key = (str(device), self.precision, tuple([p._version for p in plist]))
         if self._plan is None or self._plan_key != key:
             self._plan = DenoiserPlan(self, device)
             self._plan_key = key

@@ -72,7 +72,18 @@ constexpr int conv_wgs_per_cu() {
     return KS == 1 ? 2 : 1;
 }
 
-template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE>
+// F16 (descriptor algo 2, the "fp16 MFMA conv path" of BASELINE cfg 5): the same kernel with the four fp32 k-steps of
+// a group (8 channels) replaced by ONE v_mfma_f32_32x32x8_f16 -- the fragments are read from the fp32 LDS images as
+// before and rounded to half (v_cvt_pk_f16_f32, round-to-nearest) on their way into the matrix core; accumulation,
+// epilogue and every tensor in HBM stay fp32.  4x the matrix rate of the fp32 form, and the fp16 MFMA leaves the
+// vector ALU free (the fp32 form does not).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x4 to_half4(const f32x4 v) {
+    f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    return h;
+}
+
+template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE, bool F16>
 __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void conv_mfma_kernel(const YondConvDesc d) {
     constexpr bool CAN_DEFER = conv_wgs_per_cu<KS, STRIDE, KC, TN>() == 1;     // two workgroups per CU cover each other's epilogues
     using C = ConvCfg<KS, STRIDE, TH, TN, KC>;
@@ -303,13 +314,26 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
             constexpr int k0 = (g - G0) * IPG;
             constexpr int nitem = (g < G0 || k0 >= C::NIN) ? 0 : (C::NIN - k0 < IPG ? C::NIN - k0 : IPG);
             if constexpr (g + 1 < NG) load_frag(g + 1, a[(g + 1) & 1], bb[(g + 1) & 1]);
+            if constexpr (F16) {
+                f16x4 ah[C::MW], bh[C::NW];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int m = 0; m < C::MW; ++m) ah[m] = to_half4(a[g & 1][m]);
+#pragma unroll
+                for (int nn = 0; nn < C::NW; ++nn) bh[nn] = to_half4(bb[g & 1][nn]);
 #pragma unroll
                 for (int m = 0; m < C::MW; ++m)
 #pragma unroll
                     for (int nn = 0; nn < C::NW; ++nn)
-                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[g & 1][nn][t], a[g & 1][m][t], acc[m][nn], 0, 0, 0);   // D = W . X^T
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x8f16(bh[nn], ah[m], acc[m][nn], 0, 0, 0);                 // D = W . X^T
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m = 0; m < C::MW; ++m)
+#pragma unroll
+                        for (int nn = 0; nn < C::NW; ++nn)
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[g & 1][nn][t], a[g & 1][m][t], acc[m][nn], 0, 0, 0);   // D = W . X^T
+            }
             // the address arithmetic and the issue of the next step's global loads (and of the pending tile's
             // residual) ride in the shadow of group 0
             if constexpr (g == 0) {
@@ -323,7 +347,7 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
             // group g+1, then the MFMAs of group g with the staging VALU work in their shadow, then the ds_writes.
             if constexpr (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, C::MW + C::NW, 0);
 #pragma unroll
-            for (int i = 0; i < 4 * C::MW * C::NW; ++i) {
+            for (int i = 0; i < (F16 ? 1 : 4) * C::MW * C::NW; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if constexpr (nitem > 0 || (EPI && g >= GE && g < GE + 4)) __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 4 : 2, 0);
             }
@@ -399,11 +423,11 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
     }
 }
 
-template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE>
-static int launch_conv(const YondConvDesc& d, hipStream_t st) {
+template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE, bool F16>
+static int launch_conv_p(const YondConvDesc& d, hipStream_t st) {
     using C = ConvCfg<KS, STRIDE, TH, TN, KC>;
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<KS, STRIDE, TH, TN, KC, PRE>;
+    auto kern = conv_mfma_kernel<KS, STRIDE, TH, TN, KC, PRE, F16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -416,6 +440,11 @@ static int launch_conv(const YondConvDesc& d, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::SMEM_BYTES, st, d);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
+}
+
+template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE>
+static int launch_conv(const YondConvDesc& d, hipStream_t st) {
+    return d.algo == 2 ? launch_conv_p<KS, STRIDE, TH, TN, KC, PRE, true>(d, st) : launch_conv_p<KS, STRIDE, TH, TN, KC, PRE, false>(d, st);
 }
 
 // Tile configuration.  3x3 stride-1 layers choose between
@@ -489,7 +518,7 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     if ((long long)d.N * d.H * d.W > 0x7fffffffLL) return YOND_EUNSUPPORTED;    // 32-bit pixel offsets
     if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;
     if (d.algo == 1) return yond_conv_wino_dispatch(d, st);
-    if (d.algo != 0) return YOND_EINVAL;
+    if (d.algo != 0 && d.algo != 2) return YOND_EINVAL;
     if (d.tn != 32 && d.tn != 64) return YOND_EINVAL;
     int tn, kc;
     const int rc = yond_conv_config(d.ksize, d.stride, d.C0 + d.C1, d.Cout, d.shuffle, 0, 0, 0, &tn, &kc);

@@ -116,6 +116,7 @@ class DenoiserPlan:
         self.lib = L.load()
         self.dev = torch.device(device)
         self.prof = None                           # list -> record (kernel tag, flops, start, end) HIP events per conv launch
+        self.precision = getattr(module, 'precision', 'fp32')      # 'fp16': MFMA convolutions on the fp16 matrix path (cfg 5)
         self.kind = type(module).__name__          # GuidedResUnet | SNRnet | UNetSeeInDark
         self.res = bool(module.res)
         self.norm = bool(module.norm)
@@ -206,15 +207,20 @@ class DenoiserPlan:
         d.Cout = pc.gemm_n
         d.ksize, d.stride, d.shuffle = pc.ksize, pc.stride, int(pc.shuffle)
         d.pre_act, d.post_act, d.slope = pre_act, post_act, slope
+        # `algo` (tests) / plan.conv_algo: 0 direct fp32, 1 Winograd fp32 where it is the faster kernel, 2 Winograd
+        # fp32 wherever supported; plan.precision 'fp16' (BASELINE cfg 5): every MFMA convolution on the fp16 matrix path
         if algo is None:
             algo = getattr(self, 'conv_algo', WINO_DEFAULT)
-        wino = pc.wino() if (algo == 2 or (algo == 1 and pc.gemm_n % 64 == 0)) else None
+        fp16 = getattr(self, 'precision', 'fp32') == 'fp16' or algo == 'fp16'
+        wino = None
+        if not fp16:
+            wino = pc.wino() if (algo == 2 or (algo == 1 and pc.gemm_n % 64 == 0)) else None
         if wino is not None:
             tn, kc, wpk = 64, 8, wino
             d.algo = 1
         else:
             tn, kc, wpk = pc.config(N, d.Ho, d.Wo)
-            d.algo = 0
+            d.algo = 2 if fp16 else 0
         d.wpk = wpk.data_ptr()
         d.tn = tn
         d.kc = kc
@@ -232,6 +238,8 @@ class DenoiserPlan:
         if prof is not None:
             e1.record()
             tag = f"conv_wino_kernel<{tn}>" if d.algo == 1 else f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{tn},{kc}>"
+            if d.algo == 2:
+                tag += "/f16"
             prof.append((tag, 2.0 * pc.macs_per_pixel * N * d.Ho * d.Wo, e0, e1))
         return dst
 

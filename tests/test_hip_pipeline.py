@@ -65,3 +65,33 @@ def test_full_frame_cfg2_properties():
     assert dn.shape == (3000, 4000) and bool(torch.isfinite(dn).all())
     assert float(dn.min()) >= 0.0 and float(dn.max()) <= 1.0
     print("[cfg2] params", res['params'])
+
+
+@pytest.mark.parametrize("K,sigma,expo,idx", [(1.0, 5.0, 0.03, 51), (2.0, 25.0, 0.03, 52), (4.0, 50.0, 0.2, 53)])
+def test_cfg5_unclipped_low_light_sweep(K, sigma, expo, idx):
+    """BASELINE cfg 5: no black-level clip (negative DN reach the VST; the bias LUT is looked up at max(x, 0),
+    YOND_SIDD.py:252), sigma sweep 5..50 DN.  fp32 path against the oracle on the same unclipped frame, then the
+    fp16 MFMA conv path against the fp32 output (PSNR >= 55 dB)."""
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    arch = ARCHS["gru32"]
+    net, sd = make_net(arch, 3)
+    # low light: the synthetic scene at 3 % / 20 % exposure, Poisson-Gaussian noise, NOT clipped at the black level
+    rng = np.random.default_rng(idx)
+    clean = (O.synth_clean(192, 256) * expo).astype(np.float32)
+    noisy = ((rng.poisson(clean * 959.0 / K) * K + rng.normal(0.0, sigma, clean.shape)) / 959.0).astype(np.float32)
+    assert noisy.min() < 0.0                                   # the case really has negative pixels
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'full_dn': True}
+    torch.set_num_threads(8)
+    ref = O.IterDenoise(noisy, arch, sd, pipe)
+    res = P.IterDenoise(noisy, net, arch, pipe, device=DEV)
+    np.testing.assert_allclose(res['regs'][0][0], ref['regs'][0][0], rtol=2e-5)
+    np.testing.assert_allclose(res['regs'][0][1], ref['regs'][0][1], rtol=0, atol=2e-5 * abs(ref['regs'][0][0]) + 1e-9)
+    dn32 = res['raw_dns'][0].cpu().numpy()
+    assert report(f"cfg5 K={K} sigma={sigma} fp32 vs oracle", dn32, ref['raw_dns'][0]) <= 1e-4
+    net.precision = 'fp16'
+    dn16 = P.IterDenoise(noisy, net, arch, pipe, device=DEV)['raw_dns'][0].cpu().numpy()
+    mse = float(np.mean((dn16.astype(np.float64) - dn32.astype(np.float64)) ** 2))
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
+    print(f"[parity] cfg5 K={K} sigma={sigma}: fp16-MFMA path vs fp32 path PSNR {psnr:.1f} dB")
+    assert psnr >= 55.0

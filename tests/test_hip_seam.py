@@ -30,6 +30,9 @@ def test_stdfilt_and_polyfit():
     assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= 2e-6
     g2 = stdfilt(rggb[:, :, 0], 5)
     assert np.max(np.abs(g2 - O.stdfilt(rggb[:, :, 0], 5))) <= 2e-6
+    for nc in (2, 5):                          # channel counts that are not a multiple of the kernel's 4 planes
+        img = np.ascontiguousarray(np.concatenate([rggb, rggb[:, :, :1]], axis=2)[:, :, :nc])
+        assert np.max(np.abs(stdfilt(img, 9) - O.stdfilt(img, 9))) <= 2e-6
     rng = np.random.default_rng(1)
     m = rng.random(30001).astype(np.float32)
     v = (0.004 * m + 4e-5 + 1e-5 * rng.standard_normal(30001)).astype(np.float32)

@@ -62,9 +62,8 @@ struct WinoCfg {
     static constexpr int NT = 512;                               // threads per workgroup
     static constexpr int NIN = (NITEM + NT - 1) / NT;
     static constexpr int NUT = U_FLOATS / 4 / NT;                // LDS-DMA instructions per thread and weight slice
-    static constexpr int EP_FLOATS = 4 * TN;
     static constexpr int RAWB_FLOATS = RAW_FLOATS + 4;           // + a dummy slot for items past the end of the tile
-    static constexpr int SMEM_BYTES = (2 * V_FLOATS + 2 * U_FLOATS + 2 * RAWB_FLOATS + EP_FLOATS) * 4;
+    static constexpr int SMEM_BYTES = (2 * V_FLOATS + 2 * U_FLOATS + 2 * RAWB_FLOATS) * 4;
 };
 
 __device__ __forceinline__ float wino_silu(float x) {
@@ -86,7 +85,6 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     float* s_v = smem;
     float* s_u = smem + 2 * C::V_FLOATS;
     float* s_raw = s_u + 2 * C::U_FLOATS;
-    float* s_ep = s_raw + 2 * C::RAWB_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 15, kq = lane >> 4;
@@ -271,8 +269,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     const float slope_eff = d.post_act == 2 ? d.slope : 1.0f;
     // (FiLM / bias vectors straight from global memory: a load inside a conditional block earlier in the step makes the
     // compiler fall back to s_waitcnt vmcnt(0) for the staged input, which exposes the memory latency every step)
-    auto epilogue = [&](const Tile& T, int par) {
-        (void)par;
+    auto epilogue = [&](const Tile& T) {
         const int cbase = T.ct * TN + cq * 16 + 4 * kq;
         const int eoff = (d.ebatch ? T.n * d.Cout : 0) + cbase;
         const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -349,7 +346,6 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     int next_ct = cur.ct;                       // channel tile of step s+1
     const Cur c1 = adv(cs), c2 = adv(c1), c3 = adv(c2);
     Cur cl = adv(c3);                           // next loads to issue: step s+4
-    int par = 0;
     zero_acc();
     float* rawA = s_raw;                        // raw(s+1) at the top of step s
     float* rawB = s_raw + C::RAWB_FLOATS;       // receives raw(s+2) during step s
@@ -416,8 +412,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         barrier_lds_keep_loads<C::NIN>();
         WDBG(4);
         if (last_ch) {
-            if (computes && (!(WINO_ABL & 4) || d.N < 0)) epilogue(cur, par);
-            par ^= 1;
+            if (computes && (!(WINO_ABL & 4) || d.N < 0)) epilogue(cur);
             zero_acc();
             if (cn.tile < total) {
                 const int n = cn.tile / tiles_per_img;

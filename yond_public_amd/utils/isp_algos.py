@@ -69,8 +69,8 @@ def stdfilt(img, k=5):
     pl, back = _planes(img)
     Cn, h, w = pl.shape
     pad = (-Cn) % 4
-    if pad:
-        pl = torch.cat([pl, pl[:pad]], 0).contiguous()
+    if pad:                                   # the kernel's grid covers 4 planes: fill up with copies of the last one
+        pl = torch.cat([pl, pl[-1:].expand(pad, h, w)], 0).contiguous()
     out = torch.empty_like(pl)
     for c0 in range(0, pl.shape[0], 4):       # the kernel filters 4 planes per launch
         L.check(lib.yond_box_stats_self2_f32(L.ptr(pl[c0:c0 + 4]), h, w, int(k), 0, L.ptr(out[c0:c0 + 4]), L.stream()),

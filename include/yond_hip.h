@@ -87,7 +87,8 @@ int yond_image_max_f32(const float* x, int N, size_t elems, float* partial, floa
  * Weights must be packed by yond_pack_conv_weight_f32 (host side) for the same (taps, TN, KC). */
 typedef struct YondConvDesc {
     const float* src0;    /* [N][H][W][C0] */
-    const float* src1;    /* [N][H][W][C1] or NULL */
+    const float* src1;    /* [N][H][W][C1] or NULL; with shuffle: the skip tensor at the OUTPUT resolution [N][2H][2W][C1],
+                             read at the sub-position each channel block stores to (fused convT + cat + 1x1 shortcut) */
     int C0, C1;           /* Cin = C0 + C1; each a multiple of kc */
     int N, H, W;          /* input extent */
     int Ho, Wo;           /* GEMM-M extent: H/stride, W/stride (convT: H, W) */

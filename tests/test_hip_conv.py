@@ -157,6 +157,28 @@ def test_conv_transpose_2x2(Ci, Co):
     assert report(f"convT {Ci}->{Co}", got, ref) < 2e-5
 
 
+def test_conv_transpose_fused_with_skip_shortcut():
+    """The decoder's ConvTranspose2d -> cat(up, skip) -> 1x1 shortcut as ONE shuffle GEMM with the skip tensor as a
+    second, output-resolution source (weights folded in float64 as engine.py does)."""
+    g = torch.Generator().manual_seed(21)
+    N, c, h, w = 2, 32, 9, 20
+    cur = torch.randn(N, 2 * c, h, w, generator=g)
+    skip = torch.randn(N, c, 2 * h, 2 * w, generator=g)
+    wt = torch.randn(2 * c, c, 2, 2, generator=g) / (2 * c) ** 0.5
+    bt = torch.randn(c, generator=g)
+    wsc = torch.randn(c, 2 * c, 1, 1, generator=g) / (2 * c) ** 0.5
+    bsc = torch.randn(c, generator=g)
+    ref = F.conv2d(torch.cat([F.conv_transpose2d(cur.double(), wt.double(), bt.double(), stride=2), skip.double()], 1),
+                   wsc.double(), bsc.double())
+    w2 = wsc.double()[:, :, 0, 0]
+    w_cur = torch.einsum('ou,iuyx->ioyx', w2[:, :c], wt.double())
+    w_skip = w2[:, c:].t()[:, :, None, None].expand(c, c, 2, 2)
+    w_f = torch.cat([w_cur, w_skip], 0).float().contiguous()
+    b_f = (bsc.double() + w2[:, :c] @ bt.double()).float()
+    got = nchw(run_conv(w_f, b_f, 1, 1, [2 * c, c], [nhwc(cur).to(DEV), nhwc(skip).to(DEV)], N, h, w, shuffle=True))
+    assert report("fused convT + cat + 1x1 shortcut", got, ref) < 2e-5
+
+
 def test_channel_padding_small_nf():
     """nf=8 style channel counts are zero-padded to 32 inside the engine."""
     g = torch.Generator().manual_seed(3)

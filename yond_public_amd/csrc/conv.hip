@@ -121,9 +121,14 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
         in_lds[k] = it < C::NITEM ? lp * C::PS + sl * 4 : KC;
     }
 
+    // shuffle (transposed conv as GEMM) with a SECOND source: src1 is the skip tensor at the OUTPUT resolution
+    // [N][2H][2W][C1], read at the sub-position (dy, dx) the tile's channel block stores to -- the fused
+    // "ConvTranspose2d -> cat(up, skip) -> 1x1 shortcut" of the decoder blocks (engine.py), K = C0 + C1
+    const bool up_skip = d.shuffle && d.C1 > 0;
     struct Tile {
         int ct, n, ox0, oy0;
         int goff[C::NIN];                      // pixel offset into the NHWC source (-1: outside the image -> zeros)
+        int goff1[C::NIN];                     // up_skip: pixel offset into src1 (output resolution)
     };
     auto decode = [&](int t, Tile& T) {
         const int n = t / tiles_per_img;
@@ -141,7 +146,14 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
             const int pix = it / C::SL;
             const int py = pix / C::IW, px = pix % C::IW;
             const int gy = iy0 + py, gx = ix0 + px;
-            T.goff[k] = (it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) ? ((n * d.H + gy) * d.W + gx) : -1;
+            const bool ok = it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            T.goff[k] = ok ? ((n * d.H + gy) * d.W + gx) : -1;
+            if (up_skip) {
+                const int sp = (T.ct * TN) / Cr;               // a channel tile never straddles two sub-positions
+                T.goff1[k] = ok ? ((n * 2 * d.H + 2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1)) : -1;
+            } else {
+                T.goff1[k] = 0;
+            }
         }
     };
 
@@ -151,15 +163,18 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
         const int c0 = ch * KC;
         const float* src;
         int Cs, cc;
-        if (c0 < d.C0) { src = d.src0; Cs = d.C0; cc = c0; }
+        const bool second = c0 >= d.C0;
+        if (!second) { src = d.src0; Cs = d.C0; cc = c0; }
         else { src = d.src1; Cs = d.C1; cc = c0 - d.C0; }
+        const bool hires = second && up_skip;
         vin_ok = 0;
 #pragma unroll
         for (int k = 0; k < C::NIN; ++k) {
             // outside the image: read pixel 0 (valid memory); the value is zeroed when it is written to LDS, so
             // nothing touches the loaded registers (and waits for them) before the middle of the MFMA stream
             const bool ok = T.goff[k] >= 0;
-            if ((YOND_ABL & 2) == 0) vin[k] = *(const f32x4*)(src + (size_t)(ok ? T.goff[k] : 0) * Cs + cc + my_sl);
+            const int po = hires ? T.goff1[k] : T.goff[k];
+            if ((YOND_ABL & 2) == 0) vin[k] = *(const f32x4*)(src + (size_t)(ok ? po : 0) * Cs + cc + my_sl);
             vin_ok |= (ok ? 1u : 0u) << k;
         }
         // weight slice: already in LDS order on the host side -> linear copy by LDS-DMA (no VGPRs, no ds_write);

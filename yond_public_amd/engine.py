@@ -137,8 +137,21 @@ class DenoiserPlan:
                 blk['conv1'] = _PackedConv(dev, sd[pre + '.conv1.weight'], None, 3, 1, [c])
                 blk['conv2'] = _PackedConv(dev, sd[pre + '.conv2.weight'], None, 3, 1, [c])
                 if i >= 6:
-                    blk['sc'] = _PackedConv(dev, sd[pre + '.short_cut.0.weight'], sd[pre + '.short_cut.0.bias'], 1, 1, [c, c])
-                    blk['up'] = _PackedConv(dev, sd[f'upv{i}.weight'], sd[f'upv{i}.bias'], 1, 1, [2 * c], shuffle=True)
+                    # Decoder: up = ConvTranspose2d(cur); x = short_cut(cat(up, skip)).  `up` feeds nothing else
+                    # (archs/Unet.py:451-466, modules.py:186-187), and both maps are linear per sub-position, so they
+                    # fold into ONE GEMM per sub-position: x = (Wsc_up . Wt[dy,dx]) cur + Wsc_skip skip + (bsc + Wsc_up bt).
+                    # The product is formed once in float64; `up` (the largest tensor of the level) is never written.
+                    wt = sd[f'upv{i}.weight'].to('cpu', torch.float64)                   # [2c][c][2][2]
+                    bt = sd[f'upv{i}.bias'].to('cpu', torch.float64)
+                    wsc = sd[pre + '.short_cut.0.weight'].to('cpu', torch.float64)[:, :, 0, 0]   # [c][up c | skip c]
+                    bsc = sd[pre + '.short_cut.0.bias'].to('cpu', torch.float64)
+                    w_cur = torch.einsum('ou,iuyx->ioyx', wsc[:, :c], wt)                # [2c][c][2][2]
+                    w_skip = wsc[:, c:].t()[:, :, None, None].expand(c, c, 2, 2)        # [c (skip in)][c][2][2]
+                    w_f = torch.cat([w_cur, w_skip], 0).to(torch.float32).contiguous()   # ConvTranspose2d layout over [cur | skip]
+                    b_f = (bsc + wsc[:, :c] @ bt).to(torch.float32)
+                    blk['upsc'] = _PackedConv(dev, w_f, b_f, 1, 1, [2 * c, c], shuffle=True)
+                    # algorithmic MACs of the two reference layers, per GEMM-M (low resolution) pixel
+                    blk['upsc'].macs_per_pixel = 2 * c * c * 4 + 2 * c * c * 4
                 if i <= 4:
                     blk['pool'] = _PackedConv(dev, sd[f'pool{i}.conv.weight'], sd[f'pool{i}.conv.bias'], 3, 2, [c])
                 self.blocks[i] = blk
@@ -314,12 +327,10 @@ class DenoiserPlan:
                 cp = blk['Cp']
                 f = film[f'conv{i}']
                 if i >= 6:
-                    # ConvT 2x2 s2 (GEMM + pixel shuffle), then the block's 1x1 shortcut over [up, skip]
-                    up = self._new(N, 2 * h, 2 * w, cp)
-                    self._conv(blk['up'], cur, None, N, h, w, up)
+                    # ConvT 2x2 s2 + the block's 1x1 shortcut over [up, skip] as one GEMM with a pixel-shuffle store
+                    xs = self._new(N, 2 * h, 2 * w, cp)
+                    self._conv(blk['upsc'], cur, skips[10 - i], N, h, w, xs)
                     h, w = 2 * h, 2 * w
-                    xs = self._new(N, h, w, cp)
-                    self._conv(blk['sc'], up, skips[10 - i], N, h, w, xs)
                     cur = xs
                 tmp = self._new(N, h, w, cp)
                 # z = conv2(SiLU(FiLM(conv1(SiLU(x))))) + x : both SiLUs run in the consumers' staging (hidden under

@@ -69,6 +69,7 @@ __device__ __forceinline__ float silu_fast(float x) {
 template <int KS, int STRIDE, int KC, int TN>
 constexpr int conv_wgs_per_cu() {
     if (KS == 3 && STRIDE == 1 && KC == 8) return TN == 32 ? YOND_B32_WGS : 2;
+    if (KS == 3 && STRIDE == 2 && TN == 32) return 2;            // instantiated with 4-row tiles: two images fit the LDS
     return KS == 1 ? 2 : 1;
 }
 
@@ -491,6 +492,8 @@ extern "C" int yond_conv_config(int ksize, int stride, int cin, int cout, int sh
                 if (sa > best) { best = sa; t = tws[i]; k = 16; }
                 if (sb > best) { best = sb; t = tws[i]; k = 8; }
             }
+        } else if (ksize == 3 && stride == 2) {
+            t = 32;       // 4-row tiles, two workgroups per CU: measured >= the 64-wide single-workgroup form on every level
         } else if (t == 64) {
             const int slots = ksize == 1 ? 512 : 256;
             if (fill(64, slots) < 0.85 && fill(32, slots) > fill(64, slots) + 0.1) t = 32;
@@ -498,6 +501,8 @@ extern "C" int yond_conv_config(int ksize, int stride, int cin, int cout, int sh
     }
     static const char* ekc = getenv("YOND_CONV_KC");            // experiments only
     static const char* etn = getenv("YOND_CONV_TN");
+    static const char* es2 = getenv("YOND_S2_TN");
+    if (es2 && ksize == 3 && stride == 2) t = atoi(es2) == 32 ? 32 : (ntile % 64 == 0 ? 64 : 32);
     if (ekc && ksize == 3 && stride == 1) k = atoi(ekc) == 8 ? 8 : 16;
     if (etn && ksize == 3 && stride == 1 && ntile % 64 == 0) t = atoi(etn) == 32 ? 32 : 64;
     if (tn) *tn = t;
@@ -561,6 +566,6 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
         return tn == 64 ? launch_conv<3, 1, 8, 64, 16, false>(d, st) : launch_conv<3, 1, 8, 32, 16, false>(d, st);
     }
     if (d.ksize == 3 && d.stride == 2)
-        return tn == 64 ? launch_conv<3, 2, 8, 64, 8, false>(d, st) : launch_conv<3, 2, 8, 32, 8, false>(d, st);
+        return tn == 64 ? launch_conv<3, 2, 8, 64, 8, false>(d, st) : launch_conv<3, 2, 4, 32, 8, false>(d, st);
     return tn == 64 ? launch_conv<1, 1, 8, 64, 16, false>(d, st) : launch_conv<1, 1, 8, 32, 16, false>(d, st);
 }

@@ -49,21 +49,29 @@ extern "C" int yond_wino_debug_read(unsigned long long* host) {
 #define WINO_ABL 0      // timing-only ablations: 1 no input loads, 2 no weight DMA, 4 no epilogue, 8 no transform, 16 no MFMA
 #endif
 
-template <int TN>
+// Two tile shapes: <TN 64, TH 8, KC 8>  8 x 32 px x 64 channels, 8-channel chunks  (layers with Cout % 64 == 0)
+//                  <TN 32, TH 16, KC 4> 16 x 32 px x 32 channels, 4-channel chunks (the 32-channel level-0 layers: all eight
+//                                        waves still own a full 32-patch x 16-channel x 16-plane block)
+template <int TN, int TH_, int KC_>
 struct WinoCfg {
-    static constexpr int KC = 8;
-    static constexpr int TH = 8, TW = 32;
-    static constexpr int NP = (TH / 2) * (TW / 2);               // 64 patches
+    static constexpr int KC = KC_;
+    static constexpr int KH = KC / 4;                            // 16-byte channel groups per chunk (1 or 2)
+    static constexpr int TH = TH_, TW = 32;
+    static constexpr int NPR = TH / 2;                           // patch rows (4 or 8), 16 patches each
+    static constexpr int NP = NPR * (TW / 2);                    // patches per tile (64 or 128)
+    static constexpr int MB = NP / 32;                           // 32-patch blocks (2 or 4)
+    static constexpr int CQ = TN / 16;                           // 16-channel quarters (4 or 2); MB * CQ = 8 waves
     static constexpr int IH = TH + 2, IW = TW + 2, HALF = IW / 2;
-    static constexpr int RAW_FLOATS = 2 * IH * 2 * HALF * 4;     // 2720
-    static constexpr int V_FLOATS = 16 * 2 * NP * 4;             // 8192
-    static constexpr int U_FLOATS = 16 * 2 * TN * 4;
-    static constexpr int NITEM = IH * IW * 2;                    // (pixel, kh) 16-byte items
+    static constexpr int RAW_FLOATS = KH * IH * 2 * HALF * 4;
+    static constexpr int V_FLOATS = 16 * KH * NP * 4;            // 8192 in both shapes
+    static constexpr int U_FLOATS = 16 * KH * TN * 4;
+    static constexpr int NITEM = IH * IW * KH;                   // (pixel, kh) 16-byte items
     static constexpr int NT = 512;                               // threads per workgroup
     static constexpr int NIN = (NITEM + NT - 1) / NT;
     static constexpr int NUT = U_FLOATS / 4 / NT;                // LDS-DMA instructions per thread and weight slice
     static constexpr int RAWB_FLOATS = RAW_FLOATS + 4;           // + a dummy slot for items past the end of the tile
     static constexpr int SMEM_BYTES = (2 * V_FLOATS + 2 * U_FLOATS + 2 * RAWB_FLOATS) * 4;
+    static_assert(MB * CQ == 8 && KH * NP * 4 == NT && NUT >= 1 && U_FLOATS / 4 % NT == 0, "wave / task maps below");
 };
 
 __device__ __forceinline__ float wino_silu(float x) {
@@ -76,10 +84,9 @@ __device__ __forceinline__ void barrier_lds_only() { if (!(WINO_ABL & 32)) asm v
 template <int N>
 __device__ __forceinline__ void barrier_lds_keep_loads() { if (!(WINO_ABL & 32)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
 
-template <int TN, bool PRE>
+template <int TN, int TH, int KC, bool PRE>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
-    using C = WinoCfg<TN>;
-    static_assert(TN == 64, "wave map below: 2 patch blocks x 4 channel quarters");
+    using C = WinoCfg<TN, TH, KC>;
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_v = smem;
@@ -88,24 +95,25 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 15, kq = lane >> 4;
-    const int mb = wave & 1, cq = wave >> 1;
+    const int mb = wave % C::MB, cq = wave / C::MB;
 
-    const int nct = (d.Cout + TN - 1) / TN;                  // Cout 32: one half-empty channel tile (U zero-padded)
-    const bool computes = cq * 16 < d.Cout;                  // the waves of the empty half only stage / transform
-    const int ntx = (d.Wo + 31) / 32, nty = (d.Ho + 7) / 8;
+    const int nct = d.Cout / TN;
+    const bool computes = d.Cout > 0;                        // always true; opaque to the compiler (keeps the MFMA stretch
+                                                             // a block of its own: merged with its neighbours it spilled)
+    const int ntx = (d.Wo + 31) / 32, nty = (d.Ho + TH - 1) / TH;
     const int tiles_per_img = nct * ntx * nty;
     const int total = tiles_per_img * d.N;
     const int G = gridDim.x;
     const int lslot = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;   // XCD-contiguous runs
     const int Cin = d.C0 + d.C1;
-    const int nchunk = Cin / 8;
-    const int my_kh = tid & 1;
+    const int nchunk = Cin / KC;
+    const int my_kh = C::KH == 2 ? (tid & 1) : 0;
 
     int raw_lds[C::NIN];
 #pragma unroll
     for (int k = 0; k < C::NIN; ++k) {
         const int it = tid + k * C::NT;
-        const int pix = it >> 1;
+        const int pix = it / C::KH;
         const int py = pix / C::IW, px = pix % C::IW;
         // items past the end of the tile go to a dummy slot behind the image (never read): no branch in the step body
         raw_lds[k] = it < C::NITEM ? ((((my_kh * C::IH + py) * 2 + (px & 1)) * C::HALF + (px >> 1)) * 4) : C::RAW_FLOATS;
@@ -123,11 +131,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         b /= nct;
         const int tx = b % ntx, ty = b / ntx;
         T.ox0 = tx * 32;
-        T.oy0 = ty * 8;
+        T.oy0 = ty * TH;
 #pragma unroll
         for (int k = 0; k < C::NIN; ++k) {
             const int it = tid + k * C::NT;
-            const int pix = it >> 1;
+            const int pix = it / C::KH;
             const int py = pix / C::IW, px = pix % C::IW;
             const int gy = T.oy0 - 1 + py, gx = T.ox0 - 1 + px;
             T.goff[k] = (it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) ? ((n * d.H + gy) * d.W + gx) : -1;
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     unsigned vin_ok[2] = {0, 0};
     auto issue_loads = [&](auto pc, const Tile& T, int ch) {
         constexpr int P = decltype(pc)::value;
-        const int c0 = ch * 8;
+        const int c0 = ch * KC;
         const float* src;
         int Cs, cc;
         if (c0 < d.C0) { src = d.src0; Cs = d.C0; cc = c0; }
@@ -184,9 +192,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     };
     // input transform: one (patch, kh, channel) scalar task per thread -- wave w takes patch row w & 3 of half
     // kh = w >> 2, lane = 4 * patch column + channel: every LDS access is 256 contiguous bytes per wave
-    const int t_kh = wave >> 2, t_pr = wave & 3, t_pc = lane >> 2, t_e = lane & 3;
+    const int t_kh = wave / C::NPR, t_pr = wave % C::NPR, t_pc = lane >> 2, t_e = lane & 3;
     const int t_src = (((t_kh * C::IH + 2 * t_pr) * 2) * C::HALF + t_pc) * 4 + t_e;
     const int t_dst = ((t_kh * C::NP) + t_pr * 16 + t_pc) * 4 + t_e;
+    constexpr int PLV = C::KH * C::NP * 4;                     // floats per plane of V
+    constexpr int PLU = C::KH * TN * 4;                        // floats per plane of U
     float traw[4][4];
     auto transform_load = [&](const float* rawbuf) {
         const float* src = rawbuf + t_src;
@@ -207,10 +217,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         float* o = vbuf + t_dst;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                          // (B^T d) B (columns)
-            o[(i * 4 + 0) * 2 * C::NP * 4] = w[i][0] - w[i][2];
-            o[(i * 4 + 1) * 2 * C::NP * 4] = w[i][1] + w[i][2];
-            o[(i * 4 + 2) * 2 * C::NP * 4] = w[i][2] - w[i][1];
-            o[(i * 4 + 3) * 2 * C::NP * 4] = w[i][1] - w[i][3];
+            o[(i * 4 + 0) * PLV] = w[i][0] - w[i][2];
+            o[(i * 4 + 1) * PLV] = w[i][1] + w[i][2];
+            o[(i * 4 + 2) * PLV] = w[i][2] - w[i][1];
+            o[(i * 4 + 3) * PLV] = w[i][1] - w[i][3];
         }
     };
 
@@ -226,10 +236,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     // mod 64, conflict-free here; merged into ds_read2_b64 they cost 8 cycles and conflict 2-way) -- and therefore in
     // program order: the loop is software-pipelined by hand, plane p + FD is requested before plane p is multiplied.
     constexpr int FD = 4;
-    const int u_off = ((kq >> 1) * TN + cq * 16 + lj) * 4 + (kq & 1) * 2;
-    const int v_off = ((kq >> 1) * C::NP + mb * 32 + lj) * 4 + (kq & 1) * 2;
+    // KC 8: lane group kq supplies channels 2 kq + kk (kk = 0, 1: two MFMAs per 16x16 tile), one float2 = 8 bytes of the
+    //       16-byte slot of half kh = kq >> 1;   KC 4: channel kq, one float of the slot (one MFMA per tile)
+    const int u_off = C::KH == 2 ? ((kq >> 1) * TN + cq * 16 + lj) * 4 + (kq & 1) * 2 : (cq * 16 + lj) * 4 + kq;
+    const int v_off = C::KH == 2 ? ((kq >> 1) * C::NP + mb * 32 + lj) * 4 + (kq & 1) * 2 : (mb * 32 + lj) * 4 + kq;
     auto mfma_all = [&](const float* vbuf, const float* ubuf) {
         typedef const volatile __attribute__((address_space(3))) f32x2_t* lds_v2;
+        typedef const volatile __attribute__((address_space(3))) float* lds_v1;
         const __attribute__((address_space(3))) float* ub = (__attribute__((address_space(3))) float*)(ubuf + u_off);
         const __attribute__((address_space(3))) float* vb = (__attribute__((address_space(3))) float*)(vbuf + v_off);
         f32x2_t uf[FD + 2], v0[FD + 2], v1[FD + 2];
@@ -237,9 +250,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
             constexpr int p = decltype(pc)::value;
             constexpr int sl = p % (FD + 2);
             if (WINO_ABL & 64) { const f32x2_t c = {1.0f + p, 0.5f}; uf[sl] = c; v0[sl] = c; v1[sl] = c; return; }
-            uf[sl] = *(lds_v2)(ub + p * 2 * TN * 4);
-            v0[sl] = *(lds_v2)(vb + p * 2 * C::NP * 4);
-            v1[sl] = *(lds_v2)(vb + p * 2 * C::NP * 4 + 16 * 4);
+            if constexpr (C::KH == 2) {
+                uf[sl] = *(lds_v2)(ub + p * PLU);
+                v0[sl] = *(lds_v2)(vb + p * PLV);
+                v1[sl] = *(lds_v2)(vb + p * PLV + 16 * 4);
+            } else {
+                uf[sl][0] = *(lds_v1)(ub + p * PLU);
+                v0[sl][0] = *(lds_v1)(vb + p * PLV);
+                v1[sl][0] = *(lds_v1)(vb + p * PLV + 16 * 4);
+            }
         };
         static_for<0, FD>([&](auto pc) { load(pc); });
         __builtin_amdgcn_sched_barrier(0);
@@ -256,10 +275,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
                 acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s0][0], v1[s0][0], acc[p][1], 0, 0, 0);
                 acc[p + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][0], v0[s1][0], acc[p + 1][0], 0, 0, 0);
                 acc[p + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][0], v1[s1][0], acc[p + 1][1], 0, 0, 0);
-                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s0][1], v0[s0][1], acc[p][0], 0, 0, 0);
-                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s0][1], v1[s0][1], acc[p][1], 0, 0, 0);
-                acc[p + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][1], v0[s1][1], acc[p + 1][0], 0, 0, 0);
-                acc[p + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][1], v1[s1][1], acc[p + 1][1], 0, 0, 0);
+                if constexpr (C::KH == 2) {
+                    acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s0][1], v0[s0][1], acc[p][0], 0, 0, 0);
+                    acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s0][1], v1[s0][1], acc[p][1], 0, 0, 0);
+                    acc[p + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][1], v0[s1][1], acc[p + 1][0], 0, 0, 0);
+                    acc[p + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[s1][1], v1[s1][1], acc[p + 1][1], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -440,17 +461,17 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     }
 }
 
-template <int TN, bool PRE>
+template <int TN, int TH, int KC, bool PRE>
 static int launch_wino(const YondConvDesc& d, hipStream_t st) {
-    using C = WinoCfg<TN>;
+    using C = WinoCfg<TN, TH, KC>;
     static bool attr_set = false;
-    auto kern = conv_wino_kernel<TN, PRE>;
+    auto kern = conv_wino_kernel<TN, TH, KC, PRE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const long long total = (long long)((d.Cout + TN - 1) / TN) * ((d.Wo + 31) / 32) * ((d.Ho + 7) / 8) * d.N;
+    const long long total = (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
     if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
     const int grid = total < 256 ? (int)total : 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::SMEM_BYTES, st, d);
@@ -458,19 +479,21 @@ static int launch_wino(const YondConvDesc& d, hipStream_t st) {
     return YOND_OK;
 }
 
-// U = G g G^T in float64, rounded once to float32, in the LDS order [ct][chunk][plane][kh][TN][4]
+// U = G g G^T in float64, rounded once to float32, in the LDS order [ct][chunk][plane][kh][tn][4]: tn 64 with 8-channel
+// chunks (kh = 0, 1), tn 32 with 4-channel chunks (kh = 0)
 extern "C" int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, float* dst) {
-    if (!w || !dst || tn != 64 || (cout % tn != 0 && cout != 32) || cin % 8 != 0) return YOND_EINVAL;
+    if (!w || !dst || (tn != 64 && tn != 32) || cout % tn != 0) return YOND_EINVAL;
+    const int kc = tn == 64 ? 8 : 4, KH = kc / 4;
+    if (cin % kc != 0) return YOND_EINVAL;
     static const double Gm[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
     size_t o = 0;
-    for (int ct = 0; ct < (cout + tn - 1) / tn; ++ct)
-        for (int ch = 0; ch < cin / 8; ++ch)
+    for (int ct = 0; ct < cout / tn; ++ct)
+        for (int ch = 0; ch < cin / kc; ++ch)
             for (int p = 0; p < 16; ++p)
-                for (int kh = 0; kh < 2; ++kh)
+                for (int kh = 0; kh < KH; ++kh)
                     for (int j = 0; j < tn; ++j)
                         for (int e = 0; e < 4; ++e) {
-                            const int co = ct * tn + j, ci = ch * 8 + kh * 4 + e;
-                            if (co >= cout) { dst[o++] = 0.0f; continue; }      // cout 32: upper half of the tile is empty
+                            const int co = ct * tn + j, ci = ch * kc + kh * 4 + e;
                             const float* g = w + ((size_t)co * cin + ci) * 9;
                             const int xi = p >> 2, nu = p & 3;
                             double s = 0.0;
@@ -481,16 +504,22 @@ extern "C" int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin,
     return YOND_OK;
 }
 
+// tile width the Winograd kernel would use for a layer: 64 (Cout % 64 == 0, Cin % 8 == 0), 32 (Cout % 32 == 0, Cin % 4 == 0), 0
 extern "C" int yond_conv_wino_supported(int cin, int cout) {
-    return (cin > 0 && cin % 8 == 0 && cout > 0 && (cout % 64 == 0 || cout == 32)) ? 1 : 0;
+    if (cin <= 0 || cout <= 0) return 0;
+    if (cout % 64 == 0 && cin % 8 == 0) return 64;
+    if (cout % 32 == 0 && cin % 4 == 0) return 32;
+    return 0;
 }
 
 // called by yond_conv2d_f32 (conv.hip) for desc.algo == 1
 int yond_conv_wino_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.ksize != 3 || d.stride != 1 || d.shuffle) return YOND_EUNSUPPORTED;
-    if (!yond_conv_wino_supported(d.C0 + d.C1, d.Cout) || d.C0 % 8 != 0 || d.C1 % 8 != 0) return YOND_EUNSUPPORTED;
-    if (d.tn != 64) return YOND_EINVAL;
+    if (d.tn != 64 && d.tn != 32) return YOND_EINVAL;
+    const int kc = d.tn == 64 ? 8 : 4;
+    if (d.Cout % d.tn != 0 || d.C0 % kc != 0 || d.C1 % kc != 0 || d.C0 + d.C1 <= 0) return YOND_EUNSUPPORTED;
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
     if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
-    return d.pre_act ? launch_wino<64, true>(d, st) : launch_wino<64, false>(d, st);
+    if (d.tn == 64) return d.pre_act ? launch_wino<64, 8, 8, true>(d, st) : launch_wino<64, 8, 8, false>(d, st);
+    return d.pre_act ? launch_wino<32, 16, 4, true>(d, st) : launch_wino<32, 16, 4, false>(d, st);
 }

@@ -30,9 +30,12 @@ def _np_ptr(a):
     return C.c_void_p(a.ctypes.data)
 
 
-# 3x3 stride-1 layers: 1 = Winograd F(2x2,3x3) where it is the faster kernel (output channels a multiple of 64: measured
-# 1.45-1.5x over the direct kernel at 64..512 channels; a 32-channel layer would leave half of its 64-wide tile empty
-# and gains nothing), 0 = direct implicit GEMM everywhere, 2 = Winograd wherever the kernel supports the shape
+# 3x3 stride-1 layers: 1 = Winograd F(2x2,3x3) on the layers whose output channels are a multiple of 64 (measured 1.45-1.5x
+# over the direct kernel at 64..512 channels), 0 = direct implicit GEMM everywhere, 2 = Winograd wherever the kernel
+# supports the shape, i.e. also the 32-channel level-0 layers (16 x 32 tiles, 4-channel chunks: 1.15x there, +3 % end to
+# end).  2 is not the default: with random weights the reference's round-2 collab estimate of tests/golden/iter.npz
+# case 0 is chaotic (beta1 -0.158 vs +0.003 for outputs that agree to 2e-6) and the extra rounding change flips its
+# `beta1 < 0 -> stop` guard away from what the reference did.
 WINO_DEFAULT = int(os.environ.get('YOND_CONV_WINO', '1'))
 
 
@@ -97,15 +100,18 @@ class _PackedConv:
         return tn.value, kc.value, self._packed[key]
 
     def wino(self):
-        """Packed Winograd F(2x2,3x3) weights (tn 64) or None when the layer does not fit that kernel."""
+        """(tn, packed Winograd F(2x2,3x3) weights) or None when the layer does not fit that kernel."""
         lib = L.load()
-        if self.ksize != 3 or self.stride != 1 or self.shuffle or not lib.yond_conv_wino_supported(self.cinp, self.gemm_n):
+        if self.ksize != 3 or self.stride != 1 or self.shuffle:
+            return None
+        tn = int(lib.yond_conv_wino_supported(self.cinp, self.gemm_n))
+        if not tn:
             return None
         if 'wino' not in self._packed:
-            packed = np.empty(16 * ((self.gemm_n + 63) // 64 * 64) * self.cinp, np.float32)
-            L.check(lib.yond_pack_conv_wino_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, 64, _np_ptr(packed)),
+            packed = np.empty(16 * self.gemm_n * self.cinp, np.float32)
+            L.check(lib.yond_pack_conv_wino_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, tn, _np_ptr(packed)),
                     "yond_pack_conv_wino_weight_f32")
-            self._packed['wino'] = torch.from_numpy(packed).to(self._dev)
+            self._packed['wino'] = (tn, torch.from_numpy(packed).to(self._dev))
         return self._packed['wino']
 
 
@@ -229,7 +235,8 @@ class DenoiserPlan:
         if not fp16:
             wino = pc.wino() if (algo == 2 or (algo == 1 and pc.gemm_n % 64 == 0)) else None
         if wino is not None:
-            tn, kc, wpk = 64, 8, wino
+            tn, wpk = wino
+            kc = 8 if tn == 64 else 4
             d.algo = 1
         else:
             tn, kc, wpk = pc.config(N, d.Ho, d.Wo)

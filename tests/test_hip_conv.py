@@ -76,7 +76,8 @@ def test_conv3x3_two_source_leaky():
 
 @pytest.mark.parametrize("C,Co,N,H,W", [(64, 64, 1, 8, 32), (64, 64, 2, 16, 64), (32, 64, 1, 9, 33), (128, 128, 1, 24, 40),
                                         (256, 64, 1, 94, 126), (32, 32, 2, 24, 72), (64, 32, 1, 17, 40),
-                                        (64, 64, 1, 1, 1), (64, 64, 1, 2, 3), (128, 64, 2, 4, 4)])
+                                        (64, 64, 1, 1, 1), (64, 64, 1, 2, 3), (128, 64, 2, 4, 4),
+                                        (32, 32, 1, 200, 352), (64, 64, 1, 136, 288)])      # > 256 tiles: several tiles per workgroup
 def test_conv3x3_winograd_plain(C, Co, N, H, W):
     """Winograd F(2x2,3x3) kernel (algo 1) against the float64 direct convolution: same tolerance as the direct
     kernel; partial tiles, odd extents, several tiles per workgroup."""

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
                 cur.ct = bq % nct;
                 bq /= nct;
                 cur.ox0 = (bq % ntx) * 32;
-                cur.oy0 = (bq / ntx) * 8;
+                cur.oy0 = (bq / ntx) * TH;
             }
         }
         WDBG(5);

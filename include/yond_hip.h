@@ -124,8 +124,7 @@ int yond_conv2d_f32(const YondConvDesc* desc, void* stream);
 /* Winograd F(2x2,3x3) variant of the 3x3 stride-1 convolution (same descriptor, algo = 1): 16 instead of 36
  * multiplications per output patch, fp32 throughout; the result differs from the direct kernel by rounding order
  * only.  yond_conv_wino_supported: the channel-tile width the kernel would use for (cin, cout) -- 64
- * (cout % 64 == 0, cin % 8 == 0: 8 x 32 pixel tiles, 8-channel chunks), 32 (cout % 32 == 0, cin % 4 == 0: 16 x 32 pixel
- * tiles, 4-channel chunks) or 0 (not supported); put it in desc.tn and pass it to the packing function.
+ * (cout % 64 == 0: 8 x 32 pixel tiles), 32 (cout % 32 == 0: 16 x 32 pixel tiles) or 0 (not supported; cin % 8 != 0); put it in desc.tn and pass it to the packing function.
  * Weights: w OIHW [cout][cin][3][3] -> dst, 16*cout*cin floats (U = G g G^T in float64, rounded once). */
 int yond_conv_wino_supported(int cin, int cout);
 int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, float* dst);

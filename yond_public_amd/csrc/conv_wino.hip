@@ -49,11 +49,17 @@ extern "C" int yond_wino_debug_read(unsigned long long* host) {
 #define WINO_ABL 0      // timing-only ablations: 1 no input loads, 2 no weight DMA, 4 no epilogue, 8 no transform, 16 no MFMA
 #endif
 
-// Two tile shapes: <TN 64, TH 8, KC 8>  8 x 32 px x 64 channels, 8-channel chunks  (layers with Cout % 64 == 0)
-//                  <TN 32, TH 16, KC 4> 16 x 32 px x 32 channels, 4-channel chunks (the 32-channel level-0 layers: all eight
-//                                        waves still own a full 32-patch x 16-channel x 16-plane block)
-template <int TN, int TH_, int KC_>
+// Tile shapes: <TN 64, TH 8, KC 8, VB 2>   8 x 32 px x 64 channels, 8-channel chunks  (layers with Cout % 64 == 0)
+//              <TN 32, TH 16, KC 8, VB 1> 16 x 32 px x 32 channels, 8-channel chunks (the 32-channel level-0 layers: all eight
+//                                         waves still own a full 32-patch x 16-channel x 16-plane block).  Its V image is
+//                                         64 KB, so there is ONE of it: MFMA phase | barrier | transform phase.  With fp32
+//                                         MFMA and VALU serial anyway this costs only the latency overlap, and the steps are
+//                                         twice as long as with 4-channel chunks (the per-step fixed cost was the problem)
+//              <TN 32, TH 16, KC 4, VB 2> the same tile with 4-channel chunks and two V images (kept for comparison)
+template <int TN, int TH_, int KC_, int VB_>
 struct WinoCfg {
+    static constexpr int VB = VB_;                               // V buffers: 2 = transform of step s+1 runs beside the MFMAs
+                                                                 // of step s; 1 = MFMA phase | barrier | transform phase
     static constexpr int KC = KC_;
     static constexpr int KH = KC / 4;                            // 16-byte channel groups per chunk (1 or 2)
     static constexpr int TH = TH_, TW = 32;
@@ -63,15 +69,16 @@ struct WinoCfg {
     static constexpr int CQ = TN / 16;                           // 16-channel quarters (4 or 2); MB * CQ = 8 waves
     static constexpr int IH = TH + 2, IW = TW + 2, HALF = IW / 2;
     static constexpr int RAW_FLOATS = KH * IH * 2 * HALF * 4;
-    static constexpr int V_FLOATS = 16 * KH * NP * 4;            // 8192 in both shapes
+    static constexpr int V_FLOATS = 16 * KH * NP * 4;
     static constexpr int U_FLOATS = 16 * KH * TN * 4;
     static constexpr int NITEM = IH * IW * KH;                   // (pixel, kh) 16-byte items
     static constexpr int NT = 512;                               // threads per workgroup
     static constexpr int NIN = (NITEM + NT - 1) / NT;
     static constexpr int NUT = U_FLOATS / 4 / NT;                // LDS-DMA instructions per thread and weight slice
     static constexpr int RAWB_FLOATS = RAW_FLOATS + 4;           // + a dummy slot for items past the end of the tile
-    static constexpr int SMEM_BYTES = (2 * V_FLOATS + 2 * U_FLOATS + 2 * RAWB_FLOATS) * 4;
-    static_assert(MB * CQ == 8 && KH * NP * 4 == NT && NUT >= 1 && U_FLOATS / 4 % NT == 0, "wave / task maps below");
+    static constexpr int TPT = KH * NP * 4 / NT;                 // transform tasks per thread (1 or 2)
+    static constexpr int SMEM_BYTES = (VB * V_FLOATS + 2 * U_FLOATS + 2 * RAWB_FLOATS) * 4;
+    static_assert(MB * CQ == 8 && KH * NP * 4 == TPT * NT && NUT >= 1 && U_FLOATS / 4 % NT == 0, "wave / task maps below");
 };
 
 __device__ __forceinline__ float wino_silu(float x) {
@@ -84,13 +91,13 @@ __device__ __forceinline__ void barrier_lds_only() { if (!(WINO_ABL & 32)) asm v
 template <int N>
 __device__ __forceinline__ void barrier_lds_keep_loads() { if (!(WINO_ABL & 32)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
 
-template <int TN, int TH, int KC, bool PRE>
+template <int TN, int TH, int KC, int VB, bool PRE>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
-    using C = WinoCfg<TN, TH, KC>;
+    using C = WinoCfg<TN, TH, KC, VB>;
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_v = smem;
-    float* s_u = smem + 2 * C::V_FLOATS;
+    float* s_u = smem + VB * C::V_FLOATS;
     float* s_raw = s_u + 2 * C::U_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -190,37 +197,46 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
             *(f32x4*)(rawbuf + raw_lds[k]) = ((vin_ok[P] >> k) & 1u) ? v : z;                     // conv zero padding
         }
     };
-    // input transform: one (patch, kh, channel) scalar task per thread -- wave w takes patch row w & 3 of half
-    // kh = w >> 2, lane = 4 * patch column + channel: every LDS access is 256 contiguous bytes per wave
-    const int t_kh = wave / C::NPR, t_pr = wave % C::NPR, t_pc = lane >> 2, t_e = lane & 3;
-    const int t_src = (((t_kh * C::IH + 2 * t_pr) * 2) * C::HALF + t_pc) * 4 + t_e;
-    const int t_dst = ((t_kh * C::NP) + t_pr * 16 + t_pc) * 4 + t_e;
+    // input transform: (patch, kh, channel) scalar tasks, TPT per thread -- task i of wave w is "virtual wave" w + 8 i: patch
+    // row (w + 8 i) % NPR of half kh = (w + 8 i) / NPR; lane = 4 * patch column + channel: every LDS access is 256 contiguous
+    // bytes per wave
+    const int t_pc = lane >> 2, t_e = lane & 3;
     constexpr int PLV = C::KH * C::NP * 4;                     // floats per plane of V
     constexpr int PLU = C::KH * TN * 4;                        // floats per plane of U
-    float traw[4][4];
+    float traw[C::TPT][4][4];
     auto transform_load = [&](const float* rawbuf) {
-        const float* src = rawbuf + t_src;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < C::TPT; ++i) {
+            const int vw = wave + 8 * i;
+            const int t_kh = vw / C::NPR, t_pr = vw % C::NPR;
+            const float* src = rawbuf + (((t_kh * C::IH + 2 * t_pr) * 2) * C::HALF + t_pc) * 4 + t_e;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) traw[r][c] = src[((r * 2 + (c & 1)) * C::HALF + (c >> 1)) * 4];
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) traw[i][r][c] = src[((r * 2 + (c & 1)) * C::HALF + (c >> 1)) * 4];
+        }
     };
     auto transform_store = [&](float* vbuf) {
-        float w[4][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {                          // B^T d (rows)
-            w[0][c] = traw[0][c] - traw[2][c];
-            w[1][c] = traw[1][c] + traw[2][c];
-            w[2][c] = traw[2][c] - traw[1][c];
-            w[3][c] = traw[1][c] - traw[3][c];
-        }
-        float* o = vbuf + t_dst;
+        for (int i = 0; i < C::TPT; ++i) {
+            const int vw = wave + 8 * i;
+            const int t_kh = vw / C::NPR, t_pr = vw % C::NPR;
+            float w[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                          // (B^T d) B (columns)
-            o[(i * 4 + 0) * PLV] = w[i][0] - w[i][2];
-            o[(i * 4 + 1) * PLV] = w[i][1] + w[i][2];
-            o[(i * 4 + 2) * PLV] = w[i][2] - w[i][1];
-            o[(i * 4 + 3) * PLV] = w[i][1] - w[i][3];
+            for (int c = 0; c < 4; ++c) {                      // B^T d (rows)
+                w[0][c] = traw[i][0][c] - traw[i][2][c];
+                w[1][c] = traw[i][1][c] + traw[i][2][c];
+                w[2][c] = traw[i][2][c] - traw[i][1][c];
+                w[3][c] = traw[i][1][c] - traw[i][3][c];
+            }
+            float* o = vbuf + ((t_kh * C::NP) + t_pr * 16 + t_pc) * 4 + t_e;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                      // (B^T d) B (columns)
+                o[(q * 4 + 0) * PLV] = w[q][0] - w[q][2];
+                o[(q * 4 + 1) * PLV] = w[q][1] + w[q][2];
+                o[(q * 4 + 2) * PLV] = w[q][2] - w[q][1];
+                o[(q * 4 + 3) * PLV] = w[q][1] - w[q][3];
+            }
         }
     };
 
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     float* rawA = s_raw;                        // raw(s+1) at the top of step s
     float* rawB = s_raw + C::RAWB_FLOATS;       // receives raw(s+2) during step s
     float* vb = s_v;
-    float* vn = s_v + C::V_FLOATS;
+    float* vn = VB == 2 ? s_v + C::V_FLOATS : s_v;
     float* ubf = s_u;
     float* un = s_u + C::U_FLOATS;
     // prologue: V(0), U(0), raw(1) in LDS; the loads of steps 2 and 3 in flight (register sets 0 and 1)
@@ -412,7 +428,16 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         // other instructions of every step (measured: 50 % MFMA busy).  In both orders the DMA is issued before the
         // step's global loads, which is what the end-of-step wait relies on.
         WDBG(1);
-        if (wave < 4) {
+        if constexpr (VB == 1) {
+            // one V image: all waves multiply, then (behind a barrier) all waves build the next image
+            if (computes) mfma_all(vb, ubf);
+            WDBG(2);
+            barrier_lds_only();                                 // every wave is done reading V(s)
+            dma();
+            if (!(WINO_ABL & 8)) { transform_load(rawA); transform_store(vn); }
+            if (!(WINO_ABL & 128)) write_raw(pc, rawB);
+            loads_for(pc, cl);
+        } else if (wave < 4) {
             dma();
             if (computes) mfma_all(vb, ubf);
             WDBG(2);
@@ -461,11 +486,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     }
 }
 
-template <int TN, int TH, int KC, bool PRE>
+template <int TN, int TH, int KC, int VB, bool PRE>
 static int launch_wino(const YondConvDesc& d, hipStream_t st) {
-    using C = WinoCfg<TN, TH, KC>;
+    using C = WinoCfg<TN, TH, KC, VB>;
     static bool attr_set = false;
-    auto kern = conv_wino_kernel<TN, TH, KC, PRE>;
+    auto kern = conv_wino_kernel<TN, TH, KC, VB, PRE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -479,11 +504,10 @@ static int launch_wino(const YondConvDesc& d, hipStream_t st) {
     return YOND_OK;
 }
 
-// U = G g G^T in float64, rounded once to float32, in the LDS order [ct][chunk][plane][kh][tn][4]: tn 64 with 8-channel
-// chunks (kh = 0, 1), tn 32 with 4-channel chunks (kh = 0)
+// U = G g G^T in float64, rounded once to float32, in the LDS order [ct][chunk of 8 channels][plane][kh][tn][4]
 extern "C" int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, float* dst) {
     if (!w || !dst || (tn != 64 && tn != 32) || cout % tn != 0) return YOND_EINVAL;
-    const int kc = tn == 64 ? 8 : 4, KH = kc / 4;
+    const int kc = 8, KH = kc / 4;
     if (cin % kc != 0) return YOND_EINVAL;
     static const double Gm[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
     size_t o = 0;
@@ -504,11 +528,11 @@ extern "C" int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin,
     return YOND_OK;
 }
 
-// tile width the Winograd kernel would use for a layer: 64 (Cout % 64 == 0, Cin % 8 == 0), 32 (Cout % 32 == 0, Cin % 4 == 0), 0
+// tile width the Winograd kernel would use for a layer: 64 (Cout % 64 == 0), 32 (Cout % 32 == 0), 0; Cin % 8 == 0
 extern "C" int yond_conv_wino_supported(int cin, int cout) {
     if (cin <= 0 || cout <= 0) return 0;
     if (cout % 64 == 0 && cin % 8 == 0) return 64;
-    if (cout % 32 == 0 && cin % 4 == 0) return 32;
+    if (cout % 32 == 0 && cin % 8 == 0) return 32;
     return 0;
 }
 
@@ -516,10 +540,10 @@ extern "C" int yond_conv_wino_supported(int cin, int cout) {
 int yond_conv_wino_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.ksize != 3 || d.stride != 1 || d.shuffle) return YOND_EUNSUPPORTED;
     if (d.tn != 64 && d.tn != 32) return YOND_EINVAL;
-    const int kc = d.tn == 64 ? 8 : 4;
+    const int kc = 8;
     if (d.Cout % d.tn != 0 || d.C0 % kc != 0 || d.C1 % kc != 0 || d.C0 + d.C1 <= 0) return YOND_EUNSUPPORTED;
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
     if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
-    if (d.tn == 64) return d.pre_act ? launch_wino<64, 8, 8, true>(d, st) : launch_wino<64, 8, 8, false>(d, st);
-    return d.pre_act ? launch_wino<32, 16, 4, true>(d, st) : launch_wino<32, 16, 4, false>(d, st);
+    if (d.tn == 64) return d.pre_act ? launch_wino<64, 8, 8, 2, true>(d, st) : launch_wino<64, 8, 8, 2, false>(d, st);
+    return d.pre_act ? launch_wino<32, 16, 8, 1, true>(d, st) : launch_wino<32, 16, 8, 1, false>(d, st);
 }

@@ -232,7 +232,7 @@ class DenoiserPlan:
             wino = pc.wino() if algo in (1, 2) else None
         if wino is not None:
             tn, wpk = wino
-            kc = 8 if tn == 64 else 4
+            kc = 8
             d.algo = 1
         else:
             tn, kc, wpk = pc.config(N, d.Ho, d.Wo)

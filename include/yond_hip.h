@@ -110,7 +110,10 @@ typedef struct YondConvDesc {
     int algo;             /* 0 direct implicit GEMM, fp32 MFMA; 1 Winograd F(2x2,3x3), fp32 MFMA (3x3 stride 1 only; wpk from
                              yond_pack_conv_wino_weight_f32, tn = 64, see yond_conv_wino_supported); 2 direct implicit GEMM
                              on the fp16 MFMA (operands rounded to half at the matrix core, fp32 accumulate, fp32 tensors:
-                             BASELINE cfg 5; same packed weights as algo 0) */
+                             BASELINE cfg 5; same packed weights as algo 0); 3 direct implicit GEMM on the fp16 MFMA with
+                             fp32-accurate SPLIT operands (a = h + l 2^-11, three fp16 products per fp32 product, fp32
+                             accumulate; 3x3 only, wpk from yond_pack_conv_split_weight_f32 with parts = 2, tn from
+                             yond_conv_split_supported); 4 the same kernel with h only = plain fp16 MFMA (parts = 1) */
 } YondConvDesc;
 
 /* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.
@@ -128,6 +131,15 @@ int yond_conv2d_f32(const YondConvDesc* desc, void* stream);
  * Weights: w OIHW [cout][cin][3][3] -> dst, 16*cout*cin floats (U = G g G^T in float64, rounded once). */
 int yond_conv_wino_supported(int cin, int cout);
 int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, float* dst);
+
+/* Split-operand fp16-MFMA form of the 3x3 convolutions (same descriptor, algo = 3 or 4; archs/modules.py:117-125,
+ * 163-233 are the layers it serves).  Each fp32 operand is split when it is staged into LDS: h = fp16(a),
+ * l = fp16((a - h) * 2^11); a*w = h_a h_w + 2^-11 (h_a l_w + l_a h_w) on v_mfma_f32_32x32x16_f16 with fp32
+ * accumulation -- 22-23 significant bits per operand, error vs a float64 convolution no larger than the fp32 kernels'.
+ * Precondition: |activations|, |weights| < 65504.  yond_conv_split_supported: channel-tile width (64, 32) or 0.
+ * Weights: w OIHW [cout][cin][3][3] -> dst, cout*cin*9*parts/2 floats (packed halves). */
+int yond_conv_split_supported(int ksize, int stride, int cin, int cout);
+int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst);
 
 /* First layer: 3x3, Cin=4 -> Cout=32k, input NHWC4, optional division by the per-image maximum
  * (data_normalize, archs/Unet.py:427-431) and LeakyReLU(slope).  wpk from yond_pack_conv_in_weight_f32. */

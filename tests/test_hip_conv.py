@@ -104,6 +104,80 @@ def test_conv3x3_winograd_fused_two_source():
     assert report("winograd conv3x3 fused two-source", got, z) < 2e-5
 
 
+@pytest.mark.parametrize("C,Co,N,H,W", [(64, 64, 1, 8, 32), (64, 64, 2, 16, 64), (32, 64, 1, 9, 33), (128, 128, 1, 24, 40),
+                                        (256, 64, 1, 94, 126), (32, 32, 2, 24, 72), (64, 32, 1, 17, 40), (32, 32, 1, 5, 7),
+                                        (64, 64, 1, 1, 1), (64, 64, 1, 2, 3), (128, 64, 2, 4, 4),
+                                        (32, 32, 1, 200, 352), (64, 64, 1, 136, 288)])      # > 256 tiles: several tiles per workgroup
+def test_conv3x3_split_plain(C, Co, N, H, W):
+    """Split-operand fp16-MFMA kernel (algo 3: a = h + l 2^-11, three fp16 products per fp32 product, fp32 accumulate)
+    against the float64 convolution: the SAME tolerance as the fp32 kernels."""
+    g = torch.Generator().manual_seed(C + H + 3)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(Co, generator=g)
+    got = nchw(run_conv(w, b, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, algo='split'))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert report(f"split conv3x3 C{C}->{Co} {N}x{H}x{W}", got, ref) < 2e-5
+
+
+def test_conv3x3_split_accuracy_beside_fp32_kernels():
+    """Error against float64 of the three 3x3 kernels on the same data, at unit scale and at magnitudes where the
+    fp16 halves are subnormal (1e-6) or large (1e3): the split kernel must be no worse than 2x the fp32 direct
+    kernel's error or no worse than the fp32 Winograd kernel's (whichever is larger); where whole operands lie below
+    fp16's normal range the documented absolute floor applies instead."""
+    g = torch.Generator().manual_seed(11)
+    N, C, H, W = 1, 128, 32, 64
+    x0 = torch.randn(N, C, H, W, generator=g)
+    w0 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    for sx, sw in ((1.0, 1.0), (1e-6, 1.0), (1e3, 1.0), (1.0, 1e-4), (3e-5, 30.0)):
+        x, w = x0 * sx, w0 * sw
+        ref = F.conv2d(x.double(), w.double(), padding=1)
+        scale = ref.abs().max().item()
+        err = {}
+        for name, algo in (('direct', 0), ('winograd', 2), ('split', 'split')):
+            got = nchw(run_conv(w, None, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, algo=algo)).double()
+            err[name] = ((got - ref).abs().max().item() / scale, ((got - ref) ** 2).mean().sqrt().item() / scale)
+        print(f"[accuracy] x*{sx:g} w*{sw:g}: max / rms error relative to max|ref|: " +
+              ", ".join(f"{k} {v[0]:.2e} / {v[1]:.2e}" for k, v in err.items()))
+        # an operand below fp16's normal range (|a| < 6.1e-5) keeps an ABSOLUTE error of 2^-36 instead of a relative one:
+        # per output that is 2^-36 * sqrt(9 C) * rms(other operand), x6 for the maximum over the tensor
+        w_rms = sw / (3 * C ** 0.5)
+        floor = 2.0 ** -36 * 6 * (9 * C) ** 0.5 * ((w_rms if sx < 1e-3 else 0.0) + (sx if w_rms < 1e-3 else 0.0)) / scale
+        assert err['split'][0] <= max(2.0 * err['direct'][0], err['winograd'][0], floor), (err, floor)
+        assert err['split'][1] <= max(2.0 * err['direct'][1], err['winograd'][1], floor), (err, floor)
+
+
+def test_conv3x3_split_fused_two_source():
+    g = torch.Generator().manual_seed(13)
+    N, C, H, W = 2, 64, 20, 48
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    es, et = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
+    res = torch.randn(N, C, H, W, generator=g)
+    got = nchw(run_conv(w, None, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, escale=es.to(DEV), eshift=et.to(DEV), ebatch=1,
+                        res=nhwc(res).to(DEV), pre_act=1, post_act=2, slope=0.3, algo='split'))
+    z = F.conv2d(F.silu(x.double()), w.double(), padding=1)
+    z = F.leaky_relu(z * es.double()[:, :, None, None] + et.double()[:, :, None, None], 0.3) + res.double()
+    assert report("split conv3x3 fused", got, z) < 2e-5
+    a, b2 = torch.randn(1, 32, 16, 32, generator=g), torch.randn(1, 32, 16, 32, generator=g)
+    w2 = torch.randn(32, 64, 3, 3, generator=g) / (3 * 64 ** 0.5)
+    b = torch.randn(32, generator=g)
+    got = nchw(run_conv(w2, b, 3, 1, [32, 32], [nhwc(a).to(DEV), nhwc(b2).to(DEV)], 1, 16, 32, post_act=2, slope=0.2, algo='split'))
+    ref = F.leaky_relu(F.conv2d(torch.cat([a, b2], 1).double(), w2.double(), b.double(), padding=1), 0.2)
+    assert report("split conv3x3 two-source", got, ref) < 2e-5
+
+
+def test_conv3x3_half_staged_path():
+    """algo 4: the same kernel with the h halves only = plain fp16 MFMA (cfg 5), fp16-level tolerance."""
+    g = torch.Generator().manual_seed(17)
+    N, C, H, W = 1, 64, 24, 40
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    got = nchw(run_conv(w, None, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, algo='half'))
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    assert report("half-staged conv3x3", got, ref) < 5e-3
+
+
 @pytest.mark.parametrize("ks,st,C,Co", [(3, 1, 64, 64), (3, 1, 32, 32), (3, 2, 32, 64), (1, 1, 64, 32)])
 def test_conv_fp16_mfma_path(ks, st, C, Co):
     """algo 'fp16' (descriptor algo 2, BASELINE cfg 5): operands rounded to half at the matrix core, fp32 accumulate.

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--H", type=int, default=1504)
     ap.add_argument("--W", type=int, default=2016)
+    ap.add_argument("--algo", default="", help="'' (engine default), 0, 1, 2, split, half")
     a = ap.parse_args()
     plan = DenoiserPlan.__new__(DenoiserPlan)
     plan.lib, plan.dev, plan.prof = L.load(), torch.device(DEV), None
@@ -55,6 +56,8 @@ def main():
         if opts.get('res'):
             kw.update(res=torch.randn_like(dst))
         kw.update({k: v for k, v in opts.items() if k in ('pre_act', 'post_act')})
+        if a.algo:
+            kw['algo'] = int(a.algo) if a.algo.isdigit() else a.algo
         run = lambda: plan._conv(pc, xs[0], xs[1] if len(xs) > 1 else None, 1, h, w, dst, **kw)
         run()
         torch.cuda.synchronize()

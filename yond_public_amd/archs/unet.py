@@ -61,11 +61,14 @@ class _HipDenoiser(nn.Module):
         self.nframes = args['nframes'] if 'nframes' in args else 1
         self.cf = 0
         self.res = args['res']
-        # 'fp32' (default, the reference's precision) or 'fp16': convolutions on the fp16 MFMA path with fp32 accumulation and
-        # fp32 tensors (BASELINE cfg 5); not a reference key -- absent means fp32
+        # not a reference key -- absent means 'fp32':
+        #   'fp32'      fp32 results (the reference's precision): 3x3 convolutions as fp32-accurate split-operand products on
+        #               the fp16 matrix cores where that kernel applies (csrc/conv_split.hip), fp32 MFMA elsewhere
+        #   'fp32-mfma' every convolution on the fp32-input MFMA (Winograd / direct kernels)
+        #   'fp16'      BASELINE cfg 5: operands rounded to half at the matrix core, fp32 accumulation, fp32 tensors
         self.precision = args.get('precision', 'fp32')
-        if self.precision not in ('fp32', 'fp16'):
-            raise ValueError(f"precision must be 'fp32' or 'fp16', got {self.precision!r}")
+        if self.precision not in ('fp32', 'fp32-mfma', 'fp16'):
+            raise ValueError(f"precision must be 'fp32', 'fp32-mfma' or 'fp16', got {self.precision!r}")
         self.norm = args['norm'] if 'norm' in args else False
         if args['in_nc'] * self.nframes != 4 or args['out_nc'] != 4:
             raise L.YondHipError("the HIP denoisers take packed Bayer input/output (in_nc*nframes == out_nc == 4)")

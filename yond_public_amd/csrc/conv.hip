@@ -528,6 +528,7 @@ extern "C" int yond_pack_conv_weight_f32(const float* w, int cout, int cin, int 
 }
 
 int yond_conv_wino_dispatch(const YondConvDesc& d, hipStream_t st);      // conv_wino.hip
+int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st);     // conv_split.hip
 
 extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     if (!dp) return YOND_EINVAL;
@@ -538,6 +539,7 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     if ((long long)d.N * d.H * d.W > 0x7fffffffLL) return YOND_EUNSUPPORTED;    // 32-bit pixel offsets
     if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;
     if (d.algo == 1) return yond_conv_wino_dispatch(d, st);
+    if (d.algo == 3 || d.algo == 4) return yond_conv_split_dispatch(d, st);
     if (d.algo != 0 && d.algo != 2) return YOND_EINVAL;
     if (d.tn != 32 && d.tn != 64) return YOND_EINVAL;
     int tn, kc;

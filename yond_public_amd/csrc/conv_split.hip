@@ -1,0 +1,522 @@
+// K2s: 3x3 convolutions on the fp16 matrix cores with fp32-accurate SPLIT operands (descriptor algo 3).
+//
+// Why: on gfx950 the fp32-input MFMA runs at 1/16 of the fp16 rate and blocks the vector ALU while it runs
+// ("fp32 MFMA and the vector ALU do not overlap").  Every fp32 operand a is therefore split ONCE, when it
+// is staged into LDS, into two halves
+//        h = fp16(a)                 (round to nearest: 11 significant bits)
+//        l = fp16((a - h) * 2^11)    (a - h is exact in fp32; the scale keeps l in fp16's normal range)
+// so that a = h + l * 2^-11 to 22-23 significant bits, and a product a*w is evaluated as
+//        h_a*h_w  +  2^-11 * (h_a*l_w + l_a*h_w)          (the l_a*l_w term, 2^-22 relative, is dropped)
+// by THREE v_mfma_f32_32x32x16_f16 -- fp16 x fp16 products are exact in the fp32 accumulator, and the two cross terms
+// go to accumulators of their own that are folded in with one FMA in the epilogue.  Measured against a float64
+// convolution (tests/test_hip_conv.py) the result is as close as the fp32 direct kernel and closer than the fp32
+// Winograd kernel; 3/16 of the matrix time of the fp32 form, and the vector work now hides under the MFMAs.
+// Range: |a| must stay below 65504 (fp16 max) -- activations and weights of the denoisers are O(1).
+// With PARTS = 1 (descriptor algo 4) only the h halves are staged and multiplied: the plain fp16 MFMA path of
+// BASELINE cfg 5 (fp32 tensors in HBM, fp32 accumulate), without the per-fragment conversions of conv.hip's F16 form.
+//
+// Structure: persistent 512-thread workgroups (two waves per SIMD), tile = TH x 32 output pixels x TN output
+// channels, walked in 16-channel steps with ONE barrier per step.  LDS (double-buffered):
+//   input   planes [channel half 0..1][part h, l][IH x TWP pixels] x 16 bytes (8 halves): the 32 lanes of a fragment
+//           read consecutive pixels = consecutive 16-byte units (conflict-free, no padding); stride 2 keeps even and
+//           odd columns in separate halves of a row so a tap still reads consecutive pixels
+//   weights [tap][channel half][part][TN] x 16 bytes, produced in this order by yond_pack_conv_split_weight_f32 and
+//           copied by LDS-DMA.
+// MFMA operand map (cdna_hip_programming.md section 3, 32x32x16): lane l (r = l&31, hh = l>>5) supplies
+// A[row r][k = 8 hh + j] and B[k = 8 hh + j][col r], j = 0..7 -- one ds_read_b128 each.  A = weights (row = output
+// channel), B = pixels, so a lane of D owns ONE pixel and channels (reg&3) + 8 (reg>>2) + 4 hh: 16-byte stores.
+// Pipeline per step s (as in conv_wino.hip): the staged registers of step s+1 (loaded two steps ago) are split and
+// written to the other input buffer, refilled with the global loads of step s+3; the weight slice of s+1 arrives by
+// LDS-DMA; the two waves of a SIMD take the MFMA half and the staging half in opposite order.
+#include "common.h"
+#include <cstdlib>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#ifndef SPLIT_DBG
+#define SPLIT_DBG 0      // 1: timestamps of workgroup 0, waves 0 and 4 -> g_split_dbg (read with yond_split_debug_read)
+#endif
+#if SPLIT_DBG
+__device__ unsigned long long g_split_dbg[2][64][8];
+extern "C" int yond_split_debug_read(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_split_dbg), sizeof(g_split_dbg));
+}
+#define SDBG(slot)                                                                                  \
+    do {                                                                                            \
+        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && dbg_step < 64)              \
+            g_split_dbg[wave >> 2][dbg_step][slot] = __builtin_readcyclecounter();                  \
+    } while (0)
+#else
+#define SDBG(slot) do {} while (0)
+#endif
+#ifndef SPLIT_ABL
+#define SPLIT_ABL 0          // timing-only ablations: 1 no global loads, 2 no weight DMA, 4 no epilogue, 8 no staging writes, 16 no MFMA
+#endif
+
+template <int STRIDE, int TH, int TN, int MW, int PARTS>
+struct SplitCfg {
+    static constexpr int NT = 512;
+    static constexpr int KC = 16;
+    static constexpr int TAPS = 9;
+    static constexpr int IH = (TH - 1) * STRIDE + 3;
+    static constexpr int IW = 31 * STRIDE + 3;
+    static constexpr int HALF = (IW + 1) / 2;
+    static constexpr int TWP = STRIDE == 2 ? 2 * HALF : IW;
+    static constexpr int PLANE = IH * TWP * 4 + 4;                  // floats; the last 16 bytes take the staging items past the tile
+    static constexpr int IN_FLOATS = 2 * PARTS * PLANE;
+    static constexpr int W_FLOATS = TAPS * 2 * PARTS * TN * 4;
+    static constexpr int RG = TH / MW;                              // row groups of waves
+    static constexpr int NCW = 8 / RG;                              // channel groups of waves
+    static constexpr int NW = TN / 32 / NCW;                        // 32-channel blocks per wave
+    static constexpr int NITEM = IH * IW * 4;                       // 16-byte (4-channel) staging items per step
+    static constexpr int NIN = (NITEM + NT - 1) / NT;
+    static constexpr int NWV = W_FLOATS / 4;
+    static constexpr int NWT = (NWV + NT - 1) / NT;
+    static constexpr int NWT_MIN = NWV / NT;                        // LDS-DMA instructions every wave issues per step
+    static constexpr int NOPS = NWT + NIN;                          // vector-memory instructions per thread and step
+    static constexpr int SMEM_BYTES = (2 * IN_FLOATS + 3 * W_FLOATS) * 4;
+    static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
+};
+
+__device__ __forceinline__ float split_silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+// ... wait for all but the N most recent vector-memory operations and for this wave's LDS traffic, then the barrier
+template <int N>
+__device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
+
+template <int STRIDE, int TH, int TN, int MW, int PARTS, bool PRE>
+__global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS>;
+    constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int rg = wave % C::RG, cg = wave / C::RG;
+
+    const int nct = d.Cout / TN;
+    const bool computes = d.Cout > 0;                        // always true; opaque to the compiler (keeps the MFMA stretch a block of its own)
+    const int ntx = (d.Wo + 31) / 32, nty = (d.Ho + TH - 1) / TH;
+    const int tiles_per_img = nct * ntx * nty;
+    const int total = tiles_per_img * d.N;
+    const int G = gridDim.x;
+    const int lslot = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;   // XCD-contiguous runs
+    const int Cin = d.C0 + d.C1;
+    const int nchunk = Cin / C::KC;
+    const int my_sl = tid & 3;                               // the thread's 4-channel slot of a pixel (512 % 4 == 0)
+    const int my_plane = (my_sl >> 1) * PARTS * C::PLANE + (my_sl & 1) * 2;
+
+    int in_lds[C::NIN];
+#pragma unroll
+    for (int k = 0; k < C::NIN; ++k) {
+        const int it = tid + k * C::NT;
+        const int pix = it / 4;
+        const int py = pix / C::IW, px = pix % C::IW;
+        const int lp = (STRIDE == 2) ? py * C::TWP + (px & 1) * C::HALF + (px >> 1) : py * C::TWP + px;
+        in_lds[k] = my_plane + (it < C::NITEM ? lp : C::IH * C::TWP) * 4;
+    }
+
+    struct Tile {
+        int ct, n, ox0, oy0;
+        int goff[C::NIN];
+    };
+    auto decode = [&](int t, Tile& T) {
+        const int n = t / tiles_per_img;
+        int b = t - n * tiles_per_img;
+        T.n = n;
+        T.ct = b % nct;
+        b /= nct;
+        const int tx = b % ntx, ty = b / ntx;
+        T.ox0 = tx * 32;
+        T.oy0 = ty * TH;
+#pragma unroll
+        for (int k = 0; k < C::NIN; ++k) {
+            const int it = tid + k * C::NT;
+            const int pix = it / 4;
+            const int py = pix / C::IW, px = pix % C::IW;
+            const int gy = T.oy0 * STRIDE - 1 + py, gx = T.ox0 * STRIDE - 1 + px;
+            T.goff[k] = (it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) ? ((n * d.H + gy) * d.W + gx) : -1;
+        }
+    };
+
+    // Three register sets: set s % 3 receives the loads of input(s+3) during step s and is split / written out as
+    // input(s+3) during step s+2, so a load has two steps to arrive.
+    f32x4 vin[3][C::NIN];
+    if (SPLIT_ABL & 1) {
+#pragma unroll
+        for (int k = 0; k < C::NIN; ++k) { const f32x4 z = {0.5f, 0.25f, -0.5f, 0.125f}; vin[0][k] = z; vin[1][k] = z; vin[2][k] = z; }
+    }
+    unsigned vin_ok[3] = {0, 0, 0};
+    // one 16-byte load of a set (item k); the source of the chunk is selected once per step (LoadSrc)
+    struct LoadSrc { const float* src; int Cs, cc; };
+    auto load_src = [&](int ch) {
+        LoadSrc L;
+        const int c0 = ch * C::KC;
+        if (c0 < d.C0) { L.src = d.src0; L.Cs = d.C0; L.cc = c0; }
+        else { L.src = d.src1; L.Cs = d.C1; L.cc = c0 - d.C0; }
+        return L;
+    };
+    auto issue_load = [&](auto pc, auto kc, const Tile& T, const LoadSrc& L) {
+        constexpr int P = decltype(pc)::value, k = decltype(kc)::value;
+        const bool ok = T.goff[k] >= 0;                        // outside the image: read pixel 0, zeroed at the LDS write
+        if (!(SPLIT_ABL & 1)) vin[P][k] = *(const f32x4*)(L.src + (size_t)(ok ? T.goff[k] : 0) * L.Cs + L.cc + my_sl * 4);
+        if (k == 0) vin_ok[P] = 0;
+        vin_ok[P] |= (ok ? 1u : 0u) << k;
+    };
+    // weight slice global -> LDS by LDS-DMA as inline assembly (a builtin DMA makes the compiler order every later LDS
+    // access behind s_waitcnt vmcnt(0)); one instruction (k) moves 512 x 16 bytes; completion is awaited by a barrier
+    auto issue_dma = [&](auto kc, const float* wsrc, float* wbuf) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)wbuf;
+        const int it = tid + k * C::NT;
+        const int it_wave = __builtin_amdgcn_readfirstlane(it - lane);
+        const unsigned lds_wave = lds0 + (unsigned)it_wave * 16u;
+        const unsigned voff = (unsigned)it * 16u;
+        if (!(SPLIT_ABL & 2) && (C::NWV % C::NT == 0 || it_wave < C::NWV))
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(wsrc) : "memory");
+    };
+    auto weight_src = [&](int ct, int ch) {                  // wave-uniform: handed to the DMA in scalar registers
+        const unsigned long long a = (unsigned long long)(uintptr_t)(d.wpk + ((size_t)ct * nchunk + ch) * C::W_FLOATS);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (const float*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    // Staging of one register set into an input image, as NE = 4 NIN element tasks so that the step can spread them
+    // between its MFMAs: task e = (item k, element j) applies SiLU / zero padding in place; the item's last task splits
+    // the four values into the h and l halves and writes them (two ds_write_b64).
+    constexpr int NE = 4 * C::NIN;
+    auto stage_task = [&](auto pc, auto ec, float* ob) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int e = decltype(ec)::value, k = e / 4, j = e % 4;
+        float x = vin[P][k][j];
+        if (PRE) x = split_silu(x);
+        vin[P][k][j] = ((vin_ok[P] >> k) & 1u) ? x : 0.0f;                              // conv zero padding
+        if constexpr (j == 3) {
+            const f32x4 v = vin[P][k];
+            const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            if (!(SPLIT_ABL & 8)) *(f16x4*)(ob + in_lds[k]) = h;
+            if constexpr (PARTS == 2) {
+                const f16x4 l = {(_Float16)((v[0] - (float)h[0]) * 2048.0f), (_Float16)((v[1] - (float)h[1]) * 2048.0f),
+                                 (_Float16)((v[2] - (float)h[2]) * 2048.0f), (_Float16)((v[3] - (float)h[3]) * 2048.0f)};
+                if (!(SPLIT_ABL & 8)) *(f16x4*)(ob + in_lds[k] + C::PLANE) = l;
+            }
+        }
+    };
+    auto write_in = [&](auto pc, float* ob) { static_for<0, NE>([&](auto ec) { stage_task(pc, ec, ob); }); };
+
+    f32x16 acc[NACC][MW][C::NW];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int nn = 0; nn < C::NW; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][m][nn][r] = 0.0f;
+    };
+
+    // ---- the multiplications of one step ----
+    // Stride 1: the wave's MW output rows read input rows r = 0 .. MW+1; fragment X(r, dx) serves every (m, dy) with
+    // m + dy = r, so it is read ONCE per step (3 (MW+2) pixel fragments per part instead of 9 MW): the kernel is
+    // LDS-bandwidth bound otherwise (1 KiB of fragments per 32-cycle MFMA and wave).  Loop: dx outermost, the three
+    // weight fragments (dy) of a column held in registers and fetched one column ahead, pixel fragments two ahead.
+    // MFMA order inside a group: h_w l_x, then h_w h_x, then l_w h_x -- the two that share an accumulator are never
+    // back to back (the dependent-issue latency of v_mfma_f32_32x32x16_f16 exceeds its 32 cycles).
+    const int x_off = (lh * PARTS) * C::PLANE + ((rg * MW * STRIDE) * C::TWP + li) * 4;
+    const int w_off = ((lh * PARTS) * TN + (cg * C::NW) * 32 + li) * 4;
+    auto mfma_stage = [&](auto pc, auto fc, const float* buf, const float* wbuf, float* ob, const float* wsrc, float* wnext, const Tile& lt,
+                          const LoadSrc& ls) {
+        typedef const __attribute__((address_space(3))) f16x8* lds_h8;
+        const __attribute__((address_space(3))) float* xb = (const __attribute__((address_space(3))) float*)(buf + x_off);
+        const __attribute__((address_space(3))) float* wb = (const __attribute__((address_space(3))) float*)(wbuf + w_off);
+        constexpr int R = MW + 2, NQ = 3 * R, XD = 3;
+        f16x8 xr[XD][PARTS], wt[2][3][C::NW][PARTS];
+        auto loadX = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int dx = q / R, r = q % R;
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p) xr[q % XD][p] = *(lds_h8)(xb + p * C::PLANE + (r * C::TWP + dx) * 4);
+        };
+        auto loadW = [&](auto dc) {
+            constexpr int dx = decltype(dc)::value;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int nn = 0; nn < C::NW; ++nn)
+#pragma unroll
+                    for (int p = 0; p < PARTS; ++p)
+                        wt[dx & 1][dy][nn][p] = *(lds_h8)(wb + (((dy * 3 + dx) * 2 * PARTS + p) * TN + nn * 32) * 4);
+        };
+        loadW(IntC<0>{});
+        loadX(IntC<0>{});
+        loadX(IntC<1>{});
+        static_for<0, NQ>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int dx = q / R, r = q % R;
+            constexpr bool wpre = (r == (R >= 4 ? R - 3 : 0) && dx < 2);
+            if constexpr (q + 2 < NQ) loadX(IntC<q + 2>{});
+            if constexpr (wpre) loadW(IntC<dx + 1>{});
+            constexpr int nmf = (PARTS == 2 ? 3 : 1) * C::NW * ((r < MW ? r : MW - 1) - (r - 2 > 0 ? r - 2 : 0) + 1);
+            if (!(SPLIT_ABL & 16)) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {                  // 0: h_w l_x   1: h_w h_x   2: l_w h_x
+                    if (PARTS == 1 && a != 1) continue;
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) {
+                        const int dy = r - m;
+                        if (dy < 0 || dy > 2) continue;
+#pragma unroll
+                        for (int nn = 0; nn < C::NW; ++nn)
+                            acc[a == 1 ? 0 : 1][m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                wt[dx & 1][dy][nn][a == 2 ? PARTS - 1 : 0], xr[q % XD][a == 0 ? PARTS - 1 : 0], acc[a == 1 ? 0 : 1][m][nn], 0, 0, 0);   // D = W . X^T
+                    }
+                }
+            }
+            // this group's share of the step's vector-memory instructions: the LDS-DMA of weights(s+2), then the loads
+            // of input(s+3) -- spread over the step so that no wave ever queues behind the CU's 64 B/clk memory pipe
+            constexpr int o_lo = (q * C::NOPS + NQ - 1) / NQ, o_hi = ((q + 1) * C::NOPS + NQ - 1) / NQ;
+            static_for<o_lo, o_hi>([&](auto oc) {
+                constexpr int o = decltype(oc)::value;
+                if constexpr (o < C::NWT) issue_dma(IntC<o>{}, wsrc, wnext);
+                else issue_load(fc, IntC<o - C::NWT>{}, lt, ls);
+            });
+            // this group's share of the staging work (element tasks e_lo .. e_hi of the set loaded during the previous step)
+            constexpr int e_lo = q * NE / NQ, e_hi = (q + 1) * NE / NQ;
+            static_for<e_lo, e_hi>([&](auto ec) { stage_task(pc, ec, ob); });
+            constexpr int nfin = (e_hi + 0) / 4 - (e_lo + 0) / 4;                     // items completed in this group
+            // Issue order of the group: its LDS reads first (they are two groups / one column ahead of their use), then
+            // each MFMA followed by a few of the vector instructions, then the LDS writes of a completed item.
+            constexpr int nrd = (q + 2 < NQ ? PARTS : 0) + (wpre ? 3 * C::NW * PARTS : 0);
+            if constexpr (nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
+            constexpr int nvalu = (e_hi - e_lo) * (PRE ? 7 : 2) + nfin * (PARTS == 2 ? 22 : 6);
+            constexpr int vpm = (nvalu + nmf - 1) / nmf;
+#pragma unroll
+            for (int i = 0; i < nmf; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (vpm > 0) __builtin_amdgcn_sched_group_barrier(0x002, vpm, 0);
+            }
+            if constexpr (nfin > 0) __builtin_amdgcn_sched_group_barrier(0x200, nfin * PARTS, 0);
+        });
+    };
+
+    // ---- output side: lane = pixel li of row rg*MW + m; registers = channels (r&3) + 8 (r>>2) + 4 lh of a 32-block ----
+    const float slope_eff = d.post_act == 2 ? d.slope : 1.0f;
+    auto epilogue = [&](const Tile& T) {
+        const int ox = T.ox0 + li;
+        const bool col_ok = ox < d.Wo;
+#pragma unroll
+        for (int nn = 0; nn < C::NW; ++nn) {
+            const int cbase = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * lh;
+            const int eoff = (d.ebatch ? T.n * d.Cout : 0) + cbase;
+            f32x4 es[4], et[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                es[g] = d.escale ? *(const f32x4*)(d.escale + eoff + 8 * g) : one;
+                et[g] = d.eshift ? *(const f32x4*)(d.eshift + eoff + 8 * g) : zero4;
+            }
+            f32x4 rr[MW][4];
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const int oy = T.oy0 + rg * MW + m;
+                const bool ok = col_ok && oy < d.Ho;
+                const long long off = ok ? ((long long)(T.n * d.Ho + oy) * d.Wo + ox) * d.Cout + cbase : 0;   // masked lanes read element 0..
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                    rr[m][g] = d.res ? *(const f32x4*)(d.res + off + (ok ? 8 * g : 0)) : z;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const int oy = T.oy0 + rg * MW + m;
+                const bool ok = col_ok && oy < d.Ho;
+                float* op = d.dst + ((long long)(T.n * d.Ho + oy) * d.Wo + ox) * d.Cout + cbase;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[0][m][nn][4 * g + e];
+                        if constexpr (PARTS == 2) x = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, x);
+                        x = fmaf(x, es[g][e], et[g][e]);
+                        x = x > 0.0f ? x : x * slope_eff;
+                        v[e] = x + rr[m][g][e];
+                    }
+                    if (ok) *(f32x4*)(op + 8 * g) = v;
+                }
+            }
+        }
+    };
+
+    // ---- the step pipeline: ONE barrier per step ----
+    struct Cur { int tile, ch; };
+    auto adv = [&](Cur c) {
+        Cur n;
+        const bool last = c.ch + 1 == nchunk;
+        n.tile = last ? c.tile + G : c.tile;
+        n.ch = last ? 0 : c.ch + 1;
+        return n;
+    };
+    if (lslot >= total) return;
+    Cur cs = {lslot, 0};                       // step being computed
+    Tile cur;                                   // its tile (epilogue)
+    Tile lt;                                    // tile of the load cursor
+    int lt_tile = -1;
+    decode(cs.tile, cur);
+    zero_acc();
+    float* ibuf = smem;                         // input(s)
+    float* obuf = smem + C::IN_FLOATS;          // receives input(s+1)
+    float* w0 = smem + 2 * C::IN_FLOATS;        // weights(s)
+    float* w1 = w0 + C::W_FLOATS;               // weights(s+1)
+    float* w2 = w1 + C::W_FLOATS;               // receives weights(s+2)
+    auto ct_of = [&](Cur c, int fallback) { return c.tile < total ? (c.tile % tiles_per_img) % nct : fallback; };
+    auto tile_for = [&](Cur c) {                // steps past the end re-read the last decoded tile (harmless)
+        if (c.tile < total && c.tile != lt_tile) { decode(c.tile, lt); lt_tile = c.tile; }
+    };
+    auto load_all = [&](auto pc, Cur c) {
+        tile_for(c);
+        const LoadSrc L = load_src(c.ch);
+        static_for<0, C::NIN>([&](auto kc) { issue_load(pc, kc, lt, L); });
+    };
+    auto dma_all = [&](Cur c, float* wb) {
+        const float* ws = weight_src(ct_of(c, cur.ct), c.ch);
+        static_for<0, C::NWT>([&](auto kc) { issue_dma(kc, ws, wb); });
+    };
+    // prologue, in the steady-state order of the memory operations (DMA of a step before its loads):
+    //   loads input(0) | DMA weights(0), loads input(1) | stage input(0) | DMA weights(1), loads input(2)
+    const Cur c1 = adv(cs), c2 = adv(c1);
+    load_all(IntC<0>{}, cs);
+    dma_all(cs, w0);
+    load_all(IntC<1>{}, c1);
+    write_in(IntC<0>{}, ibuf);
+    dma_all(c1, w1);
+    load_all(IntC<2>{}, c2);
+    Cur cl = adv(c2);                           // loads of step s: input(s+3)
+    Cur cw = c2;                                // DMA of step s: weights(s+2)
+    split_barrier_keep_loads<2 * C::NIN + C::NWT_MIN>();
+    int dbg_step = 0;
+    (void)dbg_step;
+    // Step s (all waves alike, S = s % 3).  In program order: the MFMAs of step s with, between them, (a) the LDS-DMA
+    // of weights(s+2) and the loads of input(s+3) into register set S, (b) the staging of set (s+1) % 3 = input(s+1),
+    // loaded two steps ago; then ONE barrier that awaits weights(s+1) only: this step's and the previous step's loads
+    // and this step's DMA stay in flight (vmcnt counts in order: DMA(s-1), loads(s-1), DMA(s), loads(s)).
+    auto step = [&](auto sc) -> bool {
+        constexpr int S = decltype(sc)::value;
+        SDBG(0);
+        const bool last_ch = (cs.ch + 1 == nchunk);
+        const Cur cn = adv(cs);
+        tile_for(cl);
+        const LoadSrc ls = load_src(cl.ch);
+        const float* wsrc = weight_src(ct_of(cw, cur.ct), cw.ch);
+        // input(s+1) was loaded two steps ago; one wait for the whole set here (the compiler does not see the DMA
+        // instructions in its vmcnt bookkeeping: a wait placed later would also wait for this step's DMA)
+#pragma unroll
+        for (int k = 0; k < C::NIN; ++k) {
+            f32x4 t = vin[(S + 1) % 3][k];
+            asm volatile("" : "+v"(t));
+            vin[(S + 1) % 3][k] = t;
+        }
+        SDBG(1);
+        if (computes) mfma_stage(IntC<(S + 1) % 3>{}, IntC<S>{}, ibuf, w0, obuf, wsrc, w2, lt, ls);
+        SDBG(2);
+        SDBG(3);
+        split_barrier_keep_loads<2 * C::NIN + C::NWT_MIN>();     // weights(s+1) have landed, input(s+1) is written
+        SDBG(4);
+        if (last_ch) {
+            if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) epilogue(cur);
+            zero_acc();
+            if (cn.tile < total) {
+                const int n = cn.tile / tiles_per_img;
+                int bq = cn.tile - n * tiles_per_img;
+                cur.n = n;
+                cur.ct = bq % nct;
+                bq /= nct;
+                cur.ox0 = (bq % ntx) * 32;
+                cur.oy0 = (bq / ntx) * TH;
+            }
+        }
+        SDBG(5);
+        ++dbg_step;
+        if (cn.tile >= total) return false;
+        cs = cn;
+        cl = adv(cl);
+        cw = adv(cw);
+        float* t = ibuf;
+        ibuf = obuf;
+        obuf = t;
+        t = w0;
+        w0 = w1;
+        w1 = w2;
+        w2 = t;
+        return true;
+    };
+    while (true) {
+        if (!step(IntC<0>{})) break;
+        if (!step(IntC<1>{})) break;
+        if (!step(IntC<2>{})) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead loads / DMA of the steps past the end
+}
+
+template <int STRIDE, int TH, int TN, int MW, int PARTS, bool PRE>
+static int launch_split(const YondConvDesc& d, hipStream_t st) {
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS>;
+    static bool attr_set = false;
+    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, PRE>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long long total = (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
+    if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
+    const int grid = total < 256 ? (int)total : 256;            // one persistent workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::SMEM_BYTES, st, d);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// the channel-tile width the split kernel uses for a layer (0: not supported)
+extern "C" int yond_conv_split_supported(int ksize, int stride, int cin, int cout) {
+    if (ksize != 3 || stride != 1 || cin <= 0 || cout <= 0 || cin % 16 != 0 || cout % 32 != 0) return 0;
+    return cout % 64 == 0 ? 64 : 32;
+}
+
+// OIHW fp32 weights -> the kernel's LDS image order [cout tile][cin chunk of 16][tap][channel half][part][tn][8 halves];
+// parts = 2: h = fp16(w), l = fp16((w - h) * 2^11); parts = 1: h only.  dst: cout*cin*9 * parts/2 floats.
+extern "C" int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst) {
+    if (!w || !dst || ksize != 3 || (tn != 32 && tn != 64) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
+    _Float16* o = (_Float16*)dst;
+    const int taps = 9;
+    for (int ct = 0; ct < cout / tn; ++ct)
+        for (int ch = 0; ch < cin / 16; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int p = 0; p < parts; ++p)
+                        for (int j = 0; j < tn; ++j)
+                            for (int e = 0; e < 8; ++e) {
+                                const int co = ct * tn + j, ci = ch * 16 + hh * 8 + e;
+                                const float v = w[((size_t)co * cin + ci) * taps + tap];
+                                const _Float16 h = (_Float16)v;
+                                *o++ = p == 0 ? h : (_Float16)((v - (float)h) * 2048.0f);
+                            }
+    return YOND_OK;
+}
+
+int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
+    const int parts = d.algo == 3 ? 2 : 1;
+    const int tn = yond_conv_split_supported(d.ksize, d.stride, d.C0 + d.C1, d.Cout);
+    if (!tn || d.shuffle || d.C0 % 16 != 0 || d.C1 % 16 != 0) return YOND_EUNSUPPORTED;
+    if (d.tn != tn) return YOND_EINVAL;                         // the layout the weights were packed for
+    if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
+    if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
+    if (tn == 64) {
+        if (parts == 2) return d.pre_act ? launch_split<1, 8, 64, 2, 2, true>(d, st) : launch_split<1, 8, 64, 2, 2, false>(d, st);
+        return d.pre_act ? launch_split<1, 8, 64, 2, 1, true>(d, st) : launch_split<1, 8, 64, 2, 1, false>(d, st);
+    }
+    if (parts == 2) return d.pre_act ? launch_split<1, 16, 32, 2, 2, true>(d, st) : launch_split<1, 16, 32, 2, 2, false>(d, st);
+    return d.pre_act ? launch_split<1, 16, 32, 2, 1, true>(d, st) : launch_split<1, 16, 32, 2, 1, false>(d, st);
+}

@@ -32,7 +32,9 @@ def _np_ptr(a):
 
 # 3x3 stride-1 layers: 1 = Winograd F(2x2,3x3) wherever the kernel supports the shape (measured 1.45-1.5x over the direct
 # kernel at 64..512 channels, 1.15x on the 32-channel level-0 layers), 0 = direct implicit GEMM everywhere
-WINO_DEFAULT = int(os.environ.get('YOND_CONV_WINO', '1'))
+_e = os.environ.get('YOND_CONV_WINO', 'split')
+WINO_DEFAULT = int(_e) if _e.isdigit() else _e          # 'split' (default): fp32-accurate split-operand fp16-MFMA kernel where it
+                                                         # applies, fp32 Winograd elsewhere; 0 direct fp32 MFMA, 1/2 Winograd fp32 MFMA
 
 
 class _PackedConv:
@@ -109,6 +111,22 @@ class _PackedConv:
                     "yond_pack_conv_wino_weight_f32")
             self._packed['wino'] = (tn, torch.from_numpy(packed).to(self._dev))
         return self._packed['wino']
+
+    def split(self, parts=2):
+        """(tn, weights packed for the split-operand fp16-MFMA kernel) or None when the layer does not fit it."""
+        lib = L.load()
+        if self.shuffle:
+            return None
+        tn = int(lib.yond_conv_split_supported(self.ksize, self.stride, self.cinp, self.gemm_n))
+        if not tn:
+            return None
+        key = ('split', parts)
+        if key not in self._packed:
+            packed = np.empty(self._wp.size * parts // 2, np.float32)
+            L.check(lib.yond_pack_conv_split_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn, parts,
+                                                        _np_ptr(packed)), "yond_pack_conv_split_weight_f32")
+            self._packed[key] = (tn, torch.from_numpy(packed).to(self._dev))
+        return self._packed[key]
 
 
 class DenoiserPlan:
@@ -224,13 +242,26 @@ class DenoiserPlan:
         d.pre_act, d.post_act, d.slope = pre_act, post_act, slope
         # `algo` (tests) / plan.conv_algo: 0 direct fp32, 1 Winograd fp32 where it is the faster kernel, 2 Winograd
         # fp32 wherever supported; plan.precision 'fp16' (BASELINE cfg 5): every MFMA convolution on the fp16 matrix path
+        prec = getattr(self, 'precision', 'fp32')
         if algo is None:
             algo = getattr(self, 'conv_algo', WINO_DEFAULT)
-        fp16 = getattr(self, 'precision', 'fp32') == 'fp16' or algo == 'fp16'
-        wino = None
-        if not fp16:
+            if prec == 'fp32-mfma' and algo == 'split':
+                algo = 1
+            if prec == 'fp16' and WINO_DEFAULT == 'split':
+                algo = 'half'                    # 3x3: h halves staged once (conv_split.hip); other layers: algo 2 below
+        fp16 = prec == 'fp16' or algo == 'fp16'
+        wino = split = None
+        if algo in ('split', 'half'):
+            split = pc.split(2 if algo == 'split' else 1)
+            if split is None and not fp16:
+                wino = pc.wino()                     # layers the split kernel does not take
+        elif not fp16:
             wino = pc.wino() if algo in (1, 2) else None
-        if wino is not None:
+        if split is not None:
+            tn, wpk = split
+            kc = 16
+            d.algo = 3 if algo == 'split' else 4
+        elif wino is not None:
             tn, wpk = wino
             kc = 8
             d.algo = 1
@@ -254,6 +285,8 @@ class DenoiserPlan:
         if prof is not None:
             e1.record()
             tag = f"conv_wino_kernel<{tn}>" if d.algo == 1 else f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{tn},{kc}>"
+            if d.algo in (3, 4):
+                tag = f"conv_split_kernel<{pc.stride},{tn},{5 - d.algo}>"
             if d.algo == 2:
                 tag += "/f16"
             prof.append((tag, 2.0 * pc.macs_per_pixel * N * d.Ho * d.Wo, e0, e1))

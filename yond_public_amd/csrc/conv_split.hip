@@ -54,7 +54,7 @@ extern "C" int yond_split_debug_read(unsigned long long* host) {
 #define SPLIT_ABL 0          // timing-only ablations: 1 no global loads, 2 no weight DMA, 4 no epilogue, 8 no staging writes, 16 no MFMA
 #endif
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB>
 struct SplitCfg {
     static constexpr int NT = 512;
     static constexpr int KC = 16;
@@ -75,10 +75,19 @@ struct SplitCfg {
     static constexpr int NWT = (NWV + NT - 1) / NT;
     static constexpr int NWT_MIN = NWV / NT;                        // LDS-DMA instructions every wave issues per step
     static constexpr int NOPS = NWT + NIN;                          // vector-memory instructions per thread and step
-    static constexpr int SMEM_BYTES = (2 * IN_FLOATS + 3 * W_FLOATS) * 4;
+    static constexpr int WAHEAD = NWB - 1;                          // the LDS-DMA of step s fetches weights(s + WAHEAD)
+    static constexpr int KEEP = WAHEAD == 2 ? 2 * NIN + NWT_MIN : NIN;   // memory operations that may stay in flight across a barrier
+    static constexpr int SMEM_BYTES = (2 * IN_FLOATS + NWB * W_FLOATS) * 4;
+    static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
     static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
 };
 
+// output rows m of a wave that read input row r (taps dy = r - m*stride in 0..2)
+constexpr int split_pairs(int mw, int stride, int r) {
+    int n = 0;
+    for (int m = 0; m < mw; ++m) n += (r - m * stride >= 0 && r - m * stride <= 2) ? 1 : 0;
+    return n;
+}
 __device__ __forceinline__ float split_silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
 }
@@ -86,9 +95,9 @@ __device__ __forceinline__ float split_silu(float x) {
 template <int N>
 __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, bool PRE>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS>;
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB>;
     constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -218,8 +227,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
 
     // ---- the multiplications of one step ----
-    // Stride 1: the wave's MW output rows read input rows r = 0 .. MW+1; fragment X(r, dx) serves every (m, dy) with
-    // m + dy = r, so it is read ONCE per step (3 (MW+2) pixel fragments per part instead of 9 MW): the kernel is
+    // The wave's MW output rows read input rows r = 0 .. (MW-1) stride + 2; fragment X(r, dx) serves every (m, dy) with
+    // m stride + dy = r, so it is read ONCE per step (3 (MW+2) pixel fragments per part instead of 9 MW): the kernel is
     // LDS-bandwidth bound otherwise (1 KiB of fragments per 32-cycle MFMA and wave).  Loop: dx outermost, the three
     // weight fragments (dy) of a column held in registers and fetched one column ahead, pixel fragments two ahead.
     // MFMA order inside a group: h_w l_x, then h_w h_x, then l_w h_x -- the two that share an accumulator are never
@@ -231,13 +240,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         typedef const __attribute__((address_space(3))) f16x8* lds_h8;
         const __attribute__((address_space(3))) float* xb = (const __attribute__((address_space(3))) float*)(buf + x_off);
         const __attribute__((address_space(3))) float* wb = (const __attribute__((address_space(3))) float*)(wbuf + w_off);
-        constexpr int R = MW + 2, NQ = 3 * R, XD = 3;
+        constexpr int R = (MW - 1) * STRIDE + 3, NQ = 3 * R, XD = 3;
         f16x8 xr[XD][PARTS], wt[2][3][C::NW][PARTS];
         auto loadX = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int dx = q / R, r = q % R;
+            constexpr int xo = (STRIDE == 2) ? (dx & 1) * C::HALF + (dx >> 1) : dx;
 #pragma unroll
-            for (int p = 0; p < PARTS; ++p) xr[q % XD][p] = *(lds_h8)(xb + p * C::PLANE + (r * C::TWP + dx) * 4);
+            for (int p = 0; p < PARTS; ++p) xr[q % XD][p] = *(lds_h8)(xb + p * C::PLANE + (r * C::TWP + xo) * 4);
         };
         auto loadW = [&](auto dc) {
             constexpr int dx = decltype(dc)::value;
@@ -258,14 +268,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             constexpr bool wpre = (r == (R >= 4 ? R - 3 : 0) && dx < 2);
             if constexpr (q + 2 < NQ) loadX(IntC<q + 2>{});
             if constexpr (wpre) loadW(IntC<dx + 1>{});
-            constexpr int nmf = (PARTS == 2 ? 3 : 1) * C::NW * ((r < MW ? r : MW - 1) - (r - 2 > 0 ? r - 2 : 0) + 1);
+            constexpr int nmf = (PARTS == 2 ? 3 : 1) * C::NW * split_pairs(MW, STRIDE, r);
             if (!(SPLIT_ABL & 16)) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {                  // 0: h_w l_x   1: h_w h_x   2: l_w h_x
                     if (PARTS == 1 && a != 1) continue;
 #pragma unroll
                     for (int m = 0; m < MW; ++m) {
-                        const int dy = r - m;
+                        const int dy = r - m * STRIDE;
                         if (dy < 0 || dy > 2) continue;
 #pragma unroll
                         for (int nn = 0; nn < C::NW; ++nn)
@@ -370,8 +380,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     float* ibuf = smem;                         // input(s)
     float* obuf = smem + C::IN_FLOATS;          // receives input(s+1)
     float* w0 = smem + 2 * C::IN_FLOATS;        // weights(s)
-    float* w1 = w0 + C::W_FLOATS;               // weights(s+1)
-    float* w2 = w1 + C::W_FLOATS;               // receives weights(s+2)
+    float* w1 = w0 + C::W_FLOATS;               // weights(s+1)  (two buffers: receives them)
+    float* w2 = w1 + (NWB == 3 ? C::W_FLOATS : 0);   // three buffers: receives weights(s+2)
     auto ct_of = [&](Cur c, int fallback) { return c.tile < total ? (c.tile % tiles_per_img) % nct : fallback; };
     auto tile_for = [&](Cur c) {                // steps past the end re-read the last decoded tile (harmless)
         if (c.tile < total && c.tile != lt_tile) { decode(c.tile, lt); lt_tile = c.tile; }
@@ -392,11 +402,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     dma_all(cs, w0);
     load_all(IntC<1>{}, c1);
     write_in(IntC<0>{}, ibuf);
-    dma_all(c1, w1);
+    if constexpr (C::WAHEAD == 2) dma_all(c1, w1);
     load_all(IntC<2>{}, c2);
     Cur cl = adv(c2);                           // loads of step s: input(s+3)
-    Cur cw = c2;                                // DMA of step s: weights(s+2)
-    split_barrier_keep_loads<2 * C::NIN + C::NWT_MIN>();
+    Cur cw = C::WAHEAD == 2 ? c2 : c1;          // DMA of step s: weights(s + WAHEAD)
+    split_barrier_keep_loads<C::WAHEAD == 2 ? 2 * C::NIN + C::NWT_MIN : 2 * C::NIN>();
     int dbg_step = 0;
     (void)dbg_step;
     // Step s (all waves alike, S = s % 3).  In program order: the MFMAs of step s with, between them, (a) the LDS-DMA
@@ -420,10 +430,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             vin[(S + 1) % 3][k] = t;
         }
         SDBG(1);
-        if (computes) mfma_stage(IntC<(S + 1) % 3>{}, IntC<S>{}, ibuf, w0, obuf, wsrc, w2, lt, ls);
+        if (computes) mfma_stage(IntC<(S + 1) % 3>{}, IntC<S>{}, ibuf, w0, obuf, wsrc, C::WAHEAD == 2 ? w2 : w1, lt, ls);
         SDBG(2);
         SDBG(3);
-        split_barrier_keep_loads<2 * C::NIN + C::NWT_MIN>();     // weights(s+1) have landed, input(s+1) is written
+        split_barrier_keep_loads<C::KEEP>();                    // weights(s+1) have landed, input(s+1) is written
         SDBG(4);
         if (last_ch) {
             if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) epilogue(cur);
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         obuf = t;
         t = w0;
         w0 = w1;
-        w1 = w2;
+        w1 = NWB == 3 ? w2 : t;
         w2 = t;
         return true;
     };
@@ -461,11 +471,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead loads / DMA of the steps past the end
 }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, bool PRE>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE>
 static int launch_split(const YondConvDesc& d, hipStream_t st) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS>;
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB>;
+    static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, PRE>;
+    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -481,7 +492,8 @@ static int launch_split(const YondConvDesc& d, hipStream_t st) {
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
 extern "C" int yond_conv_split_supported(int ksize, int stride, int cin, int cout) {
-    if (ksize != 3 || stride != 1 || cin <= 0 || cout <= 0 || cin % 16 != 0 || cout % 32 != 0) return 0;
+    if (ksize != 3 || (stride != 1 && stride != 2) || cin <= 0 || cout <= 0 || cin % 16 != 0 || cout % 32 != 0) return 0;
+    if (stride == 2) return cout % 64 == 0 ? 64 : 0;
     return cout % 64 == 0 ? 64 : 32;
 }
 
@@ -511,12 +523,18 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     const int tn = yond_conv_split_supported(d.ksize, d.stride, d.C0 + d.C1, d.Cout);
     if (!tn || d.shuffle || d.C0 % 16 != 0 || d.C1 % 16 != 0) return YOND_EUNSUPPORTED;
     if (d.tn != tn) return YOND_EINVAL;                         // the layout the weights were packed for
+    if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
+    if (d.stride == 2) {
+        if (d.Ho != (d.H + 1) / 2 || d.Wo != (d.W + 1) / 2 || d.pre_act) return YOND_EINVAL;
+        // stride 2: 4 x 32 output pixels read 9 x 65 input pixels -- two weight buffers fit beside the two input images
+        return parts == 2 ? launch_split<2, 4, 64, 1, 2, 2, false>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false>(d, st);
+    }
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
     if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
     if (tn == 64) {
-        if (parts == 2) return d.pre_act ? launch_split<1, 8, 64, 2, 2, true>(d, st) : launch_split<1, 8, 64, 2, 2, false>(d, st);
-        return d.pre_act ? launch_split<1, 8, 64, 2, 1, true>(d, st) : launch_split<1, 8, 64, 2, 1, false>(d, st);
+        if (parts == 2) return d.pre_act ? launch_split<1, 8, 64, 2, 2, 3, true>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false>(d, st);
+        return d.pre_act ? launch_split<1, 8, 64, 2, 1, 3, true>(d, st) : launch_split<1, 8, 64, 2, 1, 3, false>(d, st);
     }
-    if (parts == 2) return d.pre_act ? launch_split<1, 16, 32, 2, 2, true>(d, st) : launch_split<1, 16, 32, 2, 2, false>(d, st);
-    return d.pre_act ? launch_split<1, 16, 32, 2, 1, true>(d, st) : launch_split<1, 16, 32, 2, 1, false>(d, st);
+    if (parts == 2) return d.pre_act ? launch_split<1, 16, 32, 2, 2, 3, true>(d, st) : launch_split<1, 16, 32, 2, 2, 3, false>(d, st);
+    return d.pre_act ? launch_split<1, 16, 32, 2, 1, 3, true>(d, st) : launch_split<1, 16, 32, 2, 1, 3, false>(d, st);
 }

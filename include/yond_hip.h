@@ -113,7 +113,9 @@ typedef struct YondConvDesc {
                              BASELINE cfg 5; same packed weights as algo 0); 3 direct implicit GEMM on the fp16 MFMA with
                              fp32-accurate SPLIT operands (a = h + l 2^-11, three fp16 products per fp32 product, fp32
                              accumulate; 3x3 only, wpk from yond_pack_conv_split_weight_f32 with parts = 2, tn from
-                             yond_conv_split_supported); 4 the same kernel with h only = plain fp16 MFMA (parts = 1) */
+                             yond_conv_split_supported); 4 the same kernel with h only = plain fp16 MFMA (parts = 1); 5 the split-operand
+                             arithmetic of algo 3 in the generic kernel of algo 0 for the 1x1 / transposed layers (wpk from
+                             yond_pack_conv_weight_split_f32, tn / kc from yond_conv_config) */
 } YondConvDesc;
 
 /* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.
@@ -122,6 +124,8 @@ int yond_conv_config(int ksize, int stride, int cin, int cout, int shuffle, int 
 /* Host-side weight packing: w is OIHW [cout][cin][k][k] (Conv2d) -- for a transposed conv pass the
  * already re-indexed [4*cout][cin][1][1] matrix.  dst has cout*cin*k*k floats. */
 int yond_pack_conv_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int kc, float* dst);
+/* as yond_pack_conv_weight_f32, every weight stored as the half pair {fp16(w), fp16((w - fp16(w)) * 2^11)} (algo 5) */
+int yond_pack_conv_weight_split_f32(const float* w, int cout, int cin, int ksize, int tn, int kc, float* dst);
 int yond_conv2d_f32(const YondConvDesc* desc, void* stream);
 
 /* Winograd F(2x2,3x3) variant of the 3x3 stride-1 convolution (same descriptor, algo = 1): 16 instead of 36

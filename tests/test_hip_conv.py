@@ -221,31 +221,34 @@ def test_conv3x3_s2_split(C, N, H, W):
     assert report(f"split conv3x3 s2 C{C} {N}x{H}x{W}", got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("algo", [0, 'split'])
 @pytest.mark.parametrize("C", [32, 128])
-def test_conv1x1_two_source(C):
+def test_conv1x1_two_source(C, algo):
     g = torch.Generator().manual_seed(C)
     N, H, W = 2, 8, 40
     a, b2 = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
     w = torch.randn(C, 2 * C, 1, 1, generator=g) / (2 * C) ** 0.5
     b = torch.randn(C, generator=g)
-    got = nchw(run_conv(w, b, 1, 1, [C, C], [nhwc(a).to(DEV), nhwc(b2).to(DEV)], N, H, W))
+    got = nchw(run_conv(w, b, 1, 1, [C, C], [nhwc(a).to(DEV), nhwc(b2).to(DEV)], N, H, W, algo=algo))
     ref = F.conv2d(torch.cat([a, b2], 1).double(), w.double(), b.double())
-    assert report(f"conv1x1 two-source C{C}", got, ref) < 2e-5
+    assert report(f"conv1x1 two-source C{C} algo {algo}", got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("algo", [0, 'split'])
 @pytest.mark.parametrize("Ci,Co", [(64, 32), (256, 128)])
-def test_conv_transpose_2x2(Ci, Co):
+def test_conv_transpose_2x2(Ci, Co, algo):
     g = torch.Generator().manual_seed(Ci)
     N, H, W = 2, 8, 24
     x = torch.randn(N, Ci, H, W, generator=g)
     w = torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5
     b = torch.randn(Co, generator=g)
-    got = nchw(run_conv(w, b, 1, 1, [Ci], [nhwc(x).to(DEV)], N, H, W, shuffle=True))
+    got = nchw(run_conv(w, b, 1, 1, [Ci], [nhwc(x).to(DEV)], N, H, W, shuffle=True, algo=algo))
     ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
-    assert report(f"convT {Ci}->{Co}", got, ref) < 2e-5
+    assert report(f"convT {Ci}->{Co} algo {algo}", got, ref) < 2e-5
 
 
-def test_conv_transpose_fused_with_skip_shortcut():
+@pytest.mark.parametrize("algo", [0, 'split'])
+def test_conv_transpose_fused_with_skip_shortcut(algo):
     """The decoder's ConvTranspose2d -> cat(up, skip) -> 1x1 shortcut as ONE shuffle GEMM with the skip tensor as a
     second, output-resolution source (weights folded in float64 as engine.py does)."""
     g = torch.Generator().manual_seed(21)
@@ -263,8 +266,8 @@ def test_conv_transpose_fused_with_skip_shortcut():
     w_skip = w2[:, c:].t()[:, :, None, None].expand(c, c, 2, 2)
     w_f = torch.cat([w_cur, w_skip], 0).float().contiguous()
     b_f = (bsc.double() + w2[:, :c] @ bt.double()).float()
-    got = nchw(run_conv(w_f, b_f, 1, 1, [2 * c, c], [nhwc(cur).to(DEV), nhwc(skip).to(DEV)], N, h, w, shuffle=True))
-    assert report("fused convT + cat + 1x1 shortcut", got, ref) < 2e-5
+    got = nchw(run_conv(w_f, b_f, 1, 1, [2 * c, c], [nhwc(cur).to(DEV), nhwc(skip).to(DEV)], N, h, w, shuffle=True, algo=algo))
+    assert report(f"fused convT + cat + 1x1 shortcut algo {algo}", got, ref) < 2e-5
 
 
 def test_channel_padding_small_nf():

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "yond_conv2d_f32": [C.POINTER(YondConvDesc), vp],
     "yond_conv_wino_supported": [i32, i32],
     "yond_pack_conv_wino_weight_f32": [vp, i32, i32, i32, vp],
+    "yond_pack_conv_weight_split_f32": [vp, i32, i32, i32, i32, i32, vp],
     "yond_conv_split_supported": [i32, i32, i32, i32],
     "yond_pack_conv_split_weight_f32": [vp, i32, i32, i32, i32, i32, vp],
     "yond_conv_in_f32": [vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp],

@@ -84,8 +84,37 @@ __device__ __forceinline__ f16x4 to_half4(const f32x4 v) {
     return h;
 }
 
-template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE, bool F16>
+// SPLIT mode (descriptor algo 5; see conv_split.hip for the arithmetic): an fp32 operand a is kept in its 4-byte LDS slot
+// as the pair {h = fp16(a), l = fp16((a - h) * 2^11)}; a fragment of four slots is de-interleaved into the h and the l
+// operand of v_mfma_f32_32x32x8_f16 with two v_perm_b32 each, and a product block costs three MFMAs
+// (h_w h_x -> acc, h_w l_x and l_w h_x -> acc2, folded in as acc + acc2 * 2^-11 in the epilogue).
+__device__ __forceinline__ unsigned split_pair(float x) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 p = {h, l};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ f32x4 split_pack4(const f32x4 v) {
+    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    f32x4 o = {__uint_as_float(split_pair(x0)), __uint_as_float(split_pair(x1)), __uint_as_float(split_pair(x2)),
+               __uint_as_float(split_pair(x3))};
+    return o;
+}
+__device__ __forceinline__ void split_unpack4(const f32x4 v, f16x4& h, f16x4& l) {
+    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    const unsigned d0 = __float_as_uint(x0), d1 = __float_as_uint(x1), d2 = __float_as_uint(x2), d3 = __float_as_uint(x3);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 hh = {__builtin_amdgcn_perm(d1, d0, 0x05040100u), __builtin_amdgcn_perm(d3, d2, 0x05040100u)};
+    const u32x2 ll = {__builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u)};
+    h = __builtin_bit_cast(f16x4, hh);
+    l = __builtin_bit_cast(f16x4, ll);
+}
+
+template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE, int MODE>
 __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void conv_mfma_kernel(const YondConvDesc d) {
+    constexpr bool F16 = MODE == 1;          // operands rounded to half on their way into the matrix core (descriptor algo 2)
+    constexpr bool SPL = MODE == 2;          // fp32-accurate split operands, staged as {h, l} half pairs (descriptor algo 5)
     constexpr bool CAN_DEFER = conv_wgs_per_cu<KS, STRIDE, KC, TN>() == 1;     // two workgroups per CU cover each other's epilogues
     using C = ConvCfg<KS, STRIDE, TH, TN, KC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -194,7 +223,9 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
         f32x4 v = vin[k];
         if (PRE) { v[0] = silu_fast(v[0]); v[1] = silu_fast(v[1]); v[2] = silu_fast(v[2]); v[3] = silu_fast(v[3]); }
         const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        if ((YOND_ABL & 2) == 0) *(f32x4*)(buf + in_lds[k]) = ((vin_ok >> k) & 1u) ? v : z;      // conv zero padding
+        v = ((vin_ok >> k) & 1u) ? v : z;                                                         // conv zero padding
+        if (SPL) v = split_pack4(v);
+        if ((YOND_ABL & 2) == 0) *(f32x4*)(buf + in_lds[k]) = v;
     };
     auto write_lds = [&](float* buf) {
 #pragma unroll
@@ -202,13 +233,28 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
     };
 
     f32x16 acc[C::MW][C::NW];
+    f32x16 acc2[SPL ? C::MW : 1][SPL ? C::NW : 1];             // SPLIT: the two cross terms (carry the 2^11 scale)
     auto zero_acc = [&]() {
 #pragma unroll
         for (int m = 0; m < C::MW; ++m)
 #pragma unroll
             for (int nn = 0; nn < C::NW; ++nn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    acc[m][nn][r] = 0.0f;
+                    if constexpr (SPL) acc2[m][nn][r] = 0.0f;
+                }
+    };
+    // SPLIT: fold the cross terms into the main accumulator (before the epilogue / before parking a finished tile)
+    auto fold_acc = [&]() {
+        if constexpr (SPL) {
+#pragma unroll
+            for (int m = 0; m < C::MW; ++m)
+#pragma unroll
+                for (int nn = 0; nn < C::NW; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][nn][r] = fmaf(acc2[m][nn][r], 1.0f / 2048.0f, acc[m][nn][r]);
+        }
     };
     // ---------------------------------------------------------------------------------------------------
     // Output side.  The MFMAs are issued with the WEIGHT fragment as the A operand and the pixel fragment as
@@ -341,6 +387,27 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
 #pragma unroll
                     for (int nn = 0; nn < C::NW; ++nn)
                         acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x8f16(bh[nn], ah[m], acc[m][nn], 0, 0, 0);                 // D = W . X^T
+            } else if constexpr (SPL) {
+                f16x4 ah[C::MW], al[C::MW], bh[C::NW], bl[C::NW];
+#pragma unroll
+                for (int m = 0; m < C::MW; ++m) split_unpack4(a[g & 1][m], ah[m], al[m]);
+#pragma unroll
+                for (int nn = 0; nn < C::NW; ++nn) split_unpack4(bb[g & 1][nn], bh[nn], bl[nn]);
+#pragma unroll
+                for (int m = 0; m < C::MW; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < C::NW; ++nn)
+                        acc2[m][nn] = __builtin_amdgcn_mfma_f32_32x32x8f16(bh[nn], al[m], acc2[m][nn], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < C::MW; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < C::NW; ++nn)
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x8f16(bh[nn], ah[m], acc[m][nn], 0, 0, 0);                 // D = W . X^T
+#pragma unroll
+                for (int m = 0; m < C::MW; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < C::NW; ++nn)
+                        acc2[m][nn] = __builtin_amdgcn_mfma_f32_32x32x8f16(bl[nn], ah[m], acc2[m][nn], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -363,9 +430,9 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
             // group g+1, then the MFMAs of group g with the staging VALU work in their shadow, then the ds_writes.
             if constexpr (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, C::MW + C::NW, 0);
 #pragma unroll
-            for (int i = 0; i < (F16 ? 1 : 4) * C::MW * C::NW; ++i) {
+            for (int i = 0; i < (F16 ? 1 : SPL ? 3 : 4) * C::MW * C::NW; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (nitem > 0 || (EPI && g >= GE && g < GE + 4)) __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 4 : 2, 0);
+                if constexpr (nitem > 0 || SPL || (EPI && g >= GE && g < GE + 4)) __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 4 : 2, 0);
             }
             if constexpr (nitem > 0) __builtin_amdgcn_sched_group_barrier(0x200, nitem, 0);
         });
@@ -409,6 +476,7 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
         pend = false;
         __syncthreads();
         if (last_ch) {
+            fold_acc();
             if (CAN_DEFER && defer) {
                 if constexpr (CAN_DEFER) {
 #pragma unroll
@@ -439,11 +507,11 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
     }
 }
 
-template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE, bool F16>
+template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE, int MODE>
 static int launch_conv_p(const YondConvDesc& d, hipStream_t st) {
     using C = ConvCfg<KS, STRIDE, TH, TN, KC>;
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<KS, STRIDE, TH, TN, KC, PRE, F16>;
+    auto kern = conv_mfma_kernel<KS, STRIDE, TH, TN, KC, PRE, MODE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -460,7 +528,11 @@ static int launch_conv_p(const YondConvDesc& d, hipStream_t st) {
 
 template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE>
 static int launch_conv(const YondConvDesc& d, hipStream_t st) {
-    return d.algo == 2 ? launch_conv_p<KS, STRIDE, TH, TN, KC, PRE, true>(d, st) : launch_conv_p<KS, STRIDE, TH, TN, KC, PRE, false>(d, st);
+    if (d.algo == 5) {
+        if constexpr (KS == 1) return launch_conv_p<KS, STRIDE, TH, TN, KC, PRE, 2>(d, st);      // split operands: the 1x1 / transposed layers
+        else return YOND_EUNSUPPORTED;                                                          // (3x3: conv_split.hip, algo 3)
+    }
+    return d.algo == 2 ? launch_conv_p<KS, STRIDE, TH, TN, KC, PRE, 1>(d, st) : launch_conv_p<KS, STRIDE, TH, TN, KC, PRE, 0>(d, st);
 }
 
 // Tile configuration.  3x3 stride-1 layers choose between
@@ -527,6 +599,24 @@ extern "C" int yond_pack_conv_weight_f32(const float* w, int cout, int cin, int 
     return YOND_OK;
 }
 
+// the same image with every weight stored as the half pair {h, l} in its 4-byte slot (descriptor algo 5)
+extern "C" int yond_pack_conv_weight_split_f32(const float* w, int cout, int cin, int ksize, int tn, int kc, float* dst) {
+    const int rc = yond_pack_conv_weight_f32(w, cout, cin, ksize, tn, kc, dst);
+    if (rc != YOND_OK) return rc;
+    const size_t n = (size_t)cout * cin * ksize * ksize;
+    for (size_t i = 0; i < n; ++i) {
+        const float v = dst[i];
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)((v - (float)h) * 2048.0f);
+        unsigned short hb, lb;
+        __builtin_memcpy(&hb, &h, 2);
+        __builtin_memcpy(&lb, &l, 2);
+        const unsigned u = (unsigned)hb | ((unsigned)lb << 16);
+        __builtin_memcpy(&dst[i], &u, 4);
+    }
+    return YOND_OK;
+}
+
 int yond_conv_wino_dispatch(const YondConvDesc& d, hipStream_t st);      // conv_wino.hip
 int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st);     // conv_split.hip
 
@@ -540,7 +630,7 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;
     if (d.algo == 1) return yond_conv_wino_dispatch(d, st);
     if (d.algo == 3 || d.algo == 4) return yond_conv_split_dispatch(d, st);
-    if (d.algo != 0 && d.algo != 2) return YOND_EINVAL;
+    if (d.algo != 0 && d.algo != 2 && d.algo != 5) return YOND_EINVAL;
     if (d.tn != 32 && d.tn != 64) return YOND_EINVAL;
     int tn, kc;
     const int rc = yond_conv_config(d.ksize, d.stride, d.C0 + d.C1, d.Cout, d.shuffle, 0, 0, 0, &tn, &kc);

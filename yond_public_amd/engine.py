@@ -83,17 +83,19 @@ class _PackedConv:
         # algorithmic MACs per GEMM-M pixel (SURVEY.md section 8d counts real, unpadded channels)
         self.macs_per_pixel = self.cin_real * self.cout_real * (4 if shuffle else ksize * ksize)
 
-    def config(self, N, Ho, Wo):
-        """(tn, kc, packed weights on the device) for a GEMM-M extent; the packing is cached per tile width."""
+    def config(self, N, Ho, Wo, split=False):
+        """(tn, kc, packed weights on the device) for a GEMM-M extent; the packing is cached per tile width.
+        split: every weight as the half pair {h, l} of the split-operand arithmetic (descriptor algo 5)."""
         lib = L.load()
         tn, kc = C.c_int(), C.c_int()
         L.check(lib.yond_conv_config(self.ksize, self.stride, self.cinp, self.gemm_n, int(self.shuffle), N, Ho, Wo,
                                      C.byref(tn), C.byref(kc)), "yond_conv_config")
-        key = (tn.value, kc.value)
+        key = (tn.value, kc.value, bool(split))
         if key not in self._packed:
             packed = np.empty(self._wp.size, np.float32)
-            L.check(lib.yond_pack_conv_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn.value, kc.value,
-                                                  _np_ptr(packed)), "yond_pack_conv_weight_f32")
+            fn = lib.yond_pack_conv_weight_split_f32 if split else lib.yond_pack_conv_weight_f32
+            L.check(fn(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn.value, kc.value, _np_ptr(packed)),
+                    "yond_pack_conv_weight_f32")
             self._packed[key] = torch.from_numpy(packed).to(self._dev)
         return tn.value, kc.value, self._packed[key]
 
@@ -253,8 +255,8 @@ class DenoiserPlan:
         wino = split = None
         if algo in ('split', 'half'):
             split = pc.split(2 if algo == 'split' else 1)
-            if split is None and not fp16:
-                wino = pc.wino()                     # layers the split kernel does not take
+            if split is None and not fp16 and pc.ksize == 3:
+                wino = pc.wino()                     # 3x3 layers the split kernel does not take
         elif not fp16:
             wino = pc.wino() if algo in (1, 2) else None
         if split is not None:
@@ -265,6 +267,9 @@ class DenoiserPlan:
             tn, wpk = wino
             kc = 8
             d.algo = 1
+        elif algo == 'split' and pc.ksize == 1 and not fp16:
+            tn, kc, wpk = pc.config(N, d.Ho, d.Wo, split=True)       # 1x1 / transposed layers: split operands in the generic kernel
+            d.algo = 5
         else:
             tn, kc, wpk = pc.config(N, d.Ho, d.Wo)
             d.algo = 2 if fp16 else 0
@@ -289,6 +294,8 @@ class DenoiserPlan:
                 tag = f"conv_split_kernel<{pc.stride},{tn},{5 - d.algo}>"
             if d.algo == 2:
                 tag += "/f16"
+            if d.algo == 5:
+                tag += "/split"
             prof.append((tag, 2.0 * pc.macs_per_pixel * N * d.Ho * d.Wo, e0, e1))
         return dst
 

@@ -311,9 +311,67 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         });
     };
 
-    // ---- output side: lane = pixel li of row rg*MW + m; registers = channels (r&3) + 8 (r>>2) + 4 lh of a 32-block ----
+    // ---- output side ----
+    // In the accumulators a lane owns ONE pixel (li) and, per 32-channel block, channels (r&3) + 8 (r>>2) + 4 lh: stored
+    // from there, every instruction would touch 32 cache lines with 32 bytes each (and the residual loads likewise) --
+    // measured, that request rate made the epilogue 4-6 thousand cycles per tile.  So each wave transposes its
+    // 32-pixel x 32-channel blocks through a private LDS scratch (pixel stride 36 floats: conflict-free both ways) and
+    // reads them back with 8 lanes per pixel: a global instruction then covers 8 whole 128-byte lines, FiLM vectors are
+    // one float4 per lane, and nothing is shared between waves (no barrier inside).
     const float slope_eff = d.post_act == 2 ? d.slope : 1.0f;
-    auto epilogue = [&](const Tile& T) {
+    constexpr int EPS = 36;                                   // floats per pixel of the scratch
+    constexpr int EP_FLOATS = 8 * 32 * EPS;                   // 36,864 bytes: one weight buffer (TN 64) or part of an input image
+    // (stride 2: short steps, no residual -- measured slower with the transpose and its extra barrier: 211 vs 175 us at level 0)
+    constexpr bool EP_FIT = STRIDE == 1 && EP_FLOATS <= (TN == 64 ? C::W_FLOATS : C::IN_FLOATS);
+    auto epilogue = [&](const Tile& T, float* scratch) {
+        float* sw = scratch + wave * (32 * EPS);
+        const int pj = lane >> 3, u = lane & 7;               // read-back: pixel pj + 8 j, channels 4 u .. 4 u + 3
+#pragma unroll
+        for (int nn = 0; nn < C::NW; ++nn) {
+            const int cb = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
+            const int eoff = (d.ebatch ? T.n * d.Cout : 0) + cb;
+            const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            const f32x4 es = d.escale ? *(const f32x4*)(d.escale + eoff) : one;
+            const f32x4 et = d.eshift ? *(const f32x4*)(d.eshift + eoff) : zero4;
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const int oy = T.oy0 + rg * MW + m;
+                const long long rowoff = ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cb;
+                f32x4 rr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                  // residual first: in flight during the transpose
+                    const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;
+                    rr[j] = d.res ? *(const f32x4*)(d.res + (ok ? rowoff + (long long)(pj + 8 * j) * d.Cout : 0)) : zero4;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[0][m][nn][4 * g + e];
+                        if constexpr (PARTS == 2) v[e] = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, v[e]);
+                    }
+                    *(f32x4*)(sw + li * EPS + 8 * g + 4 * lh) = v;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;
+                    const f32x4 x = *(const f32x4*)(sw + (pj + 8 * j) * EPS + 4 * u);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float y = fmaf(x[e], es[e], et[e]);
+                        y = y > 0.0f ? y : y * slope_eff;
+                        v[e] = y + rr[j][e];
+                    }
+                    if (ok) *(f32x4*)(d.dst + rowoff + (long long)(pj + 8 * j) * d.Cout) = v;
+                }
+            }
+        }
+    };
+
+    // (plain form, lane = pixel: kept for the shapes whose free buffer is smaller than the scratch -- the h-only fp16 path)
+    auto epilogue_direct = [&](const Tile& T) {
         const int ox = T.ox0 + li;
         const bool col_ok = ox < d.Wo;
 #pragma unroll
@@ -436,7 +494,13 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         split_barrier_keep_loads<C::KEEP>();                    // weights(s+1) have landed, input(s+1) is written
         SDBG(4);
         if (last_ch) {
-            if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) epilogue(cur);
+            // scratch: weights(s) / input(s), which no wave reads any more; the barrier behind the epilogue keeps the next
+            // step's DMA and staging writes (of OTHER waves) out of it until every wave has read its block back
+            if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) {
+                if constexpr (EP_FIT) epilogue(cur, TN == 64 ? w0 : ibuf);
+                else epilogue_direct(cur);
+            }
+            if constexpr (EP_FIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             zero_acc();
             if (cn.tile < total) {
                 const int n = cn.tile / tiles_per_img;

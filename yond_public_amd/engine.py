@@ -283,12 +283,6 @@ class DenoiserPlan:
         d.dst = dst.data_ptr()
         prof = getattr(self, 'prof', None)
         if prof is not None:
-            # events on the stream the kernel is launched on (torch's current stream)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        L.check(self.lib.yond_conv2d_f32(C.byref(d), L.stream()), "yond_conv2d_f32")
-        if prof is not None:
-            e1.record()
             tag = f"conv_wino_kernel<{tn}>" if d.algo == 1 else f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{tn},{kc}>"
             if d.algo in (3, 4):
                 tag = f"conv_split_kernel<{pc.stride},{tn},{5 - d.algo}>"
@@ -296,6 +290,16 @@ class DenoiserPlan:
                 tag += "/f16"
             if d.algo == 5:
                 tag += "/split"
+            only = getattr(self, 'prof_only', None)      # bench.py: events around one kernel family only (an event pair
+            if only is not None and not only(tag):       # costs the stream a few microseconds)
+                prof = None
+        if prof is not None:
+            # events on the stream the kernel is launched on (torch's current stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(self.lib.yond_conv2d_f32(C.byref(d), L.stream()), "yond_conv2d_f32")
+        if prof is not None:
+            e1.record()
             prof.append((tag, 2.0 * pc.macs_per_pixel * N * d.Ho * d.Wo, e0, e1))
         return dst
 

@@ -76,7 +76,8 @@ struct SplitCfg {
     static constexpr int NWT_MIN = NWV / NT;                        // LDS-DMA instructions every wave issues per step
     static constexpr int NOPS = NWT + NIN;                          // vector-memory instructions per thread and step
     static constexpr int WAHEAD = NWB - 1;                          // the LDS-DMA of step s fetches weights(s + WAHEAD)
-    static constexpr int KEEP = WAHEAD == 2 ? 2 * NIN + NWT_MIN : NIN;   // memory operations that may stay in flight across a barrier
+    static constexpr bool LOADS_FIRST = WAHEAD == 2;                // order of a step's memory operations (see the step pipeline)
+    static constexpr int KEEP = WAHEAD == 2 ? NIN + NWT_MIN : NIN;  // memory operations that may stay in flight across a barrier
     static constexpr int SMEM_BYTES = (2 * IN_FLOATS + NWB * W_FLOATS) * 4;
     static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
     static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
@@ -289,8 +290,13 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             constexpr int o_lo = (q * C::NOPS + NQ - 1) / NQ, o_hi = ((q + 1) * C::NOPS + NQ - 1) / NQ;
             static_for<o_lo, o_hi>([&](auto oc) {
                 constexpr int o = decltype(oc)::value;
-                if constexpr (o < C::NWT) issue_dma(IntC<o>{}, wsrc, wnext);
-                else issue_load(fc, IntC<o - C::NWT>{}, lt, ls);
+                if constexpr (C::LOADS_FIRST) {
+                    if constexpr (o < C::NIN) issue_load(fc, IntC<o>{}, lt, ls);
+                    else issue_dma(IntC<o - C::NIN>{}, wsrc, wnext);
+                } else {
+                    if constexpr (o < C::NWT) issue_dma(IntC<o>{}, wsrc, wnext);
+                    else issue_load(fc, IntC<o - C::NWT>{}, lt, ls);
+                }
             });
             // this group's share of the staging work (element tasks e_lo .. e_hi of the set loaded during the previous step)
             constexpr int e_lo = q * NE / NQ, e_hi = (q + 1) * NE / NQ;
@@ -457,20 +463,30 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     //   loads input(0) | DMA weights(0), loads input(1) | stage input(0) | DMA weights(1), loads input(2)
     const Cur c1 = adv(cs), c2 = adv(c1);
     load_all(IntC<0>{}, cs);
-    dma_all(cs, w0);
-    load_all(IntC<1>{}, c1);
-    write_in(IntC<0>{}, ibuf);
-    if constexpr (C::WAHEAD == 2) dma_all(c1, w1);
-    load_all(IntC<2>{}, c2);
+    if constexpr (C::LOADS_FIRST) {
+        load_all(IntC<1>{}, c1);
+        dma_all(cs, w0);
+        write_in(IntC<0>{}, ibuf);
+        load_all(IntC<2>{}, c2);
+        dma_all(c1, w1);
+    } else {
+        dma_all(cs, w0);
+        load_all(IntC<1>{}, c1);
+        write_in(IntC<0>{}, ibuf);
+        if constexpr (C::WAHEAD == 2) dma_all(c1, w1);
+        load_all(IntC<2>{}, c2);
+    }
     Cur cl = adv(c2);                           // loads of step s: input(s+3)
     Cur cw = C::WAHEAD == 2 ? c2 : c1;          // DMA of step s: weights(s + WAHEAD)
-    split_barrier_keep_loads<C::WAHEAD == 2 ? 2 * C::NIN + C::NWT_MIN : 2 * C::NIN>();
+    split_barrier_keep_loads<C::WAHEAD == 2 ? C::NIN + C::NWT_MIN : 2 * C::NIN>();
     int dbg_step = 0;
     (void)dbg_step;
-    // Step s (all waves alike, S = s % 3).  In program order: the MFMAs of step s with, between them, (a) the LDS-DMA
-    // of weights(s+2) and the loads of input(s+3) into register set S, (b) the staging of set (s+1) % 3 = input(s+1),
-    // loaded two steps ago; then ONE barrier that awaits weights(s+1) only: this step's and the previous step's loads
-    // and this step's DMA stay in flight (vmcnt counts in order: DMA(s-1), loads(s-1), DMA(s), loads(s)).
+    // Step s (all waves alike, S = s % 3).  In program order: the MFMAs of step s with, between them, (a) the loads of
+    // input(s+3) into register set S and the LDS-DMA of weights(s+2) (three weight buffers; with two: DMA of weights(s+1)
+    // first, then the loads), (b) the staging of set (s+1) % 3 = input(s+1), loaded two steps ago; then ONE barrier that
+    // awaits weights(s+1) only -- vmcnt counts in order: loads(s-1), DMA(s-1), loads(s), DMA(s): the last two stay in
+    // flight.  Loads before DMA because the compiler (which does not see the DMA) makes the next step wait for every
+    // outstanding operation before it touches the staged set: the youngest are then L2-resident weight slices.
     auto step = [&](auto sc) -> bool {
         constexpr int S = decltype(sc)::value;
         SDBG(0);

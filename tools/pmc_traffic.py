@@ -24,6 +24,10 @@ def short(name):
     if m:
         a = [x.strip() for x in m.group(1).split(',')]
         return f"conv_mfma_kernel<{a[0]},{a[1]},{a[2]},{a[3]},{a[4]}>"
+    m = re.search(r"conv_split_kernel<([^>]*)>", name)
+    if m:
+        a = [x.strip() for x in m.group(1).split(',')]
+        return f"conv_split_kernel<{a[0]},{a[2]},{a[4]}>"           # stride, channel-tile width, parts (bench.py's tag)
     m = re.search(r"conv_wino_kernel<\s*(\d+)", name)
     if m:
         return f"conv_wino_kernel<{m.group(1)}>"

@@ -26,4 +26,5 @@ for wv in range(2):
     for sidx in range(2, 40):
         r = t[wv, sidx]
         nxt = t[wv, sidx + 1][0]
-        print(" %3d %6d %6d %6d %5d %5d | %6d" % (sidx, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], nxt - r[0]))
+        extra = "  epilogue %d, barrier behind it %d, rest %d" % (r[6] - r[4], r[7] - r[6], r[5] - r[7]) if r[6] > r[4] and r[5] - r[4] > 1000 else ""
+        print(" %3d %6d %6d %6d %5d %5d | %6d%s" % (sidx, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], nxt - r[0], extra))

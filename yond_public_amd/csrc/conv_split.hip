@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)wbuf;
         const int it = tid + k * C::NT;
         const int it_wave = __builtin_amdgcn_readfirstlane(it - lane);
-        const unsigned lds_wave = lds0 + (unsigned)it_wave * 16u;
+        const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)it_wave * 16u);
         const unsigned voff = (unsigned)it * 16u;
         if (!(SPLIT_ABL & 2) && (C::NWV % C::NT == 0 || it_wave < C::NWV))
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(wsrc) : "memory");
@@ -329,26 +329,50 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     constexpr int EP_FLOATS = 8 * 32 * EPS;                   // 36,864 bytes: one weight buffer (TN 64) or part of an input image
     // (stride 2: short steps, no residual -- measured slower with the transpose and its extra barrier: 211 vs 175 us at level 0)
     constexpr bool EP_FIT = STRIDE == 1 && EP_FLOATS <= (TN == 64 ? C::W_FLOATS : C::IN_FLOATS);
-    auto epilogue = [&](const Tile& T, float* scratch) {
-        float* sw = scratch + wave * (32 * EPS);
-        const int pj = lane >> 3, u = lane & 7;               // read-back: pixel pj + 8 j, channels 4 u .. 4 u + 3
+    // Straight-line on purpose: a branch around a load (`res ? load : 0`) makes the compiler lose count of the outstanding
+    // memory operations and wait with vmcnt(0) before EVERY store -- i.e. for the previous store (measured: 3.4-4.9
+    // thousand cycles per tile).  So the variant (residual / scale / shift present) is chosen by ONE uniform switch
+    // outside, and all loads precede the first store.
+    f32x4 pes[C::NW], pet[C::NW];
+    auto epi_prefetch = [&](const Tile& T) __attribute__((always_inline)) {
+        const int u = lane & 7;
 #pragma unroll
         for (int nn = 0; nn < C::NW; ++nn) {
+            const int eoff = (d.ebatch ? T.n * d.Cout : 0) + T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
+            // (no branch around the loads: an absent vector is read from the weights and never used)
+            pes[nn] = *(const f32x4*)(d.escale ? d.escale + eoff : d.wpk);
+            pet[nn] = *(const f32x4*)(d.eshift ? d.eshift + eoff : d.wpk);
+        }
+    };
+    auto epilogue = [&](auto hr, const Tile& T, float* scratch) __attribute__((always_inline)) {
+        constexpr bool HAS_RES = (decltype(hr)::value & 1) != 0, HAS_SCALE = (decltype(hr)::value & 2) != 0, HAS_SHIFT = (decltype(hr)::value & 4) != 0;
+        float* sw = scratch + wave * (32 * EPS);
+        const int pj = lane >> 3, u = lane & 7;               // read-back: pixel pj + 8 j, channels 4 u .. 4 u + 3
+        static_for<0, C::NW>([&](auto nc) __attribute__((always_inline)) {
+            constexpr int nn = decltype(nc)::value;
             const int cb = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
             const int eoff = (d.ebatch ? T.n * d.Cout : 0) + cb;
             const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            const f32x4 es = d.escale ? *(const f32x4*)(d.escale + eoff) : one;
-            const f32x4 et = d.eshift ? *(const f32x4*)(d.eshift + eoff) : zero4;
+            (void)eoff;
+            f32x4 es = one, et = zero4;                        // FiLM / bias vectors: requested at the start of the tile's last step
+            if constexpr (HAS_SCALE) es = pes[nn];
+            if constexpr (HAS_SHIFT) et = pet[nn];
+            f32x4 rr[MW][4];
+            long long rowoff[MW];
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
                 const int oy = T.oy0 + rg * MW + m;
-                const long long rowoff = ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cb;
-                f32x4 rr[4];
+                rowoff[m] = ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cb;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {                  // residual first: in flight during the transpose
-                    const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;
-                    rr[j] = d.res ? *(const f32x4*)(d.res + (ok ? rowoff + (long long)(pj + 8 * j) * d.Cout : 0)) : zero4;
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;      // masked lanes read element 0..
+                    if constexpr (HAS_RES) rr[m][j] = *(const f32x4*)(d.res + (ok ? rowoff[m] + (long long)(pj + 8 * j) * d.Cout : 0));
+                    else rr[m][j] = zero4;
                 }
+            }
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const int oy = T.oy0 + rg * MW + m;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
@@ -368,12 +392,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                     for (int e = 0; e < 4; ++e) {
                         float y = fmaf(x[e], es[e], et[e]);
                         y = y > 0.0f ? y : y * slope_eff;
-                        v[e] = y + rr[j][e];
+                        v[e] = y + rr[m][j][e];
                     }
-                    if (ok) *(f32x4*)(d.dst + rowoff + (long long)(pj + 8 * j) * d.Cout) = v;
+                    if (ok) *(f32x4*)(d.dst + rowoff[m] + (long long)(pj + 8 * j) * d.Cout) = v;
                 }
             }
-        }
+        });
     };
 
     // (plain form, lane = pixel: kept for the shapes whose free buffer is smaller than the scratch -- the h-only fp16 path)
@@ -492,6 +516,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         SDBG(0);
         const bool last_ch = (cs.ch + 1 == nchunk);
         const Cur cn = adv(cs);
+        if constexpr (EP_FIT) {
+            if (last_ch) epi_prefetch(cur);
+        }
         tile_for(cl);
         const LoadSrc ls = load_src(cl.ch);
         const float* wsrc = weight_src(ct_of(cw, cur.ct), cw.ch);
@@ -513,10 +540,25 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             // scratch: weights(s) / input(s), which no wave reads any more; the barrier behind the epilogue keeps the next
             // step's DMA and staging writes (of OTHER waves) out of it until every wave has read its block back
             if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) {
-                if constexpr (EP_FIT) epilogue(cur, TN == 64 ? w0 : ibuf);
-                else epilogue_direct(cur);
+                if constexpr (EP_FIT) {
+                    float* scr = TN == 64 ? w0 : ibuf;
+                    switch ((d.res ? 1 : 0) | (d.escale ? 2 : 0) | (d.eshift ? 4 : 0)) {
+                        case 0: epilogue(IntC<0>{}, cur, scr); break;
+                        case 1: epilogue(IntC<1>{}, cur, scr); break;
+                        case 2: epilogue(IntC<2>{}, cur, scr); break;
+                        case 3: epilogue(IntC<3>{}, cur, scr); break;
+                        case 4: epilogue(IntC<4>{}, cur, scr); break;
+                        case 5: epilogue(IntC<5>{}, cur, scr); break;
+                        case 6: epilogue(IntC<6>{}, cur, scr); break;
+                        default: epilogue(IntC<7>{}, cur, scr); break;
+                    }
+                } else {
+                    epilogue_direct(cur);
+                }
             }
+            SDBG(6);
             if constexpr (EP_FIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            SDBG(7);
             zero_acc();
             if (cn.tile < total) {
                 const int n = cn.tile / tiles_per_img;

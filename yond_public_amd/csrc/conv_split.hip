@@ -236,12 +236,17 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // back to back (the dependent-issue latency of v_mfma_f32_32x32x16_f16 exceeds its 32 cycles).
     const int x_off = (lh * PARTS) * C::PLANE + ((rg * MW * STRIDE) * C::TWP + li) * 4;
     const int w_off = ((lh * PARTS) * TN + (cg * C::NW) * 32 + li) * 4;
-    auto mfma_stage = [&](auto pc, auto fc, const float* buf, const float* wbuf, float* ob, const float* wsrc, float* wnext, const Tile& lt,
-                          const LoadSrc& ls) {
+    // (the step's cursor arithmetic -- `prep`, which sets wsrc_s / ls_s and may decode the next tile -- runs after the
+    // first groups of MFMAs have been issued; memory instructions and staging start at group Q0)
+    const float* wsrc_s = nullptr;
+    const bool wave_hi = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    LoadSrc ls_s = {nullptr, 0, 0};
+    auto mfma_stage = [&](auto pc, auto fc, const float* buf, const float* wbuf, float* ob, float* wnext, const Tile& lt, auto&& prep)
+        __attribute__((always_inline)) {
         typedef const __attribute__((address_space(3))) f16x8* lds_h8;
         const __attribute__((address_space(3))) float* xb = (const __attribute__((address_space(3))) float*)(buf + x_off);
         const __attribute__((address_space(3))) float* wb = (const __attribute__((address_space(3))) float*)(wbuf + w_off);
-        constexpr int R = (MW - 1) * STRIDE + 3, NQ = 3 * R, XD = 3;
+        constexpr int R = (MW - 1) * STRIDE + 3, NQ = 3 * R, XD = 3, Q0 = 2, NQW = NQ - Q0;
         f16x8 xr[XD][PARTS], wt[2][3][C::NW][PARTS];
         auto loadX = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -287,19 +292,25 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             }
             // this group's share of the step's vector-memory instructions: the LDS-DMA of weights(s+2), then the loads
             // of input(s+3) -- spread over the step so that no wave ever queues behind the CU's 64 B/clk memory pipe
-            constexpr int o_lo = (q * C::NOPS + NQ - 1) / NQ, o_hi = ((q + 1) * C::NOPS + NQ - 1) / NQ;
+            // the older wave of a SIMD wins the issue arbitration and would finish its MFMAs ~900 cycles before the younger
+            // one, which then runs alone and exposes its LDS latencies: the younger half leads for the first half instead
+            if constexpr (q == 0) { if (wave_hi) __builtin_amdgcn_s_setprio(1); }
+            if constexpr (q == NQ / 2) { if (wave_hi) __builtin_amdgcn_s_setprio(0); }
+            if constexpr (q == Q0 - 1) prep();
+            constexpr int qq = q >= Q0 ? q - Q0 : 0;
+            constexpr int o_lo = q >= Q0 ? (qq * C::NOPS + NQW - 1) / NQW : 0, o_hi = q >= Q0 ? ((qq + 1) * C::NOPS + NQW - 1) / NQW : 0;
             static_for<o_lo, o_hi>([&](auto oc) {
                 constexpr int o = decltype(oc)::value;
                 if constexpr (C::LOADS_FIRST) {
-                    if constexpr (o < C::NIN) issue_load(fc, IntC<o>{}, lt, ls);
-                    else issue_dma(IntC<o - C::NIN>{}, wsrc, wnext);
+                    if constexpr (o < C::NIN) issue_load(fc, IntC<o>{}, lt, ls_s);
+                    else issue_dma(IntC<o - C::NIN>{}, wsrc_s, wnext);
                 } else {
-                    if constexpr (o < C::NWT) issue_dma(IntC<o>{}, wsrc, wnext);
-                    else issue_load(fc, IntC<o - C::NWT>{}, lt, ls);
+                    if constexpr (o < C::NWT) issue_dma(IntC<o>{}, wsrc_s, wnext);
+                    else issue_load(fc, IntC<o - C::NWT>{}, lt, ls_s);
                 }
             });
             // this group's share of the staging work (element tasks e_lo .. e_hi of the set loaded during the previous step)
-            constexpr int e_lo = q * NE / NQ, e_hi = (q + 1) * NE / NQ;
+            constexpr int e_lo = q >= Q0 ? qq * NE / NQW : 0, e_hi = q >= Q0 ? (qq + 1) * NE / NQW : 0;
             static_for<e_lo, e_hi>([&](auto ec) { stage_task(pc, ec, ob); });
             constexpr int nfin = (e_hi + 0) / 4 - (e_lo + 0) / 4;                     // items completed in this group
             // Issue order of the group: its LDS reads first (they are two groups / one column ahead of their use), then
@@ -519,19 +530,13 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         if constexpr (EP_FIT) {
             if (last_ch) epi_prefetch(cur);
         }
-        tile_for(cl);
-        const LoadSrc ls = load_src(cl.ch);
-        const float* wsrc = weight_src(ct_of(cw, cur.ct), cw.ch);
-        // input(s+1) was loaded two steps ago; one wait for the whole set here (the compiler does not see the DMA
-        // instructions in its vmcnt bookkeeping: a wait placed later would also wait for this step's DMA)
-#pragma unroll
-        for (int k = 0; k < C::NIN; ++k) {
-            f32x4 t = vin[(S + 1) % 3][k];
-            asm volatile("" : "+v"(t));
-            vin[(S + 1) % 3][k] = t;
-        }
+        auto prep = [&]() __attribute__((always_inline)) {
+            tile_for(cl);
+            ls_s = load_src(cl.ch);
+            wsrc_s = weight_src(ct_of(cw, cur.ct), cw.ch);
+        };
         SDBG(1);
-        if (computes) mfma_stage(IntC<(S + 1) % 3>{}, IntC<S>{}, ibuf, w0, obuf, wsrc, C::WAHEAD == 2 ? w2 : w1, lt, ls);
+        if (computes) mfma_stage(IntC<(S + 1) % 3>{}, IntC<S>{}, ibuf, w0, obuf, C::WAHEAD == 2 ? w2 : w1, lt, prep);
         SDBG(2);
         SDBG(3);
         split_barrier_keep_loads<C::KEEP>();                    // weights(s+1) have landed, input(s+1) is written

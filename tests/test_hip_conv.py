@@ -107,7 +107,8 @@ def test_conv3x3_winograd_fused_two_source():
 @pytest.mark.parametrize("C,Co,N,H,W", [(64, 64, 1, 8, 32), (64, 64, 2, 16, 64), (32, 64, 1, 9, 33), (128, 128, 1, 24, 40),
                                         (256, 64, 1, 94, 126), (32, 32, 2, 24, 72), (64, 32, 1, 17, 40), (32, 32, 1, 5, 7),
                                         (64, 64, 1, 1, 1), (64, 64, 1, 2, 3), (128, 64, 2, 4, 4),
-                                        (32, 32, 1, 200, 352), (64, 64, 1, 136, 288)])      # > 256 tiles: several tiles per workgroup
+                                        (32, 32, 1, 200, 352), (64, 64, 1, 136, 288),       # > 256 tiles: several tiles per workgroup
+                                        (64, 64, 1, 190, 520), (128, 128, 2, 94, 126)])     # >= 256 12-row tiles: the three-rows-per-wave shape
 def test_conv3x3_split_plain(C, Co, N, H, W):
     """Split-operand fp16-MFMA kernel (algo 3: a = h + l 2^-11, three fp16 products per fp32 product, fp32 accumulate)
     against the float64 convolution: the SAME tolerance as the fp32 kernels."""
@@ -165,6 +166,21 @@ def test_conv3x3_split_fused_two_source():
     got = nchw(run_conv(w2, b, 3, 1, [32, 32], [nhwc(a).to(DEV), nhwc(b2).to(DEV)], 1, 16, 32, post_act=2, slope=0.2, algo='split'))
     ref = F.leaky_relu(F.conv2d(torch.cat([a, b2], 1).double(), w2.double(), b.double(), padding=1), 0.2)
     assert report("split conv3x3 two-source", got, ref) < 2e-5
+
+
+def test_conv3x3_split_fused_12_row_tiles():
+    """FiLM + SiLU + LeakyReLU + residual on a layer large enough for the 12 x 32-pixel tile shape (partial tiles both ways)."""
+    g = torch.Generator().manual_seed(19)
+    N, C, H, W = 1, 64, 188, 540
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    es, et = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
+    res = torch.randn(N, C, H, W, generator=g)
+    got = nchw(run_conv(w, None, 3, 1, [C], [nhwc(x).to(DEV)], N, H, W, escale=es.to(DEV), eshift=et.to(DEV), ebatch=1,
+                        res=nhwc(res).to(DEV), pre_act=1, post_act=2, slope=0.3, algo='split'))
+    z = F.conv2d(F.silu(x.double()), w.double(), padding=1)
+    z = F.leaky_relu(z * es.double()[:, :, None, None] + et.double()[:, :, None, None], 0.3) + res.double()
+    assert report("split conv3x3 fused, 12-row tiles", got, z) < 2e-5
 
 
 def test_conv3x3_half_staged_path():

@@ -153,12 +153,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 
     // Three register sets: set s % 3 receives the loads of input(s+3) during step s and is split / written out as
     // input(s+3) during step s+2, so a load has two steps to arrive.
-    f32x4 vin[3][C::NIN];
+    constexpr int NSET = MW >= 3 ? 2 : 3;                     // (three rows per wave: 96 accumulator registers leave room for two sets)
+    static_assert(NSET == 3 || C::WAHEAD == 1, "the two-set pipeline goes with two weight buffers");
+    f32x4 vin[NSET][C::NIN];
     if (SPLIT_ABL & 1) {
 #pragma unroll
-        for (int k = 0; k < C::NIN; ++k) { const f32x4 z = {0.5f, 0.25f, -0.5f, 0.125f}; vin[0][k] = z; vin[1][k] = z; vin[2][k] = z; }
+        for (int k = 0; k < C::NIN; ++k) { const f32x4 z = {0.5f, 0.25f, -0.5f, 0.125f}; vin[0][k] = z; vin[1][k] = z; vin[NSET - 1][k] = z; }
     }
-    unsigned vin_ok[3] = {0, 0, 0};
+    unsigned vin_ok[NSET] = {};
     // one 16-byte load of a set (item k); the source of the chunk is selected once per step (LoadSrc)
     struct LoadSrc { const float* src; int Cs, cc; };
     auto load_src = [&](int ch) {
@@ -247,7 +249,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         const __attribute__((address_space(3))) float* xb = (const __attribute__((address_space(3))) float*)(buf + x_off);
         const __attribute__((address_space(3))) float* wb = (const __attribute__((address_space(3))) float*)(wbuf + w_off);
         constexpr int R = (MW - 1) * STRIDE + 3, NQ = 3 * R, XD = 3, Q0 = 2, NQW = NQ - Q0;
-        f16x8 xr[XD][PARTS], wt[2][3][C::NW][PARTS];
+        // weight fragments of a column: two sets (the next column is fetched during the current one), or -- three rows per
+        // wave, register budget -- ONE set, each dy refilled for the next column right behind its last use (two groups ahead
+        // of its next use)
+        constexpr bool WINPLACE = MW >= 3;
+        constexpr int WS = WINPLACE ? 1 : 2;
+        f16x8 xr[XD][PARTS], wt[WS][3][C::NW][PARTS];
         auto loadX = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int dx = q / R, r = q % R;
@@ -255,23 +262,24 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
             for (int p = 0; p < PARTS; ++p) xr[q % XD][p] = *(lds_h8)(xb + p * C::PLANE + (r * C::TWP + xo) * 4);
         };
-        auto loadW = [&](auto dc) {
-            constexpr int dx = decltype(dc)::value;
+        auto loadW1 = [&](auto dc, auto yc) {
+            constexpr int dx = decltype(dc)::value, dy = decltype(yc)::value;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int nn = 0; nn < C::NW; ++nn)
 #pragma unroll
-                for (int nn = 0; nn < C::NW; ++nn)
-#pragma unroll
-                    for (int p = 0; p < PARTS; ++p)
-                        wt[dx & 1][dy][nn][p] = *(lds_h8)(wb + (((dy * 3 + dx) * 2 * PARTS + p) * TN + nn * 32) * 4);
+                for (int p = 0; p < PARTS; ++p)
+                    wt[dx % WS][dy][nn][p] = *(lds_h8)(wb + (((dy * 3 + dx) * 2 * PARTS + p) * TN + nn * 32) * 4);
         };
+        auto loadW = [&](auto dc) { static_for<0, 3>([&](auto yc) { loadW1(dc, yc); }); };
         loadW(IntC<0>{});
         loadX(IntC<0>{});
         loadX(IntC<1>{});
         static_for<0, NQ>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int dx = q / R, r = q % R;
-            constexpr bool wpre = (r == (R >= 4 ? R - 3 : 0) && dx < 2);
+            constexpr bool wpre = !WINPLACE && (r == (R >= 4 ? R - 3 : 0) && dx < 2);
+            constexpr int wdy = r - (MW - 1) * STRIDE;                      // WINPLACE: the tap row whose last use is this group
+            constexpr bool wrep = WINPLACE && dx < 2 && wdy >= 0 && wdy <= 2;
             if constexpr (q + 2 < NQ) loadX(IntC<q + 2>{});
             if constexpr (wpre) loadW(IntC<dx + 1>{});
             constexpr int nmf = (PARTS == 2 ? 3 : 1) * C::NW * split_pairs(MW, STRIDE, r);
@@ -286,17 +294,18 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
                         for (int nn = 0; nn < C::NW; ++nn)
                             acc[a == 1 ? 0 : 1][m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                wt[dx & 1][dy][nn][a == 2 ? PARTS - 1 : 0], xr[q % XD][a == 0 ? PARTS - 1 : 0], acc[a == 1 ? 0 : 1][m][nn], 0, 0, 0);   // D = W . X^T
+                                wt[dx % WS][dy][nn][a == 2 ? PARTS - 1 : 0], xr[q % XD][a == 0 ? PARTS - 1 : 0], acc[a == 1 ? 0 : 1][m][nn], 0, 0, 0);   // D = W . X^T
                     }
                 }
             }
-            // this group's share of the step's vector-memory instructions: the LDS-DMA of weights(s+2), then the loads
-            // of input(s+3) -- spread over the step so that no wave ever queues behind the CU's 64 B/clk memory pipe
+            if constexpr (wrep) loadW1(IntC<dx + 1>{}, IntC<wdy>{});          // behind this group's MFMAs (its last readers)
             // the older wave of a SIMD wins the issue arbitration and would finish its MFMAs ~900 cycles before the younger
             // one, which then runs alone and exposes its LDS latencies: the younger half leads for the first half instead
             if constexpr (q == 0) { if (wave_hi) __builtin_amdgcn_s_setprio(1); }
             if constexpr (q == NQ / 2) { if (wave_hi) __builtin_amdgcn_s_setprio(0); }
             if constexpr (q == Q0 - 1) prep();
+            // this group's share of the step's vector-memory instructions (loads of input(s+3) / LDS-DMA of the weights) --
+            // spread over the step so that no wave ever queues behind the CU's 64 B/clk memory pipe
             constexpr int qq = q >= Q0 ? q - Q0 : 0;
             constexpr int o_lo = q >= Q0 ? (qq * C::NOPS + NQW - 1) / NQW : 0, o_hi = q >= Q0 ? ((qq + 1) * C::NOPS + NQW - 1) / NQW : 0;
             static_for<o_lo, o_hi>([&](auto oc) {
@@ -324,6 +333,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if constexpr (vpm > 0) __builtin_amdgcn_sched_group_barrier(0x002, vpm, 0);
             }
+            if constexpr (wrep) __builtin_amdgcn_sched_group_barrier(0x100, C::NW * PARTS, 0);
             if constexpr (nfin > 0) __builtin_amdgcn_sched_group_barrier(0x200, nfin * PARTS, 0);
         });
     };
@@ -368,46 +378,53 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             f32x4 es = one, et = zero4;                        // FiLM / bias vectors: requested at the start of the tile's last step
             if constexpr (HAS_SCALE) es = pes[nn];
             if constexpr (HAS_SHIFT) et = pet[nn];
-            f32x4 rr[MW][4];
-            long long rowoff[MW];
+            // two rows at a time: their residual loads first, then transposes / arithmetic / stores
+            constexpr int MG = MW < 2 ? MW : 2;
+            static_for<0, (MW + MG - 1) / MG>([&](auto gcx) __attribute__((always_inline)) {
+                constexpr int m0 = decltype(gcx)::value * MG;
+                constexpr int MGN = MW - m0 < MG ? MW - m0 : MG;           // rows of this group
+                f32x4 rr[MG][4];
+                long long rowoff[MG];
 #pragma unroll
-            for (int m = 0; m < MW; ++m) {
-                const int oy = T.oy0 + rg * MW + m;
-                rowoff[m] = ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cb;
+                for (int mm = 0; mm < MGN; ++mm) {
+                    const int oy = T.oy0 + rg * MW + m0 + mm;
+                    rowoff[mm] = ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cb;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;      // masked lanes read element 0..
-                    if constexpr (HAS_RES) rr[m][j] = *(const f32x4*)(d.res + (ok ? rowoff[m] + (long long)(pj + 8 * j) * d.Cout : 0));
-                    else rr[m][j] = zero4;
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < MW; ++m) {
-                const int oy = T.oy0 + rg * MW + m;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[0][m][nn][4 * g + e];
-                        if constexpr (PARTS == 2) v[e] = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, v[e]);
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;      // masked lanes read element 0..
+                        if constexpr (HAS_RES) rr[mm][j] = *(const f32x4*)(d.res + (ok ? rowoff[mm] + (long long)(pj + 8 * j) * d.Cout : 0));
+                        else rr[mm][j] = zero4;
                     }
-                    *(f32x4*)(sw + li * EPS + 8 * g + 4 * lh) = v;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;
-                    const f32x4 x = *(const f32x4*)(sw + (pj + 8 * j) * EPS + 4 * u);
-                    f32x4 v;
+                for (int mm = 0; mm < MGN; ++mm) {
+                    const int m = m0 + mm;
+                    const int oy = T.oy0 + rg * MW + m;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float y = fmaf(x[e], es[e], et[e]);
-                        y = y > 0.0f ? y : y * slope_eff;
-                        v[e] = y + rr[m][j][e];
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[0][m][nn][4 * g + e];
+                            if constexpr (PARTS == 2) v[e] = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, v[e]);
+                        }
+                        *(f32x4*)(sw + li * EPS + 8 * g + 4 * lh) = v;
                     }
-                    if (ok) *(f32x4*)(d.dst + rowoff[m] + (long long)(pj + 8 * j) * d.Cout) = v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;
+                        const f32x4 x = *(const f32x4*)(sw + (pj + 8 * j) * EPS + 4 * u);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float y = fmaf(x[e], es[e], et[e]);
+                            y = y > 0.0f ? y : y * slope_eff;
+                            v[e] = y + rr[mm][j][e];
+                        }
+                        if (ok) *(f32x4*)(d.dst + rowoff[mm] + (long long)(pj + 8 * j) * d.Cout) = v;
+                    }
                 }
-            }
+            });
         });
     };
 
@@ -498,25 +515,36 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     //   loads input(0) | DMA weights(0), loads input(1) | stage input(0) | DMA weights(1), loads input(2)
     const Cur c1 = adv(cs), c2 = adv(c1);
     load_all(IntC<0>{}, cs);
-    if constexpr (C::LOADS_FIRST) {
-        load_all(IntC<1>{}, c1);
+    Cur cl, cw;                                 // cursors of the step's loads / weight DMA
+    if constexpr (NSET == 2) {
+        // two register sets (and two weight buffers): set s % 2 receives input(s+2) during step s, staged in step s+1
         dma_all(cs, w0);
         write_in(IntC<0>{}, ibuf);
-        load_all(IntC<2>{}, c2);
-        dma_all(c1, w1);
+        load_all(IntC<1>{}, c1);
+        cl = c2;
+        cw = c1;
+        split_barrier_keep_loads<C::NIN>();
     } else {
-        dma_all(cs, w0);
-        load_all(IntC<1>{}, c1);
-        write_in(IntC<0>{}, ibuf);
-        if constexpr (C::WAHEAD == 2) dma_all(c1, w1);
-        load_all(IntC<2>{}, c2);
+        if constexpr (C::LOADS_FIRST) {
+            load_all(IntC<1>{}, c1);
+            dma_all(cs, w0);
+            write_in(IntC<0>{}, ibuf);
+            load_all(IntC<2>{}, c2);
+            dma_all(c1, w1);
+        } else {
+            dma_all(cs, w0);
+            load_all(IntC<1>{}, c1);
+            write_in(IntC<0>{}, ibuf);
+            if constexpr (C::WAHEAD == 2) dma_all(c1, w1);
+            load_all(IntC<2>{}, c2);
+        }
+        cl = adv(c2);                           // loads of step s: input(s+3)
+        cw = C::WAHEAD == 2 ? c2 : c1;          // DMA of step s: weights(s + WAHEAD)
+        split_barrier_keep_loads<C::WAHEAD == 2 ? C::NIN + C::NWT_MIN : 2 * C::NIN>();
     }
-    Cur cl = adv(c2);                           // loads of step s: input(s+3)
-    Cur cw = C::WAHEAD == 2 ? c2 : c1;          // DMA of step s: weights(s + WAHEAD)
-    split_barrier_keep_loads<C::WAHEAD == 2 ? C::NIN + C::NWT_MIN : 2 * C::NIN>();
     int dbg_step = 0;
     (void)dbg_step;
-    // Step s (all waves alike, S = s % 3).  In program order: the MFMAs of step s with, between them, (a) the loads of
+    // Step s (all waves alike, S = s % NSET; described for three register sets).  In program order: the MFMAs of step s with, between them, (a) the loads of
     // input(s+3) into register set S and the LDS-DMA of weights(s+2) (three weight buffers; with two: DMA of weights(s+1)
     // first, then the loads), (b) the staging of set (s+1) % 3 = input(s+1), loaded two steps ago; then ONE barrier that
     // awaits weights(s+1) only -- vmcnt counts in order: loads(s-1), DMA(s-1), loads(s), DMA(s): the last two stay in
@@ -536,7 +564,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             wsrc_s = weight_src(ct_of(cw, cur.ct), cw.ch);
         };
         SDBG(1);
-        if (computes) mfma_stage(IntC<(S + 1) % 3>{}, IntC<S>{}, ibuf, w0, obuf, C::WAHEAD == 2 ? w2 : w1, lt, prep);
+        if (computes) mfma_stage(IntC<(S + 1) % NSET>{}, IntC<S>{}, ibuf, w0, obuf, C::WAHEAD == 2 ? w2 : w1, lt, prep);
         SDBG(2);
         SDBG(3);
         split_barrier_keep_loads<C::KEEP>();                    // weights(s+1) have landed, input(s+1) is written
@@ -593,7 +621,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     while (true) {
         if (!step(IntC<0>{})) break;
         if (!step(IntC<1>{})) break;
-        if (!step(IntC<2>{})) break;
+        if constexpr (NSET == 3) {
+            if (!step(IntC<2>{})) break;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead loads / DMA of the steps past the end
 }
@@ -659,6 +689,12 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
     if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
     if (tn == 64) {
+        // 12 x 32-pixel tiles, three rows per wave: 0.59 instead of 0.78 KiB of LDS fragments per MFMA, 1.5x the MFMA work per
+        // step (and per barrier), and 94 / 188 / 376 / 752 rows fill 256 workgroups in whole rounds (1 / 2 / 4 / 8)
+        static const char* e12 = getenv("YOND_SPLIT_TH12");              // experiments: 0 never, 1 always
+        const long long tiles12 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
+        const bool th12 = e12 ? atoi(e12) != 0 : tiles12 >= 256;
+        if (parts == 2 && th12) return d.pre_act ? launch_split<1, 12, 64, 3, 2, 2, true>(d, st) : launch_split<1, 12, 64, 3, 2, 2, false>(d, st);
         if (parts == 2) return d.pre_act ? launch_split<1, 8, 64, 2, 2, 3, true>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false>(d, st);
         return d.pre_act ? launch_split<1, 8, 64, 2, 1, 3, true>(d, st) : launch_split<1, 8, 64, 2, 1, 3, false>(d, st);
     }

@@ -116,6 +116,16 @@ typedef struct YondConvDesc {
                              yond_conv_split_supported); 4 the same kernel with h only = plain fp16 MFMA (parts = 1); 5 the split-operand
                              arithmetic of algo 3 in the generic kernel of algo 0 for the 1x1 / transposed layers (wpk from
                              yond_pack_conv_weight_split_f32, tn / kc from yond_conv_config) */
+    /* Fused output projection (archs/Unet.py:466-470 `conv10` + residual + data_inv_normalize, i.e. what yond_conv_out_f32
+       does as a kernel of its own): when out4_dst is set the convolution must produce ONE 32-channel tile (Cout = tn = 32,
+       algo 3, stride 1); its result v is not stored (dst may be NULL) and out4_dst[n][y][x][c] =
+       ((sum_k out4_w[c][k] v[k]) + out4_b[c] + out4_x / ub) * ub is written instead (same operation order as
+       yond_conv_out_f32: bit-identical). */
+    const float* out4_w;  /* [4][Cout] */
+    const float* out4_b;  /* [4] or NULL */
+    const float* out4_x;  /* NHWC4 network input [N][Ho][Wo][4] (global residual) or NULL */
+    const float* out4_ub; /* [N] per-image maximum (data_normalize) or NULL */
+    float* out4_dst;      /* [N][Ho][Wo][4] or NULL (no fused projection) */
 } YondConvDesc;
 
 /* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.

@@ -183,6 +183,36 @@ def test_conv3x3_split_fused_12_row_tiles():
     assert report("split conv3x3 fused, 12-row tiles", got, z) < 2e-5
 
 
+@pytest.mark.parametrize("with_x,with_ub,res", [(True, True, True), (False, False, False), (True, False, True)])
+def test_conv3x3_split_fused_output_projection(with_x, with_ub, res):
+    """The 1x1 output projection (conv10 + global residual + de-normalisation) computed in the epilogue of the last 3x3
+    convolution must be BIT-identical to the convolution followed by yond_conv_out_f32."""
+    from yond_public_amd import _lib as L
+    from yond_public_amd.engine import _PackedConv, DenoiserPlan
+    lib = L.load()
+    g = torch.Generator().manual_seed(23)
+    N, C, H, W = 2, 32, 37, 70
+    x = nhwc(torch.randn(N, C, H, W, generator=g)).to(DEV)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(C, generator=g)
+    r = nhwc(torch.randn(N, C, H, W, generator=g)).to(DEV) if res else None
+    w4 = (torch.randn(4, C, generator=g) / C ** 0.5).to(DEV)
+    b4 = torch.randn(4, generator=g).to(DEV)
+    xin = torch.rand(N, H, W, 4, generator=g).to(DEV) if with_x else None
+    ub = (torch.rand(N, generator=g) + 0.5).to(DEV) if with_ub else None
+    pc = _PackedConv(torch.device(DEV), w, b, 3, 1, [C])
+    plan = DenoiserPlan.__new__(DenoiserPlan)
+    plan.lib, plan.dev = lib, torch.device(DEV)
+    feat = torch.empty(N, H, W, C, device=DEV)
+    plan._conv(pc, x, None, N, H, W, feat, res=r, pre_act=1, post_act=2, slope=0.2, algo='split')
+    ref = torch.full((N, H, W, 4), float('nan'), device=DEV)
+    L.check(lib.yond_conv_out_f32(L.ptr(feat), C, L.ptr(w4), L.ptr(b4), L.ptr(xin), L.ptr(ub), N, H, W, L.ptr(ref), L.stream()), "conv_out")
+    got = torch.full((N, H, W, 4), float('nan'), device=DEV)
+    plan._conv(pc, x, None, N, H, W, None, res=r, pre_act=1, post_act=2, slope=0.2, algo='split', out4=(w4, b4, xin, ub, got))
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), ref.cpu()), float((got - ref).abs().max())
+
+
 def test_conv3x3_half_staged_path():
     """algo 4: the same kernel with the h halves only = plain fp16 MFMA (cfg 5), fp16-level tolerance."""
     g = torch.Generator().manual_seed(17)

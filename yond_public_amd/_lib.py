@@ -20,7 +20,8 @@ class YondConvDesc(C.Structure):
     _fields_ = [("src0", vp), ("src1", vp), ("C0", i32), ("C1", i32), ("N", i32), ("H", i32), ("W", i32),
                 ("Ho", i32), ("Wo", i32), ("Cout", i32), ("ksize", i32), ("stride", i32), ("shuffle", i32),
                 ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
-                ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32)]
+                ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32),
+                ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp)]
 
 
 class YondFilmDesc(C.Structure):

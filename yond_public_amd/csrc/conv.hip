@@ -624,7 +624,8 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     if (!dp) return YOND_EINVAL;
     const YondConvDesc& d = *dp;
     hipStream_t st = (hipStream_t)stream;
-    if (!d.src0 || !d.dst || !d.wpk || d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Ho <= 0 || d.Wo <= 0) return YOND_EINVAL;
+    if (!d.src0 || !(d.dst || d.out4_dst) || !d.wpk || d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Ho <= 0 || d.Wo <= 0) return YOND_EINVAL;
+    if (d.out4_dst && (d.algo != 3 || !d.out4_w || d.Cout != 32 || d.stride != 1)) return YOND_EUNSUPPORTED;   // fused projection: conv_split.hip only
     if (d.C1 > 0 && !d.src1) return YOND_EINVAL;
     if ((long long)d.N * d.H * d.W > 0x7fffffffLL) return YOND_EUNSUPPORTED;    // 32-bit pixel offsets
     if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;

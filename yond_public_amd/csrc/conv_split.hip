@@ -78,7 +78,8 @@ struct SplitCfg {
     static constexpr int WAHEAD = NWB - 1;                          // the LDS-DMA of step s fetches weights(s + WAHEAD)
     static constexpr bool LOADS_FIRST = WAHEAD == 2;                // order of a step's memory operations (see the step pipeline)
     static constexpr int KEEP = WAHEAD == 2 ? NIN + NWT_MIN : NIN;  // memory operations that may stay in flight across a barrier
-    static constexpr int SMEM_BYTES = (2 * IN_FLOATS + NWB * W_FLOATS) * 4;
+    static constexpr int W4_OFF = 2 * IN_FLOATS + NWB * W_FLOATS;   // floats: 4 x 32 weights of the fused output projection
+    static constexpr int SMEM_BYTES = (W4_OFF + (TN == 32 ? 128 : 0)) * 4;   // (the 512 bytes are used by the O4 instantiation only)
     static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
     static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
 };
@@ -96,7 +97,7 @@ __device__ __forceinline__ float split_silu(float x) {
 template <int N>
 __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB>;
     constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
@@ -367,8 +368,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
     auto epilogue = [&](auto hr, const Tile& T, float* scratch) __attribute__((always_inline)) {
         constexpr bool HAS_RES = (decltype(hr)::value & 1) != 0, HAS_SCALE = (decltype(hr)::value & 2) != 0, HAS_SHIFT = (decltype(hr)::value & 4) != 0;
+        constexpr bool OUT4 = O4;                                            // fused 1x1 output projection (see YondConvDesc)
         float* sw = scratch + wave * (32 * EPS);
         const int pj = lane >> 3, u = lane & 7;               // read-back: pixel pj + 8 j, channels 4 u .. 4 u + 3
+        float ubv = 1.0f, bq = 0.0f;                          // OUT4: per-image maximum, bias of output component u & 3
+        if constexpr (OUT4) {
+            if (d.out4_ub) ubv = d.out4_ub[T.n];
+            if (d.out4_b) bq = d.out4_b[u & 3];
+        }
         static_for<0, C::NW>([&](auto nc) __attribute__((always_inline)) {
             constexpr int nn = decltype(nc)::value;
             const int cb = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
@@ -384,11 +391,20 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 constexpr int m0 = decltype(gcx)::value * MG;
                 constexpr int MGN = MW - m0 < MG ? MW - m0 : MG;           // rows of this group
                 f32x4 rr[MG][4];
+                float xq[OUT4 ? MG : 1][OUT4 ? 4 : 1];                      // OUT4: component u & 3 of the pixel's network input (global residual)
                 long long rowoff[MG];
 #pragma unroll
                 for (int mm = 0; mm < MGN; ++mm) {
                     const int oy = T.oy0 + rg * MW + m0 + mm;
                     rowoff[mm] = ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cb;
+                    if constexpr (OUT4) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo && d.out4_x;
+                            const long long gp = (long long)(T.n * d.Ho + oy) * d.Wo + T.ox0 + pj + 8 * j;
+                            xq[mm][j] = *((d.out4_x ? d.out4_x : d.wpk) + (ok ? gp * 4 + (u & 3) : 0));
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;      // masked lanes read element 0..
@@ -421,7 +437,38 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                             y = y > 0.0f ? y : y * slope_eff;
                             v[e] = y + rr[mm][j][e];
                         }
-                        if (ok) *(f32x4*)(d.dst + rowoff[mm] + (long long)(pj + 8 * j) * d.Cout) = v;
+                        if constexpr (OUT4) {
+                            // 1x1 projection 32 -> 4 in yond_conv_out_f32's operation order: per lane four FMAs per output over its
+                            // channels 4u..4u+3, xor-shuffle tree over the pixel's 8 lanes, then bias, residual, de-normalisation
+                            const float* w4 = smem + C::W4_OFF + 4 * u;
+                            float o[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const f32x4 wv = *(const f32x4*)(w4 + 32 * c);
+                                float t = 0.0f;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) t = fmaf(v[e], wv[e], t);
+                                o[c] = t;
+                            }
+                            // xor 1, xor 2 (quad permutes), then the other half of the 8 lanes (half-row mirror: every lane of a
+                            // quad holds the same sum by then) -- DPP instead of 12 dependent ds_bpermute round trips
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                o[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o[c]), 0xB1, 0xF, 0xF, true));
+                                o[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o[c]), 0x4E, 0xF, 0xF, true));
+                                o[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o[c]), 0x141, 0xF, 0xF, true));
+                            }
+                            // every lane of the pixel now holds all four sums: lane u < 4 finishes and stores component u
+                            const int cu = u & 3;
+                            float t = cu == 0 ? o[0] : cu == 1 ? o[1] : cu == 2 ? o[2] : o[3];
+                            if (d.out4_b) t += bq;
+                            if (d.out4_x) t += d.out4_ub ? xq[mm][j] / ubv : xq[mm][j];
+                            if (d.out4_ub) t *= ubv;
+                            const long long gp = (long long)(T.n * d.Ho + oy) * d.Wo + T.ox0 + pj + 8 * j;
+                            if (ok && u < 4) d.out4_dst[gp * 4 + cu] = t;
+                        } else {
+                            if (ok) *(f32x4*)(d.dst + rowoff[mm] + (long long)(pj + 8 * j) * d.Cout) = v;
+                        }
                     }
                 }
             });
@@ -487,6 +534,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         return n;
     };
     if (lslot >= total) return;
+    if constexpr (O4) {
+        if (tid < 128) smem[C::W4_OFF + tid] = d.out4_w[tid];                    // visible behind the prologue's barrier
+    }
     Cur cs = {lslot, 0};                       // step being computed
     Tile cur;                                   // its tile (epilogue)
     Tile lt;                                    // tile of the load cursor
@@ -575,16 +625,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) {
                 if constexpr (EP_FIT) {
                     float* scr = TN == 64 ? w0 : ibuf;
-                    switch ((d.res ? 1 : 0) | (d.escale ? 2 : 0) | (d.eshift ? 4 : 0)) {
-                        case 0: epilogue(IntC<0>{}, cur, scr); break;
-                        case 1: epilogue(IntC<1>{}, cur, scr); break;
-                        case 2: epilogue(IntC<2>{}, cur, scr); break;
-                        case 3: epilogue(IntC<3>{}, cur, scr); break;
-                        case 4: epilogue(IntC<4>{}, cur, scr); break;
-                        case 5: epilogue(IntC<5>{}, cur, scr); break;
-                        case 6: epilogue(IntC<6>{}, cur, scr); break;
-                        default: epilogue(IntC<7>{}, cur, scr); break;
-                    }
+                    const int flags = (d.res ? 1 : 0) | (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
+                    static_for<0, 8>([&](auto fcx) __attribute__((always_inline)) {
+                        if (flags == decltype(fcx)::value) epilogue(fcx, cur, scr);
+                    });
                 } else {
                     epilogue_direct(cur);
                 }
@@ -628,12 +672,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead loads / DMA of the steps past the end
 }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false>
 static int launch_split(const YondConvDesc& d, hipStream_t st) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB>;
     static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE>;
+    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -688,6 +732,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     }
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
     if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
+    if (d.out4_dst && (tn != 32 || parts != 2)) return YOND_EUNSUPPORTED;
     if (tn == 64) {
         // 12 x 32-pixel tiles, three rows per wave: 0.59 instead of 0.78 KiB of LDS fragments per MFMA, 1.5x the MFMA work per
         // step (and per barrier), and 94 / 188 / 376 / 752 rows fill 256 workgroups in whole rounds (1 / 2 / 4 / 8)
@@ -698,6 +743,8 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         if (parts == 2) return d.pre_act ? launch_split<1, 8, 64, 2, 2, 3, true>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false>(d, st);
         return d.pre_act ? launch_split<1, 8, 64, 2, 1, 3, true>(d, st) : launch_split<1, 8, 64, 2, 1, 3, false>(d, st);
     }
+    if (parts == 2 && d.out4_dst)      // the last convolution of the network with the 1x1 output projection in its epilogue
+        return d.pre_act ? launch_split<1, 16, 32, 2, 2, 3, true, true>(d, st) : launch_split<1, 16, 32, 2, 2, 3, false, true>(d, st);
     if (parts == 2) return d.pre_act ? launch_split<1, 16, 32, 2, 2, 3, true>(d, st) : launch_split<1, 16, 32, 2, 2, 3, false>(d, st);
     return d.pre_act ? launch_split<1, 16, 32, 2, 1, 3, true>(d, st) : launch_split<1, 16, 32, 2, 1, 3, false>(d, st);
 }

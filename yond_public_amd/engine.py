@@ -227,8 +227,14 @@ class DenoiserPlan:
         return wp.to(self.dev).contiguous()
 
     # -- launches ----------------------------------------------------------------------------
+    def _out4_fusable(self, pc):
+        """The 1x1 output projection can ride in the epilogue of the last 3x3 convolution: split kernel, one 32-channel tile."""
+        return (getattr(self, 'conv_algo', WINO_DEFAULT) == 'split' and getattr(self, 'precision', 'fp32') == 'fp32'
+                and pc.ksize == 3 and pc.stride == 1 and pc.gemm_n == 32 and pc.split(2) is not None
+                and os.environ.get('YOND_FUSE_OUT4', '1') != '0')
+
     def _conv(self, pc, src0, src1, N, H, W, dst, escale=None, eshift=None, ebatch=0, res=None, pre_act=0, post_act=0,
-              slope=0.0, algo=None):
+              slope=0.0, algo=None, out4=None):
         d = L.YondConvDesc()
         d.src0 = src0.data_ptr()
         d.src1 = src1.data_ptr() if src1 is not None else None
@@ -280,7 +286,16 @@ class DenoiserPlan:
         d.eshift = (eshift if eshift is not None else pc.bias).data_ptr()
         d.ebatch = ebatch
         d.res = res.data_ptr() if res is not None else None
-        d.dst = dst.data_ptr()
+        d.dst = dst.data_ptr() if dst is not None else None
+        if out4 is not None:
+            # (w [4][Cout], bias [4], network input NHWC4 or None, per-image maxima or None, destination NHWC4)
+            w4, b4, x4, ub4, o4 = out4
+            if d.algo != 3:
+                raise L.YondHipError("fused output projection needs the split-operand 3x3 kernel")
+            d.out4_w, d.out4_b = w4.data_ptr(), (b4.data_ptr() if b4 is not None else None)
+            d.out4_x = x4.data_ptr() if x4 is not None else None
+            d.out4_ub = ub4.data_ptr() if ub4 is not None else None
+            d.out4_dst = o4.data_ptr()
         prof = getattr(self, 'prof', None)
         if prof is not None:
             tag = f"conv_wino_kernel<{tn}>" if d.algo == 1 else f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{tn},{kc}>"
@@ -383,6 +398,12 @@ class DenoiserPlan:
                 # z = conv2(SiLU(FiLM(conv1(SiLU(x))))) + x : both SiLUs run in the consumers' staging (hidden under
                 # the MFMAs), the epilogues only scale/shift (+ residual)
                 self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1)
+                if i == 9 and self._out4_fusable(blk['conv2']):
+                    # the last block's output feeds only the 1x1 output projection: computed in this epilogue, never stored
+                    out4 = self._new(N, H, W, 4)
+                    self._conv(blk['conv2'], tmp, None, N, h, w, None, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=1,
+                               out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4))
+                    return out4
                 out = self._new(N, h, w, cp)
                 self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=1)
                 cur = out
@@ -420,6 +441,11 @@ class DenoiserPlan:
                 c1 = cv[f'conv{i}_1']
                 cur = self._conv(c1, up, skips[10 - i], N, h, w, self._new(N, h, w, c1.coutp), post_act=2, slope=0.2)
                 c2 = cv[f'conv{i}_2']
+                if i == 9 and self._out4_fusable(c2):
+                    out4 = self._new(N, H, W, 4)
+                    self._conv(c2, cur, None, N, h, w, None, post_act=2, slope=0.2,
+                               out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4))
+                    return out4
                 cur = self._conv(c2, cur, None, N, h, w, self._new(N, h, w, c2.coutp), post_act=2, slope=0.2)
             feat = cur
         out4 = self._new(N, H, W, 4)

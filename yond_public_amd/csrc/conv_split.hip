@@ -2,32 +2,35 @@
 //
 // Why: on gfx950 the fp32-input MFMA runs at 1/16 of the fp16 rate and blocks the vector ALU while it runs
 // ("fp32 MFMA and the vector ALU do not overlap").  Every fp32 operand a is therefore split ONCE, when it
-// is staged into LDS, into two halves
+// is staged into LDS (activations) or packed on the host (weights), into two halves
 //        h = fp16(a)                 (round to nearest: 11 significant bits)
 //        l = fp16((a - h) * 2^11)    (a - h is exact in fp32; the scale keeps l in fp16's normal range)
 // so that a = h + l * 2^-11 to 22-23 significant bits, and a product a*w is evaluated as
 //        h_a*h_w  +  2^-11 * (h_a*l_w + l_a*h_w)          (the l_a*l_w term, 2^-22 relative, is dropped)
-// by THREE v_mfma_f32_32x32x16_f16 -- fp16 x fp16 products are exact in the fp32 accumulator, and the two cross terms
-// go to accumulators of their own that are folded in with one FMA in the epilogue.  Measured against a float64
-// convolution (tests/test_hip_conv.py) the result is as close as the fp32 direct kernel and closer than the fp32
-// Winograd kernel; 3/16 of the matrix time of the fp32 form, and the vector work now hides under the MFMAs.
-// Range: |a| must stay below 65504 (fp16 max) -- activations and weights of the denoisers are O(1).
+// by THREE v_mfma_f32_32x32x16_f16 -- fp16 x fp16 products are exact in the fp32 accumulator; the two cross terms share
+// a second accumulator that is folded in with one FMA in the epilogue.  Measured against a float64 convolution
+// (tests/test_hip_conv.py::test_conv3x3_split_accuracy_beside_fp32_kernels) the error is that of the fp32 direct kernel.
+// Limits: |a| < 65504 (fp16 max); an operand below fp16's normal range (|a| < 6.1e-5) keeps an absolute error of 2^-36
+// instead of a relative one.  Activations and weights of the denoisers are O(1).
 // With PARTS = 1 (descriptor algo 4) only the h halves are staged and multiplied: the plain fp16 MFMA path of
-// BASELINE cfg 5 (fp32 tensors in HBM, fp32 accumulate), without the per-fragment conversions of conv.hip's F16 form.
+// BASELINE cfg 5 (fp32 tensors in HBM, fp32 accumulate), without the per-fragment conversions of conv.hip's mode 1.
 //
 // Structure: persistent 512-thread workgroups (two waves per SIMD), tile = TH x 32 output pixels x TN output
-// channels, walked in 16-channel steps with ONE barrier per step.  LDS (double-buffered):
-//   input   planes [channel half 0..1][part h, l][IH x TWP pixels] x 16 bytes (8 halves): the 32 lanes of a fragment
-//           read consecutive pixels = consecutive 16-byte units (conflict-free, no padding); stride 2 keeps even and
-//           odd columns in separate halves of a row so a tap still reads consecutive pixels
-//   weights [tap][channel half][part][TN] x 16 bytes, produced in this order by yond_pack_conv_split_weight_f32 and
-//           copied by LDS-DMA.
+// channels, walked in 16-channel steps with ONE barrier per step.  Shapes (STRIDE, TH, TN, rows per wave MW):
+// (1,12,64,3) and (1,8,64,2) for >= 64 channels, (1,16,32,2) for 32 channels, (2,4,64,1) for stride 2.  LDS:
+//   input   two images of planes [channel half 0..1][part h, l][IH x TWP pixels] x 16 bytes (8 halves): the 32 lanes of
+//           a fragment read consecutive pixels = consecutive 16-byte units (conflict-free, no padding); stride 2 keeps
+//           even and odd columns in separate halves of a row so a tap still reads consecutive pixels
+//   weights two or three buffers [tap][channel half][part][TN] x 16 bytes, produced in this order by
+//           yond_pack_conv_split_weight_f32 and copied by LDS-DMA one or two steps ahead.
 // MFMA operand map (cdna_hip_programming.md section 3, 32x32x16): lane l (r = l&31, hh = l>>5) supplies
 // A[row r][k = 8 hh + j] and B[k = 8 hh + j][col r], j = 0..7 -- one ds_read_b128 each.  A = weights (row = output
-// channel), B = pixels, so a lane of D owns ONE pixel and channels (reg&3) + 8 (reg>>2) + 4 hh: 16-byte stores.
-// Pipeline per step s (as in conv_wino.hip): the staged registers of step s+1 (loaded two steps ago) are split and
-// written to the other input buffer, refilled with the global loads of step s+3; the weight slice of s+1 arrives by
-// LDS-DMA; the two waves of a SIMD take the MFMA half and the staging half in opposite order.
+// channel), B = pixels, so a lane of D owns ONE pixel and channels (reg&3) + 8 (reg>>2) + 4 hh.
+// Pipeline: all waves run the same program.  Between the MFMAs of step s the compiler is handed, group by group
+// (sched_group_barrier), the step's memory instructions (loads of a later input into a free register set, LDS-DMA of
+// later weights) and the staging of input(s+1) -- SiLU, zero padding, split, ds_write -- as single-element tasks: the fp16
+// MFMA co-executes with the vector ALU.  The end-of-step barrier waits with a counted vmcnt.  See DESIGN.md (K2s) for the
+// measurements behind each of these choices; the kernel runs at the board's power limit.
 #include "common.h"
 #include <cstdlib>
 

@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--height", type=int, default=3000)
     ap.add_argument("--width", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sequential", action="store_true", help="one frame at a time (IterDenoise) instead of the two-stream driver")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiments: no HIP events around the kernels (no roofline objects)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-mfma", "fp16"],
                     help="fp32 (headline): fp32 results, 3x3 convolutions as fp32-accurate split-operand products on the fp16 MFMA; "
@@ -110,8 +111,19 @@ def main():
     def step():
         return P.IterDenoise(frame, net, arch, pipe)
 
-    for _ in range(a.warmup):
-        res = step()
+    def run(nsteps):
+        """nsteps passes of the hot path; 'once' mode through the two-stream driver (the NLE of frame k+1 overlaps the
+        convolutions of frame k), unless --sequential."""
+        last = None
+        if a.sequential:
+            for _ in range(nsteps):
+                last = step()
+        else:
+            for last in P.denoise_stream((frame for _ in range(nsteps)), net, arch, pipe):
+                pass
+        return last
+
+    res = run(a.warmup)
     plan = P._plan_of(net, dev)
     torch.cuda.synchronize()
     D.barrier()
@@ -123,8 +135,7 @@ def main():
     plan.prof = None if a.no_kernel_events else []
     plan.prof_only = is33
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        res = step()
+    res = run(a.steps)
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
@@ -238,7 +249,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[{4 if a.precision == 'fp16' else 1}]: one {H}x{W} synthetic Poisson-Gaussian Bayer frame per GPU, full "
                                    f"NLE+VST+{a.arch}(nf=32)+iVST, pipeline '{a.mode}', bias_corr=pre, k=29",
-                       "frames_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}"},
+                       "frames_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}",
+                       "driver": "IterDenoise, one frame at a time" if (a.sequential or a.mode != "once") else
+                                 "denoise_stream: NLE of frame k+1 on a second HIP stream while the convolutions of frame k run"},
             "roofline": roof,
             "fp32_mfma_path": strict,
             "roofline_vst_nle": roof_hbm,

@@ -95,3 +95,27 @@ def test_cfg5_unclipped_low_light_sweep(K, sigma, expo, idx):
     psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
     print(f"[parity] cfg5 K={K} sigma={sigma}: fp16-MFMA path vs fp32 path PSNR {psnr:.1f} dB")
     assert psnr >= 55.0
+
+
+def test_denoise_stream_matches_iterdenoise():
+    """The two-stream driver (NLE of frame k+1 overlapped with the network of frame k) must return, frame by frame,
+    what IterDenoise returns (same kernels and arguments; the NLE's float64 moment sums are accumulated with atomics,
+    so the estimates agree to rounding of the summation order, not bit for bit -- also between two IterDenoise runs)."""
+    import yond_public_amd.pipeline as P
+    import yond_public_amd.archs as A
+    import yond_public_amd.synthetic as S
+    dev = torch.device('cuda:0')
+    arch = dict(name='GuidedResUnet', in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True, guided=True)
+    net = A.GuidedResUnet(dict(arch))
+    net.load_state_dict(S.procedural_state_dict(net, 0))
+    net = net.to(dev).eval()
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'max_iter': 1, 'full_dn': True}
+    frames = [torch.from_numpy(S.synth_noisy(256, 320, 3.0 + i, 5.0 + 2 * i, 10 + i)[0]).to(dev) for i in range(4)]
+    seq = [P.IterDenoise(f, net, arch, pipe) for f in frames]
+    got = list(P.denoise_stream(iter(frames), net, arch, pipe))
+    torch.cuda.synchronize()
+    assert len(got) == len(seq)
+    for a_, b_ in zip(got, seq):
+        assert np.allclose(np.asarray(a_['regs'], np.float64), np.asarray(b_['regs'], np.float64), rtol=1e-10, atol=0)
+        assert np.allclose(np.asarray(a_['params'], np.float64), np.asarray(b_['params'], np.float64), rtol=1e-10, atol=0)
+        assert float((a_['raw_dns'][0] - b_['raw_dns'][0]).abs().max()) <= 1e-6

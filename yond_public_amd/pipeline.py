@@ -481,6 +481,65 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     return dict(raw_dns=raw_dns, regs=regs, params=params)
 
 
+def denoise_stream(frames, net, arch, pipe, p=None, device=None):
+    """`IterDenoise` over a sequence of full Bayer frames with the two phases of consecutive frames overlapped
+    (pipe['iter'] == 'once', pipe['full_dn']): the noise-level estimation of frame k+1 -- memory / latency bound kernels
+    and the one host round trip of the path (YOND_SIDD.py:341-356) -- runs on a second HIP stream while the
+    convolution stack of frame k (:387-389) occupies the matrix cores on the first.  Same kernels, same arguments and
+    therefore the same results as IterDenoise, frame by frame (tests/test_hip_pipeline.py); yields its dict per frame.
+    Any other mode falls back to IterDenoise."""
+    if pipe.get('iter', 'iter') != 'once' or not pipe.get('full_dn', False):
+        for f in frames:
+            yield IterDenoise(f, net, arch, pipe, p=p, device=device)
+        return
+    p0 = dict(p or default_params())
+    k = pipe.get('k', 29)
+    bias_corr = pipe.get('bias_corr', 'pre')
+    if bias_corr == 'none':
+        bias_corr = None
+    vst_type = pipe.get('vst_type', 'exact')
+    scale = p0['wp'] - p0['bl']
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+
+    def estimate(f, ready):                # phase 1 on the side stream; returns host scalars only
+        lr = _dev(f, device)
+        side.wait_event(ready)             # the frame as it stood when it was handed in -- NOT the work queued since
+        with torch.cuda.stream(side):
+            lr_max_dev = lr.max()
+            reg = SimpleNLF(lr, k=k, setting={'mode': 'self'})
+            lr_max = np.float32(lr_max_dev.item())
+        return lr, reg, lr_max
+
+    it = iter(frames)
+    try:
+        f = next(it)
+    except StopIteration:
+        return
+    nxt = estimate(f, main.record_event())
+    while nxt is not None:
+        lr, reg, lr_max = nxt
+        try:                               # take the next frame (and mark the main stream) BEFORE queuing this one's network
+            f_next, ready = next(it), main.record_event()
+        except StopIteration:
+            f_next = None
+        pp = dict(p0)
+        pp['gain'], pp['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale
+        raw_dn = VST_Denoiser(lr, pp, net, arch, bias_corr, None, vst_type, clip01=True, lr_max=lr_max)   # phase 2, asynchronous
+        nxt = estimate(f_next, ready) if f_next is not None else None     # overlaps with the convolutions just queued
+        yield dict(raw_dns=[raw_dn], regs=[reg], params=[(pp['gain'], pp['sigma'])])
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    key = str(dev)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 # ------------------------------------------------------------------------------------------------
 # metrics (YOND_SIDD.py:649-652, 679-697)
 # ------------------------------------------------------------------------------------------------

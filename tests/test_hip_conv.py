@@ -293,12 +293,13 @@ def test_conv_transpose_2x2(Ci, Co, algo):
     assert report(f"convT {Ci}->{Co} algo {algo}", got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("c,h,w", [(32, 9, 20), (64, 9, 20), (128, 11, 37), (64, 40, 130)])
 @pytest.mark.parametrize("algo", [0, 'split'])
-def test_conv_transpose_fused_with_skip_shortcut(algo):
+def test_conv_transpose_fused_with_skip_shortcut(algo, c, h, w):
     """The decoder's ConvTranspose2d -> cat(up, skip) -> 1x1 shortcut as ONE shuffle GEMM with the skip tensor as a
     second, output-resolution source (weights folded in float64 as engine.py does)."""
-    g = torch.Generator().manual_seed(21)
-    N, c, h, w = 2, 32, 9, 20
+    g = torch.Generator().manual_seed(21 + c + w)
+    N = 2
     cur = torch.randn(N, 2 * c, h, w, generator=g)
     skip = torch.randn(N, c, 2 * h, 2 * w, generator=g)
     wt = torch.randn(2 * c, c, 2, 2, generator=g) / (2 * c) ** 0.5

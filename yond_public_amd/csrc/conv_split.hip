@@ -57,22 +57,27 @@ extern "C" int yond_split_debug_read(unsigned long long* host) {
 #define SPLIT_ABL 0          // timing-only ablations: 1 no global loads, 2 no weight DMA, 4 no epilogue, 8 no staging writes, 16 no MFMA
 #endif
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool K1 = false>
 struct SplitCfg {
     static constexpr int NT = 512;
     static constexpr int KC = 16;
-    static constexpr int TAPS = 9;
-    static constexpr int IH = (TH - 1) * STRIDE + 3;
-    static constexpr int IW = 31 * STRIDE + 3;
+    // K1: the decoder's 1x1 GEMM (ConvTranspose2d 2x2 + cat + 1x1 shortcut folded, engine.py) -- one tap, so a step takes
+    // THREE consecutive 16-channel chunks as pseudo-taps (a short step is all overhead); no halo
+    static constexpr int NPT = K1 ? 3 : 1;                           // 16-channel chunks per step
+    static constexpr int KSTEP = KC * NPT;
+    static constexpr int TAPS = K1 ? NPT : 9;
+    static constexpr int IH = K1 ? TH : (TH - 1) * STRIDE + 3;
+    static constexpr int IW = K1 ? 32 : 31 * STRIDE + 3;
     static constexpr int HALF = (IW + 1) / 2;
     static constexpr int TWP = STRIDE == 2 ? 2 * HALF : IW;
     static constexpr int PLANE = IH * TWP * 4 + 4;                  // floats; the last 16 bytes take the staging items past the tile
-    static constexpr int IN_FLOATS = 2 * PARTS * PLANE;
+    static constexpr int IN_FLOATS = NPT * 2 * PARTS * PLANE;       // planes [pseudo-tap][channel half][part]
+    static constexpr int PIX_ITEMS = IH * IW * 4;                    // staging items of one 16-channel chunk
     static constexpr int W_FLOATS = TAPS * 2 * PARTS * TN * 4;
     static constexpr int RG = TH / MW;                              // row groups of waves
     static constexpr int NCW = 8 / RG;                              // channel groups of waves
     static constexpr int NW = TN / 32 / NCW;                        // 32-channel blocks per wave
-    static constexpr int NITEM = IH * IW * 4;                       // 16-byte (4-channel) staging items per step
+    static constexpr int NITEM = NPT * IH * IW * 4;                 // 16-byte (4-channel) staging items per step
     static constexpr int NIN = (NITEM + NT - 1) / NT;
     static constexpr int NWV = W_FLOATS / 4;
     static constexpr int NWT = (NWV + NT - 1) / NT;
@@ -84,6 +89,7 @@ struct SplitCfg {
     static constexpr int W4_OFF = 2 * IN_FLOATS + NWB * W_FLOATS;   // floats: 4 x 32 weights of the fused output projection
     static constexpr int SMEM_BYTES = (W4_OFF + (TN == 32 ? 128 : 0)) * 4;   // (the 512 bytes are used by the O4 instantiation only)
     static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
+    static_assert(!K1 || (STRIDE == 1 && PIX_ITEMS % NT == 0), "1x1 mode: whole chunks per pass of the staging threads");
     static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
 };
 
@@ -100,9 +106,9 @@ __device__ __forceinline__ float split_silu(float x) {
 template <int N>
 __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB>;
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
     constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -118,7 +124,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     const int G = gridDim.x;
     const int lslot = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;   // XCD-contiguous runs
     const int Cin = d.C0 + d.C1;
-    const int nchunk = Cin / C::KC;
+    const int nchunk = Cin / C::KSTEP;                       // steps per tile
+    const int Cr = K1 ? d.Cout / 4 : d.Cout;                 // K1: channels of an OUTPUT pixel (GEMM N = 4 sub-positions x Cr)
     const int my_sl = tid & 3;                               // the thread's 4-channel slot of a pixel (512 % 4 == 0)
     const int my_plane = (my_sl >> 1) * PARTS * C::PLANE + (my_sl & 1) * 2;
 
@@ -126,16 +133,18 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
     for (int k = 0; k < C::NIN; ++k) {
         const int it = tid + k * C::NT;
-        const int pix = it / 4;
+        const int pt = it / C::PIX_ITEMS;                   // pseudo-tap (K1; 0 otherwise)
+        const int pix = (it % C::PIX_ITEMS) / 4;
         const int py = pix / C::IW, px = pix % C::IW;
         const int lp = (STRIDE == 2) ? py * C::TWP + (px & 1) * C::HALF + (px >> 1) : py * C::TWP + px;
-        in_lds[k] = my_plane + (it < C::NITEM ? lp : C::IH * C::TWP) * 4;
+        in_lds[k] = my_plane + (it < C::NITEM ? pt * 2 * PARTS * C::PLANE + lp * 4 : C::IH * C::TWP * 4);
     }
 
     struct Tile {
         int ct, n, ox0, oy0;
-        int goff[C::NIN];
-    };
+        int goff[C::NIN];                      // pixel offset into the NHWC source (-1: outside the image -> zeros)
+        int goff1[K1 ? C::NIN : 1];            // K1: pixel offset into src1, the skip tensor at the OUTPUT resolution, read at
+    };                                         // the sub-position (dy, dx) this tile's channel block stores to
     auto decode = [&](int t, Tile& T) {
         const int n = t / tiles_per_img;
         int b = t - n * tiles_per_img;
@@ -148,10 +157,15 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
         for (int k = 0; k < C::NIN; ++k) {
             const int it = tid + k * C::NT;
-            const int pix = it / 4;
+            const int pix = (it % C::PIX_ITEMS) / 4;
             const int py = pix / C::IW, px = pix % C::IW;
-            const int gy = T.oy0 * STRIDE - 1 + py, gx = T.ox0 * STRIDE - 1 + px;
-            T.goff[k] = (it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) ? ((n * d.H + gy) * d.W + gx) : -1;
+            const int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
+            const bool ok = it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            T.goff[k] = ok ? ((n * d.H + gy) * d.W + gx) : -1;
+            if constexpr (K1) {
+                const int sp = (T.ct * TN) / Cr;               // a channel tile never straddles two sub-positions
+                T.goff1[k] = ok ? ((n * 2 * d.H + 2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1)) : -1;
+            }
         }
     };
 
@@ -166,18 +180,25 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     }
     unsigned vin_ok[NSET] = {};
     // one 16-byte load of a set (item k); the source of the chunk is selected once per step (LoadSrc)
-    struct LoadSrc { const float* src; int Cs, cc; };
+    // source of a step's 16-channel chunks (K1: three of them, each from the low-resolution input or from the skip tensor)
+    struct LoadSrc { const float* src[C::NPT]; int Cs[C::NPT], cc[C::NPT]; bool hi[C::NPT]; };
     auto load_src = [&](int ch) {
         LoadSrc L;
-        const int c0 = ch * C::KC;
-        if (c0 < d.C0) { L.src = d.src0; L.Cs = d.C0; L.cc = c0; }
-        else { L.src = d.src1; L.Cs = d.C1; L.cc = c0 - d.C0; }
+#pragma unroll
+        for (int t = 0; t < C::NPT; ++t) {
+            const int c0 = (ch * C::NPT + t) * C::KC;
+            if (c0 < d.C0) { L.src[t] = d.src0; L.Cs[t] = d.C0; L.cc[t] = c0; L.hi[t] = false; }
+            else { L.src[t] = d.src1; L.Cs[t] = d.C1; L.cc[t] = c0 - d.C0; L.hi[t] = K1; }
+        }
         return L;
     };
     auto issue_load = [&](auto pc, auto kc, const Tile& T, const LoadSrc& L) {
         constexpr int P = decltype(pc)::value, k = decltype(kc)::value;
+        constexpr int t = K1 ? (k * C::NT) / C::PIX_ITEMS : 0;  // the item's chunk (K1: PIX_ITEMS is a multiple of the thread count)
         const bool ok = T.goff[k] >= 0;                        // outside the image: read pixel 0, zeroed at the LDS write
-        if (!(SPLIT_ABL & 1)) vin[P][k] = *(const f32x4*)(L.src + (size_t)(ok ? T.goff[k] : 0) * L.Cs + L.cc + my_sl * 4);
+        int po = T.goff[k];
+        if constexpr (K1) po = L.hi[t] ? T.goff1[k] : po;
+        if (!(SPLIT_ABL & 1)) vin[P][k] = *(const f32x4*)(L.src[t] + (size_t)(ok ? po : 0) * L.Cs[t] + L.cc[t] + my_sl * 4);
         if (k == 0) vin_ok[P] = 0;
         vin_ok[P] |= (ok ? 1u : 0u) << k;
     };
@@ -240,19 +261,20 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // weight fragments (dy) of a column held in registers and fetched one column ahead, pixel fragments two ahead.
     // MFMA order inside a group: h_w l_x, then h_w h_x, then l_w h_x -- the two that share an accumulator are never
     // back to back (the dependent-issue latency of v_mfma_f32_32x32x16_f16 exceeds its 32 cycles).
-    const int x_off = (lh * PARTS) * C::PLANE + ((rg * MW * STRIDE) * C::TWP + li) * 4;
+    const int x_off = (lh * PARTS) * C::PLANE + ((rg * MW * (K1 ? 1 : STRIDE)) * C::TWP + li) * 4;
     const int w_off = ((lh * PARTS) * TN + (cg * C::NW) * 32 + li) * 4;
     // (the step's cursor arithmetic -- `prep`, which sets wsrc_s / ls_s and may decode the next tile -- runs after the
     // first groups of MFMAs have been issued; memory instructions and staging start at group Q0)
     const float* wsrc_s = nullptr;
     const bool wave_hi = __builtin_amdgcn_readfirstlane(wave) >= 4;
-    LoadSrc ls_s = {nullptr, 0, 0};
+    LoadSrc ls_s = {};
     auto mfma_stage = [&](auto pc, auto fc, const float* buf, const float* wbuf, float* ob, float* wnext, const Tile& lt, auto&& prep)
         __attribute__((always_inline)) {
         typedef const __attribute__((address_space(3))) f16x8* lds_h8;
         const __attribute__((address_space(3))) float* xb = (const __attribute__((address_space(3))) float*)(buf + x_off);
         const __attribute__((address_space(3))) float* wb = (const __attribute__((address_space(3))) float*)(wbuf + w_off);
-        constexpr int R = (MW - 1) * STRIDE + 3, NQ = 3 * R, XD = 3, Q0 = 2, NQW = NQ - Q0;
+        // K1: the three 'columns' are the step's three 16-channel chunks, a row r serves output row m = r only
+        constexpr int R = K1 ? MW : (MW - 1) * STRIDE + 3, NQ = 3 * R, XD = 3, Q0 = 2, NQW = NQ - Q0;
         // weight fragments of a column: two sets (the next column is fetched during the current one), or -- three rows per
         // wave, register budget -- ONE set, each dy refilled for the next column right behind its last use (two groups ahead
         // of its next use)
@@ -262,19 +284,21 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         auto loadX = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int dx = q / R, r = q % R;
-            constexpr int xo = (STRIDE == 2) ? (dx & 1) * C::HALF + (dx >> 1) : dx;
+            constexpr int xo = K1 ? 0 : (STRIDE == 2) ? (dx & 1) * C::HALF + (dx >> 1) : dx;
+            constexpr int po = K1 ? dx * 2 * PARTS * C::PLANE : 0;         // K1: the chunk's planes
 #pragma unroll
-            for (int p = 0; p < PARTS; ++p) xr[q % XD][p] = *(lds_h8)(xb + p * C::PLANE + (r * C::TWP + xo) * 4);
+            for (int p = 0; p < PARTS; ++p) xr[q % XD][p] = *(lds_h8)(xb + po + p * C::PLANE + (r * C::TWP + xo) * 4);
         };
         auto loadW1 = [&](auto dc, auto yc) {
             constexpr int dx = decltype(dc)::value, dy = decltype(yc)::value;
+            constexpr int tap = K1 ? dx : dy * 3 + dx;
 #pragma unroll
             for (int nn = 0; nn < C::NW; ++nn)
 #pragma unroll
                 for (int p = 0; p < PARTS; ++p)
-                    wt[dx % WS][dy][nn][p] = *(lds_h8)(wb + (((dy * 3 + dx) * 2 * PARTS + p) * TN + nn * 32) * 4);
+                    wt[dx % WS][dy][nn][p] = *(lds_h8)(wb + ((tap * 2 * PARTS + p) * TN + nn * 32) * 4);
         };
-        auto loadW = [&](auto dc) { static_for<0, 3>([&](auto yc) { loadW1(dc, yc); }); };
+        auto loadW = [&](auto dc) { static_for<0, (K1 ? 1 : 3)>([&](auto yc) { loadW1(dc, yc); }); };
         loadW(IntC<0>{});
         loadX(IntC<0>{});
         loadX(IntC<1>{});
@@ -286,14 +310,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             constexpr bool wrep = WINPLACE && dx < 2 && wdy >= 0 && wdy <= 2;
             if constexpr (q + 2 < NQ) loadX(IntC<q + 2>{});
             if constexpr (wpre) loadW(IntC<dx + 1>{});
-            constexpr int nmf = (PARTS == 2 ? 3 : 1) * C::NW * split_pairs(MW, STRIDE, r);
+            constexpr int nmf = (PARTS == 2 ? 3 : 1) * C::NW * (K1 ? 1 : split_pairs(MW, STRIDE, r));
             if (!(SPLIT_ABL & 16)) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {                  // 0: h_w l_x   1: h_w h_x   2: l_w h_x
                     if (PARTS == 1 && a != 1) continue;
 #pragma unroll
                     for (int m = 0; m < MW; ++m) {
-                        const int dy = r - m * STRIDE;
+                        const int dy = K1 ? (m == r ? 0 : -1) : r - m * STRIDE;
                         if (dy < 0 || dy > 2) continue;
 #pragma unroll
                         for (int nn = 0; nn < C::NW; ++nn)
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             constexpr int nfin = (e_hi + 0) / 4 - (e_lo + 0) / 4;                     // items completed in this group
             // Issue order of the group: its LDS reads first (they are two groups / one column ahead of their use), then
             // each MFMA followed by a few of the vector instructions, then the LDS writes of a completed item.
-            constexpr int nrd = (q + 2 < NQ ? PARTS : 0) + (wpre ? 3 * C::NW * PARTS : 0);
+            constexpr int nrd = (q + 2 < NQ ? PARTS : 0) + (wpre ? (K1 ? 1 : 3) * C::NW * PARTS : 0);
             if constexpr (nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
             constexpr int nvalu = (e_hi - e_lo) * (PRE ? 7 : 2) + nfin * (PARTS == 2 ? 22 : 6);
             constexpr int vpm = (nvalu + nmf - 1) / nmf;
@@ -353,7 +377,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     constexpr int EPS = 36;                                   // floats per pixel of the scratch
     constexpr int EP_FLOATS = 8 * 32 * EPS;                   // 36,864 bytes: one weight buffer (TN 64) or part of an input image
     // (stride 2: short steps, no residual -- measured slower with the transpose and its extra barrier: 211 vs 175 us at level 0)
-    constexpr bool EP_FIT = STRIDE == 1 && EP_FLOATS <= (TN == 64 ? C::W_FLOATS : C::IN_FLOATS);
+    constexpr bool EP_IN_W = TN == 64 && !K1;                 // scratch = the weight buffer just consumed; else the input image
+    constexpr bool EP_FIT = STRIDE == 1 && EP_FLOATS <= (EP_IN_W ? C::W_FLOATS : C::IN_FLOATS);
     // Straight-line on purpose: a branch around a load (`res ? load : 0`) makes the compiler lose count of the outstanding
     // memory operations and wait with vmcnt(0) before EVERY store -- i.e. for the previous store (measured: 3.4-4.9
     // thousand cycles per tile).  So the variant (residual / scale / shift present) is chosen by ONE uniform switch
@@ -363,7 +388,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         const int u = lane & 7;
 #pragma unroll
         for (int nn = 0; nn < C::NW; ++nn) {
-            const int eoff = (d.ebatch ? T.n * d.Cout : 0) + T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
+            const int cu = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
+            const int eoff = (d.ebatch ? T.n * Cr : 0) + (K1 ? cu % Cr : cu);
             // (no branch around the loads: an absent vector is read from the weights and never used)
             pes[nn] = *(const f32x4*)(d.escale ? d.escale + eoff : d.wpk);
             pet[nn] = *(const f32x4*)(d.eshift ? d.eshift + eoff : d.wpk);
@@ -381,8 +407,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         }
         static_for<0, C::NW>([&](auto nc) __attribute__((always_inline)) {
             constexpr int nn = decltype(nc)::value;
-            const int cb = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
-            const int eoff = (d.ebatch ? T.n * d.Cout : 0) + cb;
+            const int cu = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
+            // K1: GEMM channel cu = sub-position sp x Cr + channel; the pixel goes to (2 y + sp/2, 2 x + sp%2) of the output
+            const int sp = K1 ? cu / Cr : 0, cb = K1 ? cu % Cr : cu;
+            const int pstep = K1 ? 2 * Cr : d.Cout;              // elements between horizontally adjacent pixels of the tile
+            const int eoff = (d.ebatch ? T.n * Cr : 0) + cb;
             const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
             (void)eoff;
             f32x4 es = one, et = zero4;                        // FiLM / bias vectors: requested at the start of the tile's last step
@@ -399,7 +428,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
                 for (int mm = 0; mm < MGN; ++mm) {
                     const int oy = T.oy0 + rg * MW + m0 + mm;
-                    rowoff[mm] = ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cb;
+                    if constexpr (K1) rowoff[mm] = ((long long)(T.n * 2 * d.Ho + 2 * oy + (sp >> 1)) * (2 * d.Wo) + 2 * T.ox0 + (sp & 1)) * Cr + cb;
+                    else rowoff[mm] = ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cb;
                     if constexpr (OUT4) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -411,7 +441,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;      // masked lanes read element 0..
-                        if constexpr (HAS_RES) rr[mm][j] = *(const f32x4*)(d.res + (ok ? rowoff[mm] + (long long)(pj + 8 * j) * d.Cout : 0));
+                        if constexpr (HAS_RES) rr[mm][j] = *(const f32x4*)(d.res + (ok ? rowoff[mm] + (long long)(pj + 8 * j) * pstep : 0));
                         else rr[mm][j] = zero4;
                     }
                 }
@@ -470,7 +500,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                             const long long gp = (long long)(T.n * d.Ho + oy) * d.Wo + T.ox0 + pj + 8 * j;
                             if (ok && u < 4) d.out4_dst[gp * 4 + cu] = t;
                         } else {
-                            if (ok) *(f32x4*)(d.dst + rowoff[mm] + (long long)(pj + 8 * j) * d.Cout) = v;
+                            if (ok) *(f32x4*)(d.dst + rowoff[mm] + (long long)(pj + 8 * j) * pstep) = v;
                         }
                     }
                 }
@@ -627,7 +657,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             // step's DMA and staging writes (of OTHER waves) out of it until every wave has read its block back
             if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) {
                 if constexpr (EP_FIT) {
-                    float* scr = TN == 64 ? w0 : ibuf;
+                    float* scr = EP_IN_W ? w0 : ibuf;
                     const int flags = (d.res ? 1 : 0) | (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
                     static_for<0, 8>([&](auto fcx) __attribute__((always_inline)) {
                         if (flags == decltype(fcx)::value) epilogue(fcx, cur, scr);
@@ -675,12 +705,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead loads / DMA of the steps past the end
 }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false>
 static int launch_split(const YondConvDesc& d, hipStream_t st) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB>;
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
     static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4>;
+    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -695,17 +725,36 @@ static int launch_split(const YondConvDesc& d, hipStream_t st) {
 }
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
+// ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has
+// shuffle = 1): 48-channel steps, 64-wide tiles that must not straddle two sub-positions
 extern "C" int yond_conv_split_supported(int ksize, int stride, int cin, int cout) {
+    if (ksize == 1) return (stride == 1 && cin > 0 && cin % 48 == 0 && cout > 0 && cout % 4 == 0 && (cout / 4) % 64 == 0) ? 64 : 0;
     if (ksize != 3 || (stride != 1 && stride != 2) || cin <= 0 || cout <= 0 || cin % 16 != 0 || cout % 32 != 0) return 0;
     if (stride == 2) return cout % 64 == 0 ? 64 : 0;
     return cout % 64 == 0 ? 64 : 32;
 }
 
 // OIHW fp32 weights -> the kernel's LDS image order [cout tile][cin chunk of 16][tap][channel half][part][tn][8 halves];
-// parts = 2: h = fp16(w), l = fp16((w - h) * 2^11); parts = 1: h only.  dst: cout*cin*9 * parts/2 floats.
+// parts = 2: h = fp16(w), l = fp16((w - h) * 2^11); parts = 1: h only.  dst: cout*cin*k*k * parts/2 floats.
+// ksize 1 (w = the re-indexed [4*cout][cin][1][1] matrix of a transposed convolution): [cout tile][step of 48 channels]
+// [chunk of 16][channel half][part][tn][8 halves].
 extern "C" int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst) {
-    if (!w || !dst || ksize != 3 || (tn != 32 && tn != 64) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
+    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
     _Float16* o = (_Float16*)dst;
+    if (ksize == 1) {
+        if (cin % 48 != 0) return YOND_EINVAL;
+        for (int ct = 0; ct < cout / tn; ++ct)
+            for (int ch = 0; ch < cin / 16; ++ch)              // (step, chunk) in order = chunk index
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int p = 0; p < parts; ++p)
+                        for (int j = 0; j < tn; ++j)
+                            for (int e = 0; e < 8; ++e) {
+                                const float v = w[(size_t)(ct * tn + j) * cin + ch * 16 + hh * 8 + e];
+                                const _Float16 h = (_Float16)v;
+                                *o++ = p == 0 ? h : (_Float16)((v - (float)h) * 2048.0f);
+                            }
+        return YOND_OK;
+    }
     const int taps = 9;
     for (int ct = 0; ct < cout / tn; ++ct)
         for (int ch = 0; ch < cin / 16; ++ch)
@@ -725,9 +774,14 @@ extern "C" int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin
 int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     const int parts = d.algo == 3 ? 2 : 1;
     const int tn = yond_conv_split_supported(d.ksize, d.stride, d.C0 + d.C1, d.Cout);
-    if (!tn || d.shuffle || d.C0 % 16 != 0 || d.C1 % 16 != 0) return YOND_EUNSUPPORTED;
+    if (!tn || d.C0 % 16 != 0 || d.C1 % 16 != 0 || (d.shuffle != 0) != (d.ksize == 1)) return YOND_EUNSUPPORTED;
     if (d.tn != tn) return YOND_EINVAL;                         // the layout the weights were packed for
     if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
+    if (d.ksize == 1) {
+        // the decoder GEMM: low-resolution input (C0) + skip tensor at the output resolution (C1), pixel-shuffle store
+        if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.Ho != d.H || d.Wo != d.W) return YOND_EUNSUPPORTED;
+        return launch_split<1, 8, 64, 2, 2, 3, false, false, true>(d, st);
+    }
     if (d.stride == 2) {
         if (d.Ho != (d.H + 1) / 2 || d.Wo != (d.W + 1) / 2 || d.pre_act) return YOND_EINVAL;
         // stride 2: 4 x 32 output pixels read 9 x 65 input pixels -- two weight buffers fit beside the two input images

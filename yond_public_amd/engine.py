@@ -117,8 +117,8 @@ class _PackedConv:
     def split(self, parts=2):
         """(tn, weights packed for the split-operand fp16-MFMA kernel) or None when the layer does not fit it."""
         lib = L.load()
-        if self.shuffle:
-            return None
+        if self.shuffle != (self.ksize == 1) or (self.shuffle and (parts != 2 or os.environ.get('YOND_SPLIT_1X1', '1') == '0')):
+            return None                     # ksize 1: the decoder's pixel-shuffle GEMM only (48-channel steps, >= 64 channels)
         tn = int(lib.yond_conv_split_supported(self.ksize, self.stride, self.cinp, self.gemm_n))
         if not tn:
             return None
@@ -300,7 +300,7 @@ class DenoiserPlan:
         if prof is not None:
             tag = f"conv_wino_kernel<{tn}>" if d.algo == 1 else f"conv_mfma_kernel<{pc.ksize},{pc.stride},8,{tn},{kc}>"
             if d.algo in (3, 4):
-                tag = f"conv_split_kernel<{pc.stride},{tn},{5 - d.algo}>"
+                tag = f"conv_split_kernel<{pc.stride if pc.ksize == 3 else 'k1'},{tn},{5 - d.algo}>"
             if d.algo == 2:
                 tag += "/f16"
             if d.algo == 5:

@@ -27,7 +27,8 @@ def short(name):
     m = re.search(r"conv_split_kernel<([^>]*)>", name)
     if m:
         a = [x.strip() for x in m.group(1).split(',')]
-        return f"conv_split_kernel<{a[0]},{a[2]},{a[4]}>"           # stride, channel-tile width, parts (bench.py's tag)
+        k1 = len(a) > 8 and a[8] == 'true'                         # the decoder's 1x1 GEMM form
+        return f"conv_split_kernel<{'k1' if k1 else a[0]},{a[2]},{a[4]}>"   # stride, channel-tile width, parts (bench.py's tag)
     m = re.search(r"conv_wino_kernel<\s*(\d+)", name)
     if m:
         return f"conv_wino_kernel<{m.group(1)}>"

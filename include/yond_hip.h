@@ -151,7 +151,10 @@ int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, fl
  * l = fp16((a - h) * 2^11); a*w = h_a h_w + 2^-11 (h_a l_w + l_a h_w) on v_mfma_f32_32x32x16_f16 with fp32
  * accumulation -- 22-23 significant bits per operand, error vs a float64 convolution no larger than the fp32 kernels'.
  * Precondition: |activations|, |weights| < 65504.  yond_conv_split_supported: channel-tile width (64, 32) or 0.
- * Weights: w OIHW [cout][cin][3][3] -> dst, cout*cin*9*parts/2 floats (packed halves). */
+ * Weights: w OIHW [cout][cin][3][3] -> dst, cout*cin*9*parts/2 floats (packed halves).
+ * ksize 1 (descriptor: ksize 1, shuffle 1, algo 3): the decoder's pixel-shuffle GEMM -- ConvTranspose2d 2x2 (src0, C0, low
+ * resolution) + the skip tensor (src1, C1, at the OUTPUT resolution) + 1x1 shortcut folded into one weight matrix
+ * [4*cout][C0+C1] (archs/Unet.py:445-463, modules.py:163-196) -- in the same kernel, for (C0+C1) % 48 == 0 and cout % 64 == 0. */
 int yond_conv_split_supported(int ksize, int stride, int cin, int cout);
 int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst);
 

@@ -17,7 +17,8 @@
 //
 // Structure: persistent 512-thread workgroups (two waves per SIMD), tile = TH x 32 output pixels x TN output
 // channels, walked in 16-channel steps with ONE barrier per step.  Shapes (STRIDE, TH, TN, rows per wave MW):
-// (1,12,64,3) and (1,8,64,2) for >= 64 channels, (1,16,32,2) for 32 channels, (2,4,64,1) for stride 2.  LDS:
+// (1,12,64,3) and (1,8,64,2) for >= 64 channels, (1,16,32,2) for 32 channels, (2,4,64,1) for stride 2; K1: the decoder's
+// 1x1 pixel-shuffle GEMM with three 16-channel chunks per step in place of the three tap columns.  LDS:
 //   input   two images of planes [channel half 0..1][part h, l][IH x TWP pixels] x 16 bytes (8 halves): the 32 lanes of
 //           a fragment read consecutive pixels = consecutive 16-byte units (conflict-free, no padding); stride 2 keeps
 //           even and odd columns in separate halves of a row so a tap still reads consecutive pixels

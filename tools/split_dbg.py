@@ -7,7 +7,7 @@ from yond_public_amd import _lib as L
 from yond_public_amd.engine import _PackedConv, DenoiserPlan
 lib = L.load()
 plan = DenoiserPlan.__new__(DenoiserPlan); plan.lib, plan.dev, plan.prof = lib, torch.device('cuda:0'), None
-Cc, h, w = 128, 376, 504
+Cc, h, w = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (128, 376, 504)
 g = torch.Generator().manual_seed(0)
 pc = _PackedConv(plan.dev, torch.randn(Cc, Cc, 3, 3, generator=g) / (3 * Cc ** 0.5), torch.randn(Cc, generator=g), 3, 1, [Cc])
 x = torch.randn(1, h, w, Cc, device='cuda'); dst = torch.empty(1, h, w, Cc, device='cuda')

@@ -74,8 +74,8 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)      # 20 frames of 5 ms: the first frame of a stream has no overlap partner
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="once", choices=["once", "iter"])
     ap.add_argument("--arch", default="GuidedResUnet", choices=list(ARCHS))
     ap.add_argument("--height", type=int, default=3000)

@@ -5,7 +5,10 @@
 
 A step is one pass of the whole per-image path over one synthetic 3000 x 4000 Bayer frame that is already
 resident in HBM (BASELINE.json configs[1]): self-calibrated noise-level estimation, bias-LUT build,
-pack+VST, SNR-Net (GuidedResUnet nf=32, fp32 MFMA) forward, inverse VST+unpack.  Frames are sharded one
+pack+VST, SNR-Net (GuidedResUnet nf=32; fp32 results, convolutions as fp32-accurate split-operand products on the fp16
+MFMA -- `--precision fp32-mfma` keeps them on the fp32-input MFMA) forward, inverse VST+unpack.  For the 'once' pipeline
+the K steps run through pipeline.denoise_stream: the NLE of frame k+1 on a second HIP stream under the convolutions
+of frame k (`--sequential`: one frame at a time).  Frames are sharded one
 per GPU (image parallel, weak scaling); there is no data-path collective, the only RCCL traffic is the
 barrier / max-over-ranks of the timing and the final PSNR reduction.  Prints ONE JSON line on rank 0.
 """
@@ -153,8 +156,8 @@ def main():
         stage_prof, P.PROF = P.PROF, None
     stage_steps = 1
 
-    # dominant kernel: the 3x3 stride-1 fp32-MFMA convolution that takes the most time (18 launches per forward, 91 % of
-    # the MACs: the Winograd kernel on the 64..512-channel layers, the direct kernel on the 32-channel ones)
+    # dominant kernel: the 3x3 stride-1 convolution kernel that takes the most time (18 launches per forward, 91 % of the
+    # MACs: the split-operand kernel's 64-channel-tile shape; with --precision fp32-mfma the Winograd kernel)
     per = {}
     for tag, flops, e0, e1 in prof:
         ms = e0.elapsed_time(e1)

@@ -113,8 +113,11 @@ def test_denoise_stream_matches_iterdenoise():
     frames = [torch.from_numpy(S.synth_noisy(256, 320, 3.0 + i, 5.0 + 2 * i, 10 + i)[0]).to(dev) for i in range(4)]
     seq = [P.IterDenoise(f, net, arch, pipe) for f in frames]
     got = list(P.denoise_stream(iter(frames), net, arch, pipe))
+    got_host = list(P.denoise_stream((f.cpu().numpy() for f in frames), net, arch, pipe, device=dev))    # host arrays are uploaded in order
     torch.cuda.synchronize()
-    assert len(got) == len(seq)
+    assert len(got) == len(seq) == len(got_host)
+    for a_, b_ in zip(got_host, seq):
+        assert float((a_['raw_dns'][0] - b_['raw_dns'][0]).abs().max()) <= 5e-6
     for a_, b_ in zip(got, seq):
         assert np.allclose(np.asarray(a_['regs'], np.float64), np.asarray(b_['regs'], np.float64), rtol=1e-10, atol=0)
         assert np.allclose(np.asarray(a_['params'], np.float64), np.asarray(b_['params'], np.float64), rtol=1e-10, atol=0)

@@ -502,8 +502,7 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
 
-    def estimate(f, ready):                # phase 1 on the side stream; returns host scalars only
-        lr = _dev(f, device)
+    def estimate(lr, ready):               # phase 1 on the side stream; returns host scalars only
         side.wait_event(ready)             # the frame as it stood when it was handed in -- NOT the work queued since
         with torch.cuda.stream(side):
             lr_max_dev = lr.max()
@@ -513,14 +512,15 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
 
     it = iter(frames)
     try:
-        f = next(it)
+        f = _dev(next(it), device)         # (a host array is uploaded on the main stream: the event below is behind it)
     except StopIteration:
         return
     nxt = estimate(f, main.record_event())
     while nxt is not None:
         lr, reg, lr_max = nxt
         try:                               # take the next frame (and mark the main stream) BEFORE queuing this one's network
-            f_next, ready = next(it), main.record_event()
+            f_next = _dev(next(it), device)
+            ready = main.record_event()
         except StopIteration:
             f_next = None
         pp = dict(p0)

@@ -1,37 +1,39 @@
 #!/usr/bin/env python
 """bench.py -- YOND hot path on MI355X: Bayer megapixels/s end-to-end (NLE + VST + denoise + iVST).
 
-    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
 
-A step is one pass of the whole per-image path over one synthetic 3000 x 4000 Bayer frame that is already
-resident in HBM (BASELINE.json configs[1]): self-calibrated noise-level estimation, bias-LUT build,
-pack+VST, SNR-Net (GuidedResUnet nf=32; fp32 results, convolutions as fp32-accurate split-operand products on the fp16
-MFMA -- `--precision fp32-mfma` keeps them on the fp32-input MFMA) forward, inverse VST+unpack.  For the 'once' pipeline
-the K steps run through pipeline.denoise_stream: the NLE of frame k+1 on a second HIP stream under the convolutions
-of frame k (`--sequential`: one frame at a time).  Frames are sharded one
-per GPU (image parallel, weak scaling); there is no data-path collective, the only RCCL traffic is the
-barrier / max-over-ranks of the timing and the final PSNR reduction.  Prints ONE JSON line on rank 0.
+`--gpus N` with N > 1 and no torchrun environment: this process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (before anything touches the GPU) and
+relays rank 0's JSON line; under torchrun (RANK / WORLD_SIZE set) it is one rank of the job.
+
+A step is one pass of the whole per-image path over one BATCH of synthetic 3000 x 4000 Bayer frames that are already
+resident in HBM (BASELINE.json configs[1]; `--frames-per-step`, default 24, so that the K = 20 timed steps of the driver
+span >= 2 s): per frame the self-calibrated noise-level estimation, bias-LUT build, pack+VST, SNR-Net forward
+(GuidedResUnet nf=32; fp32 results, convolutions as fp32-accurate split-operand products on the fp16 MFMA --
+`--precision fp32-mfma` keeps them on the fp32-input MFMA), inverse VST + unpack.  'once' pipelines stream the frames
+through pipeline.denoise_stream (NLE of frame k+1 on a second HIP stream under the convolutions of frame k); the
+per-frame latency of SURVEY section 8d (one frame at a time, resident -> resident) is measured right behind the timed region
+and reported as `sequential` on the same line.  `--mode iter`: the shipped two-round pipeline (YOND_SIDD.py:419-472), one
+frame at a time, asserted to run BOTH rounds.  Frames are sharded one stream per GPU (image parallel, weak scaling);
+there is no data-path collective, the only RCCL traffic is the barrier / max-over-ranks of the timing and the final
+PSNR reduction.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from yond_public_amd import distributed as D          # noqa: E402
-from yond_public_amd import pipeline as P             # noqa: E402
-from yond_public_amd import synthetic as S            # noqa: E402
-from yond_public_amd import archs as A                # noqa: E402
-from yond_public_amd import _lib as L                 # noqa: E402
-
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16 MFMA (MI355X_MICROARCH.md)
-PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
 PEAK_HBM_GBPS = 8000.0
 
 ARCHS = {
@@ -40,60 +42,176 @@ ARCHS = {
 }
 
 
-def cpu_baseline(arch, mode, seed, threads):
-    """The oracle (CPU restatement of the reference path) timed on the host, on a bounded sample of the
-    same workload.  Test infrastructure used ONLY as the reported baseline."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=0,
+                    help="frames per step and GPU (0 = default: 24 for 'once', 12 for 'iter', the batch size with --batch)")
+    ap.add_argument("--mode", default="once", choices=["once", "iter"])
+    ap.add_argument("--arch", default="GuidedResUnet", choices=list(ARCHS))
+    ap.add_argument("--cfg", type=int, default=2, choices=[2, 4, 5],
+                    help="BASELINE.json config: 2 (headline) one 3000x4000 frame at a time, SNR-Net; 4 UNetSeeInDark, batch 8 of "
+                         "3000x4000 in one forward; 5 low light, no black-level clip, 4000x6000, fp16 MFMA conv path")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0, help="frames per batched forward (cfg 4: 8)")
+    ap.add_argument("--weights", default="denoising", choices=["denoising", "procedural"],
+                    help="denoising: synthetic.denoising_state_dict (a real, weak denoiser: round 2 of 'iter' runs, PSNR is "
+                         "meaningful); procedural: seeded random weights (round 2 ends at the reference's beta1 < 0 guard)")
+    ap.add_argument("--distinct-frames", type=int, default=3, help="resident frames cycled through (different noise seeds)")
+    ap.add_argument("--min-warmup-s", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (no sequential / fp32-mfma / parity legs)")
+    ap.add_argument("--sequential", action="store_true", help="time one frame at a time (IterDenoise) instead of the two-stream driver")
+    ap.add_argument("--no-kernel-events", action="store_true", help="experiments: no HIP events around the kernels (no roofline objects)")
+    ap.add_argument("--precision", default=None, choices=["fp32", "fp32-mfma", "fp16"],
+                    help="fp32 (headline): fp32 results, 3x3 convolutions as fp32-accurate split-operand products on the fp16 MFMA; "
+                         "fp32-mfma: every convolution on the fp32-input MFMA; fp16: BASELINE cfg 5 (not the headline configuration)")
+    a = ap.parse_args(argv)
+    if a.cfg == 4:
+        a.arch = 'UNetSeeInDark'
+        a.batch = a.batch or 8
+    if a.cfg == 5:
+        a.precision = a.precision or 'fp16'
+        a.height, a.width = a.height or 4000, a.width or 6000
+    a.precision = a.precision or 'fp32'
+    a.height, a.width = a.height or 3000, a.width or 4000
+    if not a.frames_per_step:
+        a.frames_per_step = a.batch if a.batch else (24 if a.mode == "once" else 12)
+        if a.cfg == 5:
+            a.frames_per_step = 12
+    if a.batch and a.frames_per_step % a.batch:
+        ap.error("--frames-per-step must be a multiple of --batch")
+    return a
+
+
+def spawn_ranks(a, argv):
+    """--gpus N without a torchrun environment: start the N ranks as a child job and relay its output.  Runs before any
+    HIP call of this process (never re-exec a process that has initialised the GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"bench.py: starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+class SclkSampler(threading.Thread):
+    """Shader clock while the timed region runs: the active level of pp_dpm_sclk (sysfs), sampled every 50 ms; the busiest
+    card's mean is reported.  (The in-kernel clock reads up to ~10 % below it, MI355X_MICROARCH.md 'DVFS give-back'.)"""
+
+    def __init__(self):
+        super().__init__(daemon=True)
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.samples = {f: [] for f in self.files}
+        self.stop_flag = False
+
+    def run(self):
+        while not self.stop_flag and self.files:
+            for f in self.files:
+                try:
+                    for line in open(f).read().splitlines():
+                        if line.rstrip().endswith('*'):
+                            self.samples[f].append(float(line.split(':')[1].strip().rstrip('*').strip().lower().replace('mhz', '')))
+                except Exception:
+                    pass
+            time.sleep(0.05)
+
+    def result(self):
+        self.stop_flag = True
+        means = [sum(v) / len(v) for v in self.samples.values() if v]
+        if not means:
+            return None
+        return {"mean_mhz": round(max(means), 1), "samples": max(len(v) for v in self.samples.values()),
+                "source": "pp_dpm_sclk (sysfs), busiest card, during the timed region"}
+
+
+def cpu_baseline_and_parity(a, arch, dev, net_factory):
+    """The oracle (CPU restatement of the reference path; test infrastructure used ONLY as the reported baseline and as
+    the checker of the parity leg) on a bounded sample of the workload, at 1 thread (the reference pins 1 thread,
+    utils/utils.py:2-6) and on all host cores; then the HIP path on the same sample frame and weights, compared with the
+    oracle's output."""
+    import numpy as np
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import yond_oracle as O
+    from yond_public_amd import pipeline as P
     H, W = 2048, 3072
-    noisy, _ = O.synth_noisy(H, W, 4.0, 6.0, 0)
-    sd = O.procedural_state_dict(arch, seed)
-    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': mode, 'max_iter': 1, 'full_dn': True,
+    noisy, clean = O.synth_noisy(H, W, 4.0, 6.0, 0, clip=(a.cfg != 5))
+    sd = O.denoising_state_dict(arch, 0) if a.weights == "denoising" else O.procedural_state_dict(arch, 0)
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': a.mode, 'max_iter': 1, 'full_dn': True,
             'collab_sidd256': False}
     old = torch.get_num_threads()
-    torch.set_num_threads(threads)
-    t0 = time.perf_counter()
-    O.IterDenoise(noisy, arch, sd, pipe)
-    dt = time.perf_counter() - t0
+    ncores = os.cpu_count() or 1
+    runs = {}
+    for threads in (1, ncores):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        ref = O.IterDenoise(noisy, arch, sd, pipe)
+        runs[threads] = time.perf_counter() - t0
     torch.set_num_threads(old)
-    return {"value": H * W / 1e6 / dt, "unit": "Bayer MP/s", "cores": threads, "kind": "port",
-            "sample": f"one {H}x{W} synthetic Bayer frame, same pipeline ('{mode}'), oracle/yond_oracle.py "
-                      f"(NumPy/SciPy + PyTorch-CPU), {dt:.1f} s"}
+    what = (f"one {H}x{W} synthetic Bayer frame, same pipeline ('{a.mode}', {len(ref['raw_dns'])} pass(es)) and weights, "
+            f"oracle/yond_oracle.py (NumPy/SciPy + PyTorch-CPU)")
+    base = {"value": round(H * W / 1e6 / runs[1], 4), "unit": "Bayer MP/s", "cores": 1, "kind": "port",
+            "sample": f"{what}, {runs[1]:.1f} s",
+            "all_cores": {"value": round(H * W / 1e6 / runs[ncores], 4), "unit": "Bayer MP/s", "cores": ncores,
+                          "sample": f"the same, torch.set_num_threads({ncores}), {runs[ncores]:.1f} s"}}
+    net = net_factory(a.precision)
+    res = P.IterDenoise(torch.from_numpy(noisy).to(dev), net, arch, pipe)
+    parity = {"sample": f"{H}x{W} frame of cpu_baseline", "passes": len(res['raw_dns'])}
+    if len(res['raw_dns']) != len(ref['raw_dns']):
+        parity["error"] = f"HIP ran {len(res['raw_dns'])} passes, oracle {len(ref['raw_dns'])}"
+    else:
+        got = res['raw_dns'][-1].cpu().numpy().astype(np.float64)
+        want = np.asarray(ref['raw_dns'][-1], np.float64)
+        mse = float(np.mean((got - want) ** 2))
+        parity.update({
+            "max_abs_vs_oracle": float(np.max(np.abs(got - want))),
+            "psnr_hip_vs_oracle_db": round(10 * np.log10(1.0 / max(mse, 1e-30)), 2),
+            "psnr_vs_clean_db": {"hip": round(O.psnr(got, clean), 4), "oracle": round(O.psnr(want, clean), 4)},
+            "psnr_delta_vs_oracle_db": round(O.psnr(got, clean) - O.psnr(want, clean), 6),
+            "regs_hip": [[float(v) for v in r] for r in res['regs']],
+            "regs_oracle": [[float(v) for v in r] for r in ref['regs']]})
+    return base, parity
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected separately, gfx950 corrections applied by tools/pmc_traffic.py); None if not collected."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    try:
-        t = json.load(open(path)).get(kernel)
-        return t and {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "unit": "B", "source": "profiles/r01_pmc_traffic.json"}
-    except Exception:
-        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path)).get(kernel)
+            if t:
+                return {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "unit": "B", "source": "profiles/" + os.path.basename(path)}
+        except Exception:
+            pass
+    return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)      # 20 frames of 5 ms: the first frame of a stream has no overlap partner
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="once", choices=["once", "iter"])
-    ap.add_argument("--arch", default="GuidedResUnet", choices=list(ARCHS))
-    ap.add_argument("--height", type=int, default=3000)
-    ap.add_argument("--width", type=int, default=4000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sequential", action="store_true", help="one frame at a time (IterDenoise) instead of the two-stream driver")
-    ap.add_argument("--no-kernel-events", action="store_true", help="experiments: no HIP events around the kernels (no roofline objects)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-mfma", "fp16"],
-                    help="fp32 (headline): fp32 results, 3x3 convolutions as fp32-accurate split-operand products on the fp16 MFMA; "
-                         "fp32-mfma: every convolution on the fp32-input MFMA; fp16: BASELINE cfg 5 (not the headline configuration)")
-    a = ap.parse_args()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and env_world is None:
+        sys.exit(spawn_ranks(a, argv))
+    if env_world is not None and int(env_world) != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={env_world}; launch with --nproc-per-node {a.gpus}")
+
+    import numpy as np
+    import torch
+    from yond_public_amd import distributed as D
+    from yond_public_amd import pipeline as P
+    from yond_public_amd import synthetic as S
+    from yond_public_amd import archs as A
+    from yond_public_amd import _lib as L
 
     rank, local, world = D.init()
-    if world != a.gpus and rank == 0:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local)
@@ -101,32 +219,61 @@ def main():
     L.load()
 
     arch = ARCHS[a.arch]
-    net = getattr(A, arch['name'])(dict(arch, precision=a.precision))
-    net.load_state_dict(S.procedural_state_dict(net, 0))
-    net = net.to(dev).eval()
+
+    def make_net(precision):
+        net = getattr(A, arch['name'])(dict(arch, precision=precision))
+        net.load_state_dict(S.denoising_state_dict(net, 0) if a.weights == "denoising" else S.procedural_state_dict(net, 0))
+        return net.to(dev).eval()
+
+    net = make_net(a.precision)
     H, W = a.height, a.width
-    noisy, clean = S.synth_noisy(H, W, 4.0, 6.0, rank)
-    frame = torch.from_numpy(noisy).to(dev)
-    clean_d = torch.from_numpy(clean).to(dev)
+    clip = a.cfg != 5                                     # cfg 5: no black-level clip (negative DN reach the VST)
+    expo = 0.2 if a.cfg == 5 else 1.0                     # cfg 5: low light
+    frames, cleans = [], []
+    for i in range(max(1, a.distinct_frames)):
+        if a.cfg == 5:
+            rng = np.random.default_rng(1997 + 1000 * rank + i)
+            clean = (S.synth_clean(H, W) * expo).astype(np.float32)
+            noisy = ((rng.poisson(clean * 959.0 / 4.0) * 4.0 + rng.normal(0.0, 25.0, clean.shape)) / 959.0).astype(np.float32)
+        else:
+            noisy, clean = S.synth_noisy(H, W, 4.0, 6.0, 1000 * rank + i, clip=clip)
+        frames.append(torch.from_numpy(noisy).to(dev))
+        cleans.append(torch.from_numpy(clean).to(dev))
     pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': a.mode, 'max_iter': 1, 'full_dn': True,
             'collab_sidd256': False}
+    n_pass = 2 if a.mode == "iter" else 1
+    stream_driver = a.mode == "once" and not a.sequential and not a.batch
+    F = a.frames_per_step
 
-    def step():
-        return P.IterDenoise(frame, net, arch, pipe)
+    def one(frame, netx=None):
+        res = P.IterDenoise(frame, netx or net, arch, pipe)
+        if len(res['raw_dns']) != n_pass:
+            raise SystemExit(f"bench.py: pipeline '{a.mode}' ran {len(res['raw_dns'])} pass(es), expected {n_pass} "
+                             f"(regs {res['regs']}): with --weights procedural the reference's guard ends round 2")
+        return res
 
-    def run(nsteps):
-        """nsteps passes of the hot path; 'once' mode through the two-stream driver (the NLE of frame k+1 overlaps the
-        convolutions of frame k), unless --sequential."""
+    def run(nframes, sequential=False):
+        """nframes passes of the hot path over the resident frames (cycled)."""
         last = None
-        if a.sequential:
-            for _ in range(nsteps):
-                last = step()
-        else:
-            for last in P.denoise_stream((frame for _ in range(nsteps)), net, arch, pipe):
+        if a.batch:
+            for b in range(nframes // a.batch):
+                last = P.IterDenoiseBatch([frames[(b * a.batch + j) % len(frames)] for j in range(a.batch)], net, arch, pipe)
+        elif stream_driver and not sequential:
+            for last in P.denoise_stream((frames[i % len(frames)] for i in range(nframes)), net, arch, pipe):
                 pass
+        else:
+            for i in range(nframes):
+                last = one(frames[i % len(frames)])
         return last
 
-    res = run(a.warmup)
+    # warm-up: W steps, continued until --min-warmup-s has passed (clocks and caches settle)
+    t_w = time.perf_counter()
+    done = 0
+    while done < a.warmup or (time.perf_counter() - t_w < a.min_warmup_s and done < 50 * max(a.warmup, 1)):
+        res = run(F)
+        torch.cuda.synchronize()
+        done += 1
+    warm_s = time.perf_counter() - t_w
     plan = P._plan_of(net, dev)
     torch.cuda.synchronize()
     D.barrier()
@@ -137,24 +284,50 @@ def main():
     is33 = lambda t: t.startswith("conv_mfma_kernel<3,1") or t.startswith("conv_wino_kernel") or t.startswith("conv_split_kernel<1,")
     plan.prof = None if a.no_kernel_events else []
     plan.prof_only = is33
+    sclk = SclkSampler() if rank == 0 else None
+    if sclk:
+        sclk.start()
     t0 = time.perf_counter()
-    res = run(a.steps)
+    for _ in range(a.steps):
+        res = run(F)
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    sclk_res = sclk.result() if sclk else None
     prof, plan.prof = plan.prof or [], None
     plan.prof_only = None
-    stage_prof = []
-    prof_all = []
+    n_timed = a.steps * F
+    last_frame = frames[(n_timed - 1) % len(frames)]
+    last_clean = cleans[(n_timed - 1) % len(frames)]
+
+    # one frame at a time (wall time from 'noisy frame resident' to 'denoised frame resident')
+    seq = None
+    if stream_driver and not a.no_extras:
+        torch.cuda.synchronize()
+        D.barrier()
+        t1 = time.perf_counter()
+        n_seq = 0
+        while n_seq < 20 or time.perf_counter() - t1 < 1.0:
+            one(frames[n_seq % len(frames)])
+            torch.cuda.synchronize()
+            n_seq += 1
+        el = D.max_over_ranks(time.perf_counter() - t1, dev)
+        seq = {"value": round(world * n_seq * H * W / 1e6 / el, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el / n_seq * 1e3, 3),
+               "frames": n_seq, "definition": "IterDenoise one frame at a time, synchronised after every frame"}
+
+    stage_prof, prof_all = [], []
     if not a.no_kernel_events:
         plan.prof = []
         P.PROF = []
-        step()
+        if a.batch:
+            run(a.batch)
+        else:
+            one(last_frame)
         torch.cuda.synchronize()
         prof_all, plan.prof = plan.prof, None
         stage_prof, P.PROF = P.PROF, None
-    stage_steps = 1
+    inst_frames = a.batch or 1
 
     # dominant kernel: the 3x3 stride-1 convolution kernel that takes the most time (18 launches per forward, 91 % of the
     # MACs: the split-operand kernel's 64-channel-tile shape; with --precision fp32-mfma the Winograd kernel)
@@ -176,8 +349,7 @@ def main():
                 "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
         if dom.startswith("conv_wino_kernel"):
             # Winograd F(2x2,3x3) issues 16 multiplications per patch where the direct algorithm has 36: `achieved`
-            # counts the ALGORITHMIC flops of the convolution (it can exceed the matrix-core peak); the flops the MFMA
-            # unit really executes are 16/36 of that
+            # counts the ALGORITHMIC flops of the convolution; the flops the MFMA unit really executes are 16/36 of that
             roof["algorithm"] = "winograd F(2x2,3x3): 16/36 of the direct multiplications, fp32 throughout"
             roof["mfma_issued_tflops"] = round(ach * 16.0 / 36.0, 2)
             roof["mfma_issued_frac"] = round(ach * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS, 4)
@@ -188,7 +360,6 @@ def main():
                                  "bits), 3 v_mfma_f32_32x32x16_f16 per fp32 product block, fp32 accumulate")
             roof["mfma_issued_tflops"] = round(3.0 * ach, 2)
             roof["mfma_issued_frac"] = round(3.0 * ach / PEAK_F16_MFMA_TFLOPS, 4)
-            roof["achieved_over_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
         others = {t: {"launches": v[0], "avg_launch_ms": round(v[1] / v[0], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
                   for t, v in per.items() if t != dom and is33(t)}
         if others:
@@ -201,48 +372,58 @@ def main():
         stage_ms[tag] = stage_ms.get(tag, 0.0) + e0.elapsed_time(e1)
     roof_hbm = None
     if stage_ms:
-        tot_ms = sum(stage_ms.values()) / stage_steps
+        tot_ms = sum(stage_ms.values()) / inst_frames
         bpp = 24.0 if a.mode == "once" else 56.0
         gbs = bpp * H * W / (tot_ms * 1e-3) / 1e9
-        roof_hbm = {"stage": "VST+NLE (K1, K4, K5-K7)", "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(gbs / 8000.0, 4), "algorithmic_bytes_per_bayer_px": bpp, "ms_per_step": round(tot_ms, 4),
-                    "stage_ms_per_step": {k: round(v / stage_steps, 4) for k, v in stage_ms.items()},
+        roof_hbm = {"stage": "VST+NLE (K1, K4, K5-K7)", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBPS, 4), "algorithmic_bytes_per_bayer_px": bpp, "ms_per_frame": round(tot_ms, 4),
+                    "stage_ms_per_frame": {k: round(v / inst_frames, 4) for k, v in stage_ms.items()},
                     "measured": "HIP events, one instrumented pass after the timed region"}
-    conv_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof_all)
-    conv_fl = sum(fl for _, fl, _, _ in prof_all)
+    conv_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof_all) / inst_frames
+    conv_fl = sum(fl for _, fl, _, _ in prof_all) / inst_frames
 
-    # the same job with every convolution on the fp32-input MFMA (Winograd / direct kernels), for reference beside the headline
+    # the same job with every convolution on the fp32-input MFMA (Winograd / direct kernels), >= 1 s, beside the headline
     strict = None
-    if a.precision == "fp32":
-        net2 = getattr(A, arch['name'])(dict(arch, precision='fp32-mfma'))
-        net2.load_state_dict(S.procedural_state_dict(net2, 0))
-        net2 = net2.to(dev).eval()
-        r2 = P.IterDenoise(frame, net2, arch, pipe)
+    if a.precision == "fp32" and not a.no_extras and not a.batch:
+        net2 = make_net('fp32-mfma')
+        r2 = one(last_frame, net2)
         torch.cuda.synchronize()
         D.barrier()
         t1 = time.perf_counter()
-        for _ in range(2):
-            r2 = P.IterDenoise(frame, net2, arch, pipe)
-        torch.cuda.synchronize()
-        D.barrier()
+        n2 = 0
+        while n2 < 10 or time.perf_counter() - t1 < 1.0:
+            r2 = one(frames[n2 % len(frames)], net2)
+            torch.cuda.synchronize()
+            n2 += 1
         el2 = D.max_over_ranks(time.perf_counter() - t1, dev)
-        dmax = (r2['raw_dns'][-1] - res['raw_dns'][-1]).abs().max().item()
-        strict = {"value": round(world * 2 * H * W / 1e6 / el2, 2), "unit": "Bayer MP/s", "ms_per_step": round(el2 / 2 * 1e3, 3),
-                  "steps": 2, "max_abs_output_difference_to_headline_path": dmax}
-        del net2, r2
+        r2 = one(last_frame, net2)
+        r1 = one(last_frame)
+        dmax = (r2['raw_dns'][-1] - r1['raw_dns'][-1]).abs().max().item()
+        strict = {"value": round(world * n2 * H * W / 1e6 / el2, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el2 / n2 * 1e3, 3),
+                  "frames": n2, "driver": "one frame at a time", "max_abs_output_difference_to_headline_path": dmax}
+        del net2, r2, r1
 
     # final metric reduction (the only collective of the eval path): PSNR of the last output vs the clean frame
     dn = res['raw_dns'][-1]
-    mse = torch.mean((dn.double() - clean_d.double()) ** 2).item()
+    dn = dn[-1] if dn.dim() == 3 else dn
+    mse = torch.mean((dn.double() - last_clean.double()) ** 2).item()
+    mse_in = torch.mean((last_frame.double() - last_clean.double()) ** 2).item()
     sums = D.MetricSums(1)
     sums.update([10 * np.log10(1.0 / mse)], [0.0])
     red = sums.reduce(dev)
 
     if rank == 0:
         mp = H * W / 1e6
+        cfg_idx = {2: 1, 4: 3, 5: 4}[a.cfg]
+        if a.batch:
+            driver = f"IterDenoiseBatch: per-frame NLE, ONE batched forward of {a.batch} frames"
+        elif stream_driver:
+            driver = "denoise_stream: NLE of frame k+1 on a second HIP stream while the convolutions of frame k run"
+        else:
+            driver = "IterDenoise, one frame at a time"
         out = {
             "metric": "Bayer megapixels/sec end-to-end (NLE+VST+denoise+iVST)",
-            "value": round(world * a.steps * mp / elapsed, 2), "unit": "Bayer MP/s",
+            "value": round(world * n_timed * mp / elapsed, 2), "unit": "Bayer MP/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
@@ -250,23 +431,29 @@ def main():
                               "f32 accumulate; error vs float64 <= the f32-MFMA kernels')",
                       "fp32-mfma": "f32", "fp16": "f16 MFMA operands, f32 accumulate and tensors (cfg 5)"}[a.precision],
             "data": "synthetic",
-            "config": {"workload": f"configs[{4 if a.precision == 'fp16' else 1}]: one {H}x{W} synthetic Poisson-Gaussian Bayer frame per GPU, full "
-                                   f"NLE+VST+{a.arch}(nf=32)+iVST, pipeline '{a.mode}', bias_corr=pre, k=29",
-                       "frames_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}",
-                       "driver": "IterDenoise, one frame at a time" if (a.sequential or a.mode != "once") else
-                                 "denoise_stream: NLE of frame k+1 on a second HIP stream while the convolutions of frame k run"},
+            "config": {"workload": f"configs[{cfg_idx}]: {H}x{W} synthetic Poisson-Gaussian Bayer frames"
+                                   f"{'' if clip else ' (low light, no black-level clip)'}, {F} per step and GPU, each through the full "
+                                   f"NLE+VST+{a.arch}(nf=32)+iVST, pipeline '{a.mode}' ({n_pass} pass(es) per frame), bias_corr=pre, k=29",
+                       "frames_per_step_per_gpu": F, "ms_per_frame": round(elapsed / n_timed * 1e3, 3),
+                       "timed_region_s": round(elapsed, 3), "warmup_s": round(warm_s, 3),
+                       "parallelism": f"image-parallel x{world}", "driver": driver,
+                       "weights": {"denoising": "synthetic.denoising_state_dict (analytic 3x3 box-mean path + eps-scaled procedural weights)",
+                                   "procedural": "synthetic.procedural_state_dict (seeded random)"}[a.weights]},
+            "sclk": sclk_res,
             "roofline": roof,
+            "sequential": seq,
             "fp32_mfma_path": strict,
             "roofline_vst_nle": roof_hbm,
-            "conv_stack": {"ms_per_step": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
-                           "share_of_step": round(conv_ms / (elapsed / a.steps * 1e3), 3) if conv_ms else None,
+            "conv_stack": {"ms_per_frame": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
+                           "share_of_frame": round(conv_ms / (elapsed / n_timed * 1e3), 3) if conv_ms else None,
                            "measured": "HIP events around every convolution launch, one instrumented pass after the timed region"},
-            "psnr_vs_clean_db": round(red["psnr_last"], 3),
-            "estimated_K_sigma": [round(float(v), 4) for v in res['params'][-1]],
+            "psnr_vs_clean_db": {"denoised": round(red["psnr_last"], 3), "noisy_input": round(10 * np.log10(1.0 / mse_in), 3)},
+            "estimated_K_sigma": [[round(float(v), 4) for v in pr] for pr in (res['params'] if not a.batch else res['params'][-1])],
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(arch, a.mode, 0, 1)
-        print(json.dumps(out))
+        if world == 1 and not a.no_cpu_baseline and not a.batch:
+            out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline_and_parity(a, arch, dev, make_net)
+        print(json.dumps(out), flush=True)
+    D.barrier()
 
 
 if __name__ == "__main__":

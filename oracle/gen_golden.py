@@ -215,21 +215,37 @@ def gen_vst_denoiser(ref):
     save("vst_denoiser", **out)
 
 
+# IterDenoise cases (row Q): (arch, full_dn, weights, K, sigma).  'random' weights end round 2 at the beta1 < 0 guard
+# (YOND_SIDD.py:445-447: the abort cases); 'denoise' weights (yond_oracle.denoising_state_dict) make round 2 run: the
+# (4, 6) cases take the beta2 < 0 -> beta1**2 branch (:438-440) and continue, the others the plain branch.
+ITER_CASES = [("gru8", False, "random", 4.0, 6.0), ("gru8", True, "random", 4.0, 6.0),
+              ("gru8", False, "denoise", 4.0, 6.0), ("gru8", True, "denoise", 4.0, 6.0),
+              ("gru8", False, "denoise", 2.0, 20.0), ("gru8", True, "denoise", 1.0, 12.0),
+              ("unet8", True, "denoise", 2.0, 20.0), ("gru32", False, "denoise", 2.0, 20.0)]
+
+
+def iter_crop(dn):
+    """What the fixtures keep of a 256 x 8192 output: the left half of the first block, a strip across a block seam, a strided sample."""
+    dn = np.asarray(dn)
+    return dn[:, :128].astype(np.float32), dn[96:160, 4000:4200].astype(np.float32), dn[5::16, 3::16].astype(np.float32)
+
+
 def gen_iter(ref):
-    out = {}
+    out = {"ncases": np.array(len(ITER_CASES))}
     H, W = 256, 8192
-    noisy, clean = O.synth_noisy(H, W, 4.0, 6.0, 31)
-    full, _ = O.synth_noisy(512, 1024, 4.0, 6.0, 32)           # "full frame" used for round-1 NLE
     tmp = tempfile.mkdtemp()
-    full_path = os.path.join(tmp, "full.npy")
-    np.save(full_path, full)
-    out["sha_noisy"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
-    out["sha_full"] = np.frombuffer(bytes.fromhex(sha(full)), np.uint8)
     base_pipe = {'data_type': 'SIDD', 'full_est': True, 'est_type': 'simple+full', 'k': 29, 'vst_type': 'exact',
                  'bias_corr': 'pre', 'denoiser_type': 'gru32n', 'iter': 'iter', 'max_iter': 1, 'clip': False}
-    for ci, (aname, full_dn) in enumerate([("gru8", False), ("gru8", True)]):
+    for ci, (aname, full_dn, wkind, K, s) in enumerate(ITER_CASES):
+        noisy, clean = O.synth_noisy(H, W, K, s, 31)
+        full, _ = O.synth_noisy(512, 1024, K, s, 32)           # "full frame" used for round-1 NLE
+        full_path = os.path.join(tmp, f"full_{ci}.npy")
+        np.save(full_path, full)
         pipe = dict(base_pipe, full_dn=full_dn)
         obj, sd = fake_self(ref, ARCHS[aname], 70 + ci, pipe)
+        if wkind == "denoise":
+            sd = O.denoising_state_dict(ARCHS[aname], 70 + ci)
+            obj.net = ref.load_weights(obj.net, sd, by_name=False).eval()
         p = dict(pipe)
         p.update({'K': 8.74253, 'sigGs': 12.81, 'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0})
         p['scale'] = (p['wp'] - p['bl']) / p['ratio']
@@ -237,13 +253,19 @@ def gen_iter(ref):
                 'hr': np.array(np.split(clean, 32, axis=-1)), 'meta': None, 'name': 'synthetic_000'}
         res = obj.IterDenoise(data, {'p': p, 'img_id': 0})
         regs = np.array([np.asarray(r, np.float64) for r in res['regs']])
+        print(f"case {ci} {aname} full_dn={full_dn} {wkind} K={K} s={s}: regs={regs.tolist()} n_out={len(res['raw_dns'])}")
         out[f"regs_{ci}"] = regs
         out[f"full_dn_{ci}"] = np.array(full_dn)
         out[f"arch_{ci}"] = np.array(aname)
+        out[f"weights_{ci}"] = np.array(wkind)
+        out[f"ksig_{ci}"] = np.array([K, s])
         out[f"seed_{ci}"] = np.array(70 + ci)
+        out[f"sha_noisy_{ci}"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
+        out[f"sha_full_{ci}"] = np.frombuffer(bytes.fromhex(sha(full)), np.uint8)
+        out[f"nout_{ci}"] = np.array(len(res['raw_dns']))
         for it, dn in enumerate(res['raw_dns']):
-            dn = np.asarray(dn)
-            out[f"dn_{ci}_{it}_crop"] = dn[:, :768].astype(np.float32)
+            a, b, c = iter_crop(dn)
+            out[f"dn_{ci}_{it}_blk"], out[f"dn_{ci}_{it}_seam"], out[f"dn_{ci}_{it}_sub"] = a, b, c
             out[f"dn_{ci}_{it}_chk"] = checks(dn)
     save("iter", **out)
 

@@ -591,6 +591,73 @@ def procedural_state_dict(arch, seed=0, gain=1.0):
     return sd
 
 
+def denoising_state_dict(arch, seed=0, eps=0.004):
+    """Deterministic weights that make the network a (weak but real) DENOISER, so that round 2 of IterDenoise --
+    the collaborative estimate from (noisy, denoised) -- is well posed and the reference's guards let it run
+    (random weights end it at the beta1 < 0 guard, YOND_SIDD.py:445-447).
+
+    An analytic path computes out = 3x3 box mean of the input: the first layer puts the box mean of input
+    channel c into feature c and the input itself into feature 4+c; every residual / U-Net stage passes its
+    input through (second convolutions scaled by eps, decoder shortcuts = identity on the skip half, or
+    centre-tap identities for UNetSeeInDark); the output projection takes feature c minus feature 4+c, and the
+    network's global residual adds the input back.  Every other weight is the procedural one scaled by `eps`,
+    so all layers still carry data and contribute a small input-dependent perturbation."""
+    sd = procedural_state_dict(arch, seed)
+    nf, name = arch['nf'], arch['name']
+    assert nf >= 8 and arch['in_nc'] * arch.get('nframes', 1) == 4 and arch['out_nc'] == 4
+
+    def first_layer(key):
+        w, b = sd[key + '.weight'], sd[key + '.bias']
+        w[8:] *= eps
+        b[8:] *= eps
+        w[:8] = 0
+        b[:8] = 0
+        for c in range(4):
+            w[c, c] = 1.0 / 9.0
+            w[4 + c, c, 1, 1] = 1.0
+
+    def last_layer(key):
+        w, b = sd[key + '.weight'], sd[key + '.bias']
+        w *= eps
+        b *= 0
+        for c in range(4):
+            w[c, c, 0, 0] = 1.0
+            w[c, 4 + c, 0, 0] = -1.0
+
+    if name == 'UNetSeeInDark':
+        first_layer('conv1_1')
+        for i in range(1, 10):
+            for j in (1, 2):
+                if (i, j) == (1, 1):
+                    continue
+                w, b = sd[f'conv{i}_{j}.weight'], sd[f'conv{i}_{j}.bias']
+                w *= eps
+                b *= eps
+                cout, cin = w.shape[:2]
+                skip0 = cin - cout if (i >= 6 and j == 1) else 0          # cat([up, skip]): the skip half comes second
+                for c in range(min(cout, cin - skip0)):
+                    w[c, skip0 + c, 1, 1] += 1.0
+        for i in range(6, 10):
+            sd[f'upv{i}.weight'] *= eps
+            sd[f'upv{i}.bias'] *= eps
+        last_layer('conv10_1')
+        return sd
+
+    first_layer('conv_in')
+    for i in range(1, 10):
+        sd[f'conv{i}.conv2.weight'] *= eps
+        sd[f'conv{i}.conv2.bias'] *= eps
+        if i >= 6:
+            w, b = sd[f'conv{i}.short_cut.0.weight'], sd[f'conv{i}.short_cut.0.bias']
+            w *= eps
+            b *= eps
+            cout = w.shape[0]
+            for c in range(cout):
+                w[c, cout + c, 0, 0] += 1.0                                # cat([up, skip]): identity on the skip half
+    last_layer('conv10')
+    return sd
+
+
 # ----------------------------------------------------------------------------------------
 # Row J -- VST_Denoiser (YOND_SIDD.py:250-299), Simple_Denoiser (:238-248)
 # ----------------------------------------------------------------------------------------
@@ -654,7 +721,8 @@ def default_params():
 
 
 def IterDenoise(lr_raw, arch, sd, pipe, lr_full=None, p=None):
-    """lr_raw: (H, W) Bayer when pipe['full_dn'] else the SIDD layout (32, 256, 256).
+    """lr_raw: the SIDD layout (32, 256, 256) (denoised block by block, or as the 256 x 8192 concatenation
+    when pipe['full_dn']) or one (H, W) Bayer frame (needs pipe['full_dn']).
     Returns dict(raw_dns=[iter0, iter1...], regs=[...], params=[(K, sigma), ...])."""
     p = dict(p or default_params())
     k = pipe.get('k', 29)
@@ -662,16 +730,19 @@ def IterDenoise(lr_raw, arch, sd, pipe, lr_full=None, p=None):
     if bias_corr == 'none':
         bias_corr = None
     full_dn = bool(pipe.get('full_dn', False))
+    lr_raw = np.asarray(lr_raw)
+    stack = lr_raw.ndim == 3                    # the SIDD layout, as YOND_SIDD.eval hands it over
     sidd = not full_dn
     vst_type = pipe.get('vst_type', 'exact')
     regs, params = [], []
     scale = p['wp'] - p['bl']
 
-    if sidd:
-        lr_cat = np.concatenate(lr_raw, axis=-1)                                  # :314
-        blocks = np.array(np.split(lr_cat, 32, axis=-1))                          # :353
+    if stack:
+        lr_cat = np.concatenate(lr_raw, axis=-1)                                  # :315 (and :388 for full_dn)
     else:
         lr_cat = lr_raw
+    if sidd:
+        blocks = np.array(np.split(lr_cat, 32, axis=-1))                          # :354
     raw4est = lr_cat if lr_full is None else lr_full                              # :340
     reg = SimpleNLF(raw4est, k=k, setting={'mode': 'self'})                       # :341
     p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale       # :356
@@ -696,9 +767,9 @@ def IterDenoise(lr_raw, arch, sd, pipe, lr_full=None, p=None):
         for epoch in range(1, pipe.get('max_iter', 1) + 1):
             # :431 hard-codes SIDD_256=True (YOND_SIDD.py only handles SIDD); the full-frame
             # drivers named in README.md:38-47 cannot (W/2 is not a multiple of 32), so the
-            # re-tiling follows the SIDD layout unless pipe['collab_sidd256'] overrides it.
+            # re-tiling is applied to SIDD-layout input (a stack, or full_dn False) unless pipe['collab_sidd256'] overrides it.
             reg = SimpleNLF(lr_cat, raw_dn, k=k,
-                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd))})
+                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd or stack))})
             if reg[1] < 0:                                                        # :438-440
                 reg = (reg[0], reg[0] ** 2)
             p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(reg[1]) * scale       # :442

@@ -1,0 +1,139 @@
+"""GPU: the evaluation entry point with the reference's surface (yond_public_amd/YOND_SIDD.py, mirroring
+YOND_SIDD.py:136-236, 485-570), the batched full-frame driver (BASELINE cfg 4) and the RCCL metric reduction."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from hip_common import ARCHS, report
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUNFILE = os.path.join(ROOT, "runfiles", "YOND", "SIDD_simple+full_pre_grumix.yml")
+
+
+def test_yond_sidd_eval_synthetic(tmp_path, monkeypatch):
+    """`YOND_SIDD.py -f runfile -m eval` on two synthetic SIDD stand-ins (no dataset in the image): both rounds run, the
+    per-image PSNR / SSIM the driver logs equal the oracle's block metrics of the driver's own outputs, the outputs and
+    estimates equal the oracle's IterDenoise, and the reduced means follow the reference's meter rules (:643-672)."""
+    import yond_oracle as O
+    from yond_public_amd import YOND_SIDD as Y
+    monkeypatch.chdir(tmp_path)                                    # the driver writes ./logs like the reference
+    trainer = Y.YOND_SIDD(['-f', RUNFILE, '-m', 'eval', '--synthetic', '2'])
+    red = trainer.eval(-1)
+    assert red['count'] == 2
+    arch = dict(trainer.arch)
+    sd = O.denoising_state_dict(arch, 0)
+    torch.set_num_threads(8)
+    p0, s0, p1, s1 = [], [], [], []
+    for k in range(2):
+        data = trainer.dst_eval[k]
+        m = trainer.metrics[data['name']]
+        assert len(m['psnr']) == 2 and len(m['reg']) == 2         # round 2 ran
+        res = trainer.IterDenoise(data, {'p': dict(trainer.pipe, wp=1023, bl=64, ratio=1, gain=1, sigma=0, scale=959.0), 'img_id': k})
+        hr = np.concatenate(data['hr'], axis=-1)
+        for it in range(2):
+            dn = res['raw_dns'][it].cpu().numpy()
+            ps, ss = O.sidd_block_metrics(dn, hr)
+            assert abs(ps - m['psnr'][it]) < 1e-5 and abs(ss - m['ssim'][it]) < 1e-7
+        if k == 0:                                                 # the whole pipeline against the oracle for one image
+            ref = O.IterDenoise(data['lr'], arch, sd, dict(trainer.pipe), lr_full=data['lr_full'])
+            assert len(ref['raw_dns']) == 2
+            for it in range(2):
+                assert report(f"eval image 0 iter {it}", res['raw_dns'][it].cpu().numpy(), ref['raw_dns'][it]) <= 1e-4
+                np.testing.assert_allclose(res['regs'][it][0], ref['regs'][it][0], rtol=2e-5)
+        p0.append(m['psnr'][0]); s0.append(m['ssim'][0]); p1.append(m['psnr'][1]); s1.append(m['ssim'][1])
+    assert abs(red['psnr_iter0'] - np.mean(p0)) < 1e-9 and abs(red['ssim_iter1'] - np.mean(s1)) < 1e-12
+    assert abs(red['psnr_last'] - np.mean(p1)) < 1e-9 and abs(red['ssim_last'] - np.mean(s1)) < 1e-12
+
+
+def test_yond_sidd_full_dn_runfile(tmp_path, monkeypatch):
+    """A runfile with full_dn: True (the ELD / LRID / DND style of SURVEY 3.2) must run on the SIDD stack the dataset
+    yields: the driver concatenates first, as YOND_SIDD.py:387-389 does."""
+    import yaml
+    import yond_oracle as O
+    from yond_public_amd import YOND_SIDD as Y
+    cfg = yaml.load(open(RUNFILE), Loader=yaml.FullLoader)
+    cfg['pipeline']['full_dn'] = True
+    cfg['arch']['nf'] = 8
+    rf = tmp_path / "full_dn.yml"
+    rf.write_text(yaml.dump(cfg))
+    monkeypatch.chdir(tmp_path)
+    trainer = Y.YOND_SIDD(['-f', str(rf), '-m', 'eval', '--synthetic', '1'])
+    red = trainer.eval(-1)
+    data = trainer.dst_eval[0]
+    arch = dict(trainer.arch)
+    torch.set_num_threads(8)
+    ref = O.IterDenoise(data['lr'], arch, O.denoising_state_dict(arch, 0), dict(trainer.pipe), lr_full=data['lr_full'])
+    m = trainer.metrics[data['name']]
+    assert len(m['psnr']) == len(ref['raw_dns']) == 2
+    hr = np.concatenate(data['hr'], axis=-1)
+    for it in range(2):
+        ps, ss = O.sidd_block_metrics(ref['raw_dns'][it], hr)
+        assert abs(ps - m['psnr'][it]) < 2e-3 and abs(ss - m['ssim'][it]) < 2e-5
+        np.testing.assert_allclose(m['reg'][it][0], ref['regs'][it][0], rtol=2e-5)
+
+
+def test_iter_denoise_batch_equals_per_frame():
+    """BASELINE cfg 4 driver: B frames with their own estimates through ONE batched forward per round give, frame by
+    frame, IterDenoise's result (UNetSeeInDark and the guided net; two rounds)."""
+    import yond_oracle as O
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    from yond_public_amd import synthetic as S
+    for aname in ("unet8", "gru8"):
+        arch = ARCHS[aname]
+        net = getattr(A, arch['name'])(dict(arch))
+        net.load_state_dict(S.denoising_state_dict(net, 5))
+        net = net.to(DEV).eval()
+        pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': True}
+        frames = [torch.from_numpy(S.synth_noisy(320, 448, 2.0 + i, 14.0 + 3 * i, 60 + i)[0]).to(DEV) for i in range(3)]
+        seq = [P.IterDenoise(f, net, arch, pipe) for f in frames]
+        bat = P.IterDenoiseBatch(frames, net, arch, pipe)
+        assert len(bat['raw_dns']) == 2 and all(bat['alive'])
+        for i, s in enumerate(seq):
+            assert len(s['raw_dns']) == 2
+            for it in range(2):
+                assert float((bat['raw_dns'][it][i] - s['raw_dns'][it]).abs().max()) <= 2e-6
+                np.testing.assert_allclose(bat['regs'][it][i][0], s['regs'][it][0], rtol=1e-6)
+
+
+NCCL_WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, os.environ["YOND_ROOT"])
+    import torch
+    from yond_public_amd import distributed as D
+    rank, local, world = D.init()                    # backend "nccl" == RCCL
+    import torch.distributed as dist
+    assert dist.get_backend() == "nccl" and world == 2
+    torch.cuda.set_device(local)
+    sums = D.MetricSums(2)
+    for k in D.shard_indices(7, rank, world):
+        sums.update([40.0 + k, 41.0 + k], [0.9 + 0.01 * k, 0.91 + 0.01 * k])
+    D.barrier()
+    t = D.max_over_ranks(1.0 + rank, torch.device("cuda", local))
+    red = sums.reduce(torch.device("cuda", local))
+    if rank == 0:
+        print("RESULT " + json.dumps({"red": red, "t": t}))
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL metric reduction)")
+def test_two_rank_rccl_metric_reduction(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, YOND_ROOT=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert r["t"] == 2.0 and r["red"]["count"] == 7
+    assert abs(r["red"]["psnr_last"] - sum(41.0 + k for k in range(7)) / 7) < 1e-12

@@ -9,30 +9,31 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-@pytest.mark.parametrize("ci", range(2))
+@pytest.mark.parametrize("ci", range(8))
 def test_iter_denoise_matches_reference(golden, ci):
-    import yond_oracle as O
+    """Row Q against the reference's own IterDenoise (tests/golden/iter.npz, oracle/gen_golden.py ITER_CASES): cases 0-1
+    end at the beta1 < 0 guard (YOND_SIDD.py:445-447, one output), 2-3 take the beta2 < 0 -> beta1**2 branch (:438-440)
+    and continue, 4-7 run the plain second round (second get_bias :450-454, second K1 -> net -> K4 pass :456-467);
+    block-wise (batch 32) and full_dn, GuidedResUnet nf 8 / 32 and UNetSeeInDark."""
+    from test_oracle_golden import iter_case, iter_crop
+    from yond_public_amd import archs as A
     from yond_public_amd import pipeline as P
     g = golden("iter")
-    noisy, clean = O.synth_noisy(256, 8192, 4.0, 6.0, 31)
-    full, _ = O.synth_noisy(512, 1024, 4.0, 6.0, 32)
-    assert np.array_equal(sha(noisy), g["sha_noisy"]) and np.array_equal(sha(full), g["sha_full"])
-    arch = ARCHS[str(g[f"arch_{ci}"])]
-    net, sd = make_net(arch, int(g[f"seed_{ci}"]))
-    full_dn = bool(g[f"full_dn_{ci}"])
-    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': full_dn,
-            'collab_sidd256': True}
-    lr = noisy if full_dn else np.array(np.split(noisy, 32, axis=-1))
+    lr, clean, full, arch, sd, pipe = iter_case(g, ci)
+    net = getattr(A, arch['name'])(dict(arch))
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
     res = P.IterDenoise(lr, net, arch, pipe, lr_full=full, device=DEV)
     regs = g[f"regs_{ci}"]
-    assert len(res['regs']) == len(regs)
+    assert len(res['regs']) == len(regs) and len(res['raw_dns']) == int(g[f"nout_{ci}"])
     for r, gr in zip(res['regs'], regs):
-        print(f"[parity] regs {r[0]:.6e},{r[1]:.6e} vs {gr[0]:.6e},{gr[1]:.6e}")
+        print(f"[parity] case {ci} regs {r[0]:.6e},{r[1]:.6e} vs {gr[0]:.6e},{gr[1]:.6e}")
         np.testing.assert_allclose(r[0], gr[0], rtol=2e-5)
         np.testing.assert_allclose(r[1], gr[1], rtol=0, atol=2e-5 * abs(gr[0]) + 1e-9)
     for it, dn in enumerate(res['raw_dns']):
         dn = dn.cpu().numpy()
-        assert report(f"IterDenoise case {ci} iter {it}", dn[:, :768], g[f"dn_{ci}_{it}_crop"]) <= 1e-4
+        for got, tag in zip(iter_crop(dn), ("blk", "seam", "sub")):
+            assert report(f"IterDenoise case {ci} iter {it} {tag}", got, g[f"dn_{ci}_{it}_{tag}"]) <= 1e-4
         np.testing.assert_allclose(np.asarray(dn, np.float64).sum(), g[f"dn_{ci}_{it}_chk"][0], rtol=1e-5)
 
 

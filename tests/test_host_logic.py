@@ -73,6 +73,22 @@ def test_shard_indices():
 def test_metric_sums_single_process():
     m = D.MetricSums(2)
     m.update([50.0, 51.0], [0.98, 0.99])
-    m.update([48.0, -1.0], [0.97, -1.0])
+    m.update([48.0], [0.97])                       # round 2 ended by the guard: -1 in iter1's meter, 'last' = iter 0's value
     r = m.reduce()
-    assert r['count'] == 2 and r['psnr_iter0'] == 49.0 and r['psnr_iter1'] == 25.0 and abs(r['ssim_last'] + 0.005) < 1e-12
+    assert r['count'] == 2 and r['psnr_iter0'] == 49.0 and r['psnr_iter1'] == 25.0
+    assert abs(r['ssim_last'] - 0.98) < 1e-12 and r['psnr_last'] == 49.5 and abs(r['ssim_iter1'] + 0.005) < 1e-12
+
+
+def test_fit_from_moments_rank_deficient_is_minimum_norm():
+    """A constant mean map (lens cap, saturated frame) makes the 2x2 normal equations singular.  The reference's
+    scipy.linalg.lstsq (utils/isp_algos.py:364) does not raise there (what it returns depends on how LAPACK rounds the
+    vanishing singular value); the product returns the minimum-norm least-squares solution instead of dividing by 0."""
+    m = np.full(1000, 0.25)
+    v = 1e-4 + 1e-5 * np.random.default_rng(0).standard_normal(1000)
+    ref = np.linalg.pinv(np.vstack([m, np.ones(len(m))]).T, rcond=1e-10) @ v
+    mom = np.array([m.size, m.sum(), v.sum(), (m * m).sum(), (m * v).sum()])
+    np.testing.assert_allclose(P._fit_from_moments(mom, mom), ref, rtol=1e-9)
+    one = np.array([1.0, 0.3, 2e-4, 0.09, 6e-5])
+    ref1 = np.linalg.pinv(np.array([[0.3, 1.0]])) @ np.array([2e-4])
+    np.testing.assert_allclose(P._fit_from_moments(one, one), ref1, rtol=1e-9)
+    assert np.all(P._fit_from_moments(np.zeros(5), np.zeros(5)) == 0)

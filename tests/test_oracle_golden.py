@@ -174,26 +174,43 @@ def test_vst_denoiser(golden, ci):
     np.testing.assert_allclose(dn, ref, rtol=0, atol=5e-6)
 
 
-@pytest.mark.parametrize("ci", range(2))
-def test_iter_denoise(golden, ci):
-    g = golden("iter")
-    noisy, clean = O.synth_noisy(256, 8192, 4.0, 6.0, 31)
-    full, _ = O.synth_noisy(512, 1024, 4.0, 6.0, 32)
-    assert np.array_equal(sha(noisy), g["sha_noisy"]) and np.array_equal(sha(full), g["sha_full"])
+def iter_case(g, ci):
+    """Inputs of IterDenoise fixture case `ci` (oracle/gen_golden.py ITER_CASES), regenerated from seeds."""
+    K, s = (float(v) for v in g[f"ksig_{ci}"])
+    noisy, clean = O.synth_noisy(256, 8192, K, s, 31)
+    full, _ = O.synth_noisy(512, 1024, K, s, 32)
+    assert np.array_equal(sha(noisy), g[f"sha_noisy_{ci}"]) and np.array_equal(sha(full), g[f"sha_full_{ci}"])
     arch = ARCHS[str(g[f"arch_{ci}"])]
-    sd = O.procedural_state_dict(arch, int(g[f"seed_{ci}"]))
+    seed = int(g[f"seed_{ci}"])
+    sd = O.denoising_state_dict(arch, seed) if str(g[f"weights_{ci}"]) == "denoise" else O.procedural_state_dict(arch, seed)
     full_dn = bool(g[f"full_dn_{ci}"])
-    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1,
-            'full_dn': full_dn, 'collab_sidd256': True}
-    lr = noisy if full_dn else np.array(np.split(noisy, 32, axis=-1))
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': full_dn}
+    return np.array(np.split(noisy, 32, axis=-1)), clean, full, arch, sd, pipe     # the SIDD stack, as eval hands it over
+
+
+def iter_crop(dn):
+    dn = np.asarray(dn)
+    return dn[:, :128], dn[96:160, 4000:4200], dn[5::16, 3::16]
+
+
+@pytest.mark.parametrize("ci", range(8))
+def test_iter_denoise(golden, ci):
+    """Row Q against the reference's own IterDenoise: cases 0-1 end at the beta1 < 0 guard (one output), 2-3 take the
+    beta2 < 0 -> beta1**2 branch and CONTINUE, 4-7 the plain second round (two outputs, two regs rows)."""
+    g = golden("iter")
+    lr, clean, full, arch, sd, pipe = iter_case(g, ci)
     torch.set_num_threads(8)
     res = O.IterDenoise(lr, arch, sd, pipe, lr_full=full)
     regs = g[f"regs_{ci}"]
-    assert len(res['regs']) == len(regs)
+    assert len(res['regs']) == len(regs) and len(res['raw_dns']) == int(g[f"nout_{ci}"])
+    assert len(regs) == (1 if str(g[f"weights_{ci}"]) == "random" else 2)
+    if ci in (2, 3):
+        assert regs[1][1] == regs[1][0] ** 2                     # the fixture really went through :438-440
     for r, gr in zip(res['regs'], regs):
         np.testing.assert_allclose(r[0], gr[0], rtol=1e-5)
         np.testing.assert_allclose(r[1], gr[1], rtol=0, atol=1e-5 * abs(gr[0]) + 1e-9)
     for it, dn in enumerate(res['raw_dns']):
-        np.testing.assert_allclose(dn[:, :768], g[f"dn_{ci}_{it}_crop"], rtol=0, atol=2e-5)
+        for got, tag in zip(iter_crop(dn), ("blk", "seam", "sub")):
+            np.testing.assert_allclose(got, g[f"dn_{ci}_{it}_{tag}"], rtol=0, atol=2e-5)
         chk = g[f"dn_{ci}_{it}_chk"]
         np.testing.assert_allclose(np.asarray(dn, np.float64).sum(), chk[0], rtol=1e-6)

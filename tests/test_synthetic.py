@@ -22,3 +22,22 @@ def test_weights_identical():
         assert mine.keys() == ref.keys()
         for k in ref:
             assert torch.equal(mine[k], ref[k]), k
+
+
+def test_denoising_weights_identical_and_denoise():
+    """The 'denoising' weight set (round 2 of IterDenoise needs a real denoiser) is the same on both sides, and the
+    network it defines is a 3x3 box mean up to its eps-sized perturbation."""
+    import torch.nn.functional as F
+    from yond_public_amd import synthetic as S
+    from yond_public_amd.archs import GuidedResUnet, SNRnet, UNetSeeInDark
+    for cls in (GuidedResUnet, SNRnet, UNetSeeInDark):
+        arch = dict(name=cls.__name__, guided=True, in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True)
+        mine = S.denoising_state_dict(cls(arch), 4)
+        ref = O.denoising_state_dict(arch, 4)
+        assert mine.keys() == ref.keys()
+        for k in ref:
+            assert torch.equal(mine[k], ref[k]), k
+        x = torch.rand(1, 4, 32, 32, generator=torch.Generator().manual_seed(1)) * 0.8 + 0.1
+        y = O.net_forward(arch, ref, x, torch.tensor(0.03))
+        box = F.avg_pool2d(F.pad(x, (1, 1, 1, 1)), 3, 1)
+        assert float((y - box).abs().max()) < 0.03

@@ -101,15 +101,15 @@ class YOND_SIDD:
                 self.net.load_state_dict(state)
                 break
         else:
-            model_path = None
-            self.net.load_state_dict(S.procedural_state_dict(self.net, 0))
+            model_path = None                      # no checkpoint: a deterministic weak denoiser (both rounds run)
+            self.net.load_state_dict(S.denoising_state_dict(self.net, 0))
         self.net = self.net.to(self.device).eval()
         if self.rank == 0:
             nparam = sum(p.numel() for p in self.net.parameters())
             log(f'Method Name:\t{self.method_name}', self.logfile, notime=True)
             log(f'Architecture:\t{self.arch["name"]}', self.logfile, notime=True)
             log(f'Parameters:\t{nparam / 1e6:.2f}M', self.logfile, notime=True)
-            log(f'Checkpoint:\t{model_path or "none found -> procedural weights (timing / parity only)"}', self.logfile, notime=True)
+            log(f'Checkpoint:\t{model_path or "none found -> synthetic denoising weights (timing / parity only)"}', self.logfile, notime=True)
             log(f"Let's use {self.world} GPUs (one process each, image-parallel)!", self.logfile, notime=True)
         self.change_eval_dst('eval')
 
@@ -130,6 +130,8 @@ class YOND_SIDD:
                               device=self.device)
 
     def IterDenoise(self, data, params):
+        # data['lr'] is the [32][256][256] stack; pipeline.IterDenoise concatenates it for the estimate (:315) and, with
+        # pipe['full_dn'], for the denoiser (:388); the collaborative estimate re-tiles per block (SIDD_256, :431)
         res = P.IterDenoise(data['lr'], self.net, self.arch, self.pipe, lr_full=data.get('lr_full'), p=params['p'],
                             device=self.device, log=(lambda s: log(s, self.logfile)) if self.parser.verbose else None)
         res['lr_raw'] = np.concatenate(data['lr'], axis=-1)
@@ -156,10 +158,7 @@ class YOND_SIDD:
                     ps, ss = P.block_metrics(dn, hr)                                   # :649-652 per 256x256 block
                     psnrs.append(float(np.mean(ps)))
                     ssims.append(float(np.mean(ss)))
-                while len(psnrs) < n_it:                                              # failed iteration (:644-647)
-                    psnrs.append(-1.0)
-                    ssims.append(-1.0)
-                sums.update(psnrs, ssims)
+                sums.update(psnrs, ssims)        # iterations that did not run count -1 in their own meter (:644-647)
             self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
             log(f"[rank {self.rank}] {data['name']}: PSNR={psnrs[-1] if psnrs else float('nan'):.2f}, "
                 f"SSIM={ssims[-1] if ssims else float('nan'):.4f}", self.logfile)

@@ -55,13 +55,15 @@ class MetricSums:
         self.vec = torch.zeros(2 * (n_iters + 1) + 1, dtype=torch.float64)
 
     def update(self, psnrs, ssims):
-        """psnrs / ssims: per-iteration values of one image; the last entry also feeds the 'last' meter
-        (YOND_SIDD.py:671-672).  Failed iterations are recorded as -1 by the caller (:644-647)."""
+        """psnrs / ssims: the values of the iterations that RAN for one image (round 2 may have been ended by the
+        reference's guard, YOND_SIDD.py:445-447).  Mirrors multiprocess_plot (:643-672): an iteration without output
+        feeds -1 into ITS meter (:644-647, `continue`); the 'last' meter gets the last value that was computed
+        (:671-672 reuse the loop variables, which a skipped iteration leaves untouched)."""
+        if not len(psnrs):
+            raise ValueError("MetricSums.update needs the metrics of at least the first iteration")
         for it in range(self.n_iters):
-            p = psnrs[it] if it < len(psnrs) else -1.0
-            s = ssims[it] if it < len(ssims) else -1.0
-            self.vec[2 * it] += p
-            self.vec[2 * it + 1] += s
+            self.vec[2 * it] += psnrs[it] if it < len(psnrs) else -1.0
+            self.vec[2 * it + 1] += ssims[it] if it < len(ssims) else -1.0
         self.vec[2 * self.n_iters] += psnrs[-1]
         self.vec[2 * self.n_iters + 1] += ssims[-1]
         self.vec[-1] += 1

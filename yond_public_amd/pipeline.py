@@ -218,6 +218,13 @@ def _fit_from_moments(m_all, m_ns):
     use = m_ns if m_ns[0] > 0.01 * m_all[0] else m_all
     n, sx, sy, sxx, sxy = (float(v) for v in use)
     det = n * sxx - sx * sx
+    if n < 2 or det <= 1e-12 * max(n * sxx, 1e-300):
+        # rank-deficient design (a constant mean map, or a single selected pixel): scipy.linalg.lstsq (:364) does not
+        # raise there; return the minimum-norm solution of [m, 1].[b1, b2] = v, (b1, b2) = vbar * (mbar, 1) / (mbar^2 + 1)
+        if n <= 0:
+            return np.array([0.0, 0.0])
+        mbar, vbar = sx / n, sy / n
+        return np.array([vbar * mbar / (mbar * mbar + 1.0), vbar / (mbar * mbar + 1.0)])
     return np.array([(n * sxy - sx * sy) / det, (sxx * sy - sx * sxy) / det])
 
 
@@ -330,10 +337,11 @@ def _plan_of(net, device):
 def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type='exact', clip01=False, device=None,
                  lr_max=None):
     """YOND_SIDD.py:250-299 for the network denoisers.  lr_raw: Bayer [H][W] -- or a stack [B][H][W] of equally
-    sized frames that share (gain, sigma) and the bias LUT, e.g. the 32 blocks of a SIDD image, which then go
-    through ONE batched forward instead of the reference's 32 batch-1 calls (:398-407).  p: dict with scale,
-    gain, sigma; returns the denoised frame(s) as a device tensor.  `clip01` folds the caller's .clip(0,1);
-    `lr_max` (float32 max of the frame) spares the device reduction + sync when the caller already has it."""
+    sized frames that go through ONE batched forward instead of B batch-1 calls: the 32 blocks of a SIDD image, which
+    share (gain, sigma) and the bias LUT (:392-407), or B independent frames (BASELINE cfg 4), for which `p`,
+    `bias_func` and `lr_max` are lists with one entry per frame.  p: dict with scale, gain, sigma; returns the
+    denoised frame(s) as a device tensor.  `clip01` folds the caller's .clip(0,1); `lr_max` (float32 max of the
+    frame) spares the device reduction + sync when the caller already has it."""
     lib = L.load()
     lr = _dev(lr_raw, device)
     single = lr.dim() == 2
@@ -341,44 +349,65 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
         lr = lr[None]
     B, H, W = lr.shape
     h, w = H // 2, W // 2
-    scale, gain, sigma = float(p['scale']), np.float64(p['gain']), np.float64(p['sigma'])
+    per_frame = isinstance(p, (list, tuple))
+    ps = list(p) if per_frame else [p] * B
+    if len(ps) != B:
+        raise L.YondHipError(f"{len(ps)} parameter sets for {B} frames")
     if bias_corr not in (None, 'pre'):
         raise NotImplementedError(f"bias_corr={bias_corr!r} (the reference's 'post' branch is commented out)")
-    if bias_corr is not None and bias_func is None:
-        if not single:
+    funcs = list(bias_func) if isinstance(bias_func, (list, tuple)) else [bias_func] * B
+    maxes = list(lr_max) if isinstance(lr_max, (list, tuple)) else [lr_max] * B
+    if bias_corr is not None and any(f is None for f in funcs):
+        if not (single or per_frame):
             raise L.YondHipError("a stack of frames needs the shared bias LUT (the reference builds one per image, :392-397)")
-        if lr_max is None:
-            lr_max = lr.max().item()
-        mx = np.float32(lr_max) * np.float32(scale)                # lr_rggb.max() of the float32 product
-        bias_func = get_bias(mx, sigma, gain, device=lr.device)
-    lower, upper = vst_scalar(0, sigma, gain), vst_scalar(scale, sigma, gain)
-    nsr = 1 / (upper - lower)
+        for i in range(B):
+            if funcs[i] is None:
+                mxv = maxes[i] if maxes[i] is not None else _frame_max(lr[i]).item()
+                mx = np.float32(mxv) * np.float32(ps[i]['scale'])    # lr_rggb.max() of the float32 product (:256)
+                funcs[i] = get_bias(mx, np.float64(ps[i]['sigma']), np.float64(ps[i]['gain']), device=lr.device)
     p2d = get_p2d((1, 4, h, w), base=32)
     Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
     x4 = torch.empty((B, Hp, Wp, 4), dtype=torch.float32, device=lr.device)
     img_max = torch.empty(B, dtype=torch.float32, device=lr.device)
     st = L.stream()
-    lut_n = len(bias_func) if bias_corr is not None else 0
+    consts, t_host = [], []
     with _stage("vst_pack"):
         for i in range(B):
+            scale, gain, sigma = float(ps[i]['scale']), np.float64(ps[i]['gain']), np.float64(ps[i]['sigma'])
+            lower, upper = vst_scalar(0, sigma, gain), vst_scalar(scale, sigma, gain)
+            consts.append((scale, gain, sigma, lower, upper))
+            t_host.append(float(np.float32(1 / (upper - lower) * (1.03 if bias_corr == 'pre' else 1.00))))   # :284-285
+            f = funcs[i]
+            lut_n = len(f) if bias_corr is not None else 0
             L.check(lib.yond_pack_vst_norm_f32(L.ptr(lr[i]), H, W, L.ptr(x4[i]), p2d[0], p2d[1], p2d[2], p2d[3], 1, scale,
                                                float(gain), float(sigma), float(lower), float(upper),
-                                               L.ptr(bias_func.x) if lut_n else None, L.ptr(bias_func.y) if lut_n else None, lut_n,
+                                               L.ptr(f.x) if lut_n else None, L.ptr(f.y) if lut_n else None, lut_n,
                                                L.ptr(img_max[i:i + 1]), st), "yond_pack_vst_norm_f32")
     plan = _plan_of(net, lr.device)
     t_dev = None
     if 'guided' in arch:
-        sigma_corr = 1.03 if bias_corr == 'pre' else 1.00
-        t_dev = torch.full((B,), float(np.float32(nsr * sigma_corr)), dtype=torch.float32, device=lr.device)
+        t_dev = torch.tensor(t_host, dtype=torch.float32).to(lr.device, non_blocking=True) if per_frame else \
+            torch.full((B,), t_host[0], dtype=torch.float32, device=lr.device)
     y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
     out = torch.empty((B, H, W), dtype=torch.float32, device=lr.device)
     exact_inverse = bias_corr is None and vst_type == 'exact'
     with _stage("ivst_unpack"):
         for i in range(B):
+            scale, gain, sigma, lower, upper = consts[i]
             L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4[i]), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out[i]),
                                                     2 if exact_inverse else 1, scale, float(gain), float(sigma), float(lower),
                                                     float(upper), int(clip01), st), "yond_denorm_ivst_unpack_f32")
     return out[0] if single else out
+
+
+def _frame_max(x):
+    """Maximum of a device tensor as a 1-element device tensor (yond_image_max_f32: two launches, deterministic)."""
+    lib = L.load()
+    x = x.contiguous()
+    partial = torch.empty(256, dtype=torch.float32, device=x.device)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    L.check(lib.yond_image_max_f32(L.ptr(x), 1, x.numel(), L.ptr(partial), L.ptr(out), L.stream()), "yond_image_max_f32")
+    return out
 
 
 def Simple_Denoiser(lr_raw, net, device=None):
@@ -416,8 +445,10 @@ def default_params():
 
 def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=None):
     """Round 1: self-calibrated NLE -> VST -> denoise -> inverse VST; round 2 (pipe['iter']=='iter'):
-    collaborative NLE from (noisy, denoised) -> guards -> second pass.  lr_raw: Bayer [H][W] when
-    pipe['full_dn'], else the SIDD layout [32][256][256].  Returns dict(raw_dns, regs, params) with
+    collaborative NLE from (noisy, denoised) -> guards -> second pass.  lr_raw: the SIDD layout [32][256][256]
+    (denoised block by block, or -- pipe['full_dn'] -- as its 256 x 8192 concatenation, :387-389) or one Bayer
+    frame [H][W] (needs pipe['full_dn']).  The collaborative estimate re-tiles per 256-block (SIDD_256, which :431
+    hard-codes) for SIDD-layout input; pipe['collab_sidd256'] overrides.  Returns dict(raw_dns, regs, params) with
     device tensors in raw_dns (each [H][W], for SIDD the 256 x 8192 concatenation as in the reference)."""
     p = dict(p or default_params())
     k = pipe.get('k', 29)
@@ -430,15 +461,21 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     scale = p['wp'] - p['bl']
     regs, params = [], []
     lr = _dev(lr_raw, device)
-    if sidd:
-        if lr.dim() != 3 or lr.shape[0] != 32:
+    stack = lr.dim() == 3                      # the SIDD layout, as YOND_SIDD.eval hands it over (:507-514)
+    if stack:
+        if lr.shape[0] != 32:
             raise L.YondHipError("SIDD layout expects [32][256][256] blocks")
-        lr_cat = torch.cat(list(lr), dim=-1).contiguous()                              # :314
+        lr_cat = torch.cat(list(lr), dim=-1).contiguous()                              # :315 (and :388 when full_dn)
         blocks = lr
+    elif sidd:
+        if lr.dim() != 2 or lr.shape[1] % 32:
+            raise L.YondHipError("block-wise denoising (full_dn False) expects the SIDD layout [32][256][256]")
+        lr_cat = lr
+        blocks = torch.stack(torch.split(lr, lr.shape[1] // 32, dim=-1)).contiguous()  # :354
     else:
         lr_cat = lr
     raw4est = lr_cat if lr_full is None else _dev(lr_full, lr.device)                  # :340
-    lr_max_dev = lr_cat.max()                  # queued ahead of the NLE; read after the NLE's own host sync
+    lr_max_dev = _frame_max(lr_cat)            # queued ahead of the NLE; read after the NLE's own host sync
     reg = SimpleNLF(raw4est, k=k, setting={'mode': 'self'})                            # :341
     p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale            # :356
     if log:
@@ -465,7 +502,7 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     if pipe.get('iter', 'iter') == 'iter':
         for epoch in range(1, pipe.get('max_iter', 1) + 1):
             reg = SimpleNLF(lr_cat, raw_dn, k=k,
-                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd))})   # :431
+                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd or stack))})   # :431
             if reg[1] < 0:                                                             # :438-440
                 reg = (reg[0], reg[0] ** 2)
             p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(reg[1]) * scale            # :442
@@ -481,13 +518,71 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     return dict(raw_dns=raw_dns, regs=regs, params=params)
 
 
+def IterDenoiseBatch(frames, net, arch, pipe, p=None, device=None):
+    """`IterDenoise` for B equally sized full Bayer frames at once (BASELINE cfg 4: batch 8; pipe['full_dn']): every frame
+    keeps its own noise-level estimate, bias LUT and VST constants -- the per-image steps of YOND_SIDD.py:341-356,
+    392-397 -- and the B stabilised frames go through ONE batched forward per round instead of B batch-1 forwards.
+    Per frame the result equals IterDenoise's.  Returns dict(raw_dns=[ [B][H][W] per round ], regs=[per round: list of B],
+    params=[per round: list of B (K, sigma)], alive=[B] booleans of the frames whose round 2 ran)."""
+    if not pipe.get('full_dn', False):
+        raise L.YondHipError("IterDenoiseBatch handles full frames (pipe['full_dn'])")
+    p0 = dict(p or default_params())
+    k = pipe.get('k', 29)
+    bias_corr = pipe.get('bias_corr', 'pre')
+    if bias_corr == 'none':
+        bias_corr = None
+    vst_type = pipe.get('vst_type', 'exact')
+    scale = p0['wp'] - p0['bl']
+    lrs = [_dev(f, device) for f in frames]
+    B = len(lrs)
+    stack = torch.stack(lrs)
+    max_dev = [_frame_max(f) for f in lrs]
+    regs = [SimpleNLF(f, k=k, setting={'mode': 'self'}) for f in lrs]                    # :341 per frame
+    maxes = [np.float32(m.item()) for m in max_dev]
+    ps = [dict(p0, gain=r[0] * scale, sigma=np.sqrt(max(r[1], 0)) * scale) for r in regs]  # :356
+    raw_dn = VST_Denoiser(stack, ps, net, arch, bias_corr, None, vst_type, clip01=True, lr_max=maxes)
+    raw_dns, all_regs, all_params = [raw_dn], [regs], [[(q['gain'], q['sigma']) for q in ps]]
+    alive = [True] * B
+    if pipe.get('iter', 'iter') == 'iter':
+        for epoch in range(1, pipe.get('max_iter', 1) + 1):
+            regs2, ps2, funcs = [], [], []
+            for i in range(B):
+                reg = SimpleNLF(lrs[i], raw_dn[i], k=k, setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', False))})
+                if reg[1] < 0:                                                             # :438-440
+                    reg = (reg[0], reg[0] ** 2)
+                if reg[0] < 0:                                                             # :445-447: this frame keeps its round-1 result
+                    alive[i] = False
+                    regs2.append(reg)
+                    ps2.append(ps[i])
+                    funcs.append(None)
+                    continue
+                q = dict(p0, gain=reg[0] * scale, sigma=np.sqrt(reg[1]) * scale)           # :442
+                regs2.append(reg)
+                ps2.append(q)
+                funcs.append(get_bias(maxes[i] * scale, q['sigma'], q['gain'], device=stack.device))   # :450-452
+            if not any(alive):
+                break
+            nxt = VST_Denoiser(stack, ps2, net, arch, bias_corr, funcs, vst_type, clip01=True, lr_max=maxes)
+            for i in range(B):
+                if not alive[i]:
+                    nxt[i] = raw_dn[i]
+            raw_dn = nxt
+            raw_dns.append(raw_dn)
+            all_regs.append(regs2)
+            all_params.append([(q['gain'], q['sigma']) for q in ps2])
+    return dict(raw_dns=raw_dns, regs=all_regs, params=all_params, alive=alive)
+
+
 def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     """`IterDenoise` over a sequence of full Bayer frames with the two phases of consecutive frames overlapped
     (pipe['iter'] == 'once', pipe['full_dn']): the noise-level estimation of frame k+1 -- memory / latency bound kernels
     and the one host round trip of the path (YOND_SIDD.py:341-356) -- runs on a second HIP stream while the
     convolution stack of frame k (:387-389) occupies the matrix cores on the first.  Same kernels, same arguments and
     therefore the same results as IterDenoise, frame by frame (tests/test_hip_pipeline.py); yields its dict per frame.
-    Any other mode falls back to IterDenoise."""
+    Any other mode falls back to IterDenoise.
+    Contract for device-tensor frames: frame k+1 is taken from the iterator BEFORE the network pass of frame k is queued
+    and its estimate reads it on the side stream, so every frame handed in must stay UNMODIFIED until its own result has
+    been yielded -- a producer that refills one buffer in place must hand in clones."""
     if pipe.get('iter', 'iter') != 'once' or not pipe.get('full_dn', False):
         for f in frames:
             yield IterDenoise(f, net, arch, pipe, p=p, device=device)
@@ -505,7 +600,7 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     def estimate(lr, ready):               # phase 1 on the side stream; returns host scalars only
         side.wait_event(ready)             # the frame as it stood when it was handed in -- NOT the work queued since
         with torch.cuda.stream(side):
-            lr_max_dev = lr.max()
+            lr_max_dev = _frame_max(lr)
             reg = SimpleNLF(lr, k=k, setting={'mode': 'self'})
             lr_max = np.float32(lr_max_dev.item())
         return lr, reg, lr_max

@@ -45,3 +45,69 @@ def procedural_state_dict(net, seed=0, gain=1.0):
             if '.gamma.2' in key or '.sfm1.2' in key or '.sfm2.2' in key:
                 sd[key] = sd[key] + 1.0
     return sd
+
+
+def denoising_state_dict(net, seed=0, eps=0.004):
+    """Deterministic weights that make the network a (weak but real) denoiser -- out = 3x3 box mean of the
+    input plus an eps-sized input-dependent perturbation from all other layers -- so that round 2 of IterDenoise
+    (the collaborative estimate, YOND_SIDD.py:419-472) is well posed: with random weights the reference's
+    beta1 < 0 guard (:445-447) ends it.  The first layer puts the box mean of input channel c into feature c and
+    the input into feature 4+c; every later stage passes them through (second convolutions and every other
+    procedural weight scaled by eps; decoder shortcuts = identity on the skip half, centre-tap identities for
+    UNetSeeInDark); the output projection takes feature c minus feature 4+c and the network's global residual
+    adds the input back."""
+    sd = procedural_state_dict(net, seed)
+    name = type(net).__name__
+
+    def first_layer(key):
+        w, b = sd[key + '.weight'], sd[key + '.bias']
+        if w.shape[0] < 8 or w.shape[1] != 4:
+            raise ValueError("denoising_state_dict needs nf >= 8 and 4 input channels")
+        w[8:] *= eps
+        b[8:] *= eps
+        w[:8] = 0
+        b[:8] = 0
+        for c in range(4):
+            w[c, c] = 1.0 / 9.0
+            w[4 + c, c, 1, 1] = 1.0
+
+    def last_layer(key):
+        w, b = sd[key + '.weight'], sd[key + '.bias']
+        w *= eps
+        b *= 0
+        for c in range(4):
+            w[c, c, 0, 0] = 1.0
+            w[c, 4 + c, 0, 0] = -1.0
+
+    if name == 'UNetSeeInDark':
+        first_layer('conv1_1')
+        for i in range(1, 10):
+            for j in (1, 2):
+                if (i, j) == (1, 1):
+                    continue
+                w, b = sd[f'conv{i}_{j}.weight'], sd[f'conv{i}_{j}.bias']
+                w *= eps
+                b *= eps
+                cout, cin = w.shape[:2]
+                skip0 = cin - cout if (i >= 6 and j == 1) else 0          # cat([up, skip]): the skip half comes second
+                for c in range(min(cout, cin - skip0)):
+                    w[c, skip0 + c, 1, 1] += 1.0
+        for i in range(6, 10):
+            sd[f'upv{i}.weight'] *= eps
+            sd[f'upv{i}.bias'] *= eps
+        last_layer('conv10_1')
+        return sd
+
+    first_layer('conv_in')
+    for i in range(1, 10):
+        sd[f'conv{i}.conv2.weight'] *= eps
+        sd[f'conv{i}.conv2.bias'] *= eps
+        if i >= 6:
+            w, b = sd[f'conv{i}.short_cut.0.weight'], sd[f'conv{i}.short_cut.0.bias']
+            w *= eps
+            b *= eps
+            cout = w.shape[0]
+            for c in range(cout):
+                w[c, cout + c, 0, 0] += 1.0                                # cat([up, skip]): identity on the skip half
+    last_layer('conv10')
+    return sd

@@ -132,6 +132,19 @@ class SclkSampler(threading.Thread):
                 "source": "pp_dpm_sclk (sysfs), busiest card, during the timed region"}
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands out a
+    share of its host -- 16 cores per GPU on this pool -- while os.cpu_count() reports the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline_and_parity(a, arch, dev, net_factory):
     """The oracle (CPU restatement of the reference path; test infrastructure used ONLY as the reported baseline and as
     the checker of the parity leg) on a bounded sample of the workload, at 1 thread (the reference pins 1 thread,
@@ -148,7 +161,7 @@ def cpu_baseline_and_parity(a, arch, dev, net_factory):
     pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': a.mode, 'max_iter': 1, 'full_dn': True,
             'collab_sidd256': False}
     old = torch.get_num_threads()
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     runs = {}
     for threads in (1, ncores):
         torch.set_num_threads(threads)

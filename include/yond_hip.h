@@ -218,6 +218,24 @@ int yond_select_ranks_f32(const float* data, size_t n, const int64_t* ranks_host
 int yond_percentiles_f32(const float* data, size_t n, const double* q_host, int nq, double* out, void* ws,
                          void* stream);
 
+/* K6'/K7' the threshold selection of the estimator in two sweeps (YOND_SIDD.py:22-49: np.percentile at :26, the masked
+ * bincounts at :37-43, score and argmin at :45-47), replacing yond_percentiles_f32 + yond_nlf_occupancy_f32 +
+ * yond_nlf_score3_f64 on the hot path.  `ws`: device workspace of yond_nle_ws_bytes(n) bytes, 16-byte aligned.
+ *   yond_nle_stats_f32      sweep 1 over (lap, mean) (n elements as rows of `width`): level-1 histogram of lap and, per
+ *                           1/1000 mean bin, the smallest lap (a bin is occupied among lap <= T iff its smallest lap <= T);
+ *                           resets the workspace first.  (The fused box kernel yond_box_stats_self_fused_f32 does the same
+ *                           while it produces the maps.)
+ *   yond_nle_threshold_f32  sweep 2 over lap + finish: the exact order statistics, np.percentile(lap, q, 'linear') ->
+ *                           ths; with want_score: npeaks[i], score = ths / (q * npeaks), i* = argmin(score[1:]) + 1 -> sel.
+ *   Results stay in the head of the workspace: yond_nle_state_layout gives the byte offsets of
+ *   {ths double[32], sel double[4] = {i*, ths[i*], q[i*], score[i*]}, mom double[10], npeaks int32[32], frame_max_key};
+ *   yond_nlf_moments_f32 can take th = ws + off[1] + 8 and mom = ws + off[2] directly. */
+size_t yond_nle_ws_bytes(size_t n);
+int yond_nle_stats_f32(const float* lap, const float* mean, size_t n, int width, const double* q_host, int nq, void* ws,
+                       void* stream);
+int yond_nle_threshold_f32(const float* lap, size_t n, const double* q_host, int nq, int want_score, void* ws, void* stream);
+int yond_nle_state_layout(int* off /*[5]*/);
+
 /* K7a occupancy: one pass over (lap, mean), n elements laid out as rows of `width` (n % width == 0; pass the
  *   image row length so that a lane can walk down a column of the smooth maps; any width is correct):
  *   for thresholds ths[0..nt) (ascending, float64, device)

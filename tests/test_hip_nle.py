@@ -209,3 +209,51 @@ def test_nlf_full_frame_size_properties():
     K, sig = reg[0] * 959, np.sqrt(max(reg[1], 0)) * 959
     print(f"[cfg2] estimated K={K:.4f} sigma={sig:.4f} (synthetic 4.0 / 6.0), percent={info['percent']}")
     assert abs(K - 4.0) < 0.2 and abs(sig - 6.0) < 3.0
+
+
+@pytest.mark.parametrize("shape", [(5, 1), (62, 70), (1000, 13), (4, 333, 500), (4, 1500, 2000)])
+def test_two_sweep_threshold_selection(shape):
+    """K6'/K7' (nle_fast.hip): percentiles bit-equal to np.percentile, npeaks and the selected index equal to the
+    reference formula (YOND_SIDD.py:22-49) -- odd widths, unaligned sizes, heavy duplicates, values outside [0, 2)."""
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    rng = np.random.default_rng(sum(shape))
+    n = int(np.prod(shape))
+    lap = ((rng.random(n).astype(np.float32) ** 3) * 0.05).reshape(shape)
+    # smooth component so that runs of equal level-1 bins occur, plus duplicates and a few outliers
+    lap = (lap + np.float32(0.01) * np.linspace(0, 1, shape[-1], dtype=np.float32)).astype(np.float32)
+    flat = lap.reshape(-1)
+    if n > 100:
+        flat[::7] = flat[3]
+        flat[5] = 3.5
+        flat[6] = 1e-30
+    mean = (rng.random(n).astype(np.float32) * 1.2 - 0.1).reshape(shape)
+    quants = np.linspace(5, 100, 20)
+    ths, npeaks, sel, _ = P._threshold_state(torch.from_numpy(lap).to(DEV), torch.from_numpy(mean).to(DEV), quants)
+    ref = np.percentile(flat, quants, method='linear')
+    assert np.array_equal(ths, ref), np.abs(ths - ref).max()
+    th, pct, info = O.get_threshold_score3(lap.reshape(-1), mean.reshape(-1), step=5, full=True)
+    np.testing.assert_array_equal(npeaks, info['npeaks'].astype(np.int64))
+    assert int(sel[0]) == info['index'] and sel[1] == th and sel[2] == pct
+
+
+def test_two_sweep_selection_constant_and_full_frame_property():
+    """Degenerate data (one level-1 bin holds everything: every element is a candidate) and, at the full cfg-2 size, a
+    size-independent property: the selected threshold splits the data at its quantile."""
+    from yond_public_amd import pipeline as P
+    quants = np.linspace(5, 100, 20)
+    c = torch.full((300, 1001), 0.0123, device=DEV)
+    m = torch.rand((300, 1001), device=DEV)
+    ths, npeaks, sel, _ = P._threshold_state(c, m, quants)
+    assert np.array_equal(ths, np.full(20, np.float64(np.float32(0.0123))))
+    assert npeaks.min() == npeaks.max() == len(torch.unique((m.clamp(0, 1) * 1000).int()))
+    g = torch.Generator(device=DEV).manual_seed(1)
+    lap = torch.rand((4, 1500, 2000), device=DEV, generator=g) ** 2 * 0.02
+    mean = torch.rand((4, 1500, 2000), device=DEV, generator=g)
+    ths, npeaks, sel, _ = P._threshold_state(lap, mean, quants)
+    n = lap.numel()
+    for q, t in zip(quants, ths):
+        below = int((lap.double() < t).sum().item())
+        le = int((lap.double() <= t).sum().item())
+        r = q / 100.0 * (n - 1)
+        assert below <= r + 1 and le >= r - 1, (q, t, below, le, r)

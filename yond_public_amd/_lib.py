@@ -62,6 +62,10 @@ PROTOTYPES = {
     "yond_select_ws_bytes": [i32],
     "yond_select_ranks_f32": [vp, sz, vp, i32, vp, vp, vp],
     "yond_percentiles_f32": [vp, sz, vp, i32, vp, vp, vp],
+    "yond_nle_ws_bytes": [sz],
+    "yond_nle_stats_f32": [vp, vp, sz, i32, vp, i32, vp, vp],
+    "yond_nle_threshold_f32": [vp, sz, vp, i32, i32, vp, vp],
+    "yond_nle_state_layout": [vp],
     "yond_nlf_occupancy_f32": [vp, vp, sz, i32, vp, i32, vp, vp],
     "yond_nlf_score3_f64": [vp, vp, vp, i32, vp, vp, vp],
     "yond_nlf_moments_f32": [vp, vp, vp, sz, vp, vp, vp],
@@ -69,7 +73,7 @@ PROTOTYPES = {
     "yond_block_metrics_tiles": [i32, i32],
     "yond_block_metrics_f32": [vp, vp, i32, i32, i32, i32, vp, vp],
 }
-_SIZE_T_RET = {"yond_select_ws_bytes"}
+_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes"}
 
 
 class YondHipError(RuntimeError):

@@ -12,7 +12,7 @@
 //   level 3  same for bits 7..0 below the 24-bit prefixes
 // A one-workgroup resolve kernel after each sweep walks the cumulative counts and hands the next level its
 // sorted list of prefixes ("slots", <= one per requested rank).  HBM-bound integer work; no MFMA.
-#include "common.h"
+#include "nle_common.h"
 
 #define SEL_MAXT 64                  // max number of order statistics per call
 #define SEL_L1_BINS 65536
@@ -35,14 +35,6 @@ struct SelState {
     unsigned int hist3[SEL_MAXT * 256];
     unsigned int hist1[SEL_L1_BINS];
 };
-
-__device__ __forceinline__ unsigned int f2key(float f) {
-    const unsigned int b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);       // total order of floats as unsigned
-}
-__device__ __forceinline__ float key2f(unsigned int k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
-}
 
 struct SelRanks { long long r[SEL_MAXT]; };
 
@@ -130,15 +122,6 @@ __device__ __forceinline__ int assign_slots(const unsigned int* s_newp, int nt, 
     }
     __syncthreads();
     return s_ns;
-}
-
-__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long up = __shfl_up(v, o);
-        if (lane >= o) v += up;
-    }
-    return v;
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void sel_resolve1_kernel(SelState* st, SelRanks ranks, int nt) {

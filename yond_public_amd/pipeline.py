@@ -228,19 +228,36 @@ def _fit_from_moments(m_all, m_ns):
     return np.array([(n * sxy - sx * sy) / det, (sxx * sy - sx * sxy) / det])
 
 
+def _threshold_state(lap, mean, quants, ws=None):
+    """K6'/K7' (nle_fast.hip): (ths float64[nq], npeaks int32[nq], sel float64[4], ws) of the two-sweep selection."""
+    lib = L.load()
+    width = lap.shape[-1] if lap.dim() > 1 else lap.numel()
+    lap, mean = lap.reshape(-1), mean.reshape(-1)
+    n = lap.numel()
+    q = np.ascontiguousarray(quants, dtype=np.float64)
+    qp = C.c_void_p(q.ctypes.data)
+    off_ths, off_sel, off_mom, off_np, _ = _nle_layout()
+    if ws is None:
+        ws = _nle_workspace(n, lap.device)
+        L.check(lib.yond_nle_stats_f32(L.ptr(lap), L.ptr(mean), n, int(width), qp, len(q), L.ptr(ws), L.stream()), "yond_nle_stats_f32")
+    L.check(lib.yond_nle_threshold_f32(L.ptr(lap), n, qp, len(q), 1, L.ptr(ws), L.stream()), "yond_nle_threshold_f32")
+    head = ws[:off_np + 4 * 32].cpu().numpy()
+    nq = len(q)
+    return (head[off_ths:off_ths + 8 * nq].view(np.float64).copy(), head[off_np:off_np + 4 * nq].view(np.int32).copy(),
+            head[off_sel:off_sel + 32].view(np.float64).copy(), ws)
+
+
 def get_threshold(data, step=5, mode='score3', print_log=False, scale=1023 - 64, _full=False):
-    """YOND_SIDD.py:13-52, mode 'score3': data = (img_lap, mean) device maps (any shape, same numel).
-    Returns (th, percent) like the reference; `_full` adds the internals (used by SimpleNLF)."""
+    """YOND_SIDD.py:13-52, mode 'score3': data = (img_lap, mean) device maps (same shape).
+    Returns (th, percent) like the reference; `_full` adds the internals."""
     if mode != 'score3':
         raise NotImplementedError(mode)
     lap, mean = data
-    width = lap.shape[-1] if lap.dim() > 1 else None
-    lap, mean = lap.reshape(-1), mean.reshape(-1)
     quants = np.linspace(step, 100, 100 // step, endpoint=True)
-    ths_dev = _percentiles(lap, quants)
-    occ = _occupancy(lap, mean, ths_dev, width)
-    ths = ths_dev.cpu().numpy()
-    th, pct, info = _score3(ths, quants, occ.cpu().numpy())
+    ths, npeaks, sel, _ = _threshold_state(lap, mean, quants)
+    th, pct, info = _score3(ths, quants, npeaks=npeaks)
+    if info['index'] != int(sel[0]) or th != sel[1]:
+        raise L.YondHipError(f"score3 mismatch: device picked {sel[0]:.0f}/{sel[1]!r}, host {info['index']}/{th!r}")
     if _full:
         return th, pct, info
     return th, pct
@@ -257,20 +274,52 @@ def _score3(ths, quants, occ=None, npeaks=None):
     return ths[i], quants[i], dict(ths=ths, npeaks=npeaks, score=score, index=i)
 
 
-def _nlf_from_maps(lap, mean, var, full=False):
-    """Shared tail of SelfNLF / CollabNLF (YOND_SIDD.py:75-87 / 103-115).  Percentiles, occupancy, score3 and
-    the moment sums below the selected threshold all run on the device; one host sync at the end."""
-    width = lap.shape[-1] if lap.dim() > 1 else None
+_NLE_LAYOUT = None
+
+
+def _nle_layout():
+    global _NLE_LAYOUT
+    if _NLE_LAYOUT is None:
+        off = (C.c_int * 5)()
+        L.check(L.load().yond_nle_state_layout(off), "yond_nle_state_layout")
+        _NLE_LAYOUT = tuple(int(v) for v in off)
+    return _NLE_LAYOUT
+
+
+QUANTS = np.linspace(5, 100, 20, endpoint=True)            # YOND_SIDD.py:25 with step = 5
+
+
+def _nle_workspace(n, dev):
+    return torch.empty(int(L.load().yond_nle_ws_bytes(n)), dtype=torch.uint8, device=dev)
+
+
+def _nlf_from_maps(lap, mean, var, full=False, ws=None):
+    """Shared tail of SelfNLF / CollabNLF (YOND_SIDD.py:75-87 / 103-115).  Percentiles, occupancy, score3 and the
+    moment sums below the selected threshold all run on the device; one host sync at the end.  `ws`: the workspace the
+    producer of the maps has already filled with the level-1 statistics (fused box kernel), else a sweep does it."""
+    lib = L.load()
+    width = lap.shape[-1] if lap.dim() > 1 else lap.numel()
     lap, mean, var = lap.reshape(-1), mean.reshape(-1), var.reshape(-1)
-    quants = np.linspace(5, 100, 20, endpoint=True)
+    n = lap.numel()
+    quants = QUANTS
+    q = np.ascontiguousarray(quants, dtype=np.float64)
+    qp = C.c_void_p(q.ctypes.data)
+    off_ths, off_sel, off_mom, off_np, _ = _nle_layout()
+    st = L.stream()
     with _stage("nle_select_score_moments"):
-        ths_dev = _percentiles(lap, quants)
-        occ = _occupancy(lap, mean, ths_dev, width)
-        sel_dev, npeaks_dev = _score3_device(occ, ths_dev, quants)
-        mom = _moments(lap, mean, var, sel_dev[1:2])
-    small = torch.cat([ths_dev, sel_dev, mom.reshape(-1), npeaks_dev.to(torch.float64)]).cpu().numpy()   # the one sync
+        if ws is None:
+            ws = _nle_workspace(n, lap.device)
+            L.check(lib.yond_nle_stats_f32(L.ptr(lap), L.ptr(mean), n, int(width), qp, len(q), L.ptr(ws), st), "yond_nle_stats_f32")
+        L.check(lib.yond_nle_threshold_f32(L.ptr(lap), n, qp, len(q), 1, L.ptr(ws), st), "yond_nle_threshold_f32")
+        base = ws.data_ptr()
+        L.check(lib.yond_nlf_moments_f32(L.ptr(lap), L.ptr(mean), L.ptr(var), n, C.c_void_p(base + off_sel + 8),
+                                         C.c_void_p(base + off_mom), st), "yond_nlf_moments_f32")
+    head = ws[:off_np + 4 * 32].cpu().numpy()                   # the one sync
     nq = len(quants)
-    ths, sel_h, mom_h, npeaks = small[:nq], small[nq:nq + 4], small[nq + 4:nq + 14].reshape(2, 5), small[nq + 14:]
+    ths = head[off_ths:off_ths + 8 * nq].view(np.float64).copy()
+    sel_h = head[off_sel:off_sel + 32].view(np.float64).copy()
+    mom_h = head[off_mom:off_mom + 80].view(np.float64).reshape(2, 5).copy()
+    npeaks = head[off_np:off_np + 4 * nq].view(np.int32).copy()
     th, pct, info = _score3(ths, quants, npeaks=npeaks)
     if info['index'] != int(sel_h[0]) or th != sel_h[1]:          # host and device run the same float64 formula
         raise L.YondHipError(f"score3 mismatch: device picked {sel_h[0]:.0f}/{sel_h[1]!r}, host {info['index']}/{th!r}")

@@ -207,6 +207,16 @@ int yond_box_stats_self2_f32(const float* blur2, int h, int w, int k, int tile_w
 int yond_box_stats_collab_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,
                               float* mean, float* var, float* lap, void* stream);
 
+/* K5' the same maps in ONE pass over the frame(s) -- the B19 map of the self mode never leaves the chip -- together with
+ * sweep 1 of the threshold selection (see yond_nle_stats_f32 below: level-1 histogram of lap, per-mean-bin minimum of lap,
+ * resolve of the percentile ranks) and the frame maximum (lr.max() for the bias LUT grid, YOND_SIDD.py:256/393; in the
+ * workspace head as an order-preserving key).  Replaces yond_box_stats_self1/self2 (or _collab) + yond_nle_stats_f32 on
+ * the hot path; continue with yond_nle_threshold_f32(lap, ...) on the same workspace.  k <= 29, k2 <= k. */
+int yond_box_stats_self_fused_f32(const float* bayer, int H, int W, int k, int k2, int tile_w, float* mean, float* var,
+                                  float* lap, const double* q_host, int nq, void* ws, void* stream);
+int yond_box_stats_collab_fused_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,
+                                    float* mean, float* var, float* lap, const double* q_host, int nq, void* ws, void* stream);
+
 /* K6  exact order statistics of a non-negative float32 map (np.percentile's two neighbours).
  * ranks: nr 0-based ranks (device int64); out: nr float values (device).  ws: workspace of
  * yond_select_ws_bytes(nr) bytes.  Replaces the sort inside np.percentile at YOND_SIDD.py:26,80. */

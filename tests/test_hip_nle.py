@@ -257,3 +257,83 @@ def test_two_sweep_selection_constant_and_full_frame_property():
         le = int((lap.double() <= t).sum().item())
         r = q / 100.0 * (n - 1)
         assert below <= r + 1 and le >= r - 1, (q, t, below, le, r)
+
+
+@pytest.mark.parametrize("H,W,tile_w", [(256, 256, 0), (200, 328, 0), (62, 70, 0), (700, 1000, 0), (256, 2048, 32)])
+def test_fused_box_statistics_self(H, W, tile_w):
+    """K5' (nle_fused.hip): one pass -> mean, var, lap (the B19 map never leaves the chip) + the level-1 statistics of
+    the threshold selection + the frame maximum.  Maps against the oracle (<= 1 ulp) and BIT-identical to the
+    stand-alone kernels; the selection state against the stand-alone sweep."""
+    import yond_oracle as O
+    from yond_public_amd import _lib as L
+    from yond_public_amd import pipeline as P
+    lib = L.load()
+    noisy, _ = O.synth_noisy(H, W, 4.0, 6.0, 11)
+    h, w = H // 2, W // 2
+    t = torch.from_numpy(noisy).to(DEV)
+    o = [torch.empty((4, h, w), device=DEV) for _ in range(7)]
+    q = np.ascontiguousarray(P.QUANTS)
+    import ctypes as C
+    qp = C.c_void_p(q.ctypes.data)
+    ws = P._nle_workspace(4 * h * w, t.device)
+    L.check(lib.yond_box_stats_self_fused_f32(L.ptr(t), H, W, 29, 19, tile_w, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), qp, len(q),
+                                              L.ptr(ws), L.stream()), "fused")
+    L.check(lib.yond_box_stats_self1_f32(L.ptr(t), H, W, 29, 19, tile_w, L.ptr(o[3]), L.ptr(o[4]), L.ptr(o[6]), L.stream()), "self1")
+    L.check(lib.yond_box_stats_self2_f32(L.ptr(o[6]), h, w, 29, tile_w, L.ptr(o[5]), L.stream()), "self2")
+    for a, b, name in zip(o[:3], o[3:6], ("mean", "var", "lap")):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    if not tile_w:
+        rggb = O.bayer2rggb(noisy)
+        assert report("fused mean", o[0].cpu().numpy(), planes(O.box_blur(rggb, 29))) <= 6e-8
+        assert report("fused var", o[1].cpu().numpy(), planes(O.stdfilt(rggb, 29) ** 2)) <= 2e-8
+        assert report("fused lap", o[2].cpu().numpy(), planes(O.stdfilt(O.box_blur(rggb, 19), 29))) <= 2e-6
+    # selection state: finish on the fused workspace and on a stand-alone one
+    ths_f, np_f, sel_f, _ = P._threshold_state(o[2], o[0], q, ws=ws)
+    ths_s, np_s, sel_s, _ = P._threshold_state(o[5], o[3], q)
+    assert np.array_equal(ths_f, ths_s) and np.array_equal(np_f, np_s) and np.array_equal(sel_f, sel_s)
+    assert np.array_equal(ths_f, np.percentile(o[2].cpu().numpy().reshape(-1), q, method='linear'))
+    off_max = P._nle_layout()[4]
+    key = int(ws[off_max:off_max + 4].cpu().numpy().view(np.uint32)[0])
+    assert P._key2float(key) == noisy.max()
+
+
+def test_fused_box_statistics_collab():
+    import ctypes as C
+    import yond_oracle as O
+    from yond_public_amd import _lib as L
+    from yond_public_amd import pipeline as P
+    lib = L.load()
+    H, W = 256, 2048
+    noisy, clean = O.synth_noisy(H, W, 4.0, 6.0, 12)
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(W)[None, :] / 37.0), 0, 1).astype(np.float32)
+    q = np.ascontiguousarray(P.QUANTS)
+    qp = C.c_void_p(q.ctypes.data)
+    h, w = H // 2, W // 2
+    nd, dd = torch.from_numpy(noisy).to(DEV), torch.from_numpy(dn).to(DEV)
+    for tile_w in (0, 64):
+        o = [torch.empty((4, h, w), device=DEV) for _ in range(6)]
+        ws = P._nle_workspace(4 * h * w, nd.device)
+        L.check(lib.yond_box_stats_collab_fused_f32(L.ptr(nd), L.ptr(dd), H, W, 29, tile_w, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]),
+                                                    qp, len(q), L.ptr(ws), L.stream()), "collab fused")
+        L.check(lib.yond_box_stats_collab_f32(L.ptr(nd), L.ptr(dd), H, W, 29, tile_w, L.ptr(o[3]), L.ptr(o[4]), L.ptr(o[5]),
+                                              L.stream()), "collab")
+        for a, b, name in zip(o[:3], o[3:], ("mean", "var", "lap")):
+            assert torch.equal(a, b), (name, tile_w, float((a - b).abs().max()))
+        ths_f, np_f, sel_f, _ = P._threshold_state(o[2], o[0], q, ws=ws)
+        ths_s, np_s, sel_s, _ = P._threshold_state(o[5], o[3], q)
+        assert np.array_equal(ths_f, ths_s) and np.array_equal(np_f, np_s) and np.array_equal(sel_f, sel_s)
+
+
+def test_simple_nlf_fused_equals_unfused_full_frame():
+    """cfg-2 size: the fused estimator and the stand-alone kernels give the same estimate (same maps bit for bit; the
+    float64 moment sums are accumulated with atomics, so the fit agrees to the summation order)."""
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    noisy, _ = O.synth_noisy(3000, 4000, 4.0, 6.0, 3)
+    t = torch.from_numpy(noisy).to(DEV)
+    ra, ia = P.SimpleNLF(t, k=29, setting={'mode': 'self'}, full=True)
+    rb, ib = P.SimpleNLF(t, k=29, setting={'mode': 'self'}, full=True, fused=False)
+    assert ia['th'] == ib['th'] and ia['percent'] == ib['percent'] and ia['nsel'] == ib['nsel']
+    np.testing.assert_array_equal(ia['npeaks'], ib['npeaks'])
+    np.testing.assert_allclose(ra, rb, rtol=1e-9)
+    assert ia['frame_max'] == noisy.max()

@@ -314,7 +314,9 @@ def _nlf_from_maps(lap, mean, var, full=False, ws=None):
         base = ws.data_ptr()
         L.check(lib.yond_nlf_moments_f32(L.ptr(lap), L.ptr(mean), L.ptr(var), n, C.c_void_p(base + off_sel + 8),
                                          C.c_void_p(base + off_mom), st), "yond_nlf_moments_f32")
-    head = ws[:off_np + 4 * 32].cpu().numpy()                   # the one sync
+    head = ws[:off_np + 4 * 32 + 4 * 64 + 8].cpu().numpy()      # the one sync (results head of the workspace)
+    off_max = _nle_layout()[4]
+    frame_max_key = int(head[off_max:off_max + 4].view(np.uint32)[0])
     nq = len(quants)
     ths = head[off_ths:off_ths + 8 * nq].view(np.float64).copy()
     sel_h = head[off_sel:off_sel + 32].view(np.float64).copy()
@@ -337,12 +339,24 @@ def _nlf_from_maps(lap, mean, var, full=False, ws=None):
         reg = _fit_from_moments(sel[0], sel[1])
     if full:
         info.update(th=th, percent=pct, nsel=int(sel[0, 0]))
+        if frame_max_key:
+            info['frame_max'] = _key2float(frame_max_key)
         return reg, info
     return reg
 
 
-def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None):
-    """YOND_SIDD.py:117-124 (+ SelfNLF :62-87, CollabNLF :89-115): Bayer frame(s) -> (beta1, beta2)."""
+def _key2float(key):
+    """Inverse of the kernels' order-preserving float key (nle_common.h f2key)."""
+    key = int(key) & 0xFFFFFFFF
+    bits = (key & 0x7FFFFFFF) if (key & 0x80000000) else (~key & 0xFFFFFFFF)
+    return np.array([bits], dtype=np.uint32).view(np.float32)[0]
+
+
+def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, fused=True):
+    """YOND_SIDD.py:117-124 (+ SelfNLF :62-87, CollabNLF :89-115): Bayer frame(s) -> (beta1, beta2).
+    fused (default): one pass over the frame(s) produces the three maps and the first sweep of the threshold selection
+    (nle_fused.hip); fused=False: the stand-alone kernels of the first version (kept for the function seam and as a
+    cross-check).  With full=True the info dict carries 'frame_max' (float32 maximum of lr_raw) on the fused path."""
     setting = setting or {'mode': 'self'}
     lib = L.load()
     lr = _dev(lr_raw, device)
@@ -354,23 +368,37 @@ def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None):
     new = lambda: torch.empty((4, h, w), dtype=torch.float32, device=lr.device)
     mean, var, lap = new(), new(), new()
     st = L.stream()
+    k2 = k // 3 * 2 + 1
+    fused = fused and k <= 29
+    ws = None
+    q = np.ascontiguousarray(QUANTS, dtype=np.float64)
+    qp = C.c_void_p(q.ctypes.data)
+    if fused:
+        ws = _nle_workspace(4 * h * w, lr.device)
     if setting['mode'] == 'self':
-        blur2 = new()
-        k2 = k // 3 * 2 + 1
         with _stage("nle_box_self"):
-            L.check(lib.yond_box_stats_self1_f32(L.ptr(lr), H, W, k, k2, tile_w, L.ptr(mean), L.ptr(var), L.ptr(blur2), st),
-                    "yond_box_stats_self1_f32")
-            L.check(lib.yond_box_stats_self2_f32(L.ptr(blur2), h, w, k, tile_w, L.ptr(lap), st), "yond_box_stats_self2_f32")
+            if fused:
+                L.check(lib.yond_box_stats_self_fused_f32(L.ptr(lr), H, W, k, k2, tile_w, L.ptr(mean), L.ptr(var), L.ptr(lap),
+                                                          qp, len(q), L.ptr(ws), st), "yond_box_stats_self_fused_f32")
+            else:
+                blur2 = new()
+                L.check(lib.yond_box_stats_self1_f32(L.ptr(lr), H, W, k, k2, tile_w, L.ptr(mean), L.ptr(var), L.ptr(blur2), st),
+                        "yond_box_stats_self1_f32")
+                L.check(lib.yond_box_stats_self2_f32(L.ptr(blur2), h, w, k, tile_w, L.ptr(lap), st), "yond_box_stats_self2_f32")
     elif setting['mode'] == 'collab':
         hr = _dev(hr_raw, lr.device)
         if hr.shape != lr.shape:
             raise L.YondHipError("collab NLF needs noisy and denoised frames of the same shape")
         with _stage("nle_box_collab"):
-            L.check(lib.yond_box_stats_collab_f32(L.ptr(lr), L.ptr(hr), H, W, k, tile_w, L.ptr(mean), L.ptr(var), L.ptr(lap), st),
-                    "yond_box_stats_collab_f32")
+            if fused:
+                L.check(lib.yond_box_stats_collab_fused_f32(L.ptr(lr), L.ptr(hr), H, W, k, tile_w, L.ptr(mean), L.ptr(var),
+                                                            L.ptr(lap), qp, len(q), L.ptr(ws), st), "yond_box_stats_collab_fused_f32")
+            else:
+                L.check(lib.yond_box_stats_collab_f32(L.ptr(lr), L.ptr(hr), H, W, k, tile_w, L.ptr(mean), L.ptr(var), L.ptr(lap), st),
+                        "yond_box_stats_collab_f32")
     else:
         raise NotImplementedError(setting['mode'])
-    return _nlf_from_maps(lap, mean, var, full)
+    return _nlf_from_maps(lap, mean, var, full, ws=ws)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -524,14 +552,16 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     else:
         lr_cat = lr
     raw4est = lr_cat if lr_full is None else _dev(lr_full, lr.device)                  # :340
-    lr_max_dev = _frame_max(lr_cat)            # queued ahead of the NLE; read after the NLE's own host sync
-    reg = SimpleNLF(raw4est, k=k, setting={'mode': 'self'})                            # :341
+    # lr.max() for the bias LUT grid: the fused estimator kernel collects it when it reads the same frame; else a
+    # reduction queued ahead of the NLE and read after the NLE's own host sync
+    lr_max_dev = _frame_max(lr_cat) if (lr_full is not None or k > 29) else None
+    reg, nle_info = SimpleNLF(raw4est, k=k, setting={'mode': 'self'}, full=True)       # :341
     p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale            # :356
     if log:
         log(f"Self Est: K={p['gain']:.4f}, b={p['sigma']:.4f} (beta1={reg[0]:.3e}, beta2={reg[1]:.3e})")
     regs.append(reg)
     params.append((p['gain'], p['sigma']))
-    lr_max = np.float32(lr_max_dev.item())
+    lr_max = np.float32(lr_max_dev.item()) if lr_max_dev is not None else np.float32(nle_info['frame_max'])
 
     def denoise_all(bias_func):
         if full_dn:                                                                    # :387-389
@@ -585,9 +615,9 @@ def IterDenoiseBatch(frames, net, arch, pipe, p=None, device=None):
     lrs = [_dev(f, device) for f in frames]
     B = len(lrs)
     stack = torch.stack(lrs)
-    max_dev = [_frame_max(f) for f in lrs]
-    regs = [SimpleNLF(f, k=k, setting={'mode': 'self'}) for f in lrs]                    # :341 per frame
-    maxes = [np.float32(m.item()) for m in max_dev]
+    est = [SimpleNLF(f, k=k, setting={'mode': 'self'}, full=True) for f in lrs]          # :341 per frame
+    regs = [e[0] for e in est]
+    maxes = [np.float32(e[1]['frame_max']) if 'frame_max' in e[1] else np.float32(_frame_max(f).item()) for e, f in zip(est, lrs)]
     ps = [dict(p0, gain=r[0] * scale, sigma=np.sqrt(max(r[1], 0)) * scale) for r in regs]  # :356
     raw_dn = VST_Denoiser(stack, ps, net, arch, bias_corr, None, vst_type, clip01=True, lr_max=maxes)
     raw_dns, all_regs, all_params = [raw_dn], [regs], [[(q['gain'], q['sigma']) for q in ps]]
@@ -649,9 +679,9 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     def estimate(lr, ready):               # phase 1 on the side stream; returns host scalars only
         side.wait_event(ready)             # the frame as it stood when it was handed in -- NOT the work queued since
         with torch.cuda.stream(side):
-            lr_max_dev = _frame_max(lr)
-            reg = SimpleNLF(lr, k=k, setting={'mode': 'self'})
-            lr_max = np.float32(lr_max_dev.item())
+            lr_max_dev = _frame_max(lr) if k > 29 else None
+            reg, info = SimpleNLF(lr, k=k, setting={'mode': 'self'}, full=True)
+            lr_max = np.float32(lr_max_dev.item()) if lr_max_dev is not None else np.float32(info['frame_max'])
         return lr, reg, lr_max
 
     it = iter(frames)

@@ -49,6 +49,7 @@ struct NleState {
     unsigned int maxinv[NF_BINS];    // per mean bin: ~key of the SMALLEST lap seen (0 = bin empty): the bin is occupied
                                      // among lap <= T  <=>  its smallest lap <= T
     unsigned int hist1[NF_L1];
+    unsigned long long dbg[64];      // cycle stamps of diagnostic builds (-DBF_STAMPS)
 };
 #define NLE_HEAD_DOUBLES (NF_MAXQ + 4 + 10)
 

@@ -206,7 +206,23 @@ __global__ __launch_bounds__(NFF_THREADS) void nf_final_kernel(NleState* st, con
         s_h[tid] = 0;
         __syncthreads();
         const int mt = s_nt;
-        for (unsigned int i = tid; i < cnt; i += NFF_THREADS) atomicAdd(&s_h[c[i] >> 8], 1u);
+        // candidate ranges start on 16-byte boundaries: 8 candidates per load, four loads in flight
+        const uint4* c4 = (const uint4*)c;
+        const unsigned int n8 = cnt / 8;
+        auto count_hi = [&](uint4 q) {
+            const unsigned int wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { atomicAdd(&s_h[(wv[j] >> 8) & 255u], 1u); atomicAdd(&s_h[wv[j] >> 24], 1u); }
+        };
+        for (unsigned int i = tid; i < n8; i += NFF_THREADS * 4) {
+            uint4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = c4[min(i + u * NFF_THREADS, n8 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * NFF_THREADS < n8) count_hi(q[u]);
+        }
+        for (unsigned int i = n8 * 8 + tid; i < cnt; i += NFF_THREADS) atomicAdd(&s_h[c[i] >> 8], 1u);
         __syncthreads();
         // wave 0: cumulative counts of the 256 bins (4 per lane), then every target finds its bin
         if (wave == 0) {
@@ -238,7 +254,23 @@ __global__ __launch_bounds__(NFF_THREADS) void nf_final_kernel(NleState* st, con
             const unsigned int b8 = (unsigned int)s_b8[k];
             s_h[tid] = 0;
             __syncthreads();
-            for (unsigned int i = tid; i < cnt; i += NFF_THREADS) {
+            auto count_lo = [&](uint4 q) {
+                const unsigned int wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (((wv[j] >> 8) & 255u) == b8) atomicAdd(&s_h[wv[j] & 255u], 1u);
+                    if ((wv[j] >> 24) == b8) atomicAdd(&s_h[(wv[j] >> 16) & 255u], 1u);
+                }
+            };
+            for (unsigned int i = tid; i < n8; i += NFF_THREADS * 4) {
+                uint4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = c4[min(i + u * NFF_THREADS, n8 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u * NFF_THREADS < n8) count_lo(q[u]);
+            }
+            for (unsigned int i = n8 * 8 + tid; i < cnt; i += NFF_THREADS) {
                 const unsigned int v = c[i];
                 if ((v >> 8) == b8) atomicAdd(&s_h[v & 255u], 1u);
             }

@@ -43,38 +43,22 @@ __device__ __forceinline__ float bf_std_from(float b1, float b2) {          // u
     return __fsqrt_rn(fmaxf(d, 0.0f));
 }
 
-// Register rings indexed by a WAVE-UNIFORM position: the switch is a scalar branch and every case names a fixed register
-// (a dynamically indexed private array would live in scratch memory).
+// Dispatch on a WAVE-UNIFORM value: a scalar branch; every case sees its value as a constant, so the register rings
+// below are indexed by constants (a dynamically indexed private array would live in scratch memory).
 #define BF_CASES16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define BF_CASES32(X) BF_CASES16(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
-struct BfRing {                       // 29-deep ring of the B19 rows of this thread's column
-    float r[32];
-    __device__ __forceinline__ float swap(int pos, float in) {
-        float out = 0.0f;
-#define BF_CASE(i) case i: out = r[i]; r[i] = in; break;
-        switch (pos) { BF_CASES32(BF_CASE) }
+#define BF_CASE(i) case i: f(IntC<i>{}); break;
+template <class F>
+__device__ __forceinline__ void uniform_switch16(int v, F&& f) { switch (v) { BF_CASES16(BF_CASE) } }
+template <class F>
+__device__ __forceinline__ void uniform_switch32(int v, F&& f) { switch (v) { BF_CASES32(BF_CASE) } }
 #undef BF_CASE
-        return out;
-    }
-};
-struct BfBins {                       // mean bins of the last 16 rows of this thread's column
-    int r[16];
-    __device__ __forceinline__ void set(int pos, int v) {
-#define BF_CASE(i) case i: r[i] = v; break;
-        switch (pos) { BF_CASES16(BF_CASE) }
-#undef BF_CASE
-    }
-    __device__ __forceinline__ int get(int pos) const {
-        int out = 0;
-#define BF_CASE(i) case i: out = r[i]; break;
-        switch (pos) { BF_CASES16(BF_CASE) }
-#undef BF_CASE
-        return out;
-    }
-};
+
+template <int N>
+struct BfPtrs { const double* p[N]; };
 
 // MODE 0: self (a = noisy Bayer frame), MODE 2: collab (a = noisy, b = denoised)
-template <int MODE>
+template <int MODE, int K, int K2>
 __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict__ fa, const float* __restrict__ fb, BfGeom g,
                                                        float* __restrict__ o_mean, float* __restrict__ o_var,
                                                        float* __restrict__ o_lap, NleState* st, NfArgs args) {
@@ -83,20 +67,22 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     constexpr int NQ = SELF ? 5 : 4;                      // all vertical sums
     constexpr int NI = SELF ? 1 : 2;                      // input frames
     constexpr int NL = SELF ? 3 : 2;                      // loads per input and row: entering, leaving (k), leaving (k2)
-    extern __shared__ unsigned char s_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];    // (unaligned, its float64 accesses crawl)
     double* s_v = (double*)s_raw;                                             // [NQ][2][BF_B][BF_RS]
     float* s_st = (float*)(s_raw + (size_t)NQ * 2 * BF_B * BF_RS * 8);        // staging [4][2][BF_B][BF_T]: mean, var, b19, lap
     unsigned int* s_h = (unsigned int*)(s_st + 4 * 2 * BF_B * BF_T);          // [NF_WIN_N / 2] two 16-bit counters per word
     unsigned int* s_mi = s_h + NF_WIN_N / 2;                                  // [NF_BINS]
-    int* s_row = (int*)(s_mi + NF_BINS);                                      // [BF_MAXOH + 2 * (2 * BF_MAXR)]
     auto V = [&](int q, int half, int r) -> double* { return s_v + ((size_t)(q * 2 + half) * BF_B + r) * BF_RS; };
+    // staging rows are indexed from the first column that is written: outputs start at HALO (b19 rows: at HALO - R), so
+    // that the 16-byte rows of the store phase are aligned
     auto ST = [&](int m, int half, int r) -> float* { return s_st + ((size_t)(m * 2 + half) * BF_B + r) * BF_T; };
 
-    const int tid = threadIdx.x, half = tid >> 8, col = tid & 255;
+    const int tid = threadIdx.x, half = tid >> 8, col = tid & 255, lane = tid & 63;
     const int dy = blockIdx.z, plane = 2 * dy + half;
-    const int h = g.h, w = g.w, k = g.k, k2 = g.k2;
-    const int R = k / 2, R2 = SELF ? k2 / 2 : 0;
-    const int HALO = SELF ? R + R2 : R;                                       // self: x -> b19 (R2) -> lap (R)
+    const int h = g.h, w = g.w;
+    constexpr int k = K, k2 = K2;                                             // window sizes are template constants: the window
+    constexpr int R = K / 2, R2 = SELF ? K2 / 2 : 0;                          // loops unroll into reads at immediate offsets
+    constexpr int HALO = SELF ? R + R2 : R;                                   // self: x -> b19 (R2) -> lap (R)
     const double inv_k = 1.0 / (double)(k * k), inv_k2 = 1.0 / (double)(k2 * k2);
     // columns: reflect inside [bx0, bx0 + bw) -- bw = tile_w (SIDD_256 re-tiling) or the whole width
     const int bw = g.tile_w > 0 ? g.tile_w : w;
@@ -106,24 +92,40 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     const int ow = min(g.ow_nom, bx0 + bw - ox0);
     const int rc = bx0 + reflect101(ox0 - HALO + col - bx0, bw);              // image column of this virtual column
     const bool writer = col >= HALO && col < HALO + ow;
-    const int ox = ox0 + col - HALO;
+    const bool vec_ok = !((w | ox0 | ow) & 3);                                // 16-byte rows: stores as float4
     // rows
     const int oy0 = blockIdx.y * g.oh;
     const int ohe = min(g.oh, h - oy0);
     const int nsteps = ohe + 2 * HALO;
     for (int i = tid; i < NF_WIN_N / 2 + NF_BINS; i += 512) s_h[i] = 0;
-    for (int l = tid; l < nsteps; l += 512) s_row[l] = reflect101(oy0 - HALO + l, h);
-    __syncthreads();
     const float* base[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) base[i] = (i == 0 ? fa : fb) + (size_t)dy * g.W2 + 2 * rc + half;
     const size_t rstride = (size_t)2 * g.W2;
-    auto ld = [&](int i, int l) -> float {
-        const int gy = s_row[min(max(l, 0), nsteps - 1)];
+    auto ld = [&](int i, int l) -> float {                                    // l is uniform: the row address is scalar arithmetic
+        int gy = oy0 - HALO + min(max(l, 0), nsteps - 1);
+        if (gy < 0 || gy >= h) {                                              // (uniform) one reflection without the modulo; else the general map
+            const int g1 = gy < 0 ? -gy : 2 * (h - 1) - gy;
+            gy = (g1 >= 0 && g1 < h) ? g1 : reflect101(gy, h);
+        }
         return base[i][(size_t)gy * rstride];
     };
     float cur[NI][NL][BF_B], nxt[NI][NL][BF_B];
     auto load_batch = [&](float (&dst)[NI][NL][BF_B], int l0) {
+        const int y0 = oy0 - HALO + l0;
+        if (l0 >= k && l0 + BF_B <= nsteps && y0 - k >= 0 && y0 + BF_B <= h) {   // (uniform) interior batch: no clamp, no reflection
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float* p = base[i] + (size_t)y0 * rstride;
+#pragma unroll
+                for (int r = 0; r < BF_B; ++r) {
+                    dst[i][0][r] = p[(size_t)r * rstride];
+                    dst[i][1][r] = (p - (size_t)k * rstride)[(size_t)r * rstride];
+                    if (NL == 3) dst[i][2][r] = (p - (size_t)k2 * rstride)[(size_t)r * rstride];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
 #pragma unroll
@@ -137,30 +139,45 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     double S[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) S[q] = 0.0;
-    BfRing ring;
+    float ring[32];                                                           // self: the last 32 b19 rows of this column (slot = row & 31)
 #pragma unroll
-    for (int i = 0; i < 32; ++i) ring.r[i] = 0.0f;
-    BfBins rbin;                                                              // self: the lap row lags its mean row by R2 rows
+    for (int i = 0; i < 32; ++i) ring[i] = 0.0f;
+    int rbin[16];                                                             // self: mean bins of the last 16 rows (the lap row lags by R2)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rbin.r[i] = 0;
-    unsigned int run_id = 0, run_cnt = 0, cmax = 0;
-    int cbin = -1;
+    for (int i = 0; i < 16; ++i) rbin[i] = 0;
     float fmax_ = -INFINITY;
-    auto hist_flush = [&]() {
-        if (!run_cnt) return;
-        const unsigned int wdw = run_id - NF_WIN_LO;
-        if (wdw < NF_WIN_N) atomicAdd(&s_h[wdw >> 1], run_cnt << ((wdw & 1u) * 16));
-        else atomicAdd(&st->hist1[run_id], run_cnt);
+    // statistics of one finished row (all lanes of the wave take part): level-1 histogram with runs of equal bins across
+    // the lanes (adjacent columns of the smooth map) merged into one LDS atomic; per mean bin the smallest lap
+    // (the four rows of a batch go through each step together, so that their LDS round trips overlap)
+    auto stats_rows = [&](const bool (&rowv)[BF_B], const float (&lapv)[BF_B], const int (&bin)[BF_B]) {
+        unsigned int key[BF_B], id[BF_B], prev[BF_B], known[BF_B];
+        bool valid[BF_B];
+#pragma unroll
+        for (int r = 0; r < BF_B; ++r) {
+            valid[r] = rowv[r] && writer;
+            key[r] = f2key(lapv[r]);
+            id[r] = valid[r] ? (key[r] >> 16) : (0xFFFF0000u | (unsigned int)lane);      // invalid lanes never merge
+            prev[r] = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)id[r], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            known[r] = s_mi[valid[r] ? bin[r] : 0];                           // what the workgroup already knows about the bin
+        }
+#pragma unroll
+        for (int r = 0; r < BF_B; ++r) {
+            const bool head = (lane == 0) || (id[r] != prev[r]);
+            const unsigned long long m = __ballot(head);
+            if (head && valid[r]) {
+                const unsigned long long rest = (m >> lane) >> 1;
+                const unsigned int len = rest ? (unsigned int)__ffsll((long long)rest) : (unsigned int)(64 - lane);
+                const unsigned int wdw = id[r] - NF_WIN_LO;
+                // two 16-bit counters per word: bins w and w + 8192, so that neighbouring bins (what neighbouring pixels
+                // hit) sit in neighbouring words / banks
+                if (wdw < NF_WIN_N) atomicAdd(&s_h[wdw & (NF_WIN_N / 2 - 1)], len << ((wdw >> 13) * 16));
+                else atomicAdd(&st->hist1[id[r]], len);
+            }
+            const unsigned int inv = ~key[r];
+            if (valid[r] && inv > known[r]) atomicMax(&s_mi[bin[r]], inv);
+        }
     };
-    auto stats = [&](float lapv, int bin) {
-        const unsigned int key = f2key(lapv);
-        const unsigned int id = key >> 16;
-        if (id != run_id) { hist_flush(); run_id = id; run_cnt = 0; }
-        run_cnt += 1;
-        if (bin != cbin) { cbin = bin; cmax = 0; }
-        const unsigned int inv = ~key;
-        if (inv > cmax) { cmax = inv; atomicMax(&s_mi[bin], inv); }
-    };
+    auto bin_of = [](float m) -> int { return (int)__fmul_rn(fminf(fmaxf(m, 0.0f), 1.0f), 1000.0f); };   // (mean.clip(0,1)*nbins).astype(int)
 
     // ---- task tables (task phase): groups A (mean, var / collab: all three), C (lap, self only), B (b19, self only) ----
     const int nA = (ow + BF_LA - 1) / BF_LA;                                  // chunks per row of the 29-window groups
@@ -169,76 +186,49 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     const int baseC = (tasksA + 63) & ~63, tasksC = SELF ? tasksA : 0;
     const int baseB = SELF ? ((baseC + tasksC + 63) & ~63) : baseC, tasksB = 2 * BF_B * nBc;
     const int ntask_threads = baseB + tasksB;                                 // <= 512 for ow <= 210 (host checks)
+    const int n4 = (ow + 3) >> 2;
 
+    __syncthreads();
     load_batch(nxt, 0);
     const int nbatch = (nsteps + BF_B - 1) / BF_B;
+#ifdef BF_STAMPS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define BF_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define BF_STAMP(i)
+#endif
+    // Sliding k-window sums of one chunk: NS sums over rows v[0..NS), first output column c0 (index into the rows), LEN
+    // outputs (only those below c1 are emitted), window radius rad = kk / 2.  All LDS reads are issued ahead of their use.
+    auto slide = [&](auto ns_c, auto len_c, auto kk_c, auto vp, int c0, int c1, auto&& emit) {
+        constexpr int NS = decltype(ns_c)::value, LEN = decltype(len_c)::value, KK = decltype(kk_c)::value, RAD = KK / 2;
+        const double* v[NS];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) v[s2] = vp.p[s2] + c0 - RAD;          // every read below is at an immediate offset
+        double a[NS];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {                                     // window of the chunk's first output
+            double t0 = 0.0, t1 = 0.0;                                        // (two chains; float64 sums of float32 data are exact)
+#pragma unroll
+            for (int i = 0; i + 1 < KK; i += 2) { t0 += v[s2][i]; t1 += v[s2][i + 1]; }
+            a[s2] = (t0 + t1) + v[s2][KK - 1];
+        }
+        emit(c0, a);
+#pragma unroll
+        for (int u = 0; u < LEN - 1; ++u) {
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) a[s2] += v[s2][KK + u] - v[s2][u];
+            if (c0 + 1 + u < c1) emit(c0 + 1 + u, a);
+        }
+    };
+
     // batch nb handles entering rows l0 .. l0 + 3.  Column phase of iteration nb: stage-1 sums of batch nb, stage-2 sums
     // of batch nb - 1 (its b19 rows were finished by the task phase of iteration nb - 1), stores of what the previous
     // task phase finished.  One extra iteration drains the pipeline.
     for (int nb = 0; nb <= nbatch + (SELF ? 1 : 0); ++nb) {
         const int l0 = nb * BF_B;
         // ================= column phase =================
-        // (a) stores + statistics of the rows the previous task phase finished
-        // (first the lap rows: they read the bins of mean rows stored up to the previous iteration -- the ring is 16 deep)
-        if (SELF && nb > 1 && writer) {
-            const int lp = l0 - 2 * BF_B;                                     // lap rows of the batch before the previous one
-#pragma unroll
-            for (int r = 0; r < BF_B; ++r) {
-                const int l = lp + r;
-                const int cl = l - R2 - R;                                    // lap row: x row l -> b19 row l - R2 -> lap row - R
-                if (cl >= HALO && cl < HALO + ohe && l < nsteps) {
-                    const size_t idx = ((size_t)plane * h + (oy0 + cl - HALO)) * w + ox;
-                    const float lv = ST(3, half, r)[col];
-                    o_lap[idx] = lv;
-                    stats(lv, rbin.get(cl & 15));
-                }
-            }
-        }
-        if (nb > 0 && writer) {
-            const int lp = l0 - BF_B;                                         // entering rows of the previous batch
-#pragma unroll
-            for (int r = 0; r < BF_B; ++r) {
-                const int l = lp + r;
-                if (SELF) {
-                    const int cm = l - R;                                     // mean / var row (k-window centred there)
-                    if (cm >= HALO && cm < HALO + ohe && l < nsteps) {
-                        const size_t idx = ((size_t)plane * h + (oy0 + cm - HALO)) * w + ox;
-                        const float m = ST(0, half, r)[col];
-                        o_mean[idx] = m;
-                        o_var[idx] = ST(1, half, r)[col];
-                        rbin.set(cm & 15, (int)__fmul_rn(fminf(fmaxf(m, 0.0f), 1.0f), 1000.0f));   // (mean.clip(0,1)*nbins).astype(int)
-                    }
-                } else {
-                    const int cm = l - R;
-                    if (cm >= HALO && cm < HALO + ohe && l < nsteps) {
-                        const size_t idx = ((size_t)plane * h + (oy0 + cm - HALO)) * w + ox;
-                        const float m = ST(0, half, r)[col], lv = ST(3, half, r)[col];
-                        o_mean[idx] = m;
-                        o_var[idx] = ST(1, half, r)[col];
-                        o_lap[idx] = lv;
-                        stats(lv, (int)__fmul_rn(fminf(fmaxf(m, 0.0f), 1.0f), 1000.0f));
-                    }
-                }
-            }
-        }
-        // (b) stage 2 (self): vertical sums of the b19 rows finished by the previous task phase
-        if (SELF && nb > 0 && nb <= nbatch) {
-            const int lp = l0 - BF_B;
-#pragma unroll
-            for (int r = 0; r < BF_B; ++r) {
-                const int l = lp + r;
-                const int j = l - R2;                                         // b19 row index (k2-window centred there)
-                if (l >= 2 * R2 && l < nsteps) {                              // first complete k2-window: rows 0 .. 2 R2
-                    const float bn = ST(2, half, r)[col];
-                    const float bo = ring.swap(j % 29, bn);                  // b19 row j - 29 (0 until the ring has filled)
-                    S[3] += (double)bn - (double)bo;
-                    S[4] += (double)__fmul_rn(bn, bn) - (double)__fmul_rn(bo, bo);
-                }
-                V(3, half, r)[col] = S[3];
-                V(4, half, r)[col] = S[4];
-            }
-        }
-        // (c) stage 1: vertical sums of the entering rows of this batch
+        // (c) stage 1: vertical sums of the entering rows of this batch (first: its loads are waited for before this
+        // iteration's stores are queued behind them)
         if (nb < nbatch) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -265,7 +255,103 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
                 if (writer && l >= HALO && l < HALO + ohe) fmax_ = fmaxf(fmax_, cur[0][0][r]);   // the frame's own pixels
             }
         }
+        BF_STAMP(0)
+        // (b) stage 2 (self): vertical sums of the b19 rows finished by the previous task phase
+        if (SELF && nb > 0 && nb <= nbatch) {
+            const int lp = l0 - BF_B;
+            const int j0 = lp - R2;                                           // b19 row of x row lp (k2-window centred there)
+            const bool bcol = col >= HALO - R && col < HALO + ow + R;
+            float bn[BF_B], bo[BF_B];
+            bool val[BF_B];
+#pragma unroll
+            for (int r = 0; r < BF_B; ++r) {
+                val[r] = lp + r >= 2 * R2 && lp + r < nsteps;                 // first complete k2-window: rows 0 .. 2 R2
+                bn[r] = ST(2, half, r)[bcol ? col - (HALO - R) : 0];
+                bo[r] = 0.0f;
+            }
+            // slot of b19 row j: j & 31; the row that leaves the 29-row window, j - 29, sits in slot (j + 3) & 31
+            uniform_switch32((j0 + 64) & 31, [&](auto bc) {
+                constexpr int B0 = decltype(bc)::value;
+#pragma unroll
+                for (int r = 0; r < BF_B; ++r) bo[r] = ring[(B0 + r + 3) & 31];
+#pragma unroll
+                for (int r = 0; r < BF_B; ++r) ring[(B0 + r) & 31] = val[r] ? bn[r] : ring[(B0 + r) & 31];
+            });
+#pragma unroll
+            for (int r = 0; r < BF_B; ++r) {
+                if (val[r]) {
+                    S[3] += (double)bn[r] - (double)bo[r];
+                    S[4] += (double)__fmul_rn(bn[r], bn[r]) - (double)__fmul_rn(bo[r], bo[r]);
+                }
+                V(3, half, r)[col] = S[3];
+                V(4, half, r)[col] = S[4];
+            }
+        }
+        BF_STAMP(1)
+        // (a) statistics of the finished lap rows (thread = column): self: rows of batch nb - 2, collab: batch nb - 1
+        {
+            const int lp = l0 - (SELF ? 2 : 1) * BF_B;
+            if (lp >= 0) {
+                const int cl0 = lp - R2 - R;                                  // lap row of x row lp (x row l -> b19 row l - R2 -> lap row - R)
+                int bins[BF_B] = {0, 0, 0, 0};
+                if (SELF) {
+                    uniform_switch16(cl0 & 15, [&](auto bc) {
+                        constexpr int B0 = decltype(bc)::value;
+#pragma unroll
+                        for (int r = 0; r < BF_B; ++r) bins[r] = rbin[(B0 + r) & 15];
+                    });
+                }
+                bool rowv[BF_B];
+                float lv[BF_B];
+#pragma unroll
+                for (int r = 0; r < BF_B; ++r) {
+                    const int cl = cl0 + r;
+                    rowv[r] = cl >= HALO && cl < HALO + ohe && lp + r < nsteps;          // uniform
+                    lv[r] = ST(3, half, r)[writer ? col - HALO : 0];
+                    if (!SELF) bins[r] = bin_of(ST(0, half, r)[writer ? col - HALO : 0]);
+                }
+                if (rowv[0] || rowv[1] || rowv[2] || rowv[3]) stats_rows(rowv, lv, bins);
+            }
+        }
+        // (a2) bins of the mean rows the previous task phase finished (self)
+        if (SELF && nb > 0) {
+            const int cm0 = l0 - BF_B - R;
+            int nbins[BF_B];
+            bool bval[BF_B];
+#pragma unroll
+            for (int r = 0; r < BF_B; ++r) {
+                const int cm = cm0 + r;
+                bval[r] = cm >= HALO && cm < HALO + ohe && l0 - BF_B + r < nsteps;
+                nbins[r] = bin_of(ST(0, half, r)[writer ? col - HALO : 0]);
+            }
+            uniform_switch16(cm0 & 15, [&](auto bc) {
+                constexpr int B0 = decltype(bc)::value;
+#pragma unroll
+                for (int r = 0; r < BF_B; ++r) rbin[(B0 + r) & 15] = bval[r] ? nbins[r] : rbin[(B0 + r) & 15];
+            });
+        }
+        BF_STAMP(2)
+        // (a3) stores of the finished rows, 16 bytes per lane (thread = (map, plane, row, 4 columns))
+        {
+            const int nmap = 3;
+            const int per_row = vec_ok ? n4 : ow;
+            const int total = nmap * 2 * BF_B * per_row;
+            for (int t = tid; t < total; t += 512) {
+                const int j = t % per_row, rr = (t / per_row) % BF_B, hf = (t / (per_row * BF_B)) & 1, m = t / (per_row * BF_B * 2);
+                const bool lapmap = m == 2;
+                const int lp = l0 - ((SELF && lapmap) ? 2 : 1) * BF_B;
+                const int l = lp + rr;
+                const int cr = l - R - ((SELF && lapmap) ? R2 : 0);           // finished row
+                if (lp < 0 || l >= nsteps || cr < HALO || cr >= HALO + ohe) continue;
+                float* op = (m == 0 ? o_mean : (m == 1 ? o_var : o_lap)) + ((size_t)(2 * dy + hf) * h + (oy0 + cr - HALO)) * w + ox0;
+                const float* sp = ST(lapmap ? 3 : m, hf, rr);
+                if (vec_ok) *(f32x4*)(op + 4 * j) = *(const f32x4*)(sp + 4 * j);
+                else op[j] = sp[j];
+            }
+        }
+        BF_STAMP(3)
         __syncthreads();
+        BF_STAMP(4)
         // ================= task phase =================
         if (tid < ntask_threads) {
             if (tid < tasksA && nb < nbatch) {
@@ -275,34 +361,28 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
                 const int l = l0 + rr;
                 const int cm = l - R;
                 if (cm >= HALO && cm < HALO + ohe && l < nsteps) {
-                    const int c0 = HALO + chunk * BF_LA, c1 = min(c0 + BF_LA, HALO + ow);
-                    const double* v0 = V(0, hf, rr);
-                    const double* v1 = V(1, hf, rr);
-                    const double* v2 = V(SELF ? 0 : 2, hf, rr);
-                    const double* v3 = V(SELF ? 1 : 3, hf, rr);
-                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                    for (int i = c0 - R; i <= c0 + R; ++i) {
-                        a0 += v0[i]; a1 += v1[i];
-                        if (!SELF) { a2 += v2[i]; a3 += v3[i]; }
-                    }
-                    for (int c = c0; c < c1; ++c) {
-                        if (c > c0) {
-                            a0 += v0[c + R] - v0[c - R - 1]; a1 += v1[c + R] - v1[c - R - 1];
-                            if (!SELF) { a2 += v2[c + R] - v2[c - R - 1]; a3 += v3[c + R] - v3[c - R - 1]; }
-                        }
-                        if (SELF) {
-                            const float m = bf_blur_round(a0, inv_k);
-                            const float sd = bf_std_from(m, bf_blur_round(a1, inv_k));
-                            ST(0, hf, rr)[c] = m;
-                            ST(1, hf, rr)[c] = __fmul_rn(sd, sd);                         // var = lr_rggb_k**2 (YOND_SIDD.py:72)
-                        } else {
-                            const float sl = bf_std_from(bf_blur_round(a0, inv_k), bf_blur_round(a1, inv_k));
-                            const float mh = bf_blur_round(a2, inv_k);
-                            const float sh = bf_std_from(mh, bf_blur_round(a3, inv_k));
-                            ST(0, hf, rr)[c] = mh;                                        // mean = blur(hr) (YOND_SIDD.py:97)
-                            ST(1, hf, rr)[c] = __fsub_rn(__fmul_rn(sl, sl), __fmul_rn(sh, sh));   // var = lr_k**2 - hr_k**2 (:96)
-                            ST(3, hf, rr)[c] = sh;                                        // img_lap = hr_k (:98)
-                        }
+                    const int c0 = HALO + chunk * BF_LA, c1 = HALO + ow;
+                    float* sm = ST(0, hf, rr) - HALO;
+                    float* sv = ST(1, hf, rr) - HALO;
+                    float* sl = ST(3, hf, rr) - HALO;
+                    if (SELF) {
+                        const BfPtrs<2> v = {{V(0, hf, rr), V(1, hf, rr)}};
+                        slide(IntC<2>{}, IntC<BF_LA>{}, IntC<K>{}, v, c0, c1, [&](int c, const double (&a)[2]) {
+                            const float m = bf_blur_round(a[0], inv_k);
+                            const float sd = bf_std_from(m, bf_blur_round(a[1], inv_k));
+                            sm[c] = m;
+                            sv[c] = __fmul_rn(sd, sd);                                    // var = lr_rggb_k**2 (YOND_SIDD.py:72)
+                        });
+                    } else {
+                        const BfPtrs<4> v = {{V(0, hf, rr), V(1, hf, rr), V(2, hf, rr), V(3, hf, rr)}};
+                        slide(IntC<4>{}, IntC<BF_LA>{}, IntC<K>{}, v, c0, c1, [&](int c, const double (&a)[4]) {
+                            const float s1 = bf_std_from(bf_blur_round(a[0], inv_k), bf_blur_round(a[1], inv_k));
+                            const float mh = bf_blur_round(a[2], inv_k);
+                            const float sh = bf_std_from(mh, bf_blur_round(a[3], inv_k));
+                            sm[c] = mh;                                                   // mean = blur(hr) (YOND_SIDD.py:97)
+                            sv[c] = __fsub_rn(__fmul_rn(s1, s1), __fmul_rn(sh, sh));      // var = lr_k**2 - hr_k**2 (:96)
+                            sl[c] = sh;                                                   // img_lap = hr_k (:98)
+                        });
                     }
                 }
             } else if (SELF && tid >= baseC && tid < baseC + tasksC && nb > 0 && nb <= nbatch) {
@@ -312,15 +392,12 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
                 const int l = l0 - BF_B + rr;
                 const int cl = l - R2 - R;
                 if (cl >= HALO && cl < HALO + ohe && l < nsteps) {
-                    const int c0 = HALO + chunk * BF_LA, c1 = min(c0 + BF_LA, HALO + ow);
-                    const double* v0 = V(3, hf, rr);
-                    const double* v1 = V(4, hf, rr);
-                    double a0 = 0.0, a1 = 0.0;
-                    for (int i = c0 - R; i <= c0 + R; ++i) { a0 += v0[i]; a1 += v1[i]; }
-                    for (int c = c0; c < c1; ++c) {
-                        if (c > c0) { a0 += v0[c + R] - v0[c - R - 1]; a1 += v1[c + R] - v1[c - R - 1]; }
-                        ST(3, hf, rr)[c] = bf_std_from(bf_blur_round(a0, inv_k), bf_blur_round(a1, inv_k));
-                    }
+                    const int c0 = HALO + chunk * BF_LA, c1 = HALO + ow;
+                    float* sl = ST(3, hf, rr) - HALO;
+                    const BfPtrs<2> v = {{V(3, hf, rr), V(4, hf, rr)}};
+                    slide(IntC<2>{}, IntC<BF_LA>{}, IntC<K>{}, v, c0, c1, [&](int c, const double (&a)[2]) {
+                        sl[c] = bf_std_from(bf_blur_round(a[0], inv_k), bf_blur_round(a[1], inv_k));
+                    });
                 }
             } else if (SELF && tid >= baseB && nb < nbatch) {
                 // group B: 19-window sums -> b19 rows (columns HALO - R .. HALO + ow + R)
@@ -328,28 +405,32 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
                 const int chunk = t % nBc, rr = (t / nBc) % BF_B, hf = t / (nBc * BF_B);
                 const int l = l0 + rr;
                 if (l >= 2 * R2 && l < nsteps) {
-                    const int c0 = HALO - R + chunk * BF_LB, c1 = min(c0 + BF_LB, HALO + ow + R);
-                    const double* v0 = V(2, hf, rr);
-                    double a0 = 0.0;
-                    for (int i = c0 - R2; i <= c0 + R2; ++i) a0 += v0[i];
-                    for (int c = c0; c < c1; ++c) {
-                        if (c > c0) a0 += v0[c + R2] - v0[c - R2 - 1];
-                        ST(2, hf, rr)[c] = bf_blur_round(a0, inv_k2);
-                    }
+                    const int c0 = HALO - R + chunk * BF_LB, c1 = HALO + ow + R;
+                    float* sb = ST(2, hf, rr) - (HALO - R);
+                    const BfPtrs<1> v = {{V(2, hf, rr)}};
+                    slide(IntC<1>{}, IntC<BF_LB>{}, IntC<SELF ? K2 : 1>{}, v, c0, c1, [&](int c, const double (&a)[1]) {
+                        sb[c] = bf_blur_round(a[0], inv_k2);
+                    });
                 }
             }
         }
+        BF_STAMP(5)
         __syncthreads();
+        BF_STAMP(6)
     }
-    hist_flush();
+#ifdef BF_STAMPS
+    if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && (tid & 63) == 0) {
+        for (int i = 0; i < 7; ++i) st->dbg[(tid >> 6) * 8 + i] = tacc[i];
+    }
+#endif
     // frame maximum (the estimator's caller needs lr.max() for the bias LUT grid, YOND_SIDD.py:256/393)
     fmax_ = wave_max(fmax_);
     if ((tid & 63) == 0 && fmax_ > -INFINITY) atomicMax(&st->frame_max_key, f2key(fmax_));
     __syncthreads();
     for (int i = tid; i < NF_WIN_N / 2; i += 512) {
         const unsigned int c = s_h[i];
-        if (c & 0xFFFFu) atomicAdd(&st->hist1[NF_WIN_LO + 2 * i], c & 0xFFFFu);
-        if (c >> 16) atomicAdd(&st->hist1[NF_WIN_LO + 2 * i + 1], c >> 16);
+        if (c & 0xFFFFu) atomicAdd(&st->hist1[NF_WIN_LO + i], c & 0xFFFFu);
+        if (c >> 16) atomicAdd(&st->hist1[NF_WIN_LO + NF_WIN_N / 2 + i], c >> 16);
     }
     for (int i = tid; i < NF_BINS; i += 512) {
         const unsigned int v = s_mi[i];
@@ -359,12 +440,12 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     if (nf_arrive_last(&st->ticket[0], nblocks)) nf_resolve1(st, args, (unsigned int*)s_raw);
 }
 
-template <int MODE>
+template <int MODE, int K, int K2>
 static int launch_fused(const float* fa, const float* fb, int H, int W, int k, int k2, int tile_w, float* mean, float* var,
                         float* lap, const double* q_host, int nq, void* ws, hipStream_t st) {
     const int h = H / 2, w = W / 2;
     if (h < 1 || w < 1 || k < 1 || !(k & 1) || k2 < 1 || !(k2 & 1) || tile_w < 0) return YOND_EINVAL;
-    if (k > 2 * BF_MAXR + 1 || k2 > k) return YOND_EUNSUPPORTED;
+    if (k != K || k2 != K2) return YOND_EUNSUPPORTED;                    // the kernel is built for the estimator's windows (29, 19)
     if (tile_w > 0 && w % tile_w != 0) return YOND_EUNSUPPORTED;
     if (!ws || ((uintptr_t)ws & 15)) return YOND_EINVAL;
     const size_t n = (size_t)4 * h * w;
@@ -380,6 +461,7 @@ static int launch_fused(const float* fa, const float* fb, int H, int W, int k, i
     const int maxow = BF_T - 2 * halo;
     g.nstrip = (bw + maxow - 1) / maxow;
     g.ow_nom = (bw + g.nstrip - 1) / g.nstrip;
+    if (!(bw & 3) && ((g.ow_nom + 3) & ~3) <= maxow) g.ow_nom = (g.ow_nom + 3) & ~3;     // 16-byte store rows
     // row segments: one workgroup per CU in one round (the kernel needs most of the LDS); longer segments re-read
     // fewer halo rows
     long target = 240;
@@ -394,18 +476,17 @@ static int launch_fused(const float* fa, const float* fb, int H, int W, int k, i
     if (g.oh > h) g.oh = h;
     const int nsy = (h + g.oh - 1) / g.oh;
     constexpr int NQ = MODE == 0 ? 5 : 4;
-    const size_t lds = (size_t)NQ * 2 * BF_B * BF_RS * 8 + (size_t)4 * 2 * BF_B * BF_T * 4 + (NF_WIN_N / 2 + NF_BINS) * 4 +
-                       (BF_MAXOH + 4 * BF_MAXR + 8) * 4;
-    static bool attr[3] = {false, false, false};
-    if (!attr[MODE]) {
-        hipError_t e = hipFuncSetAttribute((const void*)box_fused_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)NQ * 2 * BF_B * BF_RS * 8 + (size_t)4 * 2 * BF_B * BF_T * 4 + (NF_WIN_N / 2 + NF_BINS) * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)box_fused_kernel<MODE, K, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr[MODE] = true;
+        attr = true;
     }
     hipError_t e = hipMemsetAsync(ws, 0, nf_state_bytes(), st);
     if (e != hipSuccess) return (int)e;
     dim3 grid((unsigned)(nblk * g.nstrip), (unsigned)nsy, 2);
-    hipLaunchKernelGGL(box_fused_kernel<MODE>, grid, dim3(512), lds, st, fa, fb, g, mean, var, lap, (NleState*)ws, a);
+    hipLaunchKernelGGL((box_fused_kernel<MODE, K, K2>), grid, dim3(512), lds, st, fa, fb, g, mean, var, lap, (NleState*)ws, a);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -413,12 +494,12 @@ static int launch_fused(const float* fa, const float* fb, int H, int W, int k, i
 extern "C" int yond_box_stats_self_fused_f32(const float* bayer, int H, int W, int k, int k2, int tile_w, float* mean,
                                              float* var, float* lap, const double* q_host, int nq, void* ws, void* stream) {
     if (!bayer || !mean || !var || !lap || (H & 1) || (W & 1)) return YOND_EINVAL;
-    return launch_fused<0>(bayer, nullptr, H, W, k, k2, tile_w, mean, var, lap, q_host, nq, ws, (hipStream_t)stream);
+    return launch_fused<0, 29, 19>(bayer, nullptr, H, W, k, k2, tile_w, mean, var, lap, q_host, nq, ws, (hipStream_t)stream);
 }
 
 extern "C" int yond_box_stats_collab_fused_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,
                                                float* mean, float* var, float* lap, const double* q_host, int nq, void* ws,
                                                void* stream) {
     if (!bayer_lr || !bayer_hr || !mean || !var || !lap || (H & 1) || (W & 1)) return YOND_EINVAL;
-    return launch_fused<2>(bayer_lr, bayer_hr, H, W, k, k, tile_w, mean, var, lap, q_host, nq, ws, (hipStream_t)stream);
+    return launch_fused<2, 29, 29>(bayer_lr, bayer_hr, H, W, k, k, tile_w, mean, var, lap, q_host, nq, ws, (hipStream_t)stream);
 }

@@ -369,7 +369,7 @@ def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, 
     mean, var, lap = new(), new(), new()
     st = L.stream()
     k2 = k // 3 * 2 + 1
-    fused = fused and k <= 29
+    fused = fused and k == 29                 # the fused kernel is built for the estimator's windows (29, 19)
     ws = None
     q = np.ascontiguousarray(QUANTS, dtype=np.float64)
     qp = C.c_void_p(q.ctypes.data)
@@ -554,7 +554,7 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     raw4est = lr_cat if lr_full is None else _dev(lr_full, lr.device)                  # :340
     # lr.max() for the bias LUT grid: the fused estimator kernel collects it when it reads the same frame; else a
     # reduction queued ahead of the NLE and read after the NLE's own host sync
-    lr_max_dev = _frame_max(lr_cat) if (lr_full is not None or k > 29) else None
+    lr_max_dev = _frame_max(lr_cat) if (lr_full is not None or k != 29) else None
     reg, nle_info = SimpleNLF(raw4est, k=k, setting={'mode': 'self'}, full=True)       # :341
     p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale            # :356
     if log:
@@ -679,7 +679,7 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     def estimate(lr, ready):               # phase 1 on the side stream; returns host scalars only
         side.wait_event(ready)             # the frame as it stood when it was handed in -- NOT the work queued since
         with torch.cuda.stream(side):
-            lr_max_dev = _frame_max(lr) if k > 29 else None
+            lr_max_dev = _frame_max(lr) if k != 29 else None
             reg, info = SimpleNLF(lr, k=k, setting={'mode': 'self'}, full=True)
             lr_max = np.float32(lr_max_dev.item()) if lr_max_dev is not None else np.float32(info['frame_max'])
         return lr, reg, lr_max

@@ -42,7 +42,10 @@ int yond_abi_version(void);
  *              disables the bias correction (bias_corr=None).
  *   img_max    optional device float[1]: max over the clamped output (must be zeroed by the caller
  *              -- the function issues the memset itself on `stream`).
- * Arithmetic: float32 x*scale, then float64 exactly as NumPy stages it, rounded once to float32. */
+ * Arithmetic: float32 x*scale, then float64 in NumPy's staging with three shortcuts that stay below 1e-12 relative --
+ * sqrt as a float32 estimate + one float64 Newton step, the LUT as per-interval coefficients a + b x, (v - lo) times the
+ * reciprocal span -- and ONE rounding to float32: the result differs from the staged float64 evaluation by at most one
+ * float32 ulp, and only where that evaluation lies within 1e-12 of a rounding boundary. */
 int yond_pack_vst_norm_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t,
                            int pad_b, int mode, double scale, double gain, double sigma, double lo,
                            double hi, const double* lut_x, const float* lut_y, int lut_n, float* img_max,

@@ -50,3 +50,15 @@ print("moments: %.1f us" % t(lambda: lib.yond_nlf_moments_f32(L.ptr(o[2]), L.ptr
 print("old self1+self2: %.1f us" % t(lambda: (lib.yond_box_stats_self1_f32(L.ptr(x), H, W, 29, 19, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[3]), st),
                                               lib.yond_box_stats_self2_f32(L.ptr(o[3]), h, w, 29, 0, L.ptr(o[2]), st))))
 print("SimpleNLF end to end (incl. host sync): %.1f us" % t(lambda: P.SimpleNLF(x, k=29, setting={'mode': 'self'})))
+
+# K1 / K4
+from yond_public_amd import pipeline as PP
+lut = PP.get_bias(np.float32(noisy.max()) * np.float32(959.0), np.float64(6.0), np.float64(4.0), device=x.device)
+lo, hi = PP.vst_scalar(0, np.float64(6.0), np.float64(4.0)), PP.vst_scalar(959.0, np.float64(6.0), np.float64(4.0))
+p2d = PP.get_p2d((1, 4, h, w), 32)
+Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
+x4 = torch.empty(Hp, Wp, 4, device='cuda')
+mx = torch.empty(1, device='cuda')
+out = torch.empty(H, W, device='cuda')
+print("K1: %.1f us" % t(lambda: lib.yond_pack_vst_norm_f32(L.ptr(x), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], 1, 959.0, 4.0, 6.0, float(lo), float(hi), L.ptr(lut.x), L.ptr(lut.y), len(lut), L.ptr(mx), st)))
+print("K4: %.1f us" % t(lambda: lib.yond_denorm_ivst_unpack_f32(L.ptr(x4), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 1, 959.0, 4.0, 6.0, float(lo), float(hi), 1, st)))

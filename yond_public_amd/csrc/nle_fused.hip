@@ -23,7 +23,9 @@
 #include "nle_common.h"
 
 #define BF_T 256             // virtual columns per plane and workgroup
-#define BF_B 4               // rows per batch
+#define BF_B 4               // rows per batch (2, with two workgroups per CU, measured slower: 364 vs 297 us -- more barriers, spills)
+#define BFW_LO 0xB080u       // LDS histogram window of this kernel: level-1 bins of 2^-30 <= lap < 4 (32 octaves x 128)
+#define BFW_N 4096           //   exact zeros (flat clipped regions) count in a word of their own, anything else goes to global memory
 #define BF_MAXR 14
 #define BF_RS 271            // LDS row stride of the vertical sums, in doubles (== 23 * 9 mod 32: chunks of 9 columns of
                              // consecutive rows continue one bank progression)
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];    // (unaligned, its float64 accesses crawl)
     double* s_v = (double*)s_raw;                                             // [NQ][2][BF_B][BF_RS]
     float* s_st = (float*)(s_raw + (size_t)NQ * 2 * BF_B * BF_RS * 8);        // staging [4][2][BF_B][BF_T]: mean, var, b19, lap
-    unsigned int* s_h = (unsigned int*)(s_st + 4 * 2 * BF_B * BF_T);          // [NF_WIN_N / 2] two 16-bit counters per word
-    unsigned int* s_mi = s_h + NF_WIN_N / 2;                                  // [NF_BINS]
+    unsigned int* s_h = (unsigned int*)(s_st + 4 * 2 * BF_B * BF_T);          // [BFW_N / 2] two 16-bit counters per word, [1] zeros
+    unsigned int* s_mi = s_h + BFW_N / 2 + 4;                                 // [NF_BINS]
     auto V = [&](int q, int half, int r) -> double* { return s_v + ((size_t)(q * 2 + half) * BF_B + r) * BF_RS; };
     // staging rows are indexed from the first column that is written: outputs start at HALO (b19 rows: at HALO - R), so
     // that the 16-byte rows of the store phase are aligned
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     const int oy0 = blockIdx.y * g.oh;
     const int ohe = min(g.oh, h - oy0);
     const int nsteps = ohe + 2 * HALO;
-    for (int i = tid; i < NF_WIN_N / 2 + NF_BINS; i += 512) s_h[i] = 0;
+    for (int i = tid; i < BFW_N / 2 + 4 + NF_BINS; i += 512) s_h[i] = 0;
     const float* base[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) base[i] = (i == 0 ? fa : fb) + (size_t)dy * g.W2 + 2 * rc + half;
@@ -167,10 +169,11 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
             if (head && valid[r]) {
                 const unsigned long long rest = (m >> lane) >> 1;
                 const unsigned int len = rest ? (unsigned int)__ffsll((long long)rest) : (unsigned int)(64 - lane);
-                const unsigned int wdw = id[r] - NF_WIN_LO;
-                // two 16-bit counters per word: bins w and w + 8192, so that neighbouring bins (what neighbouring pixels
+                const unsigned int wdw = id[r] - BFW_LO;
+                // two 16-bit counters per word: bins w and w + 2048, so that neighbouring bins (what neighbouring pixels
                 // hit) sit in neighbouring words / banks
-                if (wdw < NF_WIN_N) atomicAdd(&s_h[wdw & (NF_WIN_N / 2 - 1)], len << ((wdw >> 13) * 16));
+                if (wdw < BFW_N) atomicAdd(&s_h[wdw & (BFW_N / 2 - 1)], len << ((wdw >> 11) * 16));
+                else if (id[r] == NF_WIN_LO) atomicAdd(&s_h[BFW_N / 2], len);            // lap == +0.0
                 else atomicAdd(&st->hist1[id[r]], len);
             }
             const unsigned int inv = ~key[r];
@@ -293,7 +296,9 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
             const int lp = l0 - (SELF ? 2 : 1) * BF_B;
             if (lp >= 0) {
                 const int cl0 = lp - R2 - R;                                  // lap row of x row lp (x row l -> b19 row l - R2 -> lap row - R)
-                int bins[BF_B] = {0, 0, 0, 0};
+                int bins[BF_B];
+#pragma unroll
+                for (int r = 0; r < BF_B; ++r) bins[r] = 0;
                 if (SELF) {
                     uniform_switch16(cl0 & 15, [&](auto bc) {
                         constexpr int B0 = decltype(bc)::value;
@@ -310,7 +315,10 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
                     lv[r] = ST(3, half, r)[writer ? col - HALO : 0];
                     if (!SELF) bins[r] = bin_of(ST(0, half, r)[writer ? col - HALO : 0]);
                 }
-                if (rowv[0] || rowv[1] || rowv[2] || rowv[3]) stats_rows(rowv, lv, bins);
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < BF_B; ++r) any = any || rowv[r];
+                if (any) stats_rows(rowv, lv, bins);
             }
         }
         // (a2) bins of the mean rows the previous task phase finished (self)
@@ -427,11 +435,12 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     fmax_ = wave_max(fmax_);
     if ((tid & 63) == 0 && fmax_ > -INFINITY) atomicMax(&st->frame_max_key, f2key(fmax_));
     __syncthreads();
-    for (int i = tid; i < NF_WIN_N / 2; i += 512) {
+    for (int i = tid; i < BFW_N / 2; i += 512) {
         const unsigned int c = s_h[i];
-        if (c & 0xFFFFu) atomicAdd(&st->hist1[NF_WIN_LO + i], c & 0xFFFFu);
-        if (c >> 16) atomicAdd(&st->hist1[NF_WIN_LO + NF_WIN_N / 2 + i], c >> 16);
+        if (c & 0xFFFFu) atomicAdd(&st->hist1[BFW_LO + i], c & 0xFFFFu);
+        if (c >> 16) atomicAdd(&st->hist1[BFW_LO + BFW_N / 2 + i], c >> 16);
     }
+    if (tid == 0 && s_h[BFW_N / 2]) atomicAdd(&st->hist1[NF_WIN_LO], s_h[BFW_N / 2]);
     for (int i = tid; i < NF_BINS; i += 512) {
         const unsigned int v = s_mi[i];
         if (v) atomicMax(&st->maxinv[i], v);
@@ -462,8 +471,7 @@ static int launch_fused(const float* fa, const float* fb, int H, int W, int k, i
     g.nstrip = (bw + maxow - 1) / maxow;
     g.ow_nom = (bw + g.nstrip - 1) / g.nstrip;
     if (!(bw & 3) && ((g.ow_nom + 3) & ~3) <= maxow) g.ow_nom = (g.ow_nom + 3) & ~3;     // 16-byte store rows
-    // row segments: one workgroup per CU in one round (the kernel needs most of the LDS); longer segments re-read
-    // fewer halo rows
+    // row segments: one workgroup per CU (132 KB of LDS) in one round; longer segments re-read fewer halo rows
     long target = 240;
     if (const char* e = getenv("YOND_BOX_WGS")) target = atol(e);        // experiments only
     const long cols = 2L * nblk * g.nstrip;
@@ -476,7 +484,7 @@ static int launch_fused(const float* fa, const float* fb, int H, int W, int k, i
     if (g.oh > h) g.oh = h;
     const int nsy = (h + g.oh - 1) / g.oh;
     constexpr int NQ = MODE == 0 ? 5 : 4;
-    const size_t lds = (size_t)NQ * 2 * BF_B * BF_RS * 8 + (size_t)4 * 2 * BF_B * BF_T * 4 + (NF_WIN_N / 2 + NF_BINS) * 4;
+    const size_t lds = (size_t)NQ * 2 * BF_B * BF_RS * 8 + (size_t)4 * 2 * BF_B * BF_T * 4 + (BFW_N / 2 + 4 + NF_BINS) * 4;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)box_fused_kernel<MODE, K, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

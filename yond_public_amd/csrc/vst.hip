@@ -8,18 +8,22 @@
 #include "common.h"
 
 #define LUT_MAX 4096
-
 #define LUT_MAXSEG 8
+#define LUT_BYTES_PER_KNOT 24
 
-// The bias LUT's knots (utils/isp_algos.py:103-108) are runs of evenly spaced values (step 0.1, 1, 10): the
-// kernel finds the runs once per workgroup, guesses the knot index of a query with one multiply and repairs the
-// guess against the knots themselves, so the result is exactly searchsorted's whatever the spacing is
-// (irregular knots only cost more repair steps; more than LUT_MAXSEG runs fall back to bisection).
+// The bias LUT (utils/isp_algos.py:103-108, 128: interp1d over knots that are runs of evenly spaced values, step 0.1 /
+// 1 / 10) is a continuous piecewise-linear function, evaluated per pixel as a + b * x with the interval's coefficients
+//   b_i = (y_i - y_{i-1}) / (x_i - x_{i-1})   (the float32 difference of the float32 ordinates, as interp1d forms it),
+//   a_i = y_{i-1} - b_i x_{i-1}                (float64)
+// from a 16-byte LDS entry.  The interval index comes from the run's spacing with one multiply; because the function is
+// continuous, landing in the neighbouring interval when x sits within rounding distance of a knot changes the value by
+// < 1e-12, far below the float32 rounding of K1's output -- so no search / repair against the knots is needed (the first
+// version spent most of K1's time there, in float64 sqrt and in the float64 divide).  Knots that are not <= 8 evenly
+// spaced runs fall back to bisection.
 struct LutLds {
-    double* x;                   // [n]  knots          (dynamic LDS: 20 bytes per knot)
-    double* slope;               // [n]  slope of the interval that ends at knot i (i >= 1)
-    float* y;                    // [n]
-    double seg_x[LUT_MAXSEG], seg_inv[LUT_MAXSEG];
+    double* x;                   // [n]  knots (bisection fallback)
+    double2* ab;                 // [n]  coefficients of the interval that ENDS at knot i (i >= 1)
+    float seg_x[LUT_MAXSEG], seg_inv[LUT_MAXSEG];
     int seg_i[LUT_MAXSEG + 1];
     int nseg;                    // 0: bisection
     int nbreak;
@@ -27,13 +31,14 @@ struct LutLds {
 
 __device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict__ lut_x, const float* __restrict__ lut_y, int n) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += 256) { L.x[i] = lut_x[i]; L.y[i] = lut_y[i]; }
+    for (int i = tid; i < n; i += 256) L.x[i] = lut_x[i];
     if (tid == 0) { L.nbreak = 0; L.nseg = 0; }
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
         if (i >= 1) {
-            const float dy = L.y[i] - L.y[i - 1];                 // float32 difference, as interp1d does with float32 knots
-            L.slope[i] = (double)dy / (L.x[i] - L.x[i - 1]);
+            const float dy = lut_y[i] - lut_y[i - 1];             // float32 difference, as interp1d does with float32 knots
+            const double b = (double)dy / (L.x[i] - L.x[i - 1]);
+            L.ab[i] = make_double2((double)lut_y[i - 1] - b * L.x[i - 1], b);
         }
         if (i >= 1 && i + 1 < n) {
             const double d0 = L.x[i] - L.x[i - 1], d1 = L.x[i + 1] - L.x[i];
@@ -55,12 +60,14 @@ __device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict_
                 L.seg_i[j + 1] = v;
             }
             L.seg_i[nb + 1] = n - 1;
+            bool ok = true;
             for (int sgm = 0; sgm <= nb; ++sgm) {
                 const int i0 = L.seg_i[sgm];
-                L.seg_x[sgm] = L.x[i0];
-                L.seg_inv[sgm] = 1.0 / (L.x[i0 + 1] - L.x[i0]);
+                L.seg_x[sgm] = (float)L.x[i0];
+                L.seg_inv[sgm] = (float)(1.0 / (L.x[i0 + 1] - L.x[i0]));
+                ok = ok && ((double)L.seg_x[sgm] == L.x[i0]);      // run starts must be float32 values (0, 50, 500 are)
             }
-            L.nseg = nb + 1;
+            L.nseg = ok ? nb + 1 : 0;
         }
     }
     __syncthreads();
@@ -68,27 +75,37 @@ __device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict_
 
 __device__ __forceinline__ double lut_eval(const LutLds& L, int n, float xq) {
     // scipy interp1d(kind='linear')._call_linear: hi = clip(searchsorted(x, xq, 'left'), 1, n-1)
-    const double x = (double)xq;
     int g;
     const int nseg = L.nseg;
     if (nseg > 0) {
         int sgm = 0;
-        for (int i = 1; i < nseg; ++i) sgm += (x >= L.seg_x[i]) ? 1 : 0;
-        const double t = (x - L.seg_x[sgm]) * L.seg_inv[sgm];
+        for (int i = 1; i < nseg; ++i) sgm += (xq >= L.seg_x[i]) ? 1 : 0;
+        const float t = (xq - L.seg_x[sgm]) * L.seg_inv[sgm];
         const int i0 = L.seg_i[sgm], i1 = L.seg_i[sgm + 1];
-        int off = t > 0.0 ? (t < 1e9 ? (int)ceil(t) : 1000000000) : 0;
-        g = i0 + off;
-        g = g > i1 ? i1 : g;
-        while (g > 0 && L.x[g - 1] >= x) --g;                      // repair: first index with x[idx] >= xq
-        while (g < n && L.x[g] < x) ++g;
+        const int off = t > 0.0f ? (t < 1e9f ? (int)ceilf(t) : 1000000000) : 0;
+        g = min(i0 + off, i1);
     } else {
+        const double x = (double)xq;
         int lo = 0, hi = n;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.x[mid] < x) lo = mid + 1; else hi = mid; }
         g = lo;
     }
     const int ih = g < 1 ? 1 : (g > n - 1 ? n - 1 : g);
-    const int il = ih - 1;
-    return L.slope[ih] * (x - L.x[il]) + (double)L.y[il];
+    const double2 c = L.ab[ih];
+    return c.x + c.y * (double)xq;
+}
+
+// sqrt of a non-negative float64 to ~1e-15 relative: the float32 hardware estimate (1 ulp of float32) and one Newton step
+// in float64; the full-precision float64 sqrt sequence costs four times as much and K1 rounds its result to float32 anyway
+__device__ __forceinline__ double sqrt_newton(double a) {
+    const float af = (float)a;
+    if (!(af > 1e-30f)) return sqrt(a);                            // tiny / zero / huge arguments: the plain routine
+    if (af > 1e30f) return sqrt(a);
+    const float s0f = __builtin_amdgcn_sqrtf(af);
+    const double s0 = (double)s0f;
+    const double r = (double)(0.5f * __builtin_amdgcn_rcpf(s0f));  // 1 / (2 s0) to float32 accuracy
+    const double e = fma(-s0, s0, a);                              // a - s0^2, exact to float64
+    return fma(e, r, s0);
 }
 
 __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restrict__ bayer, int H, int W,
@@ -101,22 +118,24 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
     __shared__ LutLds L;
     __shared__ float s_red[4];
     if (threadIdx.x == 0) {
-        L.x = (double*)lut_raw;
-        L.slope = L.x + lut_n;
-        L.y = (float*)(L.slope + lut_n);
+        L.ab = (double2*)lut_raw;
+        L.x = (double*)(L.ab + lut_n);
     }
     __syncthreads();
     if (lut_n > 0) lut_prepare(L, lut_x, lut_y, lut_n);
     const int h = H / 2, w = W / 2;
-    const size_t total = (size_t)Hp * Wp;
     const double c0 = 0.375 * gain * gain;       // (3/8)*gain**2
     const double s2 = sigma * sigma;
     const double two_over_gain = 2.0 / gain;
-    const double span = hi - lo;
+    const double inv_span = 1.0 / (hi - lo);
     float vmax = 0.0f;
-    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
-        const int yp = (int)(p / Wp), xp = (int)(p % Wp);
-        const int sy = reflect101(yp - pad_t, h), sx = reflect101(xp - pad_l, w);
+    // rows over the workgroups, columns over the threads: no 64-bit divisions per pixel
+    for (int yp = blockIdx.x; yp < Hp; yp += gridDim.x)
+    for (int xp = threadIdx.x; xp < Wp; xp += 256) {
+        const size_t p = (size_t)yp * Wp + xp;
+        int sy = yp - pad_t, sx = xp - pad_l;
+        if ((unsigned)sy >= (unsigned)h) sy = reflect101(sy, h);            // (uniform)
+        if ((unsigned)sx >= (unsigned)w) sx = reflect101(sx, w);
         const f32x2 r0 = *(const f32x2*)(bayer + (size_t)(2 * sy) * W + 2 * sx);
         const f32x2 r1 = *(const f32x2*)(bayer + (size_t)(2 * sy + 1) * W + 2 * sx);
         float q[4] = {r0[0], r0[1], r1[0], r1[1]};
@@ -130,9 +149,9 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
                 const float x32 = q[c] * scale_f;                       // float32 * python float -> float32
                 double fz = gain * (double)x32 + c0 + s2;               // gain*x + (3/8)gain^2 + sigma^2 (- gain*0)
                 fz = fz > 0.0 ? fz : 0.0;
-                double v = two_over_gain * sqrt(fz);
+                double v = two_over_gain * sqrt_newton(fz);
                 if (lut_n > 0) v -= lut_eval(L, lut_n, fmaxf(x32, 0.0f));
-                u = (float)((v - lo) / span);
+                u = (float)((v - lo) * inv_span);                       // (v - lo) / (hi - lo) to one float64 ulp, then ONE rounding
             }
             u = fminf(fmaxf(u, 0.0f), 1.0f);
             o[c] = u;
@@ -167,17 +186,16 @@ extern "C" int yond_pack_vst_norm_f32(const float* bayer, int H, int W, float* o
         hipError_t e = hipMemsetAsync(img_max, 0, sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    const size_t total = (size_t)Hp * Wp;
-    size_t nb = (total + 255) / 256;
+    size_t nb = (size_t)Hp;
     if (nb > 256 * 4) nb = 256 * 4;          // every workgroup prepares the LUT once: keep them few and long-lived
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)pack_vst_norm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_MAX * 20);
+        hipError_t e = hipFuncSetAttribute((const void*)pack_vst_norm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_MAX * LUT_BYTES_PER_KNOT);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     const int use_lut = mode == 1 ? lut_n : 0;
-    hipLaunchKernelGGL(pack_vst_norm_kernel, dim3((unsigned)nb), dim3(256), (size_t)use_lut * 20, st, bayer, H, W, out,
+    hipLaunchKernelGGL(pack_vst_norm_kernel, dim3((unsigned)nb), dim3(256), (size_t)use_lut * LUT_BYTES_PER_KNOT, st, bayer, H, W, out,
                        pad_l, pad_t, Hp, Wp, mode, (float)scale, gain, sigma, lo, hi, lut_x, lut_y, use_lut, (unsigned int*)img_max);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
@@ -187,13 +205,12 @@ __global__ __launch_bounds__(256) void denorm_ivst_unpack_kernel(const float* __
                                                                  int pad_l, int h, int w, float* __restrict__ bayer,
                                                                  int mode, double scale, double gain, double sigma,
                                                                  double lo, double hi, int clip01) {
-    const size_t total = (size_t)h * w;
     const double span = hi - lo;
     const double sg = sigma / gain;                 // inverse_VST: sigma = sigma / gain
     const double sg2 = sg * sg;
     const double r32 = sqrt(1.5);                   // (3/2)**0.5
-    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
-        const int y = (int)(p / w), x = (int)(p % w);
+    for (int y = blockIdx.x; y < h; y += gridDim.x)
+    for (int x = threadIdx.x; x < w; x += 256) {
         const f32x4 v = *(const f32x4*)(net_out + ((size_t)(y + pad_t) * Wp + x + pad_l) * 4);
         float o[4];
 #pragma unroll
@@ -228,8 +245,7 @@ extern "C" int yond_denorm_ivst_unpack_f32(const float* net_out, int Hp, int Wp,
     if (pad_t + h > Hp || pad_l + w > Wp) return YOND_EINVAL;
     if (mode < 0 || mode > 2) return YOND_EINVAL;
     if (mode != 0 && (!(gain > 0.0) || !(scale > 0.0))) return YOND_EINVAL;
-    const size_t total = (size_t)h * w;
-    size_t nb = (total + 255) / 256;
+    size_t nb = (size_t)h;
     if (nb > 256 * 16) nb = 256 * 16;
     hipLaunchKernelGGL(denorm_ivst_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, net_out, Wp, pad_t,
                        pad_l, h, w, bayer_out, mode, scale, gain, sigma, lo, hi, clip01);

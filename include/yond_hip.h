@@ -129,7 +129,13 @@ typedef struct YondConvDesc {
     const float* out4_x;  /* NHWC4 network input [N][Ho][Wo][4] (global residual) or NULL */
     const float* out4_ub; /* [N] per-image maximum (data_normalize) or NULL */
     float* out4_dst;      /* [N][Ho][Wo][4] or NULL (no fused projection) */
+    /* Range guard of the half-precision operand paths (algo 2..5): a device word (or NULL) into which a kernel ORs
+       YOND_STATUS_HALF_OVERFLOW when a staged activation does not fit fp16 (|a| > 65504: its h half would be +-inf and the
+       result silently wrong).  The caller zeroes it, reads it after the forward and falls back to the fp32-input MFMA
+       kernels (algo 0 / 1).  Weights are checked by the packing functions (YOND_EUNSUPPORTED). */
+    unsigned int* status;
 } YondConvDesc;
+#define YOND_STATUS_HALF_OVERFLOW 1u
 
 /* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.
  * N, Ho, Wo (GEMM-M extent; 0 = unknown) let the library pick the tn that fills its persistent grid best. */
@@ -153,7 +159,8 @@ int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, fl
  * 163-233 are the layers it serves).  Each fp32 operand is split when it is staged into LDS: h = fp16(a),
  * l = fp16((a - h) * 2^11); a*w = h_a h_w + 2^-11 (h_a l_w + l_a h_w) on v_mfma_f32_32x32x16_f16 with fp32
  * accumulation -- 22-23 significant bits per operand, error vs a float64 convolution no larger than the fp32 kernels'.
- * Precondition: |activations|, |weights| < 65504.  yond_conv_split_supported: channel-tile width (64, 32) or 0.
+ * Precondition: |activations|, |weights| <= 65504 -- enforced: the packing functions return YOND_EUNSUPPORTED for a weight
+ * outside that range and the kernels report an activation outside it through YondConvDesc.status.  yond_conv_split_supported: channel-tile width (64, 32) or 0.
  * Weights: w OIHW [cout][cin][3][3] -> dst, cout*cin*9*parts/2 floats (packed halves).
  * ksize 1 (descriptor: ksize 1, shuffle 1, algo 3): the decoder's pixel-shuffle GEMM -- ConvTranspose2d 2x2 (src0, C0, low
  * resolution) + the skip tensor (src1, C1, at the OUTPUT resolution) + 1x1 shortcut folded into one weight matrix

@@ -7,6 +7,8 @@ import torch
 
 from hip_common import ARCHS, make_net, report
 
+DEV = "cuda:0"
+
 pytestmark = pytest.mark.gpu
 
 
@@ -75,3 +77,52 @@ def test_net_fp16_mfma_path_vs_fp32(aname):
     with torch.no_grad():
         y32 = (net(x.to('cuda:0'), t.to('cuda:0')) if guided else net(x.to('cuda:0'))).cpu().numpy()
     assert report(f"net {aname} back on fp32", y32, ref) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_split_path_range_guard():
+    """The split-operand / fp16 paths stage activations as fp16: |a| > 65504 would become inf silently.  A layer whose
+    output is ~1e6 (and whose consumer scales it back) must give the strict fp32 result, with a warning -- and weights
+    outside fp16's range must keep their layer off the half-precision kernels."""
+    import warnings
+    import yond_oracle as O
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    arch = ARCHS["gru8"]
+    sd = O.procedural_state_dict(arch, 9)
+    sd['conv1.conv1.weight'] = sd['conv1.conv1.weight'] * 1e6          # conv1's output ~ 1e6 ...
+    sd['conv1.conv1.bias'] = sd['conv1.conv1.bias'] * 1e6
+    sd['conv1.conv2.weight'] = sd['conv1.conv2.weight'] * 1e-6         # ... conv2 brings it back to O(1)
+    net = A.GuidedResUnet(dict(arch))
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    noisy, _ = O.synth_noisy(128, 192, 4.0, 6.0, 77)
+    p = O.default_params()
+    p['gain'], p['sigma'] = np.float64(4.0), np.float64(6.0)
+    torch.set_num_threads(8)
+    ref = O.VST_Denoiser(noisy, p, arch, sd, bias_corr='pre')
+    assert np.isfinite(ref).all()
+    x = torch.from_numpy(noisy).to(DEV)
+    plan = P._plan_of(net, x.device)
+    assert plan.blocks[1]['conv1'].split(2) is None                    # 1e6-sized weights: refused by the split packing
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        dn = P.VST_Denoiser(x, p, net, arch, bias_corr='pre').cpu().numpy()
+    assert any("fp16's range" in str(w.message) for w in wlist)
+    assert np.isfinite(dn).all()
+    assert report("guarded forward vs oracle", dn, ref) <= 2e-4
+    # without the guard the same forward is wrong (this is what the guard prevents)
+    raw = P.VST_Denoiser(x, p, net, arch, bias_corr='pre', guard=False).cpu().numpy()
+    assert not np.isfinite(raw).all() or np.abs(raw - ref).max() > 1e-2
+    # the stream driver recomputes the offending frame, too
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'full_dn': True}
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        outs = list(P.denoise_stream([x, x.clone()], net, arch, pipe))
+    assert len(outs) == 2 and all(bool(torch.isfinite(o['raw_dns'][0]).all()) for o in outs)
+    assert sum("fp16's range" in str(w.message) for w in wlist) == 2
+    # a well-scaled network does not trip it
+    net2, _ = make_net(arch, 9)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        P.VST_Denoiser(x, p, net2, arch, bias_corr='pre')
+    assert not any("fp16's range" in str(w.message) for w in wlist)

@@ -21,7 +21,7 @@ class YondConvDesc(C.Structure):
                 ("Ho", i32), ("Wo", i32), ("Cout", i32), ("ksize", i32), ("stride", i32), ("shuffle", i32),
                 ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
                 ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32),
-                ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp)]
+                ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp), ("status", vp)]
 
 
 class YondFilmDesc(C.Structure):

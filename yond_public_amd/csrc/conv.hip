@@ -221,11 +221,13 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
                                                  16, 0, 0);
         }
     };
+    float amax = 0.0f;                                         // largest |activation| staged for a half-precision operand path
     auto write_item = [&](float* buf, int k) {
         f32x4 v = vin[k];
         if (PRE) { v[0] = silu_fast(v[0]); v[1] = silu_fast(v[1]); v[2] = silu_fast(v[2]); v[3] = silu_fast(v[3]); }
         const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
         v = ((vin_ok >> k) & 1u) ? v : z;                                                         // conv zero padding
+        if (MODE != 0) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));   // range guard
         if (SPL) v = split_pack4(v);
         if ((YOND_ABL & 2) == 0) *(f32x4*)(buf + in_lds[k]) = v;
     };
@@ -507,6 +509,7 @@ __global__ __launch_bounds__(256, (conv_wgs_per_cu<KS, STRIDE, KC, TN>())) void 
             if ((YOND_ABL & 4) == 0) epilogue_from(prev, eacc, ppar);
         }
     }
+    if (MODE != 0 && d.status && !(amax <= 65504.0f)) atomicOr(d.status, YOND_STATUS_HALF_OVERFLOW);
 }
 
 template <int KS, int STRIDE, int TH, int TN, int KC, bool PRE, int MODE>
@@ -609,6 +612,8 @@ extern "C" int yond_pack_conv_weight_split_f32(const float* w, int cout, int cin
     const int rc = yond_pack_conv_weight_f32(w, cout, cin, ksize, tn, kc, dst);
     if (rc != YOND_OK) return rc;
     const size_t n = (size_t)cout * cin * ksize * ksize;
+    for (size_t i = 0; i < n; ++i)
+        if (!(fabsf(w[i]) <= 65504.0f)) return YOND_EUNSUPPORTED;          // its h half would be +-inf
     for (size_t i = 0; i < n; ++i) {
         const float v = dst[i];
         const _Float16 h = (_Float16)v;

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         for (int k = 0; k < C::NIN; ++k) { const f32x4 z = {0.5f, 0.25f, -0.5f, 0.125f}; vin[0][k] = z; vin[1][k] = z; vin[NSET - 1][k] = z; }
     }
     unsigned vin_ok[NSET] = {};
+    float amax = 0.0f;                                         // largest |activation| this thread has staged (range guard)
     // one 16-byte load of a set (item k); the source of the chunk is selected once per step (LoadSrc)
     // source of a step's 16-channel chunks (K1: three of them, each from the low-resolution input or from the skip tensor)
     struct LoadSrc { const float* src[C::NPT]; int Cs[C::NPT], cc[C::NPT]; bool hi[C::NPT]; };
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         vin[P][k][j] = ((vin_ok[P] >> k) & 1u) ? x : 0.0f;                              // conv zero padding
         if constexpr (j == 3) {
             const f32x4 v = vin[P][k];
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));   // two v_max3
             const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             if (!(SPLIT_ABL & 8)) *(f16x4*)(ob + in_lds[k]) = h;
             if constexpr (PARTS == 2) {
@@ -704,6 +706,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead loads / DMA of the steps past the end
+    if (d.status && !(amax <= 65504.0f)) atomicOr(d.status, YOND_STATUS_HALF_OVERFLOW);   // an h half became +-inf
 }
 
 template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false>
@@ -742,6 +745,8 @@ extern "C" int yond_conv_split_supported(int ksize, int stride, int cin, int cou
 extern "C" int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst) {
     if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
     _Float16* o = (_Float16*)dst;
+    for (size_t i = 0, n = (size_t)cout * cin * ksize * ksize; i < n; ++i)
+        if (!(fabsf(w[i]) <= 65504.0f)) return YOND_EUNSUPPORTED;          // its h half would be +-inf
     if (ksize == 1) {
         if (cin % 48 != 0) return YOND_EINVAL;
         for (int ct = 0; ct < cout / tn; ++ct)

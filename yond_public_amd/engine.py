@@ -80,6 +80,7 @@ class _PackedConv:
         self.psplits, self.gemm_n, self.coutp, self.cinp = psplits, gemm_n, coutp, cinp
         self.cin_real, self.cout_real = sum(splits), cout
         self.config(0, 0, 0)                       # validates the shape and packs the default layout
+        self.wmax = float(np.abs(self._wp).max()) if self._wp.size else 0.0
         # algorithmic MACs per GEMM-M pixel (SURVEY.md section 8d counts real, unpadded channels)
         self.macs_per_pixel = self.cin_real * self.cout_real * (4 if shuffle else ksize * ksize)
 
@@ -94,9 +95,12 @@ class _PackedConv:
         if key not in self._packed:
             packed = np.empty(self._wp.size, np.float32)
             fn = lib.yond_pack_conv_weight_split_f32 if split else lib.yond_pack_conv_weight_f32
-            L.check(fn(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn.value, kc.value, _np_ptr(packed)),
-                    "yond_pack_conv_weight_f32")
-            self._packed[key] = torch.from_numpy(packed).to(self._dev)
+            rc = fn(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn.value, kc.value, _np_ptr(packed))
+            if split and rc == -2:          # a weight outside fp16's range: the caller takes the fp32 packing
+                self._packed[key] = None
+            else:
+                L.check(rc, "yond_pack_conv_weight_f32")
+                self._packed[key] = torch.from_numpy(packed).to(self._dev)
         return tn.value, kc.value, self._packed[key]
 
     def wino(self):
@@ -125,8 +129,11 @@ class _PackedConv:
         key = ('split', parts)
         if key not in self._packed:
             packed = np.empty(self._wp.size * parts // 2, np.float32)
-            L.check(lib.yond_pack_conv_split_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn, parts,
-                                                        _np_ptr(packed)), "yond_pack_conv_split_weight_f32")
+            rc = lib.yond_pack_conv_split_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn, parts, _np_ptr(packed))
+            if rc == -2:                    # a weight outside fp16's range: this layer stays on the fp32-input MFMA kernels
+                self._packed[key] = None
+                return None
+            L.check(rc, "yond_pack_conv_split_weight_f32")
             self._packed[key] = (tn, torch.from_numpy(packed).to(self._dev))
         return self._packed[key]
 
@@ -138,6 +145,9 @@ class DenoiserPlan:
         self.lib = L.load()
         self.dev = torch.device(device)
         self.prof = None                           # list -> record (kernel tag, flops, start, end) HIP events per conv launch
+        self.status = torch.zeros(4, dtype=torch.int32, device=self.dev)     # range-guard words of the half-precision paths
+        self.status_slot = 0
+        self.strict = False                        # True: every convolution on the fp32-input MFMA kernels (guard fallback)
         self.precision = getattr(module, 'precision', 'fp32')      # 'fp16': MFMA convolutions on the fp16 matrix path (cfg 5)
         self.kind = type(module).__name__          # GuidedResUnet | SNRnet | UNetSeeInDark
         self.res = bool(module.res)
@@ -229,7 +239,7 @@ class DenoiserPlan:
     # -- launches ----------------------------------------------------------------------------
     def _out4_fusable(self, pc):
         """The 1x1 output projection can ride in the epilogue of the last 3x3 convolution: split kernel, one 32-channel tile."""
-        return (getattr(self, 'conv_algo', WINO_DEFAULT) == 'split' and getattr(self, 'precision', 'fp32') == 'fp32'
+        return (not getattr(self, 'strict', False) and getattr(self, 'conv_algo', WINO_DEFAULT) == 'split' and getattr(self, 'precision', 'fp32') == 'fp32'
                 and pc.ksize == 3 and pc.stride == 1 and pc.gemm_n == 32 and pc.split(2) is not None
                 and os.environ.get('YOND_FUSE_OUT4', '1') != '0')
 
@@ -251,6 +261,8 @@ class DenoiserPlan:
         # `algo` (tests) / plan.conv_algo: 0 direct fp32, 1 Winograd fp32 where it is the faster kernel, 2 Winograd
         # fp32 wherever supported; plan.precision 'fp16' (BASELINE cfg 5): every MFMA convolution on the fp16 matrix path
         prec = getattr(self, 'precision', 'fp32')
+        if getattr(self, 'strict', False) and algo is None:
+            prec, algo = 'fp32-mfma', 1
         if algo is None:
             algo = getattr(self, 'conv_algo', WINO_DEFAULT)
             if prec == 'fp32-mfma' and algo == 'split':
@@ -273,12 +285,12 @@ class DenoiserPlan:
             tn, wpk = wino
             kc = 8
             d.algo = 1
-        elif algo == 'split' and pc.ksize == 1 and not fp16:
+        elif algo == 'split' and pc.ksize == 1 and not fp16 and pc.config(N, d.Ho, d.Wo, split=True)[2] is not None:
             tn, kc, wpk = pc.config(N, d.Ho, d.Wo, split=True)       # 1x1 / transposed layers: split operands in the generic kernel
             d.algo = 5
         else:
             tn, kc, wpk = pc.config(N, d.Ho, d.Wo)
-            d.algo = 2 if fp16 else 0
+            d.algo = 2 if (fp16 and pc.wmax <= 65504.0) else 0       # (a weight outside fp16's range keeps the layer in fp32)
         d.wpk = wpk.data_ptr()
         d.tn = tn
         d.kc = kc
@@ -287,6 +299,8 @@ class DenoiserPlan:
         d.ebatch = ebatch
         d.res = res.data_ptr() if res is not None else None
         d.dst = dst.data_ptr() if dst is not None else None
+        status = getattr(self, 'status', None)                       # (bare plans of the kernel tests have none)
+        d.status = status.data_ptr() + 4 * self.status_slot if status is not None else None
         if out4 is not None:
             # (w [4][Cout], bias [4], network input NHWC4 or None, per-image maxima or None, destination NHWC4)
             w4, b4, x4, ub4, o4 = out4
@@ -349,6 +363,20 @@ class DenoiserPlan:
         outs, raw, nb = self._film_cache[key]
         L.check(self.lib.yond_film_f32(L.ptr(raw), nb, L.ptr(t_dev), L.ptr(ub), N, L.stream()), "yond_film_f32")
         return outs
+
+    # -- range guard of the half-precision operand paths -------------------------------------------------------
+    def uses_half_operands(self):
+        """True when forwards stage activations as fp16 (split operands or the fp16 path): they need |a| <= 65504."""
+        return not self.strict and getattr(self, 'precision', 'fp32') in ('fp32', 'fp16') and getattr(self, 'conv_algo', WINO_DEFAULT) in ('split', 'half', 'fp16')
+
+    def begin_guard(self, slot=0):
+        """Zero the status word `slot` and direct the following launches to it (asynchronous)."""
+        self.status_slot = slot
+        self.status[slot:slot + 1].zero_()
+
+    def overflowed(self, slot=0):
+        """Read the status word (synchronises the current stream): True if a staged activation left fp16's range."""
+        return bool(int(self.status[slot].item()) & 1)
 
     def image_max(self, x4, N):
         elems = x4.numel() // N

@@ -411,14 +411,51 @@ def _plan_of(net, device):
     return mod._get_plan(device)
 
 
+class _Guard:
+    """Range guard of the half-precision operand paths (engine.DenoiserPlan.uses_half_operands): the convolution kernels
+    report a staged activation outside fp16's range in a device word; `finish` waits for the forward it watched, and if
+    the word is set re-runs that forward on the fp32-input MFMA kernels -- an overflow never reaches the caller as a
+    silent inf."""
+
+    def __init__(self, plan, slot):
+        self.plan, self.slot = plan, slot
+        if not hasattr(plan, '_flag_host'):
+            plan._flag_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        plan.begin_guard(slot)
+
+    def arm(self, rerun):
+        """Queue the read-back of the status word behind the forward; `rerun()` recomputes the result strictly."""
+        self.rerun = rerun
+        self.plan._flag_host[self.slot:self.slot + 1].copy_(self.plan.status[self.slot:self.slot + 1], non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        return self
+
+    def finish(self):
+        """None if the forward stayed in range, else the strictly recomputed result."""
+        self.event.synchronize()
+        if not (int(self.plan._flag_host[self.slot]) & 1):
+            return None
+        import warnings
+        warnings.warn("an activation left fp16's range (|a| > 65504) in the split-operand convolution path: "
+                      "this forward is recomputed on the fp32-input MFMA kernels")
+        self.plan.strict = True
+        try:
+            return self.rerun()
+        finally:
+            self.plan.strict = False
+
+
 def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type='exact', clip01=False, device=None,
-                 lr_max=None):
+                 lr_max=None, guard=True, guard_slot=0):
     """YOND_SIDD.py:250-299 for the network denoisers.  lr_raw: Bayer [H][W] -- or a stack [B][H][W] of equally
     sized frames that go through ONE batched forward instead of B batch-1 calls: the 32 blocks of a SIDD image, which
     share (gain, sigma) and the bias LUT (:392-407), or B independent frames (BASELINE cfg 4), for which `p`,
     `bias_func` and `lr_max` are lists with one entry per frame.  p: dict with scale, gain, sigma; returns the
     denoised frame(s) as a device tensor.  `clip01` folds the caller's .clip(0,1); `lr_max` (float32 max of the
-    frame) spares the device reduction + sync when the caller already has it."""
+    frame) spares the device reduction + sync when the caller already has it.  guard: True -- wait for the forward and
+    recompute it on the fp32-input MFMA kernels if an activation left fp16's range (see _Guard); 'defer' -- return
+    (result, guard) and let the caller call guard.finish() later; False -- no check."""
     lib = L.load()
     lr = _dev(lr_raw, device)
     single = lr.dim() == 2
@@ -465,16 +502,28 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
     if 'guided' in arch:
         t_dev = torch.tensor(t_host, dtype=torch.float32).to(lr.device, non_blocking=True) if per_frame else \
             torch.full((B,), t_host[0], dtype=torch.float32, device=lr.device)
-    y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
-    out = torch.empty((B, H, W), dtype=torch.float32, device=lr.device)
     exact_inverse = bias_corr is None and vst_type == 'exact'
-    with _stage("ivst_unpack"):
-        for i in range(B):
-            scale, gain, sigma, lower, upper = consts[i]
-            L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4[i]), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out[i]),
-                                                    2 if exact_inverse else 1, scale, float(gain), float(sigma), float(lower),
-                                                    float(upper), int(clip01), st), "yond_denorm_ivst_unpack_f32")
-    return out[0] if single else out
+
+    def forward_and_invert():
+        y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
+        out = torch.empty((B, H, W), dtype=torch.float32, device=lr.device)
+        with _stage("ivst_unpack"):
+            for i in range(B):
+                scale, gain, sigma, lower, upper = consts[i]
+                L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4[i]), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out[i]),
+                                                        2 if exact_inverse else 1, scale, float(gain), float(sigma), float(lower),
+                                                        float(upper), int(clip01), st), "yond_denorm_ivst_unpack_f32")
+        return out[0] if single else out
+
+    watch = _Guard(plan, guard_slot) if (guard and plan.uses_half_operands()) else None
+    out = forward_and_invert()
+    if watch is None:
+        return (out, None) if guard == 'defer' else out
+    watch.arm(forward_and_invert)
+    if guard == 'defer':
+        return out, watch
+    redo = watch.finish()
+    return out if redo is None else redo
 
 
 def _frame_max(x):
@@ -503,10 +552,18 @@ def Simple_Denoiser(lr_raw, net, device=None):
     plan = _plan_of(net, lr.device)
     if plan.guided:
         raise L.YondHipError("Simple_Denoiser calls net(x) without a noise level (YOND_SIDD.py:244)")
-    y4 = plan.forward_nhwc4(x4, None, ub=img_max)
-    out = torch.empty((H, W), dtype=torch.float32, device=lr.device)
-    L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 0, 1.0, 1.0, 0.0, 0.0, 1.0, 0, st),
-            "yond_denorm_ivst_unpack_f32")
+    def forward_and_unpack():
+        y4 = plan.forward_nhwc4(x4, None, ub=img_max)
+        out = torch.empty((H, W), dtype=torch.float32, device=lr.device)
+        L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 0, 1.0, 1.0, 0.0, 0.0, 1.0, 0, st),
+                "yond_denorm_ivst_unpack_f32")
+        return out
+
+    watch = _Guard(plan, 0) if plan.uses_half_operands() else None
+    out = forward_and_unpack()
+    if watch is not None:
+        redo = watch.arm(forward_and_unpack).finish()
+        out = out if redo is None else redo
     return out
 
 
@@ -690,6 +747,17 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     except StopIteration:
         return
     nxt = estimate(f, main.record_event())
+    pending = None                         # the previous frame's result: yielded once its range guard has been read
+    k_frame = 0
+
+    def release(item):
+        res, watch = item
+        if watch is not None:
+            redo = watch.finish()          # the frame's forward finished a whole frame ago: no waiting in steady state
+            if redo is not None:
+                res['raw_dns'][0] = redo
+        return res
+
     while nxt is not None:
         lr, reg, lr_max = nxt
         try:                               # take the next frame (and mark the main stream) BEFORE queuing this one's network
@@ -699,9 +767,15 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
             f_next = None
         pp = dict(p0)
         pp['gain'], pp['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale
-        raw_dn = VST_Denoiser(lr, pp, net, arch, bias_corr, None, vst_type, clip01=True, lr_max=lr_max)   # phase 2, asynchronous
+        raw_dn, watch = VST_Denoiser(lr, pp, net, arch, bias_corr, None, vst_type, clip01=True, lr_max=lr_max,
+                                     guard='defer', guard_slot=k_frame & 1)                     # phase 2, asynchronous
+        k_frame += 1
         nxt = estimate(f_next, ready) if f_next is not None else None     # overlaps with the convolutions just queued
-        yield dict(raw_dns=[raw_dn], regs=[reg], params=[(pp['gain'], pp['sigma'])])
+        if pending is not None:
+            yield release(pending)
+        pending = (dict(raw_dns=[raw_dn], regs=[reg], params=[(pp['gain'], pp['sigma'])]), watch)
+    if pending is not None:
+        yield release(pending)
 
 
 _SIDE_STREAMS = {}

@@ -51,6 +51,20 @@ int yond_pack_vst_norm_f32(const float* bayer, int H, int W, float* out, int pad
                            double hi, const double* lut_x, const float* lut_y, int lut_n, float* img_max,
                            void* stream);
 
+/* K1 with the 2-D bias LUT (YOND_SIDD.py:258-259 -> utils/isp_algos.py:162-231 BiasLUT.get_lut): lut_x = the table's x
+ * knots in DN (x_lut * gain, float64), lut_y = the table row merged for sigma / gain (float64; the host interpolates the
+ * two neighbouring sigma rows, :188-194).  Beyond the last knot: the last ordinate for one more interval, then
+ * get_bias_points' closed form (:226-230).  Otherwise as yond_pack_vst_norm_f32 with mode 1. */
+int yond_pack_vst_norm_biaslut_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t,
+                                   int pad_b, double scale, double gain, double sigma, double lo, double hi,
+                                   const double* lut_x, const double* lut_y, int lut_n, float* img_max, void* stream);
+
+/* The bias LUT alone on a flat float32 array (the callable get_bias returns, utils/isp_algos.py:128, or
+ * BiasLUT.get_lut(x), :196-231): y_is_f64 selects float64 ordinates, biaslut the 2-D LUT's behaviour beyond the knots.
+ * out: float64[n]. */
+int yond_bias_eval_f32(const float* x, size_t n, const double* lut_x, const void* lut_y, int lut_n, int y_is_f64, int biaslut,
+                       double gain, double sigma, double* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K4  clamp + crop + de-normalise + inverse VST + unpack (+ /scale, clip)          (8 B / Bayer px)
  * Replaces YOND_SIDD.py:286 (output clamp), :289-299 and utils/isp_algos.py:17-33 (inverse_VST).

@@ -39,6 +39,21 @@ def _cv2_blur(src, ksize, dst=None, anchor=None, borderType=None):
     return out.astype(a.dtype)
 
 
+def _cv2_gaussian_kernel(ksize, sigma, ktype=None):
+    """cv2.getGaussianKernel restated from its documentation: G_i = alpha * exp(-(i - (ksize-1)/2)^2 / (2 sigma^2)),
+    sum G_i = 1, as a (ksize, 1) float64 column.  (Called by the reference's SSIM, YOND_SIDD.py:684; unpinned.)"""
+    i = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+    g = np.exp(-(i * i) / (2.0 * sigma * sigma))
+    return (g / g.sum()).reshape(-1, 1)
+
+
+def _cv2_filter2d(src, ddepth, kernel, dst=None, anchor=None, delta=0, borderType=None):
+    """cv2.filter2D restated: CORRELATION with the kernel, anchor at its centre, BORDER_REFLECT_101, output depth =
+    input depth for ddepth = -1.  (YOND_SIDD.py:686-693 crop the border away, so only the interior matters.)"""
+    from scipy.ndimage import correlate
+    return correlate(np.asarray(src, np.float64), np.asarray(kernel, np.float64), mode="mirror").astype(np.asarray(src).dtype)
+
+
 def install_stubs():
     def stub(name, **attrs):
         m = types.ModuleType(name)
@@ -46,7 +61,8 @@ def install_stubs():
         sys.modules[name] = m
         return m
 
-    cv2 = stub("cv2", setNumThreads=lambda n: None, blur=_cv2_blur)
+    cv2 = stub("cv2", setNumThreads=lambda n: None, blur=_cv2_blur, getGaussianKernel=_cv2_gaussian_kernel,
+               filter2D=_cv2_filter2d)
     cv2.__stub__ = True
     stub("rawpy")
     stub("rawpy.enhance")

@@ -270,8 +270,61 @@ def gen_iter(ref):
     save("iter", **out)
 
 
+def small_bias_grids():
+    """A reduced (x, sigma) grid with the structure of the shipped one (linear head + log tail; utils/isp_algos.py:168-177)."""
+    x_lut = np.concatenate((np.linspace(0, 2 ** -4, 4, endpoint=False), np.exp(np.linspace(np.log(2 ** -4), np.log(2 ** 10), 57))))
+    sg_lut = np.concatenate((np.linspace(0, 1, 4, endpoint=False), np.linspace(1, 10, 7)))
+    return x_lut, sg_lut
+
+
+def gen_biaslut(ref):
+    """Row H': a small 2-D table built with the reference's get_bias_points (utils/isp_algos.py:142-160), then the
+    reference's BiasLUT.get_lut (:196-231) on it -- in-table lookups, the sigma-outside fallback and x beyond the table."""
+    x_lut, sg_lut = small_bias_grids()
+    table = np.zeros((len(x_lut), len(sg_lut)))
+    for j, sg in enumerate(sg_lut):
+        table[:, j] = ref.get_bias_points(x_lut.copy(), 1.0, float(sg), pho_min=20, close_form=True)
+    lut = object.__new__(ref.BiasLUT)
+    lut.bias_lut, lut.x_lut, lut.sg_lut = table, x_lut, sg_lut
+    out = {"table": table, "x_lut": x_lut, "sg_lut": sg_lut}
+    rng = np.random.default_rng(5)
+    cases = [(4.37, 6.27), (22.65, 37.09), (0.72, 1.8), (1.0, 0.0), (2.0, 19.5), (0.5, 7.0)]     # last: sigma/K = 14 > 10 e-
+    for ci, (K, s) in enumerate(cases):
+        npts = 1400 if s / K > sg_lut[-1] else 200        # sigma outside the table: > 1000 points take the get_bias branch (:207-209),
+        x = np.concatenate((np.linspace(0, 1100 if npts == 200 else 950, npts), rng.random(120) * 960,      # as every image does
+                            [0.0, 1e-3] + ([2000.0, 3000.0] if npts == 200 else []))).astype(np.float32)
+        x = np.maximum(x * np.float32(1.0), 0)
+        got = lut.get_lut(x.copy(), K=np.float64(K), sigGs=np.float64(s))
+        out[f"x_{ci}"] = x
+        out[f"bias_{ci}"] = np.asarray(got, np.float64)
+        out[f"ksig_{ci}"] = np.array([K, s])
+    out["ncases"] = np.array(len(cases))
+    # YOND_SIDD.py:254-259 through the 2-D LUT: VST_Denoiser with self.biaslut set
+    arch = ARCHS["gru8"]
+    obj, sd = fake_self(ref, arch, 91, {'vst_type': 'exact'})
+    obj.biaslut = lut
+    noisy, _ = O.synth_noisy(96, 128, 4.37, 6.27, 55)
+    p = {'wp': 1023, 'bl': 64, 'ratio': 1, 'scale': 959.0, 'gain': np.float64(4.37), 'sigma': np.float64(6.27)}
+    out["dn_vd"] = np.asarray(ref.YOND_SIDD.VST_Denoiser(obj, noisy, None, 'pre', None, denoiser='gru32n', p=p))
+    out["sha_vd"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
+    save("biaslut", **out)
+
+
+def gen_ssim(ref):
+    """N1: the reference's own ssim / calculate_ssim (YOND_SIDD.py:679-721) around the stubbed cv2 filter, and the PSNR
+    formula its skimage call stands for, on seeded blocks -- pins the oracle's arithmetic around the (unpinned) filter."""
+    out = {}
+    for ci, (K, s) in enumerate([(4.0, 6.0), (22.65, 37.09), (0.72, 1.8)]):
+        noisy, clean = O.synth_noisy(256, 512, K, s, 61 + ci)
+        dn = np.clip(clean + 0.3 * (noisy - clean), 0, 1).astype(np.float32)
+        vals = [ref.calculate_ssim(a * 255, b * 255) for a, b in zip(np.split(dn, 2, axis=-1), np.split(clean, 2, axis=-1))]
+        out[f"ssim_{ci}"] = np.array(vals, np.float64)
+        out[f"ksig_{ci}"] = np.array([K, s])
+    save("ssim", **out)
+
+
 GENS = dict(pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
-            vst_denoiser=gen_vst_denoiser, iter=gen_iter)
+            vst_denoiser=gen_vst_denoiser, iter=gen_iter, biaslut=gen_biaslut, ssim=gen_ssim)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

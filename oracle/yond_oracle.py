@@ -371,6 +371,77 @@ def get_bias(img_max, sigGs, K):
 
 
 # ----------------------------------------------------------------------------------------
+# Row H' -- 2-D bias LUT (utils/isp_algos.py:142-231).  The shipped table (checkpoints/bias_lut_2d.npy:
+# x in [0, 2^10] e- on 128 linear + 14*128 log knots, sigma in [0, 10] e- on 1101 knots) is a missing blob;
+# the class works on any (x_lut, sg_lut, table) -- the fixtures use a small table built with the reference's own
+# get_bias_points.
+# ----------------------------------------------------------------------------------------
+
+def get_bias_points(lams, K, sigGs, pho_min=100, close_form=False):
+    """utils/isp_algos.py:142-160 (clip=False)."""
+    lams = np.asarray(lams)
+    bias = np.zeros_like(lams)                      # (the caller's dtype: float32 queries give float32 biases, :143)
+    pho = np.maximum(int(K ** 0.5), pho_min)
+    if close_form:
+        th = 50 * K if K < 1 else 50 * K ** 0.5
+        bias[lams > th] = close_form_bias(lams[lams > th], sigGs, K)
+    else:
+        th = lams.max() + 1
+    for i, lam in enumerate(lams[lams <= th]):
+        x, p = getGsP(lam, K, sigGs, r=int(lam * (1 / K) * 2 + sigGs * 2 + lam + 10), pho=pho)
+        bias[i] = np.sum(p * VST(K * x, sigGs, gain=K) / pho) - VST(lam, sigGs, gain=K)
+    return bias
+
+
+def default_bias_lut_grids(sp=128):
+    """utils/isp_algos.py:168-177: the grids of the shipped table."""
+    x_lut = np.concatenate((np.linspace(0, 2 ** -4, sp, endpoint=False),
+                            np.exp(np.linspace(np.log(2 ** (-4)), np.log(2 ** 10), 14 * sp + 1))))
+    sg_lut = np.concatenate((np.linspace(0, 1, 200, endpoint=False), np.linspace(1, 10, 901)))
+    return x_lut, sg_lut
+
+
+class BiasLUT:
+    """utils/isp_algos.py:162-231 restated (func=False, the call of YOND_SIDD.py:259)."""
+
+    def __init__(self, bias_lut, x_lut=None, sg_lut=None):
+        self.bias_lut = np.asarray(bias_lut)
+        dx, ds = default_bias_lut_grids()
+        self.x_lut = np.asarray(x_lut if x_lut is not None else dx, np.float64)
+        self.sg_lut = np.asarray(sg_lut if sg_lut is not None else ds, np.float64)
+
+    def pos_interp(self, data, x):                                   # :179-186
+        data = np.concatenate(([-np.inf, ], data))
+        idx = np.searchsorted(data, x).clip(0, len(data) - 1)
+        w = data[idx] - x
+        diff = data[idx] - data[idx - 1]
+        return idx - w / diff - 1
+
+    def data_merge(self, data, pos):                                  # :188-194 (clips with len(x_lut) on either axis)
+        pos = pos.clip(0, len(self.x_lut) - 1)
+        l, r = np.int32(np.floor(pos)), np.int32(np.ceil(pos))
+        weight_r = pos - l
+        return data[..., l] * (1 - weight_r) + data[..., r] * weight_r
+
+    def get_lut(self, x, K=1, sigGs=2):                               # :196-231, func=False
+        xe, sg = x / K, sigGs / K
+        sg_pos = self.pos_interp(self.sg_lut, sg)
+        sg_len, x_len = len(self.sg_lut), len(self.x_lut)
+        if sg_pos >= sg_len:                                          # :204-212: outside the table
+            if x.size > 1000:
+                return BiasFunc(*get_bias_table(x.max(), sigGs, K))(x)
+            return get_bias_points(x.reshape(-1), K, sigGs, close_form=True).reshape(*x.shape)
+        x_pos = self.pos_interp(self.x_lut, xe)
+        data = self.data_merge(self.bias_lut.reshape(-1, sg_len), sg_pos)
+        bias = self.data_merge(data[None], x_pos)[0]
+        if np.any(x_pos >= x_len):                                    # :226-230
+            if len(bias.shape) == 0:
+                bias = np.array([bias])
+            bias[x_pos >= x_len] = get_bias_points(x[x_pos >= x_len], K, sigGs, close_form=True)
+        return bias
+
+
+# ----------------------------------------------------------------------------------------
 # Row I -- padding helper (utils/utils.py:246-252)
 # ----------------------------------------------------------------------------------------
 
@@ -662,13 +733,16 @@ def denoising_state_dict(arch, seed=0, eps=0.004):
 # Row J -- VST_Denoiser (YOND_SIDD.py:250-299), Simple_Denoiser (:238-248)
 # ----------------------------------------------------------------------------------------
 
-def VST_Denoiser(lr_raw, p, arch, sd, bias_corr='pre', bias_func=None, vst_type='exact', full=False):
+def VST_Denoiser(lr_raw, p, arch, sd, bias_corr='pre', bias_func=None, vst_type='exact', full=False, biaslut=None):
     lr_rggb = bayer2rggb(lr_raw) * p['scale']
     bias_base = np.maximum(lr_rggb, 0)
     if bias_corr is not None:
-        if bias_func is None:
-            bias_func = get_bias(lr_rggb.max(), p['sigma'], p['gain'])
-        bias = bias_func(bias_base)
+        if biaslut is not None:                                                   # YOND_SIDD.py:258-259
+            bias = biaslut.get_lut(bias_base, K=p['gain'], sigGs=p['sigma'])
+        else:
+            if bias_func is None:
+                bias_func = get_bias(lr_rggb.max(), p['sigma'], p['gain'])
+            bias = bias_func(bias_base)
     raw_vst = VST(lr_rggb, p['sigma'], gain=p['gain'])
     if bias_corr == 'pre':
         raw_vst = raw_vst - bias

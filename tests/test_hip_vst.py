@@ -113,3 +113,41 @@ def test_vst_denoiser_matches_reference(golden, ci):
     ref = g[f"dn_{ci}"]
     err = report(f"VST_Denoiser case {ci}", dn, ref)
     assert err <= 1e-4
+
+
+def test_bias_lut_2d_matches_reference(golden):
+    """Row H' (utils/isp_algos.py:162-231): the 2-D bias LUT lookup on the device -- in-table interpolation, the constant /
+    closed-form region beyond the table, the sigma-outside fallback to get_bias -- against the reference's own
+    BiasLUT.get_lut on a small table built with the reference's get_bias_points (tests/golden/biaslut.npz)."""
+    from yond_public_amd import pipeline as P
+    g = golden("biaslut")
+    lut = P.BiasLUT(table=g["table"], x_lut=g["x_lut"], sg_lut=g["sg_lut"])
+    for ci in range(int(g["ncases"])):
+        K, s = (np.float64(v) for v in g[f"ksig_{ci}"])
+        x = g[f"x_{ci}"]
+        got = lut.get_lut(torch.from_numpy(x).to(DEV), K=K, sigGs=s).cpu().numpy()
+        ref = g[f"bias_{ci}"]
+        err = report(f"BiasLUT.get_lut K={K} sigma={s}", got, ref)
+        # in-table: float64 interpolation (1e-12); sigma outside the table (last case): the device-built 1-D LUT, float32 knots
+        assert err <= (3e-7 if lut.row(K, s, DEV) is None else 1e-10)
+
+
+def test_vst_denoiser_with_bias_lut_2d(golden):
+    """YOND_SIDD.py:254-259 with self.biaslut set: K1 evaluates the merged table row per pixel."""
+    import yond_oracle as O
+    from hip_common import ARCHS, make_net, sha
+    from yond_public_amd import pipeline as P
+    g = golden("biaslut")
+    lut = P.BiasLUT(table=g["table"], x_lut=g["x_lut"], sg_lut=g["sg_lut"])
+    noisy, _ = O.synth_noisy(96, 128, 4.37, 6.27, 55)
+    assert np.array_equal(sha(noisy), g["sha_vd"])
+    arch = ARCHS["gru8"]
+    net, sd = make_net(arch, 91)
+    p = {'wp': 1023, 'bl': 64, 'ratio': 1, 'scale': 959.0, 'gain': np.float64(4.37), 'sigma': np.float64(6.27)}
+    dn = P.VST_Denoiser(torch.from_numpy(noisy).to(DEV), p, net, arch, bias_corr='pre', biaslut=lut).cpu().numpy()
+    assert report("VST_Denoiser through the 2-D bias LUT", dn, g["dn_vd"]) <= 1e-4
+    # and the estimator-driven pipeline accepts the table (full frame and SIDD stack)
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'full_dn': True}
+    ref = O.IterDenoise(noisy, arch, sd, pipe)      # 1-D LUT path of the oracle: the two LUTs agree to the table's resolution
+    res = P.IterDenoise(noisy, net, arch, pipe, device=DEV, biaslut=lut)
+    assert float(np.abs(res['raw_dns'][0].cpu().numpy() - ref['raw_dns'][0]).max()) < 5e-3

@@ -214,3 +214,35 @@ def test_iter_denoise(golden, ci):
             np.testing.assert_allclose(got, g[f"dn_{ci}_{it}_{tag}"], rtol=0, atol=2e-5)
         chk = g[f"dn_{ci}_{it}_chk"]
         np.testing.assert_allclose(np.asarray(dn, np.float64).sum(), chk[0], rtol=1e-6)
+
+
+def test_bias_lut_2d(golden):
+    """Row H': the oracle's BiasLUT against the reference's BiasLUT.get_lut on a small table built with the reference's
+    get_bias_points -- table regenerated bit for bit by the oracle's restatement, lookups equal, VST_Denoiser through it."""
+    g = golden("biaslut")
+    x_lut, sg_lut, table = g["x_lut"], g["sg_lut"], g["table"]
+    col = O.get_bias_points(x_lut.copy(), 1.0, float(sg_lut[5]), pho_min=20, close_form=True)
+    np.testing.assert_allclose(col, table[:, 5], rtol=0, atol=1e-12)
+    lut = O.BiasLUT(table, x_lut, sg_lut)
+    for ci in range(int(g["ncases"])):
+        K, s = (np.float64(v) for v in g[f"ksig_{ci}"])
+        got = lut.get_lut(g[f"x_{ci}"].copy(), K=K, sigGs=s)
+        np.testing.assert_allclose(got, g[f"bias_{ci}"], rtol=1e-12, atol=1e-12)
+    noisy, _ = O.synth_noisy(96, 128, 4.37, 6.27, 55)
+    assert np.array_equal(sha(noisy), g["sha_vd"])
+    arch = ARCHS["gru8"]
+    p = {'wp': 1023, 'bl': 64, 'ratio': 1, 'scale': 959.0, 'gain': np.float64(4.37), 'sigma': np.float64(6.27)}
+    dn = O.VST_Denoiser(noisy, p, arch, O.procedural_state_dict(arch, 91), bias_corr='pre', biaslut=lut)
+    np.testing.assert_allclose(dn, g["dn_vd"], rtol=0, atol=5e-6)
+
+
+def test_ssim_against_reference_arithmetic(golden):
+    """N1: the reference's own calculate_ssim (YOND_SIDD.py:679-721), run around a documented-semantics stub of
+    cv2.getGaussianKernel / filter2D, against the oracle's restatement (the filter itself stays unpinned)."""
+    g = golden("ssim")
+    for ci in range(3):
+        K, s = g[f"ksig_{ci}"]
+        noisy, clean = O.synth_noisy(256, 512, K, s, 61 + ci)
+        dn = np.clip(clean + 0.3 * (noisy - clean), 0, 1).astype(np.float32)
+        vals = [O.ssim(a * 255, b * 255) for a, b in zip(np.split(dn, 2, axis=-1), np.split(clean, 2, axis=-1))]
+        np.testing.assert_allclose(vals, g[f"ssim_{ci}"], rtol=1e-12)

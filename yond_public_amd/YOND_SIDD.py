@@ -104,6 +104,8 @@ class YOND_SIDD:
             model_path = None                      # no checkpoint: a deterministic weak denoiser (both rounds run)
             self.net.load_state_dict(S.denoising_state_dict(self.net, 0))
         self.net = self.net.to(self.device).eval()
+        # the 2-D bias LUT when its blob is present (YOND_SIDD.py:171), else get_bias per image
+        self.biaslut = P.BiasLUT() if os.path.exists('checkpoints/bias_lut_2d.npy') else None
         if self.rank == 0:
             nparam = sum(p.numel() for p in self.net.parameters())
             log(f'Method Name:\t{self.method_name}', self.logfile, notime=True)
@@ -127,13 +129,14 @@ class YOND_SIDD:
 
     def VST_Denoiser(self, lr_raw, hr_raw=None, bias_corr='pre', bias_func=None, denoiser='gru32n', p=None):
         return P.VST_Denoiser(lr_raw, p, self.net, self.arch, bias_corr, bias_func, self.pipe.get('vst_type', 'exact'),
-                              device=self.device)
+                              device=self.device, biaslut=self.biaslut)
 
     def IterDenoise(self, data, params):
         # data['lr'] is the [32][256][256] stack; pipeline.IterDenoise concatenates it for the estimate (:315) and, with
         # pipe['full_dn'], for the denoiser (:388); the collaborative estimate re-tiles per block (SIDD_256, :431)
         res = P.IterDenoise(data['lr'], self.net, self.arch, self.pipe, lr_full=data.get('lr_full'), p=params['p'],
-                            device=self.device, log=(lambda s: log(s, self.logfile)) if self.parser.verbose else None)
+                            device=self.device, log=(lambda s: log(s, self.logfile)) if self.parser.verbose else None,
+                            biaslut=self.biaslut)
         res['lr_raw'] = np.concatenate(data['lr'], axis=-1)
         res['hr_raw'] = np.concatenate(data['hr'], axis=-1) if 'hr' in data else None
         return res

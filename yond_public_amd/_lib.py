@@ -35,6 +35,8 @@ class YondFilmDesc(C.Structure):
 PROTOTYPES = {
     "yond_abi_version": [],
     "yond_pack_vst_norm_f32": [vp, i32, i32, vp, i32, i32, i32, i32, i32, f64, f64, f64, f64, f64, vp, vp, i32, vp, vp],
+    "yond_pack_vst_norm_biaslut_f32": [vp, i32, i32, vp, i32, i32, i32, i32, f64, f64, f64, f64, f64, vp, vp, i32, vp, vp],
+    "yond_bias_eval_f32": [vp, sz, vp, vp, i32, i32, i32, f64, f64, vp, vp],
     "yond_denorm_ivst_unpack_f32": [vp, i32, i32, i32, i32, i32, i32, vp, i32, f64, f64, f64, f64, f64, i32, vp],
     "yond_vst_elem_f32": [vp, sz, f64, f64, f64, vp, vp],
     "yond_ivst_elem_f64": [vp, sz, f64, f64, i32, vp, vp],

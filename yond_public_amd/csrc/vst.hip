@@ -29,16 +29,26 @@ struct LutLds {
     int nbreak;
 };
 
-__device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict__ lut_x, const float* __restrict__ lut_y, int n) {
+// flags: bit 0 -- ordinates are float64 (the 2-D BiasLUT's merged row) instead of float32 (get_bias' interp1d knots);
+//        bit 1 -- BiasLUT semantics beyond the last knot (utils/isp_algos.py:188-194, 226-230): the last ordinate up to one
+//                 more interval, Foi's closed form (float32-rounded, as the reference stores it) further out
+#define LUT_Y64 1
+#define LUT_BIASLUT 2
+__device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict__ lut_x, const void* __restrict__ lut_yv, int n,
+                                            int flags) {
     const int tid = threadIdx.x;
+    const float* lut_y = (const float*)lut_yv;
+    const double* lut_y64 = (const double*)lut_yv;
     for (int i = tid; i < n; i += 256) L.x[i] = lut_x[i];
     if (tid == 0) { L.nbreak = 0; L.nseg = 0; }
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
         if (i >= 1) {
-            const float dy = lut_y[i] - lut_y[i - 1];             // float32 difference, as interp1d does with float32 knots
-            const double b = (double)dy / (L.x[i] - L.x[i - 1]);
-            L.ab[i] = make_double2((double)lut_y[i - 1] - b * L.x[i - 1], b);
+            double dy, y0;
+            if (flags & LUT_Y64) { dy = lut_y64[i] - lut_y64[i - 1]; y0 = lut_y64[i - 1]; }
+            else { dy = (double)(lut_y[i] - lut_y[i - 1]); y0 = (double)lut_y[i - 1]; }   // float32 difference, as interp1d forms it
+            const double b = dy / (L.x[i] - L.x[i - 1]);
+            L.ab[i] = make_double2(y0 - b * L.x[i - 1], b);
         }
         if (i >= 1 && i + 1 < n) {
             const double d0 = L.x[i] - L.x[i - 1], d1 = L.x[i + 1] - L.x[i];
@@ -95,6 +105,29 @@ __device__ __forceinline__ double lut_eval(const LutLds& L, int n, float xq) {
     return c.x + c.y * (double)xq;
 }
 
+// Foi's closed-form bias of the generalized Anscombe transform (utils/isp_algos.py:84-96)
+__device__ __forceinline__ double close_form_bias_dev(double x, double sigma, double gain) {
+    const double y = x / gain, sg = sigma / gain;
+    const double yh = y + 0.375 + sg * sg;
+    const double m1 = (y + sg * sg) / (yh * yh);
+    const double m2 = y / (yh * yh * yh);
+    const double q = y + sg * sg;
+    const double m3 = (y + 3.0 * q * q) / (yh * yh * yh * yh);
+    return 2.0 * sqrt(yh) * (-0.125 * m1 + 0.0625 * m2 - 0.0390625 * m3);
+}
+
+// 2-D BiasLUT semantics (flags & LUT_BIASLUT): inside the knots as lut_eval; beyond the last knot the reference's index
+// position is clipped (constant = last ordinate) until it reaches x_len, from where get_bias_points' closed form takes over
+__device__ __forceinline__ double biaslut_eval(const LutLds& L, int n, float xq, double gain, double sigma) {
+    const double x = (double)xq, xl = L.x[n - 1];
+    if (x > xl) {
+        const double2 c = L.ab[n - 1];
+        if (x - xl >= xl - L.x[n - 2]) return (double)(float)close_form_bias_dev(x, sigma, gain);
+        return c.x + c.y * xl;                                   // the last ordinate
+    }
+    return lut_eval(L, n, xq);
+}
+
 // sqrt of a non-negative float64 to ~1e-15 relative: the float32 hardware estimate (1 ulp of float32) and one Newton step
 // in float64; the full-precision float64 sqrt sequence costs four times as much and K1 rounds its result to float32 anyway
 __device__ __forceinline__ double sqrt_newton(double a) {
@@ -112,7 +145,7 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
                                                             float* __restrict__ out, int pad_l, int pad_t, int Hp,
                                                             int Wp, int mode, float scale_f, double gain, double sigma,
                                                             double lo, double hi, const double* __restrict__ lut_x,
-                                                            const float* __restrict__ lut_y, int lut_n,
+                                                            const void* __restrict__ lut_y, int lut_n, int lut_flags,
                                                             unsigned int* __restrict__ img_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lut_raw[];
     __shared__ LutLds L;
@@ -122,7 +155,7 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
         L.x = (double*)(L.ab + lut_n);
     }
     __syncthreads();
-    if (lut_n > 0) lut_prepare(L, lut_x, lut_y, lut_n);
+    if (lut_n > 0) lut_prepare(L, lut_x, lut_y, lut_n, lut_flags);
     const int h = H / 2, w = W / 2;
     const double c0 = 0.375 * gain * gain;       // (3/8)*gain**2
     const double s2 = sigma * sigma;
@@ -150,7 +183,8 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
                 double fz = gain * (double)x32 + c0 + s2;               // gain*x + (3/8)gain^2 + sigma^2 (- gain*0)
                 fz = fz > 0.0 ? fz : 0.0;
                 double v = two_over_gain * sqrt_newton(fz);
-                if (lut_n > 0) v -= lut_eval(L, lut_n, fmaxf(x32, 0.0f));
+                if (lut_n > 0) v -= (lut_flags & LUT_BIASLUT) ? biaslut_eval(L, lut_n, fmaxf(x32, 0.0f), gain, sigma)
+                                                              : lut_eval(L, lut_n, fmaxf(x32, 0.0f));
                 u = (float)((v - lo) * inv_span);                       // (v - lo) / (hi - lo) to one float64 ulp, then ONE rounding
             }
             u = fminf(fmaxf(u, 0.0f), 1.0f);
@@ -170,10 +204,9 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
     }
 }
 
-extern "C" int yond_pack_vst_norm_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t,
-                                      int pad_b, int mode, double scale, double gain, double sigma, double lo,
-                                      double hi, const double* lut_x, const float* lut_y, int lut_n, float* img_max,
-                                      void* stream) {
+static int launch_pack_vst(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b, int mode,
+                           double scale, double gain, double sigma, double lo, double hi, const double* lut_x, const void* lut_y,
+                           int lut_n, int lut_flags, float* img_max, void* stream) {
     if (!bayer || !out || H < 2 || W < 2 || (H & 1) || (W & 1)) return YOND_EINVAL;
     if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0) return YOND_EINVAL;
     if (mode != 0 && mode != 1) return YOND_EINVAL;
@@ -196,7 +229,56 @@ extern "C" int yond_pack_vst_norm_f32(const float* bayer, int H, int W, float* o
     }
     const int use_lut = mode == 1 ? lut_n : 0;
     hipLaunchKernelGGL(pack_vst_norm_kernel, dim3((unsigned)nb), dim3(256), (size_t)use_lut * LUT_BYTES_PER_KNOT, st, bayer, H, W, out,
-                       pad_l, pad_t, Hp, Wp, mode, (float)scale, gain, sigma, lo, hi, lut_x, lut_y, use_lut, (unsigned int*)img_max);
+                       pad_l, pad_t, Hp, Wp, mode, (float)scale, gain, sigma, lo, hi, lut_x, lut_y, use_lut, lut_flags, (unsigned int*)img_max);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_pack_vst_norm_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t,
+                                      int pad_b, int mode, double scale, double gain, double sigma, double lo,
+                                      double hi, const double* lut_x, const float* lut_y, int lut_n, float* img_max,
+                                      void* stream) {
+    return launch_pack_vst(bayer, H, W, out, pad_l, pad_r, pad_t, pad_b, mode, scale, gain, sigma, lo, hi, lut_x, lut_y, lut_n, 0,
+                           img_max, stream);
+}
+
+extern "C" int yond_pack_vst_norm_biaslut_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t,
+                                              int pad_b, double scale, double gain, double sigma, double lo, double hi,
+                                              const double* lut_x, const double* lut_y, int lut_n, float* img_max, void* stream) {
+    if (lut_n < 2) return YOND_EINVAL;
+    return launch_pack_vst(bayer, H, W, out, pad_l, pad_r, pad_t, pad_b, 1, scale, gain, sigma, lo, hi, lut_x, lut_y, lut_n,
+                           LUT_Y64 | LUT_BIASLUT, img_max, stream);
+}
+
+// the LUT alone, per element (function seam: the interp1d object of get_bias / BiasLUT.get_lut called on an array)
+__global__ __launch_bounds__(256) void bias_eval_kernel(const float* __restrict__ x, size_t n, const double* __restrict__ lut_x,
+                                                        const void* __restrict__ lut_y, int lut_n, int lut_flags, double gain,
+                                                        double sigma, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lut_raw[];
+    __shared__ LutLds L;
+    if (threadIdx.x == 0) {
+        L.ab = (double2*)lut_raw;
+        L.x = (double*)(L.ab + lut_n);
+    }
+    __syncthreads();
+    lut_prepare(L, lut_x, lut_y, lut_n, lut_flags);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (lut_flags & LUT_BIASLUT) ? biaslut_eval(L, lut_n, x[i], gain, sigma) : lut_eval(L, lut_n, x[i]);
+}
+
+extern "C" int yond_bias_eval_f32(const float* x, size_t n, const double* lut_x, const void* lut_y, int lut_n, int y_is_f64,
+                                  int biaslut, double gain, double sigma, double* out, void* stream) {
+    if (!x || !out || !lut_x || !lut_y || n == 0 || lut_n < 2 || lut_n > LUT_MAX) return YOND_EINVAL;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)bias_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_MAX * LUT_BYTES_PER_KNOT);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    size_t nb = (n + 255) / 256;
+    if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(bias_eval_kernel, dim3((unsigned)nb), dim3(256), (size_t)lut_n * LUT_BYTES_PER_KNOT, (hipStream_t)stream, x, n,
+                       lut_x, lut_y, lut_n, (y_is_f64 ? LUT_Y64 : 0) | (biaslut ? LUT_BIASLUT : 0), gain, sigma, out);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -134,9 +134,88 @@ class DeviceBiasLUT:
     def __len__(self):
         return int(self.x.numel())
 
-    def __call__(self, *a, **k):
-        raise L.YondHipError("the bias LUT is evaluated per pixel inside yond_pack_vst_norm_f32 (VST_Denoiser); "
-                             "use .x / .y for the knots")
+    def __call__(self, x):
+        """The interp1d object called on an array (utils/isp_algos.py:128): float64 biases on the device.  (The hot path
+        evaluates the LUT per pixel inside yond_pack_vst_norm_f32 instead.)"""
+        xd = _dev(x, self.x.device).reshape(-1)
+        out = torch.empty(xd.numel(), dtype=torch.float64, device=xd.device)
+        L.check(L.load().yond_bias_eval_f32(L.ptr(xd), xd.numel(), L.ptr(self.x), L.ptr(self.y), len(self), 0, 0, 1.0, 0.0,
+                                            L.ptr(out), L.stream()), "yond_bias_eval_f32")
+        return out.reshape(tuple(np.shape(x)))
+
+
+class BiasLUT:
+    """utils/isp_algos.py:162-231: the precomputed 2-D bias table (x in e-, sigma in e-), `get_lut(x, K, sigGs)` per pixel.
+    lut_path: the reference's checkpoints/bias_lut_2d.npy ((x_len, sg_len) on the grids of :168-177); or pass `table`
+    with its own `x_lut` / `sg_lut` grids.  The table stays on the host (two rows are merged per (K, sigma) on the host,
+    :188-194); the merged row is evaluated per pixel on the device (K1 / yond_bias_eval_f32)."""
+
+    def __init__(self, lut_path='checkpoints/bias_lut_2d.npy', table=None, x_lut=None, sg_lut=None):
+        self.bias_lut = np.load(lut_path) if table is None else np.asarray(table)
+        sp = 128
+        self.x_lut = np.asarray(x_lut, np.float64) if x_lut is not None else np.concatenate((
+            np.linspace(0, 2 ** -4, sp, endpoint=False), np.exp(np.linspace(np.log(2 ** (-4)), np.log(2 ** 10), 14 * sp + 1))))
+        self.sg_lut = np.asarray(sg_lut, np.float64) if sg_lut is not None else np.concatenate((
+            np.linspace(0, 1, 200, endpoint=False), np.linspace(1, 10, 901)))
+        if self.bias_lut.size != len(self.x_lut) * len(self.sg_lut):
+            raise L.YondHipError(f"bias table of {self.bias_lut.size} entries does not match the {len(self.x_lut)} x {len(self.sg_lut)} grid")
+        if len(self.x_lut) > 4096:
+            raise L.YondHipError("the kernels hold at most 4096 LUT knots")
+
+    def pos_interp(self, data, x):                                   # :179-186
+        data = np.concatenate(([-np.inf, ], data))
+        idx = np.searchsorted(data, x).clip(0, len(data) - 1)
+        with np.errstate(invalid='ignore'):
+            return idx - (data[idx] - x) / (data[idx] - data[idx - 1]) - 1
+
+    def row(self, K, sigGs, device=None):
+        """The 1-D LUT for (K, sigGs): (knots in DN float64, ordinates float64) on the device, or None when sigma / K lies
+        outside the table (:204-212: the caller falls back to get_bias)."""
+        sg = np.float64(sigGs) / np.float64(K)
+        sg_pos = self.pos_interp(self.sg_lut, sg)
+        sg_len = len(self.sg_lut)
+        if sg_pos >= sg_len:
+            return None
+        pos = np.clip(sg_pos, 0, len(self.x_lut) - 1)                  # :189 (clips with len(x_lut) on this axis too)
+        l, r = int(np.floor(pos)), int(np.ceil(pos))
+        wr = pos - l
+        tab = self.bias_lut.reshape(-1, sg_len)
+        data = tab[:, l] * (1 - wr) + tab[:, r] * wr                  # :194
+        dev = torch.device(device if device is not None else 'cuda')
+        return DeviceBiasRow(torch.from_numpy(np.ascontiguousarray(self.x_lut * np.float64(K))).to(dev),
+                             torch.from_numpy(np.ascontiguousarray(data, np.float64)).to(dev), float(K), float(sigGs))
+
+    def get_lut(self, x, K=1, sigGs=2, func=False, device=None):
+        """:196-231 with func=False: biases (float64, on the device) of an array of DN values."""
+        if func:
+            raise NotImplementedError("BiasLUT.get_lut(func=True) is not used by YOND_SIDD.py")
+        dev = x.device if isinstance(x, torch.Tensor) and x.is_cuda else device
+        row = self.row(K, sigGs, dev)
+        if row is None:                                                # sigma outside the table: the 1-D construction (:207-209)
+            if int(np.prod(np.shape(x))) <= 1000:
+                raise L.YondHipError("BiasLUT.get_lut outside the sigma grid on <= 1000 points: the reference evaluates "
+                                     "get_bias_points pointwise with pho_min=100 there (:210-212), which is not built; "
+                                     "images (> 1000 pixels) take the get_bias branch, as here")
+            mx = x.max().item() if isinstance(x, torch.Tensor) else np.max(x)
+            return get_bias(np.float32(mx), sigGs, K, device=dev)(x)
+        return row(x)
+
+
+class DeviceBiasRow:
+    """One (K, sigma) row of the 2-D table on the device; K1 evaluates it per pixel (yond_pack_vst_norm_biaslut_f32)."""
+
+    def __init__(self, x_dev, y_dev, K, sigma):
+        self.x, self.y, self.K, self.sigma = x_dev, y_dev, K, sigma
+
+    def __len__(self):
+        return int(self.x.numel())
+
+    def __call__(self, x):
+        xd = _dev(x, self.x.device).reshape(-1)
+        out = torch.empty(xd.numel(), dtype=torch.float64, device=xd.device)
+        L.check(L.load().yond_bias_eval_f32(L.ptr(xd), xd.numel(), L.ptr(self.x), L.ptr(self.y), len(self), 1, 1, self.K, self.sigma,
+                                            L.ptr(out), L.stream()), "yond_bias_eval_f32")
+        return out.reshape(tuple(np.shape(x)))
 
 
 def get_bias(img=None, sigGs=25.853043, K=24.48128, device=None):
@@ -447,7 +526,7 @@ class _Guard:
 
 
 def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type='exact', clip01=False, device=None,
-                 lr_max=None, guard=True, guard_slot=0):
+                 lr_max=None, guard=True, guard_slot=0, biaslut=None):
     """YOND_SIDD.py:250-299 for the network denoisers.  lr_raw: Bayer [H][W] -- or a stack [B][H][W] of equally
     sized frames that go through ONE batched forward instead of B batch-1 calls: the 32 blocks of a SIDD image, which
     share (gain, sigma) and the bias LUT (:392-407), or B independent frames (BASELINE cfg 4), for which `p`,
@@ -471,8 +550,12 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
         raise NotImplementedError(f"bias_corr={bias_corr!r} (the reference's 'post' branch is commented out)")
     funcs = list(bias_func) if isinstance(bias_func, (list, tuple)) else [bias_func] * B
     maxes = list(lr_max) if isinstance(lr_max, (list, tuple)) else [lr_max] * B
+    if bias_corr is not None and biaslut is not None:                 # :258-259: the 2-D table instead of get_bias
+        for i in range(B):
+            if funcs[i] is None:
+                funcs[i] = biaslut.row(ps[i]['gain'], ps[i]['sigma'], lr.device)    # None: sigma outside -> get_bias below
     if bias_corr is not None and any(f is None for f in funcs):
-        if not (single or per_frame):
+        if not (single or per_frame or biaslut is not None):
             raise L.YondHipError("a stack of frames needs the shared bias LUT (the reference builds one per image, :392-397)")
         for i in range(B):
             if funcs[i] is None:
@@ -493,6 +576,11 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
             t_host.append(float(np.float32(1 / (upper - lower) * (1.03 if bias_corr == 'pre' else 1.00))))   # :284-285
             f = funcs[i]
             lut_n = len(f) if bias_corr is not None else 0
+            if lut_n and isinstance(f, DeviceBiasRow):
+                L.check(lib.yond_pack_vst_norm_biaslut_f32(L.ptr(lr[i]), H, W, L.ptr(x4[i]), p2d[0], p2d[1], p2d[2], p2d[3], scale,
+                                                           float(gain), float(sigma), float(lower), float(upper), L.ptr(f.x),
+                                                           L.ptr(f.y), lut_n, L.ptr(img_max[i:i + 1]), st), "yond_pack_vst_norm_biaslut_f32")
+                continue
             L.check(lib.yond_pack_vst_norm_f32(L.ptr(lr[i]), H, W, L.ptr(x4[i]), p2d[0], p2d[1], p2d[2], p2d[3], 1, scale,
                                                float(gain), float(sigma), float(lower), float(upper),
                                                L.ptr(f.x) if lut_n else None, L.ptr(f.y) if lut_n else None, lut_n,
@@ -577,7 +665,7 @@ def default_params():
     return p
 
 
-def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=None):
+def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=None, biaslut=None):
     """Round 1: self-calibrated NLE -> VST -> denoise -> inverse VST; round 2 (pipe['iter']=='iter'):
     collaborative NLE from (noisy, denoised) -> guards -> second pass.  lr_raw: the SIDD layout [32][256][256]
     (denoised block by block, or -- pipe['full_dn'] -- as its 256 x 8192 concatenation, :387-389) or one Bayer
@@ -622,16 +710,22 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
 
     def denoise_all(bias_func):
         if full_dn:                                                                    # :387-389
-            return VST_Denoiser(lr_cat, p, net, arch, bias_corr, bias_func, vst_type, clip01=True, lr_max=lr_max)
+            return VST_Denoiser(lr_cat, p, net, arch, bias_corr, bias_func, vst_type, clip01=True, lr_max=lr_max, biaslut=biaslut)
         if bias_corr is not None:
-            outs = VST_Denoiser(blocks, p, net, arch, bias_corr, bias_func, vst_type, clip01=True)   # one batch-32 forward
+            outs = VST_Denoiser(blocks, p, net, arch, bias_corr, bias_func, vst_type, clip01=True, biaslut=biaslut)   # one batch-32 forward
         else:                                  # no shared LUT: per-block calls as the reference does (:398-407)
             outs = [VST_Denoiser(blocks[num], p, net, arch, bias_corr, bias_func, vst_type, clip01=True) for num in range(32)]
         return torch.cat(list(outs), dim=-1).contiguous()                              # :408
 
+    def shared_lut():
+        """:392-397 / :450-454: with the 2-D table (self.biaslut) no per-image LUT is built; outside the table get_bias is"""
+        if biaslut is not None and biaslut.row(p['gain'], p['sigma'], lr.device) is not None:
+            return None
+        return get_bias(lr_max * scale, p['sigma'], p['gain'], device=lr.device)
+
     bias_func = None
     if sidd and bias_corr is not None:
-        bias_func = get_bias(lr_max * scale, p['sigma'], p['gain'], device=lr.device)  # :393-395
+        bias_func = shared_lut()                                                       # :393-395
     raw_dn = denoise_all(bias_func)
     raw_dns = [raw_dn]
 
@@ -646,7 +740,7 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
                 log(f"Iter {epoch} Est: K={p['gain']:.4f}, sigma={p['sigma']:.4f} (beta1={reg[0]:.3e}, beta2={reg[1]:.3e})")
             if reg[0] < 0:                                                             # :445-447
                 break
-            bias_func = get_bias(lr_max * scale, p['sigma'], p['gain'], device=lr.device)   # :450-452
+            bias_func = shared_lut()                                                   # :450-454
             raw_dn = denoise_all(bias_func)
             raw_dns.append(raw_dn)
             regs.append(reg)

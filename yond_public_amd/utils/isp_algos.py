@@ -10,7 +10,7 @@ import torch
 
 from .. import _lib as L
 from .. import pipeline as _P
-from ..pipeline import get_bias, DeviceBiasLUT  # noqa: F401  (utils/isp_algos.py:98-140)
+from ..pipeline import get_bias, DeviceBiasLUT, BiasLUT  # noqa: F401  (utils/isp_algos.py:98-140, 162-231)
 
 
 def _is_scalar(x):

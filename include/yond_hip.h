@@ -85,6 +85,10 @@ int yond_ivst_elem_f64(const double* z, size_t n, double sigma, double gain, int
 int yond_bayer2rggb_f32(const float* bayer, int H, int W, float* rggb /*[H/2][W/2][4]*/, void* stream);
 int yond_rggb2bayer_f32(const float* rggb, int h, int w, float* bayer /*[2h][2w]*/, void* stream);
 
+/* np.rot90(x, k, axes=(-2, -1)) on a stack [N][H][W] -> [N][H'][W'] (rot_bayer: utils/sidd_utils.py:198-213, used around
+ * the denoiser when the runfile sets rot_cfa, YOND_SIDD.py:402-404, 462-464), bit exact. */
+int yond_rot90_f32(const float* src, int N, int H, int W, int k, float* dst, void* stream);
+
 /* Layout helpers for the archs plugin surface (NCHW tensors in, NCHW out; C == 4). */
 int yond_nchw4_to_nhwc4_f32(const float* src, float* dst, int N, int H, int W, void* stream);
 int yond_nhwc4_to_nchw4_f32(const float* src, float* dst, int N, int H, int W, void* stream);

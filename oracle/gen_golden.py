@@ -323,7 +323,45 @@ def gen_ssim(ref):
     save("ssim", **out)
 
 
-GENS = dict(pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
+def gen_rot(ref):
+    """N3: rot_bayer (utils/sidd_utils.py:198-213) for the four CFA patterns, and IterDenoise with p['rot_cfa'] set
+    (YOND_SIDD.py:402-404, 462-464: every block turned to RGGB around the denoiser) on a GBRG image."""
+    out = {}
+    a = np.arange(6 * 8, dtype=np.float32).reshape(6, 8)
+    pats = [[[1, 2], [2, 3]], [[2, 1], [3, 2]], [[2, 3], [1, 2]], [[3, 2], [2, 1]]]
+    for i, pat in enumerate(pats):
+        out[f"pat_{i}"] = np.array(pat)
+        out[f"fwd_{i}"] = np.ascontiguousarray(ref.rot_bayer(a, pat))
+        out[f"rev_{i}"] = np.ascontiguousarray(ref.rot_bayer(a, pat, rev=True))
+    out["a"] = a
+    K, s = 2.0, 20.0
+    noisy, clean = O.synth_noisy(256, 8192, K, s, 31)
+    full, _ = O.synth_noisy(512, 1024, K, s, 32)
+    tmp = tempfile.mkdtemp()
+    full_path = os.path.join(tmp, "full.npy")
+    np.save(full_path, full)
+    pipe = {'data_type': 'SIDD', 'full_est': True, 'est_type': 'simple+full', 'k': 29, 'vst_type': 'exact',
+            'bias_corr': 'pre', 'denoiser_type': 'gru32n', 'iter': 'iter', 'max_iter': 1, 'clip': False, 'full_dn': False}
+    obj, sd = fake_self(ref, ARCHS["gru8"], 81, pipe)
+    sd = O.denoising_state_dict(ARCHS["gru8"], 81)
+    obj.net = ref.load_weights(obj.net, sd, by_name=False).eval()
+    p = dict(pipe)
+    p.update({'K': 8.74253, 'sigGs': 12.81, 'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0, 'rot_cfa': True,
+              'cfa': [[2, 1], [3, 2]]})
+    p['scale'] = (p['wp'] - p['bl']) / p['ratio']
+    data = {'lr_path_full': full_path, 'lr': np.array(np.split(noisy, 32, axis=-1)),
+            'hr': np.array(np.split(clean, 32, axis=-1)), 'meta': None, 'name': 'synthetic_000'}
+    res = obj.IterDenoise(data, {'p': p, 'img_id': 0})
+    out["regs"] = np.array([np.asarray(r, np.float64) for r in res['regs']])
+    out["nout"] = np.array(len(res['raw_dns']))
+    for it, dn in enumerate(res['raw_dns']):
+        a_, b_, c_ = iter_crop(dn)
+        out[f"dn_{it}_blk"], out[f"dn_{it}_seam"], out[f"dn_{it}_sub"] = a_, b_, c_
+        out[f"dn_{it}_chk"] = checks(dn)
+    save("rot", **out)
+
+
+GENS = dict(rot=gen_rot, pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
             vst_denoiser=gen_vst_denoiser, iter=gen_iter, biaslut=gen_biaslut, ssim=gen_ssim)
 
 if __name__ == "__main__":

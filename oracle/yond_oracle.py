@@ -794,6 +794,15 @@ def default_params():
     return p
 
 
+def rot_bayer(image, bayer_pattern, rev=False, axis=(-2, -1)):
+    """utils/sidd_utils.py:198-213: quarter turns that bring the CFA pattern (1=R 2=G 3=B) to RGGB."""
+    pat = np.asarray(bayer_pattern).reshape(2, 2).tolist()
+    k = {str([[1, 2], [2, 3]]): 0, str([[2, 1], [3, 2]]): 3, str([[2, 3], [1, 2]]): 1, str([[3, 2], [2, 1]]): 2}[str(pat)]
+    if rev:
+        k = (4 - k) % 4
+    return np.rot90(image, k=k, axes=axis)
+
+
 def IterDenoise(lr_raw, arch, sd, pipe, lr_full=None, p=None):
     """lr_raw: the SIDD layout (32, 256, 256) (denoised block by block, or as the 256 x 8192 concatenation
     when pipe['full_dn']) or one (H, W) Bayer frame (needs pipe['full_dn']).
@@ -828,7 +837,11 @@ def IterDenoise(lr_raw, arch, sd, pipe, lr_full=None, p=None):
             return VST_Denoiser(lr_cat, p, arch, sd, bias_corr, bias_func, vst_type).clip(0, 1)
         out = np.empty((32, 256, 256), np.float32)                                # :391
         for num in range(32):                                                     # :398-407
-            out[num] = VST_Denoiser(blocks[num], p, arch, sd, bias_corr, bias_func, vst_type).clip(0, 1)
+            if 'rot_cfa' in p:                                                    # :402-404 / :462-464
+                out[num] = rot_bayer(VST_Denoiser(rot_bayer(blocks[num], p['cfa']), p, arch, sd, bias_corr, bias_func,
+                                                  vst_type).clip(0, 1), p['cfa'], rev=True)
+            else:
+                out[num] = VST_Denoiser(blocks[num], p, arch, sd, bias_corr, bias_func, vst_type).clip(0, 1)
         return np.concatenate(out, axis=-1)
 
     bias_func = None

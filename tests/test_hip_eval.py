@@ -137,3 +137,67 @@ def test_two_rank_rccl_metric_reduction(tmp_path):
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
     assert r["t"] == 2.0 and r["red"]["count"] == 7
     assert abs(r["red"]["psnr_last"] - sum(41.0 + k for k in range(7)) / 7) < 1e-12
+
+
+def test_rot90_kernel_and_rot_cfa_pipeline(golden):
+    """N3: the rot90 copy kernel (bit exact vs np.rot90) and IterDenoise with p['rot_cfa'] (YOND_SIDD.py:402-404, 462-464)
+    against the reference's own run on a GBRG image (tests/golden/rot.npz)."""
+    from test_oracle_golden import rot_case, iter_crop
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    from yond_public_amd.utils.sidd_utils import rot_bayer
+    rng = np.random.default_rng(1)
+    x = rng.random((3, 10, 14)).astype(np.float32)
+    for k in range(4):
+        assert np.array_equal(P.rot90(torch.from_numpy(x).to(DEV), k).cpu().numpy(), np.rot90(x, k, axes=(-2, -1)))
+    t = torch.from_numpy(x[0]).to(DEV)
+    assert np.array_equal(rot_bayer(t, [[2, 3], [1, 2]]).cpu().numpy(), np.rot90(x[0], 1))
+    g = golden("rot")
+    lr, full, arch, sd, pipe, p = rot_case()
+    net = A.GuidedResUnet(dict(arch))
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    res = P.IterDenoise(lr, net, arch, pipe, lr_full=full, p=p, device=DEV)
+    assert len(res['raw_dns']) == int(g["nout"]) == 2
+    for r, gr in zip(res['regs'], g["regs"]):
+        np.testing.assert_allclose(r[0], gr[0], rtol=2e-5)
+    for it, dn in enumerate(res['raw_dns']):
+        for got, tag in zip(iter_crop(dn.cpu().numpy()), ("blk", "seam", "sub")):
+            assert report(f"rot_cfa IterDenoise iter {it} {tag}", got, g[f"dn_{it}_{tag}"]) <= 1e-4
+
+
+def test_eval_on_a_mat_tree_in_the_reference_layout(tmp_path, monkeypatch):
+    """`YOND_SIDD.py -m eval` on SIDD_Validation_Raw/*.mat (MATLAB v5, written here) + SIDD_Benchmark_Data metadata: the
+    loader feeds the driver, the CFA of the metadata reaches p['cfa'], metrics come out per image."""
+    import scipy.io as sio
+    import yaml
+    import yond_oracle as O
+    from yond_public_amd import YOND_SIDD as Y
+    root = tmp_path / "SIDD"
+    vr = root / "SIDD_Validation_Raw"
+    vr.mkdir(parents=True)
+    lrs, hrs = [], []
+    for i in range(2):
+        noisy, clean = O.synth_noisy(256, 8192, 3.0 + i, 12.0, 300 + i)
+        lrs.append(np.array(np.split(noisy, 32, axis=-1)))
+        hrs.append(np.array(np.split(clean, 32, axis=-1)))
+    sio.savemat(vr / "ValidationNoisyBlocksRaw.mat", {"ValidationNoisyBlocksRaw": np.array(lrs)})
+    sio.savemat(vr / "ValidationGtBlocksRaw.mat", {"ValidationGtBlocksRaw": np.array(hrs)})
+    cfg = yaml.load(open(RUNFILE), Loader=yaml.FullLoader)
+    for key in ('dst', 'dst_eval', 'dst_test'):
+        cfg[key]['root_dir'] = str(root)
+    cfg['arch']['nf'] = 8
+    rf = tmp_path / "mat.yml"
+    rf.write_text(yaml.dump(cfg))
+    monkeypatch.chdir(tmp_path)
+    trainer = Y.YOND_SIDD(['-f', str(rf), '-m', 'eval'])
+    assert type(trainer.dst_eval).__name__ == 'SIDD_Dataset' and len(trainer.dst_eval) == 2
+    red = trainer.eval(-1)
+    assert red['count'] == 2 and red['psnr_iter0'] > 20 and len(trainer.metrics) == 2
+    arch = dict(trainer.arch)
+    torch.set_num_threads(8)
+    ref = O.IterDenoise(lrs[0], arch, O.denoising_state_dict(arch, 0), dict(trainer.pipe))
+    m = trainer.metrics['sidd_0000']
+    for it in range(len(ref['raw_dns'])):
+        ps, ss = O.sidd_block_metrics(ref['raw_dns'][it], np.concatenate(hrs[0], axis=-1))
+        assert abs(ps - m['psnr'][it]) < 2e-3 and abs(ss - m['ssim'][it]) < 2e-5

@@ -246,3 +246,35 @@ def test_ssim_against_reference_arithmetic(golden):
         dn = np.clip(clean + 0.3 * (noisy - clean), 0, 1).astype(np.float32)
         vals = [O.ssim(a * 255, b * 255) for a, b in zip(np.split(dn, 2, axis=-1), np.split(clean, 2, axis=-1))]
         np.testing.assert_allclose(vals, g[f"ssim_{ci}"], rtol=1e-12)
+
+
+def rot_case():
+    K, s = 2.0, 20.0
+    noisy, clean = O.synth_noisy(256, 8192, K, s, 31)
+    full, _ = O.synth_noisy(512, 1024, K, s, 32)
+    arch = ARCHS["gru8"]
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': False}
+    p = dict(O.default_params(), rot_cfa=True, cfa=[[2, 1], [3, 2]])
+    return np.array(np.split(noisy, 32, axis=-1)), full, arch, O.denoising_state_dict(arch, 81), pipe, p
+
+
+def test_rot_bayer_and_rot_cfa_pipeline(golden):
+    """N3: rot_bayer for the four CFA patterns, and IterDenoise with p['rot_cfa'] (YOND_SIDD.py:402-404, 462-464) against
+    the reference's own run."""
+    from yond_public_amd.utils.sidd_utils import rot_bayer, rot_k
+    g = golden("rot")
+    a = g["a"]
+    for i in range(4):
+        pat = g[f"pat_{i}"].tolist()
+        assert np.array_equal(O.rot_bayer(a, pat), g[f"fwd_{i}"]) and np.array_equal(O.rot_bayer(a, pat, rev=True), g[f"rev_{i}"])
+        assert np.array_equal(rot_bayer(a, pat), g[f"fwd_{i}"]) and np.array_equal(rot_bayer(a, pat, rev=True), g[f"rev_{i}"])
+        assert (rot_k(pat) + rot_k(pat, rev=True)) % 4 == 0
+    lr, full, arch, sd, pipe, p = rot_case()
+    torch.set_num_threads(8)
+    res = O.IterDenoise(lr, arch, sd, pipe, lr_full=full, p=p)
+    assert len(res['raw_dns']) == int(g["nout"]) == 2
+    for r, gr in zip(res['regs'], g["regs"]):
+        np.testing.assert_allclose(r[0], gr[0], rtol=1e-5)
+    for it, dn in enumerate(res['raw_dns']):
+        for got, tag in zip(iter_crop(dn), ("blk", "seam", "sub")):
+            np.testing.assert_allclose(got, g[f"dn_{it}_{tag}"], rtol=0, atol=2e-5)

@@ -9,10 +9,11 @@ are the point of this build: every per-pixel pass runs on the MI355X HIP kernels
 GPU process (image k -> rank k mod world) instead of nn.DataParallel over batch 1; per-block PSNR/SSIM are
 computed on the device and reduced with ONE all-reduce at the end.
 
-Datasets: SIDD validation blocks are read from `<root_dir>/npy/{noisy,gt}_{k:03d}.npy` ((32,256,256) float32 in
-[0,1], plus optional `full_{k:03d}.npy`) when present; `.mat` / DNG ingestion is the reference's
-data_process/ (out of scope).  Without data the driver evaluates seeded synthetic
-stand-ins so the whole control flow can be exercised and timed.
+Datasets: the reference's SIDD layout (`<root_dir>/SIDD_Validation_Raw/Validation{Noisy,Gt}BlocksRaw.mat`, MATLAB v5, plus
+`SIDD_Benchmark_Data/*/*_010.MAT` metadata: yond_public_amd/data.py mirrors data_process/yond_datasets.py:767-868), or
+`<root_dir>/npy/{noisy,gt}_{k:03d}.npy` ((32,256,256) float32 in [0,1], plus optional `full_{k:03d}.npy`); DNG / ARW and
+MATLAB v7.3 need rawpy / h5py, which this image lacks.  Without data the driver evaluates seeded synthetic stand-ins so
+the whole control flow can be exercised and timed.
 """
 import argparse
 import os
@@ -118,7 +119,12 @@ class YOND_SIDD:
     def change_eval_dst(self, mode='eval'):
         self.dst = self.args[f'dst_{mode}']
         root = os.path.join(self.dst['root_dir'], 'npy')
-        if os.path.isdir(root) and list(Path(root).glob('noisy_*.npy')):
+        mat = os.path.join(self.dst['root_dir'], 'SIDD_Validation_Raw',
+                           'ValidationNoisyBlocksRaw.mat' if mode == 'eval' else 'BenchmarkNoisyBlocksRaw.mat')
+        if os.path.exists(mat):                       # the reference's layout (data_process/yond_datasets.py:797-806)
+            from .data import SIDD_Dataset
+            self.dst_eval = SIDD_Dataset(dict(self.dst, mode=mode))
+        elif os.path.isdir(root) and list(Path(root).glob('noisy_*.npy')):
             self.dst_eval = NpySIDD(root)
         else:
             self.dst_eval = SyntheticSIDD(self.parser.synthetic)
@@ -153,6 +159,7 @@ class YOND_SIDD:
         t0 = time.perf_counter()
         for k in mine:
             data = self.dst_eval[k]
+            p['cfa'] = data.get('cfa', [[1, 2], [2, 3]])                                # YOND_SIDD.py:510
             res = self.IterDenoise(data, {'p': p, 'img_id': k})
             psnrs, ssims = [], []
             if res['hr_raw'] is not None:

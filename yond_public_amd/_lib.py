@@ -42,6 +42,7 @@ PROTOTYPES = {
     "yond_ivst_elem_f64": [vp, sz, f64, f64, i32, vp, vp],
     "yond_bayer2rggb_f32": [vp, i32, i32, vp, vp],
     "yond_rggb2bayer_f32": [vp, i32, i32, vp, vp],
+    "yond_rot90_f32": [vp, i32, i32, i32, i32, vp, vp],
     "yond_nchw4_to_nhwc4_f32": [vp, vp, i32, i32, i32, vp],
     "yond_nhwc4_to_nchw4_f32": [vp, vp, i32, i32, i32, vp],
     "yond_image_max_f32": [vp, i32, sz, vp, vp, vp],

@@ -502,3 +502,30 @@ extern "C" int yond_ivst_elem_f64(const double* z, size_t n, double sigma, doubl
 }
 
 extern "C" int yond_abi_version(void) { return 1; }
+
+// ---- rot90 of a stack of frames (np.rot90(x, k, axes=(-2, -1)): utils/sidd_utils.py:198-213 rot_bayer), bit exact ----
+// dst[n][i][j] (H' x W' = W x H for odd k): k=1: src[j][W-1-i]; k=2: src[H-1-i][W-1-j]; k=3: src[H-1-j][i]
+__global__ __launch_bounds__(256) void rot90_kernel(const float* __restrict__ src, int H, int W, int k, float* __restrict__ dst,
+                                                    size_t per, size_t total) {
+    const int Ho = (k & 1) ? W : H, Wo = (k & 1) ? H : W;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        const size_t n = p / per;
+        const int r = (int)(p % per), i = r / Wo, j = r % Wo;
+        int sy, sx;
+        if (k == 0) { sy = i; sx = j; }
+        else if (k == 1) { sy = j; sx = W - 1 - i; }
+        else if (k == 2) { sy = H - 1 - i; sx = W - 1 - j; }
+        else { sy = H - 1 - j; sx = i; }
+        (void)Ho;
+        dst[p] = src[n * per + (size_t)sy * W + sx];
+    }
+}
+
+extern "C" int yond_rot90_f32(const float* src, int N, int H, int W, int k, float* dst, void* stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0) return YOND_EINVAL;
+    k = ((k % 4) + 4) % 4;
+    const size_t per = (size_t)H * W, total = per * N;
+    hipLaunchKernelGGL(rot90_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, src, H, W, k, dst, per, total);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}

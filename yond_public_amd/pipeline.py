@@ -74,6 +74,17 @@ def rggb2bayer(rggb, device=None):
     return out
 
 
+def rot90(x, k):
+    """np.rot90(x, k, axes=(-2, -1)) of a device tensor [.., H, W] (bit exact copy kernel)."""
+    x = _dev(x)
+    H, W = x.shape[-2:]
+    n = x.numel() // (H * W)
+    k = k % 4
+    out = torch.empty(x.shape[:-2] + ((W, H) if k & 1 else (H, W)), dtype=torch.float32, device=x.device)
+    L.check(L.load().yond_rot90_f32(L.ptr(x), n, H, W, k, L.ptr(out), L.stream()), "yond_rot90_f32")
+    return out
+
+
 def get_p2d(shape, base=16):
     """utils/utils.py:246-252."""
     xb, xc, xh, xw = shape
@@ -682,6 +693,10 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     vst_type = pipe.get('vst_type', 'exact')
     scale = p['wp'] - p['bl']
     regs, params = [], []
+    rot_k_ = 0
+    if 'rot_cfa' in p and not full_dn:         # YOND_SIDD.py:402, 462 (the block-wise branch only)
+        from .utils.sidd_utils import rot_k
+        rot_k_ = rot_k(p['cfa'])
     lr = _dev(lr_raw, device)
     stack = lr.dim() == 3                      # the SIDD layout, as YOND_SIDD.eval hands it over (:507-514)
     if stack:
@@ -711,10 +726,15 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     def denoise_all(bias_func):
         if full_dn:                                                                    # :387-389
             return VST_Denoiser(lr_cat, p, net, arch, bias_corr, bias_func, vst_type, clip01=True, lr_max=lr_max, biaslut=biaslut)
+        blk = blocks
+        if rot_k_:                             # :402-404 / :462-464: every block turned to RGGB around the denoiser
+            blk = rot90(blocks, rot_k_)
         if bias_corr is not None:
-            outs = VST_Denoiser(blocks, p, net, arch, bias_corr, bias_func, vst_type, clip01=True, biaslut=biaslut)   # one batch-32 forward
+            outs = VST_Denoiser(blk, p, net, arch, bias_corr, bias_func, vst_type, clip01=True, biaslut=biaslut)   # one batch-32 forward
         else:                                  # no shared LUT: per-block calls as the reference does (:398-407)
-            outs = [VST_Denoiser(blocks[num], p, net, arch, bias_corr, bias_func, vst_type, clip01=True) for num in range(32)]
+            outs = torch.stack([VST_Denoiser(blk[num], p, net, arch, bias_corr, bias_func, vst_type, clip01=True) for num in range(32)])
+        if rot_k_:
+            outs = rot90(outs, 4 - rot_k_)
         return torch.cat(list(outs), dim=-1).contiguous()                              # :408
 
     def shared_lut():

@@ -123,3 +123,60 @@ def test_denoise_stream_matches_iterdenoise():
         assert np.allclose(np.asarray(a_['regs'], np.float64), np.asarray(b_['regs'], np.float64), rtol=1e-10, atol=0)
         assert np.allclose(np.asarray(a_['params'], np.float64), np.asarray(b_['params'], np.float64), rtol=1e-10, atol=0)
         assert float((a_['raw_dns'][0] - b_['raw_dns'][0]).abs().max()) <= 5e-6      # two IterDenoise runs differ by up to 1e-6 themselves
+
+
+def test_cfg4_unet_batch8_full_size():
+    """BASELINE cfg 4 at its real shape: UNetSeeInDark, batch 8 of 3000 x 4000 frames (packed, padded 1504 x 2016) in ONE
+    forward; every item equals its batch-1 forward bit for bit (no cross-item coupling, deterministic tile arithmetic)."""
+    from yond_public_amd import pipeline as P
+    arch = ARCHS["unet32"]
+    net, _ = make_net(arch, 2)
+    plan = P._plan_of(net, torch.device(DEV))
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.rand((8, 1504, 2016, 4), device=DEV, generator=g) * 0.9
+    ub = x.reshape(8, -1).max(dim=1).values.contiguous()
+    y = plan.forward_nhwc4(x, None, ub=ub)
+    torch.cuda.synchronize()
+    assert y.shape == x.shape and bool(torch.isfinite(y).all())
+    for i in (0, 3, 7):
+        yi = plan.forward_nhwc4(x[i:i + 1].contiguous(), None, ub=ub[i:i + 1].contiguous())
+        assert torch.equal(yi[0], y[i]), float((yi[0] - y[i]).abs().max())
+    # the batched full-frame driver on two of these sizes' worth of Bayer frames (per-frame estimates, one forward)
+    import yond_public_amd.synthetic as S
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'full_dn': True}
+    frames = [torch.from_numpy(S.synth_noisy(3000, 4000, 4.0, 6.0, 70 + i)[0]).to(DEV) for i in range(2)]
+    bat = P.IterDenoiseBatch(frames + frames, net, arch, pipe)           # batch 4
+    one = P.IterDenoise(frames[1], net, arch, pipe)
+    assert bat['raw_dns'][0].shape == (4, 3000, 4000)
+    assert float((bat['raw_dns'][0][1] - one['raw_dns'][0]).abs().max()) <= 2e-6
+    # (the same frame twice: its two estimates differ in the last bits -- float64 atomics -- and so may the outputs)
+    assert float((bat['raw_dns'][0][1] - bat['raw_dns'][0][3]).abs().max()) <= 2e-6
+
+
+def test_cfg5_fp16_path_unclipped_4000x6000():
+    """BASELINE cfg 5 at its real shape: one low-light 4000 x 6000 frame without black-level clip (negative DN reach the
+    VST), GuidedResUnet with precision='fp16' (fp16 MFMA operands, fp32 accumulate): finite, in range, and >= 55 dB from
+    the fp32 path -- on the whole frame and on a 512 x 512 crop."""
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    arch = ARCHS["gru32"]
+    net, _ = make_net(arch, 3)
+    H, W, K, sigma = 4000, 6000, 2.0, 25.0
+    clean = torch.from_numpy((O.synth_clean(H, W) * 0.2).astype(np.float32)).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    noisy = (torch.poisson(clean * (959.0 / K), generator=g) * K + torch.randn((H, W), device=DEV, generator=g) * sigma) / 959.0
+    noisy = noisy.float().contiguous()
+    assert float(noisy.min()) < 0.0                             # the case really has negative pixels
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'full_dn': True}
+    r32 = P.IterDenoise(noisy, net, arch, pipe)
+    net.precision = 'fp16'
+    r16 = P.IterDenoise(noisy, net, arch, pipe)
+    net.precision = 'fp32'
+    a, b = r16['raw_dns'][0], r32['raw_dns'][0]
+    assert a.shape == (H, W) and bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    np.testing.assert_allclose(r16['regs'][0], r32['regs'][0], rtol=1e-9)         # the estimate does not depend on the conv path
+    for name, (u, v) in {"frame": (a, b), "crop": (a[1700:2212, 2700:3212], b[1700:2212, 2700:3212])}.items():
+        mse = float(((u.double() - v.double()) ** 2).mean())
+        psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
+        print(f"[parity] cfg5 4000x6000 fp16-MFMA path vs fp32 path, {name}: PSNR {psnr:.1f} dB")
+        assert psnr >= 55.0

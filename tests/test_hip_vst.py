@@ -43,6 +43,17 @@ def test_k1_pack_vst_norm(H, W, K, s, bc):
     from yond_public_amd import pipeline as P, _lib as L
     lib = L.load()
     noisy, _ = O.synth_noisy(H, W, K, s, 3)
+    # pixels that land EXACTLY on the LUT's knots, the repeated ones (50, 500: get_bias concatenates its runs) included
+    hits = []
+    for target in (50.0, 500.0, 49.9, 0.1, 51.0, 510.0):
+        q = np.float32(target / 959.0)
+        for _ in range(8):
+            if np.float32(q * np.float32(959.0)) == np.float32(target):
+                hits.append(q)
+                break
+            q = np.nextafter(q, np.float32(2.0 if np.float32(q * np.float32(959.0)) < target else 0.0), dtype=np.float32)
+    assert len(hits) >= 3
+    noisy.reshape(-1)[7:7 + len(hits)] = hits
     K, s = np.float64(K), np.float64(s)
     # oracle staging (YOND_SIDD.py:251-269, 281-286)
     lr = O.bayer2rggb(noisy) * 959.0

@@ -47,8 +47,19 @@ __device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict_
             double dy, y0;
             if (flags & LUT_Y64) { dy = lut_y64[i] - lut_y64[i - 1]; y0 = lut_y64[i - 1]; }
             else { dy = (double)(lut_y[i] - lut_y[i - 1]); y0 = (double)lut_y[i - 1]; }   // float32 difference, as interp1d forms it
-            const double b = dy / (L.x[i] - L.x[i - 1]);
-            L.ab[i] = make_double2(y0 - b * L.x[i - 1], b);
+            double dx = L.x[i] - L.x[i - 1];
+            if (dx == 0.0 && i >= 2) {
+                // a repeated knot (get_bias concatenates its runs, so 50 and 500 appear twice): searchsorted('left') never
+                // selects the empty interval -- a query equal to the knot belongs to the interval that ENDS at its first copy
+                dx = L.x[i - 1] - L.x[i - 2];
+                if (flags & LUT_Y64) { dy = lut_y64[i - 1] - lut_y64[i - 2]; y0 = lut_y64[i - 2]; }
+                else { dy = (double)(lut_y[i - 1] - lut_y[i - 2]); y0 = (double)lut_y[i - 2]; }
+                const double b = dy / dx;
+                L.ab[i] = make_double2(y0 - b * L.x[i - 2], b);
+            } else {
+                const double b = dy / dx;
+                L.ab[i] = make_double2(y0 - b * L.x[i - 1], b);
+            }
         }
         if (i >= 1 && i + 1 < n) {
             const double d0 = L.x[i] - L.x[i - 1], d1 = L.x[i + 1] - L.x[i];

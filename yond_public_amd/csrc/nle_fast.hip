@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NFC_THREADS) void nf_collect_kernel(const float* __
 // ------------------------------------------------------------------------------------------------------------
 // finish: one workgroup per slot selects inside its candidates; the last one evaluates percentiles and score 3
 // ------------------------------------------------------------------------------------------------------------
-#define NFF_THREADS 256
+#define NFF_THREADS 1024
 
 __global__ __launch_bounds__(NFF_THREADS) void nf_final_kernel(NleState* st, const unsigned short* __restrict__ cand, NfArgs a,
                                                                int want_score) {
@@ -197,13 +197,14 @@ __global__ __launch_bounds__(NFF_THREADS) void nf_final_kernel(NleState* st, con
         const unsigned int cnt = st->slot_cnt[s];
         const unsigned short* c = cand + st->slot_off[s];
         const unsigned int prefix = st->slot_prefix[s];
-        if (tid == 0) {
-            int k = 0;
-            for (int t = 0; t < nt; ++t)
-                if (st->tgt_slot[t] == s) { s_tl[k] = t; s_rk[k] = st->tgt_rank[t]; ++k; }
-            s_nt = k;
+        if (tid == 0) s_nt = 0;
+        if (tid < 256) s_h[tid] = 0;
+        __syncthreads();
+        if (tid < nt && st->tgt_slot[tid] == s) {            // (one load per thread; a serial scan by one thread cost 20 us)
+            const int k = atomicAdd(&s_nt, 1);
+            s_tl[k] = tid;
+            s_rk[k] = st->tgt_rank[tid];
         }
-        s_h[tid] = 0;
         __syncthreads();
         const int mt = s_nt;
         // candidate ranges start on 16-byte boundaries: 8 candidates per load, four loads in flight
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(NFF_THREADS) void nf_final_kernel(NleState* st, con
             for (int u = 0; u < k; ++u) dup = dup || (s_b8[u] == s_b8[k]);
             if (dup) continue;                              // uniform: handled together with the first target of that byte
             const unsigned int b8 = (unsigned int)s_b8[k];
-            s_h[tid] = 0;
+            if (tid < 256) s_h[tid] = 0;
             __syncthreads();
             auto count_lo = [&](uint4 q) {
                 const unsigned int wv[4] = {q.x, q.y, q.z, q.w};
@@ -321,12 +322,15 @@ __global__ __launch_bounds__(NFF_THREADS) void nf_final_kernel(NleState* st, con
         const unsigned int inv = st->maxinv[b];
         if (inv) {
             const double lmin = (double)key2f(~inv);        // smallest lap of the bin
-            for (int i = 0; i < nq; ++i)
-                if (lmin <= s_ths[i]) atomicAdd(&s_np[i], 1);   // YOND_SIDD.py:37: data <= ths[i]
+            int first = nq;                                 // first threshold that admits the bin (YOND_SIDD.py:37: data <= ths[i]);
+            for (int i = nq - 1; i >= 0; --i)               // percentiles ascend, so it counts for every later one too
+                if (lmin <= s_ths[i]) first = i;
+            if (first < nq) atomicAdd(&s_np[first], 1);
         }
     }
     __syncthreads();
     if (tid == 0) {
+        for (int i = 1; i < nq; ++i) s_np[i] += s_np[i - 1];
         double best = INFINITY;
         int bi = 0;
         for (int i = 0; i < nq; ++i) {

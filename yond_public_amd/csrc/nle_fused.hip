@@ -190,6 +190,14 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     const int baseB = SELF ? ((baseC + tasksC + 63) & ~63) : baseC, tasksB = 2 * BF_B * nBc;
     const int ntask_threads = baseB + tasksB;                                 // <= 512 for ow <= 210 (host checks)
     const int n4 = (ow + 3) >> 2;
+    // this thread's task of the task phase, decoded ONCE (the divisions by run-time chunk counts cost ~100 instructions)
+    int tk_chunk, tk_rr, tk_hf;
+    {
+        const int grp = tid < tasksA ? 0 : ((SELF && tid >= baseC && tid < baseC + tasksC) ? 1 : 2);
+        const int t = grp == 0 ? tid : (grp == 1 ? tid - baseC : tid - baseB);
+        const int nch = grp == 2 ? max(nBc, 1) : max(nA, 1);
+        tk_chunk = t % nch; tk_rr = (t / nch) % BF_B; tk_hf = t / (nch * BF_B);
+    }
 
     __syncthreads();
     load_batch(nxt, 0);
@@ -341,20 +349,21 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
         BF_STAMP(2)
         // (a3) stores of the finished rows, 16 bytes per lane (thread = (map, plane, row, 4 columns))
         {
-            const int nmap = 3;
+            // one (map, plane, row) item per wave and trip -- decoded with shifts --, the lanes along the row
             const int per_row = vec_ok ? n4 : ow;
-            const int total = nmap * 2 * BF_B * per_row;
-            for (int t = tid; t < total; t += 512) {
-                const int j = t % per_row, rr = (t / per_row) % BF_B, hf = (t / (per_row * BF_B)) & 1, m = t / (per_row * BF_B * 2);
+            for (int item = tid >> 6; item < 3 * 2 * BF_B; item += 8) {
+                const int m = item / (2 * BF_B), hf = (item / BF_B) & 1, rr = item % BF_B;
                 const bool lapmap = m == 2;
                 const int lp = l0 - ((SELF && lapmap) ? 2 : 1) * BF_B;
                 const int l = lp + rr;
                 const int cr = l - R - ((SELF && lapmap) ? R2 : 0);           // finished row
-                if (lp < 0 || l >= nsteps || cr < HALO || cr >= HALO + ohe) continue;
+                if (lp < 0 || l >= nsteps || cr < HALO || cr >= HALO + ohe) continue;                       // (uniform)
                 float* op = (m == 0 ? o_mean : (m == 1 ? o_var : o_lap)) + ((size_t)(2 * dy + hf) * h + (oy0 + cr - HALO)) * w + ox0;
                 const float* sp = ST(lapmap ? 3 : m, hf, rr);
-                if (vec_ok) *(f32x4*)(op + 4 * j) = *(const f32x4*)(sp + 4 * j);
-                else op[j] = sp[j];
+                for (int j = lane; j < per_row; j += 64) {
+                    if (vec_ok) *(f32x4*)(op + 4 * j) = *(const f32x4*)(sp + 4 * j);
+                    else op[j] = sp[j];
+                }
             }
         }
         BF_STAMP(3)
@@ -364,8 +373,7 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
         if (tid < ntask_threads) {
             if (tid < tasksA && nb < nbatch) {
                 // group A: 29-window sums of stage 1 -> mean, var (collab: + lap)
-                const int t = tid;
-                const int chunk = t % nA, rr = (t / nA) % BF_B, hf = t / (nA * BF_B);
+                const int chunk = tk_chunk, rr = tk_rr, hf = tk_hf;
                 const int l = l0 + rr;
                 const int cm = l - R;
                 if (cm >= HALO && cm < HALO + ohe && l < nsteps) {
@@ -395,8 +403,7 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
                 }
             } else if (SELF && tid >= baseC && tid < baseC + tasksC && nb > 0 && nb <= nbatch) {
                 // group C: 29-window sums of stage 2 (b19 rows of the previous batch) -> lap
-                const int t = tid - baseC;
-                const int chunk = t % nA, rr = (t / nA) % BF_B, hf = t / (nA * BF_B);
+                const int chunk = tk_chunk, rr = tk_rr, hf = tk_hf;
                 const int l = l0 - BF_B + rr;
                 const int cl = l - R2 - R;
                 if (cl >= HALO && cl < HALO + ohe && l < nsteps) {
@@ -409,8 +416,7 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
                 }
             } else if (SELF && tid >= baseB && nb < nbatch) {
                 // group B: 19-window sums -> b19 rows (columns HALO - R .. HALO + ow + R)
-                const int t = tid - baseB;
-                const int chunk = t % nBc, rr = (t / nBc) % BF_B, hf = t / (nBc * BF_B);
+                const int chunk = tk_chunk, rr = tk_rr, hf = tk_hf;
                 const int l = l0 + rr;
                 if (l >= 2 * R2 && l < nsteps) {
                     const int c0 = HALO - R + chunk * BF_LB, c1 = HALO + ow + R;

@@ -273,6 +273,8 @@ int yond_nle_stats_f32(const float* lap, const float* mean, size_t n, int width,
                        void* stream);
 int yond_nle_threshold_f32(const float* lap, size_t n, const double* q_host, int nq, int want_score, void* ws, void* stream);
 int yond_nle_state_layout(int* off /*[5]*/);
+/* K7b on that workspace: the moment sums below sel[1] into the workspace's mom (zeroed by the reset of sweep 1). */
+int yond_nle_moments_f32(const float* lap, const float* mean, const float* var, size_t n, void* ws, void* stream);
 
 /* K7a occupancy: one pass over (lap, mean), n elements laid out as rows of `width` (n % width == 0; pass the
  *   image row length so that a lane can walk down a column of the smooth maps; any width is correct):

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "yond_nle_stats_f32": [vp, vp, sz, i32, vp, i32, vp, vp],
     "yond_nle_threshold_f32": [vp, sz, vp, i32, i32, vp, vp],
     "yond_nle_state_layout": [vp],
+    "yond_nle_moments_f32": [vp, vp, vp, sz, vp, vp],
     "yond_nlf_occupancy_f32": [vp, vp, sz, i32, vp, i32, vp, vp],
     "yond_nlf_score3_f64": [vp, vp, vp, i32, vp, vp, vp],
     "yond_nlf_moments_f32": [vp, vp, vp, sz, vp, vp, vp],

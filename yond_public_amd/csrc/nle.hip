@@ -6,7 +6,7 @@
 //   K7  occupancy of the 1/1000 mean bins per threshold bucket (one sweep), score-3 selection on the device,
 //       and the five moment sums of the least-squares line below the selected threshold (one sweep).
 // All of it is integer / streaming work bound by HBM and LDS, not MFMA.
-#include "common.h"
+#include "nle_common.h"
 
 // =====================================================================================================
 // K5: box statistics, streamed down the rows
@@ -506,12 +506,29 @@ extern "C" int yond_nlf_score3_f64(const uint32_t* occ, const double* ths, const
     return YOND_OK;
 }
 
+static int launch_moments(const float* lap, const float* mean, const float* var, size_t n, const double* th, double* mom,
+                          bool zero, hipStream_t st);
+
 extern "C" int yond_nlf_moments_f32(const float* lap, const float* mean, const float* var, size_t n, const double* th,
                                     double* mom, void* stream) {
     if (!lap || !mean || !var || !th || !mom || n == 0) return YOND_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(mom, 0, sizeof(double) * 10, st);
-    if (e != hipSuccess) return (int)e;
+    return launch_moments(lap, mean, var, n, th, mom, true, (hipStream_t)stream);
+}
+
+// the same sweep on the workspace of the two-sweep selection (nle_fast.hip): threshold = sel[1], sums -> mom, which the
+// workspace reset of sweep 1 has already zeroed (no memset launch of its own)
+extern "C" int yond_nle_moments_f32(const float* lap, const float* mean, const float* var, size_t n, void* ws, void* stream) {
+    if (!lap || !mean || !var || !ws || n == 0) return YOND_EINVAL;
+    NleState* s = (NleState*)ws;
+    return launch_moments(lap, mean, var, n, &s->sel[1], s->mom, false, (hipStream_t)stream);
+}
+
+static int launch_moments(const float* lap, const float* mean, const float* var, size_t n, const double* th, double* mom,
+                          bool zero, hipStream_t st) {
+    if (zero) {
+        hipError_t e = hipMemsetAsync(mom, 0, sizeof(double) * 10, st);
+        if (e != hipSuccess) return (int)e;
+    }
     const int vec_ok = !(((uintptr_t)lap | (uintptr_t)mean | (uintptr_t)var) & 15);
     size_t nb = (n / 4 + 256 * MOM_UNROLL - 1) / (256 * MOM_UNROLL);
     if (nb > 2048) nb = 2048;

@@ -401,9 +401,7 @@ def _nlf_from_maps(lap, mean, var, full=False, ws=None):
             ws = _nle_workspace(n, lap.device)
             L.check(lib.yond_nle_stats_f32(L.ptr(lap), L.ptr(mean), n, int(width), qp, len(q), L.ptr(ws), st), "yond_nle_stats_f32")
         L.check(lib.yond_nle_threshold_f32(L.ptr(lap), n, qp, len(q), 1, L.ptr(ws), st), "yond_nle_threshold_f32")
-        base = ws.data_ptr()
-        L.check(lib.yond_nlf_moments_f32(L.ptr(lap), L.ptr(mean), L.ptr(var), n, C.c_void_p(base + off_sel + 8),
-                                         C.c_void_p(base + off_mom), st), "yond_nlf_moments_f32")
+        L.check(lib.yond_nle_moments_f32(L.ptr(lap), L.ptr(mean), L.ptr(var), n, L.ptr(ws), st), "yond_nle_moments_f32")
     head = ws[:off_np + 4 * 32 + 4 * 64 + 8].cpu().numpy()      # the one sync (results head of the workspace)
     off_max = _nle_layout()[4]
     frame_max_key = int(head[off_max:off_max + 4].view(np.uint32)[0])

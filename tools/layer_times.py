@@ -1,0 +1,25 @@
+"""Per-launch times of one SNR-Net forward at the cfg-2 shape (HIP events around every convolution launch)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from yond_public_amd import archs as A, synthetic as S, pipeline as P
+arch = dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True)
+net = A.GuidedResUnet(dict(arch)); net.load_state_dict(S.procedural_state_dict(net, 0)); net = net.to('cuda').eval()
+plan = P._plan_of(net, torch.device('cuda'))
+x = torch.rand(1, 1504, 2016, 4, device='cuda'); t = torch.full((1,), 0.03, device='cuda'); ub = x.reshape(1, -1).max(1).values.contiguous()
+for _ in range(3): plan.forward_nhwc4(x, t, ub=ub)
+torch.cuda.synchronize()
+acc = {}
+for rep in range(5):
+    plan.prof = []
+    plan.forward_nhwc4(x, t, ub=ub)
+    torch.cuda.synchronize()
+    for i, (tag, fl, e0, e1) in enumerate(plan.prof):
+        acc.setdefault((i, tag), []).append(e0.elapsed_time(e1) * 1e3)
+    plan.prof = None
+tot = 0
+for (i, tag), v in sorted(acc.items()):
+    m = sorted(v)[len(v) // 2]
+    tot += m
+    print(f"{i:2d} {tag:42s} {m:8.1f} us")
+print("sum of conv launches: %.1f us" % tot)

@@ -732,7 +732,10 @@ static int launch_split(const YondConvDesc& d, hipStream_t st) {
 // ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has
 // shuffle = 1): 48-channel steps, 64-wide tiles that must not straddle two sub-positions
 extern "C" int yond_conv_split_supported(int ksize, int stride, int cin, int cout) {
-    if (ksize == 1) return (stride == 1 && cin > 0 && cin % 48 == 0 && cout > 0 && cout % 4 == 0 && (cout / 4) % 64 == 0) ? 64 : 0;
+    if (ksize == 1) {
+        if (!(stride == 1 && cin > 0 && cin % 48 == 0 && cout > 0 && cout % 4 == 0)) return 0;
+        return (cout / 4) % 64 == 0 ? 64 : ((cout / 4) % 32 == 0 ? 32 : 0);       // a tile may not straddle two sub-positions
+    }
     if (ksize != 3 || (stride != 1 && stride != 2) || cin <= 0 || cout <= 0 || cin % 16 != 0 || cout % 32 != 0) return 0;
     if (stride == 2) return cout % 64 == 0 ? 64 : 0;
     return cout % 64 == 0 ? 64 : 32;
@@ -786,6 +789,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.ksize == 1) {
         // the decoder GEMM: low-resolution input (C0) + skip tensor at the output resolution (C1), pixel-shuffle store
         if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.Ho != d.H || d.Wo != d.W) return YOND_EUNSUPPORTED;
+        if (tn == 32) return launch_split<1, 8, 32, 1, 2, 3, false, false, true>(d, st);    // level 1 -> 0: 32-channel output pixels
         return launch_split<1, 8, 64, 2, 2, 3, false, false, true>(d, st);
     }
     if (d.stride == 2) {

@@ -98,8 +98,11 @@ int yond_nhwc4_to_nchw4_f32(const float* src, float* dst, int N, int H, int W, v
 int yond_image_max_f32(const float* x, int N, size_t elems, float* partial, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * K2  convolutions of the denoiser as fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32).
- * Activations are NHWC float32.  One descriptor covers: 3x3 stride 1 / stride 2 and 1x1 convolutions,
+ * K2  convolutions of the denoiser as MFMA implicit GEMMs on NHWC float32 activations with float32 results.  `algo`
+ * selects the arithmetic: 3 / 5 (the default path of engine.py) fp32-accurate split-operand products on the fp16 matrix
+ * cores (v_mfma_f32_32x32x16_f16 / 32x32x8_f16, three per fp32 product block), 0 / 1 the fp32-input MFMA
+ * (v_mfma_f32_32x32x2_f32 direct, v_mfma_f32_16x16x4_f32 Winograd), 2 / 4 fp16 operands (BASELINE cfg 5).
+ * One descriptor covers: 3x3 stride 1 / stride 2 and 1x1 convolutions,
  * an input that is the channel concatenation of two tensors (torch.cat([up, skip], 1) is never
  * materialised), 2x2 stride-2 transposed convolution (as a 1x1 GEMM with a pixel-shuffle store), an
  * optional SiLU on the staged input, and the epilogue  v = acc*escale + eshift ; act(v) ; v += res.

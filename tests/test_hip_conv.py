@@ -1,5 +1,6 @@
-"""GPU: every variant of the fp32-MFMA convolution kernels against torch CPU convolutions
-(float64 reference of the same op), through the C ABI."""
+"""GPU: every variant of the convolution kernels behind YondConvDesc -- K2s split-operand products on the fp16 MFMA (the
+default path), K2w Winograd / K2 direct on the fp32-input MFMA, the fp16 path, first / last layers, pooling, FiLM --
+against torch CPU convolutions (float64 reference of the same op), through the C ABI."""
 import numpy as np
 import pytest
 import torch

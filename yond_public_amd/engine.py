@@ -2,8 +2,11 @@
 UNetSeeInDark) on the HIP kernels of libyond_hip.so.
 
 The reference runs these nets through torch.nn / cuDNN in NCHW (archs/Unet.py:55-104, 332-378,
-424-470).  Here a forward pass is a fixed sequence of launches of the fp32-MFMA implicit-GEMM
-kernels over NHWC float32 activations:
+424-470).  Here a forward pass is a fixed sequence of launches of the MFMA implicit-GEMM kernels over
+NHWC float32 activations -- by default (precision 'fp32') fp32-accurate split-operand products on the
+fp16 matrix cores (csrc/conv_split.hip), with 'fp32-mfma' the fp32-input MFMA kernels (Winograd /
+direct), with 'fp16' the BASELINE cfg 5 path; a range guard (DenoiserPlan.begin_guard / overflowed)
+reports activations that leave fp16's range:
 
     [data_normalize max] -> sigma-MLPs (one launch) -> conv_in -> 9 x (conv1, conv2) with fused
     SiLU / FiLM / residual -> 4 stride-2 convs -> 4 x (convT as GEMM + pixel-shuffle store,

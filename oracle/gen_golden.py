@@ -358,6 +358,18 @@ def gen_rot(ref):
         a_, b_, c_ = iter_crop(dn)
         out[f"dn_{it}_blk"], out[f"dn_{it}_seam"], out[f"dn_{it}_sub"] = a_, b_, c_
         out[f"dn_{it}_chk"] = checks(dn)
+    # YOND_SIDD.py:358-381: full_est False -> no estimate, every block through Simple_Denoiser (an unguided net)
+    pipe2 = dict(pipe, full_est=False, est_type='simple')
+    obj2, _ = fake_self(ref, ARCHS["unet8"], 82, pipe2)
+    sd2 = O.denoising_state_dict(ARCHS["unet8"], 82)
+    obj2.net = ref.load_weights(obj2.net, sd2, by_name=False).eval()
+    p2 = dict(pipe2)
+    p2.update({'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0, 'scale': 959.0})
+    res2 = obj2.IterDenoise(dict(data, lr_path_full=None), {'p': p2, 'img_id': 0})
+    assert res2['regs'] == (0, 0) and len(res2['raw_dns']) == 1
+    a_, b_, c_ = iter_crop(res2['raw_dns'][0])
+    out["simple_blk"], out["simple_seam"], out["simple_sub"] = a_, b_, c_
+    out["simple_chk"] = checks(res2['raw_dns'][0])
     save("rot", **out)
 
 

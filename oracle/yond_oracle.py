@@ -826,6 +826,11 @@ def IterDenoise(lr_raw, arch, sd, pipe, lr_full=None, p=None):
         lr_cat = lr_raw
     if sidd:
         blocks = np.array(np.split(lr_cat, 32, axis=-1))                          # :354
+    if not pipe.get('full_est', True):                                            # :358-381 (est_type without 'pge')
+        out = np.empty((32, 256, 256), np.float32)
+        for num in range(32):
+            out[num] = Simple_Denoiser(blocks[num], arch, sd)                     # :369-370
+        return dict(raw_dns=[np.concatenate(out, axis=-1)], regs=(0, 0), params=[])
     raw4est = lr_cat if lr_full is None else lr_full                              # :340
     reg = SimpleNLF(raw4est, k=k, setting={'mode': 'self'})                       # :341
     p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale       # :356

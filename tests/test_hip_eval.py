@@ -201,3 +201,23 @@ def test_eval_on_a_mat_tree_in_the_reference_layout(tmp_path, monkeypatch):
     for it in range(len(ref['raw_dns'])):
         ps, ss = O.sidd_block_metrics(ref['raw_dns'][it], np.concatenate(hrs[0], axis=-1))
         assert abs(ps - m['psnr'][it]) < 2e-3 and abs(ss - m['ssim'][it]) < 2e-5
+
+
+def test_iter_denoise_without_estimate_branch(golden):
+    """YOND_SIDD.py:358-381 (full_est False): every block through Simple_Denoiser, regs = (0, 0); against the reference's run."""
+    import yond_oracle as O
+    from test_oracle_golden import iter_crop
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    g = golden("rot")
+    noisy, _ = O.synth_noisy(256, 8192, 2.0, 20.0, 31)
+    arch = ARCHS["unet8"]
+    net = A.UNetSeeInDark(dict(arch))
+    net.load_state_dict(O.denoising_state_dict(arch, 82))
+    net = net.to(DEV).eval()
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': False, 'full_est': False,
+            'est_type': 'simple'}
+    res = P.IterDenoise(np.array(np.split(noisy, 32, axis=-1)), net, arch, pipe, device=DEV)
+    assert res['regs'] == (0, 0) and len(res['raw_dns']) == 1
+    for got, tag in zip(iter_crop(res['raw_dns'][0].cpu().numpy()), ("blk", "seam", "sub")):
+        assert report(f"Simple_Denoiser branch {tag}", got, g[f"simple_{tag}"]) <= 1e-4

@@ -278,3 +278,18 @@ def test_rot_bayer_and_rot_cfa_pipeline(golden):
     for it, dn in enumerate(res['raw_dns']):
         for got, tag in zip(iter_crop(dn), ("blk", "seam", "sub")):
             np.testing.assert_allclose(got, g[f"dn_{it}_{tag}"], rtol=0, atol=2e-5)
+
+
+def test_iter_denoise_without_estimate_branch(golden):
+    """YOND_SIDD.py:358-381 (full_est False, est_type without 'pge'): no noise estimate, every block through
+    Simple_Denoiser, regs = (0, 0) -- against the reference's own run."""
+    g = golden("rot")
+    noisy, _ = O.synth_noisy(256, 8192, 2.0, 20.0, 31)
+    arch = ARCHS["unet8"]
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': False, 'full_est': False,
+            'est_type': 'simple'}
+    torch.set_num_threads(8)
+    res = O.IterDenoise(np.array(np.split(noisy, 32, axis=-1)), arch, O.denoising_state_dict(arch, 82), pipe)
+    assert res['regs'] == (0, 0) and len(res['raw_dns']) == 1
+    for got, tag in zip(iter_crop(res['raw_dns'][0]), ("blk", "seam", "sub")):
+        np.testing.assert_allclose(got, g[f"simple_{tag}"], rtol=0, atol=2e-5)

@@ -14,8 +14,8 @@
 // four at a time with TWO barriers per batch:
 //   column phase (thread = column)   vertical running sums S += entering - leaving (float64 registers; the leaving row
 //       is read again from L2) -> LDS; for the self mode also the vertical sums of the B19 rows (entering from LDS, the
-//       leaving one from a 29-deep register ring) -> LDS; stores of the finished output rows (coalesced), histogram /
-//       minimum updates;
+//       leaving one from a 32-deep register ring) -> LDS; stores of the finished output rows (16 bytes per lane), one
+//       LDS atomic per pixel for the level-1 histogram, read-then-atomic-max for the per-bin minimum;
 //   task phase (thread = (plane, row, chunk of 9..17 columns))   horizontal k-window sums by SLIDING along the chunk:
 //       two LDS reads and two adds per sum and output after a k-read start -- the 64-lane float64 prefix scans of the
 //       first version (6 DPP steps x 3 instructions per sum) were its whole cost (109 + 65 us); results -> LDS staging.
@@ -152,32 +152,27 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     // the lanes (adjacent columns of the smooth map) merged into one LDS atomic; per mean bin the smallest lap
     // (the four rows of a batch go through each step together, so that their LDS round trips overlap)
     auto stats_rows = [&](const bool (&rowv)[BF_B], const float (&lapv)[BF_B], const int (&bin)[BF_B]) {
-        unsigned int key[BF_B], id[BF_B], prev[BF_B], known[BF_B];
+        unsigned int key[BF_B], known[BF_B];
         bool valid[BF_B];
 #pragma unroll
         for (int r = 0; r < BF_B; ++r) {
             valid[r] = rowv[r] && writer;
             key[r] = f2key(lapv[r]);
-            id[r] = valid[r] ? (key[r] >> 16) : (0xFFFF0000u | (unsigned int)lane);      // invalid lanes never merge
-            prev[r] = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)id[r], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             known[r] = s_mi[valid[r] ? bin[r] : 0];                           // what the workgroup already knows about the bin
         }
 #pragma unroll
         for (int r = 0; r < BF_B; ++r) {
-            const bool head = (lane == 0) || (id[r] != prev[r]);
-            const unsigned long long m = __ballot(head);
-            if (head && valid[r]) {
-                const unsigned long long rest = (m >> lane) >> 1;
-                const unsigned int len = rest ? (unsigned int)__ffsll((long long)rest) : (unsigned int)(64 - lane);
-                const unsigned int wdw = id[r] - BFW_LO;
-                // two 16-bit counters per word: bins w and w + 2048, so that neighbouring bins (what neighbouring pixels
-                // hit) sit in neighbouring words / banks
-                if (wdw < BFW_N) atomicAdd(&s_h[wdw & (BFW_N / 2 - 1)], len << ((wdw >> 11) * 16));
-                else if (id[r] == NF_WIN_LO) atomicAdd(&s_h[BFW_N / 2], len);            // lap == +0.0
-                else atomicAdd(&st->hist1[id[r]], len);
+            if (valid[r]) {
+                // one LDS atomic per pixel: neighbouring pixels hit neighbouring bins (two 16-bit counters per word: bins w
+                // and w + 2048 share one, so neighbours sit in different words / banks); merging runs of equal bins across
+                // the lanes first cost ~30 vector instructions per row, more than the few same-address replays it saved
+                const unsigned int id = key[r] >> 16, wdw = id - BFW_LO;
+                if (wdw < BFW_N) atomicAdd(&s_h[wdw & (BFW_N / 2 - 1)], 1u << ((wdw >> 11) * 16));
+                else if (id == NF_WIN_LO) atomicAdd(&s_h[BFW_N / 2], 1u);                // lap == +0.0
+                else atomicAdd(&st->hist1[id], 1u);
+                const unsigned int inv = ~key[r];
+                if (inv > known[r]) atomicMax(&s_mi[bin[r]], inv);
             }
-            const unsigned int inv = ~key[r];
-            if (valid[r] && inv > known[r]) atomicMax(&s_mi[bin[r]], inv);
         }
     };
     auto bin_of = [](float m) -> int { return (int)__fmul_rn(fminf(fmaxf(m, 0.0f), 1.0f), 1000.0f); };   // (mean.clip(0,1)*nbins).astype(int)

@@ -5,6 +5,7 @@
 // coalesced across the wave) and one 16-byte NHWC4 slot.  Arithmetic follows the dtype staging of the
 // reference under NumPy 2: float32 x*scale, float64 for everything up to the single rounding to float32
 // (YOND_SIDD.py:251-269, 292-299; utils/isp_algos.py:5-33).
+#include <stdlib.h>
 #include "common.h"
 
 #define LUT_MAX 4096
@@ -231,7 +232,8 @@ static int launch_pack_vst(const float* bayer, int H, int W, float* out, int pad
         if (e != hipSuccess) return (int)e;
     }
     size_t nb = (size_t)Hp;
-    if (nb > 256 * 4) nb = 256 * 4;          // every workgroup prepares the LUT once: keep them few and long-lived
+    static const long k1_wgs = getenv("YOND_K1_WGS") ? atol(getenv("YOND_K1_WGS")) : 1536;     // (experiments)
+    if (nb > (size_t)k1_wgs) nb = (size_t)k1_wgs;   // every workgroup prepares the LUT once: keep them few and long-lived
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)pack_vst_norm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_MAX * LUT_BYTES_PER_KNOT);

@@ -709,6 +709,13 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
         blocks = torch.stack(torch.split(lr, lr.shape[1] // 32, dim=-1)).contiguous()  # :354
     else:
         lr_cat = lr
+    if not pipe.get('full_est', True):         # :358-381: no estimate at all -- every block through Simple_Denoiser
+        if 'pge' in str(pipe.get('est_type', '')):
+            raise NotImplementedError("est_type 'pge' reads precomputed estimates from the dataset directory (:359-366)")
+        if not stack:
+            raise L.YondHipError("the Simple_Denoiser branch works on the SIDD stack [32][256][256]")
+        outs = [Simple_Denoiser(blocks[num], net) for num in range(32)]                # :369-370
+        return dict(raw_dns=[torch.cat(outs, dim=-1).contiguous()], regs=(0, 0), params=[])   # :372-378
     raw4est = lr_cat if lr_full is None else _dev(lr_full, lr.device)                  # :340
     # lr.max() for the bias LUT grid: the fused estimator kernel collects it when it reads the same frame; else a
     # reduction queued ahead of the NLE and read after the NLE's own host sync

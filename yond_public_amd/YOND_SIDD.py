@@ -157,9 +157,12 @@ class YOND_SIDD:
         self.metrics = {}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        t_path = 0.0
         for k in mine:
-            data = self.dst_eval[k]
+            data = self.dst_eval[k]                                                     # (host side: file reads / synthesis)
             p['cfa'] = data.get('cfa', [[1, 2], [2, 3]])                                # YOND_SIDD.py:510
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
             res = self.IterDenoise(data, {'p': p, 'img_id': k})
             psnrs, ssims = [], []
             if res['hr_raw'] is not None:
@@ -169,6 +172,8 @@ class YOND_SIDD:
                     psnrs.append(float(np.mean(ps)))
                     ssims.append(float(np.mean(ss)))
                 sums.update(psnrs, ssims)        # iterations that did not run count -1 in their own meter (:644-647)
+            torch.cuda.synchronize()
+            t_path += time.perf_counter() - t1              # estimate + denoise (+ metrics) of this image, uploads included
             self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
             log(f"[rank {self.rank}] {data['name']}: PSNR={psnrs[-1] if psnrs else float('nan'):.2f}, "
                 f"SSIM={ssims[-1] if ssims else float('nan'):.4f}", self.logfile)
@@ -181,7 +186,8 @@ class YOND_SIDD:
             for it in range(n_it):
                 log(f"Iter{it}: PSNR={red[f'psnr_iter{it}']:.2f}, SSIM={red[f'ssim_iter{it}']:.4f}", self.logfile)
             log(f"Iter_last: PSNR={red['psnr_last']:.2f}, SSIM={red['ssim_last']:.4f}", self.logfile)
-            log(f"{red['count']} images on {self.world} GPU(s) in {dt:.2f} s", self.logfile)
+            log(f"{red['count']} images on {self.world} GPU(s) in {dt:.2f} s "
+                f"(rank 0: {t_path / max(len(mine), 1) * 1e3:.1f} ms per image in IterDenoise + metrics, the rest is data loading)", self.logfile)
         return red
 
 

@@ -343,16 +343,67 @@ def test_fused_box_statistics_collab():
         assert np.array_equal(ths_f, ths_s) and np.array_equal(np_f, np_s) and np.array_equal(sel_f, sel_s)
 
 
+@pytest.mark.parametrize("H,W,tile_w,k", [(256, 256, 0, 29), (200, 328, 0, 29), (62, 70, 0, 13), (700, 1000, 0, 29), (256, 2048, 32, 29),
+                                          (1024, 1024, 0, 21)])
+def test_two_pass_box_statistics(H, W, tile_w, k):
+    """K5+ (nle.hip, STATS): the streaming kernels with the level-1 statistics, the per-bin minimum of lap, the resolve of
+    the ranks and the frame maximum folded in -- maps bit-identical to the plain kernels (same code), selection state
+    identical to the stand-alone sweep, for self and collab, any window size."""
+    import ctypes as C
+    import yond_oracle as O
+    from yond_public_amd import _lib as L
+    from yond_public_amd import pipeline as P
+    lib = L.load()
+    noisy, clean = O.synth_noisy(H, W, 4.0, 6.0, 21)
+    noisy[::7, ::5] = 0.0                                   # exact zeros: flat windows give lap == +0.0 (the side counter)
+    h, w = H // 2, W // 2
+    k2 = k // 3 * 2 + 1
+    t, c = torch.from_numpy(noisy).to(DEV), torch.from_numpy(clean).to(DEV)
+    q = np.ascontiguousarray(P.QUANTS)
+    qp = C.c_void_p(q.ctypes.data)
+    off_max = P._nle_layout()[4]
+    st = L.stream()
+    # self
+    o = [torch.empty((4, h, w), device=DEV) for _ in range(8)]
+    ws = P._nle_workspace(4 * h * w, t.device)
+    L.check(lib.yond_box_stats_self_stats_f32(L.ptr(t), H, W, k, k2, tile_w, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[6]), L.ptr(o[2]),
+                                              qp, len(q), L.ptr(ws), st), "self stats")
+    L.check(lib.yond_box_stats_self1_f32(L.ptr(t), H, W, k, k2, tile_w, L.ptr(o[3]), L.ptr(o[4]), L.ptr(o[7]), st), "self1")
+    L.check(lib.yond_box_stats_self2_f32(L.ptr(o[7]), h, w, k, tile_w, L.ptr(o[5]), st), "self2")
+    for a, b, name in zip(o[:3], o[3:6], ("mean", "var", "lap")):
+        assert torch.equal(a, b), name
+    ths_f, np_f, sel_f, _ = P._threshold_state(o[2], o[0], q, ws=ws)
+    ths_s, np_s, sel_s, _ = P._threshold_state(o[5], o[3], q)
+    assert np.array_equal(ths_f, ths_s) and np.array_equal(np_f, np_s) and np.array_equal(sel_f, sel_s)
+    assert np.array_equal(ths_f, np.percentile(o[2].cpu().numpy().reshape(-1), q, method='linear'))
+    key = int(ws[off_max:off_max + 4].cpu().numpy().view(np.uint32)[0])
+    assert P._key2float(key) == noisy.max()
+    # collab
+    L.check(lib.yond_box_stats_collab_stats_f32(L.ptr(t), L.ptr(c), H, W, k, tile_w, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), qp, len(q),
+                                                L.ptr(ws), st), "collab stats")
+    L.check(lib.yond_box_stats_collab_f32(L.ptr(t), L.ptr(c), H, W, k, tile_w, L.ptr(o[3]), L.ptr(o[4]), L.ptr(o[5]), st), "collab")
+    for a, b, name in zip(o[:3], o[3:6], ("mean", "var", "lap")):
+        assert torch.equal(a, b), name
+    ths_f, np_f, sel_f, _ = P._threshold_state(o[2], o[0], q, ws=ws)
+    ths_s, np_s, sel_s, _ = P._threshold_state(o[5], o[3], q)
+    assert np.array_equal(ths_f, ths_s) and np.array_equal(np_f, np_s) and np.array_equal(sel_f, sel_s)
+
+
 def test_simple_nlf_fused_equals_unfused_full_frame():
-    """cfg-2 size: the fused estimator and the stand-alone kernels give the same estimate (same maps bit for bit; the
-    float64 moment sums are accumulated with atomics, so the fit agrees to the summation order)."""
+    """cfg-2 size: the three producers of the maps (two-pass with the statistics folded in -- the default --, the
+    one-pass kernel, the stand-alone kernels + separate sweep) give the same estimate (same maps bit for bit; the float64
+    moment sums are accumulated with atomics, so the fit agrees to the summation order)."""
     import yond_oracle as O
     from yond_public_amd import pipeline as P
     noisy, _ = O.synth_noisy(3000, 4000, 4.0, 6.0, 3)
     t = torch.from_numpy(noisy).to(DEV)
     ra, ia = P.SimpleNLF(t, k=29, setting={'mode': 'self'}, full=True)
-    rb, ib = P.SimpleNLF(t, k=29, setting={'mode': 'self'}, full=True, fused=False)
-    assert ia['th'] == ib['th'] and ia['percent'] == ib['percent'] and ia['nsel'] == ib['nsel']
-    np.testing.assert_array_equal(ia['npeaks'], ib['npeaks'])
-    np.testing.assert_allclose(ra, rb, rtol=1e-9)
+    rb, ib = P.SimpleNLF(t, k=29, setting={'mode': 'self'}, full=True, box='plain')
+    for box in ('one-pass', 'plain'):
+        rb, ib = P.SimpleNLF(t, k=29, setting={'mode': 'self'}, full=True, box=box)
+        assert ia['th'] == ib['th'] and ia['percent'] == ib['percent'] and ia['nsel'] == ib['nsel'], box
+        np.testing.assert_array_equal(ia['npeaks'], ib['npeaks'])
+        np.testing.assert_allclose(ra, rb, rtol=1e-9)
+        if box != 'plain':
+            assert ib['frame_max'] == noisy.max()
     assert ia['frame_max'] == noisy.max()

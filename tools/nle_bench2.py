@@ -36,6 +36,10 @@ def t(fn, n=10):
 fused = lambda: lib.yond_box_stats_self_fused_f32(L.ptr(x), H, W, 29, 19, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), qp, len(q), L.ptr(ws), st)
 print("fused self (memset + kernel + resolve): %.1f us" % t(fused))
 print("fused collab: %.1f us" % t(lambda: lib.yond_box_stats_collab_fused_f32(L.ptr(x), L.ptr(xc), H, W, 29, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[3]), qp, len(q), L.ptr(ws), st)))
+o8 = torch.empty_like(o[0])
+twop = lambda: lib.yond_box_stats_self_stats_f32(L.ptr(x), H, W, 29, 19, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o8), L.ptr(o[2]), qp, len(q), L.ptr(ws), st)
+print("two-pass self (memset + self1 + self2 with statistics + resolve): %.1f us" % t(twop))
+print("two-pass collab: %.1f us" % t(lambda: lib.yond_box_stats_collab_stats_f32(L.ptr(x), L.ptr(xc), H, W, 29, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[3]), qp, len(q), L.ptr(ws), st)))
 fused()
 n = 4 * h * w
 print("stats sweep (stand-alone): %.1f us" % t(lambda: lib.yond_nle_stats_f32(L.ptr(o[2]), L.ptr(o[0]), n, w, qp, len(q), L.ptr(ws), st)))
@@ -49,7 +53,10 @@ base = ws.data_ptr()
 print("moments: %.1f us" % t(lambda: lib.yond_nlf_moments_f32(L.ptr(o[2]), L.ptr(o[0]), L.ptr(o[1]), n, C.c_void_p(base + off[1] + 8), C.c_void_p(base + off[2]), st)))
 print("old self1+self2: %.1f us" % t(lambda: (lib.yond_box_stats_self1_f32(L.ptr(x), H, W, 29, 19, 0, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[3]), st),
                                               lib.yond_box_stats_self2_f32(L.ptr(o[3]), h, w, 29, 0, L.ptr(o[2]), st))))
-print("SimpleNLF end to end (incl. host sync): %.1f us" % t(lambda: P.SimpleNLF(x, k=29, setting={'mode': 'self'})))
+for box in ('two-pass', 'one-pass', 'plain'):
+    print("SimpleNLF self  box=%-8s end to end (incl. host sync): %.1f us" % (box, t(lambda: P.SimpleNLF(x, k=29, setting={'mode': 'self'}, box=box), 20)))
+for box in ('two-pass', 'one-pass', 'plain'):
+    print("SimpleNLF collab box=%-8s end to end (incl. host sync): %.1f us" % (box, t(lambda: P.SimpleNLF(x, xc, k=29, setting={'mode': 'collab'}, box=box), 20)))
 
 # K1 / K4
 from yond_public_amd import pipeline as PP

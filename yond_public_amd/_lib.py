@@ -64,6 +64,8 @@ PROTOTYPES = {
     "yond_box_stats_collab_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp],
     "yond_box_stats_self_fused_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
     "yond_box_stats_collab_fused_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
+    "yond_box_stats_self_stats_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp],
+    "yond_box_stats_collab_stats_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
     "yond_select_ws_bytes": [i32],
     "yond_select_ranks_f32": [vp, sz, vp, i32, vp, vp, vp],
     "yond_percentiles_f32": [vp, sz, vp, i32, vp, vp, vp],

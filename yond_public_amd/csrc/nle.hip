@@ -73,10 +73,16 @@ __device__ __forceinline__ float std_from(float b1, float b2) {
 
 // mode 0: self stage 1 (mean, var, blur2 from the Bayer frame); 1: self stage 2 (lap from blur2);
 // 2: collab (mean, var, lap from noisy + denoised Bayer frames)
-template <int MODE>
+// STATS (MODE 0): stage 1 reads every pixel of the frame exactly once as an "own" pixel, so it also collects the frame
+// maximum (lr.max() for the bias LUT grid, YOND_SIDD.py:256/393) into st->frame_max_key.  (Round 2 also tried the first
+// sweep of the threshold selection inside the producers of the lap map: with ~1000 workgroups each flushing its LDS
+// histogram the fold cost 66 us against 62 us for the stand-alone sweep of nle_fast.hip -- not kept.)
+template <int MODE, bool STATS>
 __global__ __launch_bounds__(BS_T) void box_stream_kernel(BoxSrc a, BoxSrc b, BoxGeom g, float* __restrict__ o0,
-                                                         float* __restrict__ o1, float* __restrict__ o2) {
+                                                         float* __restrict__ o1, float* __restrict__ o2, NleState* st) {
+    static_assert(!STATS || MODE == 0, "only stage 1 collects the frame maximum");
     constexpr int NQ = MODE == 0 ? 3 : (MODE == 1 ? 2 : 4);      // running sums per column
+    float fmax_ = -INFINITY;
     constexpr int NI = MODE == 2 ? 2 : 1;                        // input frames
     constexpr int NL = MODE == 0 ? 3 : 2;                        // loads per input and row: entering, leaving (k), leaving (k2)
     __shared__ double s_p[NQ][BS_B][BS_T];
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(BS_T) void box_stream_kernel(BoxSrc a, BoxSrc b, Bo
                 S[2 * i + 1] += (double)__fmul_rn(xn, xn) - (double)__fmul_rn(xo, xo);
             }
             if (MODE == 0) S[2] += (double)cur[0][0][r] - (double)__fmul_rn(cur[0][2][r], mk2);
+            if (STATS) fmax_ = fmaxf(fmax_, cur[0][0][r]);       // halo, idle columns and clamped rows are pixels of the frame too
 #pragma unroll
             for (int q = 0; q < NQ; ++q) P[q * BS_B + r] = S[q];
         }
@@ -215,6 +222,14 @@ __global__ __launch_bounds__(BS_T) void box_stream_kernel(BoxSrc a, BoxSrc b, Bo
         }
         __syncthreads();
     }
+    if constexpr (STATS) {
+        fmax_ = wave_max(fmax_);
+        // ~4000 waves, one word: look first (a coherent load) -- after the first few arrivals nearly nobody has to write
+        if (lane == 0 && fmax_ > -INFINITY) {
+            const unsigned int key = f2key(fmax_);
+            if (key > __hip_atomic_load(&st->frame_max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->frame_max_key, key);
+        }
+    }
 }
 
 static int box_args_ok(int h, int w, int k, int tile_w) {
@@ -226,8 +241,9 @@ static int box_args_ok(int h, int w, int k, int tile_w) {
     return YOND_OK;
 }
 
-template <int MODE>
-static int launch_box(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_w, float* o0, float* o1, float* o2, hipStream_t st) {
+template <int MODE, bool STATS = false>
+static int launch_box(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_w, float* o0, float* o1, float* o2, hipStream_t st,
+                      NleState* state = nullptr) {
     if (k2 > k) return YOND_EUNSUPPORTED;
     BoxGeom g;
     g.h = h; g.w = w; g.k = k; g.k2 = k2; g.tile_w = tile_w;
@@ -248,7 +264,7 @@ static int launch_box(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_
     if (g.oh > h) g.oh = h;
     const int nsy = (h + g.oh - 1) / g.oh;
     dim3 grid((unsigned)(nblk * g.nstrip), (unsigned)nsy, 4);
-    hipLaunchKernelGGL(box_stream_kernel<MODE>, grid, dim3(BS_T), 0, st, a, b, g, o0, o1, o2);
+    hipLaunchKernelGGL((box_stream_kernel<MODE, STATS>), grid, dim3(BS_T), 0, st, a, b, g, o0, o1, o2, state);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -279,6 +295,41 @@ extern "C" int yond_box_stats_collab_f32(const float* bayer_lr, const float* bay
     if (rc) return rc;
     BoxSrc a{bayer_lr, 1}, b{bayer_hr, 1};
     return launch_box<2>(a, b, H / 2, W / 2, k, k, tile_w, mean, var, lap, (hipStream_t)stream);
+}
+
+// The default producers of the estimator: the kernels above (stage 1 also collects the frame maximum) followed by sweep 1 of
+// the threshold selection (nle_fast.hip) on the workspace -- one call per frame.  `blur2` is a scratch plane [4][h][w].
+extern "C" int yond_box_stats_self_stats_f32(const float* bayer, int H, int W, int k, int k2, int tile_w, float* mean, float* var,
+                                             float* blur2, float* lap, const double* q_host, int nq, void* ws, void* stream) {
+    if (!bayer || !mean || !var || !blur2 || !lap || !ws || ((uintptr_t)ws & 15) || (H & 1) || (W & 1)) return YOND_EINVAL;
+    int rc = box_args_ok(H / 2, W / 2, k, tile_w);
+    if (rc) return rc;
+    rc = box_args_ok(H / 2, W / 2, k2, tile_w);
+    if (rc) return rc;
+    const int h = H / 2, w = W / 2;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ws, 0, nf_state_bytes(), st);
+    if (e != hipSuccess) return (int)e;
+    BoxSrc s1{bayer, 1}, s2{blur2, 0}, nb{nullptr, 0};
+    rc = launch_box<0, true>(s1, nb, h, w, k, k2, tile_w, mean, var, blur2, st, (NleState*)ws);
+    if (rc) return rc;
+    rc = launch_box<1>(s2, nb, h, w, k, k, tile_w, lap, nullptr, nullptr, st);
+    if (rc) return rc;
+    return nf_launch_stats(lap, mean, (size_t)4 * h * w, w, q_host, nq, ws, st, false);
+}
+
+extern "C" int yond_box_stats_collab_stats_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,
+                                               float* mean, float* var, float* lap, const double* q_host, int nq, void* ws,
+                                               void* stream) {
+    if (!bayer_lr || !bayer_hr || !mean || !var || !lap || !ws || ((uintptr_t)ws & 15) || (H & 1) || (W & 1)) return YOND_EINVAL;
+    int rc = box_args_ok(H / 2, W / 2, k, tile_w);
+    if (rc) return rc;
+    const int h = H / 2, w = W / 2;
+    hipStream_t st = (hipStream_t)stream;
+    BoxSrc s1{bayer_lr, 1}, s2{bayer_hr, 1};
+    rc = launch_box<2>(s1, s2, h, w, k, k, tile_w, mean, var, lap, st);
+    if (rc) return rc;
+    return nf_launch_stats(lap, mean, (size_t)4 * h * w, w, q_host, nq, ws, st, true);
 }
 
 // =====================================================================================================

@@ -28,17 +28,18 @@
 template <int VEC>
 __global__ __launch_bounds__(512) void nf_stats_kernel(const float* __restrict__ lap, const float* __restrict__ mean, int rows,
                                                        int width, NleState* st, NfArgs a) {
-    extern __shared__ unsigned int s_dyn[];                // [NF_WIN_N] histogram window, [NF_BINS] per-bin ~min key
+    extern __shared__ __attribute__((aligned(16))) unsigned int s_dyn[];                // [NF_WIN_N] histogram window, [NF_BINS] per-bin ~min key
     unsigned int* s_h = s_dyn;
     unsigned int* s_mi = s_dyn + NF_WIN_N;
     const int tid = threadIdx.x;
-    for (int i = tid; i < NF_WIN_N + NF_BINS; i += 512) s_dyn[i] = 0;
+    for (int i = tid; i < (NF_WIN_N + NF_BINS) / 4; i += 512) ((uint4*)s_dyn)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    unsigned int bmask = 0;                                // blocks of 4096 level-1 bins this lane added to in global memory
     auto flush = [&](unsigned int id, unsigned int cnt) {
         if (!cnt) return;
         const unsigned int w = id - NF_WIN_LO;
         if (w < NF_WIN_N) atomicAdd(&s_h[w], cnt);
-        else atomicAdd(&st->hist1[id], cnt);
+        else { atomicAdd(&st->hist1[nf_hpos(id)], cnt); bmask |= 1u << (id >> 12); }
     };
     const int G = (width + VEC - 1) / VEC;
     const int nseg = (rows + NF_SEG - 1) / NF_SEG;
@@ -80,14 +81,22 @@ __global__ __launch_bounds__(512) void nf_stats_kernel(const float* __restrict__
         for (int e = 0; e < VEC; ++e) flush(rid[e], rcnt[e]);
     }
     __syncthreads();
-    for (int i = tid; i < NF_WIN_N; i += 512) {
-        const unsigned int c = s_h[i];
-        if (c) atomicAdd(&st->hist1[NF_WIN_LO + i], c);
+    for (int i = tid; i < NF_WIN_N / 4; i += 512) {        // mostly empty: four bins per look
+        const uint4 c4 = ((const uint4*)s_h)[i];
+        if (c4.x | c4.y | c4.z | c4.w) {
+            const unsigned int cc[4] = {c4.x, c4.y, c4.z, c4.w};
+            bmask |= 1u << ((NF_WIN_LO + 4 * i) >> 12);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (cc[j]) atomicAdd(&st->hist1[nf_hpos(NF_WIN_LO + 4 * i + j)], cc[j]);
+            }
+        }
     }
     for (int i = tid; i < NF_BINS; i += 512) {
         const unsigned int v = s_mi[i];
         if (v) atomicMax(&st->maxinv[i], v);
     }
+    nf_mark_blocks(st, bmask);
     if (nf_arrive_last(&st->ticket[0], gridDim.x)) nf_resolve1(st, a, s_dyn);
 }
 
@@ -375,16 +384,18 @@ int nf_make_args(size_t n, const double* q_host, int nq, NfArgs* a) {   // decla
     return YOND_OK;
 }
 
-extern "C" int yond_nle_stats_f32(const float* lap, const float* mean, size_t n, int width, const double* q_host, int nq,
-                                  void* ws, void* stream) {
+int nf_launch_stats(const float* lap, const float* mean, size_t n, int width, const double* q_host, int nq, void* ws,
+                    hipStream_t st, bool reset) {                       // declared in nle_common.h
     if (!lap || !mean || !ws || n == 0 || n > 0xFFFFFFFFull || ((uintptr_t)ws & 15)) return YOND_EINVAL;
     if (width <= 0 || n % (size_t)width != 0 || n / (size_t)width > 0x7FFFFFFFull) return YOND_EINVAL;
     NfArgs a;
     int rc = nf_make_args(n, q_host, nq, &a);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ws, 0, nf_state_bytes(), st);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
+    if (reset) {
+        e = hipMemsetAsync(ws, 0, nf_state_bytes(), st);
+        if (e != hipSuccess) return (int)e;
+    }
     static bool attr = false;
     const int lds = (NF_WIN_N + NF_BINS) * 4;
     if (!attr) {
@@ -399,12 +410,19 @@ extern "C" int yond_nle_stats_f32(const float* lap, const float* mean, size_t n,
     const int G = vec ? width / 4 : width;
     const size_t nitems = (size_t)G * ((rows + NF_SEG - 1) / NF_SEG);
     size_t nb = (nitems + 511) / 512;
-    if (nb > 512) nb = 512;
+    size_t cap = 256;                                      // one workgroup per CU: fewer flushes onto the same counters (56 vs 61 us at 512)
+    if (const char* ev = getenv("YOND_STATS_WGS")) cap = (size_t)atol(ev);       // experiments only
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     if (vec) hipLaunchKernelGGL(nf_stats_kernel<4>, dim3((unsigned)nb), dim3(512), lds, st, lap, mean, rows, width, (NleState*)ws, a);
     else hipLaunchKernelGGL(nf_stats_kernel<1>, dim3((unsigned)nb), dim3(512), lds, st, lap, mean, rows, width, (NleState*)ws, a);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
+}
+
+extern "C" int yond_nle_stats_f32(const float* lap, const float* mean, size_t n, int width, const double* q_host, int nq,
+                                  void* ws, void* stream) {
+    return nf_launch_stats(lap, mean, n, width, q_host, nq, ws, (hipStream_t)stream, true);
 }
 
 extern "C" int yond_nle_threshold_f32(const float* lap, size_t n, const double* q_host, int nq, int want_score, void* ws,

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) rbin[i] = 0;
     float fmax_ = -INFINITY;
+    unsigned int bmask_ = 0;                                                  // blocks of 4096 level-1 bins this lane added to in global memory
     // statistics of one finished row (all lanes of the wave take part): level-1 histogram with runs of equal bins across
     // the lanes (adjacent columns of the smooth map) merged into one LDS atomic; per mean bin the smallest lap
     // (the four rows of a batch go through each step together, so that their LDS round trips overlap)
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
                 const unsigned int id = key[r] >> 16, wdw = id - BFW_LO;
                 if (wdw < BFW_N) atomicAdd(&s_h[wdw & (BFW_N / 2 - 1)], 1u << ((wdw >> 11) * 16));
                 else if (id == NF_WIN_LO) atomicAdd(&s_h[BFW_N / 2], 1u);                // lap == +0.0
-                else atomicAdd(&st->hist1[id], 1u);
+                else { atomicAdd(&st->hist1[nf_hpos(id)], 1u); bmask_ |= 1u << (id >> 12); }
                 const unsigned int inv = ~key[r];
                 if (inv > known[r]) atomicMax(&s_mi[bin[r]], inv);
             }
@@ -438,10 +439,11 @@ __global__ __launch_bounds__(512) void box_fused_kernel(const float* __restrict_
     __syncthreads();
     for (int i = tid; i < BFW_N / 2; i += 512) {
         const unsigned int c = s_h[i];
-        if (c & 0xFFFFu) atomicAdd(&st->hist1[BFW_LO + i], c & 0xFFFFu);
-        if (c >> 16) atomicAdd(&st->hist1[BFW_LO + BFW_N / 2 + i], c >> 16);
+        if (c & 0xFFFFu) { atomicAdd(&st->hist1[nf_hpos(BFW_LO + i)], c & 0xFFFFu); bmask_ |= 1u << ((BFW_LO + i) >> 12); }
+        if (c >> 16) { atomicAdd(&st->hist1[nf_hpos(BFW_LO + BFW_N / 2 + i)], c >> 16); bmask_ |= 1u << ((BFW_LO + BFW_N / 2 + i) >> 12); }
     }
-    if (tid == 0 && s_h[BFW_N / 2]) atomicAdd(&st->hist1[NF_WIN_LO], s_h[BFW_N / 2]);
+    if (tid == 0 && s_h[BFW_N / 2]) { atomicAdd(&st->hist1[nf_hpos(NF_WIN_LO)], s_h[BFW_N / 2]); bmask_ |= 1u << (NF_WIN_LO >> 12); }
+    nf_mark_blocks(st, bmask_);
     for (int i = tid; i < NF_BINS; i += 512) {
         const unsigned int v = s_mi[i];
         if (v) atomicMax(&st->maxinv[i], v);

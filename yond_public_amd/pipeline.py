@@ -440,11 +440,16 @@ def _key2float(key):
     return np.array([bits], dtype=np.uint32).view(np.float32)[0]
 
 
-def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, fused=True):
+def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, fused=None, box=None):
     """YOND_SIDD.py:117-124 (+ SelfNLF :62-87, CollabNLF :89-115): Bayer frame(s) -> (beta1, beta2).
-    fused (default): one pass over the frame(s) produces the three maps and the first sweep of the threshold selection
-    (nle_fused.hip); fused=False: the stand-alone kernels of the first version (kept for the function seam and as a
-    cross-check).  With full=True the info dict carries 'frame_max' (float32 maximum of lr_raw) on the fused path."""
+    box selects the kernels that produce the three maps:
+      'two-pass' (default)  the streaming box kernels with the first sweep of the threshold selection folded into the
+                            producer of the lap map and the frame maximum into stage 1 (nle.hip, STATS);
+      'one-pass'            one kernel per frame that keeps the B19 map in LDS (nle_fused.hip; k == 29 only);
+      'plain'               the stand-alone kernels of the first version, followed by a separate statistics sweep (kept
+                            for the function seam and as a cross-check).
+    `fused` is the older spelling (True -> 'one-pass', False -> 'plain').  With full=True the info dict carries
+    'frame_max' (float32 maximum of lr_raw) except on the 'plain' path."""
     setting = setting or {'mode': 'self'}
     lib = L.load()
     lr = _dev(lr_raw, device)
@@ -457,17 +462,26 @@ def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, 
     mean, var, lap = new(), new(), new()
     st = L.stream()
     k2 = k // 3 * 2 + 1
-    fused = fused and k == 29                 # the fused kernel is built for the estimator's windows (29, 19)
+    if box is None:
+        box = 'two-pass' if fused is None else ('one-pass' if fused else 'plain')
+    if box == 'one-pass' and k != 29:         # the one-pass kernel is built for the estimator's windows (29, 19)
+        box = 'two-pass'
+    if box not in ('two-pass', 'one-pass', 'plain'):
+        raise ValueError(f"box={box!r}")
     ws = None
     q = np.ascontiguousarray(QUANTS, dtype=np.float64)
     qp = C.c_void_p(q.ctypes.data)
-    if fused:
+    if box != 'plain':
         ws = _nle_workspace(4 * h * w, lr.device)
     if setting['mode'] == 'self':
         with _stage("nle_box_self"):
-            if fused:
+            if box == 'one-pass':
                 L.check(lib.yond_box_stats_self_fused_f32(L.ptr(lr), H, W, k, k2, tile_w, L.ptr(mean), L.ptr(var), L.ptr(lap),
                                                           qp, len(q), L.ptr(ws), st), "yond_box_stats_self_fused_f32")
+            elif box == 'two-pass':
+                blur2 = new()
+                L.check(lib.yond_box_stats_self_stats_f32(L.ptr(lr), H, W, k, k2, tile_w, L.ptr(mean), L.ptr(var), L.ptr(blur2),
+                                                          L.ptr(lap), qp, len(q), L.ptr(ws), st), "yond_box_stats_self_stats_f32")
             else:
                 blur2 = new()
                 L.check(lib.yond_box_stats_self1_f32(L.ptr(lr), H, W, k, k2, tile_w, L.ptr(mean), L.ptr(var), L.ptr(blur2), st),
@@ -478,9 +492,12 @@ def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, 
         if hr.shape != lr.shape:
             raise L.YondHipError("collab NLF needs noisy and denoised frames of the same shape")
         with _stage("nle_box_collab"):
-            if fused:
+            if box == 'one-pass':
                 L.check(lib.yond_box_stats_collab_fused_f32(L.ptr(lr), L.ptr(hr), H, W, k, tile_w, L.ptr(mean), L.ptr(var),
                                                             L.ptr(lap), qp, len(q), L.ptr(ws), st), "yond_box_stats_collab_fused_f32")
+            elif box == 'two-pass':
+                L.check(lib.yond_box_stats_collab_stats_f32(L.ptr(lr), L.ptr(hr), H, W, k, tile_w, L.ptr(mean), L.ptr(var),
+                                                            L.ptr(lap), qp, len(q), L.ptr(ws), st), "yond_box_stats_collab_stats_f32")
             else:
                 L.check(lib.yond_box_stats_collab_f32(L.ptr(lr), L.ptr(hr), H, W, k, tile_w, L.ptr(mean), L.ptr(var), L.ptr(lap), st),
                         "yond_box_stats_collab_f32")
@@ -717,9 +734,9 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
         outs = [Simple_Denoiser(blocks[num], net) for num in range(32)]                # :369-370
         return dict(raw_dns=[torch.cat(outs, dim=-1).contiguous()], regs=(0, 0), params=[])   # :372-378
     raw4est = lr_cat if lr_full is None else _dev(lr_full, lr.device)                  # :340
-    # lr.max() for the bias LUT grid: the fused estimator kernel collects it when it reads the same frame; else a
+    # lr.max() for the bias LUT grid: the estimator's first kernel collects it when it reads the same frame; else a
     # reduction queued ahead of the NLE and read after the NLE's own host sync
-    lr_max_dev = _frame_max(lr_cat) if (lr_full is not None or k != 29) else None
+    lr_max_dev = _frame_max(lr_cat) if lr_full is not None else None
     reg, nle_info = SimpleNLF(raw4est, k=k, setting={'mode': 'self'}, full=True)       # :341
     p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale            # :356
     if log:
@@ -855,9 +872,8 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     def estimate(lr, ready):               # phase 1 on the side stream; returns host scalars only
         side.wait_event(ready)             # the frame as it stood when it was handed in -- NOT the work queued since
         with torch.cuda.stream(side):
-            lr_max_dev = _frame_max(lr) if k != 29 else None
             reg, info = SimpleNLF(lr, k=k, setting={'mode': 'self'}, full=True)
-            lr_max = np.float32(lr_max_dev.item()) if lr_max_dev is not None else np.float32(info['frame_max'])
+            lr_max = np.float32(info['frame_max'])
         return lr, reg, lr_max
 
     it = iter(frames)

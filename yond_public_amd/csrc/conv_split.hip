@@ -146,15 +146,32 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         int goff[C::NIN];                      // pixel offset into the NHWC source (-1: outside the image -> zeros)
         int goff1[K1 ? C::NIN : 1];            // K1: pixel offset into src1, the skip tensor at the OUTPUT resolution, read at
     };                                         // the sub-position (dy, dx) this tile's channel block stores to
-    auto decode = [&](int t, Tile& T) {
-        const int n = t / tiles_per_img;
-        int b = t - n * tiles_per_img;
+    // A cursor walks the tiles lslot, lslot + G, ...: its position is kept as the digits (n, ty, tx, ct) of the tile index
+    // and advanced by adding the digits of G with carries -- scalar compares instead of four integer divisions per tile
+    // (they sat in the middle of the MFMA stretch of every tile's last step).
+    struct Cur { int tile, ch, ct, tx, ty, n; };
+    int g_ct, g_tx, g_ty, g_n;
+    {
+        int b = G;
+        g_ct = b % nct; b /= nct;
+        g_tx = b % ntx; b /= ntx;
+        g_ty = b % nty; g_n = b / nty;
+    }
+    auto cursor_at = [&](int t) {                // once per workgroup
+        Cur c;
+        c.tile = t; c.ch = 0;
+        int b = t;
+        c.ct = b % nct; b /= nct;
+        c.tx = b % ntx; b /= ntx;
+        c.ty = b % nty; c.n = b / nty;
+        return c;
+    };
+    auto decode = [&](const Cur& c, Tile& T) {
+        const int n = c.n;
         T.n = n;
-        T.ct = b % nct;
-        b /= nct;
-        const int tx = b % ntx, ty = b / ntx;
-        T.ox0 = tx * 32;
-        T.oy0 = ty * TH;
+        T.ct = c.ct;
+        T.ox0 = c.tx * 32;
+        T.oy0 = c.ty * TH;
 #pragma unroll
         for (int k = 0; k < C::NIN; ++k) {
             const int it = tid + k * C::NT;
@@ -561,32 +578,40 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
 
     // ---- the step pipeline: ONE barrier per step ----
-    struct Cur { int tile, ch; };
     auto adv = [&](Cur c) {
-        Cur n;
+        Cur n = c;
         const bool last = c.ch + 1 == nchunk;
-        n.tile = last ? c.tile + G : c.tile;
         n.ch = last ? 0 : c.ch + 1;
+        if (last) {
+            n.tile = c.tile + G;
+            int v = c.ct + g_ct, cy = v >= nct ? 1 : 0;
+            n.ct = v - (cy ? nct : 0);
+            v = c.tx + g_tx + cy; cy = v >= ntx ? 1 : 0;
+            n.tx = v - (cy ? ntx : 0);
+            v = c.ty + g_ty + cy; cy = v >= nty ? 1 : 0;
+            n.ty = v - (cy ? nty : 0);
+            n.n = c.n + g_n + cy;
+        }
         return n;
     };
     if (lslot >= total) return;
     if constexpr (O4) {
         if (tid < 128) smem[C::W4_OFF + tid] = d.out4_w[tid];                    // visible behind the prologue's barrier
     }
-    Cur cs = {lslot, 0};                       // step being computed
+    Cur cs = cursor_at(lslot);                 // step being computed
     Tile cur;                                   // its tile (epilogue)
     Tile lt;                                    // tile of the load cursor
     int lt_tile = -1;
-    decode(cs.tile, cur);
+    decode(cs, cur);
     zero_acc();
     float* ibuf = smem;                         // input(s)
     float* obuf = smem + C::IN_FLOATS;          // receives input(s+1)
     float* w0 = smem + 2 * C::IN_FLOATS;        // weights(s)
     float* w1 = w0 + C::W_FLOATS;               // weights(s+1)  (two buffers: receives them)
     float* w2 = w1 + (NWB == 3 ? C::W_FLOATS : 0);   // three buffers: receives weights(s+2)
-    auto ct_of = [&](Cur c, int fallback) { return c.tile < total ? (c.tile % tiles_per_img) % nct : fallback; };
+    auto ct_of = [&](Cur c, int fallback) { return c.tile < total ? c.ct : fallback; };
     auto tile_for = [&](Cur c) {                // steps past the end re-read the last decoded tile (harmless)
-        if (c.tile < total && c.tile != lt_tile) { decode(c.tile, lt); lt_tile = c.tile; }
+        if (c.tile < total && c.tile != lt_tile) { decode(c, lt); lt_tile = c.tile; }
     };
     auto load_all = [&](auto pc, Cur c) {
         tile_for(c);
@@ -674,13 +699,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             SDBG(7);
             zero_acc();
             if (cn.tile < total) {
-                const int n = cn.tile / tiles_per_img;
-                int bq = cn.tile - n * tiles_per_img;
-                cur.n = n;
-                cur.ct = bq % nct;
-                bq /= nct;
-                cur.ox0 = (bq % ntx) * 32;
-                cur.oy0 = (bq / ntx) * TH;
+                cur.n = cn.n;
+                cur.ct = cn.ct;
+                cur.ox0 = cn.tx * 32;
+                cur.oy0 = cn.ty * TH;
             }
         }
         SDBG(5);

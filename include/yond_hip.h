@@ -248,11 +248,11 @@ int yond_box_stats_self_fused_f32(const float* bayer, int H, int W, int k, int k
 int yond_box_stats_collab_fused_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,
                                     float* mean, float* var, float* lap, const double* q_host, int nq, void* ws, void* stream);
 
-/* K5+ the two (one) streaming kernels of K5 with the same statistics folded in: stage 1 of the self mode also collects the
- * frame maximum, and the kernel that writes the lap map (stage 2 / collab) also runs sweep 1 of the threshold selection
- * and resolves the percentile ranks in the workgroup that finishes last.  Same results and same workspace contract as
- * K5'; `blur2` [4][H/2][W/2] is scratch (the B19 map).  The default of SimpleNLF: fewer instructions per pixel than K5'
- * at 32 B/px more HBM traffic, which the estimator (issue-bound, not HBM-bound) does not notice.  Any k that K5 takes. */
+/* K5+ the hot-path producers of the estimator, one call per frame: the streaming kernels of K5 (stage 1 of the self mode also
+ * collects the frame maximum into the workspace head) followed by sweep 1 of the threshold selection (yond_nle_stats_f32
+ * below) on the same workspace, which this call resets first.  Same results and same workspace contract as K5';
+ * `blur2` [4][H/2][W/2] is scratch (the B19 map).  The default of SimpleNLF: fewer instructions per pixel than K5' at
+ * 32 B/px more HBM traffic, which the estimator (issue-bound, not HBM-bound) does not notice.  Any k that K5 takes. */
 int yond_box_stats_self_stats_f32(const float* bayer, int H, int W, int k, int k2, int tile_w, float* mean, float* var,
                                   float* blur2, float* lap, const double* q_host, int nq, void* ws, void* stream);
 int yond_box_stats_collab_stats_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,

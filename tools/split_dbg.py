@@ -14,7 +14,7 @@ x = torch.randn(1, h, w, Cc, device='cuda'); dst = torch.empty(1, h, w, Cc, devi
 for _ in range(3):
     plan._conv(pc, x, None, 1, h, w, dst, pre_act=1)
 torch.cuda.synchronize()
-buf = np.zeros((2, 64, 8), np.uint64)
+buf = np.zeros((2, 64, 12), np.uint64)
 lib._FuncPtr  # noqa
 f = C.CDLL(os.environ["YOND_HIP_LIB"]).yond_split_debug_read
 f.argtypes = [C.c_void_p]; f.restype = C.c_int
@@ -27,4 +27,5 @@ for wv in range(2):
         r = t[wv, sidx]
         nxt = t[wv, sidx + 1][0]
         extra = "  epilogue %d, barrier behind it %d, rest %d" % (r[6] - r[4], r[7] - r[6], r[5] - r[7]) if r[6] > r[4] and r[5] - r[4] > 1000 else ""
-        print(" %3d %6d %6d %6d %5d %5d | %6d%s" % (sidx, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], nxt - r[0], extra))
+        q = "  quarters of the MFMA stretch %d %d %d %d" % (r[8] - r[1], r[9] - r[8], r[10] - r[9], r[2] - r[10])
+        print(" %3d %6d %6d %6d %5d %5d | %6d%s%s" % (sidx, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], nxt - r[0], q, extra))

@@ -483,17 +483,29 @@ __global__ __launch_bounds__(256) void nlf_moments_kernel(const float* __restric
     };
     const size_t nvec = vec_ok ? n / 4 : 0;
     const size_t stride = (size_t)gridDim.x * 256;
+    // lap first: the selected pixels (a low percentile of a smooth map) cluster, so most waves find nothing below the
+    // threshold in their 256 elements and never read mean / var there (144 MB -> lap + the selected neighbourhoods)
     for (size_t v = (size_t)blockIdx.x * 256 + tid; v < nvec; v += stride * MOM_UNROLL) {
         f32x4 L[MOM_UNROLL], M[MOM_UNROLL], V[MOM_UNROLL];
+        bool take[MOM_UNROLL];
 #pragma unroll
         for (int u = 0; u < MOM_UNROLL; ++u) {
             const size_t vu = v + u * stride;
-            const size_t idx = (vu < nvec ? vu : v) * 4;
-            L[u] = *(const f32x4*)(lap + idx); M[u] = *(const f32x4*)(mean + idx); V[u] = *(const f32x4*)(var + idx);
+            L[u] = *(const f32x4*)(lap + (vu < nvec ? vu : v) * 4);
         }
 #pragma unroll
         for (int u = 0; u < MOM_UNROLL; ++u) {
-            if (v + u * stride < nvec) {
+            const bool mine = v + u * stride < nvec && (L[u][0] < tl || L[u][1] < tl || L[u][2] < tl || L[u][3] < tl);
+            take[u] = __ballot(mine) != 0ull;                               // wave-uniform
+            if (take[u]) {
+                const size_t vu = v + u * stride;
+                const size_t idx = (vu < nvec ? vu : v) * 4;
+                M[u] = *(const f32x4*)(mean + idx); V[u] = *(const f32x4*)(var + idx);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MOM_UNROLL; ++u) {
+            if (take[u] && v + u * stride < nvec) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) add(L[u][e], M[u][e], V[u][e]);
             }
@@ -582,7 +594,9 @@ static int launch_moments(const float* lap, const float* mean, const float* var,
     }
     const int vec_ok = !(((uintptr_t)lap | (uintptr_t)mean | (uintptr_t)var) & 15);
     size_t nb = (n / 4 + 256 * MOM_UNROLL - 1) / (256 * MOM_UNROLL);
-    if (nb > 2048) nb = 2048;
+    size_t cap = 512;                                      // two workgroups per CU: 24.7 us (41 at 2048: ten same-line atomics per workgroup)
+    if (const char* ev = getenv("YOND_MOM_WGS")) cap = (size_t)atol(ev);        // experiments only
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(nlf_moments_kernel, dim3((unsigned)nb), dim3(256), 0, st, lap, mean, var, n, vec_ok, th, mom);
     YOND_LAUNCH_CHECK();

@@ -237,6 +237,35 @@ def test_two_sweep_threshold_selection(shape):
     assert int(sel[0]) == info['index'] and sel[1] == th and sel[2] == pct
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_two_sweep_selection_wide_dynamic_range(seed):
+    """The level-1 histogram is stored transposed inside blocks of 4096 bins and the resolve reads only the blocks the
+    writers marked: data that spreads over MANY blocks (negative values, denormals, 1e-30 ... 1e30, +-0, exact
+    duplicates across block borders) must still give np.percentile bit for bit, and the reference's npeaks / index."""
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    rng = np.random.default_rng(100 + seed)
+    shape = (257, 1003) if seed else (64, 4096)
+    n = int(np.prod(shape))
+    expo = rng.uniform(-30, 30, n) if seed < 2 else rng.uniform(-3, 1, n)
+    lap = (np.float32(10.0) ** expo.astype(np.float32)).astype(np.float32)
+    lap[rng.random(n) < 0.2] *= np.float32(-1.0)                     # keys below 0x80000000: the lower eight blocks
+    lap[rng.random(n) < 0.05] = 0.0
+    lap[rng.random(n) < 0.01] = -0.0
+    lap[::11] = np.float32(2.0) ** np.float32(-14)                   # first bin of a block (key 0xB880 0000 >> 16 = 0xB880)
+    lap[1::13] = np.nextafter(np.float32(2.0) ** np.float32(-14), np.float32(0))   # last bin of the block below
+    lap[5] = np.float32(1e-42)                                        # a denormal
+    lap = lap.reshape(shape)
+    mean = (rng.random(n).astype(np.float32) * 1.2 - 0.1).reshape(shape)
+    quants = np.linspace(5, 100, 20)
+    ths, npeaks, sel, _ = P._threshold_state(torch.from_numpy(lap).to(DEV), torch.from_numpy(mean).to(DEV), quants)
+    ref = np.percentile(lap.reshape(-1), quants, method='linear')
+    assert np.array_equal(ths, ref), (ths, ref)
+    th, pct, info = O.get_threshold_score3(lap.reshape(-1), mean.reshape(-1), step=5, full=True)
+    np.testing.assert_array_equal(npeaks, info['npeaks'].astype(np.int64))
+    assert int(sel[0]) == info['index'] and sel[1] == th and sel[2] == pct
+
+
 def test_two_sweep_selection_constant_and_full_frame_property():
     """Degenerate data (one level-1 bin holds everything: every element is a candidate) and, at the full cfg-2 size, a
     size-independent property: the selected threshold splits the data at its quantile."""

@@ -121,7 +121,7 @@ typedef struct YondConvDesc {
     int stride;           /* 1 or 2 (2 only with ksize 3) */
     int shuffle;          /* 1: convT 2x2 s2 store, dst is [N][2Ho][2Wo][Cout/4] */
     int pre_act;          /* 0 none, 1 SiLU applied to the staged input */
-    int post_act;         /* 0 none, 1 SiLU, 2 LeakyReLU(slope) */
+    int post_act;         /* 0 none, 1 SiLU (algo 3 / 4, 3x3 only: the stored tensor is the consumer's SiLU input), 2 LeakyReLU(slope) */
     float slope;
     const float* wpk;     /* packed weights */
     const float* escale;  /* [ebatch ? N : 1][Cout'] or NULL (=1) ; Cout' = real Cout */

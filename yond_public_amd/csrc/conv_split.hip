@@ -394,6 +394,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // reads them back with 8 lanes per pixel: a global instruction then covers 8 whole 128-byte lines, FiLM vectors are
     // one float4 per lane, and nothing is shared between waves (no barrier inside).
     const float slope_eff = d.post_act == 2 ? d.slope : 1.0f;
+    // post_act 1: SiLU of the stored value -- the block-internal tensor of a residual block has ONE consumer, whose staging
+    // would otherwise apply the same SiLU once per output-channel tile (Cout / 64 times at the deeper levels)
+    const bool silu_out = d.post_act == 1;
     constexpr int EPS = 36;                                   // floats per pixel of the scratch
     constexpr int EP_FLOATS = 8 * 32 * EPS;                   // 36,864 bytes: one weight buffer (TN 64) or part of an input image
     // (stride 2: short steps, no residual -- measured slower with the transpose and its extra barrier: 211 vs 175 us at level 0)
@@ -488,6 +491,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                         for (int e = 0; e < 4; ++e) {
                             float y = fmaf(x[e], es[e], et[e]);
                             y = y > 0.0f ? y : y * slope_eff;
+                            if (silu_out) y = split_silu(y);
                             v[e] = y + rr[mm][j][e];
                         }
                         if constexpr (OUT4) {
@@ -569,6 +573,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                         if constexpr (PARTS == 2) x = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, x);
                         x = fmaf(x, es[g][e], et[g][e]);
                         x = x > 0.0f ? x : x * slope_eff;
+                        if (silu_out) x = split_silu(x);
                         v[e] = x + rr[m][g][e];
                     }
                     if (ok) *(f32x4*)(op + 8 * g) = v;
@@ -807,10 +812,10 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     const int tn = yond_conv_split_supported(d.ksize, d.stride, d.C0 + d.C1, d.Cout);
     if (!tn || d.C0 % 16 != 0 || d.C1 % 16 != 0 || (d.shuffle != 0) != (d.ksize == 1)) return YOND_EUNSUPPORTED;
     if (d.tn != tn) return YOND_EINVAL;                         // the layout the weights were packed for
-    if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
+    if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
     if (d.ksize == 1) {
         // the decoder GEMM: low-resolution input (C0) + skip tensor at the output resolution (C1), pixel-shuffle store
-        if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.Ho != d.H || d.Wo != d.W) return YOND_EUNSUPPORTED;
+        if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W) return YOND_EUNSUPPORTED;
         if (tn == 32) return launch_split<1, 8, 32, 1, 2, 3, false, false, true>(d, st);    // level 1 -> 0: 32-channel output pixels
         return launch_split<1, 8, 64, 2, 2, 3, false, false, true>(d, st);
     }
@@ -820,7 +825,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         return parts == 2 ? launch_split<2, 4, 64, 1, 2, 2, false>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false>(d, st);
     }
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
-    if (d.post_act != 0 && d.post_act != 2) return YOND_EUNSUPPORTED;
+    if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
     if (d.out4_dst && (tn != 32 || parts != 2)) return YOND_EUNSUPPORTED;
     if (tn == 64) {
         // 12 x 32-pixel tiles, three rows per wave: 0.59 instead of 0.78 KiB of LDS fragments per MFMA, 1.5x the MFMA work per

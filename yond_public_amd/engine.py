@@ -240,6 +240,19 @@ class DenoiserPlan:
         return wp.to(self.dev).contiguous()
 
     # -- launches ----------------------------------------------------------------------------
+    def _split_pair(self, pc1, pc2):
+        """Both 3x3 layers of a residual block run on the split-operand kernel (algo 3, or 4 on the fp16 path): the SiLU
+        between them may then sit in the producer's epilogue (descriptor post_act 1)."""
+        if getattr(self, 'strict', False) or getattr(self, 'conv_algo', WINO_DEFAULT) != 'split':
+            return False
+        if os.environ.get('YOND_SILU_PRODUCER', '1') == '0':          # experiments: the SiLU back in the consumer's staging
+            return False
+        prec = getattr(self, 'precision', 'fp32')
+        if prec not in ('fp32', 'fp16'):
+            return False
+        parts = 2 if prec == 'fp32' else 1
+        return all(pc.ksize == 3 and pc.stride == 1 and pc.split(parts) is not None for pc in (pc1, pc2))
+
     def _out4_fusable(self, pc):
         """The 1x1 output projection can ride in the epilogue of the last 3x3 convolution: split kernel, one 32-channel tile."""
         return (not getattr(self, 'strict', False) and getattr(self, 'conv_algo', WINO_DEFAULT) == 'split' and getattr(self, 'precision', 'fp32') == 'fp32'
@@ -426,17 +439,21 @@ class DenoiserPlan:
                     h, w = 2 * h, 2 * w
                     cur = xs
                 tmp = self._new(N, h, w, cp)
-                # z = conv2(SiLU(FiLM(conv1(SiLU(x))))) + x : both SiLUs run in the consumers' staging (hidden under
-                # the MFMAs), the epilogues only scale/shift (+ residual)
-                self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1)
+                # z = conv2(SiLU(FiLM(conv1(SiLU(x))))) + x : the first SiLU runs in conv1's staging (x has other readers); the
+                # second in conv1's EPILOGUE where both layers run on the split kernel -- tmp has one reader, whose staging
+                # would repeat it once per output-channel tile (bit-identical: the same fp32 function of the same value)
+                act_in_producer = self._split_pair(blk['conv1'], blk['conv2'])
+                self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1,
+                           post_act=1 if act_in_producer else 0)
+                pre2 = 0 if act_in_producer else 1
                 if i == 9 and self._out4_fusable(blk['conv2']):
                     # the last block's output feeds only the 1x1 output projection: computed in this epilogue, never stored
                     out4 = self._new(N, H, W, 4)
-                    self._conv(blk['conv2'], tmp, None, N, h, w, None, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=1,
+                    self._conv(blk['conv2'], tmp, None, N, h, w, None, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2,
                                out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4))
                     return out4
                 out = self._new(N, h, w, cp)
-                self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=1)
+                self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2)
                 cur = out
                 if i <= 4:
                     skips[i] = cur

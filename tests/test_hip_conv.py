@@ -169,6 +169,32 @@ def test_conv3x3_split_fused_two_source():
     assert report("split conv3x3 two-source", got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("C,H,W", [(32, 40, 70), (64, 50, 96), (128, 24, 64)])
+def test_conv3x3_split_silu_epilogue(C, H, W):
+    """Descriptor post_act 1: SiLU of the stored value (the inner activation of a residual block in conv1's epilogue).
+    conv(post_act 1) followed by conv(pre_act 0) must equal conv(post_act 0) followed by conv(pre_act 1) bit for bit --
+    the same fp32 function of the same value -- and match the float64 block; other kernels refuse the flag."""
+    g = torch.Generator().manual_seed(C + W)
+    N = 2
+    x = torch.randn(N, C, H, W, generator=g)
+    w1 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    es, et = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
+    xd = nhwc(x).to(DEV)
+    kw = dict(escale=es.to(DEV), eshift=et.to(DEV), ebatch=1, pre_act=1, algo='split')
+    t_act = run_conv(w1, None, 3, 1, [C], [xd], N, H, W, post_act=1, **kw)
+    t_raw = run_conv(w1, None, 3, 1, [C], [xd], N, H, W, **kw)
+    out_a = run_conv(w2, None, 3, 1, [C], [t_act.to(DEV)], N, H, W, res=xd, algo="split")
+    out_b = run_conv(w2, None, 3, 1, [C], [t_raw.to(DEV)], N, H, W, res=xd, pre_act=1, algo="split")
+    assert torch.equal(out_a, out_b)
+    z = F.conv2d(F.silu(x.double()), w1.double(), padding=1) * es.double()[:, :, None, None] + et.double()[:, :, None, None]
+    assert report(f"split conv3x3 SiLU epilogue C{C}", nchw(t_act), F.silu(z)) < 2e-5
+    ref = F.conv2d(F.silu(z), w2.double(), padding=1) + x.double()
+    assert report(f"residual block with the SiLU in the producer C{C}", nchw(out_a), ref) < 4e-5
+    with pytest.raises(Exception):
+        run_conv(w1, None, 3, 1, [C], [xd], N, H, W, post_act=1, algo=0)
+
+
 def test_conv3x3_split_fused_12_row_tiles():
     """FiLM + SiLU + LeakyReLU + residual on a layer large enough for the 12 x 32-pixel tile shape (partial tiles both ways)."""
     g = torch.Generator().manual_seed(19)

@@ -462,11 +462,15 @@ def main(argv=None):
                            "measured": "HIP events around every convolution launch, one instrumented pass after the timed region"},
             "psnr_vs_clean_db": {"denoised": round(red["psnr_last"], 3), "noisy_input": round(10 * np.log10(1.0 / mse_in), 3)},
             "estimated_K_sigma": [[round(float(v), 4) for v in pr] for pr in (res['params'] if not a.batch else res['params'][-1])],
+            # torch.distributed traffic of this run (a process group exists whenever the torchrun environment is set,
+            # world size 1 included): barrier + max-over-ranks of the timing + the PSNR reduction
+            "collectives": dict(D.STATS),
         }
         if world == 1 and not a.no_cpu_baseline and not a.batch:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline_and_parity(a, arch, dev, make_net)
         print(json.dumps(out), flush=True)
     D.barrier()
+    D.finalize()
 
 
 if __name__ == "__main__":

@@ -25,7 +25,8 @@ extern "C" {
 #define YOND_EINVAL (-1)      /* bad pointer / size / flag */
 #define YOND_EUNSUPPORTED (-2) /* valid request the kernels do not cover (e.g. channel count) */
 
-/* Library / device probe.  Returns the ABI version (this header: 1). */
+/* Library / device probe.  Returns the ABI version (this header: YOND_ABI_VERSION; the loader refuses a mismatch). */
+#define YOND_ABI_VERSION 3
 int yond_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -155,8 +156,24 @@ typedef struct YondConvDesc {
        result silently wrong).  The caller zeroes it, reads it after the forward and falls back to the fp32-input MFMA
        kernels (algo 0 / 1).  Weights are checked by the packing functions (YOND_EUNSUPPORTED). */
     unsigned int* status;
+    /* Tensor formats (algo 3 only; 0 = [N][H][W][C] float32, the default everywhere).
+       1 = SPLIT PLANES: what the consumer's LDS staging holds, stored once by the producer -- every value a (after the
+       consumer's pre-activation, which the PRODUCER applies: post_act) as the half pair h = fp16(a), l = fp16((a - h) 2^11),
+       laid out [N][C/16][channel half 0..1][part h, l][YOND_SP_PLANE_UNITS(H, W)] in units of 16 bytes = 8 consecutive
+       channels of one pixel, pixel index y*W + x; the units behind H*W of every plane are a zero pad that the CALLER
+       zeroes once (producers never write it; consumers read conv zero padding from it).  A consumer (in_fmt 1: src0 and
+       src1, pre_act must be 0) stages its input by LDS-DMA alone; a producer (out_fmt 1: dst, 3x3 stride 1, no res,
+       no fused projection) stores from the accumulator layout without an LDS transpose.  Bit-identical to staging the
+       float32 tensor (the same split of the same float32 value). */
+    int in_fmt, out_fmt;
 } YondConvDesc;
 #define YOND_STATUS_HALF_OVERFLOW 1u
+#define YOND_FMT_NHWC_F32 0
+#define YOND_FMT_SPLIT_PLANES 1
+/* 16-byte units per plane of a split-plane tensor: H*W pixels + at least one zero unit, rounded to 128 bytes */
+#define YOND_SP_PLANE_UNITS(H, W) ((((H) * (W)) + 8) / 8 * 8)
+/* bytes of a split-plane tensor of C channels (C a multiple of 16) */
+#define YOND_SP_BYTES(N, C, H, W) ((size_t)(N) * ((C) / 16) * 4 * (size_t)YOND_SP_PLANE_UNITS(H, W) * 16)
 
 /* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.
  * N, Ho, Wo (GEMM-M extent; 0 = unknown) let the library pick the tn that fills its persistent grid best. */

@@ -195,6 +195,77 @@ def test_conv3x3_split_silu_epilogue(C, H, W):
         run_conv(w1, None, 3, 1, [C], [xd], N, H, W, post_act=1, algo=0)
 
 
+def sp_decode(sp, N, C, H, W):
+    """A split-plane tensor (YondConvDesc out_fmt 1) back to [N][C][H][W] float64: h + l * 2^-11; also returns the pad units."""
+    from yond_public_amd.engine import sp_plane_units
+    ps = sp_plane_units(H, W)
+    u = sp.cpu().view(torch.float16).reshape(N, C // 16, 2, 2, ps, 8)
+    v = u[..., :H * W, :].double()
+    val = v[:, :, :, 0] + v[:, :, :, 1] / 2048.0                      # [N][C/16][half][H*W][8]
+    val = val.permute(0, 1, 2, 4, 3).reshape(N, C, H, W)               # channel = c16*16 + half*8 + j
+    return val, u[..., H * W:, :]
+
+
+@pytest.mark.parametrize("C,N,H,W,out4", [(64, 2, 40, 70, False), (128, 1, 380, 100, False), (32, 2, 50, 75, False), (32, 1, 37, 70, True),
+                                          (256, 1, 30, 61, False)])
+def test_conv3x3_split_planes_pair(C, N, H, W, out4):
+    """The block-internal tensor of a residual block in SPLIT PLANES: conv1 stores SiLU(FiLM(conv1)) as the (h, l) halves its
+    consumer would stage (out_fmt 1), conv2 stages them by LDS-DMA alone (in_fmt 1).  The pair must equal the float32-NHWC
+    pair BIT FOR BIT (the same split of the same float32 value), the stored planes must decode to the NHWC tensor to 2^-22,
+    the zero pads must stay zero; every tile shape of the kernel (8 / 12 / 16-row tiles, partial tiles, batch), with and without
+    the fused output projection."""
+    from yond_public_amd.engine import _PackedConv, DenoiserPlan, sp_plane_units
+    from yond_public_amd import _lib as L
+    g = torch.Generator().manual_seed(C + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w1 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    es, et = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
+    es2, et2 = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
+    xd = nhwc(x).to(DEV)
+    plan = DenoiserPlan.__new__(DenoiserPlan)
+    plan.lib, plan.dev = L.load(), torch.device(DEV)
+    pc1 = _PackedConv(plan.dev, w1, None, 3, 1, [C])
+    pc2 = _PackedConv(plan.dev, w2, None, 3, 1, [C])
+    kw1 = dict(escale=es.to(DEV), eshift=et.to(DEV), ebatch=1, pre_act=1, post_act=1, algo='split')
+    kw2 = dict(escale=es2.to(DEV), eshift=et2.to(DEV), ebatch=1, res=xd, algo='split')
+    t_nhwc = torch.full((N, H, W, C), float('nan'), device=DEV)
+    plan._conv(pc1, xd, None, N, H, W, t_nhwc, **kw1)
+    t_sp = plan._new_sp('t', N, H, W, C)
+    plan._conv(pc1, xd, None, N, H, W, t_sp, out_fmt=1, **kw1)
+    if out4:
+        w4 = (torch.randn(4, C, generator=g) / C ** 0.5).to(DEV)
+        b4 = torch.randn(4, generator=g).to(DEV)
+        xin = torch.rand(N, H, W, 4, generator=g).to(DEV)
+        ub = (torch.rand(N, generator=g) + 0.5).to(DEV)
+        o_a = torch.full((N, H, W, 4), float('nan'), device=DEV)
+        o_b = torch.full((N, H, W, 4), float('nan'), device=DEV)
+        plan._conv(pc2, t_nhwc, None, N, H, W, None, out4=(w4, b4, xin, ub, o_a), **kw2)
+        plan._conv(pc2, t_sp, None, N, H, W, None, out4=(w4, b4, xin, ub, o_b), in_fmt=1, **kw2)
+    else:
+        o_a = torch.full((N, H, W, C), float('nan'), device=DEV)
+        o_b = torch.full((N, H, W, C), float('nan'), device=DEV)
+        plan._conv(pc2, t_nhwc, None, N, H, W, o_a, **kw2)
+        plan._conv(pc2, t_sp, None, N, H, W, o_b, in_fmt=1, **kw2)
+    torch.cuda.synchronize()
+    val, pads = sp_decode(t_sp, N, C, H, W)
+    assert not pads.view(torch.int16).any()
+    ref_t = nchw(t_nhwc.cpu()).double()
+    assert float((val - ref_t).abs().max()) <= 2.0 ** -21 * max(1.0, float(ref_t.abs().max()))
+    assert torch.equal(o_a.cpu(), o_b.cpu()), float((o_a - o_b).abs().max())
+    if not out4:
+        z = F.conv2d(F.silu(x.double()), w1.double(), padding=1) * es.double()[:, :, None, None] + et.double()[:, :, None, None]
+        ref = F.conv2d(F.silu(z), w2.double(), padding=1) * es2.double()[:, :, None, None] + et2.double()[:, :, None, None] + x.double()
+        assert report(f"residual block through split planes C{C} {H}x{W}", nchw(o_b.cpu()), ref) < 6e-5
+    # refused where it is not built: other kernels, a pre-activation on split-plane input, a residual on split-plane output
+    with pytest.raises(Exception):
+        plan._conv(pc2, t_sp, None, N, H, W, o_b if not out4 else torch.empty(N, H, W, C, device=DEV), in_fmt=1, algo=0)
+    with pytest.raises(Exception):
+        plan._conv(pc2, t_sp, None, N, H, W, torch.empty(N, H, W, C, device=DEV), in_fmt=1, pre_act=1, algo='split')
+    with pytest.raises(Exception):
+        plan._conv(pc1, xd, None, N, H, W, t_sp, out_fmt=1, res=xd, algo='split')
+
+
 def test_conv3x3_split_fused_12_row_tiles():
     """FiLM + SiLU + LeakyReLU + residual on a layer large enough for the 12 x 32-pixel tile shape (partial tiles both ways)."""
     g = torch.Generator().manual_seed(19)

@@ -139,6 +139,42 @@ def test_two_rank_rccl_metric_reduction(tmp_path):
     assert abs(r["red"]["psnr_last"] - sum(41.0 + k for k in range(7)) / 7) < 1e-12
 
 
+def _torchrun_one_rank(args, cwd, port):
+    """Run a driver as a CHILD job under torchrun with ONE rank, backend "nccl" (= RCCL): the process group, the barrier and
+    the all-reduces are the very calls an eight-GPU node executes.  (A child: never re-exec a process that touched the GPU.)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    out = subprocess.run(cmd, env=env, cwd=str(cwd), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    return out
+
+
+def test_bench_one_rank_under_torchrun_runs_rccl(tmp_path):
+    """bench.py as the driver launches it for N > 1, with N = 1: a process group on backend nccl, barrier + max-over-ranks +
+    the PSNR all-reduce really issued (counted), one JSON line with n_gpus 1."""
+    out = _torchrun_one_rank([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--min-warmup-s", "0",
+                              "--frames-per-step", "2", "--no-extras", "--no-cpu-baseline"], tmp_path, 29541)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["value"] > 0
+    assert r["collectives"]["backend"] == "nccl"
+    assert r["collectives"]["all_reduce"] >= 2 and r["collectives"]["barrier"] >= 2
+
+
+def test_yond_sidd_one_rank_under_torchrun_runs_rccl(tmp_path):
+    """`YOND_SIDD.py -m eval --synthetic 2` under torchrun --nproc-per-node 1: the metric reduction is an RCCL all-reduce."""
+    out = _torchrun_one_rank([os.path.join(ROOT, "YOND_SIDD.py"), "-f", RUNFILE, "-m", "eval", "--synthetic", "2"], tmp_path, 29542)
+    text = out.stdout
+    assert "2 images on 1 GPU(s)" in text, text[-2000:]
+    line = [l for l in text.splitlines() if "collectives:" in l][-1]
+    assert "backend=nccl" in line
+    assert int(line.split("all_reduce=")[1].split(",")[0]) >= 2
+
+
 def test_rot90_kernel_and_rot_cfa_pipeline(golden):
     """N3: the rot90 copy kernel (bit exact vs np.rot90) and IterDenoise with p['rot_cfa'] (YOND_SIDD.py:402-404, 462-464)
     against the reference's own run on a GBRG image (tests/golden/rot.npz)."""

@@ -120,6 +120,16 @@ def test_split_path_range_guard():
         outs = list(P.denoise_stream([x, x.clone()], net, arch, pipe))
     assert len(outs) == 2 and all(bool(torch.isfinite(o['raw_dns'][0]).all()) for o in outs)
     assert sum("fp16's range" in str(w.message) for w in wlist) == 2
+    # the archs plugin surface `net(x, t)` (engine.DenoiserPlan.forward_nchw) is guarded as well: same network, NCHW input
+    xn = torch.rand((1, 4, 64, 96), generator=torch.Generator().manual_seed(3))
+    tn = torch.tensor(0.04)
+    refn = O.net_forward(arch, sd, xn, tn).numpy()
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            yn = net(xn.to(DEV), tn.to(DEV)).cpu().numpy()
+    assert any("fp16's range" in str(w.message) for w in wlist)
+    assert np.isfinite(yn).all() and report("guarded net(x, t) vs oracle", yn, refn) <= 2e-4 * max(1.0, float(np.abs(refn).max()))
     # a well-scaled network does not trip it
     net2, _ = make_net(arch, 9)
     with warnings.catch_warnings(record=True) as wlist:

@@ -188,6 +188,7 @@ class YOND_SIDD:
             log(f"Iter_last: PSNR={red['psnr_last']:.2f}, SSIM={red['ssim_last']:.4f}", self.logfile)
             log(f"{red['count']} images on {self.world} GPU(s) in {dt:.2f} s "
                 f"(rank 0: {t_path / max(len(mine), 1) * 1e3:.1f} ms per image in IterDenoise + metrics, the rest is data loading)", self.logfile)
+            log(f"collectives: backend={D.STATS['backend']}, all_reduce={D.STATS['all_reduce']}, barrier={D.STATS['barrier']}", self.logfile)
         return red
 
 
@@ -210,8 +211,11 @@ class YONDParser:
 
 def main(argv=None):
     trainer = YOND_SIDD(argv)
-    if 'eval' in trainer.mode or 'test' in trainer.mode:
-        return trainer.eval(-1)
+    try:
+        if 'eval' in trainer.mode or 'test' in trainer.mode:
+            return trainer.eval(-1)
+    finally:
+        D.finalize()
 
 
 if __name__ == '__main__':

@@ -12,6 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOND_HIP_LIB", os.path.join(_HERE, "libyond_hip.so"))   # override: experiments only
 _lib = None
+ABI_VERSION = 3                     # include/yond_hip.h YOND_ABI_VERSION
 
 vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 
@@ -21,7 +22,8 @@ class YondConvDesc(C.Structure):
                 ("Ho", i32), ("Wo", i32), ("Cout", i32), ("ksize", i32), ("stride", i32), ("shuffle", i32),
                 ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
                 ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32),
-                ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp), ("status", vp)]
+                ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp), ("status", vp),
+                ("in_fmt", i32), ("out_fmt", i32)]
 
 
 class YondFilmDesc(C.Structure):
@@ -102,6 +104,9 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_size_t if name in _SIZE_T_RET else C.c_int
+    if lib.yond_abi_version() != ABI_VERSION:
+        raise YondHipError(f"{LIB_PATH} has ABI version {lib.yond_abi_version()}, this package binds version {ABI_VERSION} "
+                           "(YondConvDesc layout): rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
 

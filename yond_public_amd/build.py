@@ -1,37 +1,87 @@
-"""Build libyond_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+"""Build libyond_hip.so for gfx950 with hipcc (cross-compiles without a GPU): every csrc/*.hip to an object file in
+parallel (csrc/.obj/, one hipcc per source, re-used while newer than the source and every header), then one link."""
 import glob
 import os
 import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(HERE, "libyond_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every float32/float64 rounding point of the NumPy-staged reference is reproduced;
 # fused multiply-adds appear only where the source says fma()/fmaf() or in the MFMA instructions.
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "yond_hip.h")]
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+
+
+def _stale(target, deps):
+    return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
+
+
+STAMP = os.path.join(HERE, "libyond_hip.stamp")      # sha256 of (flags, sources, headers) the library was built from
+
+
+def source_hash(extra_flags=()):
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS + list(extra_flags)).encode())
+    for f in sorted(sources() + [os.path.normpath(x) for x in headers()]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """True unless the library exists and was built from exactly these sources (content hash, not mtimes: a snapshot or
+    a checkout does not keep them)."""
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "yond_hip.h")]
-    return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+    return open(STAMP).read().split()[0] != source_hash()
 
 
-def build_lib(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB] + sources()
+def build_lib(force=False, verbose=True, extra_flags=(), lib=None):
+    """Compile what is out of date (force=True: everything) and link.  Returns (path, mode) with mode one of
+    'reused' (the library's stamp equals the hash of the sources), 'compiled N of M sources'."""
+    lib = lib or LIB
+    if not force and lib == LIB and not needs_build():
+        if verbose:
+            print(f"yond_public_amd.build: {LIB} matches the hash of every source: reused", flush=True)
+        return LIB, "reused"
+    os.makedirs(OBJ, exist_ok=True)
+    todo = [s for s in sources() if force or extra_flags or _stale(_obj(s), [s] + headers())]
+
+    def cc(src):
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", src, "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
+        list(ex.map(cc, todo))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [_obj(s) for s in sources()]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    mode = f"compiled {len(todo)} of {len(sources())} sources"
+    if lib == LIB:
+        with open(STAMP, "w") as f:
+            f.write(f"{source_hash(extra_flags)} {mode}\n")
+    if verbose:
+        print(f"yond_public_amd.build: {mode}, linked {lib}", flush=True)
+    return lib, mode
 
 
 if __name__ == "__main__":
-    build_lib(force=True)
+    print(build_lib(force="--force" in sys.argv)[1])

@@ -58,6 +58,8 @@ extern "C" int yond_split_debug_read(unsigned long long* host) {
 #define SPLIT_ABL 0          // timing-only ablations: 1 no global loads, 2 no weight DMA, 4 no epilogue, 8 no staging writes, 16 no MFMA
 #endif
 
+__host__ __device__ constexpr int yond_sp_plane_units(int H, int W) { return YOND_SP_PLANE_UNITS(H, W); }
+
 template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool K1 = false>
 struct SplitCfg {
     static constexpr int NT = 512;
@@ -88,7 +90,16 @@ struct SplitCfg {
     static constexpr bool LOADS_FIRST = WAHEAD == 2;                // order of a step's memory operations (see the step pipeline)
     static constexpr int KEEP = WAHEAD == 2 ? NIN + NWT_MIN : NIN;  // memory operations that may stay in flight across a barrier
     static constexpr int W4_OFF = 2 * IN_FLOATS + NWB * W_FLOATS;   // floats: 4 x 32 weights of the fused output projection
-    static constexpr int SMEM_BYTES = (W4_OFF + (TN == 32 ? 128 : 0)) * 4;   // (the 512 bytes are used by the O4 instantiation only)
+    static constexpr int FILM_OFF = W4_OFF + (TN == 32 ? 128 : 0);  // floats: per wave and 32-channel block {scale[32], shift[32]} (split-plane epilogue)
+    static constexpr int FILM_FLOATS = 8 * NW * 64;
+    static constexpr int SMEM_BYTES = (FILM_OFF + FILM_FLOATS) * 4;  // (W4: the O4 instantiation only; FILM: the split-plane epilogue only)
+    // input in SPLIT PLANES (YondConvDesc.in_fmt 1): a step's 2 x PARTS x NPT planes arrive by LDS-DMA alone, one 16-byte unit
+    // per lane, a wave-instruction per 64 consecutive units of a plane's LDS image
+    static constexpr int UPP = IH * TWP;                            // units of a plane's LDS image
+    static constexpr int WPP = (UPP + 63) / 64;                     // wave-instructions per plane
+    static constexpr int NPL = NPT * 2 * PARTS;                     // planes per step
+    static constexpr int NDS = NPL * WPP;                           // DMA wave-slots per step
+    static constexpr int NDI = (NDS + 7) / 8;                       // ... per wave
     static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
     static_assert(!K1 || (STRIDE == 1 && PIX_ITEMS % NT == 0), "1x1 mode: whole chunks per pass of the staging threads");
     static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
@@ -107,10 +118,22 @@ __device__ __forceinline__ float split_silu(float x) {
 template <int N>
 __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false>
+// ISP: the input tensor(s) are SPLIT PLANES [n][C/16][channel half][part][H*W (+ zero pad)] of 16-byte units (8 halves) --
+// what the staging below would have written into LDS, stored once by the PRODUCER's epilogue (OSP) with the consumer's
+// pre-activation already applied; the consumer's step then has no vector work at all for its input: 2 x PARTS LDS-DMAs per
+// 16-channel chunk (out-of-image units come from the zero unit behind every plane).  Same bits as staging the fp32 tensor.
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, bool ISP = false, bool OSP = false>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
+    static_assert(!ISP || (!PRE && PARTS == 2), "split-plane input: the producer applied the activation; split precision only");
+    static_assert(!OSP || (!O4 && !K1 && STRIDE == 1 && PARTS == 2), "split-plane output: 3x3 stride-1 layers at split precision");
     constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
+    constexpr int NIN = ISP ? 0 : C::NIN;                    // register-staged 16-byte items per thread and step
+    constexpr int NINA = NIN > 0 ? NIN : 1;                  // (array extents)
+    constexpr int NDI = ISP ? C::NDI : 0;                    // input LDS-DMAs per wave and step
+    constexpr int NG = ISP ? NDI : NIN;                      // per-tile offsets a thread keeps
+    constexpr int NOPS = C::NWT + NIN + NDI;                 // vector-memory instructions per thread and step
+    constexpr int KEEP = ISP ? (C::WAHEAD == 2 ? C::NWT_MIN : 0) : C::KEEP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,9 +153,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     const int my_sl = tid & 3;                               // the thread's 4-channel slot of a pixel (512 % 4 == 0)
     const int my_plane = (my_sl >> 1) * PARTS * C::PLANE + (my_sl & 1) * 2;
 
-    int in_lds[C::NIN];
+    int in_lds[NINA];
 #pragma unroll
-    for (int k = 0; k < C::NIN; ++k) {
+    for (int k = 0; k < NIN; ++k) {
         const int it = tid + k * C::NT;
         const int pt = it / C::PIX_ITEMS;                   // pseudo-tap (K1; 0 otherwise)
         const int pix = (it % C::PIX_ITEMS) / 4;
@@ -143,9 +166,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 
     struct Tile {
         int ct, n, ox0, oy0;
-        int goff[C::NIN];                      // pixel offset into the NHWC source (-1: outside the image -> zeros)
-        int goff1[K1 ? C::NIN : 1];            // K1: pixel offset into src1, the skip tensor at the OUTPUT resolution, read at
+        int goff[NG];                          // pixel offset into the NHWC source (-1: outside the image -> zeros)
+        int goff1[K1 ? NG : 1];                // K1: pixel offset into src1, the skip tensor at the OUTPUT resolution, read at
     };                                         // the sub-position (dy, dx) this tile's channel block stores to
+    // (ISP: goff / goff1 are the BYTE offsets of the thread's unit inside a plane for each of its DMA slots -- the zero unit
+    // behind the plane for a pixel outside the image, -1 for a lane without a unit)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int PS0 = yond_sp_plane_units(d.H, d.W);                                   // units per plane of src0 (and of a same-size src1)
+    const int PS1 = K1 ? yond_sp_plane_units(2 * d.H, 2 * d.W) : PS0;                // K1: the skip tensor at twice the resolution
     // A cursor walks the tiles lslot, lslot + G, ...: its position is kept as the digits (n, ty, tx, ct) of the tile index
     // and advanced by adding the digits of G with carries -- scalar compares instead of four integer divisions per tile
     // (they sat in the middle of the MFMA stretch of every tile's last step).
@@ -172,8 +200,25 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         T.ct = c.ct;
         T.ox0 = c.tx * 32;
         T.oy0 = c.ty * TH;
+        if constexpr (ISP) {
 #pragma unroll
-        for (int k = 0; k < C::NIN; ++k) {
+            for (int k = 0; k < NDI; ++k) {
+                const int sid = k * 8 + wave_s;                 // DMA wave-slot: plane sid / WPP, units (sid % WPP) * 64 ...
+                const int q = (sid % C::WPP) * 64 + lane;       // the lane's unit of the plane's LDS image
+                const int py = q / C::TWP, rem = q % C::TWP;
+                const int px = STRIDE == 2 ? 2 * (rem % C::HALF) + rem / C::HALF : rem;      // stride 2: even columns first
+                const bool valid = sid < C::NDS && q < C::UPP && px < C::IW;
+                const int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
+                const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+                T.goff[k] = !valid ? -1 : (in ? gy * d.W + gx : d.H * d.W) * 16;
+                if constexpr (K1) {
+                    const int sp = (T.ct * TN) / Cr;
+                    T.goff1[k] = !valid ? -1 : (in ? (2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1) : 4 * d.H * d.W) * 16;
+                }
+            }
+        } else {
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
             const int it = tid + k * C::NT;
             const int pix = (it % C::PIX_ITEMS) / 4;
             const int py = pix / C::IW, px = pix % C::IW;
@@ -185,16 +230,17 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 T.goff1[k] = ok ? ((n * 2 * d.H + 2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1)) : -1;
             }
         }
+        }
     };
 
     // Three register sets: set s % 3 receives the loads of input(s+3) during step s and is split / written out as
     // input(s+3) during step s+2, so a load has two steps to arrive.
     constexpr int NSET = MW >= 3 ? 2 : 3;                     // (three rows per wave: 96 accumulator registers leave room for two sets)
     static_assert(NSET == 3 || C::WAHEAD == 1, "the two-set pipeline goes with two weight buffers");
-    f32x4 vin[NSET][C::NIN];
+    f32x4 vin[NSET][NINA];
     if (SPLIT_ABL & 1) {
 #pragma unroll
-        for (int k = 0; k < C::NIN; ++k) { const f32x4 z = {0.5f, 0.25f, -0.5f, 0.125f}; vin[0][k] = z; vin[1][k] = z; vin[NSET - 1][k] = z; }
+        for (int k = 0; k < NIN; ++k) { const f32x4 z = {0.5f, 0.25f, -0.5f, 0.125f}; vin[0][k] = z; vin[1][k] = z; vin[NSET - 1][k] = z; }
     }
     unsigned vin_ok[NSET] = {};
     float amax = 0.0f;                                         // largest |activation| this thread has staged (range guard)
@@ -233,6 +279,42 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         if (!(SPLIT_ABL & 2) && (C::NWV % C::NT == 0 || it_wave < C::NWV))
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(wsrc) : "memory");
     };
+    // ISP: the planes of a step's chunk(s), wave-uniform: [n][chunk][half][part][PS units]; DMA slot k of this wave moves the
+    // 64 units (sid % WPP) * 64 ... of plane sid / WPP, sid = 8 k + wave
+    struct InSrc { const char* base[C::NPT]; unsigned hi; };
+    auto in_src = [&](int ch, int n) {
+        InSrc I;
+        I.hi = 0;
+#pragma unroll
+        for (int t = 0; t < C::NPT; ++t) {
+            const int c0 = (ch * C::NPT + t) * C::KC;
+            const bool second = c0 >= d.C0;
+            const bool hi = K1 && second;
+            const int c16 = (second ? c0 - d.C0 : c0) / 16, nc16 = (second ? d.C1 : d.C0) / 16;
+            const char* src = (const char*)(second ? d.src1 : d.src0);
+            const unsigned long long a = (unsigned long long)(uintptr_t)(src + (size_t)(n * nc16 + c16) * (2 * PARTS) * (size_t)(hi ? PS1 : PS0) * 16);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            I.base[t] = (const char*)(uintptr_t)(((unsigned long long)hi32 << 32) | lo);
+            I.hi |= (hi ? 1u : 0u) << t;
+        }
+        return I;
+    };
+    auto issue_in_dma = [&](auto kc, const Tile& T, const InSrc& I, float* ob) {
+        constexpr int k = decltype(kc)::value;
+        const int sid = k * 8 + wave_s;
+        const int plane = sid / C::WPP, wv = sid - plane * C::WPP;
+        const int pt = plane / (2 * PARTS), pl = plane - pt * (2 * PARTS);
+        const bool hi = K1 && ((I.hi >> pt) & 1u);
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ob;
+        const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(plane * C::PLANE * 4 + wv * 1024));
+        const char* b0 = I.base[0];
+        if constexpr (C::NPT > 1) b0 = pt == 1 ? I.base[1] : (pt == 2 ? I.base[C::NPT - 1] : b0);
+        const char* gb = b0 + (size_t)pl * (size_t)(hi ? PS1 : PS0) * 16;
+        int voff = T.goff[k];
+        if constexpr (K1) voff = hi ? T.goff1[k] : voff;
+        if (voff >= 0)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(gb) : "memory");
+    };
     auto weight_src = [&](int ct, int ch) {                  // wave-uniform: handed to the DMA in scalar registers
         const unsigned long long a = (unsigned long long)(uintptr_t)(d.wpk + ((size_t)ct * nchunk + ch) * C::W_FLOATS);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
@@ -241,7 +323,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // Staging of one register set into an input image, as NE = 4 NIN element tasks so that the step can spread them
     // between its MFMAs: task e = (item k, element j) applies SiLU / zero padding in place; the item's last task splits
     // the four values into the h and l halves and writes them (two ds_write_b64).
-    constexpr int NE = 4 * C::NIN;
+    constexpr int NE = 4 * NIN;
     auto stage_task = [&](auto pc, auto ec, float* ob) {
         constexpr int P = decltype(pc)::value;
         constexpr int e = decltype(ec)::value, k = e / 4, j = e % 4;
@@ -288,6 +370,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     const float* wsrc_s = nullptr;
     const bool wave_hi = __builtin_amdgcn_readfirstlane(wave) >= 4;
     LoadSrc ls_s = {};
+    InSrc is_s = {};
     auto mfma_stage = [&](auto pc, auto fc, const float* buf, const float* wbuf, float* ob, float* wnext, const Tile& lt, auto&& prep)
         __attribute__((always_inline)) {
         typedef const __attribute__((address_space(3))) f16x8* lds_h8;
@@ -355,12 +438,16 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             // this group's share of the step's vector-memory instructions (loads of input(s+3) / LDS-DMA of the weights) --
             // spread over the step so that no wave ever queues behind the CU's 64 B/clk memory pipe
             constexpr int qq = q >= Q0 ? q - Q0 : 0;
-            constexpr int o_lo = q >= Q0 ? (qq * C::NOPS + NQW - 1) / NQW : 0, o_hi = q >= Q0 ? ((qq + 1) * C::NOPS + NQW - 1) / NQW : 0;
+            constexpr int o_lo = q >= Q0 ? (qq * NOPS + NQW - 1) / NQW : 0, o_hi = q >= Q0 ? ((qq + 1) * NOPS + NQW - 1) / NQW : 0;
             static_for<o_lo, o_hi>([&](auto oc) {
                 constexpr int o = decltype(oc)::value;
-                if constexpr (C::LOADS_FIRST) {
-                    if constexpr (o < C::NIN) issue_load(fc, IntC<o>{}, lt, ls_s);
-                    else issue_dma(IntC<o - C::NIN>{}, wsrc_s, wnext);
+                if constexpr (ISP) {
+                    // input(s+1) first (it has the whole step to land), then the weights
+                    if constexpr (o < NDI) issue_in_dma(IntC<o>{}, lt, is_s, ob);
+                    else issue_dma(IntC<o - NDI>{}, wsrc_s, wnext);
+                } else if constexpr (C::LOADS_FIRST) {
+                    if constexpr (o < NIN) issue_load(fc, IntC<o>{}, lt, ls_s);
+                    else issue_dma(IntC<o - NIN>{}, wsrc_s, wnext);
                 } else {
                     if constexpr (o < C::NWT) issue_dma(IntC<o>{}, wsrc_s, wnext);
                     else issue_load(fc, IntC<o - C::NWT>{}, lt, ls_s);
@@ -532,6 +619,63 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         });
     };
 
+    // ---- split-plane output (OSP): the stored tensor is what its ONE consumer would have staged -- act(FiLM(conv)) split into
+    // (h, l) halves, planes [n][C/16][channel half][part][Ho*Wo (+ zero pad)] of 16-byte units.  The accumulator layout is
+    // already the store layout: a lane owns 4 consecutive channels of one pixel = half a unit, the 32 pixels of a fragment
+    // are 32 consecutive units, so a wave-instruction writes 512 contiguous bytes and nothing goes through LDS but the FiLM
+    // vectors (prefetched 8 lanes per block as for the transposed epilogue, redistributed through 256 private bytes).
+    auto epilogue_sp = [&](auto hr, const Tile& T) __attribute__((always_inline)) {
+        constexpr bool HAS_SCALE = (decltype(hr)::value & 2) != 0, HAS_SHIFT = (decltype(hr)::value & 4) != 0;
+        float* fw = smem + C::FILM_OFF + wave * (C::NW * 64);
+        if (lane < 8) {
+#pragma unroll
+            for (int nn = 0; nn < C::NW; ++nn) {
+                *(f32x4*)(fw + nn * 64 + 4 * lane) = pes[nn];
+                *(f32x4*)(fw + nn * 64 + 32 + 4 * lane) = pet[nn];
+            }
+        }
+        const int PSo = yond_sp_plane_units(d.Ho, d.Wo);
+        const int nc16o = d.Cout / 16;
+        const int ox = T.ox0 + li;
+        const bool col_ok = ox < d.Wo;
+#pragma unroll
+        for (int nn = 0; nn < C::NW; ++nn) {
+            const int cb = T.ct * TN + (cg * C::NW + nn) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 es = one, et = zero4;
+                if constexpr (HAS_SCALE) es = *(const f32x4*)(fw + nn * 64 + 8 * g + 4 * lh);
+                if constexpr (HAS_SHIFT) et = *(const f32x4*)(fw + nn * 64 + 32 + 8 * g + 4 * lh);
+                const int c16 = (cb + 8 * g) >> 4, hh = g & 1;
+                char* pb = (char*)d.dst + (size_t)(((T.n * nc16o + c16) * 2 + hh) * PARTS) * (size_t)PSo * 16 + lh * 8;
+#pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    const int oy = T.oy0 + rg * MW + m;
+                    const bool ok = col_ok && oy < d.Ho;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float y = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, acc[0][m][nn][4 * g + e]);
+                        y = fmaf(y, es[e], et[e]);
+                        y = y > 0.0f ? y : y * slope_eff;
+                        if (silu_out) y = split_silu(y);
+                        v[e] = y;
+                    }
+                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                    const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    const f16x4 l = {(_Float16)((v[0] - (float)h[0]) * 2048.0f), (_Float16)((v[1] - (float)h[1]) * 2048.0f),
+                                     (_Float16)((v[2] - (float)h[2]) * 2048.0f), (_Float16)((v[3] - (float)h[3]) * 2048.0f)};
+                    char* pp = pb + (size_t)(oy * d.Wo + ox) * 16;
+                    if (ok) {
+                        *(f16x4*)pp = h;
+                        *(f16x4*)(pp + (size_t)PSo * 16) = l;
+                    }
+                }
+            }
+        }
+    };
+
     // (plain form, lane = pixel: kept for the shapes whose free buffer is smaller than the scratch -- the h-only fp16 path)
     auto epilogue_direct = [&](const Tile& T) {
         const int ox = T.ox0 + li;
@@ -621,7 +765,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     auto load_all = [&](auto pc, Cur c) {
         tile_for(c);
         const LoadSrc L = load_src(c.ch);
-        static_for<0, C::NIN>([&](auto kc) { issue_load(pc, kc, lt, L); });
+        static_for<0, NIN>([&](auto kc) { issue_load(pc, kc, lt, L); });
+    };
+    auto dma_in_all = [&](Cur c, float* ob) {      // ISP: a whole input image by LDS-DMA
+        tile_for(c);
+        const InSrc I = in_src(c.ch, lt.n);
+        static_for<0, NDI>([&](auto kc) { issue_in_dma(kc, lt, I, ob); });
     };
     auto dma_all = [&](Cur c, float* wb) {
         const float* ws = weight_src(ct_of(c, cur.ct), c.ch);
@@ -630,16 +779,24 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // prologue, in the steady-state order of the memory operations (DMA of a step before its loads):
     //   loads input(0) | DMA weights(0), loads input(1) | stage input(0) | DMA weights(1), loads input(2)
     const Cur c1 = adv(cs), c2 = adv(c1);
-    load_all(IntC<0>{}, cs);
+    if constexpr (!ISP) load_all(IntC<0>{}, cs);
     Cur cl, cw;                                 // cursors of the step's loads / weight DMA
-    if constexpr (NSET == 2) {
+    if constexpr (ISP) {
+        // split-plane input: input(0), weights(0) (, weights(1)); step s issues the DMA of input(s+1) and of weights(s + WAHEAD)
+        dma_in_all(cs, ibuf);
+        dma_all(cs, w0);
+        if constexpr (C::WAHEAD == 2) dma_all(c1, w1);
+        cl = c1;
+        cw = C::WAHEAD == 2 ? c2 : c1;
+        split_barrier_keep_loads<C::WAHEAD == 2 ? C::NWT_MIN : 0>();
+    } else if constexpr (NSET == 2) {
         // two register sets (and two weight buffers): set s % 2 receives input(s+2) during step s, staged in step s+1
         dma_all(cs, w0);
         write_in(IntC<0>{}, ibuf);
         load_all(IntC<1>{}, c1);
         cl = c2;
         cw = c1;
-        split_barrier_keep_loads<C::NIN>();
+        split_barrier_keep_loads<NIN>();
     } else {
         if constexpr (C::LOADS_FIRST) {
             load_all(IntC<1>{}, c1);
@@ -656,7 +813,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         }
         cl = adv(c2);                           // loads of step s: input(s+3)
         cw = C::WAHEAD == 2 ? c2 : c1;          // DMA of step s: weights(s + WAHEAD)
-        split_barrier_keep_loads<C::WAHEAD == 2 ? C::NIN + C::NWT_MIN : 2 * C::NIN>();
+        split_barrier_keep_loads<C::WAHEAD == 2 ? NIN + C::NWT_MIN : 2 * NIN>();
     }
     int dbg_step = 0;
     (void)dbg_step;
@@ -671,25 +828,31 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         SDBG(0);
         const bool last_ch = (cs.ch + 1 == nchunk);
         const Cur cn = adv(cs);
-        if constexpr (EP_FIT) {
+        if constexpr (EP_FIT || OSP) {
             if (last_ch) epi_prefetch(cur);
         }
         auto prep = [&]() __attribute__((always_inline)) {
             tile_for(cl);
-            ls_s = load_src(cl.ch);
+            if constexpr (ISP) is_s = in_src(cl.ch, lt.n);
+            else ls_s = load_src(cl.ch);
             wsrc_s = weight_src(ct_of(cw, cur.ct), cw.ch);
         };
         SDBG(1);
         if (computes) mfma_stage(IntC<(S + 1) % NSET>{}, IntC<S>{}, ibuf, w0, obuf, C::WAHEAD == 2 ? w2 : w1, lt, prep);
         SDBG(2);
         SDBG(3);
-        split_barrier_keep_loads<C::KEEP>();                    // weights(s+1) have landed, input(s+1) is written
+        split_barrier_keep_loads<KEEP>();                       // weights(s+1) have landed, input(s+1) is written
         SDBG(4);
         if (last_ch) {
             // scratch: weights(s) / input(s), which no wave reads any more; the barrier behind the epilogue keeps the next
             // step's DMA and staging writes (of OTHER waves) out of it until every wave has read its block back
             if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) {
-                if constexpr (EP_FIT) {
+                if constexpr (OSP) {
+                    const int flags = (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
+                    static_for<0, 4>([&](auto fcx) __attribute__((always_inline)) {
+                        if (flags == 2 * decltype(fcx)::value) epilogue_sp(IntC<2 * decltype(fcx)::value>{}, cur);
+                    });
+                } else if constexpr (EP_FIT) {
                     float* scr = EP_IN_W ? w0 : ibuf;
                     const int flags = (d.res ? 1 : 0) | (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
                     static_for<0, 8>([&](auto fcx) __attribute__((always_inline)) {
@@ -700,7 +863,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 }
             }
             SDBG(6);
-            if constexpr (EP_FIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (EP_FIT && !OSP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (OSP: nothing shared was touched)
             SDBG(7);
             zero_acc();
             if (cn.tile < total) {
@@ -736,12 +899,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     if (d.status && !(amax <= 65504.0f)) atomicOr(d.status, YOND_STATUS_HALF_OVERFLOW);   // an h half became +-inf
 }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, bool ISP = false, bool OSP = false>
 static int launch_split(const YondConvDesc& d, hipStream_t st) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
     static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1>;
+    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -813,6 +976,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (!tn || d.C0 % 16 != 0 || d.C1 % 16 != 0 || (d.shuffle != 0) != (d.ksize == 1)) return YOND_EUNSUPPORTED;
     if (d.tn != tn) return YOND_EINVAL;                         // the layout the weights were packed for
     if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
+    if ((d.in_fmt || d.out_fmt) && (d.ksize != 3 || d.stride != 1)) return YOND_EUNSUPPORTED;
     if (d.ksize == 1) {
         // the decoder GEMM: low-resolution input (C0) + skip tensor at the output resolution (C1), pixel-shuffle store
         if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W) return YOND_EUNSUPPORTED;
@@ -827,6 +991,23 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
     if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
     if (d.out4_dst && (tn != 32 || parts != 2)) return YOND_EUNSUPPORTED;
+    const bool isp = d.in_fmt == YOND_FMT_SPLIT_PLANES, osp = d.out_fmt == YOND_FMT_SPLIT_PLANES;
+    if (isp || osp) {
+        // split planes: the producer side of a block-internal tensor (register-staged input, split-plane store) or its consumer
+        // (input by LDS-DMA alone); both at once is not instantiated
+        if (parts != 2 || (isp && osp) || (isp && d.pre_act) || (osp && (d.res || d.out4_dst))) return YOND_EUNSUPPORTED;
+        if ((long long)YOND_SP_PLANE_UNITS(d.H, d.W) * 16 * 4 >= 0x7fffffffLL) return YOND_EUNSUPPORTED;     // 32-bit unit offsets
+        const long long tiles12 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
+        if (osp) {
+            if (tn == 64 && tiles12 >= 256) return d.pre_act ? launch_split<1, 12, 64, 3, 2, 2, true, false, false, false, true>(d, st) : launch_split<1, 12, 64, 3, 2, 2, false, false, false, false, true>(d, st);
+            if (tn == 64) return d.pre_act ? launch_split<1, 8, 64, 2, 2, 3, true, false, false, false, true>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false, false, false, false, true>(d, st);
+            return d.pre_act ? launch_split<1, 16, 32, 2, 2, 3, true, false, false, false, true>(d, st) : launch_split<1, 16, 32, 2, 2, 3, false, false, false, false, true>(d, st);
+        }
+        if (tn == 64 && tiles12 >= 256) return launch_split<1, 12, 64, 3, 2, 2, false, false, false, true>(d, st);
+        if (tn == 64) return launch_split<1, 8, 64, 2, 2, 3, false, false, false, true>(d, st);
+        if (d.out4_dst) return launch_split<1, 16, 32, 2, 2, 3, false, true, false, true>(d, st);
+        return launch_split<1, 16, 32, 2, 2, 3, false, false, false, true>(d, st);
+    }
     if (tn == 64) {
         // 12 x 32-pixel tiles, three rows per wave: 0.59 instead of 0.78 KiB of LDS fragments per MFMA, 1.5x the MFMA work per
         // step (and per barrier), and 94 / 188 / 376 / 752 rows fill 256 workgroups in whole rounds (1 / 2 / 4 / 8)

@@ -93,6 +93,27 @@ __device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict_
         }
     }
     __syncthreads();
+    // The index guess of lut_eval trusts that every run is EVENLY spaced.  The break detection above compares neighbouring
+    // intervals with a relative tolerance, so a slowly drifting grid (a log grid of ratio < 1.001) would pass as one run:
+    // check every knot against its run's ideal position x[i0] + (i - i0) * step and fall back to the bisection (exact for
+    // any spacing) if one is off by more than 1e-6 of a step (np.linspace knots are exact to ~1e-13 of a step).
+    const int nseg = L.nseg;
+    if (nseg > 0) {
+        bool bad = false;
+        for (int i = tid; i < n; i += 256) {
+            int sgm = 0;
+            for (int a = 1; a < nseg; ++a) sgm += (i > L.seg_i[a]) ? 1 : 0;
+            const int i0 = L.seg_i[sgm];
+            const double step = L.x[i0 + 1] - L.x[i0];
+            // (a repeated knot -- get_bias' 50 and 500 -- opens a run: i0 is its second copy, the first copy closes the previous run)
+            const double dev = fabs(L.x[i] - (L.x[i0] + (double)(i - i0) * step));
+            bad = bad || !(dev <= 1e-6 * fabs(step));          // (the zero-width run between the two copies: dev = 0)
+        }
+        if (__syncthreads_or(bad ? 1 : 0)) {
+            if (tid == 0) L.nseg = 0;
+        }
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ double lut_eval(const LutLds& L, int n, float xq) {
@@ -514,7 +535,7 @@ extern "C" int yond_ivst_elem_f64(const double* z, size_t n, double sigma, doubl
     return YOND_OK;
 }
 
-extern "C" int yond_abi_version(void) { return 1; }
+extern "C" int yond_abi_version(void) { return YOND_ABI_VERSION; }
 
 // ---- rot90 of a stack of frames (np.rot90(x, k, axes=(-2, -1)): utils/sidd_utils.py:198-213 rot_bayer), bit exact ----
 // dst[n][i][j] (H' x W' = W x H for odd k): k=1: src[j][W-1-i]; k=2: src[H-1-i][W-1-j]; k=3: src[H-1-j][i]

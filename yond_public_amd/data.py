@@ -23,7 +23,9 @@ def dataload(path):
             import h5py                                   # the full-resolution SIDD frames are MATLAB v7.3 files (:331-332)
         except ImportError:
             try:
-                return np.asarray(scipy.io.loadmat(path)['x'])            # a v5 re-save of the same variable
+                # a v5 re-save of the same variable.  h5py hands MATLAB's column-major array over with reversed axes (the
+                # reference works on that orientation, utils/utils.py:331-332); loadmat returns MATLAB's own: transpose
+                return np.ascontiguousarray(np.asarray(scipy.io.loadmat(path)['x']).T)
             except NotImplementedError as e:
                 raise RuntimeError(f"{path} is a MATLAB v7.3 file and h5py is not installed; convert it to .npy "
                                    f"(np.save of f['x']) and point lr_path_full at that") from e

@@ -15,11 +15,23 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+# collectives this process has issued through this module (tests and bench.py report it: a one-rank torchrun job
+# exercises the same RCCL calls as an eight-rank one)
+STATS = {"all_reduce": 0, "barrier": 0, "backend": None}
+
+
+def launched_by_torchrun():
+    """True when the torchrun environment is present (RANK and WORLD_SIZE set) -- world size 1 included."""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process).
+    """Initialise torch.distributed from the torchrun environment: a process group is created whenever RANK / WORLD_SIZE
+    are set -- also for WORLD_SIZE = 1, so that a one-GPU box runs the very collectives (RCCL all-reduce, barrier) an
+    eight-GPU node will; a plain `python bench.py` without that environment stays a single process without a group.
     Returns (rank, local_rank, world)."""
     rank, local, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or launched_by_torchrun()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -27,7 +39,12 @@ def init(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        STATS["backend"] = backend
     return rank, local, world
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_indices(n_items, rank, world, sizes=None):
@@ -71,10 +88,11 @@ class MetricSums:
     def reduce(self, device=None):
         """One all-reduce (sum); returns the dataset means as a dict.  Every rank gets the same result."""
         v = self.vec.clone()
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _active():
             if dist.get_backend() == "nccl":
                 v = v.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            STATS["all_reduce"] += 1
             v = v.cpu()
         cnt = float(v[-1])
         out = {"count": int(cnt)}
@@ -87,15 +105,23 @@ class MetricSums:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
+        STATS["barrier"] += 1
 
 
 def max_over_ranks(x, device=None):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         t = torch.tensor([x], dtype=torch.float64)
         if dist.get_backend() == "nccl":
             t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        STATS["all_reduce"] += 1
         return float(t.item())
     return float(x)
+
+
+def finalize():
+    """Tear the process group down (end of a torchrun job)."""
+    if _active():
+        dist.destroy_process_group()

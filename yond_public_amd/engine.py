@@ -40,6 +40,17 @@ WINO_DEFAULT = int(_e) if _e.isdigit() else _e          # 'split' (default): fp3
                                                          # applies, fp32 Winograd elsewhere; 0 direct fp32 MFMA, 1/2 Winograd fp32 MFMA
 
 
+# Block-internal tensors in SPLIT PLANES (include/yond_hip.h, YondConvDesc.in_fmt / out_fmt): conv1's epilogue stores
+# SiLU(FiLM(conv1)) already split into the (h, l) fp16 halves its one consumer would stage, conv2 stages by LDS-DMA alone.
+# (Module attribute, not an environment switch: tools/ flip it for A/B runs.)
+SPLIT_PLANES = True
+
+
+def sp_plane_units(H, W):
+    """YOND_SP_PLANE_UNITS: 16-byte units per plane = H*W pixels + a zero pad (conv zero padding is read from it)."""
+    return (H * W + 8) // 8 * 8
+
+
 class _PackedConv:
     """One convolution's device-side constants."""
 
@@ -259,8 +270,17 @@ class DenoiserPlan:
                 and pc.ksize == 3 and pc.stride == 1 and pc.gemm_n == 32 and pc.split(2) is not None
                 and os.environ.get('YOND_FUSE_OUT4', '1') != '0')
 
+    def _new_sp(self, key, N, H, W, Cc):
+        """A split-plane tensor [N][Cc/16][2][2][sp_plane_units(H, W)] x 16 bytes, kept per (key, shape) across forwards: the
+        zero units behind every plane are written once, here (producers never touch them)."""
+        cache = self.__dict__.setdefault('_sp_cache', {})
+        k = (key, N, H, W, Cc)
+        if k not in cache:
+            cache[k] = torch.zeros(N * (Cc // 16) * 4 * sp_plane_units(H, W) * 4, dtype=torch.float32, device=self.dev)
+        return cache[k]
+
     def _conv(self, pc, src0, src1, N, H, W, dst, escale=None, eshift=None, ebatch=0, res=None, pre_act=0, post_act=0,
-              slope=0.0, algo=None, out4=None):
+              slope=0.0, algo=None, out4=None, in_fmt=0, out_fmt=0):
         d = L.YondConvDesc()
         d.src0 = src0.data_ptr()
         d.src1 = src1.data_ptr() if src1 is not None else None
@@ -317,6 +337,9 @@ class DenoiserPlan:
         d.dst = dst.data_ptr() if dst is not None else None
         status = getattr(self, 'status', None)                       # (bare plans of the kernel tests have none)
         d.status = status.data_ptr() + 4 * self.status_slot if status is not None else None
+        d.in_fmt, d.out_fmt = in_fmt, out_fmt
+        if (in_fmt or out_fmt) and d.algo != 3:
+            raise L.YondHipError("split-plane tensors need the split-operand 3x3 kernel (algo 3)")
         if out4 is not None:
             # (w [4][Cout], bias [4], network input NHWC4 or None, per-image maxima or None, destination NHWC4)
             w4, b4, x4, ub4, o4 = out4
@@ -438,22 +461,26 @@ class DenoiserPlan:
                     self._conv(blk['upsc'], cur, skips[10 - i], N, h, w, xs)
                     h, w = 2 * h, 2 * w
                     cur = xs
-                tmp = self._new(N, h, w, cp)
                 # z = conv2(SiLU(FiLM(conv1(SiLU(x))))) + x : the first SiLU runs in conv1's staging (x has other readers); the
                 # second in conv1's EPILOGUE where both layers run on the split kernel -- tmp has one reader, whose staging
-                # would repeat it once per output-channel tile (bit-identical: the same fp32 function of the same value)
+                # would repeat it once per output-channel tile (bit-identical: the same fp32 function of the same value).
+                # At split precision tmp is stored in SPLIT PLANES: conv1 writes the (h, l) halves conv2 would have staged,
+                # conv2 stages them by LDS-DMA alone (the same bits again)
                 act_in_producer = self._split_pair(blk['conv1'], blk['conv2'])
+                sp = 1 if (act_in_producer and SPLIT_PLANES and getattr(self, 'precision', 'fp32') == 'fp32'
+                           and sp_plane_units(h, w) * 64 < 2 ** 31) else 0
+                tmp = self._new_sp(('tmp', i), N, h, w, cp) if sp else self._new(N, h, w, cp)
                 self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1,
-                           post_act=1 if act_in_producer else 0)
+                           post_act=1 if act_in_producer else 0, out_fmt=sp)
                 pre2 = 0 if act_in_producer else 1
                 if i == 9 and self._out4_fusable(blk['conv2']):
                     # the last block's output feeds only the 1x1 output projection: computed in this epilogue, never stored
                     out4 = self._new(N, H, W, 4)
                     self._conv(blk['conv2'], tmp, None, N, h, w, None, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2,
-                               out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4))
+                               out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4), in_fmt=sp)
                     return out4
                 out = self._new(N, h, w, cp)
-                self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2)
+                self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2, in_fmt=sp)
                 cur = out
                 if i <= 4:
                     skips[i] = cur
@@ -517,7 +544,23 @@ class DenoiserPlan:
             if t_dev.numel() != N:
                 raise L.YondHipError(f"t must have 1 or {N} elements, got {t_dev.numel()}")
             t_dev = t_dev.contiguous()
+        # Plugin surface = the place a caller cannot be asked to bracket the call: the range guard of the half-precision
+        # operand paths runs here (status slot 3; the pipeline wrappers use slots 0-2): the forward, one read of the status
+        # word (this surface is synchronous for its callers anyway -- the reference's `.cpu()` follows), and if a staged
+        # activation left fp16's range the forward is recomputed on the fp32-input MFMA kernels.
+        guarded = self.uses_half_operands()
+        if guarded:
+            self.begin_guard(3)
         y4 = self.forward_nhwc4(x4, t_dev)
+        if guarded and self.overflowed(3):
+            import warnings
+            warnings.warn("an activation left fp16's range (|a| > 65504) in the split-operand convolution path: "
+                          "this forward is recomputed on the fp32-input MFMA kernels")
+            self.strict = True
+            try:
+                y4 = self.forward_nhwc4(x4, t_dev)
+            finally:
+                self.strict = False
         y = torch.empty_like(x)
         L.check(self.lib.yond_nhwc4_to_nchw4_f32(L.ptr(y4), L.ptr(y), N, H, W, L.stream()), "yond_nhwc4_to_nchw4_f32")
         return y

@@ -185,16 +185,24 @@ class BiasLUT:
         sg = np.float64(sigGs) / np.float64(K)
         sg_pos = self.pos_interp(self.sg_lut, sg)
         sg_len = len(self.sg_lut)
-        if sg_pos >= sg_len:
+        # the reference tests `sg_pos >= sg_len` (:204) and then indexes column ceil(sg_pos) (:189-194): for sigma / K just
+        # above the last sigma knot (sg_len - 1 < sg_pos < sg_len) that is column sg_len -> IndexError in the reference.
+        # Here such a sigma takes the get_bias fallback, like every other sigma outside the table.
+        if sg_pos > sg_len - 1:
             return None
+        key = (float(K), float(sigGs), str(device))
+        if getattr(self, '_row_cache', None) is not None and self._row_cache[0] == key:
+            return self._row_cache[1]                                  # the 32 blocks of a SIDD image share (K, sigma)
         pos = np.clip(sg_pos, 0, len(self.x_lut) - 1)                  # :189 (clips with len(x_lut) on this axis too)
         l, r = int(np.floor(pos)), int(np.ceil(pos))
         wr = pos - l
         tab = self.bias_lut.reshape(-1, sg_len)
         data = tab[:, l] * (1 - wr) + tab[:, r] * wr                  # :194
         dev = torch.device(device if device is not None else 'cuda')
-        return DeviceBiasRow(torch.from_numpy(np.ascontiguousarray(self.x_lut * np.float64(K))).to(dev),
-                             torch.from_numpy(np.ascontiguousarray(data, np.float64)).to(dev), float(K), float(sigGs))
+        row = DeviceBiasRow(torch.from_numpy(np.ascontiguousarray(self.x_lut * np.float64(K))).to(dev),
+                            torch.from_numpy(np.ascontiguousarray(data, np.float64)).to(dev), float(K), float(sigGs))
+        self._row_cache = (key, row)
+        return row
 
     def get_lut(self, x, K=1, sigGs=2, func=False, device=None):
         """:196-231 with func=False: biases (float64, on the device) of an array of DN values."""

@@ -1,0 +1,50 @@
+"""Phase timestamps of the split-plane kernels (debug build tools/probe/libyond_sdbg.so, -DSPLIT_DBG=1): cycles per phase of
+workgroup 0, waves 0 and 4, for conv1 (register-staged input, split-plane store: reader `osp`) and conv2 (LDS-DMA input: `isp`).
+    python tools/split_dbg_sp.py build            (on the CPU box: compiles the debug library)
+    python tools/split_dbg_sp.py C H W            (on the GPU box)"""
+import ctypes as C, os, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+DBG = os.path.join(HERE, "probe", "libyond_sdbg.so")
+if len(sys.argv) > 1 and sys.argv[1] == "build":
+    from yond_public_amd.build import build_lib
+    print(build_lib(extra_flags=["-DSPLIT_DBG=1"], lib=DBG))
+    sys.exit(0)
+import numpy as np, torch
+os.environ["YOND_HIP_LIB"] = DBG
+from yond_public_amd import _lib as L
+from yond_public_amd.engine import _PackedConv, DenoiserPlan
+lib = L.load()
+plan = DenoiserPlan.__new__(DenoiserPlan); plan.lib, plan.dev, plan.prof = lib, torch.device('cuda:0'), None
+Cc, h, w = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (128, 376, 504)
+g = torch.Generator().manual_seed(0)
+pc = _PackedConv(plan.dev, torch.randn(Cc, Cc, 3, 3, generator=g) / (3 * Cc ** 0.5), torch.randn(Cc, generator=g), 3, 1, [Cc])
+x = torch.randn(1, h, w, Cc, device='cuda'); dst = torch.empty(1, h, w, Cc, device='cuda')
+es = torch.randn(1, Cc, device='cuda'); et = torch.randn(1, Cc, device='cuda')
+tsp = plan._new_sp('t', 1, h, w, Cc)
+dll = C.CDLL(DBG)
+
+
+def show(reader, title):
+    f = getattr(dll, reader); f.argtypes = [C.c_void_p]; f.restype = C.c_int
+    buf = np.zeros((2, 64, 12), np.uint64)
+    assert f(buf.ctypes.data) == 0
+    t = buf.astype(np.int64)
+    print(title)
+    for wv in range(2):
+        print(" wave", wv * 4, ": step | head  mfma-stretch (quarters)  barrier  tail | total")
+        for sidx in range(2, 26):
+            r = t[wv, sidx]; nxt = t[wv, sidx + 1][0]
+            epi = "   epilogue %d + barrier %d" % (r[6] - r[4], r[7] - r[6]) if r[6] > r[4] and r[5] - r[4] > 600 else ""
+            print("   %3d | %5d  %6d (%5d %5d %5d %5d)  %5d  %5d | %6d%s" % (sidx, r[1] - r[0], r[2] - r[1], r[8] - r[1], r[9] - r[8], r[10] - r[9],
+                  r[2] - r[10], r[4] - r[2], r[5] - r[4], nxt - r[0], epi))
+
+
+for _ in range(3):
+    plan._conv(pc, x, None, 1, h, w, tsp, escale=es, eshift=et, ebatch=1, pre_act=1, post_act=1, algo='split', out_fmt=1)
+torch.cuda.synchronize()
+show("yond_split_debug_read_osp", "conv1: register-staged input, split-plane store")
+for _ in range(3):
+    plan._conv(pc, tsp, None, 1, h, w, dst, escale=es, eshift=et, ebatch=1, res=x, algo='split', in_fmt=1)
+torch.cuda.synchronize()
+show("yond_split_debug_read_isp", "conv2: split-plane input by LDS-DMA, residual, NHWC store")

@@ -24,8 +24,25 @@ def headers():
     return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "yond_hip.h")]
 
 
-def _obj(src):
-    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+def _obj(src, extra_flags=()):
+    # (experiment builds with extra flags keep their objects apart from the product's)
+    import hashlib
+    sub = hashlib.sha256(" ".join(extra_flags).encode()).hexdigest()[:8] if extra_flags else "product"
+    return os.path.join(OBJ, sub, os.path.basename(src)[:-4] + ".o")
+
+
+def _deps(src):
+    """src + the headers it includes (transitively; quoted includes resolved against csrc/ and include/)."""
+    import re
+    seen, todo = [], [src]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(f).read()):
+            todo.append(os.path.normpath(os.path.join(os.path.dirname(f), inc)))
+    return seen
 
 
 def _stale(target, deps):
@@ -60,17 +77,17 @@ def build_lib(force=False, verbose=True, extra_flags=(), lib=None):
         if verbose:
             print(f"yond_public_amd.build: {LIB} matches the hash of every source: reused", flush=True)
         return LIB, "reused"
-    os.makedirs(OBJ, exist_ok=True)
-    todo = [s for s in sources() if force or extra_flags or _stale(_obj(s), [s] + headers())]
+    os.makedirs(os.path.dirname(_obj("x.hip", extra_flags)), exist_ok=True)
+    todo = [s for s in sources() if force or _stale(_obj(s, extra_flags), _deps(s))]
 
     def cc(src):
-        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", src, "-o", _obj(src)]
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", src, "-o", _obj(src, extra_flags)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
         list(ex.map(cc, todo))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [_obj(s) for s in sources()]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [_obj(s, extra_flags) for s in sources()]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

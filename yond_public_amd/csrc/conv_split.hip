@@ -1,922 +1,13 @@
-// K2s: 3x3 convolutions on the fp16 matrix cores with fp32-accurate SPLIT operands (descriptor algo 3).
-//
-// Why: on gfx950 the fp32-input MFMA runs at 1/16 of the fp16 rate and blocks the vector ALU while it runs
-// ("fp32 MFMA and the vector ALU do not overlap").  Every fp32 operand a is therefore split ONCE, when it
-// is staged into LDS (activations) or packed on the host (weights), into two halves
-//        h = fp16(a)                 (round to nearest: 11 significant bits)
-//        l = fp16((a - h) * 2^11)    (a - h is exact in fp32; the scale keeps l in fp16's normal range)
-// so that a = h + l * 2^-11 to 22-23 significant bits, and a product a*w is evaluated as
-//        h_a*h_w  +  2^-11 * (h_a*l_w + l_a*h_w)          (the l_a*l_w term, 2^-22 relative, is dropped)
-// by THREE v_mfma_f32_32x32x16_f16 -- fp16 x fp16 products are exact in the fp32 accumulator; the two cross terms share
-// a second accumulator that is folded in with one FMA in the epilogue.  Measured against a float64 convolution
-// (tests/test_hip_conv.py::test_conv3x3_split_accuracy_beside_fp32_kernels) the error is that of the fp32 direct kernel.
-// Limits: |a| < 65504 (fp16 max); an operand below fp16's normal range (|a| < 6.1e-5) keeps an absolute error of 2^-36
-// instead of a relative one.  Activations and weights of the denoisers are O(1).
-// With PARTS = 1 (descriptor algo 4) only the h halves are staged and multiplied: the plain fp16 MFMA path of
-// BASELINE cfg 5 (fp32 tensors in HBM, fp32 accumulate), without the per-fragment conversions of conv.hip's mode 1.
-//
-// Structure: persistent 512-thread workgroups (two waves per SIMD), tile = TH x 32 output pixels x TN output
-// channels, walked in 16-channel steps with ONE barrier per step.  Shapes (STRIDE, TH, TN, rows per wave MW):
-// (1,12,64,3) and (1,8,64,2) for >= 64 channels, (1,16,32,2) for 32 channels, (2,4,64,1) for stride 2; K1: the decoder's
-// 1x1 pixel-shuffle GEMM with three 16-channel chunks per step in place of the three tap columns.  LDS:
-//   input   two images of planes [channel half 0..1][part h, l][IH x TWP pixels] x 16 bytes (8 halves): the 32 lanes of
-//           a fragment read consecutive pixels = consecutive 16-byte units (conflict-free, no padding); stride 2 keeps
-//           even and odd columns in separate halves of a row so a tap still reads consecutive pixels
-//   weights two or three buffers [tap][channel half][part][TN] x 16 bytes, produced in this order by
-//           yond_pack_conv_split_weight_f32 and copied by LDS-DMA one or two steps ahead.
-// MFMA operand map (cdna_hip_programming.md section 3, 32x32x16): lane l (r = l&31, hh = l>>5) supplies
-// A[row r][k = 8 hh + j] and B[k = 8 hh + j][col r], j = 0..7 -- one ds_read_b128 each.  A = weights (row = output
-// channel), B = pixels, so a lane of D owns ONE pixel and channels (reg&3) + 8 (reg>>2) + 4 hh.
-// Pipeline: all waves run the same program.  Between the MFMAs of step s the compiler is handed, group by group
-// (sched_group_barrier), the step's memory instructions (loads of a later input into a free register set, LDS-DMA of
-// later weights) and the staging of input(s+1) -- SiLU, zero padding, split, ds_write -- as single-element tasks: the fp16
-// MFMA co-executes with the vector ALU.  The end-of-step barrier waits with a counted vmcnt.  See DESIGN.md (K2s) for the
-// measurements behind each of these choices; the kernel runs at the board's power limit.
-#include "common.h"
-#include <cstdlib>
+// K2s dispatcher, weight packing and shape support of the split-operand kernel (conv_split_kernel.h); the kernel's
+// instantiations live in conv_split_*.hip (one group per translation unit, compiled in parallel).
+#include "conv_split_kernel.h"
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-#ifndef SPLIT_DBG
-#define SPLIT_DBG 0      // 1: timestamps of workgroup 0, waves 0 and 4 -> g_split_dbg (read with yond_split_debug_read)
-#endif
-#if SPLIT_DBG
-__device__ unsigned long long g_split_dbg[2][64][8];
-extern "C" int yond_split_debug_read(unsigned long long* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_split_dbg), sizeof(g_split_dbg));
-}
-#define SDBG(slot)                                                                                  \
-    do {                                                                                            \
-        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && dbg_step < 64)              \
-            g_split_dbg[wave >> 2][dbg_step][slot] = __builtin_readcyclecounter();                  \
-    } while (0)
-#else
-#define SDBG(slot) do {} while (0)
-#endif
-#ifndef SPLIT_ABL
-#define SPLIT_ABL 0          // timing-only ablations: 1 no global loads, 2 no weight DMA, 4 no epilogue, 8 no staging writes, 16 no MFMA
-#endif
-
-__host__ __device__ constexpr int yond_sp_plane_units(int H, int W) { return YOND_SP_PLANE_UNITS(H, W); }
-
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool K1 = false>
-struct SplitCfg {
-    static constexpr int NT = 512;
-    static constexpr int KC = 16;
-    // K1: the decoder's 1x1 GEMM (ConvTranspose2d 2x2 + cat + 1x1 shortcut folded, engine.py) -- one tap, so a step takes
-    // THREE consecutive 16-channel chunks as pseudo-taps (a short step is all overhead); no halo
-    static constexpr int NPT = K1 ? 3 : 1;                           // 16-channel chunks per step
-    static constexpr int KSTEP = KC * NPT;
-    static constexpr int TAPS = K1 ? NPT : 9;
-    static constexpr int IH = K1 ? TH : (TH - 1) * STRIDE + 3;
-    static constexpr int IW = K1 ? 32 : 31 * STRIDE + 3;
-    static constexpr int HALF = (IW + 1) / 2;
-    static constexpr int TWP = STRIDE == 2 ? 2 * HALF : IW;
-    static constexpr int PLANE = IH * TWP * 4 + 4;                  // floats; the last 16 bytes take the staging items past the tile
-    static constexpr int IN_FLOATS = NPT * 2 * PARTS * PLANE;       // planes [pseudo-tap][channel half][part]
-    static constexpr int PIX_ITEMS = IH * IW * 4;                    // staging items of one 16-channel chunk
-    static constexpr int W_FLOATS = TAPS * 2 * PARTS * TN * 4;
-    static constexpr int RG = TH / MW;                              // row groups of waves
-    static constexpr int NCW = 8 / RG;                              // channel groups of waves
-    static constexpr int NW = TN / 32 / NCW;                        // 32-channel blocks per wave
-    static constexpr int NITEM = NPT * IH * IW * 4;                 // 16-byte (4-channel) staging items per step
-    static constexpr int NIN = (NITEM + NT - 1) / NT;
-    static constexpr int NWV = W_FLOATS / 4;
-    static constexpr int NWT = (NWV + NT - 1) / NT;
-    static constexpr int NWT_MIN = NWV / NT;                        // LDS-DMA instructions every wave issues per step
-    static constexpr int NOPS = NWT + NIN;                          // vector-memory instructions per thread and step
-    static constexpr int WAHEAD = NWB - 1;                          // the LDS-DMA of step s fetches weights(s + WAHEAD)
-    static constexpr bool LOADS_FIRST = WAHEAD == 2;                // order of a step's memory operations (see the step pipeline)
-    static constexpr int KEEP = WAHEAD == 2 ? NIN + NWT_MIN : NIN;  // memory operations that may stay in flight across a barrier
-    static constexpr int W4_OFF = 2 * IN_FLOATS + NWB * W_FLOATS;   // floats: 4 x 32 weights of the fused output projection
-    static constexpr int FILM_OFF = W4_OFF + (TN == 32 ? 128 : 0);  // floats: per wave and 32-channel block {scale[32], shift[32]} (split-plane epilogue)
-    static constexpr int FILM_FLOATS = 8 * NW * 64;
-    static constexpr int SMEM_BYTES = (FILM_OFF + FILM_FLOATS) * 4;  // (W4: the O4 instantiation only; FILM: the split-plane epilogue only)
-    // input in SPLIT PLANES (YondConvDesc.in_fmt 1): a step's 2 x PARTS x NPT planes arrive by LDS-DMA alone, one 16-byte unit
-    // per lane, a wave-instruction per 64 consecutive units of a plane's LDS image
-    static constexpr int UPP = IH * TWP;                            // units of a plane's LDS image
-    static constexpr int WPP = (UPP + 63) / 64;                     // wave-instructions per plane
-    static constexpr int NPL = NPT * 2 * PARTS;                     // planes per step
-    static constexpr int NDS = NPL * WPP;                           // DMA wave-slots per step
-    static constexpr int NDI = (NDS + 7) / 8;                       // ... per wave
-    static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
-    static_assert(!K1 || (STRIDE == 1 && PIX_ITEMS % NT == 0), "1x1 mode: whole chunks per pass of the staging threads");
-    static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
-};
-
-// output rows m of a wave that read input row r (taps dy = r - m*stride in 0..2)
-constexpr int split_pairs(int mw, int stride, int r) {
-    int n = 0;
-    for (int m = 0; m < mw; ++m) n += (r - m * stride >= 0 && r - m * stride <= 2) ? 1 : 0;
-    return n;
-}
-__device__ __forceinline__ float split_silu(float x) {
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
-}
-// ... wait for all but the N most recent vector-memory operations and for this wave's LDS traffic, then the barrier
-template <int N>
-__device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
-
-// ISP: the input tensor(s) are SPLIT PLANES [n][C/16][channel half][part][H*W (+ zero pad)] of 16-byte units (8 halves) --
-// what the staging below would have written into LDS, stored once by the PRODUCER's epilogue (OSP) with the consumer's
-// pre-activation already applied; the consumer's step then has no vector work at all for its input: 2 x PARTS LDS-DMAs per
-// 16-channel chunk (out-of-image units come from the zero unit behind every plane).  Same bits as staging the fp32 tensor.
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, bool ISP = false, bool OSP = false>
-__global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
-    static_assert(!ISP || (!PRE && PARTS == 2), "split-plane input: the producer applied the activation; split precision only");
-    static_assert(!OSP || (!O4 && !K1 && STRIDE == 1 && PARTS == 2), "split-plane output: 3x3 stride-1 layers at split precision");
-    constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
-    constexpr int NIN = ISP ? 0 : C::NIN;                    // register-staged 16-byte items per thread and step
-    constexpr int NINA = NIN > 0 ? NIN : 1;                  // (array extents)
-    constexpr int NDI = ISP ? C::NDI : 0;                    // input LDS-DMAs per wave and step
-    constexpr int NG = ISP ? NDI : NIN;                      // per-tile offsets a thread keeps
-    constexpr int NOPS = C::NWT + NIN + NDI;                 // vector-memory instructions per thread and step
-    constexpr int KEEP = ISP ? (C::WAHEAD == 2 ? C::NWT_MIN : 0) : C::KEEP;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int rg = wave % C::RG, cg = wave / C::RG;
-
-    const int nct = d.Cout / TN;
-    const bool computes = d.Cout > 0;                        // always true; opaque to the compiler (keeps the MFMA stretch a block of its own)
-    const int ntx = (d.Wo + 31) / 32, nty = (d.Ho + TH - 1) / TH;
-    const int tiles_per_img = nct * ntx * nty;
-    const int total = tiles_per_img * d.N;
-    const int G = gridDim.x;
-    const int lslot = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;   // XCD-contiguous runs
-    const int Cin = d.C0 + d.C1;
-    const int nchunk = Cin / C::KSTEP;                       // steps per tile
-    const int Cr = K1 ? d.Cout / 4 : d.Cout;                 // K1: channels of an OUTPUT pixel (GEMM N = 4 sub-positions x Cr)
-    const int my_sl = tid & 3;                               // the thread's 4-channel slot of a pixel (512 % 4 == 0)
-    const int my_plane = (my_sl >> 1) * PARTS * C::PLANE + (my_sl & 1) * 2;
-
-    int in_lds[NINA];
-#pragma unroll
-    for (int k = 0; k < NIN; ++k) {
-        const int it = tid + k * C::NT;
-        const int pt = it / C::PIX_ITEMS;                   // pseudo-tap (K1; 0 otherwise)
-        const int pix = (it % C::PIX_ITEMS) / 4;
-        const int py = pix / C::IW, px = pix % C::IW;
-        const int lp = (STRIDE == 2) ? py * C::TWP + (px & 1) * C::HALF + (px >> 1) : py * C::TWP + px;
-        in_lds[k] = my_plane + (it < C::NITEM ? pt * 2 * PARTS * C::PLANE + lp * 4 : C::IH * C::TWP * 4);
-    }
-
-    struct Tile {
-        int ct, n, ox0, oy0;
-        int goff[NG];                          // pixel offset into the NHWC source (-1: outside the image -> zeros)
-        int goff1[K1 ? NG : 1];                // K1: pixel offset into src1, the skip tensor at the OUTPUT resolution, read at
-    };                                         // the sub-position (dy, dx) this tile's channel block stores to
-    // (ISP: goff / goff1 are the BYTE offsets of the thread's unit inside a plane for each of its DMA slots -- the zero unit
-    // behind the plane for a pixel outside the image, -1 for a lane without a unit)
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const int PS0 = yond_sp_plane_units(d.H, d.W);                                   // units per plane of src0 (and of a same-size src1)
-    const int PS1 = K1 ? yond_sp_plane_units(2 * d.H, 2 * d.W) : PS0;                // K1: the skip tensor at twice the resolution
-    // A cursor walks the tiles lslot, lslot + G, ...: its position is kept as the digits (n, ty, tx, ct) of the tile index
-    // and advanced by adding the digits of G with carries -- scalar compares instead of four integer divisions per tile
-    // (they sat in the middle of the MFMA stretch of every tile's last step).
-    struct Cur { int tile, ch, ct, tx, ty, n; };
-    int g_ct, g_tx, g_ty, g_n;
-    {
-        int b = G;
-        g_ct = b % nct; b /= nct;
-        g_tx = b % ntx; b /= ntx;
-        g_ty = b % nty; g_n = b / nty;
-    }
-    auto cursor_at = [&](int t) {                // once per workgroup
-        Cur c;
-        c.tile = t; c.ch = 0;
-        int b = t;
-        c.ct = b % nct; b /= nct;
-        c.tx = b % ntx; b /= ntx;
-        c.ty = b % nty; c.n = b / nty;
-        return c;
-    };
-    auto decode = [&](const Cur& c, Tile& T) {
-        const int n = c.n;
-        T.n = n;
-        T.ct = c.ct;
-        T.ox0 = c.tx * 32;
-        T.oy0 = c.ty * TH;
-        if constexpr (ISP) {
-#pragma unroll
-            for (int k = 0; k < NDI; ++k) {
-                const int sid = k * 8 + wave_s;                 // DMA wave-slot: plane sid / WPP, units (sid % WPP) * 64 ...
-                const int q = (sid % C::WPP) * 64 + lane;       // the lane's unit of the plane's LDS image
-                const int py = q / C::TWP, rem = q % C::TWP;
-                const int px = STRIDE == 2 ? 2 * (rem % C::HALF) + rem / C::HALF : rem;      // stride 2: even columns first
-                const bool valid = sid < C::NDS && q < C::UPP && px < C::IW;
-                const int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
-                const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-                T.goff[k] = !valid ? -1 : (in ? gy * d.W + gx : d.H * d.W) * 16;
-                if constexpr (K1) {
-                    const int sp = (T.ct * TN) / Cr;
-                    T.goff1[k] = !valid ? -1 : (in ? (2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1) : 4 * d.H * d.W) * 16;
-                }
-            }
-        } else {
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) {
-            const int it = tid + k * C::NT;
-            const int pix = (it % C::PIX_ITEMS) / 4;
-            const int py = pix / C::IW, px = pix % C::IW;
-            const int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
-            const bool ok = it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-            T.goff[k] = ok ? ((n * d.H + gy) * d.W + gx) : -1;
-            if constexpr (K1) {
-                const int sp = (T.ct * TN) / Cr;               // a channel tile never straddles two sub-positions
-                T.goff1[k] = ok ? ((n * 2 * d.H + 2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1)) : -1;
-            }
-        }
-        }
-    };
-
-    // Three register sets: set s % 3 receives the loads of input(s+3) during step s and is split / written out as
-    // input(s+3) during step s+2, so a load has two steps to arrive.
-    constexpr int NSET = MW >= 3 ? 2 : 3;                     // (three rows per wave: 96 accumulator registers leave room for two sets)
-    static_assert(NSET == 3 || C::WAHEAD == 1, "the two-set pipeline goes with two weight buffers");
-    f32x4 vin[NSET][NINA];
-    if (SPLIT_ABL & 1) {
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) { const f32x4 z = {0.5f, 0.25f, -0.5f, 0.125f}; vin[0][k] = z; vin[1][k] = z; vin[NSET - 1][k] = z; }
-    }
-    unsigned vin_ok[NSET] = {};
-    float amax = 0.0f;                                         // largest |activation| this thread has staged (range guard)
-    // one 16-byte load of a set (item k); the source of the chunk is selected once per step (LoadSrc)
-    // source of a step's 16-channel chunks (K1: three of them, each from the low-resolution input or from the skip tensor)
-    struct LoadSrc { const float* src[C::NPT]; int Cs[C::NPT], cc[C::NPT]; bool hi[C::NPT]; };
-    auto load_src = [&](int ch) {
-        LoadSrc L;
-#pragma unroll
-        for (int t = 0; t < C::NPT; ++t) {
-            const int c0 = (ch * C::NPT + t) * C::KC;
-            if (c0 < d.C0) { L.src[t] = d.src0; L.Cs[t] = d.C0; L.cc[t] = c0; L.hi[t] = false; }
-            else { L.src[t] = d.src1; L.Cs[t] = d.C1; L.cc[t] = c0 - d.C0; L.hi[t] = K1; }
-        }
-        return L;
-    };
-    auto issue_load = [&](auto pc, auto kc, const Tile& T, const LoadSrc& L) {
-        constexpr int P = decltype(pc)::value, k = decltype(kc)::value;
-        constexpr int t = K1 ? (k * C::NT) / C::PIX_ITEMS : 0;  // the item's chunk (K1: PIX_ITEMS is a multiple of the thread count)
-        const bool ok = T.goff[k] >= 0;                        // outside the image: read pixel 0, zeroed at the LDS write
-        int po = T.goff[k];
-        if constexpr (K1) po = L.hi[t] ? T.goff1[k] : po;
-        if (!(SPLIT_ABL & 1)) vin[P][k] = *(const f32x4*)(L.src[t] + (size_t)(ok ? po : 0) * L.Cs[t] + L.cc[t] + my_sl * 4);
-        if (k == 0) vin_ok[P] = 0;
-        vin_ok[P] |= (ok ? 1u : 0u) << k;
-    };
-    // weight slice global -> LDS by LDS-DMA as inline assembly (a builtin DMA makes the compiler order every later LDS
-    // access behind s_waitcnt vmcnt(0)); one instruction (k) moves 512 x 16 bytes; completion is awaited by a barrier
-    auto issue_dma = [&](auto kc, const float* wsrc, float* wbuf) {
-        constexpr int k = decltype(kc)::value;
-        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)wbuf;
-        const int it = tid + k * C::NT;
-        const int it_wave = __builtin_amdgcn_readfirstlane(it - lane);
-        const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)it_wave * 16u);
-        const unsigned voff = (unsigned)it * 16u;
-        if (!(SPLIT_ABL & 2) && (C::NWV % C::NT == 0 || it_wave < C::NWV))
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(wsrc) : "memory");
-    };
-    // ISP: the planes of a step's chunk(s), wave-uniform: [n][chunk][half][part][PS units]; DMA slot k of this wave moves the
-    // 64 units (sid % WPP) * 64 ... of plane sid / WPP, sid = 8 k + wave
-    struct InSrc { const char* base[C::NPT]; unsigned hi; };
-    auto in_src = [&](int ch, int n) {
-        InSrc I;
-        I.hi = 0;
-#pragma unroll
-        for (int t = 0; t < C::NPT; ++t) {
-            const int c0 = (ch * C::NPT + t) * C::KC;
-            const bool second = c0 >= d.C0;
-            const bool hi = K1 && second;
-            const int c16 = (second ? c0 - d.C0 : c0) / 16, nc16 = (second ? d.C1 : d.C0) / 16;
-            const char* src = (const char*)(second ? d.src1 : d.src0);
-            const unsigned long long a = (unsigned long long)(uintptr_t)(src + (size_t)(n * nc16 + c16) * (2 * PARTS) * (size_t)(hi ? PS1 : PS0) * 16);
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-            I.base[t] = (const char*)(uintptr_t)(((unsigned long long)hi32 << 32) | lo);
-            I.hi |= (hi ? 1u : 0u) << t;
-        }
-        return I;
-    };
-    auto issue_in_dma = [&](auto kc, const Tile& T, const InSrc& I, float* ob) {
-        constexpr int k = decltype(kc)::value;
-        const int sid = k * 8 + wave_s;
-        const int plane = sid / C::WPP, wv = sid - plane * C::WPP;
-        const int pt = plane / (2 * PARTS), pl = plane - pt * (2 * PARTS);
-        const bool hi = K1 && ((I.hi >> pt) & 1u);
-        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ob;
-        const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(plane * C::PLANE * 4 + wv * 1024));
-        const char* b0 = I.base[0];
-        if constexpr (C::NPT > 1) b0 = pt == 1 ? I.base[1] : (pt == 2 ? I.base[C::NPT - 1] : b0);
-        const char* gb = b0 + (size_t)pl * (size_t)(hi ? PS1 : PS0) * 16;
-        int voff = T.goff[k];
-        if constexpr (K1) voff = hi ? T.goff1[k] : voff;
-        if (voff >= 0)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(gb) : "memory");
-    };
-    auto weight_src = [&](int ct, int ch) {                  // wave-uniform: handed to the DMA in scalar registers
-        const unsigned long long a = (unsigned long long)(uintptr_t)(d.wpk + ((size_t)ct * nchunk + ch) * C::W_FLOATS);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        return (const float*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-    };
-    // Staging of one register set into an input image, as NE = 4 NIN element tasks so that the step can spread them
-    // between its MFMAs: task e = (item k, element j) applies SiLU / zero padding in place; the item's last task splits
-    // the four values into the h and l halves and writes them (two ds_write_b64).
-    constexpr int NE = 4 * NIN;
-    auto stage_task = [&](auto pc, auto ec, float* ob) {
-        constexpr int P = decltype(pc)::value;
-        constexpr int e = decltype(ec)::value, k = e / 4, j = e % 4;
-        float x = vin[P][k][j];
-        if (PRE) x = split_silu(x);
-        vin[P][k][j] = ((vin_ok[P] >> k) & 1u) ? x : 0.0f;                              // conv zero padding
-        if constexpr (j == 3) {
-            const f32x4 v = vin[P][k];
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));   // two v_max3
-            const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-            if (!(SPLIT_ABL & 8)) *(f16x4*)(ob + in_lds[k]) = h;
-            if constexpr (PARTS == 2) {
-                const f16x4 l = {(_Float16)((v[0] - (float)h[0]) * 2048.0f), (_Float16)((v[1] - (float)h[1]) * 2048.0f),
-                                 (_Float16)((v[2] - (float)h[2]) * 2048.0f), (_Float16)((v[3] - (float)h[3]) * 2048.0f)};
-                if (!(SPLIT_ABL & 8)) *(f16x4*)(ob + in_lds[k] + C::PLANE) = l;
-            }
-        }
-    };
-    auto write_in = [&](auto pc, float* ob) { static_for<0, NE>([&](auto ec) { stage_task(pc, ec, ob); }); };
-
-    f32x16 acc[NACC][MW][C::NW];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int a = 0; a < NACC; ++a)
-#pragma unroll
-            for (int m = 0; m < MW; ++m)
-#pragma unroll
-                for (int nn = 0; nn < C::NW; ++nn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[a][m][nn][r] = 0.0f;
-    };
-
-    // ---- the multiplications of one step ----
-    // The wave's MW output rows read input rows r = 0 .. (MW-1) stride + 2; fragment X(r, dx) serves every (m, dy) with
-    // m stride + dy = r, so it is read ONCE per step (3 (MW+2) pixel fragments per part instead of 9 MW): the kernel is
-    // LDS-bandwidth bound otherwise (1 KiB of fragments per 32-cycle MFMA and wave).  Loop: dx outermost, the three
-    // weight fragments (dy) of a column held in registers and fetched one column ahead, pixel fragments two ahead.
-    // MFMA order inside a group: h_w l_x, then h_w h_x, then l_w h_x -- the two that share an accumulator are never
-    // back to back (the dependent-issue latency of v_mfma_f32_32x32x16_f16 exceeds its 32 cycles).
-    const int x_off = (lh * PARTS) * C::PLANE + ((rg * MW * (K1 ? 1 : STRIDE)) * C::TWP + li) * 4;
-    const int w_off = ((lh * PARTS) * TN + (cg * C::NW) * 32 + li) * 4;
-    // (the step's cursor arithmetic -- `prep`, which sets wsrc_s / ls_s and may decode the next tile -- runs after the
-    // first groups of MFMAs have been issued; memory instructions and staging start at group Q0)
-    const float* wsrc_s = nullptr;
-    const bool wave_hi = __builtin_amdgcn_readfirstlane(wave) >= 4;
-    LoadSrc ls_s = {};
-    InSrc is_s = {};
-    auto mfma_stage = [&](auto pc, auto fc, const float* buf, const float* wbuf, float* ob, float* wnext, const Tile& lt, auto&& prep)
-        __attribute__((always_inline)) {
-        typedef const __attribute__((address_space(3))) f16x8* lds_h8;
-        const __attribute__((address_space(3))) float* xb = (const __attribute__((address_space(3))) float*)(buf + x_off);
-        const __attribute__((address_space(3))) float* wb = (const __attribute__((address_space(3))) float*)(wbuf + w_off);
-        // K1: the three 'columns' are the step's three 16-channel chunks, a row r serves output row m = r only
-        constexpr int R = K1 ? MW : (MW - 1) * STRIDE + 3, NQ = 3 * R, XD = 3, Q0 = 2, NQW = NQ - Q0;
-        // weight fragments of a column: two sets (the next column is fetched during the current one), or -- three rows per
-        // wave, register budget -- ONE set, each dy refilled for the next column right behind its last use (two groups ahead
-        // of its next use)
-        constexpr bool WINPLACE = MW >= 3;
-        constexpr int WS = WINPLACE ? 1 : 2;
-        f16x8 xr[XD][PARTS], wt[WS][3][C::NW][PARTS];
-        auto loadX = [&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            constexpr int dx = q / R, r = q % R;
-            constexpr int xo = K1 ? 0 : (STRIDE == 2) ? (dx & 1) * C::HALF + (dx >> 1) : dx;
-            constexpr int po = K1 ? dx * 2 * PARTS * C::PLANE : 0;         // K1: the chunk's planes
-#pragma unroll
-            for (int p = 0; p < PARTS; ++p) xr[q % XD][p] = *(lds_h8)(xb + po + p * C::PLANE + (r * C::TWP + xo) * 4);
-        };
-        auto loadW1 = [&](auto dc, auto yc) {
-            constexpr int dx = decltype(dc)::value, dy = decltype(yc)::value;
-            constexpr int tap = K1 ? dx : dy * 3 + dx;
-#pragma unroll
-            for (int nn = 0; nn < C::NW; ++nn)
-#pragma unroll
-                for (int p = 0; p < PARTS; ++p)
-                    wt[dx % WS][dy][nn][p] = *(lds_h8)(wb + ((tap * 2 * PARTS + p) * TN + nn * 32) * 4);
-        };
-        auto loadW = [&](auto dc) { static_for<0, (K1 ? 1 : 3)>([&](auto yc) { loadW1(dc, yc); }); };
-        loadW(IntC<0>{});
-        loadX(IntC<0>{});
-        loadX(IntC<1>{});
-        static_for<0, NQ>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            constexpr int dx = q / R, r = q % R;
-            constexpr bool wpre = !WINPLACE && (r == (R >= 4 ? R - 3 : 0) && dx < 2);
-            constexpr int wdy = r - (MW - 1) * STRIDE;                      // WINPLACE: the tap row whose last use is this group
-            constexpr bool wrep = WINPLACE && dx < 2 && wdy >= 0 && wdy <= 2;
-            if constexpr (q + 2 < NQ) loadX(IntC<q + 2>{});
-            if constexpr (wpre) loadW(IntC<dx + 1>{});
-            constexpr int nmf = (PARTS == 2 ? 3 : 1) * C::NW * (K1 ? 1 : split_pairs(MW, STRIDE, r));
-            if (!(SPLIT_ABL & 16)) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {                  // 0: h_w l_x   1: h_w h_x   2: l_w h_x
-                    if (PARTS == 1 && a != 1) continue;
-#pragma unroll
-                    for (int m = 0; m < MW; ++m) {
-                        const int dy = K1 ? (m == r ? 0 : -1) : r - m * STRIDE;
-                        if (dy < 0 || dy > 2) continue;
-#pragma unroll
-                        for (int nn = 0; nn < C::NW; ++nn)
-                            acc[a == 1 ? 0 : 1][m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                wt[dx % WS][dy][nn][a == 2 ? PARTS - 1 : 0], xr[q % XD][a == 0 ? PARTS - 1 : 0], acc[a == 1 ? 0 : 1][m][nn], 0, 0, 0);   // D = W . X^T
-                    }
-                }
-            }
-            if constexpr (wrep) loadW1(IntC<dx + 1>{}, IntC<wdy>{});          // behind this group's MFMAs (its last readers)
-            // the older wave of a SIMD wins the issue arbitration and would finish its MFMAs ~900 cycles before the younger
-            // one, which then runs alone and exposes its LDS latencies: the younger half leads for the first half instead
-            if constexpr (q == 0) { if (wave_hi) __builtin_amdgcn_s_setprio(1); }
-            if constexpr (q == NQ / 2) { if (wave_hi) __builtin_amdgcn_s_setprio(0); }
-            if constexpr (q == Q0 - 1) prep();
-            // this group's share of the step's vector-memory instructions (loads of input(s+3) / LDS-DMA of the weights) --
-            // spread over the step so that no wave ever queues behind the CU's 64 B/clk memory pipe
-            constexpr int qq = q >= Q0 ? q - Q0 : 0;
-            constexpr int o_lo = q >= Q0 ? (qq * NOPS + NQW - 1) / NQW : 0, o_hi = q >= Q0 ? ((qq + 1) * NOPS + NQW - 1) / NQW : 0;
-            static_for<o_lo, o_hi>([&](auto oc) {
-                constexpr int o = decltype(oc)::value;
-                if constexpr (ISP) {
-                    // input(s+1) first (it has the whole step to land), then the weights
-                    if constexpr (o < NDI) issue_in_dma(IntC<o>{}, lt, is_s, ob);
-                    else issue_dma(IntC<o - NDI>{}, wsrc_s, wnext);
-                } else if constexpr (C::LOADS_FIRST) {
-                    if constexpr (o < NIN) issue_load(fc, IntC<o>{}, lt, ls_s);
-                    else issue_dma(IntC<o - NIN>{}, wsrc_s, wnext);
-                } else {
-                    if constexpr (o < C::NWT) issue_dma(IntC<o>{}, wsrc_s, wnext);
-                    else issue_load(fc, IntC<o - C::NWT>{}, lt, ls_s);
-                }
-            });
-            // this group's share of the staging work (element tasks e_lo .. e_hi of the set loaded during the previous step)
-            constexpr int e_lo = q >= Q0 ? qq * NE / NQW : 0, e_hi = q >= Q0 ? (qq + 1) * NE / NQW : 0;
-            static_for<e_lo, e_hi>([&](auto ec) { stage_task(pc, ec, ob); });
-            constexpr int nfin = (e_hi + 0) / 4 - (e_lo + 0) / 4;                     // items completed in this group
-            // Issue order of the group: its LDS reads first (they are two groups / one column ahead of their use), then
-            // each MFMA followed by a few of the vector instructions, then the LDS writes of a completed item.
-            constexpr int nrd = (q + 2 < NQ ? PARTS : 0) + (wpre ? (K1 ? 1 : 3) * C::NW * PARTS : 0);
-            if constexpr (nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
-            constexpr int nvalu = (e_hi - e_lo) * (PRE ? 7 : 2) + nfin * (PARTS == 2 ? 22 : 6);
-            constexpr int vpm = (nvalu + nmf - 1) / nmf;
-#pragma unroll
-            for (int i = 0; i < nmf; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (vpm > 0) __builtin_amdgcn_sched_group_barrier(0x002, vpm, 0);
-            }
-            if constexpr (wrep) __builtin_amdgcn_sched_group_barrier(0x100, C::NW * PARTS, 0);
-            if constexpr (nfin > 0) __builtin_amdgcn_sched_group_barrier(0x200, nfin * PARTS, 0);
-        });
-    };
-
-    // ---- output side ----
-    // In the accumulators a lane owns ONE pixel (li) and, per 32-channel block, channels (r&3) + 8 (r>>2) + 4 lh: stored
-    // from there, every instruction would touch 32 cache lines with 32 bytes each (and the residual loads likewise) --
-    // measured, that request rate made the epilogue 4-6 thousand cycles per tile.  So each wave transposes its
-    // 32-pixel x 32-channel blocks through a private LDS scratch (pixel stride 36 floats: conflict-free both ways) and
-    // reads them back with 8 lanes per pixel: a global instruction then covers 8 whole 128-byte lines, FiLM vectors are
-    // one float4 per lane, and nothing is shared between waves (no barrier inside).
-    const float slope_eff = d.post_act == 2 ? d.slope : 1.0f;
-    // post_act 1: SiLU of the stored value -- the block-internal tensor of a residual block has ONE consumer, whose staging
-    // would otherwise apply the same SiLU once per output-channel tile (Cout / 64 times at the deeper levels)
-    const bool silu_out = d.post_act == 1;
-    constexpr int EPS = 36;                                   // floats per pixel of the scratch
-    constexpr int EP_FLOATS = 8 * 32 * EPS;                   // 36,864 bytes: one weight buffer (TN 64) or part of an input image
-    // (stride 2: short steps, no residual -- measured slower with the transpose and its extra barrier: 211 vs 175 us at level 0)
-    constexpr bool EP_IN_W = TN == 64 && !K1;                 // scratch = the weight buffer just consumed; else the input image
-    constexpr bool EP_FIT = STRIDE == 1 && EP_FLOATS <= (EP_IN_W ? C::W_FLOATS : C::IN_FLOATS);
-    // Straight-line on purpose: a branch around a load (`res ? load : 0`) makes the compiler lose count of the outstanding
-    // memory operations and wait with vmcnt(0) before EVERY store -- i.e. for the previous store (measured: 3.4-4.9
-    // thousand cycles per tile).  So the variant (residual / scale / shift present) is chosen by ONE uniform switch
-    // outside, and all loads precede the first store.
-    f32x4 pes[C::NW], pet[C::NW];
-    auto epi_prefetch = [&](const Tile& T) __attribute__((always_inline)) {
-        const int u = lane & 7;
-#pragma unroll
-        for (int nn = 0; nn < C::NW; ++nn) {
-            const int cu = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
-            const int eoff = (d.ebatch ? T.n * Cr : 0) + (K1 ? cu % Cr : cu);
-            // (no branch around the loads: an absent vector is read from the weights and never used)
-            pes[nn] = *(const f32x4*)(d.escale ? d.escale + eoff : d.wpk);
-            pet[nn] = *(const f32x4*)(d.eshift ? d.eshift + eoff : d.wpk);
-        }
-    };
-    auto epilogue = [&](auto hr, const Tile& T, float* scratch) __attribute__((always_inline)) {
-        constexpr bool HAS_RES = (decltype(hr)::value & 1) != 0, HAS_SCALE = (decltype(hr)::value & 2) != 0, HAS_SHIFT = (decltype(hr)::value & 4) != 0;
-        constexpr bool OUT4 = O4;                                            // fused 1x1 output projection (see YondConvDesc)
-        float* sw = scratch + wave * (32 * EPS);
-        const int pj = lane >> 3, u = lane & 7;               // read-back: pixel pj + 8 j, channels 4 u .. 4 u + 3
-        float ubv = 1.0f, bq = 0.0f;                          // OUT4: per-image maximum, bias of output component u & 3
-        if constexpr (OUT4) {
-            if (d.out4_ub) ubv = d.out4_ub[T.n];
-            if (d.out4_b) bq = d.out4_b[u & 3];
-        }
-        static_for<0, C::NW>([&](auto nc) __attribute__((always_inline)) {
-            constexpr int nn = decltype(nc)::value;
-            const int cu = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
-            // K1: GEMM channel cu = sub-position sp x Cr + channel; the pixel goes to (2 y + sp/2, 2 x + sp%2) of the output
-            const int sp = K1 ? cu / Cr : 0, cb = K1 ? cu % Cr : cu;
-            const int pstep = K1 ? 2 * Cr : d.Cout;              // elements between horizontally adjacent pixels of the tile
-            const int eoff = (d.ebatch ? T.n * Cr : 0) + cb;
-            const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            (void)eoff;
-            f32x4 es = one, et = zero4;                        // FiLM / bias vectors: requested at the start of the tile's last step
-            if constexpr (HAS_SCALE) es = pes[nn];
-            if constexpr (HAS_SHIFT) et = pet[nn];
-            // two rows at a time: their residual loads first, then transposes / arithmetic / stores
-            constexpr int MG = MW < 2 ? MW : 2;
-            static_for<0, (MW + MG - 1) / MG>([&](auto gcx) __attribute__((always_inline)) {
-                constexpr int m0 = decltype(gcx)::value * MG;
-                constexpr int MGN = MW - m0 < MG ? MW - m0 : MG;           // rows of this group
-                f32x4 rr[MG][4];
-                float xq[OUT4 ? MG : 1][OUT4 ? 4 : 1];                      // OUT4: component u & 3 of the pixel's network input (global residual)
-                long long rowoff[MG];
-#pragma unroll
-                for (int mm = 0; mm < MGN; ++mm) {
-                    const int oy = T.oy0 + rg * MW + m0 + mm;
-                    if constexpr (K1) rowoff[mm] = ((long long)(T.n * 2 * d.Ho + 2 * oy + (sp >> 1)) * (2 * d.Wo) + 2 * T.ox0 + (sp & 1)) * Cr + cb;
-                    else rowoff[mm] = ((long long)(T.n * d.Ho + oy) * d.Wo + T.ox0) * d.Cout + cb;
-                    if constexpr (OUT4) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo && d.out4_x;
-                            const long long gp = (long long)(T.n * d.Ho + oy) * d.Wo + T.ox0 + pj + 8 * j;
-                            xq[mm][j] = *((d.out4_x ? d.out4_x : d.wpk) + (ok ? gp * 4 + (u & 3) : 0));
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;      // masked lanes read element 0..
-                        if constexpr (HAS_RES) rr[mm][j] = *(const f32x4*)(d.res + (ok ? rowoff[mm] + (long long)(pj + 8 * j) * pstep : 0));
-                        else rr[mm][j] = zero4;
-                    }
-                }
-#pragma unroll
-                for (int mm = 0; mm < MGN; ++mm) {
-                    const int m = m0 + mm;
-                    const int oy = T.oy0 + rg * MW + m;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[0][m][nn][4 * g + e];
-                            if constexpr (PARTS == 2) v[e] = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, v[e]);
-                        }
-                        *(f32x4*)(sw + li * EPS + 8 * g + 4 * lh) = v;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;
-                        const f32x4 x = *(const f32x4*)(sw + (pj + 8 * j) * EPS + 4 * u);
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float y = fmaf(x[e], es[e], et[e]);
-                            y = y > 0.0f ? y : y * slope_eff;
-                            if (silu_out) y = split_silu(y);
-                            v[e] = y + rr[mm][j][e];
-                        }
-                        if constexpr (OUT4) {
-                            // 1x1 projection 32 -> 4 in yond_conv_out_f32's operation order: per lane four FMAs per output over its
-                            // channels 4u..4u+3, xor-shuffle tree over the pixel's 8 lanes, then bias, residual, de-normalisation
-                            const float* w4 = smem + C::W4_OFF + 4 * u;
-                            float o[4];
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                const f32x4 wv = *(const f32x4*)(w4 + 32 * c);
-                                float t = 0.0f;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) t = fmaf(v[e], wv[e], t);
-                                o[c] = t;
-                            }
-                            // xor 1, xor 2 (quad permutes), then the other half of the 8 lanes (half-row mirror: every lane of a
-                            // quad holds the same sum by then) -- DPP instead of 12 dependent ds_bpermute round trips
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                o[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o[c]), 0xB1, 0xF, 0xF, true));
-                                o[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o[c]), 0x4E, 0xF, 0xF, true));
-                                o[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o[c]), 0x141, 0xF, 0xF, true));
-                            }
-                            // every lane of the pixel now holds all four sums: lane u < 4 finishes and stores component u
-                            const int cu = u & 3;
-                            float t = cu == 0 ? o[0] : cu == 1 ? o[1] : cu == 2 ? o[2] : o[3];
-                            if (d.out4_b) t += bq;
-                            if (d.out4_x) t += d.out4_ub ? xq[mm][j] / ubv : xq[mm][j];
-                            if (d.out4_ub) t *= ubv;
-                            const long long gp = (long long)(T.n * d.Ho + oy) * d.Wo + T.ox0 + pj + 8 * j;
-                            if (ok && u < 4) d.out4_dst[gp * 4 + cu] = t;
-                        } else {
-                            if (ok) *(f32x4*)(d.dst + rowoff[mm] + (long long)(pj + 8 * j) * pstep) = v;
-                        }
-                    }
-                }
-            });
-        });
-    };
-
-    // ---- split-plane output (OSP): the stored tensor is what its ONE consumer would have staged -- act(FiLM(conv)) split into
-    // (h, l) halves, planes [n][C/16][channel half][part][Ho*Wo (+ zero pad)] of 16-byte units.  The accumulator layout is
-    // already the store layout: a lane owns 4 consecutive channels of one pixel = half a unit, the 32 pixels of a fragment
-    // are 32 consecutive units, so a wave-instruction writes 512 contiguous bytes and nothing goes through LDS but the FiLM
-    // vectors (prefetched 8 lanes per block as for the transposed epilogue, redistributed through 256 private bytes).
-    auto epilogue_sp = [&](auto hr, const Tile& T) __attribute__((always_inline)) {
-        constexpr bool HAS_SCALE = (decltype(hr)::value & 2) != 0, HAS_SHIFT = (decltype(hr)::value & 4) != 0;
-        float* fw = smem + C::FILM_OFF + wave * (C::NW * 64);
-        if (lane < 8) {
-#pragma unroll
-            for (int nn = 0; nn < C::NW; ++nn) {
-                *(f32x4*)(fw + nn * 64 + 4 * lane) = pes[nn];
-                *(f32x4*)(fw + nn * 64 + 32 + 4 * lane) = pet[nn];
-            }
-        }
-        const int PSo = yond_sp_plane_units(d.Ho, d.Wo);
-        const int nc16o = d.Cout / 16;
-        const int ox = T.ox0 + li;
-        const bool col_ok = ox < d.Wo;
-#pragma unroll
-        for (int nn = 0; nn < C::NW; ++nn) {
-            const int cb = T.ct * TN + (cg * C::NW + nn) * 32;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                f32x4 es = one, et = zero4;
-                if constexpr (HAS_SCALE) es = *(const f32x4*)(fw + nn * 64 + 8 * g + 4 * lh);
-                if constexpr (HAS_SHIFT) et = *(const f32x4*)(fw + nn * 64 + 32 + 8 * g + 4 * lh);
-                const int c16 = (cb + 8 * g) >> 4, hh = g & 1;
-                char* pb = (char*)d.dst + (size_t)(((T.n * nc16o + c16) * 2 + hh) * PARTS) * (size_t)PSo * 16 + lh * 8;
-#pragma unroll
-                for (int m = 0; m < MW; ++m) {
-                    const int oy = T.oy0 + rg * MW + m;
-                    const bool ok = col_ok && oy < d.Ho;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float y = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, acc[0][m][nn][4 * g + e]);
-                        y = fmaf(y, es[e], et[e]);
-                        y = y > 0.0f ? y : y * slope_eff;
-                        if (silu_out) y = split_silu(y);
-                        v[e] = y;
-                    }
-                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-                    const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    const f16x4 l = {(_Float16)((v[0] - (float)h[0]) * 2048.0f), (_Float16)((v[1] - (float)h[1]) * 2048.0f),
-                                     (_Float16)((v[2] - (float)h[2]) * 2048.0f), (_Float16)((v[3] - (float)h[3]) * 2048.0f)};
-                    char* pp = pb + (size_t)(oy * d.Wo + ox) * 16;
-                    if (ok) {
-                        *(f16x4*)pp = h;
-                        *(f16x4*)(pp + (size_t)PSo * 16) = l;
-                    }
-                }
-            }
-        }
-    };
-
-    // (plain form, lane = pixel: kept for the shapes whose free buffer is smaller than the scratch -- the h-only fp16 path)
-    auto epilogue_direct = [&](const Tile& T) {
-        const int ox = T.ox0 + li;
-        const bool col_ok = ox < d.Wo;
-#pragma unroll
-        for (int nn = 0; nn < C::NW; ++nn) {
-            const int cbase = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * lh;
-            const int eoff = (d.ebatch ? T.n * d.Cout : 0) + cbase;
-            f32x4 es[4], et[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                es[g] = d.escale ? *(const f32x4*)(d.escale + eoff + 8 * g) : one;
-                et[g] = d.eshift ? *(const f32x4*)(d.eshift + eoff + 8 * g) : zero4;
-            }
-            f32x4 rr[MW][4];
-#pragma unroll
-            for (int m = 0; m < MW; ++m) {
-                const int oy = T.oy0 + rg * MW + m;
-                const bool ok = col_ok && oy < d.Ho;
-                const long long off = ok ? ((long long)(T.n * d.Ho + oy) * d.Wo + ox) * d.Cout + cbase : 0;   // masked lanes read element 0..
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                    rr[m][g] = d.res ? *(const f32x4*)(d.res + off + (ok ? 8 * g : 0)) : z;
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < MW; ++m) {
-                const int oy = T.oy0 + rg * MW + m;
-                const bool ok = col_ok && oy < d.Ho;
-                float* op = d.dst + ((long long)(T.n * d.Ho + oy) * d.Wo + ox) * d.Cout + cbase;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = acc[0][m][nn][4 * g + e];
-                        if constexpr (PARTS == 2) x = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, x);
-                        x = fmaf(x, es[g][e], et[g][e]);
-                        x = x > 0.0f ? x : x * slope_eff;
-                        if (silu_out) x = split_silu(x);
-                        v[e] = x + rr[m][g][e];
-                    }
-                    if (ok) *(f32x4*)(op + 8 * g) = v;
-                }
-            }
-        }
-    };
-
-    // ---- the step pipeline: ONE barrier per step ----
-    auto adv = [&](Cur c) {
-        Cur n = c;
-        const bool last = c.ch + 1 == nchunk;
-        n.ch = last ? 0 : c.ch + 1;
-        if (last) {
-            n.tile = c.tile + G;
-            int v = c.ct + g_ct, cy = v >= nct ? 1 : 0;
-            n.ct = v - (cy ? nct : 0);
-            v = c.tx + g_tx + cy; cy = v >= ntx ? 1 : 0;
-            n.tx = v - (cy ? ntx : 0);
-            v = c.ty + g_ty + cy; cy = v >= nty ? 1 : 0;
-            n.ty = v - (cy ? nty : 0);
-            n.n = c.n + g_n + cy;
-        }
-        return n;
-    };
-    if (lslot >= total) return;
-    if constexpr (O4) {
-        if (tid < 128) smem[C::W4_OFF + tid] = d.out4_w[tid];                    // visible behind the prologue's barrier
-    }
-    Cur cs = cursor_at(lslot);                 // step being computed
-    Tile cur;                                   // its tile (epilogue)
-    Tile lt;                                    // tile of the load cursor
-    int lt_tile = -1;
-    decode(cs, cur);
-    zero_acc();
-    float* ibuf = smem;                         // input(s)
-    float* obuf = smem + C::IN_FLOATS;          // receives input(s+1)
-    float* w0 = smem + 2 * C::IN_FLOATS;        // weights(s)
-    float* w1 = w0 + C::W_FLOATS;               // weights(s+1)  (two buffers: receives them)
-    float* w2 = w1 + (NWB == 3 ? C::W_FLOATS : 0);   // three buffers: receives weights(s+2)
-    auto ct_of = [&](Cur c, int fallback) { return c.tile < total ? c.ct : fallback; };
-    auto tile_for = [&](Cur c) {                // steps past the end re-read the last decoded tile (harmless)
-        if (c.tile < total && c.tile != lt_tile) { decode(c, lt); lt_tile = c.tile; }
-    };
-    auto load_all = [&](auto pc, Cur c) {
-        tile_for(c);
-        const LoadSrc L = load_src(c.ch);
-        static_for<0, NIN>([&](auto kc) { issue_load(pc, kc, lt, L); });
-    };
-    auto dma_in_all = [&](Cur c, float* ob) {      // ISP: a whole input image by LDS-DMA
-        tile_for(c);
-        const InSrc I = in_src(c.ch, lt.n);
-        static_for<0, NDI>([&](auto kc) { issue_in_dma(kc, lt, I, ob); });
-    };
-    auto dma_all = [&](Cur c, float* wb) {
-        const float* ws = weight_src(ct_of(c, cur.ct), c.ch);
-        static_for<0, C::NWT>([&](auto kc) { issue_dma(kc, ws, wb); });
-    };
-    // prologue, in the steady-state order of the memory operations (DMA of a step before its loads):
-    //   loads input(0) | DMA weights(0), loads input(1) | stage input(0) | DMA weights(1), loads input(2)
-    const Cur c1 = adv(cs), c2 = adv(c1);
-    if constexpr (!ISP) load_all(IntC<0>{}, cs);
-    Cur cl, cw;                                 // cursors of the step's loads / weight DMA
-    if constexpr (ISP) {
-        // split-plane input: input(0), weights(0) (, weights(1)); step s issues the DMA of input(s+1) and of weights(s + WAHEAD)
-        dma_in_all(cs, ibuf);
-        dma_all(cs, w0);
-        if constexpr (C::WAHEAD == 2) dma_all(c1, w1);
-        cl = c1;
-        cw = C::WAHEAD == 2 ? c2 : c1;
-        split_barrier_keep_loads<C::WAHEAD == 2 ? C::NWT_MIN : 0>();
-    } else if constexpr (NSET == 2) {
-        // two register sets (and two weight buffers): set s % 2 receives input(s+2) during step s, staged in step s+1
-        dma_all(cs, w0);
-        write_in(IntC<0>{}, ibuf);
-        load_all(IntC<1>{}, c1);
-        cl = c2;
-        cw = c1;
-        split_barrier_keep_loads<NIN>();
-    } else {
-        if constexpr (C::LOADS_FIRST) {
-            load_all(IntC<1>{}, c1);
-            dma_all(cs, w0);
-            write_in(IntC<0>{}, ibuf);
-            load_all(IntC<2>{}, c2);
-            dma_all(c1, w1);
-        } else {
-            dma_all(cs, w0);
-            load_all(IntC<1>{}, c1);
-            write_in(IntC<0>{}, ibuf);
-            if constexpr (C::WAHEAD == 2) dma_all(c1, w1);
-            load_all(IntC<2>{}, c2);
-        }
-        cl = adv(c2);                           // loads of step s: input(s+3)
-        cw = C::WAHEAD == 2 ? c2 : c1;          // DMA of step s: weights(s + WAHEAD)
-        split_barrier_keep_loads<C::WAHEAD == 2 ? NIN + C::NWT_MIN : 2 * NIN>();
-    }
-    int dbg_step = 0;
-    (void)dbg_step;
-    // Step s (all waves alike, S = s % NSET; described for three register sets).  In program order: the MFMAs of step s with, between them, (a) the loads of
-    // input(s+3) into register set S and the LDS-DMA of weights(s+2) (three weight buffers; with two: DMA of weights(s+1)
-    // first, then the loads), (b) the staging of set (s+1) % 3 = input(s+1), loaded two steps ago; then ONE barrier that
-    // awaits weights(s+1) only -- vmcnt counts in order: loads(s-1), DMA(s-1), loads(s), DMA(s): the last two stay in
-    // flight.  Loads before DMA because the compiler (which does not see the DMA) makes the next step wait for every
-    // outstanding operation before it touches the staged set: the youngest are then L2-resident weight slices.
-    auto step = [&](auto sc) -> bool {
-        constexpr int S = decltype(sc)::value;
-        SDBG(0);
-        const bool last_ch = (cs.ch + 1 == nchunk);
-        const Cur cn = adv(cs);
-        if constexpr (EP_FIT || OSP) {
-            if (last_ch) epi_prefetch(cur);
-        }
-        auto prep = [&]() __attribute__((always_inline)) {
-            tile_for(cl);
-            if constexpr (ISP) is_s = in_src(cl.ch, lt.n);
-            else ls_s = load_src(cl.ch);
-            wsrc_s = weight_src(ct_of(cw, cur.ct), cw.ch);
-        };
-        SDBG(1);
-        if (computes) mfma_stage(IntC<(S + 1) % NSET>{}, IntC<S>{}, ibuf, w0, obuf, C::WAHEAD == 2 ? w2 : w1, lt, prep);
-        SDBG(2);
-        SDBG(3);
-        split_barrier_keep_loads<KEEP>();                       // weights(s+1) have landed, input(s+1) is written
-        SDBG(4);
-        if (last_ch) {
-            // scratch: weights(s) / input(s), which no wave reads any more; the barrier behind the epilogue keeps the next
-            // step's DMA and staging writes (of OTHER waves) out of it until every wave has read its block back
-            if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) {
-                if constexpr (OSP) {
-                    const int flags = (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
-                    static_for<0, 4>([&](auto fcx) __attribute__((always_inline)) {
-                        if (flags == 2 * decltype(fcx)::value) epilogue_sp(IntC<2 * decltype(fcx)::value>{}, cur);
-                    });
-                } else if constexpr (EP_FIT) {
-                    float* scr = EP_IN_W ? w0 : ibuf;
-                    const int flags = (d.res ? 1 : 0) | (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
-                    static_for<0, 8>([&](auto fcx) __attribute__((always_inline)) {
-                        if (flags == decltype(fcx)::value) epilogue(fcx, cur, scr);
-                    });
-                } else {
-                    epilogue_direct(cur);
-                }
-            }
-            SDBG(6);
-            if constexpr (EP_FIT && !OSP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (OSP: nothing shared was touched)
-            SDBG(7);
-            zero_acc();
-            if (cn.tile < total) {
-                cur.n = cn.n;
-                cur.ct = cn.ct;
-                cur.ox0 = cn.tx * 32;
-                cur.oy0 = cn.ty * TH;
-            }
-        }
-        SDBG(5);
-        ++dbg_step;
-        if (cn.tile >= total) return false;
-        cs = cn;
-        cl = adv(cl);
-        cw = adv(cw);
-        float* t = ibuf;
-        ibuf = obuf;
-        obuf = t;
-        t = w0;
-        w0 = w1;
-        w1 = NWB == 3 ? w2 : t;
-        w2 = t;
-        return true;
-    };
-    while (true) {
-        if (!step(IntC<0>{})) break;
-        if (!step(IntC<1>{})) break;
-        if constexpr (NSET == 3) {
-            if (!step(IntC<2>{})) break;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead loads / DMA of the steps past the end
-    if (d.status && !(amax <= 65504.0f)) atomicOr(d.status, YOND_STATUS_HALF_OVERFLOW);   // an h half became +-inf
-}
-
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, bool ISP = false, bool OSP = false>
-static int launch_split(const YondConvDesc& d, hipStream_t st) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
-    static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const long long total = (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
-    if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
-    const int grid = total < 256 ? (int)total : 256;            // one persistent workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::SMEM_BYTES, st, d);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
-}
+SPLIT_GROUP_K1S2(SPLIT_EXTERN)
+SPLIT_GROUP_S1_64(SPLIT_EXTERN)
+SPLIT_GROUP_S1_32(SPLIT_EXTERN)
+SPLIT_GROUP_HALF(SPLIT_EXTERN)
+SPLIT_GROUP_OSP(SPLIT_EXTERN)
+SPLIT_GROUP_ISP(SPLIT_EXTERN)
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
 // ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has

@@ -166,10 +166,17 @@ typedef struct YondConvDesc {
        no fused projection) stores from the accumulator layout without an LDS transpose.  Bit-identical to staging the
        float32 tensor (the same split of the same float32 value). */
     int in_fmt, out_fmt;
+    /* 2 = PLANES OF 4 CHANNELS, float32 [N][C/4][H*W][4]: the format of the tensors that are read as RESIDUALS by a
+       split-plane store (res_fmt 2 is required with out_fmt 1 and a residual, and only there): in the accumulator layout
+       a lane reads / writes 16 bytes of its own pixel and a wave 512 contiguous bytes.  Producers: the stride-2 and
+       transposed layers (out_fmt 2), yond_conv_in_f32; consumers: the register-staged input of a 3x3 layer (in_fmt 2:
+       src0 and src1) and `res`. */
+    int res_fmt;
 } YondConvDesc;
 #define YOND_STATUS_HALF_OVERFLOW 1u
 #define YOND_FMT_NHWC_F32 0
 #define YOND_FMT_SPLIT_PLANES 1
+#define YOND_FMT_PLANES4 2
 /* 16-byte units per plane of a split-plane tensor: H*W pixels + at least one zero unit, rounded to 128 bytes */
 #define YOND_SP_PLANE_UNITS(H, W) ((((H) * (W)) + 8) / 8 * 8)
 /* bytes of a split-plane tensor of C channels (C a multiple of 16) */
@@ -209,7 +216,8 @@ int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize
 /* First layer: 3x3, Cin=4 -> Cout=32k, input NHWC4, optional division by the per-image maximum
  * (data_normalize, archs/Unet.py:427-431) and LeakyReLU(slope).  wpk from yond_pack_conv_in_weight_f32. */
 int yond_conv_in_f32(const float* x, const float* ub /*[N] or NULL*/, int N, int H, int W, int Cout,
-                     const float* wpk, const float* bias, float slope, float* dst, void* stream);
+                     const float* wpk, const float* bias, float slope, float* dst,
+                     int out_fmt /* YOND_FMT_NHWC_F32: [N][H][W][Cout]; YOND_FMT_PLANES4: [N][Cout/4][H*W][4] */, void* stream);
 int yond_pack_conv_in_weight_f32(const float* w /*[cout][4][3][3]*/, int cout, float* dst /*cout*40*/);
 
 /* Last layer: 1x1 Cin -> 4, + x/ub residual, * ub (archs/Unet.py:463-468). */

@@ -266,6 +266,128 @@ def test_conv3x3_split_planes_pair(C, N, H, W, out4):
         plan._conv(pc1, xd, None, N, H, W, t_sp, out_fmt=1, res=xd, algo='split')
 
 
+def to_sp(x):
+    """[N][H][W][C] float32 (CPU) -> split planes (float32-typed buffer on the device), the exact halves the staging forms."""
+    from yond_public_amd.engine import sp_plane_units
+    N, H, W, C = x.shape
+    ps = sp_plane_units(H, W)
+    h = x.half()
+    l = ((x - h.float()) * 2048.0).half()
+    out = torch.zeros(N, C // 16, 2, 2, ps, 8, dtype=torch.float16)
+    for part, t in enumerate((h, l)):
+        out[:, :, :, part, :H * W, :] = t.reshape(N, H * W, C // 16, 2, 8).permute(0, 2, 3, 1, 4)
+    return out.reshape(-1).view(torch.float32).to(DEV)
+
+
+def sp_halves(sp, N, C, H, W):
+    """split planes -> (h, l) as [N][H][W][C] float16 tensors (CPU)."""
+    from yond_public_amd.engine import sp_plane_units
+    u = sp.cpu().view(torch.float16).reshape(N, C // 16, 2, 2, sp_plane_units(H, W), 8)[:, :, :, :, :H * W, :]
+    return [u[:, :, :, part].permute(0, 3, 1, 2, 4).reshape(N, H, W, C) for part in (0, 1)]
+
+
+def to_p4(x):
+    """[N][H][W][C] -> planes of 4 channels [N][C/4][H*W][4] (device)."""
+    N, H, W, C = x.shape
+    return x.reshape(N, H * W, C // 4, 4).permute(0, 2, 1, 3).contiguous().to(DEV)
+
+
+def from_p4(p, N, H, W, C):
+    return p.cpu().reshape(N, C // 4, H * W, 4).permute(0, 2, 1, 3).reshape(N, H, W, C)
+
+
+def bare_plan():
+    from yond_public_amd.engine import DenoiserPlan
+    from yond_public_amd import _lib as L
+    plan = DenoiserPlan.__new__(DenoiserPlan)
+    plan.lib, plan.dev = L.load(), torch.device(DEV)
+    return plan
+
+
+@pytest.mark.parametrize("C,N,H,W", [(64, 2, 40, 70), (128, 1, 380, 100), (32, 2, 50, 75)])
+def test_conv3x3_split_plane_flow_block(C, N, H, W):
+    """The residual block in the formats of the default data flow: x in planes of 4 channels (conv1's staged input, conv2's
+    residual), tmp and out in split planes.  Every tensor must hold exactly what the [N][H][W][C] float32 path computes: tmp and
+    out decode to the split of the float32 results, bit for bit."""
+    from yond_public_amd.engine import _PackedConv
+    g = torch.Generator().manual_seed(C + H)
+    x = nhwc(torch.randn(N, C, H, W, generator=g))
+    w1 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    es, et = torch.randn(N, C, generator=g).to(DEV), torch.randn(N, C, generator=g).to(DEV)
+    es2, et2 = torch.randn(N, C, generator=g).to(DEV), torch.randn(N, C, generator=g).to(DEV)
+    plan = bare_plan()
+    pc1, pc2 = _PackedConv(plan.dev, w1, None, 3, 1, [C]), _PackedConv(plan.dev, w2, None, 3, 1, [C])
+    xd, xp = x.to(DEV), to_p4(x)
+    kw1 = dict(escale=es, eshift=et, ebatch=1, pre_act=1, post_act=1, algo='split')
+    kw2 = dict(escale=es2, eshift=et2, ebatch=1, algo='split')
+    t_ref = torch.empty(N, H, W, C, device=DEV)
+    o_ref = torch.empty(N, H, W, C, device=DEV)
+    plan._conv(pc1, xd, None, N, H, W, t_ref, **kw1)
+    plan._conv(pc2, t_ref, None, N, H, W, o_ref, res=xd, **kw2)
+    t_sp, o_sp = plan._new_sp('t', N, H, W, C), plan._new_sp('o', N, H, W, C)
+    plan._conv(pc1, xp, None, N, H, W, t_sp, in_fmt=2, out_fmt=1, **kw1)
+    plan._conv(pc2, t_sp, None, N, H, W, o_sp, res=xp, in_fmt=1, out_fmt=1, res_fmt=2, **kw2)
+    torch.cuda.synchronize()
+    for name, sp, ref in (("tmp", t_sp, t_ref), ("out", o_sp, o_ref)):
+        h, l = sp_halves(sp, N, C, H, W)
+        rh = ref.cpu().half()
+        rl = ((ref.cpu() - rh.float()) * 2048.0).half()
+        assert torch.equal(h.view(torch.int16), rh.view(torch.int16)), name
+        assert torch.equal(l.view(torch.int16), rl.view(torch.int16)), name
+    with pytest.raises(Exception):          # a split-plane store takes its residual in planes of 4 only
+        plan._conv(pc2, t_sp, None, N, H, W, o_sp, res=xd, in_fmt=1, out_fmt=1, **kw2)
+
+
+@pytest.mark.parametrize("C,N,H,W", [(32, 2, 37, 70), (64, 1, 64, 130), (128, 1, 23, 45)])
+def test_conv3x3_s2_split_plane_input_planes4_output(C, N, H, W):
+    """Stride-2 layer of the default data flow: input in split planes (raw block output) staged by LDS-DMA, output in planes of
+    4 channels -- equal to the [N][H][W][C] path bit for bit, in both output formats."""
+    from yond_public_amd.engine import _PackedConv
+    g = torch.Generator().manual_seed(C + W)
+    x = nhwc(torch.randn(N, C, H, W, generator=g))
+    w = torch.randn(2 * C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(2 * C, generator=g)
+    plan = bare_plan()
+    pc = _PackedConv(plan.dev, w, b, 3, 2, [C])
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    ref = torch.empty(N, Ho, Wo, 2 * C, device=DEV)
+    plan._conv(pc, x.to(DEV), None, N, H, W, ref, algo='split')
+    got = torch.empty(N, Ho, Wo, 2 * C, device=DEV)
+    plan._conv(pc, to_sp(x), None, N, H, W, got, algo='split', in_fmt=1)
+    gp4 = torch.empty(N * 2 * C * Ho * Wo, device=DEV)
+    plan._conv(pc, to_sp(x), None, N, H, W, gp4, algo='split', in_fmt=1, out_fmt=2)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), ref.cpu())
+    assert torch.equal(from_p4(gp4, N, Ho, Wo, 2 * C), ref.cpu())
+    z = F.conv2d(nchw(x).double(), w.double(), b.double(), stride=2, padding=1)
+    assert report(f"stride-2 from split planes C{C}", nchw(got.cpu()), z) < 2e-5
+
+
+@pytest.mark.parametrize("c,h,w", [(64, 24, 40), (32, 19, 33), (128, 9, 35)])
+def test_decoder_gemm_split_plane_inputs(c, h, w):
+    """The decoder GEMM (ConvTranspose2d 2x2 + cat + 1x1 shortcut folded) with BOTH sources in split planes -- the
+    low-resolution tensor and the skip tensor gathered at the sub-position -- and the output in either format."""
+    from yond_public_amd.engine import _PackedConv
+    g = torch.Generator().manual_seed(c + h)
+    N = 2
+    cur = nhwc(torch.randn(N, 2 * c, h, w, generator=g))
+    skip = nhwc(torch.randn(N, c, 2 * h, 2 * w, generator=g))
+    wf = torch.randn(3 * c, c, 2, 2, generator=g) / (3 * c) ** 0.5        # ConvTranspose2d layout over [cur | skip]
+    bf = torch.randn(c, generator=g)
+    plan = bare_plan()
+    pc = _PackedConv(plan.dev, wf, bf, 1, 1, [2 * c, c], shuffle=True)
+    ref = torch.empty(N, 2 * h, 2 * w, c, device=DEV)
+    plan._conv(pc, cur.to(DEV), skip.to(DEV), N, h, w, ref, algo='split')
+    got = torch.empty(N, 2 * h, 2 * w, c, device=DEV)
+    plan._conv(pc, to_sp(cur), to_sp(skip), N, h, w, got, algo='split', in_fmt=1)
+    gp4 = torch.empty(N * c * 4 * h * w, device=DEV)
+    plan._conv(pc, to_sp(cur), to_sp(skip), N, h, w, gp4, algo='split', in_fmt=1, out_fmt=2)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), ref.cpu())
+    assert torch.equal(from_p4(gp4, N, 2 * h, 2 * w, c), ref.cpu())
+
+
 def test_conv3x3_split_fused_12_row_tiles():
     """FiLM + SiLU + LeakyReLU + residual on a layer large enough for the 12 x 32-pixel tile shape (partial tiles both ways)."""
     g = torch.Generator().manual_seed(19)
@@ -449,7 +571,10 @@ def test_conv_in_and_out_and_maxpool_and_film():
     torch.cuda.synchronize()
     assert torch.equal(ubd.cpu(), ub)
     dst = torch.empty(N, H, W, 32, device=DEV)
-    L.check(lib.yond_conv_in_f32(L.ptr(x4), L.ptr(ubd), N, H, W, 32, L.ptr(wp), L.ptr(bp), 0.01, L.ptr(dst), L.stream()), "conv_in")
+    L.check(lib.yond_conv_in_f32(L.ptr(x4), L.ptr(ubd), N, H, W, 32, L.ptr(wp), L.ptr(bp), 0.01, L.ptr(dst), 0, L.stream()), "conv_in")
+    dst4 = torch.empty(N * 32 * H * W, device=DEV)
+    L.check(lib.yond_conv_in_f32(L.ptr(x4), L.ptr(ubd), N, H, W, 32, L.ptr(wp), L.ptr(bp), 0.01, L.ptr(dst4), 2, L.stream()), "conv_in")
+    assert torch.equal(from_p4(dst4, N, H, W, 32), dst.cpu())          # planes of 4 channels: the same values
     ref = F.leaky_relu(F.conv2d((x / ub.view(-1, 1, 1, 1)).double(), w.double(), b.double(), padding=1), 0.01)
     assert report("conv_in", nchw(dst.cpu()), ref) < 1e-5
     # conv_out

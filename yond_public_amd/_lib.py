@@ -23,7 +23,7 @@ class YondConvDesc(C.Structure):
                 ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
                 ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32),
                 ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp), ("status", vp),
-                ("in_fmt", i32), ("out_fmt", i32)]
+                ("in_fmt", i32), ("out_fmt", i32), ("res_fmt", i32)]
 
 
 class YondFilmDesc(C.Structure):
@@ -56,7 +56,7 @@ PROTOTYPES = {
     "yond_pack_conv_weight_split_f32": [vp, i32, i32, i32, i32, i32, vp],
     "yond_conv_split_supported": [i32, i32, i32, i32],
     "yond_pack_conv_split_weight_f32": [vp, i32, i32, i32, i32, i32, vp],
-    "yond_conv_in_f32": [vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp],
+    "yond_conv_in_f32": [vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, i32, vp],
     "yond_pack_conv_in_weight_f32": [vp, i32, vp],
     "yond_conv_out_f32": [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "yond_maxpool2_f32": [vp, i32, i32, i32, i32, vp, vp],

@@ -639,8 +639,8 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     if (d.C1 > 0 && !d.src1) return YOND_EINVAL;
     if ((long long)d.N * d.H * d.W > 0x7fffffffLL) return YOND_EUNSUPPORTED;    // 32-bit pixel offsets
     if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;
-    if ((d.in_fmt != 0 && d.in_fmt != 1) || (d.out_fmt != 0 && d.out_fmt != 1)) return YOND_EINVAL;
-    if ((d.in_fmt || d.out_fmt) && d.algo != 3) return YOND_EUNSUPPORTED;       // split planes: the split-operand kernel only
+    if (d.in_fmt < 0 || d.in_fmt > 2 || d.out_fmt < 0 || d.out_fmt > 2 || (d.res_fmt != 0 && d.res_fmt != 2)) return YOND_EINVAL;
+    if ((d.in_fmt || d.out_fmt || d.res_fmt) && d.algo != 3) return YOND_EUNSUPPORTED;       // other formats: the split-operand kernel only
     if (d.algo == 1) return yond_conv_wino_dispatch(d, st);
     if (d.algo == 3 || d.algo == 4) return yond_conv_split_dispatch(d, st);
     if (d.algo != 0 && d.algo != 2 && d.algo != 5) return YOND_EINVAL;

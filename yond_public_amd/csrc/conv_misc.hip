@@ -11,7 +11,7 @@ template <int TH>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ ub,
                                                       int H, int W, int Cout, const float* __restrict__ wpk,
                                                       const float* __restrict__ bias, float slope,
-                                                      float* __restrict__ dst) {
+                                                      float* __restrict__ dst, int out_p4) {
     constexpr int IH = TH + 2, IW = 34, MW = TH / 4;
     __shared__ __attribute__((aligned(16))) float s_in[IH * IW * 4];
     __shared__ __attribute__((aligned(16))) float s_w[5 * 2 * 32 * 4];
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     for (int m = 0; m < MW; ++m) {
         const int oy = oy0 + wave * MW + m;
         if (oy < H && ox < W) {
-            float* op = dst + ((size_t)(n * H + oy) * W + ox) * Cout + ct * 32 + 4 * lh;
+            // [N][H][W][Cout], or planes of 4 channels [N][Cout/4][H*W][4] (YOND_FMT_PLANES4: a wave stores 512 contiguous bytes)
+            float* op = out_p4 ? dst + (((size_t)n * (Cout / 4) + ct * 8 + lh) * H * W + (size_t)oy * W + ox) * 4
+                               : dst + ((size_t)(n * H + oy) * W + ox) * Cout + ct * 32 + 4 * lh;
+            const size_t gstep = out_p4 ? (size_t)8 * H * W : 8;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
                     const float x = acc[m][4 * g + e] + bv[e];
                     v[e] = x > 0.0f ? x : x * slope;
                 }
-                *(f32x4*)(op + 8 * g) = v;
+                *(f32x4*)(op + g * gstep) = v;
             }
         }
     }
@@ -95,12 +98,14 @@ extern "C" int yond_pack_conv_in_weight_f32(const float* w, int cout, float* dst
 }
 
 extern "C" int yond_conv_in_f32(const float* x, const float* ub, int N, int H, int W, int Cout, const float* wpk,
-                                const float* bias, float slope, float* dst, void* stream) {
+                                const float* bias, float slope, float* dst, int out_fmt, void* stream) {
     if (!x || !wpk || !dst || N <= 0 || H <= 0 || W <= 0 || N > 65535) return YOND_EINVAL;
+    if (out_fmt != YOND_FMT_NHWC_F32 && out_fmt != YOND_FMT_PLANES4) return YOND_EINVAL;
     if (Cout % 32 != 0) return YOND_EUNSUPPORTED;
     constexpr int TH = 8;
     dim3 grid((Cout / 32) * ((W + 31) / 32) * ((H + TH - 1) / TH), N);
-    hipLaunchKernelGGL(conv_in_kernel<TH>, grid, dim3(256), 0, (hipStream_t)stream, x, ub, H, W, Cout, wpk, bias, slope, dst);
+    hipLaunchKernelGGL(conv_in_kernel<TH>, grid, dim3(256), 0, (hipStream_t)stream, x, ub, H, W, Cout, wpk, bias, slope, dst,
+                       out_fmt == YOND_FMT_PLANES4 ? 1 : 0);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

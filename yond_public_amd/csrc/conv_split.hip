@@ -8,6 +8,8 @@ SPLIT_GROUP_S1_32(SPLIT_EXTERN)
 SPLIT_GROUP_HALF(SPLIT_EXTERN)
 SPLIT_GROUP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP(SPLIT_EXTERN)
+SPLIT_GROUP_ISP_OSP(SPLIT_EXTERN)
+SPLIT_GROUP_ISP_K1S2(SPLIT_EXTERN)
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
 // ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has
@@ -67,28 +69,52 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (!tn || d.C0 % 16 != 0 || d.C1 % 16 != 0 || (d.shuffle != 0) != (d.ksize == 1)) return YOND_EUNSUPPORTED;
     if (d.tn != tn) return YOND_EINVAL;                         // the layout the weights were packed for
     if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
-    if ((d.in_fmt || d.out_fmt) && (d.ksize != 3 || d.stride != 1)) return YOND_EUNSUPPORTED;
+    // tensor formats (include/yond_hip.h): split planes in (LDS-DMA staging) / out (stored from the accumulator layout), planes
+    // of 4 channels for the float32 tensors that are read as residuals
+    const bool isp = d.in_fmt == YOND_FMT_SPLIT_PLANES, osp = d.out_fmt == YOND_FMT_SPLIT_PLANES;
+    const bool ip4 = d.in_fmt == YOND_FMT_PLANES4, op4 = d.out_fmt == YOND_FMT_PLANES4, rp4 = d.res_fmt == YOND_FMT_PLANES4;
+    if ((d.in_fmt || d.out_fmt || d.res_fmt) && parts != 2) return YOND_EUNSUPPORTED;
+    if (d.res_fmt != YOND_FMT_NHWC_F32 && !rp4) return YOND_EINVAL;
+    if (isp && d.pre_act) return YOND_EUNSUPPORTED;             // the producer applied the activation
+    if (rp4 != (osp && d.res != nullptr)) return YOND_EUNSUPPORTED;   // a split-plane store reads its residual in planes of 4, nothing else does
+    if (osp && d.res && !isp) return YOND_EUNSUPPORTED;              // ... and only conv2 of a block has one: split-plane input
+    if (ip4 && (long long)d.N * (d.C0 > d.C1 ? d.C0 : d.C1) * d.H * d.W * (d.ksize == 1 ? 4 : 1) >= 0x7fffffffLL) return YOND_EUNSUPPORTED;   // 32-bit element offsets
+    if (isp && (d.ksize == 1 || d.stride == 2)) {
+        // (these stage split planes through registers: 32-bit element offsets over the whole tensor)
+        const long long e0 = (long long)d.N * (d.C0 / 16) * 4 * YOND_SP_PLANE_UNITS(d.H, d.W) * 4;
+        const long long e1 = d.ksize == 1 ? (long long)d.N * (d.C1 / 16) * 4 * YOND_SP_PLANE_UNITS(2 * d.H, 2 * d.W) * 4 : 0;
+        if (e0 >= 0x7fffffffLL || e1 >= 0x7fffffffLL) return YOND_EUNSUPPORTED;
+    }
+    if (isp) {
+        // 32-bit unit offsets inside a plane, 32-bit plane arithmetic
+        const long long ps = (long long)YOND_SP_PLANE_UNITS(d.H, d.W) * (d.ksize == 1 ? 4 : 1);
+        if (ps * 16 * 4 >= 0x7fffffffLL) return YOND_EUNSUPPORTED;
+    }
     if (d.ksize == 1) {
         // the decoder GEMM: low-resolution input (C0) + skip tensor at the output resolution (C1), pixel-shuffle store
-        if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W) return YOND_EUNSUPPORTED;
+        if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W || osp || ip4) return YOND_EUNSUPPORTED;
+        if (isp) return tn == 32 ? launch_split<1, 8, 32, 1, 2, 3, false, false, true, 2>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2>(d, st);
         if (tn == 32) return launch_split<1, 8, 32, 1, 2, 3, false, false, true>(d, st);    // level 1 -> 0: 32-channel output pixels
         return launch_split<1, 8, 64, 2, 2, 3, false, false, true>(d, st);
     }
     if (d.stride == 2) {
         if (d.Ho != (d.H + 1) / 2 || d.Wo != (d.W + 1) / 2 || d.pre_act) return YOND_EINVAL;
+        if (osp || ip4 || (op4 && d.res)) return YOND_EUNSUPPORTED;
         // stride 2: 4 x 32 output pixels read 9 x 65 input pixels -- two weight buffers fit beside the two input images
+        if (isp) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2>(d, st);
         return parts == 2 ? launch_split<2, 4, 64, 1, 2, 2, false>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false>(d, st);
     }
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
-    if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
     if (d.out4_dst && (tn != 32 || parts != 2)) return YOND_EUNSUPPORTED;
-    const bool isp = d.in_fmt == YOND_FMT_SPLIT_PLANES, osp = d.out_fmt == YOND_FMT_SPLIT_PLANES;
+    if (op4) return YOND_EUNSUPPORTED;                          // (3x3 stride-1 layers store [N][H][W][C] or split planes)
+    const long long tiles12 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
     if (isp || osp) {
-        // split planes: the producer side of a block-internal tensor (register-staged input, split-plane store) or its consumer
-        // (input by LDS-DMA alone); both at once is not instantiated
-        if (parts != 2 || (isp && osp) || (isp && d.pre_act) || (osp && (d.res || d.out4_dst))) return YOND_EUNSUPPORTED;
-        if ((long long)YOND_SP_PLANE_UNITS(d.H, d.W) * 16 * 4 >= 0x7fffffffLL) return YOND_EUNSUPPORTED;     // 32-bit unit offsets
-        const long long tiles12 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
+        if (osp && d.out4_dst) return YOND_EUNSUPPORTED;
+        if (isp && osp) {
+            if (tn == 64 && tiles12 >= 256) return launch_split<1, 12, 64, 3, 2, 2, false, false, false, true, true>(d, st);
+            if (tn == 64) return launch_split<1, 8, 64, 2, 2, 3, false, false, false, true, true>(d, st);
+            return launch_split<1, 16, 32, 2, 2, 3, false, false, false, true, true>(d, st);
+        }
         if (osp) {
             if (tn == 64 && tiles12 >= 256) return d.pre_act ? launch_split<1, 12, 64, 3, 2, 2, true, false, false, false, true>(d, st) : launch_split<1, 12, 64, 3, 2, 2, false, false, false, false, true>(d, st);
             if (tn == 64) return d.pre_act ? launch_split<1, 8, 64, 2, 2, 3, true, false, false, false, true>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false, false, false, false, true>(d, st);
@@ -102,9 +128,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (tn == 64) {
         // 12 x 32-pixel tiles, three rows per wave: 0.59 instead of 0.78 KiB of LDS fragments per MFMA, 1.5x the MFMA work per
         // step (and per barrier), and 94 / 188 / 376 / 752 rows fill 256 workgroups in whole rounds (1 / 2 / 4 / 8)
-        static const char* e12 = getenv("YOND_SPLIT_TH12");              // experiments: 0 never, 1 always
-        const long long tiles12 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
-        const bool th12 = e12 ? atoi(e12) != 0 : tiles12 >= 256;
+        const bool th12 = tiles12 >= 256;
         if (parts == 2 && th12) return d.pre_act ? launch_split<1, 12, 64, 3, 2, 2, true>(d, st) : launch_split<1, 12, 64, 3, 2, 2, false>(d, st);
         if (parts == 2) return d.pre_act ? launch_split<1, 8, 64, 2, 2, 3, true>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false>(d, st);
         return d.pre_act ? launch_split<1, 8, 64, 2, 1, 3, true>(d, st) : launch_split<1, 8, 64, 2, 1, 3, false>(d, st);

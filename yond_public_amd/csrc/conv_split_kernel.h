@@ -125,10 +125,14 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 // what the staging below would have written into LDS, stored once by the PRODUCER's epilogue (OSP) with the consumer's
 // pre-activation already applied; the consumer's step then has no vector work at all for its input: 2 x PARTS LDS-DMAs per
 // 16-channel chunk (out-of-image units come from the zero unit behind every plane).  Same bits as staging the fp32 tensor.
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, bool ISP = false, bool OSP = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
-    static_assert(!ISP || (!PRE && PARTS == 2), "split-plane input: the producer applied the activation; split precision only");
+    // split-plane input: ISPM 1 (ISP) by LDS-DMA, one step ahead -- the layers whose steps are long enough to cover the DMA's
+    // latency; ISPM 2 (ISR) through the three register sets of the staging pipeline (a load has two steps to arrive), written to LDS
+    // as whole 16-byte units with no arithmetic -- the stride-2 layers and the decoder GEMMs, whose steps hold 9-27 MFMAs per wave
+    constexpr bool ISP = ISPM == 1, ISR = ISPM == 2;
+    static_assert(ISPM == 0 || (!PRE && PARTS == 2), "split-plane input: the producer applied the activation; split precision only");
     static_assert(!OSP || (!O4 && !K1 && STRIDE == 1 && PARTS == 2), "split-plane output: 3x3 stride-1 layers at split precision");
     constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
     constexpr int NIN = ISP ? 0 : C::NIN;                    // register-staged 16-byte items per thread and step
@@ -165,6 +169,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         const int py = pix / C::IW, px = pix % C::IW;
         const int lp = (STRIDE == 2) ? py * C::TWP + (px & 1) * C::HALF + (px >> 1) : py * C::TWP + px;
         in_lds[k] = my_plane + (it < C::NITEM ? pt * 2 * PARTS * C::PLANE + lp * 4 : C::IH * C::TWP * 4);
+        // ISR: the thread's slot is a PLANE (channel half my_sl >> 1, part my_sl & 1) and the item a whole 16-byte unit
+        if constexpr (ISR) in_lds[k] = ((my_sl >> 1) * PARTS + (my_sl & 1)) * C::PLANE + (it < C::NITEM ? pt * 2 * PARTS * C::PLANE + lp * 4 : C::IH * C::TWP * 4);
     }
 
     struct Tile {
@@ -228,9 +234,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             const int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
             const bool ok = it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
             T.goff[k] = ok ? ((n * d.H + gy) * d.W + gx) : -1;
+            if constexpr (ISR) T.goff[k] = ok ? gy * d.W + gx : d.H * d.W;      // unit inside a plane (n is in the plane base); outside: the zero unit
             if constexpr (K1) {
                 const int sp = (T.ct * TN) / Cr;               // a channel tile never straddles two sub-positions
                 T.goff1[k] = ok ? ((n * 2 * d.H + 2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1)) : -1;
+                if constexpr (ISR) T.goff1[k] = ok ? (2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1) : 4 * d.H * d.W;
             }
         }
         }
@@ -249,14 +257,31 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     float amax = 0.0f;                                         // largest |activation| this thread has staged (range guard)
     // one 16-byte load of a set (item k); the source of the chunk is selected once per step (LoadSrc)
     // source of a step's 16-channel chunks (K1: three of them, each from the low-resolution input or from the skip tensor)
-    struct LoadSrc { const float* src[C::NPT]; int Cs[C::NPT], cc[C::NPT]; bool hi[C::NPT]; };
-    auto load_src = [&](int ch) {
+    // (address of an item = src + pixel offset * A + B: [N][H][W][C] float32: A = C, B = chunk channel + 4 slot; planes of 4
+    // channels, YOND_FMT_PLANES4 [N][C/4][H*W][4]: A = 4, B = 4 (plane index * H*W - n H*W): the pixel offset carries n H*W)
+    struct LoadSrc { const float* src[C::NPT]; int A[C::NPT], B[C::NPT]; bool hi[C::NPT]; };     // (B: 32 bits -- the dispatcher checks the extent)
+    const bool in_p4 = d.in_fmt == YOND_FMT_PLANES4;
+    auto load_src = [&](int ch, int n) {
         LoadSrc L;
 #pragma unroll
         for (int t = 0; t < C::NPT; ++t) {
             const int c0 = (ch * C::NPT + t) * C::KC;
-            if (c0 < d.C0) { L.src[t] = d.src0; L.Cs[t] = d.C0; L.cc[t] = c0; L.hi[t] = false; }
-            else { L.src[t] = d.src1; L.Cs[t] = d.C1; L.cc[t] = c0 - d.C0; L.hi[t] = K1; }
+            const bool second = c0 >= d.C0;
+            const int Cs = second ? d.C1 : d.C0, cc = second ? c0 - d.C0 : c0;
+            L.src[t] = second ? d.src1 : d.src0;
+            L.hi[t] = second && K1;
+            if constexpr (ISR) {
+                // split planes: unit index inside the plane * 4 floats + the base of plane (n, chunk, channel half, part = the slot)
+                L.A[t] = 4;
+                L.B[t] = ((n * (Cs / 16) + cc / 16) * 4 + my_sl) * (L.hi[t] ? PS1 : PS0) * 4;
+            } else if (in_p4) {
+                const int hw = d.H * d.W * (L.hi[t] ? 4 : 1);
+                L.A[t] = 4;
+                L.B[t] = 4 * ((n * (Cs / 4) + cc / 4 + my_sl) * hw - n * hw);
+            } else {
+                L.A[t] = Cs;
+                L.B[t] = cc + my_sl * 4;
+            }
         }
         return L;
     };
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         const bool ok = T.goff[k] >= 0;                        // outside the image: read pixel 0, zeroed at the LDS write
         int po = T.goff[k];
         if constexpr (K1) po = L.hi[t] ? T.goff1[k] : po;
-        if (!(SPLIT_ABL & 1)) vin[P][k] = *(const f32x4*)(L.src[t] + (size_t)(ok ? po : 0) * L.Cs[t] + L.cc[t] + my_sl * 4);
+        if (!(SPLIT_ABL & 1)) vin[P][k] = *(const f32x4*)(L.src[t] + (long long)(ok ? po : 0) * L.A[t] + L.B[t]);
         if (k == 0) vin_ok[P] = 0;
         vin_ok[P] |= (ok ? 1u : 0u) << k;
     };
@@ -312,7 +337,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(plane * C::PLANE * 4 + wv * 1024));
         const char* b0 = I.base[0];
         if constexpr (C::NPT > 1) b0 = pt == 1 ? I.base[1] : (pt == 2 ? I.base[C::NPT - 1] : b0);
-        const char* gb = b0 + (size_t)pl * (size_t)(hi ? PS1 : PS0) * 16;
+        const unsigned long long ga = (unsigned long long)(uintptr_t)(b0 + (size_t)pl * (size_t)(hi ? PS1 : PS0) * 16);
+        // (wave-uniform: the DMA takes it in SGPRs.  readfirstlane returns int: through unsigned, or the low half sign-extends)
+        const unsigned ga_lo = __builtin_amdgcn_readfirstlane((unsigned)ga), ga_hi = __builtin_amdgcn_readfirstlane((unsigned)(ga >> 32));
+        const char* gb = (const char*)(uintptr_t)(((unsigned long long)ga_hi << 32) | ga_lo);
         int voff = T.goff[k];
         if constexpr (K1) voff = hi ? T.goff1[k] : voff;
         if (voff >= 0)
@@ -330,6 +358,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     auto stage_task = [&](auto pc, auto ec, float* ob) {
         constexpr int P = decltype(pc)::value;
         constexpr int e = decltype(ec)::value, k = e / 4, j = e % 4;
+        if constexpr (ISR) {
+            // the unit is already what the LDS image holds (zero unit outside the image): one 16-byte store per item
+            if constexpr (j == 3) *(f32x4*)(ob + in_lds[k]) = vin[P][k];
+            return;
+        }
         float x = vin[P][k][j];
         if (PRE) x = split_silu(x);
         vin[P][k][j] = ((vin_ok[P] >> k) & 1u) ? x : 0.0f;                              // conv zero padding
@@ -473,7 +506,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             // each MFMA followed by a few of the vector instructions, then the LDS writes of a completed item.
             constexpr int nrd = (q + 2 < NQ ? PARTS : 0) + (wpre ? (K1 ? 1 : 3) * C::NW * PARTS : 0);
             if constexpr (nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
-            constexpr int nvalu = (e_hi - e_lo) * (PRE ? 7 : 2) + nfin * (PARTS == 2 ? 22 : 6);
+            constexpr int nvalu = ISR ? 0 : (e_hi - e_lo) * (PRE ? 7 : 2) + nfin * (PARTS == 2 ? 22 : 6);
             constexpr int vpm = (nvalu + nmf - 1) / nmf;
 #pragma unroll
             for (int i = 0; i < nmf; ++i) {
@@ -481,7 +514,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 if constexpr (vpm > 0) __builtin_amdgcn_sched_group_barrier(0x002, vpm, 0);
             }
             if constexpr (wrep) __builtin_amdgcn_sched_group_barrier(0x100, C::NW * PARTS, 0);
-            if constexpr (nfin > 0) __builtin_amdgcn_sched_group_barrier(0x200, nfin * PARTS, 0);
+            if constexpr (nfin > 0) __builtin_amdgcn_sched_group_barrier(0x200, ISR ? nfin : nfin * PARTS, 0);
         });
     };
 
@@ -521,7 +554,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // transposed epilogue waiting 10-14 thousand cycles per tile for its residual loads (two dependent round trips to HBM per
     // tile, every wave of the CU at once): the loads of the first two rows are issued at the START of the tile's last step
     // and land under its MFMAs; a third row is requested when the epilogue begins, ahead of the first rows' arithmetic.
-    constexpr bool RPF = ISP && EP_FIT && !K1 && C::NW == 1;
+    constexpr bool RPF = ISP && !OSP && EP_FIT && !K1 && C::NW == 1;
     constexpr int PFR = MW < 2 ? MW : 2;
     f32x4 prr[RPF ? PFR : 1][4];
     float pxq[RPF && O4 ? PFR : 1][4];
@@ -698,9 +731,43 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // already the store layout: a lane owns 4 consecutive channels of one pixel = half a unit, the 32 pixels of a fragment
     // are 32 consecutive units, so a wave-instruction writes 512 contiguous bytes and nothing goes through LDS but the FiLM
     // vectors (prefetched 8 lanes per block as for the transposed epilogue, redistributed through 256 private bytes).
+    // The residual of a split-plane store is read in PLANES OF 4 CHANNELS (YOND_FMT_PLANES4): in the accumulator layout a lane
+    // then loads 16 bytes of its own pixel and the 32 pixels of a fragment are 512 contiguous bytes -- no transpose either.
+    // With split-plane input (no staging registers) the first two rows' residual is requested at the start of the tile's last
+    // step, like the FiLM vectors.
+    constexpr bool ORP = OSP && ISP;
+    f32x4 qrr[ORP ? PFR : 1][C::NW][4];
+    auto res4_addr = [&](const Tile& T, int nn, int m, int g) -> const float* {
+        const int oy = T.oy0 + rg * MW + m, ox = T.ox0 + li;
+        const bool ok = d.res && oy < d.Ho && ox < d.Wo;
+        const int c4 = (T.ct * TN + (cg * C::NW + nn) * 32 + 8 * g) / 4 + lh;
+        const long long off = (((long long)T.n * (d.Cout / 4) + c4) * d.Ho * d.Wo + (long long)oy * d.Wo + ox) * 4;
+        return (d.res ? d.res : d.wpk) + (ok ? off : 0);
+    };
+    auto res4_prefetch = [&](const Tile& T) __attribute__((always_inline)) {
+        if constexpr (ORP) {
+#pragma unroll
+            for (int mm = 0; mm < PFR; ++mm)
+#pragma unroll
+                for (int nn = 0; nn < C::NW; ++nn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) qrr[mm][nn][g] = *(const f32x4*)res4_addr(T, nn, mm, g);
+        }
+    };
     auto epilogue_sp = [&](auto hr, auto actc, const Tile& T) __attribute__((always_inline)) {
-        constexpr bool HAS_SCALE = (decltype(hr)::value & 2) != 0, HAS_SHIFT = (decltype(hr)::value & 4) != 0;
+        constexpr bool HAS_RES = (decltype(hr)::value & 1) != 0, HAS_SCALE = (decltype(hr)::value & 2) != 0, HAS_SHIFT = (decltype(hr)::value & 4) != 0;
         constexpr int ACT = decltype(actc)::value;
+        // residual rows that were not prefetched: requested first, ahead of all arithmetic
+        constexpr int LR0 = ORP ? PFR : 0;
+        f32x4 lrr[HAS_RES && MW > LR0 ? MW - LR0 : 1][C::NW][4];
+        if constexpr (HAS_RES && MW > LR0) {
+#pragma unroll
+            for (int mm = LR0; mm < MW; ++mm)
+#pragma unroll
+                for (int nn = 0; nn < C::NW; ++nn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) lrr[mm - LR0][nn][g] = *(const f32x4*)res4_addr(T, nn, mm, g);
+        }
         float* fw = smem + C::FILM_OFF + wave * (C::NW * 64);
         if (lane < 8) {
 #pragma unroll
@@ -736,6 +803,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                         if constexpr (ACT == 2 || ACT < 0) y = y > 0.0f ? y : y * slope_eff;
                         if constexpr (ACT == 1) y = split_silu(y);
                         if constexpr (ACT < 0) { if (silu_out) y = split_silu(y); }
+                        if constexpr (HAS_RES) y += (m < LR0 ? qrr[m < LR0 ? m : 0][nn][g][e] : lrr[m >= LR0 ? m - LR0 : 0][nn][g][e]);
                         v[e] = y;
                     }
                     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -754,12 +822,17 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 
     // (plain form, lane = pixel: kept for the shapes whose free buffer is smaller than the scratch -- the h-only fp16 path)
     auto epilogue_direct = [&](const Tile& T) {
+        // lane = pixel: NHWC stores from here touch 32 lines with 32 bytes each; into PLANES OF 4 CHANNELS (out_fmt 2) the 32
+        // pixels of a fragment are 512 contiguous bytes (K1: every other 16-byte unit of the pixel-shuffled row)
         const int ox = T.ox0 + li;
         const bool col_ok = ox < d.Wo;
+        const bool out_p4 = d.out_fmt == YOND_FMT_PLANES4;
+        const int Hout = K1 ? 2 * d.Ho : d.Ho, Wout = K1 ? 2 * d.Wo : d.Wo;
 #pragma unroll
         for (int nn = 0; nn < C::NW; ++nn) {
-            const int cbase = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * lh;
-            const int eoff = (d.ebatch ? T.n * d.Cout : 0) + cbase;
+            const int cfull = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * lh;
+            const int sp = K1 ? cfull / Cr : 0, cbase = K1 ? cfull % Cr : cfull;     // K1: sub-position of the tile's channel block
+            const int eoff = (d.ebatch ? T.n * Cr : 0) + cbase;
             f32x4 es[4], et[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -776,14 +849,17 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                    rr[m][g] = d.res ? *(const f32x4*)(d.res + off + (ok ? 8 * g : 0)) : z;
+                    rr[m][g] = (d.res && !K1) ? *(const f32x4*)(d.res + off + (ok ? 8 * g : 0)) : z;
                 }
             }
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
                 const int oy = T.oy0 + rg * MW + m;
                 const bool ok = col_ok && oy < d.Ho;
-                float* op = d.dst + ((long long)(T.n * d.Ho + oy) * d.Wo + ox) * d.Cout + cbase;
+                const long long pixo = (long long)(K1 ? 2 * oy + (sp >> 1) : oy) * Wout + (K1 ? 2 * ox + (sp & 1) : ox);
+                float* op = out_p4 ? d.dst + (((long long)T.n * (Cr / 4) + cbase / 4) * Hout * Wout + pixo) * 4
+                                   : d.dst + ((long long)T.n * Hout * Wout + pixo) * Cr + cbase;
+                const long long gstep = out_p4 ? 8LL * Hout * Wout : 8;              // elements from one 8-channel group to the next
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
@@ -796,7 +872,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                         if (silu_out) x = split_silu(x);
                         v[e] = x + rr[m][g][e];
                     }
-                    if (ok) *(f32x4*)(op + 8 * g) = v;
+                    if (ok) *(f32x4*)(op + g * gstep) = v;
                 }
             }
         }
@@ -840,7 +916,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
     auto load_all = [&](auto pc, Cur c) {
         tile_for(c);
-        const LoadSrc L = load_src(c.ch);
+        const LoadSrc L = load_src(c.ch, lt.n);
         static_for<0, NIN>([&](auto kc) { issue_load(pc, kc, lt, L); });
     };
     auto dma_in_all = [&](Cur c, float* ob) {      // ISP: a whole input image by LDS-DMA
@@ -906,12 +982,13 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             if (last_ch) {
                 epi_prefetch(cur);
                 res_prefetch(cur);
+                res4_prefetch(cur);
             }
         }
         auto prep = [&]() __attribute__((always_inline)) {
             tile_for(cl);
             if constexpr (ISP) is_s = in_src(cl.ch, lt.n);
-            else ls_s = load_src(cl.ch);
+            else ls_s = load_src(cl.ch, lt.n);
             wsrc_s = weight_src(ct_of(cw, cur.ct), cw.ch);
         };
         SDBG(1);
@@ -925,14 +1002,22 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             // step's DMA and staging writes (of OTHER waves) out of it until every wave has read its block back
             if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) {
                 if constexpr (OSP) {
-                    // straight-line variants: the residual blocks' conv1 (FiLM + SiLU), a plain layer with LeakyReLU; the rest generic
-                    const int flags = (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
+                    // straight-line variants: the residual blocks' conv1 (FiLM + SiLU) and conv2 (FiLM + residual), a plain layer
+                    // with LeakyReLU; the rest generic
+                    const int flags = (d.res ? 1 : 0) | (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
                     if (flags == 6 && d.post_act == 1) epilogue_sp(IntC<6>{}, IntC<1>{}, cur);
-                    else if (flags == 4 && d.post_act == 2) epilogue_sp(IntC<4>{}, IntC<2>{}, cur);
+                    else if (ORP && flags == 7 && d.post_act == 0) {
+                        if constexpr (ORP) epilogue_sp(IntC<7>{}, IntC<0>{}, cur);
+                    } else if (flags == 4 && d.post_act == 2) epilogue_sp(IntC<4>{}, IntC<2>{}, cur);
                     else
-                        static_for<0, 4>([&](auto fcx) __attribute__((always_inline)) {
-                            if (flags == 2 * decltype(fcx)::value) epilogue_sp(IntC<2 * decltype(fcx)::value>{}, IntC<-1>{}, cur);
+                        static_for<0, 8>([&](auto fcx) __attribute__((always_inline)) {
+                            // (a residual only with split-plane input -- conv2 of a block: the dispatcher refuses the rest)
+                            if constexpr (ORP || (decltype(fcx)::value & 1) == 0) {
+                                if (flags == decltype(fcx)::value) epilogue_sp(fcx, IntC<-1>{}, cur);
+                            }
                         });
+                } else if (K1 && d.out_fmt == YOND_FMT_PLANES4) {
+                    epilogue_direct(cur);                          // (planes of 4 channels: stored from the accumulator layout)
                 } else if constexpr (EP_FIT) {
                     float* scr = EP_IN_W ? w0 : ibuf;
                     const int flags = (d.res ? 1 : 0) | (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
@@ -987,7 +1072,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     if (d.status && !(amax <= 65504.0f)) atomicOr(d.status, YOND_STATUS_HALF_OVERFLOW);   // an h half became +-inf
 }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, bool ISP = false, bool OSP = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false>
 int launch_split(const YondConvDesc& d, hipStream_t st) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
     static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
@@ -1028,5 +1113,11 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 #define SPLIT_GROUP_ISP(X)                                                                              \
     X(1, 12, 64, 3, 2, 2, false, false, false, true, false) X(1, 8, 64, 2, 2, 3, false, false, false, true, false) \
     X(1, 16, 32, 2, 2, 3, false, true, false, true, false) X(1, 16, 32, 2, 2, 3, false, false, false, true, false)
+#define SPLIT_GROUP_ISP_OSP(X)                                                                          \
+    X(1, 12, 64, 3, 2, 2, false, false, false, true, true) X(1, 8, 64, 2, 2, 3, false, false, false, true, true) \
+    X(1, 16, 32, 2, 2, 3, false, false, false, true, true)
+#define SPLIT_GROUP_ISP_K1S2(X)                                                                         \
+    X(1, 8, 32, 1, 2, 3, false, false, true, 2, false) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false) \
+    X(2, 4, 64, 1, 2, 2, false, false, false, 2, false)
 #define SPLIT_INSTANTIATE(...) template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);
 #define SPLIT_EXTERN(...) extern template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);

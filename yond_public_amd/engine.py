@@ -35,15 +35,16 @@ def _np_ptr(a):
 
 # 3x3 stride-1 layers: 1 = Winograd F(2x2,3x3) wherever the kernel supports the shape (measured 1.45-1.5x over the direct
 # kernel at 64..512 channels, 1.15x on the 32-channel level-0 layers), 0 = direct implicit GEMM everywhere
-_e = os.environ.get('YOND_CONV_WINO', 'split')
-WINO_DEFAULT = int(_e) if _e.isdigit() else _e          # 'split' (default): fp32-accurate split-operand fp16-MFMA kernel where it
-                                                         # applies, fp32 Winograd elsewhere; 0 direct fp32 MFMA, 1/2 Winograd fp32 MFMA
+WINO_DEFAULT = 'split'              # 'split': fp32-accurate split-operand fp16-MFMA kernels where they apply, fp32 Winograd elsewhere;
+                                    # 0 direct fp32 MFMA, 1 / 2 Winograd fp32 MFMA (module attribute: tools/ set it for A/B runs)
 
 
 # Block-internal tensors in SPLIT PLANES (include/yond_hip.h, YondConvDesc.in_fmt / out_fmt): conv1's epilogue stores
 # SiLU(FiLM(conv1)) already split into the (h, l) fp16 halves its one consumer would stage, conv2 stages by LDS-DMA alone.
 # (Module attribute, not an environment switch: tools/ flip it for A/B runs.)
 SPLIT_PLANES = True
+SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
+FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
 
 
 def sp_plane_units(H, W):
@@ -135,7 +136,7 @@ class _PackedConv:
     def split(self, parts=2):
         """(tn, weights packed for the split-operand fp16-MFMA kernel) or None when the layer does not fit it."""
         lib = L.load()
-        if self.shuffle != (self.ksize == 1) or (self.shuffle and (parts != 2 or os.environ.get('YOND_SPLIT_1X1', '1') == '0')):
+        if self.shuffle != (self.ksize == 1) or (self.shuffle and parts != 2):
             return None                     # ksize 1: the decoder's pixel-shuffle GEMM only (48-channel steps, >= 64 channels)
         tn = int(lib.yond_conv_split_supported(self.ksize, self.stride, self.cinp, self.gemm_n))
         if not tn:
@@ -256,19 +257,29 @@ class DenoiserPlan:
         between them may then sit in the producer's epilogue (descriptor post_act 1)."""
         if getattr(self, 'strict', False) or getattr(self, 'conv_algo', WINO_DEFAULT) != 'split':
             return False
-        if os.environ.get('YOND_SILU_PRODUCER', '1') == '0':          # experiments: the SiLU back in the consumer's staging
-            return False
         prec = getattr(self, 'precision', 'fp32')
         if prec not in ('fp32', 'fp16'):
             return False
         parts = 2 if prec == 'fp32' else 1
         return all(pc.ksize == 3 and pc.stride == 1 and pc.split(parts) is not None for pc in (pc1, pc2))
 
+    def _sp_flow(self, N, H, W):
+        """True when a guided net's whole forward runs in the split-plane data flow (see forward_nhwc4): fp32 results at
+        split precision, every 3x3 / stride-2 / decoder layer on the split-operand kernel, the output projection fused."""
+        if not (SPLIT_PLANES and SP_FLOW) or getattr(self, 'strict', False) or getattr(self, 'conv_algo', WINO_DEFAULT) != 'split':
+            return False
+        if getattr(self, 'precision', 'fp32') != 'fp32' or sp_plane_units(H, W) * 64 * 4 >= 2 ** 31:
+            return False
+        for i, blk in self.blocks.items():
+            for k in ('conv1', 'conv2', 'pool', 'upsc'):
+                if k in blk and blk[k].split(2) is None:
+                    return False
+        return self._out4_fusable(self.blocks[9]['conv2'])
+
     def _out4_fusable(self, pc):
         """The 1x1 output projection can ride in the epilogue of the last 3x3 convolution: split kernel, one 32-channel tile."""
         return (not getattr(self, 'strict', False) and getattr(self, 'conv_algo', WINO_DEFAULT) == 'split' and getattr(self, 'precision', 'fp32') == 'fp32'
-                and pc.ksize == 3 and pc.stride == 1 and pc.gemm_n == 32 and pc.split(2) is not None
-                and os.environ.get('YOND_FUSE_OUT4', '1') != '0')
+                and pc.ksize == 3 and pc.stride == 1 and pc.gemm_n == 32 and pc.split(2) is not None and FUSE_OUT4)
 
     def _new_sp(self, key, N, H, W, Cc):
         """A split-plane tensor [N][Cc/16][2][2][sp_plane_units(H, W)] x 16 bytes, kept per (key, shape) across forwards: the
@@ -280,7 +291,7 @@ class DenoiserPlan:
         return cache[k]
 
     def _conv(self, pc, src0, src1, N, H, W, dst, escale=None, eshift=None, ebatch=0, res=None, pre_act=0, post_act=0,
-              slope=0.0, algo=None, out4=None, in_fmt=0, out_fmt=0):
+              slope=0.0, algo=None, out4=None, in_fmt=0, out_fmt=0, res_fmt=0):
         d = L.YondConvDesc()
         d.src0 = src0.data_ptr()
         d.src1 = src1.data_ptr() if src1 is not None else None
@@ -337,9 +348,9 @@ class DenoiserPlan:
         d.dst = dst.data_ptr() if dst is not None else None
         status = getattr(self, 'status', None)                       # (bare plans of the kernel tests have none)
         d.status = status.data_ptr() + 4 * self.status_slot if status is not None else None
-        d.in_fmt, d.out_fmt = in_fmt, out_fmt
-        if (in_fmt or out_fmt) and d.algo != 3:
-            raise L.YondHipError("split-plane tensors need the split-operand 3x3 kernel (algo 3)")
+        d.in_fmt, d.out_fmt, d.res_fmt = in_fmt, out_fmt, res_fmt
+        if (in_fmt or out_fmt or res_fmt) and d.algo != 3:
+            raise L.YondHipError("split-plane / 4-channel-plane tensors need the split-operand kernel (algo 3)")
         if out4 is not None:
             # (w [4][Cout], bias [4], network input NHWC4 or None, per-image maxima or None, destination NHWC4)
             w4, b4, x4, ub4, o4 = out4
@@ -445,9 +456,17 @@ class DenoiserPlan:
             if t_dev is None:
                 raise L.YondHipError(f"{self.kind}.forward needs the noise level t")
             film = self._film(t_dev, ub, N)
+            # Tensor formats of the default path (every MFMA layer on the split-operand kernel, fp32 results):
+            #   x   (block input: conv_in / stride-2 / decoder GEMM output; read by conv1 and as conv2's residual)  planes of 4 channels
+            #   tmp (conv1 -> conv2)      split planes of SiLU(FiLM(conv1)), stored by conv1's epilogue
+            #   out (block output; read by the stride-2 layer and, as `cur` / skip, by the decoder GEMMs)  split planes, raw
+            # so conv2, the stride-2 layers and the decoder GEMMs stage by LDS-DMA alone and every epilogue but the last stores
+            # from the accumulator layout.  The last block keeps [N][H][W][C]: its conv2 carries the fused output projection.
+            flow = self._sp_flow(N, H, W)
+            P4, SP = 2, 1
             a = self._new(N, H, W, nfp)
             L.check(lib.yond_conv_in_f32(L.ptr(x4), L.ptr(ub), N, H, W, nfp, L.ptr(self.conv_in_w), L.ptr(self.conv_in_b),
-                                         0.01, L.ptr(a), st), "yond_conv_in_f32")
+                                         0.01, L.ptr(a), P4 if flow else 0, st), "yond_conv_in_f32")
             skips = {}
             h, w = H, W
             cur = a
@@ -455,10 +474,12 @@ class DenoiserPlan:
                 blk = self.blocks[i]
                 cp = blk['Cp']
                 f = film[f'conv{i}']
+                last = i == 9
+                xfmt = P4 if (flow and not last) else 0          # format of this block's input x
                 if i >= 6:
                     # ConvT 2x2 s2 + the block's 1x1 shortcut over [up, skip] as one GEMM with a pixel-shuffle store
                     xs = self._new(N, 2 * h, 2 * w, cp)
-                    self._conv(blk['upsc'], cur, skips[10 - i], N, h, w, xs)
+                    self._conv(blk['upsc'], cur, skips[10 - i], N, h, w, xs, in_fmt=SP if flow else 0, out_fmt=xfmt)
                     h, w = 2 * h, 2 * w
                     cur = xs
                 # z = conv2(SiLU(FiLM(conv1(SiLU(x))))) + x : the first SiLU runs in conv1's staging (x has other readers); the
@@ -467,32 +488,37 @@ class DenoiserPlan:
                 # At split precision tmp is stored in SPLIT PLANES: conv1 writes the (h, l) halves conv2 would have staged,
                 # conv2 stages them by LDS-DMA alone (the same bits again)
                 act_in_producer = self._split_pair(blk['conv1'], blk['conv2'])
-                sp = 1 if (act_in_producer and SPLIT_PLANES and getattr(self, 'precision', 'fp32') == 'fp32'
-                           and sp_plane_units(h, w) * 64 < 2 ** 31) else 0
+                sp = SP if (flow or (act_in_producer and SPLIT_PLANES and getattr(self, 'precision', 'fp32') == 'fp32'
+                                      and sp_plane_units(h, w) * 64 < 2 ** 31)) else 0
                 tmp = self._new_sp(('tmp', i), N, h, w, cp) if sp else self._new(N, h, w, cp)
                 self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1,
-                           post_act=1 if act_in_producer else 0, out_fmt=sp)
+                           post_act=1 if act_in_producer else 0, in_fmt=xfmt, out_fmt=sp)
                 pre2 = 0 if act_in_producer else 1
-                if i == 9 and self._out4_fusable(blk['conv2']):
+                if last and self._out4_fusable(blk['conv2']):
                     # the last block's output feeds only the 1x1 output projection: computed in this epilogue, never stored
                     out4 = self._new(N, H, W, 4)
                     self._conv(blk['conv2'], tmp, None, N, h, w, None, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2,
                                out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4), in_fmt=sp)
                     return out4
-                out = self._new(N, h, w, cp)
-                self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2, in_fmt=sp)
+                if flow:
+                    out = self._new_sp(('out', i), N, h, w, cp)
+                    self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2,
+                               in_fmt=SP, out_fmt=SP, res_fmt=P4)
+                else:
+                    out = self._new(N, h, w, cp)
+                    self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2, in_fmt=sp)
                 cur = out
                 if i <= 4:
                     skips[i] = cur
                     nxt = self._new(N, h // 2, w // 2, blk['pool'].coutp)
-                    self._conv(blk['pool'], cur, None, N, h, w, nxt)
+                    self._conv(blk['pool'], cur, None, N, h, w, nxt, in_fmt=SP if flow else 0, out_fmt=P4 if flow else 0)
                     h, w = h // 2, w // 2
                     cur = nxt
             feat = cur
         else:
             a = self._new(N, H, W, nfp)
             L.check(lib.yond_conv_in_f32(L.ptr(x4), L.ptr(ub), N, H, W, nfp, L.ptr(self.conv_in_w), L.ptr(self.conv_in_b),
-                                         0.2, L.ptr(a), st), "yond_conv_in_f32")
+                                         0.2, L.ptr(a), 0, st), "yond_conv_in_f32")
             cv = self.convs
             h, w = H, W
             cur = self._conv(cv['conv1_2'], a, None, N, h, w, self._new(N, h, w, cv['conv1_2'].coutp), post_act=2, slope=0.2)

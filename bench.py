@@ -102,34 +102,45 @@ def spawn_ranks(a, argv):
     return subprocess.call(cmd, env=env)
 
 
-class SclkSampler(threading.Thread):
-    """Shader clock while the timed region runs: the active level of pp_dpm_sclk (sysfs), sampled every 50 ms; the busiest
-    card's mean is reported.  (The in-kernel clock reads up to ~10 % below it, MI355X_MICROARCH.md 'DVFS give-back'.)"""
+class GpuSampler(threading.Thread):
+    """Clock and power of the busiest card while the timed region runs, sampled every 50 ms from sysfs hwmon
+    (freq1_input: current shader clock in Hz; power1_average / power1_input: socket power in microwatts).  The clock the
+    kernels really see is measured in-kernel by yond_clock_probe (`gfx_clock.in_kernel_mhz`): hwmon reads a little above it
+    (MI355X_MICROARCH.md 'DVFS give-back'), and the DPM level table (pp_dpm_sclk) only names the ceiling."""
 
     def __init__(self):
         super().__init__(daemon=True)
-        self.files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.samples = {f: [] for f in self.files}
+        self.cards = []
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            f = os.path.join(hw, "freq1_input")
+            pw = [q for q in (os.path.join(hw, "power1_average"), os.path.join(hw, "power1_input")) if os.path.exists(q)]
+            if os.path.exists(f):
+                self.cards.append((f, pw[0] if pw else None))
+        self.mhz = {c[0]: [] for c in self.cards}
+        self.watt = {c[0]: [] for c in self.cards}
         self.stop_flag = False
 
     def run(self):
-        while not self.stop_flag and self.files:
-            for f in self.files:
+        while not self.stop_flag and self.cards:
+            for f, pw in self.cards:
                 try:
-                    for line in open(f).read().splitlines():
-                        if line.rstrip().endswith('*'):
-                            self.samples[f].append(float(line.split(':')[1].strip().rstrip('*').strip().lower().replace('mhz', '')))
+                    self.mhz[f].append(float(open(f).read()) / 1e6)
+                    if pw:
+                        self.watt[f].append(float(open(pw).read()) / 1e6)
                 except Exception:
                     pass
             time.sleep(0.05)
 
     def result(self):
         self.stop_flag = True
-        means = [sum(v) / len(v) for v in self.samples.values() if v]
-        if not means:
-            return None
-        return {"mean_mhz": round(max(means), 1), "samples": max(len(v) for v in self.samples.values()),
-                "source": "pp_dpm_sclk (sysfs), busiest card, during the timed region"}
+        best = max((f for f in self.mhz if self.watt[f] or self.mhz[f]), key=lambda f: (sum(self.watt[f]) / len(self.watt[f])) if self.watt[f]
+                   else (sum(self.mhz[f]) / max(len(self.mhz[f]), 1)), default=None)
+        if best is None:
+            return {}
+        out = {"hwmon_mhz": round(sum(self.mhz[best]) / max(len(self.mhz[best]), 1), 1), "samples": len(self.mhz[best])}
+        if self.watt[best]:
+            out["socket_power_w"] = round(sum(self.watt[best]) / len(self.watt[best]), 1)
+        return out
 
 
 def host_cores():
@@ -155,7 +166,7 @@ def cpu_baseline_and_parity(a, arch, dev, net_factory):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import yond_oracle as O
     from yond_public_amd import pipeline as P
-    H, W = 2048, 3072
+    H, W = (a.height, a.width) if a.cfg == 2 else (2048, 3072)      # the headline's own 3000x4000 frame (bounded sample: one frame)
     noisy, clean = O.synth_noisy(H, W, 4.0, 6.0, 0, clip=(a.cfg != 5))
     sd = O.denoising_state_dict(arch, 0) if a.weights == "denoising" else O.procedural_state_dict(arch, 0)
     pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': a.mode, 'max_iter': 1, 'full_dn': True,
@@ -297,9 +308,14 @@ def main(argv=None):
     is33 = lambda t: t.startswith("conv_mfma_kernel<3,1") or t.startswith("conv_wino_kernel") or t.startswith("conv_split_kernel<1,")
     plan.prof = None if a.no_kernel_events else []
     plan.prof_only = is33
-    sclk = SclkSampler() if rank == 0 else None
+    sclk = GpuSampler() if rank == 0 else None
     if sclk:
         sclk.start()
+    # in-kernel shader clock of the split-operand convolution launches of the timed region: workgroup 0 of every launch adds its
+    # elapsed shader cycles and 100 MHz reference ticks to two device counters (YondConvDesc.clk).  (A probe kernel BESIDE the
+    # region cannot be used: these kernels take every vector register of their CUs, so a single foreign wave keeps one of the
+    # 256 persistent workgroups waiting for a CU -- measured: every launch 1.45x longer.)
+    plan.clk = torch.zeros(2, dtype=torch.int64, device=dev)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = run(F)
@@ -308,6 +324,13 @@ def main(argv=None):
     torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     sclk_res = sclk.result() if sclk else None
+    clk_c, clk_r = (int(v) for v in plan.clk.cpu())
+    plan.clk = None
+    if rank == 0:
+        sclk_res = dict(sclk_res or {}, in_kernel_mhz=round(clk_c / clk_r * 100.0, 1) if clk_r > 0 else None,
+                        source="in_kernel_mhz: s_memtime / s_memrealtime of workgroup 0 of every split-operand convolution launch of the "
+                               "timed region (YondConvDesc.clk); hwmon_mhz / socket_power_w: sysfs hwmon of the busiest card, 50 ms "
+                               "samples during the timed region")
     prof, plan.prof = plan.prof or [], None
     plan.prof_only = None
     n_timed = a.steps * F
@@ -328,6 +351,41 @@ def main(argv=None):
         el = D.max_over_ranks(time.perf_counter() - t1, dev)
         seq = {"value": round(world * n_seq * H * W / 1e6 / el, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el / n_seq * 1e3, 3),
                "frames": n_seq, "definition": "IterDenoise one frame at a time, synchronised after every frame"}
+
+    # what the HIP event pairs inside the timed region cost: the same job for >= 1 s without them
+    noev = None
+    if not a.no_extras and not a.no_kernel_events:
+        torch.cuda.synchronize()
+        D.barrier()
+        t1 = time.perf_counter()
+        n_ne = 0
+        while n_ne < 2 or time.perf_counter() - t1 < 1.0:
+            run(F)
+            torch.cuda.synchronize()
+            n_ne += 1
+        el = D.max_over_ranks(time.perf_counter() - t1, dev)
+        noev = {"value": round(world * n_ne * F * H * W / 1e6 / el, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el / (n_ne * F) * 1e3, 3),
+                "steps": n_ne, "definition": "the timed region's job without the HIP event pairs around the 3x3 stride-1 launches"}
+
+    # the shipped default pipeline: 'iter' (two rounds per frame, YOND_SIDD.py:419-472), one frame at a time, >= 1 s
+    iter_leg = None
+    if a.mode == "once" and not a.no_extras and not a.batch:
+        pipe_it = dict(pipe, iter='iter')
+        r_it = P.IterDenoise(frames[0], net, arch, pipe_it)
+        torch.cuda.synchronize()
+        D.barrier()
+        t1 = time.perf_counter()
+        n_it = 0
+        while n_it < 10 or time.perf_counter() - t1 < 1.0:
+            r_it = P.IterDenoise(frames[n_it % len(frames)], net, arch, pipe_it)
+            torch.cuda.synchronize()
+            n_it += 1
+        el = D.max_over_ranks(time.perf_counter() - t1, dev)
+        if len(r_it['raw_dns']) != 2:
+            raise SystemExit(f"bench.py: the 'iter' leg ran {len(r_it['raw_dns'])} pass(es), expected 2 (regs {r_it['regs']})")
+        iter_leg = {"value": round(world * n_it * H * W / 1e6 / el, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el / n_it * 1e3, 3),
+                    "frames": n_it, "passes_per_frame": 2,
+                    "definition": "pipeline 'iter' (self NLE + denoise, collaborative NLE + denoise), one frame at a time, synchronised after every frame"}
 
     stage_prof, prof_all = [], []
     if not a.no_kernel_events:
@@ -452,9 +510,11 @@ def main(argv=None):
                        "parallelism": f"image-parallel x{world}", "driver": driver,
                        "weights": {"denoising": "synthetic.denoising_state_dict (analytic 3x3 box-mean path + eps-scaled procedural weights)",
                                    "procedural": "synthetic.procedural_state_dict (seeded random)"}[a.weights]},
-            "sclk": sclk_res,
+            "gfx_clock": sclk_res,
             "roofline": roof,
             "sequential": seq,
+            "iter_pipeline": iter_leg,
+            "without_kernel_events": noev,
             "fp32_mfma_path": strict,
             "roofline_vst_nle": roof_hbm,
             "conv_stack": {"ms_per_frame": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,

@@ -172,6 +172,10 @@ typedef struct YondConvDesc {
        transposed layers (out_fmt 2), yond_conv_in_f32; consumers: the register-staged input of a 3x3 layer (in_fmt 2:
        src0 and src1) and `res`. */
     int res_fmt;
+    /* Measurement aid (algo 3 / 4; NULL = off): workgroup 0 adds its elapsed shader cycles (s_memtime) to clk[0] and the
+       elapsed 100 MHz reference ticks (s_memrealtime) to clk[1]: over many launches clk[0] / clk[1] * 100 MHz is the clock the
+       chip really held inside these kernels (bench.py `gfx_clock.in_kernel_mhz`).  Two counter reads and two atomics per launch. */
+    unsigned long long* clk;
 } YondConvDesc;
 #define YOND_STATUS_HALF_OVERFLOW 1u
 #define YOND_FMT_NHWC_F32 0
@@ -347,6 +351,11 @@ int yond_bias_lut_f64(const double* lams, int n, double gain, double sigma, floa
 int yond_block_metrics_tiles(int bh, int bw);
 int yond_block_metrics_f32(const float* dn, const float* hr, int H, int W, int bh, int bw, double* out,
                            void* stream);
+
+/* Measurement aid (bench.py; not on the reference's path): one wave sleeps for `us` microseconds (<= 5 s) of wall time and
+ * writes out[0] = elapsed shader cycles (s_memtime), out[1] = elapsed 100 MHz reference ticks (s_memrealtime): the clock
+ * the chip holds under the load running beside it = out[0] / out[1] * 100 MHz. */
+int yond_clock_probe(double us, unsigned long long* out /* [2], device */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -270,6 +270,62 @@ def gen_iter(ref):
     save("iter", **out)
 
 
+def gen_nle_full(ref):
+    """SURVEY section 8c plan item 3: the estimator on the BASELINE cfg-2 frame itself (3000 x 4000): threshold, percentile,
+    beta1, beta2 of the self and of the collaborative estimate -- eight numbers from the reference's own SimpleNLF."""
+    import cv2
+    H, W, K, s, idx = 3000, 4000, 4.0, 6.0, 0
+    noisy, clean = O.synth_noisy(H, W, K, s, idx)
+    k = 29
+    rggb = ref.bayer2rggb(noisy)
+    mean = cv2.blur(rggb, (k, k))
+    lap = ref.stdfilt(cv2.blur(rggb, (k // 3 * 2 + 1,) * 2), k)
+    th, pct = ref.get_threshold((lap, mean), step=5, mode='score3')
+    reg = ref.SimpleNLF(noisy, k=k, setting={'mode': 'self'})
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(W)[None, :] / 37.0), 0, 1).astype(np.float32)
+    regc = ref.SimpleNLF(noisy, dn, k=k, setting={'mode': 'collab'})
+    hr = ref.bayer2rggb(dn)
+    hr_k = ref.stdfilt(hr, k)
+    thc, pctc = ref.get_threshold((hr_k, cv2.blur(hr, (k, k))), step=5, mode='score3')
+    save("nle_full", meta=np.array([H, W, K, s, idx]), sha=np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8),
+         self=np.array([th, pct, reg[0], reg[1]]), collab=np.array([thc, pctc, regc[0], regc[1]]))
+
+
+def iter_full_case():
+    """A bare full frame (not the SIDD stack) whose packed width divides by 32: the reference's IterDenoise runs on it as shipped
+    (its np.split(lr_raw, 32) at :354 and the SIDD_256 re-tiling of :431 both accept it)."""
+    H, W, K, s = 320, 2048, 2.0, 20.0
+    noisy, clean = O.synth_noisy(H, W, K, s, 41)
+    arch = ARCHS["gru8"]
+    sd = O.denoising_state_dict(arch, 91)
+    pipe = {'data_type': 'SIDD', 'full_est': True, 'est_type': 'simple+full', 'k': 29, 'vst_type': 'exact', 'full_dn': True,
+            'bias_corr': 'pre', 'denoiser_type': 'gru32n', 'iter': 'iter', 'max_iter': 1, 'clip': False}
+    return noisy, clean, arch, sd, pipe
+
+
+def gen_iter_full(ref):
+    noisy, clean, arch, sd, pipe = iter_full_case()
+    tmp = tempfile.mkdtemp()
+    full_path = os.path.join(tmp, "frame.npy")
+    np.save(full_path, noisy)
+    obj, _ = fake_self(ref, arch, 91, pipe)
+    obj.net = ref.load_weights(obj.net, sd, by_name=False).eval()
+    p = dict(pipe)
+    p.update({'K': 8.74253, 'sigGs': 12.81, 'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0})
+    p['scale'] = (p['wp'] - p['bl']) / p['ratio']
+    data = {'lr_path_full': full_path, 'lr': np.array(np.split(noisy, 32, axis=-1)), 'hr': np.array(np.split(clean, 32, axis=-1)),
+            'meta': None, 'name': 'frame_000'}
+    res = obj.IterDenoise(data, {'p': p, 'img_id': 0})
+    regs = np.array([np.asarray(r, np.float64) for r in res['regs']])
+    print(f"bare full frame: regs={regs.tolist()} n_out={len(res['raw_dns'])}")
+    out = {"regs": regs, "nout": np.array(len(res['raw_dns'])), "sha": np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)}
+    for it, dn in enumerate(res['raw_dns']):
+        dn = np.asarray(dn)
+        out[f"dn_{it}_a"], out[f"dn_{it}_b"], out[f"dn_{it}_c"] = dn[:96, :160].astype(np.float32), dn[200:264, 1000:1100].astype(np.float32), dn[3::8, 5::8].astype(np.float32)
+        out[f"dn_{it}_chk"] = checks(dn)
+    save("iter_full", **out)
+
+
 def small_bias_grids():
     """A reduced (x, sigma) grid with the structure of the shipped one (linear head + log tail; utils/isp_algos.py:168-177)."""
     x_lut = np.concatenate((np.linspace(0, 2 ** -4, 4, endpoint=False), np.exp(np.linspace(np.log(2 ** -4), np.log(2 ** 10), 57))))
@@ -374,7 +430,8 @@ def gen_rot(ref):
 
 
 GENS = dict(rot=gen_rot, pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
-            vst_denoiser=gen_vst_denoiser, iter=gen_iter, biaslut=gen_biaslut, ssim=gen_ssim)
+            vst_denoiser=gen_vst_denoiser, iter=gen_iter, biaslut=gen_biaslut, ssim=gen_ssim, nle_full=gen_nle_full,
+            iter_full=gen_iter_full)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -860,8 +860,9 @@ def IterDenoise(lr_raw, arch, sd, pipe, lr_full=None, p=None):
             # :431 hard-codes SIDD_256=True (YOND_SIDD.py only handles SIDD); the full-frame
             # drivers named in README.md:38-47 cannot (W/2 is not a multiple of 32), so the
             # re-tiling is applied to SIDD-layout input (a stack, or full_dn False) unless pipe['collab_sidd256'] overrides it.
+            can_tile = (np.shape(lr_cat)[-1] // 2) % 32 == 0       # ... and bare frames whose packed width the split accepts
             reg = SimpleNLF(lr_cat, raw_dn, k=k,
-                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd or stack))})
+                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd or stack or can_tile))})
             if reg[1] < 0:                                                        # :438-440
                 reg = (reg[0], reg[0] ** 2)
             p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(reg[1]) * scale       # :442

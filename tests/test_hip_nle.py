@@ -197,6 +197,32 @@ def test_simple_nlf_sidd256(golden):
         np.testing.assert_allclose(r[1], gr[1], rtol=0, atol=1e-5 * abs(gr[0]) + 1e-9)
 
 
+def test_simple_nlf_full_frame_matches_reference(golden):
+    """SURVEY section 8c plan item 3: the estimator on the BASELINE cfg-2 frame itself (3000 x 4000) against the eight numbers
+    the reference's own SimpleNLF / get_threshold produce for it (tests/golden/nle_full.npz): self and collaborative."""
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    g = golden("nle_full")
+    H, W, K, s, idx = g["meta"]
+    noisy, clean = O.synth_noisy(int(H), int(W), K, s, int(idx))
+    assert np.array_equal(sha(noisy), g["sha"])
+    reg, info = P.SimpleNLF(noisy, k=29, setting={'mode': 'self'}, full=True, device=DEV)
+    th, pct, b1, b2 = g["self"]
+    print(f"[parity] NLE self 3000x4000: th {info['th']:.8e} vs {th:.8e}; b1 {reg[0]:.8e} vs {b1:.8e}; b2 {reg[1]:.8e} vs {b2:.8e}")
+    assert info['percent'] == pct
+    np.testing.assert_allclose(info['th'], th, rtol=1e-5)
+    np.testing.assert_allclose(reg[0], b1, rtol=1e-5)
+    np.testing.assert_allclose(reg[1], b2, rtol=0, atol=1e-5 * abs(b1) + 1e-9)
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(int(W))[None, :] / 37.0), 0, 1).astype(np.float32)
+    regc, infoc = P.SimpleNLF(noisy, dn, k=29, setting={'mode': 'collab'}, full=True, device=DEV)
+    thc, pctc, c1, c2 = g["collab"]
+    print(f"[parity] NLE collab 3000x4000: th {infoc['th']:.8e} vs {thc:.8e}; b1 {regc[0]:.8e} vs {c1:.8e}; b2 {regc[1]:.8e} vs {c2:.8e}")
+    assert infoc['percent'] == pctc
+    np.testing.assert_allclose(infoc['th'], thc, rtol=1e-5)
+    np.testing.assert_allclose(regc[0], c1, rtol=1e-5)
+    np.testing.assert_allclose(regc[1], c2, rtol=0, atol=1e-5 * abs(c1) + 1e-9)
+
+
 def test_nlf_full_frame_size_properties():
     """BASELINE cfg-2 size (3000 x 4000): size-independent checks -- percentiles are sorted and bracket the
     data, bucket counts add up to the pixel count, the estimate recovers the synthetic (K, sigma)."""

@@ -37,6 +37,30 @@ def test_iter_denoise_matches_reference(golden, ci):
         np.testing.assert_allclose(np.asarray(dn, np.float64).sum(), g[f"dn_{ci}_{it}_chk"][0], rtol=1e-5)
 
 
+def test_iter_denoise_bare_full_frame_matches_reference(golden):
+    """A bare full-frame 'iter' run (full_dn, not the SIDD stack) against the reference's own IterDenoise on a 320 x 2048
+    frame (tests/golden/iter_full.npz): the packed width divides by 32, so the reference's hard-coded SIDD_256 re-tiling of
+    the collaborative estimate (YOND_SIDD.py:431, :91-93) runs -- and is what pipeline.IterDenoise does by default there."""
+    from test_oracle_golden import iter_full_case, iter_full_crop
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    g = golden("iter_full")
+    noisy, clean, arch, sd, pipe = iter_full_case()
+    assert np.array_equal(sha(noisy), g["sha"])
+    net = A.GuidedResUnet(dict(arch))
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    res = P.IterDenoise(noisy, net, arch, pipe, device=DEV)
+    assert len(res['raw_dns']) == int(g["nout"]) == 2
+    for r, gr in zip(res['regs'], g["regs"]):
+        print(f"[parity] bare full frame regs {r[0]:.6e},{r[1]:.6e} vs {gr[0]:.6e},{gr[1]:.6e}")
+        np.testing.assert_allclose(r[0], gr[0], rtol=2e-5)
+        np.testing.assert_allclose(r[1], gr[1], rtol=0, atol=2e-5 * abs(gr[0]) + 1e-9)
+    for it, dn in enumerate(res['raw_dns']):
+        for got, tag in zip(iter_full_crop(dn.cpu().numpy()), "abc"):
+            assert report(f"bare full-frame IterDenoise iter {it} {tag}", got, g[f"dn_{it}_{tag}"]) <= 1e-4
+
+
 def test_block_metrics_vs_oracle():
     import yond_oracle as O
     from yond_public_amd import pipeline as P

@@ -293,3 +293,59 @@ def test_iter_denoise_without_estimate_branch(golden):
     assert res['regs'] == (0, 0) and len(res['raw_dns']) == 1
     for got, tag in zip(iter_crop(res['raw_dns'][0]), ("blk", "seam", "sub")):
         np.testing.assert_allclose(got, g[f"simple_{tag}"], rtol=0, atol=2e-5)
+
+
+def iter_full_case():
+    """The bare full frame of tests/golden/iter_full.npz (oracle/gen_golden.py iter_full_case): inputs are regenerated from seeds."""
+    noisy, clean = O.synth_noisy(320, 2048, 2.0, 20.0, 41)
+    arch = ARCHS["gru8"]
+    sd = O.denoising_state_dict(arch, 91)
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': True}
+    return noisy, clean, arch, sd, pipe
+
+
+def iter_full_crop(dn):
+    dn = np.asarray(dn)
+    return dn[:96, :160].astype(np.float32), dn[200:264, 1000:1100].astype(np.float32), dn[3::8, 5::8].astype(np.float32)
+
+
+def test_iter_denoise_bare_full_frame(golden):
+    """What a bare full-frame 'iter' run equals: the reference's own IterDenoise (full_dn) on a 320 x 2048 frame, packed width
+    1024 = 32 x 32, so its hard-coded SIDD_256 re-tiling of the collaborative estimate (:431) RUNS -- and so does the oracle's
+    by default (no collab_sidd256 key in the pipe)."""
+    g = golden("iter_full")
+    noisy, clean, arch, sd, pipe = iter_full_case()
+    assert np.array_equal(sha(noisy), g["sha"])
+    torch.set_num_threads(8)
+    res = O.IterDenoise(noisy, arch, sd, pipe)
+    assert len(res['raw_dns']) == int(g["nout"]) == 2
+    for r, gr in zip(res['regs'], g["regs"]):
+        np.testing.assert_allclose(r[0], gr[0], rtol=1e-5)
+        np.testing.assert_allclose(r[1], gr[1], rtol=0, atol=1e-5 * abs(gr[0]) + 1e-9)
+    for it, dn in enumerate(res['raw_dns']):
+        for got, tag in zip(iter_full_crop(dn), "abc"):
+            np.testing.assert_allclose(got, g[f"dn_{it}_{tag}"], rtol=0, atol=2e-5)
+    # without the re-tiling the second estimate is a different number: the fixture does pin the branch
+    res2 = O.IterDenoise(noisy, arch, sd, dict(pipe, collab_sidd256=False))
+    assert abs(res2['regs'][1][0] - g["regs"][1][0]) > 1e-7 * abs(g["regs"][1][0])
+
+
+def test_nle_full_frame_3000x4000(golden):
+    """SURVEY section 8c plan item 3: the oracle's estimator on the cfg-2 frame against the reference's eight numbers."""
+    g = golden("nle_full")
+    H, W, K, s, idx = g["meta"]
+    noisy, clean = O.synth_noisy(int(H), int(W), K, s, int(idx))
+    assert np.array_equal(sha(noisy), g["sha"])
+    reg, info = O.SimpleNLF(noisy, k=29, setting={'mode': 'self'}, full=True)
+    th, pct, b1, b2 = g["self"]
+    assert info['percent'] == pct
+    np.testing.assert_allclose(info['th'], th, rtol=1e-6)
+    np.testing.assert_allclose(reg[0], b1, rtol=1e-6)
+    np.testing.assert_allclose(reg[1], b2, rtol=0, atol=1e-6 * abs(b1) + 1e-10)
+    dn = np.clip(clean + 0.002 * np.sin(np.arange(int(W))[None, :] / 37.0), 0, 1).astype(np.float32)
+    regc, infoc = O.SimpleNLF(noisy, dn, k=29, setting={'mode': 'collab'}, full=True)
+    thc, pctc, c1, c2 = g["collab"]
+    assert infoc['percent'] == pctc
+    np.testing.assert_allclose(infoc['th'], thc, rtol=1e-6)
+    np.testing.assert_allclose(regc[0], c1, rtol=1e-6)
+    np.testing.assert_allclose(regc[1], c2, rtol=0, atol=1e-6 * abs(c1) + 1e-10)

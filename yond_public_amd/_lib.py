@@ -23,7 +23,7 @@ class YondConvDesc(C.Structure):
                 ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
                 ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32),
                 ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp), ("status", vp),
-                ("in_fmt", i32), ("out_fmt", i32), ("res_fmt", i32)]
+                ("in_fmt", i32), ("out_fmt", i32), ("res_fmt", i32), ("clk", vp)]
 
 
 class YondFilmDesc(C.Structure):
@@ -82,6 +82,7 @@ PROTOTYPES = {
     "yond_bias_lut_f64": [vp, i32, f64, f64, vp, vp],
     "yond_block_metrics_tiles": [i32, i32],
     "yond_block_metrics_f32": [vp, vp, i32, i32, i32, i32, vp, vp],
+    "yond_clock_probe": [f64, vp, vp],
 }
 _SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes"}
 

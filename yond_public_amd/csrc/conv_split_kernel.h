@@ -896,6 +896,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         return n;
     };
     if (lslot >= total) return;
+    const bool clk_on = d.clk != nullptr && blockIdx.x == 0 && tid == 0;       // measurement aid (YondConvDesc.clk)
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk_on) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     if constexpr (O4) {
         if (tid < 128) smem[C::W4_OFF + tid] = d.out4_w[tid];                    // visible behind the prologue's barrier
     }
@@ -1070,6 +1073,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead loads / DMA of the steps past the end
     if (d.status && !(amax <= 65504.0f)) atomicOr(d.status, YOND_STATUS_HALF_OVERFLOW);   // an h half became +-inf
+    if (clk_on) {
+        atomicAdd(d.clk, __builtin_amdgcn_s_memtime() - clk_c0);
+        atomicAdd(d.clk + 1, __builtin_amdgcn_s_memrealtime() - clk_r0);
+    }
 }
 
 template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false>

@@ -104,3 +104,30 @@ extern "C" int yond_block_metrics_f32(const float* dn, const float* hr, int H, i
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------
+// Measurement aid (bench.py): the shader clock the chip really holds while a workload runs.  One wave sleeps on one CU
+// for `us` microseconds of wall time and returns the elapsed shader cycles (s_memtime) and reference ticks (s_memrealtime,
+// 100 MHz): clock = cycles / ticks * 100 MHz (MI355X_MICROARCH.md 'DVFS give-back' item 6).  Launched on a side stream
+// next to the timed region; it occupies one wave slot and issues no memory traffic but its final store.
+// ------------------------------------------------------------------------------------------------------
+__global__ void clock_probe_kernel(unsigned long long ticks, unsigned long long* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    for (unsigned long long guard = 0; r1 - r0 < ticks && guard < (1ull << 36); ++guard) {     // (bounded: every wave exits)
+        __builtin_amdgcn_s_sleep(127);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+
+extern "C" int yond_clock_probe(double us, unsigned long long* out, void* stream) {
+    if (!out || !(us > 0.0) || us > 5e6) return YOND_EINVAL;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)(us * 100.0), out);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}

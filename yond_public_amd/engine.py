@@ -349,6 +349,8 @@ class DenoiserPlan:
         status = getattr(self, 'status', None)                       # (bare plans of the kernel tests have none)
         d.status = status.data_ptr() + 4 * self.status_slot if status is not None else None
         d.in_fmt, d.out_fmt, d.res_fmt = in_fmt, out_fmt, res_fmt
+        clk = getattr(self, 'clk', None)             # bench.py: in-kernel clock of the split-operand launches (int64[2] on the device)
+        d.clk = clk.data_ptr() if (clk is not None and d.algo in (3, 4)) else None
         if (in_fmt or out_fmt or res_fmt) and d.algo != 3:
             raise L.YondHipError("split-plane / 4-channel-plane tensors need the split-operand kernel (algo 3)")
         if out4 is not None:

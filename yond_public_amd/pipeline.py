@@ -703,8 +703,8 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     """Round 1: self-calibrated NLE -> VST -> denoise -> inverse VST; round 2 (pipe['iter']=='iter'):
     collaborative NLE from (noisy, denoised) -> guards -> second pass.  lr_raw: the SIDD layout [32][256][256]
     (denoised block by block, or -- pipe['full_dn'] -- as its 256 x 8192 concatenation, :387-389) or one Bayer
-    frame [H][W] (needs pipe['full_dn']).  The collaborative estimate re-tiles per 256-block (SIDD_256, which :431
-    hard-codes) for SIDD-layout input; pipe['collab_sidd256'] overrides.  Returns dict(raw_dns, regs, params) with
+    frame [H][W] (needs pipe['full_dn']).  The collaborative estimate re-tiles into 32 vertical tiles (SIDD_256, which :431
+    hard-codes) wherever the reference's split can run (packed width divisible by 32); pipe['collab_sidd256'] overrides.  Returns dict(raw_dns, regs, params) with
     device tensors in raw_dns (each [H][W], for SIDD the 256 x 8192 concatenation as in the reference)."""
     p = dict(p or default_params())
     k = pipe.get('k', 29)
@@ -781,8 +781,13 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
 
     if pipe.get('iter', 'iter') == 'iter':
         for epoch in range(1, pipe.get('max_iter', 1) + 1):
+            # :431 hard-codes SIDD_256=True: the packed frame is cut into 32 vertical tiles (np.split(..., 32, axis=-2), :91-93).
+            # That is what runs here whenever it CAN run in the reference -- the SIDD layout, and any bare frame whose packed
+            # width divides by 32 (pinned by tests/golden/iter_full.npz); for other widths (3000 x 4000: 2000 / 32) the
+            # reference's split raises, and the estimate is taken without re-tiling.  pipe['collab_sidd256'] overrides.
+            can_tile = (lr_cat.shape[-1] // 2) % 32 == 0
             reg = SimpleNLF(lr_cat, raw_dn, k=k,
-                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd or stack))})   # :431
+                            setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', sidd or stack or can_tile))})   # :431
             if reg[1] < 0:                                                             # :438-440
                 reg = (reg[0], reg[0] ** 2)
             p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(reg[1]) * scale            # :442
@@ -827,7 +832,8 @@ def IterDenoiseBatch(frames, net, arch, pipe, p=None, device=None):
         for epoch in range(1, pipe.get('max_iter', 1) + 1):
             regs2, ps2, funcs = [], [], []
             for i in range(B):
-                reg = SimpleNLF(lrs[i], raw_dn[i], k=k, setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', False))})
+                can_tile = (lrs[i].shape[-1] // 2) % 32 == 0                                # as IterDenoise: where the reference's split runs
+                reg = SimpleNLF(lrs[i], raw_dn[i], k=k, setting={'mode': 'collab', 'SIDD_256': bool(pipe.get('collab_sidd256', can_tile))})
                 if reg[1] < 0:                                                             # :438-440
                     reg = (reg[0], reg[0] ** 2)
                 if reg[0] < 0:                                                             # :445-447: this frame keeps its round-1 result

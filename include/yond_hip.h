@@ -352,6 +352,53 @@ int yond_block_metrics_tiles(int bh, int bw);
 int yond_block_metrics_f32(const float* dn, const float* hr, int H, int W, int bh, int bw, double* out,
                            void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The per-frame parameter chain on the device: no host round trip between the estimator and the network.
+ * Replaces the host arithmetic of YOND_SIDD.py:341-356 (beta -> K, sigma), :438-447 (round-2 guards), :263-264, 284-285
+ * (lower = VST(0), upper = VST(scale), t = 1.03 / (upper - lower)), utils/isp_algos.py:101-108 (knot grid of get_bias)
+ * and :345-365 (polyfit on the moment sums).
+ * yond_frame_params_f64: reads the estimator's workspace (after yond_nle_moments_f32) and writes
+ *   prm[YOND_PRM_N]   the parameter block below (float64),
+ *   t_out             the network's noise level as float32 (or NULL),
+ *   lut_x[lut_cap]    the knot grid of get_bias for the frame maximum (max_dev: a float32 device scalar, or NULL: the
+ *                     maximum the estimator's first kernel collected).
+ * mode 0: round 1 (:356), 1: round 2 (:438-447).  Branches that need more work than this chain does are FLAGGED in
+ * prm[YOND_PRM_FLAGS] and left to the caller (host path): no flat area, knot capacity, K <= 0.
+ * The *_dev_* entry points below take gain / sigma / lower / upper / the LUT size from such a block. */
+#define YOND_PRM_BETA1 0
+#define YOND_PRM_BETA2 1
+#define YOND_PRM_GAIN 2
+#define YOND_PRM_SIGMA 3
+#define YOND_PRM_LO 4
+#define YOND_PRM_HI 5
+#define YOND_PRM_NSR 6
+#define YOND_PRM_T 7          /* float32 value of the network's t */
+#define YOND_PRM_FLAGS 8      /* YOND_PRM_FLAG_* as a number */
+#define YOND_PRM_LUT_N 9
+#define YOND_PRM_NSEL 10      /* pixels below the selected threshold */
+#define YOND_PRM_TH 11
+#define YOND_PRM_PCT 12
+#define YOND_PRM_FRAME_MAX 13
+#define YOND_PRM_N 16
+#define YOND_PRM_FLAG_NO_FLAT_AREA 1   /* YOND_SIDD.py:79-84: the 25 % fallback needs the host path */
+#define YOND_PRM_FLAG_LUT_CAPACITY 2   /* more knots than lut_cap (or more LDS than the LUT kernel has) */
+#define YOND_PRM_FLAG_ROUND_ABORTED 4  /* round 2: beta1 < 0 (:445-447): the caller drops this round's output */
+#define YOND_PRM_FLAG_BAD_ESTIMATE 8   /* K <= 0 or NaN: nothing downstream is defined */
+int yond_frame_params_f64(const void* nle_ws, const float* max_dev, int mode, double scale, double tfac, int lut_cap,
+                          double* prm, float* t_out, double* lut_x, void* stream);
+/* Row H with (n, K, sigma) read from the block: launches lut_cap workgroups, those beyond prm[LUT_N] exit. */
+int yond_bias_lut_dev_f64(const double* lams, int lut_cap, double* prm, float* bias, void* stream);
+/* The LUT in the form K1 evaluates (per-interval coefficients + run table), prepared ONCE per frame instead of once per
+ * workgroup of K1: lut_ws must hold yond_lut_ws_bytes(lut_cap) bytes.  n < 0: the size comes from prm. */
+size_t yond_lut_ws_bytes(int lut_cap);
+int yond_lut_table_f64(const double* lut_x, const float* lut_y, int n, const double* prm /* n < 0: also receives a flag */, void* lut_ws, void* stream);
+/* K1 / K4 with the frame's constants in a parameter block and the LUT as a prepared table. */
+int yond_pack_vst_norm_dev_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
+                               double scale, const double* prm, const void* lut_ws /* NULL: no bias correction */,
+                               int lut_cap /* the capacity lut_ws was prepared for */, float* img_max, void* stream);
+int yond_denorm_ivst_unpack_dev_f32(const float* net_out, int Hp, int Wp, int pad_t, int pad_l, int h, int w, float* bayer,
+                                    int mode, double scale, const double* prm, int clip01, void* stream);
+
 /* Measurement aid (bench.py; not on the reference's path): one wave sleeps for `us` microseconds (<= 5 s) of wall time and
  * writes out[0] = elapsed shader cycles (s_memtime), out[1] = elapsed 100 MHz reference ticks (s_memrealtime): the clock
  * the chip holds under the load running beside it = out[0] / out[1] * 100 MHz. */

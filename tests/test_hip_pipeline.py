@@ -61,6 +61,76 @@ def test_iter_denoise_bare_full_frame_matches_reference(golden):
             assert report(f"bare full-frame IterDenoise iter {it} {tag}", got, g[f"dn_{it}_{tag}"]) <= 1e-4
 
 
+def test_device_chain_equals_host_chain():
+    """The per-frame parameter chain on the device (csrc/frame_chain.hip: moments -> beta -> K, sigma, lower, upper, t, knot grid
+    -> bias LUT -> K1 -> net -> K4, no host round trip) against the host-side chain it replaces, on the same frames: the
+    estimates agree to float64 rounding, the knot grids and LUT ordinates bit for bit, the outputs to float32 rounding."""
+    import yond_oracle as O
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    from yond_public_amd import synthetic as S
+    arch = ARCHS["gru8"]
+    net = A.GuidedResUnet(dict(arch))
+    net.load_state_dict(S.denoising_state_dict(net, 3))
+    net = net.to(DEV).eval()
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': True}
+    for (H, W, K, s, clipf, expo) in [(512, 768, 4.0, 6.0, True, 1.0), (384, 640, 2.0, 20.0, True, 1.0), (320, 512, 1.0, 12.0, False, 0.2)]:
+        noisy, _ = O.synth_noisy(H, W, K, s, 11, clip=clipf)
+        x = torch.from_numpy((noisy * expo).astype(np.float32)).to(DEV)
+        assert P.chain_applies(x, net, arch, pipe)
+        res_d = P.IterDenoise(x, net, arch, pipe)
+        lut_d = [P._chain_buffers(x.device, sl) for sl in (0, 1)]
+        knots_d = [b.lut_x.cpu().numpy()[:int(b.prm_host[P.PRM['lut_n']])].copy() for b in lut_d]
+        ys_d = [b.lut_y.cpu().numpy()[:int(b.prm_host[P.PRM['lut_n']])].copy() for b in lut_d]
+        P.DEVICE_CHAIN = False
+        try:
+            res_h = P.IterDenoise(x, net, arch, pipe)
+        finally:
+            P.DEVICE_CHAIN = True
+        assert len(res_d['raw_dns']) == len(res_h['raw_dns'])
+        for rd, rh in zip(res_d['regs'], res_h['regs']):
+            np.testing.assert_allclose(rd[0], rh[0], rtol=1e-13)
+            np.testing.assert_allclose(rd[1], rh[1], rtol=1e-13, atol=1e-20)
+        for pd_, ph in zip(res_d['params'], res_h['params']):
+            np.testing.assert_allclose(pd_, ph, rtol=1e-13)
+        for it, (a, b) in enumerate(zip(res_d['raw_dns'], res_h['raw_dns'])):
+            assert report(f"device chain vs host chain {H}x{W} round {it}", a.cpu().numpy(), b.cpu().numpy()) <= 2e-7
+        # knot grid and ordinates of each round that ran: the reference's own np.linspace calls / the host-launched LUT kernel
+        lr_max = np.float32(res_d['nle_info']['frame_max'])
+        for it in range(len(res_d['raw_dns'])):
+            K_, s_ = res_d['params'][it]
+            f = P.get_bias(lr_max * np.float32(959.0), s_, K_, device=x.device)
+            assert np.array_equal(knots_d[it], np.asarray(f.lams, np.float64))
+            assert np.array_equal(ys_d[it], f.y.cpu().numpy())
+
+
+@pytest.mark.parametrize("ub", [3.0, 17.0, 49.0, 50.0, 51.0, 137.0, 499.0, 500.0, 501.0, 509.0, 510.0, 961.0, 1024.0, 1475.0])
+def test_device_knot_grid_bit_identical(ub):
+    """yond_frame_params_f64's knot grid against the reference's np.linspace calls (utils/isp_algos.py:101-108, pipeline._bias_knots)
+    for float32 maxima on both sides of every branch: bit-identical float64 knots, NumPy 2's float32 linspace included."""
+    import ctypes as C
+    from yond_public_amd import _lib as L
+    from yond_public_amd import pipeline as P
+    lib = L.load()
+    mx = np.float32(ub - 1.0) - np.float32(0.3)                 # ceil(mx) + 1 == ub
+    assert np.ceil(mx) + 1 == np.float32(ub)
+    ws = torch.zeros(int(lib.yond_nle_ws_bytes(1024)), dtype=torch.uint8, device=DEV)
+    off_mom = P._nle_layout()[2]
+    mom = np.array([100, 30, 0.3, 10, 0.1, 100, 30, 0.3, 10, 0.1], np.float64)      # any well-posed moment sums
+    ws[off_mom:off_mom + 80] = torch.from_numpy(mom.view(np.uint8)).to(DEV)
+    mxd = torch.tensor([float(mx) / 959.0], dtype=torch.float32, device=DEV)
+    # (the kernel multiplies the float32 maximum by float32(scale): feed it scale = 1 and the maximum itself)
+    mxd = torch.tensor([float(mx)], dtype=torch.float32, device=DEV)
+    prm = torch.zeros(16, dtype=torch.float64, device=DEV)
+    lut_x = torch.zeros(P.LUT_CAP, dtype=torch.float64, device=DEV)
+    L.check(lib.yond_frame_params_f64(L.ptr(ws), L.ptr(mxd), 0, 1.0, 1.03, P.LUT_CAP, L.ptr(prm), None, L.ptr(lut_x), L.stream()), "frame_params")
+    torch.cuda.synchronize()
+    n = int(prm[P.PRM['lut_n']].item())
+    want = np.asarray(P._bias_knots(np.ceil(mx) + 1), np.float64)
+    assert n == len(want)
+    assert np.array_equal(lut_x.cpu().numpy()[:n], want)
+
+
 def test_block_metrics_vs_oracle():
     import yond_oracle as O
     from yond_public_amd import pipeline as P

@@ -162,3 +162,25 @@ def test_vst_denoiser_with_bias_lut_2d(golden):
     ref = O.IterDenoise(noisy, arch, sd, pipe)      # 1-D LUT path of the oracle: the two LUTs agree to the table's resolution
     res = P.IterDenoise(noisy, net, arch, pipe, device=DEV, biaslut=lut)
     assert float(np.abs(res['raw_dns'][0].cpu().numpy() - ref['raw_dns'][0]).max()) < 5e-3
+
+
+def test_bias_eval_on_drifting_and_float32_grids():
+    """K1's interval lookup trusts evenly spaced runs (one multiply instead of a search).  A slowly drifting grid (log spacing of
+    ratio 1.0005: neighbouring intervals differ by less than the break tolerance) must fall back to the bisection, not be
+    extrapolated from the wrong interval; a grid whose knots are float32-rounded (what NumPy 2 produces for a float32 maximum)
+    must still take the fast path and agree with interp1d."""
+    from scipy.interpolate import interp1d
+    from yond_public_amd import pipeline as P
+    rng = np.random.default_rng(5)
+    for name, x in (("log 1.0005", 10.0 * 1.0005 ** np.arange(1500)),
+                    ("float32 linspace", np.concatenate((np.linspace(0, 50, 501), np.linspace(50, 500, 451),
+                                                         np.linspace(np.float32(500), np.float32(961), 48).astype(np.float64))))):
+        y = np.sin(x / 40.0).astype(np.float32)
+        f = P.DeviceBiasLUT(x, torch.from_numpy(np.ascontiguousarray(x, np.float64)).to(DEV), torch.from_numpy(y).to(DEV))
+        xq = rng.uniform(x[0], x[-1], 20000).astype(np.float32)
+        xq[:len(x)] = x.astype(np.float32).clip(x[0], x[-1])          # the knots themselves
+        got = f(xq).cpu().numpy()
+        want = interp1d(x, y.astype(np.float64))(xq.astype(np.float64).clip(x[0], x[-1]))
+        err = np.abs(got - want).max()
+        print(f"[parity] bias LUT on a {name} grid: max |delta| = {err:.3e}")
+        assert err < 1e-7

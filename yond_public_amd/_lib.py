@@ -83,8 +83,14 @@ PROTOTYPES = {
     "yond_block_metrics_tiles": [i32, i32],
     "yond_block_metrics_f32": [vp, vp, i32, i32, i32, i32, vp, vp],
     "yond_clock_probe": [f64, vp, vp],
+    "yond_frame_params_f64": [vp, vp, i32, f64, f64, i32, vp, vp, vp, vp],
+    "yond_bias_lut_dev_f64": [vp, i32, vp, vp, vp],
+    "yond_lut_ws_bytes": [i32],
+    "yond_lut_table_f64": [vp, vp, i32, vp, vp, vp],
+    "yond_pack_vst_norm_dev_f32": [vp, i32, i32, vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, vp],
+    "yond_denorm_ivst_unpack_dev_f32": [vp, i32, i32, i32, i32, i32, i32, vp, i32, f64, vp, i32, vp],
 }
-_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes"}
+_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes", "yond_lut_ws_bytes"}
 
 
 class YondHipError(RuntimeError):

@@ -33,11 +33,29 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
 }
 
 __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict__ lams, int n, double K, double sigma,
-                                                       double th, int pho, int lmax, float* __restrict__ bias) {
+                                                       double th, int pho, int lmax, float* __restrict__ bias,
+                                                       double* __restrict__ prm, int smem_doubles) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double s_red[4];
+    if (prm) {
+        // (n, K, sigma) from the frame's parameter block (frame_chain.hip); the derived constants as the host entry computes them
+        const int fl = (int)prm[YOND_PRM_FLAGS];
+        n = (int)prm[YOND_PRM_LUT_N];
+        K = prm[YOND_PRM_GAIN];
+        sigma = prm[YOND_PRM_SIGMA];
+        if ((fl & (YOND_PRM_FLAG_BAD_ESTIMATE | YOND_PRM_FLAG_LUT_CAPACITY)) || (int)blockIdx.x >= n) return;
+        pho = (int)sqrt(K);
+        if (pho < 1) pho = 1;
+        th = K < 1.0 ? 50.0 * K : 50.0 * sqrt(K);
+        const int rmax = (int)(th * (1.0 / K) * 2.0 + sigma * 2.0 + th + 10.0) + 1;
+        lmax = 2 * pho * rmax + 1;
+        if (lmax + rmax + 2 > smem_doubles) {                                     // more LDS than this launch has: host path
+            if (blockIdx.x == 0 && threadIdx.x == 0) prm[YOND_PRM_FLAGS] = (double)(fl | YOND_PRM_FLAG_LUT_CAPACITY);
+            return;
+        }
+    }
     double* s_g = sm;                 // Gaussian table on the grid, l entries
     double* s_p = sm + lmax;          // Poisson mass at integer point m (x = m), r+1 entries; 0 if the grid misses it
-    __shared__ double s_red[4];
     const int i = blockIdx.x;
     if (i >= n) return;
     const double lam = lams[i];
@@ -111,6 +129,16 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
     }
 }
 
+static int bias_lut_attr() {                 // the kernel may use the whole LDS of a CU (set once for both entry points)
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)bias_lut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    return 0;
+}
+
 extern "C" int yond_bias_lut_f64(const double* lams, int n, double gain, double sigma, float* bias, void* stream) {
     if (!lams || !bias || n <= 0 || !(gain > 0.0) || !(sigma >= 0.0)) return YOND_EINVAL;
     const double K = gain;
@@ -122,13 +150,23 @@ extern "C" int yond_bias_lut_f64(const double* lams, int n, double gain, double 
     const int lmax = 2 * pho * rmax + 1;
     const size_t smem = ((size_t)lmax + rmax + 2) * sizeof(double);
     if (smem > 160 * 1024 - 64) return YOND_EUNSUPPORTED;
-    static size_t attr_bytes = 0;
-    if (smem > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void*)bias_lut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_bytes = smem;
-    }
-    hipLaunchKernelGGL(bias_lut_kernel, dim3(n), dim3(256), smem, (hipStream_t)stream, lams, n, K, sigma, th, pho, lmax, bias);
+    if (int e = bias_lut_attr()) return e;
+    hipLaunchKernelGGL(bias_lut_kernel, dim3(n), dim3(256), smem, (hipStream_t)stream, lams, n, K, sigma, th, pho, lmax, bias,
+                       (double*)nullptr, 0);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// (n, K, sigma) from the frame's parameter block: the grid is the knot CAPACITY, workgroups beyond the frame's knots exit;
+// the LDS allotment is fixed at 48 KB (the integration tables of K ~ 0.5 ... 40, sigma ~ 0 ... 40 DN need 4-35 KB; a frame that
+// needs more is flagged for the host path)
+#define BIAS_DEV_SMEM_DOUBLES 6144
+extern "C" int yond_bias_lut_dev_f64(const double* lams, int lut_cap, double* prm, float* bias, void* stream) {
+    if (!lams || !prm || !bias || lut_cap < 2 || lut_cap > 4096) return YOND_EINVAL;
+    const size_t smem = (size_t)BIAS_DEV_SMEM_DOUBLES * sizeof(double);
+    if (int e = bias_lut_attr()) return e;
+    hipLaunchKernelGGL(bias_lut_kernel, dim3(lut_cap), dim3(256), smem, (hipStream_t)stream, lams, 0, 1.0, 0.0, 0.0, 1, 0, bias, prm,
+                       BIAS_DEV_SMEM_DOUBLES);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -96,7 +96,10 @@ __device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict_
     // The index guess of lut_eval trusts that every run is EVENLY spaced.  The break detection above compares neighbouring
     // intervals with a relative tolerance, so a slowly drifting grid (a log grid of ratio < 1.001) would pass as one run:
     // check every knot against its run's ideal position x[i0] + (i - i0) * step and fall back to the bisection (exact for
-    // any spacing) if one is off by more than 1e-6 of a step (np.linspace knots are exact to ~1e-13 of a step).
+    // any spacing) if one is off by more than 1e-3 of a step.  (float64 np.linspace knots are exact to ~1e-13 of a step;
+    // the float32 ones NumPy 2 produces for a float32 maximum -- 500 ... ub in steps of ~9.8 -- to 6e-6 of a step; a query
+    // that close to a knot may be evaluated on the neighbouring interval, which differs from the right one by the change of
+    // slope times that distance: < 1e-9 on these tables.  A drifting grid is off by whole steps after a few hundred knots.)
     const int nseg = L.nseg;
     if (nseg > 0) {
         bool bad = false;
@@ -107,13 +110,36 @@ __device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict_
             const double step = L.x[i0 + 1] - L.x[i0];
             // (a repeated knot -- get_bias' 50 and 500 -- opens a run: i0 is its second copy, the first copy closes the previous run)
             const double dev = fabs(L.x[i] - (L.x[i0] + (double)(i - i0) * step));
-            bad = bad || !(dev <= 1e-6 * fabs(step));          // (the zero-width run between the two copies: dev = 0)
+            bad = bad || !(dev <= 1e-3 * fabs(step));          // (the zero-width run between the two copies: dev = 0)
         }
         if (__syncthreads_or(bad ? 1 : 0)) {
             if (tid == 0) L.nseg = 0;
         }
         __syncthreads();
     }
+}
+
+// ---- the prepared table in global memory (yond_lut_table_f64): header, coefficients, knots ----
+struct LutHeader {
+    int n, nseg, nbreak, pad;
+    float seg_x[LUT_MAXSEG], seg_inv[LUT_MAXSEG];
+    int seg_i[LUT_MAXSEG + 1];
+    int pad2[7];
+};
+static_assert(sizeof(LutHeader) == 144, "LutHeader layout");
+__device__ __forceinline__ void lut_load(LutLds& L, const void* __restrict__ ws, int& n_out) {
+    // plain copy of the image yond_lut_table_f64 stored: no arithmetic per workgroup
+    const LutHeader* hd = (const LutHeader*)ws;
+    const int n = hd->n;
+    const double2* ab = (const double2*)((const char*)ws + sizeof(LutHeader));
+    const double* x = (const double*)(ab + LUT_MAX);
+    (void)x;                                          // (the knots themselves stay in global memory: the table's runs are even,
+    for (int i = threadIdx.x; i < n; i += blockDim.x) L.ab[i] = ab[i];      //  yond_lut_table_f64 flags a grid that is not)
+    if (threadIdx.x < LUT_MAXSEG) { L.seg_x[threadIdx.x] = hd->seg_x[threadIdx.x]; L.seg_inv[threadIdx.x] = hd->seg_inv[threadIdx.x]; }
+    if (threadIdx.x <= LUT_MAXSEG) L.seg_i[threadIdx.x] = hd->seg_i[threadIdx.x];
+    if (threadIdx.x == 0) { L.nseg = hd->nseg; L.nbreak = hd->nbreak; }
+    n_out = n;
+    __syncthreads();
 }
 
 __device__ __forceinline__ double lut_eval(const LutLds& L, int n, float xq) {
@@ -179,16 +205,26 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
                                                             int Wp, int mode, float scale_f, double gain, double sigma,
                                                             double lo, double hi, const double* __restrict__ lut_x,
                                                             const void* __restrict__ lut_y, int lut_n, int lut_flags,
-                                                            unsigned int* __restrict__ img_max) {
+                                                            unsigned int* __restrict__ img_max,
+                                                            const double* __restrict__ prm, const void* __restrict__ lut_ws, int lut_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lut_raw[];
     __shared__ LutLds L;
     __shared__ float s_red[4];
+    if (prm) {
+        // the frame's constants from its parameter block (frame_chain.hip); a flagged frame is left to the host path
+        const int fl = (int)prm[YOND_PRM_FLAGS];
+        if (fl & (YOND_PRM_FLAG_BAD_ESTIMATE | YOND_PRM_FLAG_LUT_CAPACITY | YOND_PRM_FLAG_NO_FLAT_AREA)) return;
+        gain = prm[YOND_PRM_GAIN]; sigma = prm[YOND_PRM_SIGMA]; lo = prm[YOND_PRM_LO]; hi = prm[YOND_PRM_HI];
+        lut_n = lut_ws ? (int)prm[YOND_PRM_LUT_N] : 0;
+        if (lut_n > lut_cap) return;                          // (cannot happen: the block's producer checked the same capacity)
+    }
     if (threadIdx.x == 0) {
         L.ab = (double2*)lut_raw;
-        L.x = (double*)(L.ab + lut_n);
+        L.x = lut_ws ? nullptr : (double*)(L.ab + lut_n);
     }
     __syncthreads();
-    if (lut_n > 0) lut_prepare(L, lut_x, lut_y, lut_n, lut_flags);
+    if (lut_ws) { if (lut_n > 0) lut_load(L, lut_ws, lut_n); }
+    else if (lut_n > 0) lut_prepare(L, lut_x, lut_y, lut_n, lut_flags);
     const int h = H / 2, w = W / 2;
     const double c0 = 0.375 * gain * gain;       // (3/8)*gain**2
     const double s2 = sigma * sigma;
@@ -253,8 +289,7 @@ static int launch_pack_vst(const float* bayer, int H, int W, float* out, int pad
         if (e != hipSuccess) return (int)e;
     }
     size_t nb = (size_t)Hp;
-    static const long k1_wgs = getenv("YOND_K1_WGS") ? atol(getenv("YOND_K1_WGS")) : 1536;     // (experiments)
-    if (nb > (size_t)k1_wgs) nb = (size_t)k1_wgs;   // every workgroup prepares the LUT once: keep them few and long-lived
+    if (nb > 1536) nb = 1536;                       // every workgroup prepares the LUT once: keep them few and long-lived
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)pack_vst_norm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_MAX * LUT_BYTES_PER_KNOT);
@@ -263,7 +298,85 @@ static int launch_pack_vst(const float* bayer, int H, int W, float* out, int pad
     }
     const int use_lut = mode == 1 ? lut_n : 0;
     hipLaunchKernelGGL(pack_vst_norm_kernel, dim3((unsigned)nb), dim3(256), (size_t)use_lut * LUT_BYTES_PER_KNOT, st, bayer, H, W, out,
-                       pad_l, pad_t, Hp, Wp, mode, (float)scale, gain, sigma, lo, hi, lut_x, lut_y, use_lut, lut_flags, (unsigned int*)img_max);
+                       pad_l, pad_t, Hp, Wp, mode, (float)scale, gain, sigma, lo, hi, lut_x, lut_y, use_lut, lut_flags, (unsigned int*)img_max,
+                       (const double*)nullptr, (const void*)nullptr, 0);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// ---- the frame's constants from a parameter block, the LUT as a prepared table (frame_chain.hip) ----
+__global__ __launch_bounds__(256) void lut_table_kernel(const double* __restrict__ lut_x, const float* __restrict__ lut_y, int n,
+                                                        const double* __restrict__ prm, void* __restrict__ ws, double* __restrict__ prm_rw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lut_raw[];
+    __shared__ LutLds L;
+    LutHeader* hd = (LutHeader*)ws;
+    if (prm) {
+        const int fl = (int)prm[YOND_PRM_FLAGS];
+        n = (fl & (YOND_PRM_FLAG_BAD_ESTIMATE | YOND_PRM_FLAG_LUT_CAPACITY)) ? 0 : (int)prm[YOND_PRM_LUT_N];
+    }
+    if (n < 2) { if (threadIdx.x == 0) { hd->n = 0; hd->nseg = 0; hd->nbreak = 0; } return; }
+    if (threadIdx.x == 0) {
+        L.ab = (double2*)lut_raw;
+        L.x = (double*)(L.ab + n);
+    }
+    __syncthreads();
+    lut_prepare(L, lut_x, lut_y, n, 0);
+    double2* ab = (double2*)((char*)ws + sizeof(LutHeader));
+    double* x = (double*)(ab + LUT_MAX);
+    for (int i = threadIdx.x; i < n; i += 256) { ab[i] = i >= 1 ? L.ab[i] : make_double2(0.0, 0.0); x[i] = L.x[i]; }
+    if (threadIdx.x < LUT_MAXSEG) { hd->seg_x[threadIdx.x] = L.seg_x[threadIdx.x]; hd->seg_inv[threadIdx.x] = L.seg_inv[threadIdx.x]; }
+    if (threadIdx.x <= LUT_MAXSEG) hd->seg_i[threadIdx.x] = L.seg_i[threadIdx.x];
+    if (threadIdx.x == 0) {
+        hd->n = n; hd->nseg = L.nseg; hd->nbreak = L.nbreak;
+        // K1 keeps only the coefficients in LDS and finds the interval from the run table: a grid that is not a few evenly
+        // spaced runs (never the case for yond_frame_params_f64's grids) goes back to the host path
+        if (prm_rw && L.nseg == 0) prm_rw[YOND_PRM_FLAGS] = (double)((int)prm_rw[YOND_PRM_FLAGS] | YOND_PRM_FLAG_LUT_CAPACITY);
+    }
+}
+
+extern "C" size_t yond_lut_ws_bytes(int lut_cap) {
+    (void)lut_cap;                                   // (the table is laid out for the kernels' maximum, LUT_MAX knots)
+    return sizeof(LutHeader) + (size_t)LUT_MAX * LUT_BYTES_PER_KNOT;
+}
+
+static int lut_smem_attr(const void* kern) {
+    return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_MAX * LUT_BYTES_PER_KNOT);
+}
+
+extern "C" int yond_lut_table_f64(const double* lut_x, const float* lut_y, int n, const double* prm, void* lut_ws, void* stream) {
+    if (!lut_x || !lut_y || !lut_ws || (n < 0 && !prm) || n > LUT_MAX || n == 1) return YOND_EINVAL;
+    static bool attr = false;
+    if (!attr) {
+        if (int e = lut_smem_attr((const void*)lut_table_kernel)) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(lut_table_kernel, dim3(1), dim3(256), (size_t)LUT_MAX * LUT_BYTES_PER_KNOT, (hipStream_t)stream, lut_x, lut_y,
+                       n < 0 ? 0 : n, n < 0 ? prm : (const double*)nullptr, lut_ws, n < 0 ? (double*)prm : (double*)nullptr);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_pack_vst_norm_dev_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
+                                          double scale, const double* prm, const void* lut_ws, int lut_cap, float* img_max, void* stream) {
+    if (!bayer || !out || !prm || H < 2 || W < 2 || (H & 1) || (W & 1)) return YOND_EINVAL;
+    if (lut_ws && (lut_cap < 2 || lut_cap > LUT_MAX)) return YOND_EINVAL;
+    if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 || !(scale > 0.0)) return YOND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int Hp = H / 2 + pad_t + pad_b, Wp = W / 2 + pad_l + pad_r;
+    if (img_max) {
+        hipError_t e = hipMemsetAsync(img_max, 0, sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    static bool attr = false;
+    if (!attr) {
+        if (int e = lut_smem_attr((const void*)pack_vst_norm_kernel)) return e;
+        attr = true;
+    }
+    const unsigned nb = Hp < 1536 ? (unsigned)Hp : 1536u;       // (the table is copied, not derived, per workgroup)
+    // (LDS: the coefficients of the caller's knot capacity: 1536 knots = 24 KB, six workgroups per CU)
+    hipLaunchKernelGGL(pack_vst_norm_kernel, dim3(nb), dim3(256), lut_ws ? (size_t)lut_cap * sizeof(double2) : 0, st, bayer, H, W, out,
+                       pad_l, pad_t, Hp, Wp, 1, (float)scale, 1.0, 0.0, 0.0, 1.0, (const double*)nullptr, (const void*)nullptr, 0, 0,
+                       (unsigned int*)img_max, prm, lut_ws, lut_cap);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -320,7 +433,12 @@ extern "C" int yond_bias_eval_f32(const float* x, size_t n, const double* lut_x,
 __global__ __launch_bounds__(256) void denorm_ivst_unpack_kernel(const float* __restrict__ net_out, int Wp, int pad_t,
                                                                  int pad_l, int h, int w, float* __restrict__ bayer,
                                                                  int mode, double scale, double gain, double sigma,
-                                                                 double lo, double hi, int clip01) {
+                                                                 double lo, double hi, int clip01, const double* __restrict__ prm) {
+    if (prm) {
+        const int fl = (int)prm[YOND_PRM_FLAGS];
+        if (fl & (YOND_PRM_FLAG_BAD_ESTIMATE | YOND_PRM_FLAG_LUT_CAPACITY | YOND_PRM_FLAG_NO_FLAT_AREA)) return;
+        gain = prm[YOND_PRM_GAIN]; sigma = prm[YOND_PRM_SIGMA]; lo = prm[YOND_PRM_LO]; hi = prm[YOND_PRM_HI];
+    }
     const double span = hi - lo;
     const double sg = sigma / gain;                 // inverse_VST: sigma = sigma / gain
     const double sg2 = sg * sg;
@@ -364,7 +482,19 @@ extern "C" int yond_denorm_ivst_unpack_f32(const float* net_out, int Hp, int Wp,
     size_t nb = (size_t)h;
     if (nb > 256 * 16) nb = 256 * 16;
     hipLaunchKernelGGL(denorm_ivst_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, net_out, Wp, pad_t,
-                       pad_l, h, w, bayer_out, mode, scale, gain, sigma, lo, hi, clip01);
+                       pad_l, h, w, bayer_out, mode, scale, gain, sigma, lo, hi, clip01, (const double*)nullptr);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_denorm_ivst_unpack_dev_f32(const float* net_out, int Hp, int Wp, int pad_t, int pad_l, int h, int w,
+                                               float* bayer_out, int mode, double scale, const double* prm, int clip01, void* stream) {
+    if (!net_out || !bayer_out || !prm || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0) return YOND_EINVAL;
+    if (pad_t + h > Hp || pad_l + w > Wp || (mode != 1 && mode != 2) || !(scale > 0.0)) return YOND_EINVAL;
+    size_t nb = (size_t)h;
+    if (nb > 256 * 16) nb = 256 * 16;
+    hipLaunchKernelGGL(denorm_ivst_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, net_out, Wp, pad_t,
+                       pad_l, h, w, bayer_out, mode, scale, 1.0, 0.0, 0.0, 1.0, clip01, prm);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -448,7 +448,7 @@ def _key2float(key):
     return np.array([bits], dtype=np.uint32).view(np.float32)[0]
 
 
-def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, fused=None, box=None):
+def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, fused=None, box=None, _maps_only=False):
     """YOND_SIDD.py:117-124 (+ SelfNLF :62-87, CollabNLF :89-115): Bayer frame(s) -> (beta1, beta2).
     box selects the kernels that produce the three maps:
       'two-pass' (default)  the streaming box kernels with the first sweep of the threshold selection folded into the
@@ -511,6 +511,8 @@ def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, 
                         "yond_box_stats_collab_f32")
     else:
         raise NotImplementedError(setting['mode'])
+    if _maps_only:
+        return lap, mean, var, ws
     return _nlf_from_maps(lap, mean, var, full, ws=ws)
 
 
@@ -648,6 +650,152 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
     return out if redo is None else redo
 
 
+# ------------------------------------------------------------------------------------------------
+# The per-frame parameter chain on the device (csrc/frame_chain.hip): estimator -> (K, sigma, lower, upper, t, knots) -> bias LUT
+# -> K1 -> network -> K4 without a host round trip.  Used by IterDenoise for bare full frames with the 1-D bias LUT (the
+# BASELINE cfg-2 / cfg-5 configuration); every other configuration keeps the host-side chain above.
+# ------------------------------------------------------------------------------------------------
+LUT_CAP = 1536                      # knots the chain's buffers hold (a [0, 1] frame at scale 959 needs 1000)
+PRM = dict(beta1=0, beta2=1, gain=2, sigma=3, lo=4, hi=5, nsr=6, t=7, flags=8, lut_n=9, nsel=10, th=11, pct=12, frame_max=13)
+PRM_NO_FLAT_AREA, PRM_LUT_CAPACITY, PRM_ROUND_ABORTED, PRM_BAD_ESTIMATE = 1, 2, 4, 8
+
+
+class _ChainBuffers:
+    """Device buffers of one round of the chain (kept per device and round: nothing is allocated per frame)."""
+
+    def __init__(self, dev):
+        lib = L.load()
+        self.prm = torch.zeros(16, dtype=torch.float64, device=dev)
+        self.t = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.lut_x = torch.zeros(LUT_CAP, dtype=torch.float64, device=dev)
+        self.lut_y = torch.zeros(LUT_CAP, dtype=torch.float32, device=dev)
+        self.lut_ws = torch.zeros(int(lib.yond_lut_ws_bytes(LUT_CAP)), dtype=torch.uint8, device=dev)
+        self.img_max = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.prm_host = torch.zeros(16, dtype=torch.float64).pin_memory()
+
+
+_CHAIN_BUFFERS = {}
+
+
+def _chain_buffers(dev, slot):
+    key = (str(dev), slot)
+    if key not in _CHAIN_BUFFERS:
+        _CHAIN_BUFFERS[key] = _ChainBuffers(dev)
+    return _CHAIN_BUFFERS[key]
+
+
+def chain_applies(lr, net, arch, pipe, biaslut=None):
+    """The configurations the device chain covers: one bare Bayer frame, full_dn, bias_corr 'pre' with the 1-D LUT."""
+    return (isinstance(lr, torch.Tensor) and lr.is_cuda and lr.dim() == 2 and bool(pipe.get('full_dn', False)) and biaslut is None
+            and pipe.get('bias_corr', 'pre') == 'pre' and pipe.get('full_est', True) and DEVICE_CHAIN)
+
+
+DEVICE_CHAIN = True                 # (module attribute: tools / tests switch the host-side chain back on for A/B)
+
+
+def _chain_round(lr, hr, mode, net, arch, pipe, p, slot, lr_max_dev=None, vst_type='exact'):
+    """One round of IterDenoise for a bare frame, queued without any host synchronisation:
+    estimator (self / collab) -> yond_frame_params_f64 -> bias LUT -> table -> K1 -> network -> K4.
+    Returns (denoised frame [H][W] on the device, buffers whose .prm block describes the round, range guard or None)."""
+    lib = L.load()
+    k = pipe.get('k', 29)
+    H, W = lr.shape
+    h, w = H // 2, W // 2
+    scale = float(p['wp'] - p['bl'])
+    buf = _chain_buffers(lr.device, slot)
+    st = L.stream()
+    setting = {'mode': mode}
+    if mode == 'collab':
+        setting['SIDD_256'] = bool(pipe.get('collab_sidd256', (W // 2) % 32 == 0))
+    lap, mean, var, ws = SimpleNLF(lr, hr, k=k, setting=setting, _maps_only=True)
+    n = lap.numel()
+    q = np.ascontiguousarray(QUANTS, dtype=np.float64)
+    qp = C.c_void_p(q.ctypes.data)
+    with _stage("nle_select_score_moments"):
+        L.check(lib.yond_nle_threshold_f32(L.ptr(lap.reshape(-1)), n, qp, len(q), 1, L.ptr(ws), st), "yond_nle_threshold_f32")
+        L.check(lib.yond_nle_moments_f32(L.ptr(lap.reshape(-1)), L.ptr(mean.reshape(-1)), L.ptr(var.reshape(-1)), n, L.ptr(ws), st),
+                "yond_nle_moments_f32")
+    with _stage("frame_params_lut"):
+        # (round 2 reads the frame maximum round 1's estimator collected: the collab kernels read the same noisy frame)
+        L.check(lib.yond_frame_params_f64(L.ptr(ws), L.ptr(lr_max_dev) if lr_max_dev is not None else None, 0 if mode == 'self' else 1,
+                                          scale, 1.03, LUT_CAP, L.ptr(buf.prm), L.ptr(buf.t), L.ptr(buf.lut_x), st), "yond_frame_params_f64")
+        L.check(lib.yond_bias_lut_dev_f64(L.ptr(buf.lut_x), LUT_CAP, L.ptr(buf.prm), L.ptr(buf.lut_y), st), "yond_bias_lut_dev_f64")
+        L.check(lib.yond_lut_table_f64(L.ptr(buf.lut_x), L.ptr(buf.lut_y), -1, L.ptr(buf.prm), L.ptr(buf.lut_ws), st), "yond_lut_table_f64")
+    p2d = get_p2d((1, 4, h, w), base=32)
+    Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
+    x4 = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=lr.device)
+    with _stage("vst_pack"):
+        L.check(lib.yond_pack_vst_norm_dev_f32(L.ptr(lr), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], scale, L.ptr(buf.prm),
+                                               L.ptr(buf.lut_ws), LUT_CAP, L.ptr(buf.img_max), st), "yond_pack_vst_norm_dev_f32")
+    plan = _plan_of(net, lr.device)
+    t_dev = buf.t if 'guided' in arch else None
+
+    def forward_and_invert():
+        y4 = plan.forward_nhwc4(x4, t_dev, ub=buf.img_max)
+        out = torch.empty((H, W), dtype=torch.float32, device=lr.device)
+        with _stage("ivst_unpack"):
+            L.check(lib.yond_denorm_ivst_unpack_dev_f32(L.ptr(y4), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 1, scale, L.ptr(buf.prm),
+                                                        1, st), "yond_denorm_ivst_unpack_dev_f32")
+        return out
+
+    watch = _Guard(plan, slot) if plan.uses_half_operands() else None
+    out = forward_and_invert()
+    if watch is not None:
+        watch.arm(forward_and_invert)
+    buf.prm_host.copy_(buf.prm, non_blocking=True)       # read by the caller behind its synchronisation
+    buf.ws = ws
+    return out, buf, watch
+
+
+def _chain_result(buf):
+    """The round's parameter block as host numbers (the caller has synchronised): (reg, (K, sigma), flags, info)."""
+    v = buf.prm_host.numpy()
+    flags = int(v[PRM['flags']])
+    reg = (np.float64(v[PRM['beta1']]), np.float64(v[PRM['beta2']]))
+    info = dict(th=float(v[PRM['th']]), percent=float(v[PRM['pct']]), nsel=int(v[PRM['nsel']]), frame_max=np.float32(v[PRM['frame_max']]))
+    return reg, (np.float64(v[PRM['gain']]), np.float64(v[PRM['sigma']])), flags, info
+
+
+def _iter_denoise_chain(lr, net, arch, pipe, p, log=None):
+    """IterDenoise for a bare full frame on the device chain: both rounds are queued back to back (round 2 speculatively: its
+    estimate needs round 1's output, not its numbers) and ONE synchronisation at the end delivers the parameter blocks.
+    Returns None when a round took a branch the chain leaves to the host (flags), and the caller runs the host-side path."""
+    out1, b1, g1 = _chain_round(lr, None, 'self', net, arch, pipe, p, slot=0)
+    two = pipe.get('iter', 'iter') == 'iter' and pipe.get('max_iter', 1) >= 1
+    if two and pipe.get('max_iter', 1) > 1:
+        return None
+    if two:
+        mx = torch.empty(1, dtype=torch.float32, device=lr.device)
+        mx.copy_(b1.prm[PRM['frame_max']:PRM['frame_max'] + 1])           # float64 holding the float32 maximum -> float32
+        out2, b2, g2 = _chain_round(lr, out1, 'collab', net, arch, pipe, p, slot=1, lr_max_dev=mx)
+    torch.cuda.current_stream().synchronize()
+    reg1, par1, fl1, info1 = _chain_result(b1)
+    if fl1 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE):
+        return None
+    if g1 is not None:
+        redo = g1.finish()
+        if redo is not None:
+            return None                                  # an activation left fp16's range: the guarded host path recomputes
+    if log:
+        log(f"Self Est: K={par1[0]:.4f}, b={par1[1]:.4f} (beta1={reg1[0]:.3e}, beta2={reg1[1]:.3e})")
+    raw_dns, regs, params = [out1], [reg1], [par1]
+    if two:
+        reg2, par2, fl2, info2 = _chain_result(b2)
+        if fl2 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY):
+            return None
+        if log:
+            log(f"Iter 1 Est: K={par2[0]:.4f}, sigma={par2[1]:.4f} (beta1={reg2[0]:.3e}, beta2={reg2[1]:.3e})")
+        if not (fl2 & PRM_ROUND_ABORTED):                # :445-447: beta1 < 0 ends the image after round 1
+            if fl2 & PRM_BAD_ESTIMATE:
+                return None
+            if g2 is not None and g2.finish() is not None:
+                return None
+            raw_dns.append(out2)
+            regs.append(reg2)
+            params.append(par2)
+    return dict(raw_dns=raw_dns, regs=regs, params=params, nle_info=info1)
+
+
 def _frame_max(x):
     """Maximum of a device tensor as a 1-element device tensor (yond_image_max_f32: two launches, deterministic)."""
     lib = L.load()
@@ -712,6 +860,12 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     if bias_corr == 'none':
         bias_corr = None
     full_dn = bool(pipe.get('full_dn', False))
+    if lr_full is None and 'rot_cfa' not in p:
+        lr_c = _dev(lr_raw, device)
+        if chain_applies(lr_c, net, arch, pipe, biaslut):
+            res = _iter_denoise_chain(lr_c, net, arch, pipe, p, log=log)
+            if res is not None:
+                return res
     sidd = not full_dn
     vst_type = pipe.get('vst_type', 'exact')
     scale = p['wp'] - p['bl']

@@ -384,8 +384,15 @@ int yond_block_metrics_f32(const float* dn, const float* hr, int H, int W, int b
 #define YOND_PRM_FLAG_LUT_CAPACITY 2   /* more knots than lut_cap (or more LDS than the LUT kernel has) */
 #define YOND_PRM_FLAG_ROUND_ABORTED 4  /* round 2: beta1 < 0 (:445-447): the caller drops this round's output */
 #define YOND_PRM_FLAG_BAD_ESTIMATE 8   /* K <= 0 or NaN: nothing downstream is defined */
-int yond_frame_params_f64(const void* nle_ws, const float* max_dev, int mode, double scale, double tfac, int lut_cap,
-                          double* prm, float* t_out, double* lut_x, void* stream);
+int yond_frame_params_f64(const void* nle_ws, const float* max_dev, int mode,
+                          double scale_est /* wp - bl: beta -> (K, sigma) in DN, :356 */, double scale /* p['scale'] = (wp - bl) / ratio: the VST's DN scale, :251 */,
+                          double tfac, int lut_cap, double* prm, float* t_out, double* lut_x, void* stream);
+/* Row H for large K * sigma (14-bit sensors at a digital gain: the Gaussian table of the integration exceeds the LDS and
+ * yond_bias_lut_f64 returns YOND_EUNSUPPORTED): the same integration with the table in a caller-provided scratch buffer of
+ * yond_bias_lut_big_scratch(gain, sigma, nwg) doubles, nwg workgroups striding over the knots.  Seconds, not microseconds. */
+size_t yond_bias_lut_big_scratch(double gain, double sigma, int nwg);
+int yond_bias_lut_big_f64(const double* lams, int n, double gain, double sigma, float* bias, double* scratch,
+                          size_t scratch_doubles, int nwg, void* stream);
 /* Row H with (n, K, sigma) read from the block: launches lut_cap workgroups, those beyond prm[LUT_N] exit. */
 int yond_bias_lut_dev_f64(const double* lams, int lut_cap, double* prm, float* bias, void* stream);
 /* The LUT in the form K1 evaluates (per-interval coefficients + run table), prepared ONCE per frame instead of once per

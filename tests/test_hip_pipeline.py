@@ -123,7 +123,7 @@ def test_device_knot_grid_bit_identical(ub):
     mxd = torch.tensor([float(mx)], dtype=torch.float32, device=DEV)
     prm = torch.zeros(16, dtype=torch.float64, device=DEV)
     lut_x = torch.zeros(P.LUT_CAP, dtype=torch.float64, device=DEV)
-    L.check(lib.yond_frame_params_f64(L.ptr(ws), L.ptr(mxd), 0, 1.0, 1.03, P.LUT_CAP, L.ptr(prm), None, L.ptr(lut_x), L.stream()), "frame_params")
+    L.check(lib.yond_frame_params_f64(L.ptr(ws), L.ptr(mxd), 0, 1.0, 1.0, 1.03, P.LUT_CAP, L.ptr(prm), None, L.ptr(lut_x), L.stream()), "frame_params")
     torch.cuda.synchronize()
     n = int(prm[P.PRM['lut_n']].item())
     want = np.asarray(P._bias_knots(np.ceil(mx) + 1), np.float64)

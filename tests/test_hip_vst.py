@@ -184,3 +184,21 @@ def test_bias_eval_on_drifting_and_float32_grids():
         err = np.abs(got - want).max()
         print(f"[parity] bias LUT on a {name} grid: max |delta| = {err:.3e}")
         assert err < 1e-7
+
+
+def test_bias_lut_large_gain_sigma_fallback():
+    """14-bit frames at a digital gain (ELD at ratio 10: K ~ 80, sigma ~ 300 DN): the Gaussian table of the integration
+    (~16 k float64 per knot) exceeds the LDS; get_bias then runs the same kernel with the table in a global scratch buffer.
+    Knots and ordinates against the oracle's restatement of utils/isp_algos.py:98-140."""
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    from yond_public_amd import _lib as L
+    K, s, mx = np.float64(80.0), np.float64(300.0), np.float32(140.3)
+    assert L.load().yond_bias_lut_f64(None, 1, float(K), float(s), None, None) != 0          # (arguments rejected before any launch)
+    lut = P.get_bias(mx, s, K, device=DEV)
+    ref = O.get_bias(mx, s, K)
+    np.testing.assert_array_equal(lut.lams, np.asarray(ref.x))
+    got, want = lut.y.cpu().numpy(), np.asarray(ref.y)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+    print(f"[parity] large-table bias LUT (K=80, sigma=300): {len(got)} knots, max |delta| = {err:.3e}, |bias| <= {np.abs(want).max():.3e}")
+    assert err <= 2e-7 * max(1.0, float(np.abs(want).max()))

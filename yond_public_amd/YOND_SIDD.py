@@ -192,6 +192,43 @@ class YOND_SIDD:
         return red
 
 
+    def benchmark(self):
+        """YOND_SIDD.py:572-630 (`-m test`): the SIDD BENCHMARK blocks (no ground truth) through IterDenoise; keeps what the
+        reference keeps -- per-image estimates as `reg_test` in self.metrics and the two submission arrays
+        bench_init / bench_results [N][32][256][256] (first / last round) -- and writes them to npy/<method>/ (the reference's
+        .mat export is commented out upstream, :615-621; sRGB previews need cv2 and are out of scope).  Images are sharded over
+        the ranks; every rank writes the blocks of its own images."""
+        n = len(self.dst_eval)
+        bench_init = np.zeros((n, 32, 256, 256), np.float32)
+        bench_results = np.zeros((n, 32, 256, 256), np.float32)
+        p = dict(self.pipe)
+        p.update({'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0})                  # :586
+        p['scale'] = (p['wp'] - p['bl']) / p['ratio']
+        self.metrics = getattr(self, 'metrics', None) or {}
+        mine = D.shard_indices(n, self.rank, self.world)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in mine:
+            data = self.dst_eval[k]
+            p['cfa'] = data.get('cfa', [[1, 2], [2, 3]])
+            res = self.IterDenoise(data, {'p': p, 'img_id': k})
+            self.metrics.setdefault(data['name'], {})['reg_test'] = res['regs']                   # :597
+            first, last = res['raw_dns'][0].cpu().numpy(), res['raw_dns'][-1].cpu().numpy()
+            bench_init[k] = np.array(np.split(first, 32, axis=-1))                                # :612-613
+            bench_results[k] = np.array(np.split(last, 32, axis=-1))
+            log(f"[rank {self.rank}] {data['name']}: {len(res['raw_dns'])} round(s), regs {[tuple(float(v) for v in r) for r in res['regs']]}", self.logfile)
+        torch.cuda.synchronize()
+        dt = D.max_over_ranks(time.perf_counter() - t0, self.device)
+        os.makedirs(f'npy/{self.method_name}', exist_ok=True)
+        tag = '' if self.world == 1 else f'_rank{self.rank}'
+        np.save(f'npy/{self.method_name}/benchmark_init{tag}.npy', bench_init)
+        np.save(f'npy/{self.method_name}/benchmark_results{tag}.npy', bench_results)
+        D.barrier()
+        if self.rank == 0:
+            log(f'{self.method_name} benchmark: {n} images on {self.world} GPU(s) in {dt:.2f} s -> npy/{self.method_name}/benchmark_*.npy', self.logfile)
+        return bench_init, bench_results
+
+
 class YONDParser:
     def __init__(self):
         self.parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
@@ -212,8 +249,14 @@ class YONDParser:
 def main(argv=None):
     trainer = YOND_SIDD(argv)
     try:
-        if 'eval' in trainer.mode or 'test' in trainer.mode:
-            return trainer.eval(-1)
+        out = None
+        if 'eval' in trainer.mode:                           # YOND_SIDD.py:736-744
+            trainer.change_eval_dst('eval')
+            out = trainer.eval(-1)
+        if 'test' in trainer.mode:
+            trainer.change_eval_dst('test')
+            out = trainer.benchmark()
+        return out
     finally:
         D.finalize()
 

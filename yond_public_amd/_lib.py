@@ -83,14 +83,16 @@ PROTOTYPES = {
     "yond_block_metrics_tiles": [i32, i32],
     "yond_block_metrics_f32": [vp, vp, i32, i32, i32, i32, vp, vp],
     "yond_clock_probe": [f64, vp, vp],
-    "yond_frame_params_f64": [vp, vp, i32, f64, f64, i32, vp, vp, vp, vp],
+    "yond_frame_params_f64": [vp, vp, i32, f64, f64, f64, i32, vp, vp, vp, vp],
     "yond_bias_lut_dev_f64": [vp, i32, vp, vp, vp],
+    "yond_bias_lut_big_scratch": [f64, f64, i32],
+    "yond_bias_lut_big_f64": [vp, i32, f64, f64, vp, vp, sz, i32, vp],
     "yond_lut_ws_bytes": [i32],
     "yond_lut_table_f64": [vp, vp, i32, vp, vp, vp],
     "yond_pack_vst_norm_dev_f32": [vp, i32, i32, vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, vp],
     "yond_denorm_ivst_unpack_dev_f32": [vp, i32, i32, i32, i32, i32, i32, vp, i32, f64, vp, i32, vp],
 }
-_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes", "yond_lut_ws_bytes"}
+_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes", "yond_lut_ws_bytes", "yond_bias_lut_big_scratch"}
 
 
 class YondHipError(RuntimeError):
@@ -106,6 +108,12 @@ def load():
         raise YondHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  yond_public_amd has no CPU fallback.")
+    if "YOND_HIP_LIB" not in os.environ:
+        # a library built from other sources than the ones beside it (an edit without a rebuild) fails here, not in a kernel
+        from . import build as _build
+        if os.path.exists(_build.STAMP) and _build.sources() and open(_build.STAMP).read().split()[0] != _build.source_hash():
+            raise YondHipError(f"{LIB_PATH} is stale: csrc/ or include/ changed since it was built "
+                               "(`python -m yond_public_amd.build`, or __graft_entry__.build())")
     lib = C.CDLL(LIB_PATH)
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)

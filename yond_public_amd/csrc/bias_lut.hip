@@ -34,7 +34,7 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
 
 __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict__ lams, int n, double K, double sigma,
                                                        double th, int pho, int lmax, float* __restrict__ bias,
-                                                       double* __restrict__ prm, int smem_doubles) {
+                                                       double* __restrict__ prm, int smem_doubles, double* __restrict__ gbuf) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double s_red[4];
     if (prm) {
@@ -54,12 +54,14 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
             return;
         }
     }
-    double* s_g = sm;                 // Gaussian table on the grid, l entries
-    double* s_p = sm + lmax;          // Poisson mass at integer point m (x = m), r+1 entries; 0 if the grid misses it
-    const int i = blockIdx.x;
-    if (i >= n) return;
-    const double lam = lams[i];
+    // Gaussian table on the grid, l entries: in LDS, or -- large K * sigma (14-bit sensors at a digital gain of 10 ...): hundreds of
+    // KB -- in a per-workgroup slice of a global scratch buffer (yond_bias_lut_big_f64: the workgroups then stride over the knots)
+    double* s_g = gbuf ? gbuf + (size_t)blockIdx.x * lmax : sm;
+    double* s_p = gbuf ? sm : sm + lmax;   // Poisson mass at integer point m (x = m), r+1 entries; 0 if the grid misses it
     const int tid = threadIdx.x;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    __syncthreads();                       // (the tables of the previous knot are no longer read)
+    const double lam = lams[i];
     if (lam > th) {
         if (tid == 0) {
             // close_form_bias (utils/isp_algos.py:84-96)
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
             const double m3 = (y + 3.0 * (y + sg * sg) * (y + sg * sg)) / (yh2 * yh2);
             bias[i] = (float)(2.0 * sqrt(yh) * (-1.0 / 8.0 * m1 + 1.0 / 16.0 * m2 - 5.0 / 128.0 * m3));
         }
-        return;
+        continue;
     }
     // getGsP (utils/isp_algos.py:49-82), r as at :124
     const int r = (int)(lam * (1.0 / K) * 2.0 + sigma * 2.0 + lam + 10.0);
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
         const double e = spv / (sp / (double)pho) / (double)pho;
         bias[i] = (float)(e - vst_d(lam, sigma, K));
     }
+    }
 }
 
 static int bias_lut_attr() {                 // the kernel may use the whole LDS of a CU (set once for both entry points)
@@ -152,7 +155,7 @@ extern "C" int yond_bias_lut_f64(const double* lams, int n, double gain, double 
     if (smem > 160 * 1024 - 64) return YOND_EUNSUPPORTED;
     if (int e = bias_lut_attr()) return e;
     hipLaunchKernelGGL(bias_lut_kernel, dim3(n), dim3(256), smem, (hipStream_t)stream, lams, n, K, sigma, th, pho, lmax, bias,
-                       (double*)nullptr, 0);
+                       (double*)nullptr, 0, (double*)nullptr);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -166,7 +169,39 @@ extern "C" int yond_bias_lut_dev_f64(const double* lams, int lut_cap, double* pr
     const size_t smem = (size_t)BIAS_DEV_SMEM_DOUBLES * sizeof(double);
     if (int e = bias_lut_attr()) return e;
     hipLaunchKernelGGL(bias_lut_kernel, dim3(lut_cap), dim3(256), smem, (hipStream_t)stream, lams, 0, 1.0, 0.0, 0.0, 1, 0, bias, prm,
-                       BIAS_DEV_SMEM_DOUBLES);
+                       BIAS_DEV_SMEM_DOUBLES, (double*)nullptr);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// Large K * sigma: the Gaussian table does not fit the LDS (yond_bias_lut_f64 returns YOND_EUNSUPPORTED): the same
+// integration with the table in a global scratch buffer, `nwg` workgroups striding over the knots.
+// yond_bias_lut_big_scratch: doubles of scratch for (gain, sigma) at nwg workgroups (0: parameters out of range).
+extern "C" size_t yond_bias_lut_big_scratch(double gain, double sigma, int nwg) {
+    if (!(gain > 0.0) || !(sigma >= 0.0) || nwg <= 0) return 0;
+    int pho = (int)sqrt(gain);
+    if (pho < 1) pho = 1;
+    const double th = gain < 1.0 ? 50.0 * gain : 50.0 * sqrt(gain);
+    const double rmax = th * (1.0 / gain) * 2.0 + sigma * 2.0 + th + 10.0 + 1.0;
+    if (!(rmax < 1.5e4)) return 0;                                   // (a 160 KB LDS holds the Poisson masses of r <= ~2e4)
+    return (size_t)nwg * (size_t)(2 * pho * (int)rmax + 1);
+}
+
+extern "C" int yond_bias_lut_big_f64(const double* lams, int n, double gain, double sigma, float* bias, double* scratch,
+                                     size_t scratch_doubles, int nwg, void* stream) {
+    if (!lams || !bias || !scratch || n <= 0 || nwg <= 0) return YOND_EINVAL;
+    const size_t need = yond_bias_lut_big_scratch(gain, sigma, nwg);
+    if (need == 0) return YOND_EUNSUPPORTED;
+    if (scratch_doubles < need) return YOND_EINVAL;
+    const double K = gain;
+    int pho = (int)sqrt(K);
+    if (pho < 1) pho = 1;
+    const double th = K < 1.0 ? 50.0 * K : 50.0 * sqrt(K);
+    const int rmax = (int)(th * (1.0 / K) * 2.0 + sigma * 2.0 + th + 10.0) + 1;
+    const int lmax = 2 * pho * rmax + 1;
+    if (int e = bias_lut_attr()) return e;
+    hipLaunchKernelGGL(bias_lut_kernel, dim3(nwg < n ? nwg : n), dim3(256), ((size_t)rmax + 2) * sizeof(double), (hipStream_t)stream, lams, n, K,
+                       sigma, th, pho, lmax, bias, (double*)nullptr, 0, scratch);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -34,7 +34,7 @@ __device__ __forceinline__ double linspace_f64(int i, int num, double start, dou
 }
 
 __global__ __launch_bounds__(256) void frame_params_kernel(const NleState* __restrict__ st, const float* __restrict__ max_dev,
-                                                           int mode, double scale, double tfac, int lut_cap,
+                                                           int mode, double scale_est, double scale, double tfac, int lut_cap,
                                                            double* __restrict__ prm, float* __restrict__ t_out,
                                                            double* __restrict__ lut_x) {
     __shared__ int s_n, s_n1, s_n2, s_n3;
@@ -63,12 +63,12 @@ __global__ __launch_bounds__(256) void frame_params_kernel(const NleState* __res
         }
         double gain, sigma;
         if (mode == 0) {                                                             // :356
-            gain = b1 * scale;
-            sigma = sqrt(b2 > 0.0 ? b2 : 0.0) * scale;
+            gain = b1 * scale_est;
+            sigma = sqrt(b2 > 0.0 ? b2 : 0.0) * scale_est;
         } else {                                                                     // :438-447
             if (b2 < 0.0) b2 = b1 * b1;
-            gain = b1 * scale;
-            sigma = sqrt(b2) * scale;
+            gain = b1 * scale_est;
+            sigma = sqrt(b2) * scale_est;
             if (b1 < 0.0) flags |= YOND_PRM_FLAG_ROUND_ABORTED;
         }
         if (!(gain > 0.0) || !(sigma >= 0.0)) flags |= YOND_PRM_FLAG_BAD_ESTIMATE;  // (K1 / the LUT need K > 0: the consumers skip their work)
@@ -106,11 +106,11 @@ __global__ __launch_bounds__(256) void frame_params_kernel(const NleState* __res
     }
 }
 
-extern "C" int yond_frame_params_f64(const void* nle_ws, const float* max_dev, int mode, double scale, double tfac, int lut_cap,
-                                     double* prm, float* t_out, double* lut_x, void* stream) {
-    if (!nle_ws || !prm || !lut_x || (mode != 0 && mode != 1) || !(scale > 0.0) || lut_cap < 2) return YOND_EINVAL;
-    hipLaunchKernelGGL(frame_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const NleState*)nle_ws, max_dev, mode, scale,
-                       tfac, lut_cap, prm, t_out, lut_x);
+extern "C" int yond_frame_params_f64(const void* nle_ws, const float* max_dev, int mode, double scale_est, double scale, double tfac,
+                                     int lut_cap, double* prm, float* t_out, double* lut_x, void* stream) {
+    if (!nle_ws || !prm || !lut_x || (mode != 0 && mode != 1) || !(scale > 0.0) || !(scale_est > 0.0) || lut_cap < 2) return YOND_EINVAL;
+    hipLaunchKernelGGL(frame_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const NleState*)nle_ws, max_dev, mode, scale_est,
+                       scale, tfac, lut_cap, prm, t_out, lut_x);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -90,3 +90,189 @@ class SIDD_Dataset:
             except RuntimeError as e:                                       # v7.3 without h5py: estimate from the blocks (:340)
                 data['lr_full_error'] = str(e)
         return data
+
+
+# ------------------------------------------------------------------------------------------------
+# Full-frame datasets: the reference reads DNG / ARW / CR2 / NEF through rawpy, which this image
+# lacks, so every class below works on `.npy`-CONVERTED trees: the same directory layout and item dictionaries, each raw
+# file replaced by (or accompanied by) `<same name>.npy` holding raw_image_visible as the camera wrote it.  Black / white
+# level come from the camera directory's `meta.json` ({"bl": .., "wp": ..}: what rawpy's black_level_per_channel /
+# white_level report) or, without one, from the runfile's dst section.
+# ------------------------------------------------------------------------------------------------
+def _npy_path(path):
+    """The converted copy of a raw file: `<stem>.npy` next to it (or the path itself when it already is one)."""
+    if path.endswith('.npy'):
+        return path
+    stem = os.path.splitext(path)[0]
+    if os.path.exists(stem + '.npy'):
+        return stem + '.npy'
+    raise RuntimeError(f"{path}: reading {os.path.splitext(path)[1] or 'this'} files needs rawpy, which this build does not have; "
+                       f"convert it once (np.save('{stem}.npy', rawpy.imread(path).raw_image_visible)) -- the datasets pick up "
+                       f"`.npy` copies next to the raw files")
+
+
+def _levels(dirpath, args):
+    import json
+    f = os.path.join(dirpath, 'meta.json')
+    if os.path.exists(f):
+        m = json.load(open(f))
+        return float(m.get('bl', args['bl'])), float(m.get('wp', args['wp']))
+    return float(args['bl']), float(args['wp'])
+
+
+class ELD_Full_Dataset:
+    """data_process/yond_datasets.py:977-1067: <root_dir>/<camera>/scene-<1..10>/IMG_<id>.<suffix>, 3 ISOs x 4 ratios per
+    scene, long-exposure references IMG_0001 / 0006 / 0011 / 0016; `change_eval_ratio(cam, ratio, iso_list)` selects the
+    evaluated subset.  Items: 'lr' = (raw - bl) * ratio / (wp - bl), 'hr' = (raw - bl) / (wp - bl) (float32 Bayer frames),
+    'name', 'ratio', 'ISO', 'wb', 'ccm' (identity without the raw file's metadata)."""
+    SUFFIX = {'CanonEOS70D': 'CR2', 'CanonEOS700D': 'CR2', 'NikonD850': 'nef', 'SonyA7S2': 'ARW'}
+
+    def __init__(self, args=None):
+        self.args = {'root_dir': 'ELD/', 'ratio': 1, 'dstname': 'ELD', 'params': None, 'mode': 'eval', 'command': '',
+                     'wp': 16383, 'bl': 512, 'clip': False}
+        self.args.update(args or {})
+        self.infos_all = {cam: [] for cam in self.SUFFIX}
+        iso_list, ratio_list = [800, 1600, 3200], [1, 10, 100, 200]
+        hr_ids = np.array([1, 6, 11, 16])
+        for cam, suffix in self.SUFFIX.items():
+            sub_dir = f'{self.args["root_dir"]}/{cam}'
+            for scene in range(1, 11):
+                for iso_id, iso in enumerate(iso_list):
+                    for ratio_id, ratio in enumerate(ratio_list):
+                        lr_id = iso_id * 5 + ratio_id + 2                                   # :1012
+                        hr_id = hr_ids[np.argmin(np.abs(lr_id - hr_ids))]
+                        self.infos_all[cam].append({
+                            'cam': cam, 'name': f'{cam}_{scene:02d}_IMG_{lr_id:04d}',
+                            'hr': f'{sub_dir}/scene-{scene}/IMG_{hr_id:04d}.{suffix}',
+                            'lr': f'{sub_dir}/scene-{scene}/IMG_{lr_id:04d}.{suffix}', 'iso': iso, 'ratio': ratio})
+        self.change_eval_ratio('SonyA7S2', ratio=1)
+
+    def __len__(self):
+        return self.length
+
+    def change_eval_ratio(self, cam='SonyA7S2', ratio=1, iso_list=None):
+        iso_list = iso_list or [800, 1600, 3200]
+        # (scenes that are not on disk are skipped: a converted subset of the dataset is a valid tree)
+        self.infos = [i for i in self.infos_all[cam] if i['iso'] in iso_list and i['ratio'] == ratio
+                      and (os.path.exists(i['lr']) or os.path.exists(os.path.splitext(i['lr'])[0] + '.npy'))]
+        self.length, self.ratio, self.cam = len(self.infos), ratio, cam
+        self.bl, self.wp = _levels(f'{self.args["root_dir"]}/{cam}', self.args)
+        if self.infos:
+            self.H, self.W = np.load(_npy_path(self.infos[0]['lr']), mmap_mode='r').shape
+
+    def __getitem__(self, idx):
+        info = self.infos[idx]
+        hr_raw = np.load(_npy_path(info['hr'])).reshape(self.H, self.W)
+        lr_raw = np.load(_npy_path(info['lr'])).reshape(self.H, self.W)
+        data = {'hr': (hr_raw.astype(np.float32) - self.bl) / (self.wp - self.bl),
+                'lr': (lr_raw.astype(np.float32) - self.bl) * info['ratio'] / (self.wp - self.bl),
+                'name': info['name'], 'ratio': info['ratio'], 'ISO': info['iso'], 'cfa': 'rggb',
+                'wb': np.ones(4, np.float32), 'ccm': np.eye(3, dtype=np.float32), 'meta': None}
+        data['hr'], data['lr'] = data['hr'].astype(np.float32), data['lr'].astype(np.float32)
+        if self.args['clip']:
+            data['hr'], data['lr'] = data['hr'].clip(0, 1), data['lr'].clip(0, 1)
+        return data
+
+
+class LRID_Dataset:
+    """data_process/yond_datasets.py:870-975.  The reference lists its files in pickled info tables (`infos/<dstname>_<GT_type>.info`,
+    `infos/<dstname>_short.info`, not shipped) whose entries point at DNG files; here the same tables are read when present
+    (paths may name the DNG: the `.npy` copy next to it is loaded), else the converted tree
+        <root_dir>/<dstname>/<scene id>/gt.npy, x<ratio:02d>.npy [, meta.json {"wb": [4], "ccm": [3][3], "ExposureTime": s}]
+    is scanned; `get_eval_id` keeps the reference's evaluation scenes (:938-950).  Items as the reference's: 'lr' scaled by
+    the ratio, 'hr', 'name' = '<scene>_x<ratio:02d>', 'ratio', 'wb', 'ccm', 'ISO' = 6400, 'ExposureTime' in ms."""
+
+    def __init__(self, args=None):
+        self.args = {'root_dir': 'LRID/', 'suffix': 'dng', 'dgain': 1, 'dstname': ['indoor_x5'], 'camera_type': 'IMX686', 'params': None,
+                     'mode': 'eval', 'GT_type': 'GT_align_ours', 'command': '', 'H': 3472, 'W': 4624, 'wp': 1023, 'bl': 64, 'clip': False}
+        self.args.update(args or {})
+        if isinstance(self.args['dstname'], str):
+            self.args['dstname'] = [self.args['dstname']]
+        self.iso = 6400
+        self.change_eval_ratio(ratio=1)
+
+    def __len__(self):
+        return self.length
+
+    @staticmethod
+    def get_eval_id(dstname='indoor_x5'):
+        return {'indoor_x5': [4, 14, 25, 41, 44, 51, 52, 53, 58], 'indoor_x3': [], 'outdoor_x5': [1, 2, 5],
+                'outdoor_x3': [9, 21, 22, 32, 44, 51]}.get(dstname, [])
+
+    def change_eval_ratio(self, ratio):
+        import json
+        import pickle as pkl
+        self.ratio, self.infos = ratio, []
+        for dstname in self.args['dstname']:
+            gt_info, short_info = f"infos/{dstname}_{self.args['GT_type']}.info", f'infos/{dstname}_short.info'
+            ids = self.get_eval_id(dstname)
+            if os.path.exists(gt_info) and os.path.exists(short_info):           # the reference's tables (:917-931)
+                with open(gt_info, 'rb') as f:
+                    gts = pkl.load(f)
+                with open(short_info, 'rb') as f:
+                    shorts = pkl.load(f)[ratio]
+                for i in ids:
+                    self.infos.append({'name': gts[i]['name'], 'hr': gts[i]['data'], 'lr': shorts[i]['data'][0], 'wb': gts[i]['wb'],
+                                       'ccm': gts[i]['ccm'], 'ExposureTime': shorts[i]['metadata'][0]['ExposureTime']})
+                continue
+            base = f"{self.args['root_dir']}/{dstname}"
+            for i in ids:                                                        # the converted tree
+                d = f'{base}/{i:03d}'
+                lr = f'{d}/x{ratio:02d}.npy'
+                if not os.path.exists(lr):
+                    continue
+                meta = json.load(open(f'{d}/meta.json')) if os.path.exists(f'{d}/meta.json') else {}
+                self.infos.append({'name': f'{dstname}_{i:03d}', 'hr': f'{d}/gt.npy', 'lr': lr,
+                                   'wb': np.asarray(meta.get('wb', [1, 1, 1, 1]), np.float32),
+                                   'ccm': np.asarray(meta.get('ccm', np.eye(3)), np.float32),
+                                   'ExposureTime': float(meta.get('ExposureTime', 0.0))})
+        self.length = len(self.infos)
+        self.bl, self.wp = _levels(self.args['root_dir'], self.args)
+        self.H, self.W = self.args['H'], self.args['W']
+        if self.infos:
+            self.H, self.W = np.load(_npy_path(self.infos[0]['lr']), mmap_mode='r').shape
+
+    def __getitem__(self, idx):
+        info = self.infos[idx]
+        hr_raw = np.load(_npy_path(info['hr'])).reshape(self.H, self.W)
+        lr_raw = np.load(_npy_path(info['lr'])).reshape(self.H, self.W)
+        data = {'hr': ((hr_raw.astype(np.float32) - self.bl) / (self.wp - self.bl)).astype(np.float32),
+                'lr': ((lr_raw.astype(np.float32) - self.bl) * self.ratio / (self.wp - self.bl)).astype(np.float32),
+                'name': f"{info['name']}_x{self.ratio:02d}", 'ratio': self.ratio, 'ccm': info['ccm'], 'wb': info['wb'], 'cfa': 'rggb',
+                'ISO': self.iso, 'ExposureTime': info['ExposureTime'] * 1000, 'meta': None}
+        if self.args['clip']:
+            data['hr'], data['lr'] = data['hr'].clip(0, 1), data['lr'].clip(0, 1)
+        return data
+
+
+class Any_Dataset:
+    """README.md:38-47 'YOND_any': any directory of Bayer frames.  <root_dir>/*.npy (raw DN as the camera wrote them; a
+    matching <root_dir>/gt/<same name>.npy is used as the reference frame when present); black / white level, ratio and clip
+    from the runfile's dst section.  Items: 'lr' = (raw - bl) * ratio / (wp - bl), 'name', 'ratio'."""
+
+    def __init__(self, args=None):
+        self.args = {'root_dir': 'frames/', 'wp': 1023, 'bl': 64, 'clip': False, 'mode': 'eval', 'dstname': 'ANY'}
+        self.args.update(args or {})
+        self.bl, self.wp = _levels(self.args['root_dir'], self.args)
+        self.files = sorted(glob.glob(os.path.join(self.args['root_dir'], '*.npy')))
+        self.change_eval_ratio(1)
+
+    def __len__(self):
+        return len(self.files)
+
+    def change_eval_ratio(self, ratio):
+        self.ratio = ratio
+
+    def __getitem__(self, idx):
+        f = self.files[idx]
+        raw = np.load(f).astype(np.float32)
+        data = {'lr': ((raw - self.bl) * self.ratio / (self.wp - self.bl)).astype(np.float32),
+                'name': f"{os.path.splitext(os.path.basename(f))[0]}_x{self.ratio:02d}", 'ratio': self.ratio, 'cfa': 'rggb', 'meta': None}
+        g = os.path.join(self.args['root_dir'], 'gt', os.path.basename(f))
+        if os.path.exists(g):
+            data['hr'] = ((np.load(g).astype(np.float32) - self.bl) / (self.wp - self.bl)).astype(np.float32)
+        if self.args['clip']:
+            data['lr'] = data['lr'].clip(0, 1)
+            if 'hr' in data:
+                data['hr'] = data['hr'].clip(0, 1)
+        return data

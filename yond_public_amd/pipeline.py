@@ -251,8 +251,19 @@ def get_bias(img=None, sigGs=25.853043, K=24.48128, device=None):
     y_dev = torch.empty(len(lams), dtype=torch.float32, device=dev)
     if len(lams) > 4096:
         raise L.YondHipError(f"bias LUT with {len(lams)} knots exceeds the kernel's 4096-knot LDS table")
-    L.check(L.load().yond_bias_lut_f64(L.ptr(x_dev), len(lams), float(K), float(sigGs), L.ptr(y_dev), L.stream()),
-            "yond_bias_lut_f64")
+    lib = L.load()
+    rc = lib.yond_bias_lut_f64(L.ptr(x_dev), len(lams), float(K), float(sigGs), L.ptr(y_dev), L.stream())
+    if rc == -2:
+        # large K * sigma (14-bit frames at a digital gain): the integration tables exceed the LDS -- the same kernel with its
+        # Gaussian table in a global scratch buffer, 256 workgroups striding over the knots (seconds instead of microseconds)
+        nwg = 256
+        need = int(lib.yond_bias_lut_big_scratch(float(K), float(sigGs), nwg))
+        if need == 0 or need * 8 > 8 << 30:
+            raise L.YondHipError(f"get_bias(K={float(K):.4g}, sigma={float(sigGs):.4g}): the integration grid is out of this build's range")
+        scratch = torch.empty(need, dtype=torch.float64, device=dev)
+        rc = lib.yond_bias_lut_big_f64(L.ptr(x_dev), len(lams), float(K), float(sigGs), L.ptr(y_dev), L.ptr(scratch), need, nwg, L.stream())
+        torch.cuda.current_stream().synchronize()            # (the scratch buffer must outlive the kernel)
+    L.check(rc, "yond_bias_lut_f64")
     return DeviceBiasLUT(lams, x_dev, y_dev)
 
 
@@ -701,7 +712,7 @@ def _chain_round(lr, hr, mode, net, arch, pipe, p, slot, lr_max_dev=None, vst_ty
     k = pipe.get('k', 29)
     H, W = lr.shape
     h, w = H // 2, W // 2
-    scale = float(p['wp'] - p['bl'])
+    scale_est, scale = float(p['wp'] - p['bl']), float(p['scale'])       # :356 / :251 (equal for ratio 1)
     buf = _chain_buffers(lr.device, slot)
     st = L.stream()
     setting = {'mode': mode}
@@ -718,7 +729,7 @@ def _chain_round(lr, hr, mode, net, arch, pipe, p, slot, lr_max_dev=None, vst_ty
     with _stage("frame_params_lut"):
         # (round 2 reads the frame maximum round 1's estimator collected: the collab kernels read the same noisy frame)
         L.check(lib.yond_frame_params_f64(L.ptr(ws), L.ptr(lr_max_dev) if lr_max_dev is not None else None, 0 if mode == 'self' else 1,
-                                          scale, 1.03, LUT_CAP, L.ptr(buf.prm), L.ptr(buf.t), L.ptr(buf.lut_x), st), "yond_frame_params_f64")
+                                          scale_est, scale, 1.03, LUT_CAP, L.ptr(buf.prm), L.ptr(buf.t), L.ptr(buf.lut_x), st), "yond_frame_params_f64")
         L.check(lib.yond_bias_lut_dev_f64(L.ptr(buf.lut_x), LUT_CAP, L.ptr(buf.prm), L.ptr(buf.lut_y), st), "yond_bias_lut_dev_f64")
         L.check(lib.yond_lut_table_f64(L.ptr(buf.lut_x), L.ptr(buf.lut_y), -1, L.ptr(buf.prm), L.ptr(buf.lut_ws), st), "yond_lut_table_f64")
     p2d = get_p2d((1, 4, h, w), base=32)

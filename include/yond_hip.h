@@ -406,6 +406,21 @@ int yond_pack_vst_norm_dev_f32(const float* bayer, int H, int W, float* out, int
 int yond_denorm_ivst_unpack_dev_f32(const float* net_out, int Hp, int Wp, int pad_t, int pad_l, int h, int w, float* bayer,
                                     int mode, double scale, const double* prm, int clip01, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N4, first slice: what one training step needs beyond the forward kernels (trainer_AWGN.py:101-117, losses/base_loss.py:81-113,
+ * torch.optim.Adam).  Data gradients run on yond_conv2d_f32 with re-indexed weights (yond_public_amd/train.py).
+ * yond_conv_wgrad_f32: dw[tap][Cout][Cin] = sum_p dy[p_out][Cout] x[p_in(p_out, tap)][Cin] on the fp32 MFMA (Cin, Cout
+ *   multiples of 32, NHWC); mode 0: 3x3 pad 1 (stride 1 / 2: Ho = ceil(H / stride)), 1: ConvTranspose2d 2x2 stride 2
+ *   (Ho = 2H; taps dy*2+dx), 2: 1x1.
+ * yond_colsum_f32: db[c] = sum_p dy[p][c].   yond_l1_loss_f32: loss_sum = sum |pred - target|, grad = sign(.) / n.
+ * yond_adam_step_f32: torch.optim.Adam's single-tensor update (no weight decay / amsgrad), step = 1, 2, ... */
+int yond_conv_wgrad_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode,
+                        int stride, float* dw, void* stream);
+int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, void* stream);
+int yond_l1_loss_f32(const float* pred, const float* target, size_t n, double* loss_sum, float* grad /* or NULL */, void* stream);
+int yond_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps,
+                       int step, void* stream);
+
 /* Measurement aid (bench.py; not on the reference's path): one wave sleeps for `us` microseconds (<= 5 s) of wall time and
  * writes out[0] = elapsed shader cycles (s_memtime), out[1] = elapsed 100 MHz reference ticks (s_memrealtime): the clock
  * the chip holds under the load running beside it = out[0] / out[1] * 100 MHz. */

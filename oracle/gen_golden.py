@@ -326,6 +326,49 @@ def gen_iter_full(ref):
     save("iter_full", **out)
 
 
+def train_case():
+    """Inputs of the training-step fixture (regenerated from seeds by the tests): a batch of two 4 x 64 x 64 patches."""
+    g = torch.Generator().manual_seed(2024)
+    hr = torch.rand((2, 4, 64, 64), generator=g) * 0.8 + 0.05
+    sigma = torch.tensor([0.04, 0.11]).view(-1, 1, 1, 1)
+    lr = (hr + torch.randn((2, 4, 64, 64), generator=g) * sigma).clamp(0, 1)
+    arch = ARCHS["gru8"]
+    return lr, hr, sigma, arch, O.procedural_state_dict(arch, 17), 1e-3
+
+
+def grad_sample(name, t):
+    """What the fixture keeps of a tensor: everything up to 4096 elements, else a strided sample of 4096."""
+    a = np.asarray(t, np.float32).reshape(-1)
+    return a if a.size <= 4096 else a[::a.size // 4096][:4096]
+
+
+def gen_train(ref):
+    """N4: ONE step of the reference's training loop (trainer_AWGN.py:101-117: pred = net(lr, sigma); loss = Unet_Loss()(pred, hr);
+    loss.backward(); Adam(lr).step()) on GuidedResUnet nf = 8 with the procedural weights: loss, every parameter's gradient
+    (checksums + samples) and the updated weights."""
+    from torch.optim import Adam
+    lr_img, hr_img, sigma, arch, sd, step = train_case()
+    net = getattr(ref, arch['name'])(dict(arch))
+    net = ref.load_weights(net, sd, by_name=False).train()
+    loss_fn = ref.Unet_Loss()
+    opt = Adam(net.parameters(), lr=step)
+    opt.zero_grad()
+    pred = net(lr_img, sigma)
+    loss = loss_fn(pred, hr_img)
+    loss.backward()
+    out = {"loss": np.array(float(loss)), "pred_chk": checks(pred.detach().numpy()), "pred_sample": grad_sample("pred", pred.detach().numpy())}
+    for k, p in net.named_parameters():
+        g = p.grad.detach().numpy()
+        out[f"g_chk/{k}"] = checks(g)
+        out[f"g/{k}"] = grad_sample(k, g)
+    opt.step()
+    for k, p in net.named_parameters():
+        out[f"w_chk/{k}"] = checks(p.detach().numpy())
+        out[f"w/{k}"] = grad_sample(k, p.detach().numpy())
+    print(f"train step: loss {float(loss):.6f}, {sum(p.numel() for p in net.parameters())} parameters")
+    save("train", **out)
+
+
 def small_bias_grids():
     """A reduced (x, sigma) grid with the structure of the shipped one (linear head + log tail; utils/isp_algos.py:168-177)."""
     x_lut = np.concatenate((np.linspace(0, 2 ** -4, 4, endpoint=False), np.exp(np.linspace(np.log(2 ** -4), np.log(2 ** 10), 57))))
@@ -431,7 +474,7 @@ def gen_rot(ref):
 
 GENS = dict(rot=gen_rot, pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
             vst_denoiser=gen_vst_denoiser, iter=gen_iter, biaslut=gen_biaslut, ssim=gen_ssim, nle_full=gen_nle_full,
-            iter_full=gen_iter_full)
+            iter_full=gen_iter_full, train=gen_train)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

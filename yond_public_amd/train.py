@@ -1,0 +1,256 @@
+"""N4, first slice: one training step of the AWGN raw denoiser on the MI355X kernels.
+
+    trainer_AWGN.py:101-117      pred = net(imgs_lr, sigma); loss = Unet_Loss()(pred, imgs_hr); loss.backward(); optimizer.step()
+    losses/base_loss.py:81-113   Unet_Loss = F.l1_loss
+    trainer_AWGN.py:36           Adam(net.parameters(), lr)
+
+`TrainStep` runs GuidedResUnet's forward (archs/Unet.py:424-470) on NHWC float32 device tensors whose channels are padded
+to multiples of 32, with every convolution -- forward, data gradient and weight gradient -- on the HIP kernels:
+  * forward / data gradient: yond_conv2d_f32, algo 0 (fp32-input MFMA, bit-exact fmaf chains).  A data gradient is a
+    convolution with re-indexed weights: 3x3 stride 1 -> 3x3 with the taps flipped and (in, out) transposed; 3x3 stride 2 ->
+    the same on the zero-interleaved gradient; ConvTranspose2d 2x2 -> a 1x1 GEMM on the pixel-unshuffled gradient; 1x1 -> W^T;
+  * weight / bias gradient: yond_conv_wgrad_f32 (fp32 MFMA outer products over the pixel axis), yond_colsum_f32;
+  * loss and optimiser: yond_l1_loss_f32, yond_adam_step_f32.
+torch.autograd only strings the layers together (custom Functions) and differentiates the elementwise glue (SiLU, LeakyReLU,
+FiLM scale / shift and its three tiny sigma-MLPs, residual adds), which is <0.1 % of the step's arithmetic.
+Scope of the slice: GuidedResUnet / fp32 / one GPU; weights are re-packed on the host every step (fine at nf = 8 ... 32; a
+production loop would keep packed weights resident); DDP's gradient all-reduce (trainer_base.py:117-125) is not wired yet.
+Pinned by tests/golden/train.npz: loss, gradients and updated weights of the reference's own step on the same inputs."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from .engine import DenoiserPlan, _PackedConv, _rup
+
+
+def _plan(dev):
+    plan = DenoiserPlan.__new__(DenoiserPlan)
+    plan.lib, plan.dev = L.load(), torch.device(dev)
+    return plan
+
+
+def _pad_c(x, cp):
+    """[N][H][W][C] -> channels zero-padded to cp."""
+    return x if x.shape[-1] == cp else F.pad(x, (0, cp - x.shape[-1]))
+
+
+def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False):
+    pc = _PackedConv(plan.dev, w.detach().cpu(), None if b is None else b.detach().cpu(), ksize, stride, splits, shuffle=shuffle)
+    if shuffle:
+        out = torch.empty((N, 2 * H, 2 * W, pc.cout_real_p), dtype=torch.float32, device=plan.dev)
+    elif stride == 2:
+        out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, pc.coutp), dtype=torch.float32, device=plan.dev)
+    else:
+        out = torch.empty((N, H, W, pc.coutp), dtype=torch.float32, device=plan.dev)
+    plan._conv(pc, srcs[0], srcs[1] if len(srcs) > 1 else None, N, H, W, out, algo=0)
+    return out
+
+
+def _wgrad(plan, x, dy, mode, stride, taps):
+    """[taps][Cout_p][Cin_p] float32 (x, dy: padded NHWC)."""
+    N, H, W, ci = x.shape
+    _, Ho, Wo, co = dy.shape
+    dw = torch.empty((taps, co, ci), dtype=torch.float32, device=x.device)
+    L.check(plan.lib.yond_conv_wgrad_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, Ho, Wo, co, mode, stride, L.ptr(dw), L.stream()),
+            "yond_conv_wgrad_f32")
+    return dw
+
+
+def _colsum(plan, dy):
+    c = dy.shape[-1]
+    db = torch.empty(c, dtype=torch.float32, device=dy.device)
+    L.check(plan.lib.yond_colsum_f32(L.ptr(dy), dy.numel() // c, c, L.ptr(db), L.stream()), "yond_colsum_f32")
+    return db
+
+
+class _Conv3x3(torch.autograd.Function):
+    """nn.Conv2d(cin, cout, 3, stride, 1): x [N][H][W][cin_p] -> [N][Ho][Wo][cout_p]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, plan, stride, need_dx):
+        N, H, W, _ = x.shape
+        cout, cin = w.shape[0], w.shape[1]
+        x = x.contiguous()
+        y = _conv_fwd(plan, w, b, 3, stride, [cin], [x], N, H, W)
+        ctx.save_for_backward(x, w)
+        ctx.plan, ctx.stride, ctx.need_dx = plan, stride, need_dx
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        plan, stride = ctx.plan, ctx.stride
+        dy = dy.contiguous()
+        N, H, W, cin_p = x.shape
+        cout, cin = w.shape[0], w.shape[1]
+        dw = _wgrad(plan, x, dy, 0, stride, 9)[:, :cout, :cin].permute(1, 2, 0).reshape(cout, cin, 3, 3)
+        db = _colsum(plan, dy)[:cout]
+        dx = None
+        if ctx.need_dx:
+            g = dy
+            if stride == 2:                            # zero-interleave: the stride-2 layer's adjoint = a stride-1 one on this
+                g = torch.zeros((N, H, W, dy.shape[-1]), dtype=torch.float32, device=dy.device)
+                g[:, ::2, ::2] = dy
+            wt = w.detach().flip(2, 3).transpose(0, 1).contiguous()            # [cin][cout][2-ky][2-kx]
+            dx = _conv_fwd(plan, wt, None, 3, 1, [cout], [g], N, H, W)
+            dx = _pad_c(dx[..., :cin], cin_p) if dx.shape[-1] != cin_p else dx
+        return dx, dw, db, None, None, None
+
+
+class _Conv1x1(torch.autograd.Function):
+    """nn.Conv2d(c0 + c1, cout, 1) over the channel concatenation of one or two tensors (torch.cat is not materialised)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, w, b, plan):
+        N, H, W, _ = x0.shape
+        srcs = [x0.contiguous()] + ([x1.contiguous()] if x1 is not None else [])
+        splits = [w.shape[1]] if x1 is None else list(ctx_splits(w, x0, x1))
+        y = _conv_fwd(plan, w, b, 1, 1, splits, srcs, N, H, W)
+        ctx.save_for_backward(*srcs, w)
+        ctx.plan, ctx.splits, ctx.two = plan, splits, x1 is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        *srcs, w = ctx.saved_tensors
+        plan, splits = ctx.plan, ctx.splits
+        dy = dy.contiguous()
+        N, H, W, _ = dy.shape
+        cout = w.shape[0]
+        w2 = w.detach()[:, :, 0, 0]
+        dws, dxs, off = [], [], 0
+        for x, s in zip(srcs, splits):
+            dws.append(_wgrad(plan, x, dy, 2, 1, 1)[0, :cout, :s])
+            wt = w2[:, off:off + s].t().contiguous()[:, :, None, None]        # [s][cout][1][1]
+            dx = _conv_fwd(plan, wt, None, 1, 1, [cout], [dy], N, H, W)
+            dxs.append(dx if dx.shape[-1] == x.shape[-1] else _pad_c(dx[..., :s], x.shape[-1]))
+            off += s
+        dw = torch.cat(dws, 1)[:, :, None, None]
+        db = _colsum(plan, dy)[:cout]
+        return dxs[0], (dxs[1] if ctx.two else None), dw, db, None
+
+
+def ctx_splits(w, x0, x1):
+    """Real channel counts of the two sources of a two-source 1x1 layer: GuidedResUnet's decoder concatenates `up` (c) and the
+    skip tensor (c) into 2c channels (archs/Unet.py:447-461)."""
+    c = w.shape[1] // 2
+    return c, w.shape[1] - c
+
+
+class _ConvT2x2(torch.autograd.Function):
+    """nn.ConvTranspose2d(cin, cout, 2, stride=2): x [N][H][W][cin_p] -> [N][2H][2W][cout_p]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, plan):
+        N, H, W, _ = x.shape
+        x = x.contiguous()
+        y = _conv_fwd(plan, w, b, 1, 1, [w.shape[0]], [x], N, H, W, shuffle=True)
+        ctx.save_for_backward(x, w)
+        ctx.plan = plan
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        plan = ctx.plan
+        dy = dy.contiguous()
+        N, H, W, cin_p = x.shape
+        cin, cout = w.shape[0], w.shape[1]
+        cop = dy.shape[-1]
+        dw = _wgrad(plan, x, dy, 1, 2, 4)[:, :cout, :cin].permute(2, 1, 0).reshape(cin, cout, 2, 2)     # [tap][co][ci] -> [ci][co][dy][dx]
+        db = _colsum(plan, dy)[:cout]
+        # adjoint: dx[y][x][ci] = sum_{dy,dx,co} g[2y+dy][2x+dx][co] W[ci][co][dy][dx] = a 1x1 GEMM on the pixel-unshuffled gradient
+        gu = dy.reshape(N, H, 2, W, 2, cop).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, 4 * cop).contiguous()
+        m = torch.zeros((cin, 4, cop), dtype=torch.float32, device=w.device)
+        m[:, :, :cout] = w.detach().permute(0, 2, 3, 1).reshape(cin, 4, cout)
+        dx = _conv_fwd(plan, m.reshape(cin, 4 * cop, 1, 1), None, 1, 1, [4 * cop], [gu], N, H, W)
+        dx = dx if dx.shape[-1] == cin_p else _pad_c(dx[..., :cin], cin_p)
+        return dx, dw, db, None
+
+
+class TrainStep:
+    """One optimisation step of a yond_public_amd.archs.GuidedResUnet (parameter names / shapes of the reference)."""
+
+    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.m = module
+        self.dev = next(module.parameters()).device
+        self.plan = _plan(self.dev)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.params = dict(module.named_parameters())
+        self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in self.params.items()}
+        self.t = 0
+
+    # -- forward on padded NHWC tensors ------------------------------------------------------------------------------
+    def _block(self, pre, x, xs, t, cp):
+        P = self.params
+        if xs is not None:                                   # decoder: short_cut = 1x1 over cat(up, skip)
+            x = _Conv1x1.apply(x, xs, P[pre + '.short_cut.0.weight'], P[pre + '.short_cut.0.bias'], self.plan)
+        c = P[pre + '.conv1.weight'].shape[0]
+        # gamma / beta: 1x1 convolutions on a (B, 1, 1, 1) tensor = three tiny linear layers (archs/modules.py:170-178)
+        w1, b1 = P[pre + '.gamma.0.weight'][:, 0, 0, 0], P[pre + '.gamma.0.bias']
+        w2, b2 = P[pre + '.gamma.2.weight'][:, :, 0, 0], P[pre + '.gamma.2.bias']
+        w3, b3 = P[pre + '.beta.1.weight'][:, :, 0, 0], P[pre + '.beta.1.bias']
+        h = F.silu(t[:, None] * w1[None] + b1[None])                              # [B][C]
+        tk = (h[:, None, :] * w2[None]).sum(-1) + b2[None]
+        tb = (F.silu(tk)[:, None, :] * w3[None]).sum(-1) + b3[None]
+        tk, tb = _pad_c(tk, cp)[:, None, None, :], _pad_c(tb, cp)[:, None, None, :]
+        z = F.silu(x)
+        z = _Conv3x3.apply(z, P[pre + '.conv1.weight'], P[pre + '.conv1.bias'], self.plan, 1, True)
+        z = F.silu(z * tk + tb)
+        z = _Conv3x3.apply(z, P[pre + '.conv2.weight'], P[pre + '.conv2.bias'], self.plan, 1, True)
+        return z + x
+
+    def forward(self, x_nchw, sigma):
+        m, P = self.m, self.params
+        x = x_nchw.permute(0, 2, 3, 1).contiguous()
+        B = x.shape[0]
+        t = sigma.reshape(B).to(torch.float32)
+        ub = None
+        if m.norm:                                           # data_normalize: the per-image maximum is a constant (modules.py:16-20)
+            ub = x.reshape(B, -1).max(1).values.detach()
+            x = x / ub[:, None, None, None]
+            t = t / ub
+        nf = P['conv_in.weight'].shape[0]
+        a = _Conv3x3.apply(_pad_c(x, 32), P['conv_in.weight'], P['conv_in.bias'], self.plan, 1, False)
+        cur = F.leaky_relu(a, 0.01)
+        skips = {}
+        for i in range(1, 5):
+            cp = _rup(nf * 2 ** (i - 1))
+            cur = self._block(f'conv{i}', cur, None, t, cp)
+            skips[i] = cur
+            cur = _Conv3x3.apply(cur, P[f'pool{i}.conv.weight'], P[f'pool{i}.conv.bias'], self.plan, 2, True)
+        cur = self._block('conv5', cur, None, t, _rup(nf * 16))
+        for i in range(6, 10):
+            up = _ConvT2x2.apply(cur, P[f'upv{i}.weight'], P[f'upv{i}.bias'], self.plan)
+            cur = self._block(f'conv{i}', up, skips[10 - i], t, _rup(nf * 2 ** (9 - i)))
+        out = _Conv1x1.apply(cur, None, P['conv10.weight'], P['conv10.bias'], self.plan)[..., :4]
+        if m.res:
+            out = out + x[..., :4]
+        if m.norm:
+            out = out * ub[:, None, None, None]
+        return out.permute(0, 3, 1, 2)
+
+    # -- loss, backward, Adam ----------------------------------------------------------------------------------------
+    def step(self, imgs_lr, imgs_hr, sigma):
+        """trainer_AWGN.py:101-117 for one batch.  Returns (loss, {name: gradient})."""
+        lib = self.plan.lib
+        for p in self.params.values():
+            p.grad = None
+        pred = self.forward(imgs_lr, sigma).contiguous()
+        tgt = imgs_hr.contiguous()
+        loss_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        dpred = torch.empty_like(pred)
+        L.check(lib.yond_l1_loss_f32(L.ptr(pred), L.ptr(tgt), pred.numel(), L.ptr(loss_sum), L.ptr(dpred), L.stream()), "yond_l1_loss_f32")
+        pred.backward(dpred)
+        self.t += 1
+        grads = {}
+        for k, p in self.params.items():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            g = g.contiguous()
+            grads[k] = g
+            mstate, vstate = self.state[k]
+            L.check(lib.yond_adam_step_f32(L.ptr(p.data), L.ptr(g), L.ptr(mstate), L.ptr(vstate), p.numel(), self.lr, self.betas[0],
+                                           self.betas[1], self.eps, self.t, L.stream()), "yond_adam_step_f32")
+        self.m._plan = None                                  # the inference plan's packed weights are stale now
+        return float(loss_sum.item()) / pred.numel(), grads

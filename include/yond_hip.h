@@ -267,15 +267,8 @@ int yond_box_stats_self2_f32(const float* blur2, int h, int w, int k, int tile_w
 int yond_box_stats_collab_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,
                               float* mean, float* var, float* lap, void* stream);
 
-/* K5' the same maps in ONE pass over the frame(s) -- the B19 map of the self mode never leaves the chip -- together with
- * sweep 1 of the threshold selection (see yond_nle_stats_f32 below: level-1 histogram of lap, per-mean-bin minimum of lap,
- * resolve of the percentile ranks) and the frame maximum (lr.max() for the bias LUT grid, YOND_SIDD.py:256/393; in the
- * workspace head as an order-preserving key).  Replaces yond_box_stats_self1/self2 (or _collab) + yond_nle_stats_f32 on
- * the hot path; continue with yond_nle_threshold_f32(lap, ...) on the same workspace.  k <= 29, k2 <= k. */
-int yond_box_stats_self_fused_f32(const float* bayer, int H, int W, int k, int k2, int tile_w, float* mean, float* var,
-                                  float* lap, const double* q_host, int nq, void* ws, void* stream);
-int yond_box_stats_collab_fused_f32(const float* bayer_lr, const float* bayer_hr, int H, int W, int k, int tile_w,
-                                    float* mean, float* var, float* lap, const double* q_host, int nq, void* ws, void* stream);
+/* (K5' -- the same maps in ONE pass, the B19 map never leaving the chip -- measured slower than K5 + sweep 1 and is built only
+ * into experiment libraries: include/yond_hip_experiments.h, `python -m yond_public_amd.build --experiments`.) */
 
 /* K5+ the hot-path producers of the estimator, one call per frame: the streaming kernels of K5 (stage 1 of the self mode also
  * collects the frame maximum into the workspace head) followed by sweep 1 of the threshold selection (yond_nle_stats_f32
@@ -303,7 +296,7 @@ int yond_percentiles_f32(const float* data, size_t n, const double* q_host, int 
  * yond_nlf_score3_f64 on the hot path.  `ws`: device workspace of yond_nle_ws_bytes(n) bytes, 16-byte aligned.
  *   yond_nle_stats_f32      sweep 1 over (lap, mean) (n elements as rows of `width`): level-1 histogram of lap and, per
  *                           1/1000 mean bin, the smallest lap (a bin is occupied among lap <= T iff its smallest lap <= T);
- *                           resets the workspace first.  (The fused box kernel yond_box_stats_self_fused_f32 does the same
+ *                           resets the workspace first.  (The experimental one-pass box kernel does the same
  *                           while it produces the maps.)
  *   yond_nle_threshold_f32  sweep 2 over lap + finish: the exact order statistics, np.percentile(lap, q, 'linear') ->
  *                           ths; with want_score: npeaks[i], score = ths / (q * npeaks), i* = argmin(score[1:]) + 1 -> sel.
@@ -391,6 +384,13 @@ int yond_frame_params_f64(const void* nle_ws, const float* max_dev, int mode,
  * yond_bias_lut_f64 returns YOND_EUNSUPPORTED): the same integration with the table in a caller-provided scratch buffer of
  * yond_bias_lut_big_scratch(gain, sigma, nwg) doubles, nwg workgroups striding over the knots.  Seconds, not microseconds. */
 size_t yond_bias_lut_big_scratch(double gain, double sigma, int nwg);
+/* get_bias_points (utils/isp_algos.py:142-160; BiasLUT.get_lut's pointwise branch :210-212 calls it with pho_min = 100,
+ * close_form = True): the integration at ARBITRARY abscissae lams[n], sampling rate max(int(sqrt K), pho_min), Foi's closed
+ * form above th only with close_form (else every point is integrated; pass lam_max = max(lams)).  Output float32 (bias32)
+ * or float64 (bias64), scratch of yond_bias_points_scratch(...) doubles. */
+size_t yond_bias_points_scratch(double gain, double sigma, int pho_min, int close_form, double lam_max, int nwg);
+int yond_bias_points_f64(const double* lams, int n, double gain, double sigma, int pho_min, int close_form, double lam_max,
+                         float* bias32, double* bias64, double* scratch, size_t scratch_doubles, int nwg, void* stream);
 int yond_bias_lut_big_f64(const double* lams, int n, double gain, double sigma, float* bias, double* scratch,
                           size_t scratch_doubles, int nwg, void* stream);
 /* Row H with (n, K, sigma) read from the block: launches lut_cap workgroups, those beyond prm[LUT_N] exit. */

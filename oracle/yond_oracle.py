@@ -423,11 +423,13 @@ class BiasLUT:
         weight_r = pos - l
         return data[..., l] * (1 - weight_r) + data[..., r] * weight_r
 
-    def get_lut(self, x, K=1, sigGs=2):                               # :196-231, func=False
+    def get_lut(self, x, K=1, sigGs=2, func=False):                   # :196-231
         xe, sg = x / K, sigGs / K
         sg_pos = self.pos_interp(self.sg_lut, sg)
         sg_len, x_len = len(self.sg_lut), len(self.x_lut)
         if sg_pos >= sg_len:                                          # :204-212: outside the table
+            if func:
+                return BiasFunc(*get_bias_table(x.max(), sigGs, K))   # :205-206
             if x.size > 1000:
                 return BiasFunc(*get_bias_table(x.max(), sigGs, K))(x)
             return get_bias_points(x.reshape(-1), K, sigGs, close_form=True).reshape(*x.shape)
@@ -832,7 +834,10 @@ def IterDenoise(lr_raw, arch, sd, pipe, lr_full=None, p=None):
             out[num] = Simple_Denoiser(blocks[num], arch, sd)                     # :369-370
         return dict(raw_dns=[np.concatenate(out, axis=-1)], regs=(0, 0), params=[])
     raw4est = lr_cat if lr_full is None else lr_full                              # :340
-    reg = SimpleNLF(raw4est, k=k, setting={'mode': 'self'})                       # :341
+    if 'manual' in str(pipe.get('est_type', 'simple')):                           # :349-351
+        reg = (14 / (p['wp'] - p['bl']), (20 / (p['wp'] - p['bl'])) ** 2)
+    else:
+        reg = SimpleNLF(raw4est, k=k, setting={'mode': 'self'})                   # :341
     p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale       # :356
     regs.append(reg)
     params.append((p['gain'], p['sigma']))

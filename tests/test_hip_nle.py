@@ -319,6 +319,8 @@ def test_fused_box_statistics_self(H, W, tile_w):
     """K5' (nle_fused.hip): one pass -> mean, var, lap (the B19 map never leaves the chip) + the level-1 statistics of
     the threshold selection + the frame maximum.  Maps against the oracle (<= 1 ulp) and BIT-identical to the
     stand-alone kernels; the selection state against the stand-alone sweep."""
+    if not __import__("yond_public_amd._lib", fromlist=["has"]).has("yond_box_stats_self_fused_f32"):
+        pytest.skip("the one-pass kernels exist only in experiment builds (python -m yond_public_amd.build --experiments)")
     import yond_oracle as O
     from yond_public_amd import _lib as L
     from yond_public_amd import pipeline as P
@@ -353,6 +355,8 @@ def test_fused_box_statistics_self(H, W, tile_w):
 
 
 def test_fused_box_statistics_collab():
+    if not __import__("yond_public_amd._lib", fromlist=["has"]).has("yond_box_stats_self_fused_f32"):
+        pytest.skip("the one-pass kernels exist only in experiment builds (python -m yond_public_amd.build --experiments)")
     import ctypes as C
     import yond_oracle as O
     from yond_public_amd import _lib as L
@@ -454,7 +458,8 @@ def test_simple_nlf_fused_equals_unfused_full_frame():
     t = torch.from_numpy(noisy).to(DEV)
     ra, ia = P.SimpleNLF(t, k=29, setting={'mode': 'self'}, full=True)
     rb, ib = P.SimpleNLF(t, k=29, setting={'mode': 'self'}, full=True, box='plain')
-    for box in ('one-pass', 'plain'):
+    from yond_public_amd import _lib as _L
+    for box in (('one-pass', 'plain') if _L.has("yond_box_stats_self_fused_f32") else ('plain',)):
         rb, ib = P.SimpleNLF(t, k=29, setting={'mode': 'self'}, full=True, box=box)
         assert ia['th'] == ib['th'] and ia['percent'] == ib['percent'] and ia['nsel'] == ib['nsel'], box
         np.testing.assert_array_equal(ia['npeaks'], ib['npeaks'])

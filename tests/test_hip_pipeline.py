@@ -89,10 +89,11 @@ def test_device_chain_equals_host_chain():
             P.DEVICE_CHAIN = True
         assert len(res_d['raw_dns']) == len(res_h['raw_dns'])
         for rd, rh in zip(res_d['regs'], res_h['regs']):
-            np.testing.assert_allclose(rd[0], rh[0], rtol=1e-13)
-            np.testing.assert_allclose(rd[1], rh[1], rtol=1e-13, atol=1e-20)
+            # (the moment sums are float64 atomics: their order, and with it the last bits of the fit, differs from run to run)
+            np.testing.assert_allclose(rd[0], rh[0], rtol=1e-11)
+            np.testing.assert_allclose(rd[1], rh[1], rtol=1e-10, atol=1e-20)
         for pd_, ph in zip(res_d['params'], res_h['params']):
-            np.testing.assert_allclose(pd_, ph, rtol=1e-13)
+            np.testing.assert_allclose(pd_, ph, rtol=1e-10)
         for it, (a, b) in enumerate(zip(res_d['raw_dns'], res_h['raw_dns'])):
             assert report(f"device chain vs host chain {H}x{W} round {it}", a.cpu().numpy(), b.cpu().numpy()) <= 2e-7
         # knot grid and ordinates of each round that ran: the reference's own np.linspace calls / the host-launched LUT kernel

@@ -202,3 +202,59 @@ def test_bias_lut_large_gain_sigma_fallback():
     err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
     print(f"[parity] large-table bias LUT (K=80, sigma=300): {len(got)} knots, max |delta| = {err:.3e}, |bias| <= {np.abs(want).max():.3e}")
     assert err <= 2e-7 * max(1.0, float(np.abs(want).max()))
+
+
+def test_get_bias_points_and_biaslut_leftovers(golden):
+    """utils/isp_algos.py:142-160 get_bias_points (pho_min = 100) on the device against the oracle's restatement, and the two
+    branches of BiasLUT.get_lut that use it / were missing: <= 1000 points with sigma outside the table (:211-212) and
+    func=True (:205-206, :216-219)."""
+    import yond_oracle as O
+    from yond_public_amd import pipeline as P
+    g = golden("biaslut")
+    x_lut, sg_lut, table = g["x_lut"], g["sg_lut"], g["table"]
+    rng = np.random.default_rng(2)
+    lams = np.concatenate(([0.0, 0.3, 5.0], rng.uniform(0, 60, 9)))
+    for (K, s, cf) in ((2.0, 3.0, False), (4.0, 45.0, True)):
+        got = P.get_bias_points(lams, K, s, pho_min=100, close_form=cf, device=DEV).cpu().numpy()
+        want = O.get_bias_points(lams.copy(), K, s, pho_min=100, close_form=cf)
+        err = np.abs(got - want).max()
+        print(f"[parity] get_bias_points K={K} sigma={s} close_form={cf}: max |delta| = {err:.3e}")
+        assert err < 1e-10
+    lut_d = P.BiasLUT(table=table, x_lut=x_lut, sg_lut=sg_lut)
+    lut_o = O.BiasLUT(table, x_lut, sg_lut)
+    K, s = np.float64(2.0), np.float64(2.0 * sg_lut[-1] * 1.5)                   # sigma / K beyond the sigma grid
+    xq = rng.uniform(0, 80, (5, 7)).astype(np.float32)                           # 35 points: the pointwise branch
+    got = lut_d.get_lut(torch.from_numpy(xq).to(DEV), K=K, sigGs=s).cpu().numpy()
+    want = lut_o.get_lut(xq.copy(), K=K, sigGs=s)
+    assert got.shape == want.shape and np.abs(got.astype(np.float32) - want).max() < 1e-6     # (the reference keeps the queries' float32)
+    f_out = lut_d.get_lut(torch.from_numpy(xq).to(DEV), K=K, sigGs=s, func=True)              # outside: get_bias' interp1d object
+    f_ref = lut_o.get_lut(xq.copy(), K=K, sigGs=s, func=True)
+    np.testing.assert_array_equal(np.asarray(f_out.lams, np.float64), np.asarray(f_ref.x, np.float64))
+    assert np.abs(f_out(xq).cpu().numpy() - f_ref(xq)).max() < 1e-6
+    K2, s2 = np.float64(2.0), np.float64(2.0 * sg_lut[5])                        # inside: the row as a callable
+    f_in = lut_d.get_lut(torch.from_numpy(xq).to(DEV), K=K2, sigGs=s2, func=True)
+    np.testing.assert_allclose(f_in(xq).cpu().numpy(), lut_o.get_lut(xq.astype(np.float64), K=K2, sigGs=s2), rtol=1e-12, atol=1e-12)
+
+
+def test_manual_est_type_and_refused_est_types():
+    """YOND_SIDD.py:349-351: est_type 'manual' runs round 1 at (K, sigma) = (14, 20) DN; the est_types that read other methods'
+    estimates from files are refused loudly instead of being ignored."""
+    import yond_oracle as O
+    from hip_common import ARCHS
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    from yond_public_amd import synthetic as S
+    arch = ARCHS["gru8"]
+    net = A.GuidedResUnet(dict(arch))
+    net.load_state_dict(S.denoising_state_dict(net, 3))
+    net = net.to(DEV).eval()
+    noisy, _ = O.synth_noisy(256, 384, 14.0, 20.0, 5)
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'max_iter': 1, 'full_dn': True, 'est_type': 'manual'}
+    res = P.IterDenoise(noisy, net, arch, pipe, device=DEV)
+    assert abs(res['params'][0][0] - 14.0) < 1e-12 and abs(res['params'][0][1] - 20.0) < 1e-12
+    torch.set_num_threads(8)
+    ref = O.IterDenoise(noisy, arch, S.denoising_state_dict(net, 3), pipe)
+    assert float(np.abs(res['raw_dns'][0].cpu().numpy() - ref['raw_dns'][0]).max()) <= 1e-5
+    for bad in ('foi', 'pge+full', 'liu'):
+        with pytest.raises(NotImplementedError):
+            P.IterDenoise(noisy, net, arch, dict(pipe, est_type=bad), device=DEV)

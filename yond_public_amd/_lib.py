@@ -64,8 +64,6 @@ PROTOTYPES = {
     "yond_box_stats_self1_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "yond_box_stats_self2_f32": [vp, i32, i32, i32, i32, vp, vp],
     "yond_box_stats_collab_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp],
-    "yond_box_stats_self_fused_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
-    "yond_box_stats_collab_fused_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
     "yond_box_stats_self_stats_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp],
     "yond_box_stats_collab_stats_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
     "yond_select_ws_bytes": [i32],
@@ -90,13 +88,20 @@ PROTOTYPES = {
     "yond_frame_params_f64": [vp, vp, i32, f64, f64, f64, i32, vp, vp, vp, vp],
     "yond_bias_lut_dev_f64": [vp, i32, vp, vp, vp],
     "yond_bias_lut_big_scratch": [f64, f64, i32],
+    "yond_bias_points_scratch": [f64, f64, i32, i32, f64, i32],
+    "yond_bias_points_f64": [vp, i32, f64, f64, i32, i32, f64, vp, vp, vp, sz, i32, vp],
     "yond_bias_lut_big_f64": [vp, i32, f64, f64, vp, vp, sz, i32, vp],
     "yond_lut_ws_bytes": [i32],
     "yond_lut_table_f64": [vp, vp, i32, vp, vp, vp],
     "yond_pack_vst_norm_dev_f32": [vp, i32, i32, vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, vp],
     "yond_denorm_ivst_unpack_dev_f32": [vp, i32, i32, i32, i32, i32, i32, vp, i32, f64, vp, i32, vp],
 }
-_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes", "yond_lut_ws_bytes", "yond_bias_lut_big_scratch"}
+# experiment builds only (include/yond_hip_experiments.h): bound when the loaded library has them
+EXPERIMENT_PROTOTYPES = {
+    "yond_box_stats_self_fused_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
+    "yond_box_stats_collab_fused_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
+}
+_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes", "yond_lut_ws_bytes", "yond_bias_lut_big_scratch", "yond_bias_points_scratch"}
 
 
 class YondHipError(RuntimeError):
@@ -123,11 +128,20 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_size_t if name in _SIZE_T_RET else C.c_int
+    for name, args in EXPERIMENT_PROTOTYPES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, C.c_int
     if lib.yond_abi_version() != ABI_VERSION:
         raise YondHipError(f"{LIB_PATH} has ABI version {lib.yond_abi_version()}, this package binds version {ABI_VERSION} "
                            "(YondConvDesc layout): rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
+
+
+def has(name):
+    """True if the loaded library exports `name` (experiment entry points exist only in -DYOND_EXPERIMENTS builds)."""
+    return hasattr(load(), name)
 
 
 def check(rc, what):

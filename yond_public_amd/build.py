@@ -100,5 +100,18 @@ def build_lib(force=False, verbose=True, extra_flags=(), lib=None):
     return lib, mode
 
 
+EXP_LIB = os.path.join(HERE, "..", "tools", "probe", "libyond_exp.so")
+
+
+def build_experiments(extra=()):
+    """The experiment library (tools/probe/libyond_exp.so): -DYOND_EXPERIMENTS adds the environment switches of the launch
+    heuristics and the measured-and-dropped alternatives (one-pass NLE kernels); use it with YOND_HIP_LIB=<path>."""
+    os.makedirs(os.path.dirname(EXP_LIB), exist_ok=True)
+    return build_lib(extra_flags=["-DYOND_EXPERIMENTS"] + list(extra), lib=os.path.normpath(EXP_LIB))
+
+
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv)[1])
+    if "--experiments" in sys.argv:
+        print(build_experiments())
+    else:
+        print(build_lib(force="--force" in sys.argv)[1])

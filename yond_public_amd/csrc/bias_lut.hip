@@ -34,7 +34,8 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
 
 __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict__ lams, int n, double K, double sigma,
                                                        double th, int pho, int lmax, float* __restrict__ bias,
-                                                       double* __restrict__ prm, int smem_doubles, double* __restrict__ gbuf) {
+                                                       double* __restrict__ prm, int smem_doubles, double* __restrict__ gbuf,
+                                                       double* __restrict__ bias64 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double s_red[4];
     if (prm) {
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
             const double m1 = (y + sg * sg) / yh2;
             const double m2 = y / (yh2 * yh);
             const double m3 = (y + 3.0 * (y + sg * sg) * (y + sg * sg)) / (yh2 * yh2);
-            bias[i] = (float)(2.0 * sqrt(yh) * (-1.0 / 8.0 * m1 + 1.0 / 16.0 * m2 - 5.0 / 128.0 * m3));
+            const double cf = 2.0 * sqrt(yh) * (-1.0 / 8.0 * m1 + 1.0 / 16.0 * m2 - 5.0 / 128.0 * m3);
+            if (bias64) bias64[i] = cf; else bias[i] = (float)cf;
         }
         continue;
     }
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
     if (tid == 0) {
         // p = conv / (sum/pho);  bias = sum(p * V / pho) - VST(lam)
         const double e = spv / (sp / (double)pho) / (double)pho;
-        bias[i] = (float)(e - vst_d(lam, sigma, K));
+        if (bias64) bias64[i] = e - vst_d(lam, sigma, K); else bias[i] = (float)(e - vst_d(lam, sigma, K));
     }
     }
 }
@@ -177,31 +179,49 @@ extern "C" int yond_bias_lut_dev_f64(const double* lams, int lut_cap, double* pr
 // Large K * sigma: the Gaussian table does not fit the LDS (yond_bias_lut_f64 returns YOND_EUNSUPPORTED): the same
 // integration with the table in a global scratch buffer, `nwg` workgroups striding over the knots.
 // yond_bias_lut_big_scratch: doubles of scratch for (gain, sigma) at nwg workgroups (0: parameters out of range).
-extern "C" size_t yond_bias_lut_big_scratch(double gain, double sigma, int nwg) {
-    if (!(gain > 0.0) || !(sigma >= 0.0) || nwg <= 0) return 0;
-    int pho = (int)sqrt(gain);
+// get_bias_points (utils/isp_algos.py:142-160): the same integration for ARBITRARY abscissae, with the sampling rate
+// pho = max(int(sqrt K), pho_min) (the reference's pointwise calls use pho_min = 100) and the closed form above th only when
+// close_form is set (else every point is integrated: th = lam_max + 1).  Gaussian table in the global scratch buffer.
+static void bias_points_consts(double gain, double sigma, int pho_min, int close_form, double lam_max, int& pho, double& th, int& rmax) {
+    pho = (int)sqrt(gain);
+    if (pho < pho_min) pho = pho_min;
     if (pho < 1) pho = 1;
-    const double th = gain < 1.0 ? 50.0 * gain : 50.0 * sqrt(gain);
-    const double rmax = th * (1.0 / gain) * 2.0 + sigma * 2.0 + th + 10.0 + 1.0;
-    if (!(rmax < 1.5e4)) return 0;                                   // (a 160 KB LDS holds the Poisson masses of r <= ~2e4)
-    return (size_t)nwg * (size_t)(2 * pho * (int)rmax + 1);
+    th = close_form ? (gain < 1.0 ? 50.0 * gain : 50.0 * sqrt(gain)) : lam_max + 1.0;
+    const double top = close_form ? th : lam_max;                    // largest numerically integrated abscissa
+    rmax = (int)(top * (1.0 / gain) * 2.0 + sigma * 2.0 + top + 10.0) + 1;
+}
+
+extern "C" size_t yond_bias_points_scratch(double gain, double sigma, int pho_min, int close_form, double lam_max, int nwg) {
+    if (!(gain > 0.0) || !(sigma >= 0.0) || nwg <= 0 || pho_min < 1) return 0;
+    int pho, rmax;
+    double th;
+    bias_points_consts(gain, sigma, pho_min, close_form, lam_max, pho, th, rmax);
+    if (rmax > 15000 || (double)pho * rmax > 2.5e7) return 0;        // (LDS: the Poisson masses; scratch: 16 bytes x pho x r per workgroup)
+    return (size_t)nwg * (size_t)(2 * pho * rmax + 1);
+}
+
+extern "C" int yond_bias_points_f64(const double* lams, int n, double gain, double sigma, int pho_min, int close_form, double lam_max,
+                                    float* bias32, double* bias64, double* scratch, size_t scratch_doubles, int nwg, void* stream) {
+    if (!lams || (!bias32 && !bias64) || !scratch || n <= 0 || nwg <= 0) return YOND_EINVAL;
+    const size_t need = yond_bias_points_scratch(gain, sigma, pho_min, close_form, lam_max, nwg);
+    if (need == 0) return YOND_EUNSUPPORTED;
+    if (scratch_doubles < need) return YOND_EINVAL;
+    int pho, rmax;
+    double th;
+    bias_points_consts(gain, sigma, pho_min, close_form, lam_max, pho, th, rmax);
+    const int lmax = 2 * pho * rmax + 1;
+    if (int e = bias_lut_attr()) return e;
+    hipLaunchKernelGGL(bias_lut_kernel, dim3(nwg < n ? nwg : n), dim3(256), ((size_t)rmax + 2) * sizeof(double), (hipStream_t)stream, lams, n, gain,
+                       sigma, th, pho, lmax, bias32, (double*)nullptr, 0, scratch, bias64);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" size_t yond_bias_lut_big_scratch(double gain, double sigma, int nwg) {
+    return yond_bias_points_scratch(gain, sigma, 1, 1, 0.0, nwg);
 }
 
 extern "C" int yond_bias_lut_big_f64(const double* lams, int n, double gain, double sigma, float* bias, double* scratch,
                                      size_t scratch_doubles, int nwg, void* stream) {
-    if (!lams || !bias || !scratch || n <= 0 || nwg <= 0) return YOND_EINVAL;
-    const size_t need = yond_bias_lut_big_scratch(gain, sigma, nwg);
-    if (need == 0) return YOND_EUNSUPPORTED;
-    if (scratch_doubles < need) return YOND_EINVAL;
-    const double K = gain;
-    int pho = (int)sqrt(K);
-    if (pho < 1) pho = 1;
-    const double th = K < 1.0 ? 50.0 * K : 50.0 * sqrt(K);
-    const int rmax = (int)(th * (1.0 / K) * 2.0 + sigma * 2.0 + th + 10.0) + 1;
-    const int lmax = 2 * pho * rmax + 1;
-    if (int e = bias_lut_attr()) return e;
-    hipLaunchKernelGGL(bias_lut_kernel, dim3(nwg < n ? nwg : n), dim3(256), ((size_t)rmax + 2) * sizeof(double), (hipStream_t)stream, lams, n, K,
-                       sigma, th, pho, lmax, bias, (double*)nullptr, 0, scratch);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
+    return yond_bias_points_f64(lams, n, gain, sigma, 1, 1, 0.0, bias, nullptr, scratch, scratch_doubles, nwg, stream);
 }

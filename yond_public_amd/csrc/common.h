@@ -4,6 +4,18 @@
 #include <stdint.h>
 #include "../../include/yond_hip.h"
 
+// Experiment switches (grid sizes, tile widths of tools/ A/B runs) exist only in -DYOND_EXPERIMENTS builds
+// (python -m yond_public_amd.build --experiments): the product library reads no environment variable.
+#ifdef YOND_EXPERIMENTS
+#include <stdlib.h>
+static inline long yond_exp_long(const char* name, long dflt) {
+    const char* e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+#else
+#define yond_exp_long(name, dflt) (dflt)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

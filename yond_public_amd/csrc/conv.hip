@@ -577,14 +577,16 @@ extern "C" int yond_conv_config(int ksize, int stride, int cin, int cout, int sh
         // (1x1 / transposed layers: the 64-wide tile wherever the channel count allows -- measured faster than the 32-wide one
         // even where that fills the grid better: 2168 vs 2146 MP/s end to end)
     }
-    static const char* ekc = getenv("YOND_CONV_KC");            // experiments only
-    static const char* etn = getenv("YOND_CONV_TN");
-    static const char* es2 = getenv("YOND_S2_TN");
-    static const char* e11 = getenv("YOND_1X1_TN");
-    if (e11 && ksize == 1) t = atoi(e11) == 32 ? 32 : (ntile % 64 == 0 ? 64 : 32);
-    if (es2 && ksize == 3 && stride == 2) t = atoi(es2) == 32 ? 32 : (ntile % 64 == 0 ? 64 : 32);
-    if (ekc && ksize == 3 && stride == 1) k = atoi(ekc) == 8 ? 8 : 16;
-    if (etn && ksize == 3 && stride == 1 && ntile % 64 == 0) t = atoi(etn) == 32 ? 32 : 64;
+#ifdef YOND_EXPERIMENTS
+    {
+        const long e11 = yond_exp_long("YOND_1X1_TN", 0), es2 = yond_exp_long("YOND_S2_TN", 0), ekc = yond_exp_long("YOND_CONV_KC", 0),
+                   etn = yond_exp_long("YOND_CONV_TN", 0);
+        if (e11 && ksize == 1) t = e11 == 32 ? 32 : (ntile % 64 == 0 ? 64 : 32);
+        if (es2 && ksize == 3 && stride == 2) t = es2 == 32 ? 32 : (ntile % 64 == 0 ? 64 : 32);
+        if (ekc && ksize == 3 && stride == 1) k = ekc == 8 ? 8 : 16;
+        if (etn && ksize == 3 && stride == 1 && ntile % 64 == 0) t = etn == 32 ? 32 : 64;
+    }
+#endif
     if (tn) *tn = t;
     if (kc) *kc = k;
     return YOND_OK;

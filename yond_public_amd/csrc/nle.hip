@@ -253,8 +253,7 @@ static int launch_box(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_
     g.nstrip = (bw + maxow - 1) / maxow;
     g.ow_nom = (bw + g.nstrip - 1) / g.nstrip;
     // row segments: about four workgroups per CU in one round; longer segments re-read fewer halo rows
-    long target = 1024;
-    if (const char* e = getenv("YOND_BOX_WGS")) target = atol(e);        // experiments only
+    const long target = yond_exp_long("YOND_BOX_WGS", 1024);
     const long cols = 4L * nblk * g.nstrip;
     long nseg = (target + cols / 2) / cols;
     if (nseg < 1) nseg = 1;
@@ -594,8 +593,7 @@ static int launch_moments(const float* lap, const float* mean, const float* var,
     }
     const int vec_ok = !(((uintptr_t)lap | (uintptr_t)mean | (uintptr_t)var) & 15);
     size_t nb = (n / 4 + 256 * MOM_UNROLL - 1) / (256 * MOM_UNROLL);
-    size_t cap = 512;                                      // two workgroups per CU: 24.7 us (41 at 2048: ten same-line atomics per workgroup)
-    if (const char* ev = getenv("YOND_MOM_WGS")) cap = (size_t)atol(ev);        // experiments only
+    const size_t cap = (size_t)yond_exp_long("YOND_MOM_WGS", 512);   // two workgroups per CU: 24.7 us (41 at 2048: ten same-line atomics per workgroup)
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(nlf_moments_kernel, dim3((unsigned)nb), dim3(256), 0, st, lap, mean, var, n, vec_ok, th, mom);

@@ -410,8 +410,7 @@ int nf_launch_stats(const float* lap, const float* mean, size_t n, int width, co
     const int G = vec ? width / 4 : width;
     const size_t nitems = (size_t)G * ((rows + NF_SEG - 1) / NF_SEG);
     size_t nb = (nitems + 511) / 512;
-    size_t cap = 256;                                      // one workgroup per CU: fewer flushes onto the same counters (56 vs 61 us at 512)
-    if (const char* ev = getenv("YOND_STATS_WGS")) cap = (size_t)atol(ev);       // experiments only
+    const size_t cap = (size_t)yond_exp_long("YOND_STATS_WGS", 256);  // one workgroup per CU: fewer flushes onto the same counters (56 vs 61 us at 512)
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     if (vec) hipLaunchKernelGGL(nf_stats_kernel<4>, dim3((unsigned)nb), dim3(512), lds, st, lap, mean, rows, width, (NleState*)ws, a);

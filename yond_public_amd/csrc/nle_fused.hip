@@ -20,6 +20,8 @@
 //       two LDS reads and two adds per sum and output after a k-read start -- the 64-lane float64 prefix scans of the
 //       first version (6 DPP steps x 3 instructions per sum) were its whole cost (109 + 65 us); results -> LDS staging.
 // The three stages (x -> B19 rows -> lap) of consecutive batches run in the same pair of phases (software pipeline).
+#ifdef YOND_EXPERIMENTS     // (built into experiment libraries only: see include/yond_hip_experiments.h)
+#include "../../include/yond_hip_experiments.h"
 #include "nle_common.h"
 
 #define BF_T 256             // virtual columns per plane and workgroup
@@ -475,8 +477,7 @@ static int launch_fused(const float* fa, const float* fb, int H, int W, int k, i
     g.ow_nom = (bw + g.nstrip - 1) / g.nstrip;
     if (!(bw & 3) && ((g.ow_nom + 3) & ~3) <= maxow) g.ow_nom = (g.ow_nom + 3) & ~3;     // 16-byte store rows
     // row segments: one workgroup per CU (132 KB of LDS) in one round; longer segments re-read fewer halo rows
-    long target = 240;
-    if (const char* e = getenv("YOND_BOX_WGS")) target = atol(e);        // experiments only
+    const long target = yond_exp_long("YOND_BOX_WGS", 240);
     const long cols = 2L * nblk * g.nstrip;
     long nseg = (target + cols / 2) / cols;
     if (nseg < 1) nseg = 1;
@@ -514,3 +515,5 @@ extern "C" int yond_box_stats_collab_fused_f32(const float* bayer_lr, const floa
     if (!bayer_lr || !bayer_hr || !mean || !var || !lap || (H & 1) || (W & 1)) return YOND_EINVAL;
     return launch_fused<2, 29, 29>(bayer_lr, bayer_hr, H, W, k, k, tile_w, mean, var, lap, q_host, nq, ws, (hipStream_t)stream);
 }
+
+#endif  // YOND_EXPERIMENTS

@@ -205,19 +205,22 @@ class BiasLUT:
         return row
 
     def get_lut(self, x, K=1, sigGs=2, func=False, device=None):
-        """:196-231 with func=False: biases (float64, on the device) of an array of DN values."""
-        if func:
-            raise NotImplementedError("BiasLUT.get_lut(func=True) is not used by YOND_SIDD.py")
+        """:196-231: biases (float64, on the device) of an array of DN values -- or, func=True, a callable.
+        sigma / K inside the table: the merged row, evaluated per pixel on the device (beyond the table's x range: the last
+        ordinate, then Foi's closed form, :226-230).  Outside the table (:204-212): get_bias for images (> 1000 points) and
+        for func=True, the pointwise integration get_bias_points(pho_min = 100, close_form = True) for <= 1000 points.
+        func=True INSIDE the table references x_pos before assignment in the reference (:214, UnboundLocalError); here it
+        returns the row as a callable over DN values, which is what that line sets out to build."""
         dev = x.device if isinstance(x, torch.Tensor) and x.is_cuda else device
         row = self.row(K, sigGs, dev)
-        if row is None:                                                # sigma outside the table: the 1-D construction (:207-209)
-            if int(np.prod(np.shape(x))) <= 1000:
-                raise L.YondHipError("BiasLUT.get_lut outside the sigma grid on <= 1000 points: the reference evaluates "
-                                     "get_bias_points pointwise with pho_min=100 there (:210-212), which is not built; "
-                                     "images (> 1000 pixels) take the get_bias branch, as here")
+        if row is None:                                                # sigma outside the table
             mx = x.max().item() if isinstance(x, torch.Tensor) else np.max(x)
-            return get_bias(np.float32(mx), sigGs, K, device=dev)(x)
-        return row(x)
+            if func:
+                return get_bias(np.float32(mx), sigGs, K, device=dev)                       # :205-206
+            if int(np.prod(np.shape(x))) > 1000:
+                return get_bias(np.float32(mx), sigGs, K, device=dev)(x)                    # :208-210
+            return get_bias_points(x, K, sigGs, close_form=True, device=dev)                # :211-212
+        return row if func else row(x)
 
 
 class DeviceBiasRow:
@@ -235,6 +238,44 @@ class DeviceBiasRow:
         L.check(L.load().yond_bias_eval_f32(L.ptr(xd), xd.numel(), L.ptr(self.x), L.ptr(self.y), len(self), 1, 1, self.K, self.sigma,
                                             L.ptr(out), L.stream()), "yond_bias_eval_f32")
         return out.reshape(tuple(np.shape(x)))
+
+
+def get_bias_points(lams, K, sigGs, pho_min=100, close_form=False, device=None):
+    """utils/isp_algos.py:142-160 (clip=False): the bias at ARBITRARY abscissae `lams` (DN), each integrated against the
+    Poisson (*) Gaussian density sampled at pho = max(int(sqrt K), pho_min) points per electron; Foi's closed form above th
+    only with close_form.  Returns a device tensor of lams' shape, float64 (the reference keeps the queries' dtype: float32
+    queries give float32-rounded biases there; round the result to compare bit for bit)."""
+    lib = L.load()
+    dev = lams.device if isinstance(lams, torch.Tensor) and lams.is_cuda else torch.device(device if device is not None else 'cuda')
+    lam_h = lams.detach().cpu().numpy() if isinstance(lams, torch.Tensor) else np.asarray(lams)
+    shape = lam_h.shape
+    x = torch.from_numpy(np.ascontiguousarray(lam_h.reshape(-1), np.float64)).to(dev)
+    n = x.numel()
+    out = torch.zeros(n, dtype=torch.float64, device=dev)
+    if n == 0:
+        return out.reshape(shape)
+    lam_max = float(lam_h.max())
+    nwg = min(256, n)
+    need = int(lib.yond_bias_points_scratch(float(K), float(sigGs), int(pho_min), int(bool(close_form)), lam_max, nwg))
+    if need == 0 or need * 8 > 8 << 30:
+        raise L.YondHipError(f"get_bias_points(K={float(K):.4g}, sigma={float(sigGs):.4g}, pho_min={pho_min}): the integration grid is out of this build's range")
+    scratch = torch.empty(need, dtype=torch.float64, device=dev)
+    L.check(lib.yond_bias_points_f64(L.ptr(x), n, float(K), float(sigGs), int(pho_min), int(bool(close_form)), lam_max, None, L.ptr(out),
+                                     L.ptr(scratch), need, nwg, L.stream()), "yond_bias_points_f64")
+    torch.cuda.current_stream().synchronize()                # (the scratch buffer must outlive the kernel)
+    if close_form:
+        # The reference's index bookkeeping, reproduced as it is (:148-159): the closed-form values go to their own positions
+        # (bias[lams > th] = ...), then `lams` is replaced by its integrated subset and the loop stores the i-th integrated
+        # value at bias[i] -- the FIRST positions, whatever their abscissae were.  For queries on one side of th (every call
+        # of the 2-D table's construction and of get_lut beyond the table) that is the identity.
+        th = 50 * float(K) if float(K) < 1 else 50 * float(K) ** 0.5
+        mask = torch.from_numpy(np.ascontiguousarray(lam_h.reshape(-1) > th)).to(dev)
+        fixed = torch.zeros_like(out)
+        fixed[mask] = out[mask]
+        sub = out[~mask]
+        fixed[:sub.numel()] = sub
+        out = fixed
+    return out.reshape(shape)
 
 
 def get_bias(img=None, sigGs=25.853043, K=24.48128, device=None):
@@ -485,6 +526,9 @@ def SimpleNLF(lr_raw, hr_raw=None, k=29, setting=None, full=False, device=None, 
         box = 'two-pass' if fused is None else ('one-pass' if fused else 'plain')
     if box == 'one-pass' and k != 29:         # the one-pass kernel is built for the estimator's windows (29, 19)
         box = 'two-pass'
+    if box == 'one-pass' and not L.has("yond_box_stats_self_fused_f32"):
+        raise L.YondHipError("box='one-pass' needs an experiment build of the library (python -m yond_public_amd.build --experiments; "
+                             "the one-pass kernels measured slower than the default producers and are not in the product)")
     if box not in ('two-pass', 'one-pass', 'plain'):
         raise ValueError(f"box={box!r}")
     ws = None
@@ -698,7 +742,8 @@ def _chain_buffers(dev, slot):
 def chain_applies(lr, net, arch, pipe, biaslut=None):
     """The configurations the device chain covers: one bare Bayer frame, full_dn, bias_corr 'pre' with the 1-D LUT."""
     return (isinstance(lr, torch.Tensor) and lr.is_cuda and lr.dim() == 2 and bool(pipe.get('full_dn', False)) and biaslut is None
-            and pipe.get('bias_corr', 'pre') == 'pre' and pipe.get('full_est', True) and DEVICE_CHAIN)
+            and pipe.get('bias_corr', 'pre') == 'pre' and pipe.get('full_est', True) and DEVICE_CHAIN
+            and 'simple' in str(pipe.get('est_type', 'simple')) and 'cal_est' not in pipe)
 
 
 DEVICE_CHAIN = True                 # (module attribute: tools / tests switch the host-side chain back on for A/B)
@@ -909,14 +954,28 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     raw4est = lr_cat if lr_full is None else _dev(lr_full, lr.device)                  # :340
     # lr.max() for the bias LUT grid: the estimator's first kernel collects it when it reads the same frame; else a
     # reduction queued ahead of the NLE and read after the NLE's own host sync
-    lr_max_dev = _frame_max(lr_cat) if lr_full is not None else None
-    reg, nle_info = SimpleNLF(raw4est, k=k, setting={'mode': 'self'}, full=True)       # :341
+    est_type = str(pipe.get('est_type', 'simple'))
+    for other in ('foi', 'liu', 'zou', 'pge', 'ours'):                                 # :322-346: precomputed estimates of other
+        if other in est_type:                                                          # methods, read from the dataset directory
+            raise NotImplementedError(f"est_type {est_type!r}: the reference reads the {other!r} estimates from files of its dataset "
+                                      "tree / a second network (YOND_SIDD.py:322-346); this build estimates with 'simple' or takes 'manual'")
+    if 'cal_est' in pipe:
+        raise NotImplementedError("pipe['cal_est'] (a pickled calibration table, YOND_SIDD.py:316-321) is not built")
+    if 'simple' in est_type:
+        lr_max_dev = _frame_max(lr_cat) if lr_full is not None else None
+        reg, nle_info = SimpleNLF(raw4est, k=k, setting={'mode': 'self'}, full=True)   # :341
+    elif 'manual' in est_type:                                                         # :349-351: a fixed (K, sigma) = (14, 20) DN
+        reg = (14 / (p['wp'] - p['bl']), (20 / (p['wp'] - p['bl'])) ** 2)
+        lr_max_dev, nle_info = _frame_max(lr_cat), {}
+    else:
+        raise NotImplementedError(est_type)                                            # :352-353
     p['gain'], p['sigma'] = reg[0] * scale, np.sqrt(max(reg[1], 0)) * scale            # :356
     if log:
         log(f"Self Est: K={p['gain']:.4f}, b={p['sigma']:.4f} (beta1={reg[0]:.3e}, beta2={reg[1]:.3e})")
     regs.append(reg)
     params.append((p['gain'], p['sigma']))
     lr_max = np.float32(lr_max_dev.item()) if lr_max_dev is not None else np.float32(nle_info['frame_max'])
+
 
     def denoise_all(bias_func):
         if full_dn:                                                                    # :387-389

@@ -302,12 +302,14 @@ def main(argv=None):
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
-    # HIP events (on the launch stream) bracket every launch of the 3x3 stride-1 convolution kernels -- the dominant
-    # family: 18 launches per forward, 91 % of the MACs -- inside the timed region; an event pair costs the stream a few
-    # microseconds, so the other kernels and the VST / NLE stages are timed in one more, instrumented pass behind it
+    # HIP events (on the launch stream) bracket the launches of the 3x3 stride-1 convolution kernels -- the dominant
+    # family: 18 launches per forward, 91 % of the MACs -- in every 4th forward of the timed region; an event pair costs
+    # the stream a few microseconds (reported: `without_kernel_events`), so the other kernels and the VST / NLE stages are
+    # timed in one more, instrumented pass behind it
     is33 = lambda t: t.startswith("conv_mfma_kernel<3,1") or t.startswith("conv_wino_kernel") or t.startswith("conv_split_kernel<1,")
     plan.prof = None if a.no_kernel_events else []
     plan.prof_only = is33
+    plan.prof_every = 4                  # every 4th forward carries the event pairs (their cost is reported: `without_kernel_events`)
     sclk = GpuSampler() if rank == 0 else None
     if sclk:
         sclk.start()
@@ -333,6 +335,7 @@ def main(argv=None):
                                "samples during the timed region")
     prof, plan.prof = plan.prof or [], None
     plan.prof_only = None
+    plan.prof_every = 1
     n_timed = a.steps * F
     last_frame = frames[(n_timed - 1) % len(frames)]
     last_clean = cleans[(n_timed - 1) % len(frames)]

@@ -374,6 +374,9 @@ class DenoiserPlan:
             only = getattr(self, 'prof_only', None)      # bench.py: events around one kernel family only (an event pair
             if only is not None and not only(tag):       # costs the stream a few microseconds)
                 prof = None
+            every = getattr(self, 'prof_every', 1)       # ... and only in every n-th forward
+            if every > 1 and getattr(self, '_fwd_idx', 0) % every:
+                prof = None
         if prof is not None:
             # events on the stream the kernel is launched on (torch's current stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -444,6 +447,7 @@ class DenoiserPlan:
         """x4: [N][H][W][4] float32 device tensor (H, W multiples of 16); t_dev: [N] float32 (guided
         nets); ub: optional precomputed per-image maximum [N] (K1 provides it).  Returns [N][H][W][4]."""
         L.require_cuda(x4, "x")
+        self._fwd_idx = getattr(self, '_fwd_idx', -1) + 1
         N, H, W, c4 = x4.shape
         if c4 != 4 or H % 16 or W % 16:
             raise L.YondHipError(f"input must be [N][H][W][4] with H, W multiples of 16, got {tuple(x4.shape)}")

@@ -378,6 +378,12 @@ def _fit_from_moments(m_all, m_ns):
     return np.array([(n * sxy - sx * sy) / det, (sxx * sy - sx * sxy) / det])
 
 
+def _same(a, b):
+    """Equality of two float64 results of the same formula, NaN included (a frame with NaN pixels has NaN percentiles on both
+    sides: the reference carries them through; the cross-check must not turn that into an error)."""
+    return a == b or (np.isnan(a) and np.isnan(b))
+
+
 def _threshold_state(lap, mean, quants, ws=None):
     """K6'/K7' (nle_fast.hip): (ths float64[nq], npeaks int32[nq], sel float64[4], ws) of the two-sweep selection."""
     lib = L.load()
@@ -406,7 +412,7 @@ def get_threshold(data, step=5, mode='score3', print_log=False, scale=1023 - 64,
     quants = np.linspace(step, 100, 100 // step, endpoint=True)
     ths, npeaks, sel, _ = _threshold_state(lap, mean, quants)
     th, pct, info = _score3(ths, quants, npeaks=npeaks)
-    if info['index'] != int(sel[0]) or th != sel[1]:
+    if info['index'] != int(sel[0]) or not _same(th, sel[1]):
         raise L.YondHipError(f"score3 mismatch: device picked {sel[0]:.0f}/{sel[1]!r}, host {info['index']}/{th!r}")
     if _full:
         return th, pct, info
@@ -471,7 +477,7 @@ def _nlf_from_maps(lap, mean, var, full=False, ws=None):
     mom_h = head[off_mom:off_mom + 80].view(np.float64).reshape(2, 5).copy()
     npeaks = head[off_np:off_np + 4 * nq].view(np.int32).copy()
     th, pct, info = _score3(ths, quants, npeaks=npeaks)
-    if info['index'] != int(sel_h[0]) or th != sel_h[1]:          # host and device run the same float64 formula
+    if info['index'] != int(sel_h[0]) or not _same(th, sel_h[1]):   # host and device run the same float64 formula
         raise L.YondHipError(f"score3 mismatch: device picked {sel_h[0]:.0f}/{sel_h[1]!r}, host {info['index']}/{th!r}")
     sel = mom_h                                                  # pixels with lap < ths[i]
     if sel[0, 0] > 0:
@@ -601,10 +607,14 @@ class _Guard:
         self.event.record()
         return self
 
+    def tripped(self):
+        """True if the watched forward staged an activation outside fp16's range (waits for it)."""
+        self.event.synchronize()
+        return bool(int(self.plan._flag_host[self.slot]) & 1)
+
     def finish(self):
         """None if the forward stayed in range, else the strictly recomputed result."""
-        self.event.synchronize()
-        if not (int(self.plan._flag_host[self.slot]) & 1):
+        if not self.tripped():
             return None
         import warnings
         warnings.warn("an activation left fp16's range (|a| > 65504) in the split-operand convolution path: "
@@ -727,6 +737,7 @@ class _ChainBuffers:
         self.lut_ws = torch.zeros(int(lib.yond_lut_ws_bytes(LUT_CAP)), dtype=torch.uint8, device=dev)
         self.img_max = torch.zeros(1, dtype=torch.float32, device=dev)
         self.prm_host = torch.zeros(16, dtype=torch.float64).pin_memory()
+        torch.cuda.synchronize(dev)        # (the zero fills above ran on the creating stream; the buffers are written from others)
 
 
 _CHAIN_BUFFERS = {}
@@ -749,16 +760,13 @@ def chain_applies(lr, net, arch, pipe, biaslut=None):
 DEVICE_CHAIN = True                 # (module attribute: tools / tests switch the host-side chain back on for A/B)
 
 
-def _chain_round(lr, hr, mode, net, arch, pipe, p, slot, lr_max_dev=None, vst_type='exact'):
-    """One round of IterDenoise for a bare frame, queued without any host synchronisation:
-    estimator (self / collab) -> yond_frame_params_f64 -> bias LUT -> table -> K1 -> network -> K4.
-    Returns (denoised frame [H][W] on the device, buffers whose .prm block describes the round, range guard or None)."""
+def _chain_estimate(lr, hr, mode, pipe, p, buf, lr_max_dev=None):
+    """First half of a round of the device chain, queued on the current stream: estimator (self / collab) -> threshold ->
+    moments -> yond_frame_params_f64 -> bias LUT -> prepared table, all into `buf`."""
     lib = L.load()
     k = pipe.get('k', 29)
-    H, W = lr.shape
-    h, w = H // 2, W // 2
+    W = lr.shape[1]
     scale_est, scale = float(p['wp'] - p['bl']), float(p['scale'])       # :356 / :251 (equal for ratio 1)
-    buf = _chain_buffers(lr.device, slot)
     st = L.stream()
     setting = {'mode': mode}
     if mode == 'collab':
@@ -777,6 +785,16 @@ def _chain_round(lr, hr, mode, net, arch, pipe, p, slot, lr_max_dev=None, vst_ty
                                           scale_est, scale, 1.03, LUT_CAP, L.ptr(buf.prm), L.ptr(buf.t), L.ptr(buf.lut_x), st), "yond_frame_params_f64")
         L.check(lib.yond_bias_lut_dev_f64(L.ptr(buf.lut_x), LUT_CAP, L.ptr(buf.prm), L.ptr(buf.lut_y), st), "yond_bias_lut_dev_f64")
         L.check(lib.yond_lut_table_f64(L.ptr(buf.lut_x), L.ptr(buf.lut_y), -1, L.ptr(buf.prm), L.ptr(buf.lut_ws), st), "yond_lut_table_f64")
+    buf.ws = ws                                              # (kept alive until the buffers' next use)
+
+
+def _chain_denoise(lr, net, arch, p, buf, guard_slot):
+    """Second half: K1 -> network -> K4 with the constants of `buf`, queued on the current stream.  Returns (frame, guard)."""
+    lib = L.load()
+    H, W = lr.shape
+    h, w = H // 2, W // 2
+    scale = float(p['scale'])
+    st = L.stream()
     p2d = get_p2d((1, 4, h, w), base=32)
     Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
     x4 = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=lr.device)
@@ -794,12 +812,21 @@ def _chain_round(lr, hr, mode, net, arch, pipe, p, slot, lr_max_dev=None, vst_ty
                                                         1, st), "yond_denorm_ivst_unpack_dev_f32")
         return out
 
-    watch = _Guard(plan, slot) if plan.uses_half_operands() else None
+    watch = _Guard(plan, guard_slot) if plan.uses_half_operands() else None
     out = forward_and_invert()
     if watch is not None:
         watch.arm(forward_and_invert)
     buf.prm_host.copy_(buf.prm, non_blocking=True)       # read by the caller behind its synchronisation
-    buf.ws = ws
+    return out, watch
+
+
+def _chain_round(lr, hr, mode, net, arch, pipe, p, slot, lr_max_dev=None, vst_type='exact'):
+    """One round of IterDenoise for a bare frame, queued without any host synchronisation:
+    estimator (self / collab) -> yond_frame_params_f64 -> bias LUT -> table -> K1 -> network -> K4.
+    Returns (denoised frame [H][W] on the device, buffers whose .prm block describes the round, range guard or None)."""
+    buf = _chain_buffers(lr.device, slot)
+    _chain_estimate(lr, hr, mode, pipe, p, buf, lr_max_dev)
+    out, watch = _chain_denoise(lr, net, arch, p, buf, slot)
     return out, buf, watch
 
 
@@ -828,10 +855,8 @@ def _iter_denoise_chain(lr, net, arch, pipe, p, log=None):
     reg1, par1, fl1, info1 = _chain_result(b1)
     if fl1 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE):
         return None
-    if g1 is not None:
-        redo = g1.finish()
-        if redo is not None:
-            return None                                  # an activation left fp16's range: the guarded host path recomputes
+    if g1 is not None and g1.tripped():
+        return None                                      # an activation left fp16's range: the guarded host path recomputes
     if log:
         log(f"Self Est: K={par1[0]:.4f}, b={par1[1]:.4f} (beta1={reg1[0]:.3e}, beta2={reg1[1]:.3e})")
     raw_dns, regs, params = [out1], [reg1], [par1]
@@ -844,7 +869,7 @@ def _iter_denoise_chain(lr, net, arch, pipe, p, log=None):
         if not (fl2 & PRM_ROUND_ABORTED):                # :445-447: beta1 < 0 ends the image after round 1
             if fl2 & PRM_BAD_ESTIMATE:
                 return None
-            if g2 is not None and g2.finish() is not None:
+            if g2 is not None and g2.tripped():
                 return None
             raw_dns.append(out2)
             regs.append(reg2)
@@ -1098,6 +1123,9 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
             yield IterDenoise(f, net, arch, pipe, p=p, device=device)
         return
     p0 = dict(p or default_params())
+    if DEVICE_CHAIN and pipe.get('bias_corr', 'pre') == 'pre' and 'simple' in str(pipe.get('est_type', 'simple')) and 'cal_est' not in pipe:
+        yield from _denoise_stream_chain(frames, net, arch, pipe, p0, device)
+        return
     k = pipe.get('k', 29)
     bias_corr = pipe.get('bias_corr', 'pre')
     if bias_corr == 'none':
@@ -1147,6 +1175,62 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
         if pending is not None:
             yield release(pending)
         pending = (dict(raw_dns=[raw_dn], regs=[reg], params=[(pp['gain'], pp['sigma'])]), watch)
+    if pending is not None:
+        yield release(pending)
+
+
+def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
+    """denoise_stream on the device chain: frame k+1's estimator AND its whole parameter chain (beta -> K, sigma, t, knots ->
+    bias LUT -> table) run on the side stream under the convolutions of frame k -- no host round trip anywhere; the host reads
+    a frame's parameter block one frame late, when it yields the result.  A frame whose block carries a flag (no flat area,
+    table capacity, K <= 0) or whose range guard tripped is recomputed on the host-side chain before it is yielded."""
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+
+    def estimate(lr, ready, slot):
+        buf = _chain_buffers(lr.device, 2 + slot % 3)            # three sets: a frame's buffers rest until two frames later
+        side.wait_event(ready)                                   # the frame as it stood when it was handed in
+        with torch.cuda.stream(side):
+            _chain_estimate(lr, None, 'self', pipe, p0, buf)
+            done = side.record_event()
+        return lr, buf, done
+
+    def release(item):
+        lr, out, buf, watch, fin = item
+        fin.synchronize()
+        reg, par, flags, info = _chain_result(buf)
+        if flags & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE) or (watch is not None and watch.tripped()):
+            global DEVICE_CHAIN
+            DEVICE_CHAIN = False
+            try:
+                return IterDenoise(lr, net, arch, pipe, p=p0)
+            finally:
+                DEVICE_CHAIN = True
+        return dict(raw_dns=[out], regs=[reg], params=[par], nle_info=info)
+
+    it = iter(frames)
+    try:
+        f = _dev(next(it), device)
+    except StopIteration:
+        return
+    k_frame = 0
+    nxt = estimate(f, main.record_event(), k_frame)
+    pending = None
+    while nxt is not None:
+        lr, buf, est_done = nxt
+        try:                               # take the next frame (and mark the main stream) BEFORE queuing this one's network
+            f_next = _dev(next(it), device)
+            ready = main.record_event()
+        except StopIteration:
+            f_next = None
+        main.wait_event(est_done)
+        out, watch = _chain_denoise(lr, net, arch, p0, buf, k_frame % 3)
+        fin = main.record_event()
+        k_frame += 1
+        nxt = estimate(f_next, ready, k_frame) if f_next is not None else None
+        if pending is not None:
+            yield release(pending)
+        pending = (lr, out, buf, watch, fin)
     if pending is not None:
         yield release(pending)
 

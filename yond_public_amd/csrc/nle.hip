@@ -9,59 +9,38 @@
 #include "nle_common.h"
 
 // =====================================================================================================
-// K5: box statistics, streamed down the rows
+// K5: box statistics -- vertical running sums per column, horizontal sliding windows per chunk of columns
 // =====================================================================================================
-// A workgroup owns one plane, a strip of <= 256 - 2R "virtual" columns (outputs plus the reflected halo of
-// R = k/2 on either side, one column per thread) and a segment of rows.  It walks down the rows:
-//   vertical   every thread keeps the running k-row sums of its column in float64 registers
-//              (S += entering - leaving; the leaving row is read again from L2) -- float32 data summed in
-//              float64 is exact, so add/subtract leaves no drift;
-//   horizontal the k-column window sum is a difference of two prefix sums across the strip: a DPP
-//              inclusive scan inside each wave (row_shr 1/2/4/8, row_bcast 15/31), wave totals through LDS,
-//              then out[c] = Q[c + R] - Q[c - R - 1].  The prefix over <= 256 columns costs a relative
-//              error of ~1e-15 on the window sum, far below the float32 rounding that follows.
-// BS_B rows are processed per barrier pair.  Every intermediate is rounded to float32 exactly where NumPy /
-// OpenCV round (cv2.blur returns float32; stdfilt squares and subtracts in float32; no FMA contraction).
-#define BS_T 256
-#define BS_B 4
-#define BS_MAXR 14
-#define BS_MAXOH 256         // rows per segment (row table in LDS)
+// A workgroup owns TWO planes (Bayer input: the two column phases dx = 0, 1 of one row parity, read together as one 8-byte
+// load per packed pixel; planar input: planes 2z, 2z + 1), a strip of <= 256 - 2R "virtual" columns (outputs plus the
+// reflected halo of R = k/2 on either side) and a segment of rows.  It walks down the rows BX_B at a time:
+//   column phase   thread = virtual column: running k-row sums of its column in float64 registers (S += entering - leaving;
+//                  float32 data summed in float64 is exact, so add / subtract leaves no drift; the leaving row comes back
+//                  from L2), written to LDS;
+//   task phase     thread = (plane, row of the batch, chunk of BX_C = 8 output columns): the k-column window sum of the
+//                  chunk's first output is added up from LDS, the next seven SLIDE (+ entering column - leaving column: two
+//                  LDS reads at immediate offsets and two float64 additions per sum and output), then the float32 finishing
+//                  arithmetic exactly where NumPy / OpenCV round (cv2.blur returns float32; stdfilt squares and subtracts in
+//                  float32; no FMA contraction) and two 16-byte stores per map: the lanes of a half-wave hold neighbouring
+//                  chunks, so a store instruction covers 1 KB of one output row.
+// LDS row of a quantity: one double per virtual column, one pad double per chunk (a half-wave's 32 chunk bases fall on 32
+// different bank pairs).  Window sizes are template constants for the shipped k = 29 / k2 = 19; any other odd k <= 29 takes
+// the same code with run-time loop bounds.  (Rounds 1-2 did the horizontal pass with wave-wide DPP prefix scans, one column
+// per thread: ~18 vector instructions per sum and output against ~5 here, and 4-byte loads at an 8-byte stride.)
+#define BX_T 256
+#define BX_C 8
+#define BX_MAXR 14
+#define BX_VW (BX_T + BX_T / BX_C)      // doubles per LDS row
 
 struct BoxSrc {
     const float* p;     // base pointer
-    int bayer;          // 1: Bayer frame [2h][2w], plane = blockIdx.z ; 0: planar [4][h][w]
+    int bayer;          // 1: Bayer frame [2h][2w]; 0: planar [4][h][w]
 };
 
 struct BoxGeom {
     int h, w, k, k2, tile_w;
     int ow_nom, nstrip, oh;     // outputs per strip, strips per (tile_w-wide) block, rows per segment
 };
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_take(double v) {
-    // lanes without a source (or masked rows) receive +0.0
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-// inclusive prefix sums across the 64 lanes of N independent values, step by step over all of them so that the
-// dependent DPP -> add chains of different values overlap
-template <int N>
-__device__ __forceinline__ void wave_incl_scan_f64(double (&v)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x111, 0xf>(v[i]);       // row_shr:1
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x112, 0xf>(v[i]);       // row_shr:2
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x114, 0xf>(v[i]);       // row_shr:4
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x118, 0xf>(v[i]);       // row_shr:8
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x142, 0xa>(v[i]);       // row_bcast:15 into rows 1, 3
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_take<0x143, 0xc>(v[i]);       // row_bcast:31 into rows 2, 3
-}
 
 __device__ __forceinline__ float blur_round(double s, int k) { return (float)(s * (1.0 / (double)(k * k))); }
 
@@ -71,25 +50,33 @@ __device__ __forceinline__ float std_from(float b1, float b2) {
     return __fsqrt_rn(fmaxf(d, 0.0f));
 }
 
+// eight consecutive outputs of one row: 16-byte stores where the row allows it
+__device__ __forceinline__ void box_store8(float* __restrict__ p, const float (&v)[BX_C], int nvalid, bool vec_ok) {
+    if (vec_ok && nvalid >= BX_C) {
+        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < BX_C; ++i)
+            if (i < nvalid) p[i] = v[i];
+    }
+}
+
 // mode 0: self stage 1 (mean, var, blur2 from the Bayer frame); 1: self stage 2 (lap from blur2);
 // 2: collab (mean, var, lap from noisy + denoised Bayer frames)
-// STATS (MODE 0): stage 1 reads every pixel of the frame exactly once as an "own" pixel, so it also collects the frame
-// maximum (lr.max() for the bias LUT grid, YOND_SIDD.py:256/393) into st->frame_max_key.  (Round 2 also tried the first
-// sweep of the threshold selection inside the producers of the lap map: with ~1000 workgroups each flushing its LDS
-// histogram the fold cost 66 us against 62 us for the stand-alone sweep of nle_fast.hip -- not kept.)
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(BS_T) void box_stream_kernel(BoxSrc a, BoxSrc b, BoxGeom g, float* __restrict__ o0,
-                                                         float* __restrict__ o1, float* __restrict__ o2, NleState* st) {
+// STATS (MODE 0): stage 1 reads every pixel of the frame as an entering pixel, so it also collects the frame maximum
+// (lr.max() for the bias LUT grid, YOND_SIDD.py:256/393) into st->frame_max_key.
+template <int MODE, int KT, int K2T, bool STATS, int BB>
+__global__ __launch_bounds__(BX_T, MODE == 1 ? 4 : 2) void box_slide_kernel(BoxSrc a, BoxSrc b, BoxGeom g, float* __restrict__ o0,
+                                                        float* __restrict__ o1, float* __restrict__ o2, NleState* st) {
     static_assert(!STATS || MODE == 0, "only stage 1 collects the frame maximum");
-    constexpr int NQ = MODE == 0 ? 3 : (MODE == 1 ? 2 : 4);      // running sums per column
-    float fmax_ = -INFINITY;
+    constexpr int NQ = MODE == 0 ? 3 : (MODE == 1 ? 2 : 4);      // running sums per column and plane
     constexpr int NI = MODE == 2 ? 2 : 1;                        // input frames
     constexpr int NL = MODE == 0 ? 3 : 2;                        // loads per input and row: entering, leaving (k), leaving (k2)
-    __shared__ double s_p[NQ][BS_B][BS_T];
-    __shared__ double s_tot[NQ][BS_B][BS_T / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int plane = blockIdx.z;
-    const int h = g.h, w = g.w, k = g.k, k2 = g.k2;
+    extern __shared__ __attribute__((aligned(16))) double s_v[]; // [NQ][BB][2][BX_VW]
+    const int tid = threadIdx.x;
+    const int h = g.h, w = g.w;
+    const int k = KT > 0 ? KT : g.k, k2 = MODE == 0 ? (K2T > 0 ? K2T : g.k2) : k;
     const int R = k / 2, R2 = k2 / 2;
     // columns: reflect inside [bx0, bx0 + bw) -- bw = tile_w (SIDD_256 re-tiling) or the whole width
     const int bw = g.tile_w > 0 ? g.tile_w : w;
@@ -97,135 +84,196 @@ __global__ __launch_bounds__(BS_T) void box_stream_kernel(BoxSrc a, BoxSrc b, Bo
     const int bx0 = blk * bw;
     const int ox0 = bx0 + strip * g.ow_nom;
     const int ow = min(g.ow_nom, bx0 + bw - ox0);
-    const bool live = tid < ow + 2 * R;
-    const int rc = bx0 + reflect101(ox0 - R + tid - bx0, bw);
-    const bool writer = tid >= R && tid < R + ow;
-    const int ox = ox0 + tid - R;
+    const int vc = min(tid, ow + 2 * R - 1);                     // idle columns repeat the last one (valid addresses, never read back)
+    const int rc = bx0 + reflect101(ox0 - R + vc - bx0, bw);
+    const int pv = tid + (tid >> 3);                             // the column's slot in an LDS row
     // rows
     const int oy0 = blockIdx.y * g.oh;
     const int ohe = min(g.oh, h - oy0);
     const int nsteps = ohe + 2 * R;
-    const float* base[NI];
-    size_t rstride[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
+    const int z = blockIdx.z;                                    // Bayer: row parity dy; planar: plane pair
+    // the two planes' values of image row gy at this thread's column
+    auto ld2 = [&](int i, int gy) -> f32x2 {
         const BoxSrc src = i == 0 ? a : b;
-        if (src.bayer) { base[i] = src.p + (size_t)(plane >> 1) * (2 * w) + 2 * rc + (plane & 1); rstride[i] = (size_t)4 * w; }
-        else { base[i] = src.p + (size_t)plane * h * w + rc; rstride[i] = (size_t)w; }
-    }
-    // image row of every local row l (reflect(oy0 - R + l)), once per workgroup
-    __shared__ int s_row[BS_MAXOH + 2 * BS_MAXR];
-    for (int l = tid; l < nsteps; l += BS_T) s_row[l] = reflect101(oy0 - R + l, h);
-    __syncthreads();
-    // value of local row l, l clamped into [0, nsteps).  Nothing depends on the loaded value until the batch is
-    // consumed, so the loads of a batch stay in flight together.  Idle columns and rows past the end read valid
-    // addresses: what they add only reaches prefix positions / rows that are never emitted.  Rows before the
-    // start (the "leaving" row of the first k steps) are zeroed by a 0/1 factor when the batch is consumed.
-    auto ld = [&](int i, int l) -> float {
-        const int gy = s_row[min(max(l, 0), nsteps - 1)];
-        return base[i][(size_t)gy * rstride[i]];
+        if (src.bayer) return *(const f32x2*)(src.p + (size_t)(2 * gy + z) * (size_t)(2 * w) + 2 * rc);
+        const float* p0 = src.p + ((size_t)(2 * z) * h + gy) * (size_t)w + rc;
+        return f32x2{p0[0], p0[(size_t)h * w]};
     };
-    float cur[NI][NL][BS_B], nxt[NI][NL][BS_B];
-    auto load_batch = [&](float (&dst)[NI][NL][BS_B], int l0) {
+    // Image rows: three cursors walk the reflected row index one step per local row -- entering row l, leaving rows l - k and
+    // l - k2 -- as the PHASE i of BORDER_REFLECT_101's period 2 (h - 1): row = i < h ? i : period - i.  Uniform, i.e. scalar
+    // arithmetic; a modulo per load (reflect101) was ~600 scalar instructions per batch and wave, and the CU has ONE scalar
+    // unit.  Rows before the segment's start (the "leaving" row of the first k steps) are zeroed by a 0/1 factor when the batch
+    // is consumed; rows past its end are rows of the image too and only reach outputs that are never emitted.
+    const int period = 2 * (h - 1);
+    auto phase0 = [&](int y) -> int {                            // once per cursor
+        if (period == 0) return 0;
+        int i = y % period;
+        return i < 0 ? i + period : i;
+    };
+    int ph[3] = {phase0(oy0 - R), phase0(oy0 - R - k), phase0(oy0 - R - k2)};
+    auto row_next = [&](int c) -> int {
+        const int i = ph[c];
+        const int y = i < h ? i : period - i;
+        ph[c] = (i + 1 >= period) ? 0 : i + 1;
+        return y;
+    };
+    f32x2 cur[NI][NL][BB], nxt[NI][NL][BB];
+    const int kl_min = MODE == 0 ? k2 : k;                       // first local row with a leaving row
+    const int first_out = MODE == 0 ? R + R2 : 2 * R;            // first local row that completes a window
+    auto load_batch = [&](f32x2 (&dst)[NI][NL][BB], int l0) {  // called for l0 = 0, BB, 2 BB, ... in this order
+        const bool leave = l0 + BB > kl_min;                   // uniform
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int r = 0; r < BB; ++r) {
+            const int y0 = row_next(0), y1 = row_next(1), y2 = NL == 3 ? row_next(2) : 0;
 #pragma unroll
-            for (int r = 0; r < BS_B; ++r) {
-                dst[i][0][r] = ld(i, l0 + r);
-                dst[i][1][r] = ld(i, l0 + r - k);
-                if (NL == 3) dst[i][2][r] = ld(i, l0 + r - k2);
+            for (int i = 0; i < NI; ++i) {
+                dst[i][0][r] = ld2(i, y0);
+                if (leave) {
+                    dst[i][1][r] = ld2(i, y1);
+                    if (NL == 3) dst[i][2][r] = ld2(i, y2);
+                }
             }
         }
     };
-    double S[NQ];
+    double S[NQ][2];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) S[q] = 0.0;
+    for (int q = 0; q < NQ; ++q) S[q][0] = S[q][1] = 0.0;
+    float fmax_ = -INFINITY;
+    // task phase: thread = (plane, row of the batch) x chunk; a half-wave holds the 32 chunk slots of one (plane, row)
+    const int chunk = tid & 31, t_r = (tid >> 5) % BB, t_pl = (tid >> 5) / BB;
+    const int c0 = chunk * BX_C;                                 // first output column of the chunk (strip-relative)
+    const bool t_on = c0 < ow && (tid >> 5) < 2 * BB;
+    const int nvalid = min(BX_C, ow - c0);
+    const double* vb = s_v + (t_r * 2 + t_pl) * BX_VW + chunk * (BX_C + 1);   // + q * BB * 2 * BX_VW ; virtual column c0 + d at d + (d >> 3)
+    constexpr int QS = BB * 2 * BX_VW;
+    const int t_plane = MODE == 1 ? 2 * z + t_pl : 2 * z + t_pl;  // output plane: Bayer (dy = z, dx = t_pl) -> 2 dy + dx
+    const bool vec_ok = (w % 4 == 0) && (ox0 % 4 == 0) && !(((uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2) & 15);
     load_batch(nxt, 0);
-    for (int l0 = 0; l0 < nsteps; l0 += BS_B) {
+    for (int l0 = 0; l0 < nsteps; l0 += BB) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
+            for (int j = 0; j < NL; ++j)
 #pragma unroll
-                for (int r = 0; r < BS_B; ++r) cur[i][j][r] = nxt[i][j][r];
+                for (int r = 0; r < BB; ++r) cur[i][j][r] = nxt[i][j][r];
+        if (l0 + BB < nsteps) load_batch(nxt, l0 + BB);
+        const bool warm = l0 + BB <= kl_min && l0 + BB <= first_out;     // uniform: no leaving row, no finished window
+        if (warm) {
+#pragma unroll
+            for (int r = 0; r < BB; ++r) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const f32x2 xn = cur[i][0][r];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        S[2 * i][pl] += (double)xn[pl];
+                        S[2 * i + 1][pl] += (double)__fmul_rn(xn[pl], xn[pl]);
+                        if (MODE == 0) S[2][pl] += (double)xn[pl];
+                    }
+                    if (STATS) fmax_ = fmaxf(fmax_, fmaxf(xn[0], xn[1]));
+                }
             }
+            continue;
         }
-        if (l0 + BS_B < nsteps) load_batch(nxt, l0 + BS_B);
-        double P[NQ * BS_B];
 #pragma unroll
-        for (int r = 0; r < BS_B; ++r) {
+        for (int r = 0; r < BB; ++r) {
             const float mk = (l0 + r >= k) ? 1.0f : 0.0f, mk2 = (l0 + r >= k2) ? 1.0f : 0.0f;   // leaving row exists
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const float xn = cur[i][0][r], xo = __fmul_rn(cur[i][1][r], mk);
-                S[2 * i] += (double)xn - (double)xo;
-                S[2 * i + 1] += (double)__fmul_rn(xn, xn) - (double)__fmul_rn(xo, xo);
+                const f32x2 xn = cur[i][0][r];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const float xo = __fmul_rn(cur[i][1][r][pl], mk);
+                    S[2 * i][pl] += (double)xn[pl] - (double)xo;
+                    S[2 * i + 1][pl] += (double)__fmul_rn(xn[pl], xn[pl]) - (double)__fmul_rn(xo, xo);
+                    if (MODE == 0) S[2][pl] += (double)xn[pl] - (double)__fmul_rn(cur[0][NL - 1][r][pl], mk2);
+                }
+                if (STATS) fmax_ = fmaxf(fmax_, fmaxf(xn[0], xn[1]));  // halo, idle columns and clamped rows are pixels of the frame too
             }
-            if (MODE == 0) S[2] += (double)cur[0][0][r] - (double)__fmul_rn(cur[0][2][r], mk2);
-            if (STATS) fmax_ = fmaxf(fmax_, cur[0][0][r]);       // halo, idle columns and clamped rows are pixels of the frame too
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) P[q * BS_B + r] = S[q];
-        }
-        // warm-up rows (no window complete yet) only feed the vertical sums: uniform skip of the horizontal pass
-        if (l0 + BS_B <= (MODE == 0 ? R + R2 : 2 * R)) continue;
-        wave_incl_scan_f64(P);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-            for (int r = 0; r < BS_B; ++r) {
-                s_p[q][r][tid] = P[q * BS_B + r];
-                if (lane == 63) s_tot[q][r][wave] = P[q * BS_B + r];
+            for (int q = 0; q < NQ; ++q) {
+                s_v[((q * BB + r) * 2 + 0) * BX_VW + pv] = S[q][0];
+                s_v[((q * BB + r) * 2 + 1) * BX_VW + pv] = S[q][1];
             }
         }
         __syncthreads();
-        if (writer) {
+        {
+            const int l = l0 + t_r;
+            const int oy = oy0 + l - 2 * R;                                       // k-window centred here is complete
+            const bool emit = t_on && l >= 2 * R && l < nsteps;
+            const int oy2 = oy0 + l - R - R2;                                     // MODE 0: k2-window centred here is complete
+            const bool emit2 = MODE == 0 && t_on && l >= R + R2 && oy2 < oy0 + ohe;
+            // window sums of quantity q over virtual columns [c0 + i + off, c0 + i + off + kk), i = 0 .. 7, by sliding; each sum
+            // is handed to `use` as soon as it exists (no array of float64 sums stays live)
+            auto slide = [&](int q, int off, int kk, auto&& use) {
+                const double* v = vb + q * QS;
+                // (four partial sums: a chain of 29 dependent float64 additions is ~300 cycles a wave cannot hide;
+                // compile-time bounds for the shipped k)
+                double wsum = 0.0;
+                if constexpr (KT > 0) {
+                    double ps[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < BS_B; ++r) {
-                const int l = l0 + r;
-                // window sum of quantity q with radius rad around this thread's column
-                auto win = [&](int q, int rad) -> double {
-                    // Q[hi] - Q[lo] with Q = in-wave prefix + totals of the waves before: hi and lo are at most
-                    // one wave apart (2 * rad + 1 <= 29 < 64), so the totals cancel except for the wave of lo
-                    const int hi = tid + rad, lo = tid - rad - 1;
-                    double d = s_p[q][r][hi];
-                    if (lo >= 0) {
-                        d -= s_p[q][r][lo];
-                        if ((hi >> 6) != (lo >> 6)) d += s_tot[q][r][lo >> 6];
-                    }
-                    return d;
-                };
-                const int oy = oy0 + l - 2 * R;                                   // k-window centred here is complete
-                if (l >= 2 * R && l < nsteps) {
-                    const size_t idx = ((size_t)plane * h + oy) * w + ox;
-                    if (MODE == 0) {
-                        const float m = blur_round(win(0, R), k);
-                        const float sd = std_from(m, blur_round(win(1, R), k));
-                        o0[idx] = m;
-                        o1[idx] = __fmul_rn(sd, sd);                              // var = lr_rggb_k**2 (YOND_SIDD.py:72)
-                    } else if (MODE == 1) {
-                        o0[idx] = std_from(blur_round(win(0, R), k), blur_round(win(1, R), k));
-                    } else {
-                        const float sl = std_from(blur_round(win(0, R), k), blur_round(win(1, R), k));
-                        const float mh = blur_round(win(2, R), k);
-                        const float sh = std_from(mh, blur_round(win(3, R), k));
-                        o0[idx] = mh;                                              // mean = blur(hr) (YOND_SIDD.py:97)
-                        o1[idx] = __fsub_rn(__fmul_rn(sl, sl), __fmul_rn(sh, sh));  // var = lr_k**2 - hr_k**2 (:96)
-                        o2[idx] = sh;                                              // img_lap = hr_k (:98)
-                    }
+                    for (int d = off; d < off + kk; ++d) ps[(d - off) & 3] += v[d + (d >> 3)];
+                    wsum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+                } else {
+                    for (int d = off; d < off + kk; ++d) wsum += v[d + (d >> 3)];
                 }
+                use(0, wsum);
+#pragma unroll
+                for (int i = 1; i < BX_C; ++i) {
+                    const int de = off + kk + i - 1, dl = off + i - 1;
+                    wsum += v[de + (de >> 3)] - v[dl + (dl >> 3)];
+                    use(i, wsum);
+                }
+                // one window at a time: with the LDS reads of the next window hoisted above this point the kernel does not fit
+                // the 128 registers of four waves per SIMD
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (emit) {
+                const size_t idx = ((size_t)t_plane * h + oy) * w + ox0 + c0;
+                float r0[BX_C], r1[BX_C], r2[BX_C];
                 if (MODE == 0) {
-                    const int oy2 = oy0 + l - R - R2;                             // k2-window centred here is complete
-                    if (l >= R + R2 && oy2 < oy0 + ohe)
-                        o2[((size_t)plane * h + oy2) * w + ox] = blur_round(win(2, R2), k2);
+                    slide(0, 0, k, [&](int i, double ws) { r0[i] = blur_round(ws, k); });
+                    slide(1, 0, k, [&](int i, double ws) {
+                        const float sd = std_from(r0[i], blur_round(ws, k));
+                        r1[i] = __fmul_rn(sd, sd);                                 // var = lr_rggb_k**2 (YOND_SIDD.py:72)
+                    });
+                    box_store8(o0 + idx, r0, nvalid, vec_ok);
+                    box_store8(o1 + idx, r1, nvalid, vec_ok);
+                } else if (MODE == 1) {
+                    slide(0, 0, k, [&](int i, double ws) { r1[i] = blur_round(ws, k); });
+                    slide(1, 0, k, [&](int i, double ws) { r0[i] = std_from(r1[i], blur_round(ws, k)); });
+                    box_store8(o0 + idx, r0, nvalid, vec_ok);
+                } else {
+                    // the two frames one after the other (a loop the compiler may not unroll): noisy -> sl^2, denoised -> mh, sh
+#pragma unroll 1
+                    for (int pass = 0; pass < 2; ++pass) {
+                        slide(2 * pass, 0, k, [&](int i, double ws) { r0[i] = blur_round(ws, k); });          // mean = blur(hr) (YOND_SIDD.py:97)
+                        slide(2 * pass + 1, 0, k, [&](int i, double ws) {
+                            const float sd = std_from(r0[i], blur_round(ws, k));
+                            const float sq = __fmul_rn(sd, sd);
+                            r1[i] = pass == 0 ? sq : __fsub_rn(r1[i], sq);                                     // var = lr_k**2 - hr_k**2 (:96)
+                            r2[i] = sd;                                                                        // img_lap = hr_k (:98)
+                        });
+                    }
+                    box_store8(o0 + idx, r0, nvalid, vec_ok);
+                    box_store8(o1 + idx, r1, nvalid, vec_ok);
+                    box_store8(o2 + idx, r2, nvalid, vec_ok);
                 }
+            }
+            if (emit2) {
+                float r2[BX_C];
+                slide(2, R - R2, k2, [&](int i, double ws) { r2[i] = blur_round(ws, k2); });
+                box_store8(o2 + ((size_t)t_plane * h + oy2) * w + ox0 + c0, r2, nvalid, vec_ok);
             }
         }
         __syncthreads();
     }
     if constexpr (STATS) {
         fmax_ = wave_max(fmax_);
-        // ~4000 waves, one word: look first (a coherent load) -- after the first few arrivals nearly nobody has to write
-        if (lane == 0 && fmax_ > -INFINITY) {
+        // a few thousand waves, one word: look first (a coherent load) -- after the first few arrivals nearly nobody has to write
+        if ((tid & 63) == 0 && fmax_ > -INFINITY) {
             const unsigned int key = f2key(fmax_);
             if (key > __hip_atomic_load(&st->frame_max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->frame_max_key, key);
         }
@@ -235,9 +283,26 @@ __global__ __launch_bounds__(BS_T) void box_stream_kernel(BoxSrc a, BoxSrc b, Bo
 static int box_args_ok(int h, int w, int k, int tile_w) {
     if (h < 1 || w < 1) return YOND_EINVAL;
     if (k < 1 || !(k & 1)) return YOND_EINVAL;
-    if (k > 2 * BS_MAXR + 1) return YOND_EUNSUPPORTED;
+    if (k > 2 * BX_MAXR + 1) return YOND_EUNSUPPORTED;
     if (tile_w < 0) return YOND_EINVAL;
     if (tile_w > 0 && w % tile_w != 0) return YOND_EUNSUPPORTED;
+    return YOND_OK;
+}
+
+template <int MODE, int KT, int K2T, bool STATS, int BB>
+static int launch_box_k(const BoxSrc& a, const BoxSrc& b, const BoxGeom& g, dim3 grid, float* o0, float* o1, float* o2, hipStream_t st,
+                        NleState* state) {
+    constexpr int NQ = MODE == 0 ? 3 : (MODE == 1 ? 2 : 4);
+    constexpr size_t smem = (size_t)NQ * BB * 2 * BX_VW * sizeof(double);
+    static bool attr_set = false;
+    auto kern = box_slide_kernel<MODE, KT, K2T, STATS, BB>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(BX_T), smem, st, a, b, g, o0, o1, o2, state);
+    YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
 
@@ -249,23 +314,25 @@ static int launch_box(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_
     g.h = h; g.w = w; g.k = k; g.k2 = k2; g.tile_w = tile_w;
     const int bw = tile_w > 0 ? tile_w : w;
     const int nblk = w / bw;
-    const int maxow = BS_T - 2 * (k / 2);
+    const int maxow = ((BX_T - 2 * (k / 2)) / BX_C) * BX_C;      // whole chunks
     g.nstrip = (bw + maxow - 1) / maxow;
-    g.ow_nom = (bw + g.nstrip - 1) / g.nstrip;
-    // row segments: about four workgroups per CU in one round; longer segments re-read fewer halo rows
-    const long target = yond_exp_long("YOND_BOX_WGS", 1024);
-    const long cols = 4L * nblk * g.nstrip;
+    g.ow_nom = (((bw + g.nstrip - 1) / g.nstrip) + BX_C - 1) / BX_C * BX_C;
+    if (g.ow_nom > maxow) g.ow_nom = maxow;
+    // row segments: one round of the workgroups the chip holds (two per CU); longer segments re-read fewer halo rows
+    const long target = yond_exp_long("YOND_BOX_WGS", MODE == 1 ? 1024 : 512);
+    const long cols = 2L * nblk * g.nstrip;
     long nseg = (target + cols / 2) / cols;
     if (nseg < 1) nseg = 1;
     g.oh = (int)((h + nseg - 1) / nseg);
     if (g.oh < 16) g.oh = 16;
-    if (g.oh > BS_MAXOH) g.oh = BS_MAXOH;
     if (g.oh > h) g.oh = h;
     const int nsy = (h + g.oh - 1) / g.oh;
-    dim3 grid((unsigned)(nblk * g.nstrip), (unsigned)nsy, 4);
-    hipLaunchKernelGGL((box_stream_kernel<MODE, STATS>), grid, dim3(BS_T), 0, st, a, b, g, o0, o1, o2, state);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
+    dim3 grid((unsigned)(nblk * g.nstrip), (unsigned)nsy, 2);
+    // rows per batch: 4 (LDS per workgroup 55 / 37 / 74 KB: two / four / two workgroups per CU).  Two rows per batch and more
+    // workgroups measured slower (self stage 1: 101 us against 70): the task phase is latency bound per wave, and half the lanes idle
+    constexpr int BB = 4;
+    if (k == 29 && (MODE != 0 || k2 == 19)) return launch_box_k<MODE, 29, 19, STATS, BB>(a, b, g, grid, o0, o1, o2, st, state);
+    return launch_box_k<MODE, 0, 0, STATS, BB>(a, b, g, grid, o0, o1, o2, st, state);
 }
 
 extern "C" int yond_box_stats_self1_f32(const float* bayer, int H, int W, int k, int k2, int tile_w, float* mean,

@@ -418,6 +418,10 @@ int yond_conv_wgrad_f32(const float* x, const float* dy, int N, int H, int W, in
                         int stride, float* dw, void* stream);
 int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, void* stream);
 int yond_l1_loss_f32(const float* pred, const float* target, size_t n, double* loss_sum, float* grad /* or NULL */, void* stream);
+/* L1_Charbonnier_loss (losses/base_loss.py:69-79; Unet_Loss(charbonnier=True), :82-85): loss_sum = sum sqrt(diff^2 + eps),
+ * grad = diff / sqrt(diff^2 + eps) / n in the float32 steps of torch's backward */
+int yond_charbonnier_loss_f32(const float* pred, const float* target, size_t n, double eps, double* loss_sum, float* grad /* or NULL */,
+                              void* stream);
 int yond_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps,
                        int step, void* stream);
 

@@ -472,9 +472,83 @@ def gen_rot(ref):
     save("rot", **out)
 
 
+SCHED_HYPERS = [
+    {'learning_rate': 2e-4, 'lr_scheduler': 'WarmupCosine', 'step_size': 5, 'stop_epoch': 40, 'last_epoch': 0, 'T': 2, 'coldstart': False},
+    {'learning_rate': 1e-4, 'lr_scheduler': 'WarmupCosine', 'step_size': 8, 'stop_epoch': 30, 'last_epoch': 0},
+    {'learning_rate': 3e-4, 'lr_scheduler': 'MultiStepLR', 'step_size': 10, 'stop_epoch': 60, 'last_epoch': 0, 'T': 2},
+]
+
+
+def sched_run_case():
+    """Batches of the two-epoch run (regenerated from seeds by the tests): 2 epochs x 2 batches of two 4 x 32 x 32 patches."""
+    g = torch.Generator().manual_seed(77)
+    batches = []
+    for _ in range(4):
+        hr = torch.rand((2, 4, 32, 32), generator=g) * 0.8 + 0.05
+        sigma = (torch.rand((2, 1, 1, 1), generator=g) * 0.1 + 0.02)
+        lr = (hr + torch.randn((2, 4, 32, 32), generator=g) * sigma).clamp(0, 1)
+        batches.append((lr, hr, sigma))
+    hyper = {'learning_rate': 1e-3, 'lr_scheduler': 'WarmupCosine', 'step_size': 1, 'stop_epoch': 4, 'last_epoch': 0, 'coldstart': False}
+    return batches, hyper, ARCHS["gru8"], O.procedural_state_dict(ARCHS["gru8"], 23)
+
+
+def gen_train_sched(ref):
+    """N4: the reference's learning-rate schedules (trainer_base.py:34-46, 138-167, through its own LambdaScheduler and
+    Base_Trainer.get_lr_lambda_func), two epochs of its training loop (trainer_AWGN.py:78-155: step per batch, scheduler.step()
+    per epoch) and its Charbonnier loss (losses/base_loss.py:69-79) with autograd's gradient."""
+    import types
+    from torch.optim import Adam
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        import trainer_base as TB
+    finally:
+        os.chdir(cwd)
+    out = {}
+    for i, h in enumerate(SCHED_HYPERS):
+        lam = TB.Base_Trainer.get_lr_lambda_func(types.SimpleNamespace(hyper=dict(h)))
+        opt = Adam([torch.nn.Parameter(torch.zeros(1))], lr=h['learning_rate'])
+        sch = TB.LambdaScheduler(opt, lam)
+        lrs = []
+        for _ in range(h['stop_epoch'] + 5):
+            lrs.append(sch.get_last_lr()[0])
+            opt.step()
+            sch.step()
+        out[f"lrs_{i}"] = np.asarray(lrs, np.float64)
+    batches, hyper, arch, sd = sched_run_case()
+    net = getattr(ref, arch['name'])(dict(arch))
+    net = ref.load_weights(net, sd, by_name=False).train()
+    opt = Adam(net.parameters(), lr=hyper['learning_rate'])
+    sch = TB.LambdaScheduler(opt, TB.Base_Trainer.get_lr_lambda_func(types.SimpleNamespace(hyper=dict(hyper))))
+    loss_fn = ref.Unet_Loss()
+    losses, lrs = [], []
+    for epoch in range(2):
+        lrs.append(sch.get_last_lr()[0])
+        for b in batches[2 * epoch:2 * epoch + 2]:
+            opt.zero_grad()
+            loss = loss_fn(net(b[0], b[2]), b[1])
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        sch.step()
+    out["run_losses"], out["run_lrs"] = np.asarray(losses), np.asarray(lrs)
+    for k, p_ in net.named_parameters():
+        out[f"run_w/{k}"] = grad_sample(k, p_.detach().numpy())
+    print(f"two epochs: losses {losses}, lrs {lrs}")
+    g = torch.Generator().manual_seed(5)
+    pred = torch.rand((2, 4, 16, 16), generator=g, requires_grad=True)
+    tgt = torch.rand((2, 4, 16, 16), generator=g)
+    with torch.no_grad():
+        tgt[0, 0, 0, :4] = pred[0, 0, 0, :4]                  # diff = 0: error = sqrt(eps)
+    closs = ref.Unet_Loss(charbonnier=True)(pred, tgt)
+    closs.backward()
+    out["charb_loss"], out["charb_grad"] = np.array(float(closs)), pred.grad.numpy().copy()
+    save("train_sched", **out)
+
+
 GENS = dict(rot=gen_rot, pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
             vst_denoiser=gen_vst_denoiser, iter=gen_iter, biaslut=gen_biaslut, ssim=gen_ssim, nle_full=gen_nle_full,
-            iter_full=gen_iter_full, train=gen_train)
+            iter_full=gen_iter_full, train=gen_train, train_sched=gen_train_sched)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

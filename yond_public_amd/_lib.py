@@ -84,6 +84,7 @@ PROTOTYPES = {
     "yond_conv_wgrad_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "yond_colsum_f32": [vp, sz, i32, vp, vp],
     "yond_l1_loss_f32": [vp, vp, sz, vp, vp, vp],
+    "yond_charbonnier_loss_f32": [vp, vp, sz, f64, vp, vp, vp],
     "yond_adam_step_f32": [vp, vp, vp, vp, sz, f64, f64, f64, f64, i32, vp],
     "yond_frame_params_f64": [vp, vp, i32, f64, f64, f64, i32, vp, vp, vp, vp],
     "yond_bias_lut_dev_f64": [vp, i32, vp, vp, vp],

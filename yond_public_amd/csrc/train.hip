@@ -145,6 +145,42 @@ extern "C" int yond_l1_loss_f32(const float* pred, const float* target, size_t n
     return YOND_OK;
 }
 
+// L1_Charbonnier_loss (losses/base_loss.py:69-79): error = sqrt(diff * diff + eps), loss = mean(error); the gradient in the
+// float32 steps of torch's backward: grad_u = (1 / n) / (2 error) through the sqrt, then grad_u * diff from EACH operand of
+// diff * diff, summed
+__global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restrict__ pred, const float* __restrict__ target, size_t n, float eps,
+                                                          float gscale, double* __restrict__ loss_sum, float* __restrict__ grad) {
+    __shared__ double s_red[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = __fsub_rn(pred[i], target[i]);
+        const float e = __fsqrt_rn(__fadd_rn(__fmul_rn(d, d), eps));
+        acc += (double)e;
+        if (grad) {
+            const float gu = __fdiv_rn(gscale, __fmul_rn(2.0f, e));
+            const float t = __fmul_rn(gu, d);
+            grad[i] = __fadd_rn(t, t);
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+extern "C" int yond_charbonnier_loss_f32(const float* pred, const float* target, size_t n, double eps, double* loss_sum, float* grad,
+                                         void* stream) {
+    if (!pred || !target || !loss_sum || n == 0 || !(eps > 0.0)) return YOND_EINVAL;
+    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    size_t nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(charbonnier_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pred, target, n, (float)eps,
+                       1.0f / (float)n, loss_sum, grad);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
 // torch.optim.Adam.step (single tensor, no weight decay, no amsgrad), float32 state as torch keeps it:
 //   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

@@ -17,7 +17,7 @@ def env_world():
 
 # collectives this process has issued through this module (tests and bench.py report it: a one-rank torchrun job
 # exercises the same RCCL calls as an eight-rank one)
-STATS = {"all_reduce": 0, "barrier": 0, "backend": None}
+STATS = {"all_reduce": 0, "barrier": 0, "broadcast": 0, "grad_all_reduce": 0, "grad_bytes": 0, "backend": None}
 
 
 def launched_by_torchrun():
@@ -119,6 +119,99 @@ def max_over_ranks(x, device=None):
         STATS["all_reduce"] += 1
         return float(t.item())
     return float(x)
+
+
+class GradReducer:
+    """The gradient exchange of data-parallel training: the reference wraps the network in
+    torch's DistributedDataParallel (trainer_AWGN.py:59-61), i.e. every rank computes the gradient of the mean loss of ITS
+    batch and the ranks' gradients are AVERAGED before the optimiser step.  Here explicitly: the parameters are laid out, in
+    reverse registration order (the order backward produces their gradients in), in flat float32 buckets of `bucket_bytes`
+    (DDP's default 25 MB: GuidedResUnet's 44.7 MB of gradients are two ring all-reduces -- on xGMI a ring is bound by one
+    link's ~153 GB/s, so few large messages, not many small ones); a bucket's all-reduce (RCCL with backend "nccl", gloo in
+    the CPU tests) is launched asynchronously from the hook of its last gradient, while backward is still producing the
+    earlier layers' gradients; `finish()` waits, divides by the world size and points every .grad at its slice.
+    Without a process group it leaves the gradients where they are."""
+
+    def __init__(self, params, bucket_bytes=25 * 2 ** 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = dist.get_world_size() if _active() else 1
+        self.buckets = []                                   # [flat tensor, [(param, offset, numel)], pending count, work handle]
+        cur, cur_n = [], 0
+        for p in reversed(self.params):
+            if cur and (cur_n + p.numel()) * 4 > bucket_bytes:
+                self.buckets.append(self._make(cur, cur_n))
+                cur, cur_n = [], 0
+            cur.append((p, cur_n, p.numel()))
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(self._make(cur, cur_n))
+        self.where = {}
+        for bi, b in enumerate(self.buckets):
+            for p, off, n in b["items"]:
+                self.where[id(p)] = (bi, off, n)
+        self.hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in self.params] if _active() else []
+
+    @staticmethod
+    def _make(items, n):
+        dev = items[0][0].device
+        return {"flat": torch.zeros(n, dtype=torch.float32, device=dev), "items": list(items), "pending": len(items), "work": None}
+
+    def begin(self):
+        """Start of a step: nothing reduced yet."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"], b["work"] = len(b["items"]), None
+
+    def _launch(self, b):
+        b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+        STATS["all_reduce"] += 1
+        STATS["grad_all_reduce"] += 1
+        STATS["grad_bytes"] += b["flat"].numel() * 4
+
+    def _ready(self, p):
+        bi, off, n = self.where[id(p)]
+        b = self.buckets[bi]
+        b["flat"][off:off + n].copy_(p.grad.reshape(-1))
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def finish(self):
+        """After backward: launch what is still waiting (a parameter without a gradient contributes zeros), wait for the
+        reductions, average, and hand every parameter its slice as .grad."""
+        if not _active():
+            return
+        for b in self.buckets:
+            if b["work"] is None:
+                self._launch(b)
+        for b in self.buckets:
+            b["work"].wait()
+            if self.world > 1:
+                b["flat"].mul_(1.0 / self.world)
+            for p, off, n in b["items"]:
+                p.grad = b["flat"][off:off + n].view_as(p)
+
+    def remove(self):
+        for h in self.hooks:
+            h.remove()
+        self.hooks = []
+
+
+def broadcast_params(params, src=0):
+    """Every rank starts from rank `src`'s weights (what DistributedDataParallel does when it wraps a module)."""
+    if not _active():
+        return
+    ps = [p for p in params]
+    if not ps:
+        return
+    flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in ps])
+    dist.broadcast(flat, src=src)
+    STATS["broadcast"] += 1
+    off = 0
+    with torch.no_grad():
+        for p in ps:
+            p.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
 
 
 def finalize():

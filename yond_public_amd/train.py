@@ -1,8 +1,11 @@
-"""N4, first slice: one training step of the AWGN raw denoiser on the MI355X kernels.
+"""N4: the training step of the AWGN raw denoiser on the MI355X kernels, its learning-rate schedule, the epoch loop and the
+data-parallel gradient exchange.
 
     trainer_AWGN.py:101-117      pred = net(imgs_lr, sigma); loss = Unet_Loss()(pred, imgs_hr); loss.backward(); optimizer.step()
-    losses/base_loss.py:81-113   Unet_Loss = F.l1_loss
+    losses/base_loss.py:69-113   Unet_Loss = F.l1_loss, or L1_Charbonnier_loss with charbonnier=True
     trainer_AWGN.py:36           Adam(net.parameters(), lr)
+    trainer_base.py:34-46, 138-167   LambdaScheduler over get_cos_lr / get_multistep_lr, stepped once per epoch (trainer_AWGN.py:56-57, 153)
+    trainer_AWGN.py:59-61        DistributedDataParallel: gradients averaged over the ranks (distributed.GradReducer, RCCL over xGMI)
 
 `TrainStep` runs GuidedResUnet's forward (archs/Unet.py:424-470) on NHWC float32 device tensors whose channels are padded
 to multiples of 32, with every convolution -- forward, data gradient and weight gradient -- on the HIP kernels:
@@ -13,9 +16,13 @@ to multiples of 32, with every convolution -- forward, data gradient and weight 
   * loss and optimiser: yond_l1_loss_f32, yond_adam_step_f32.
 torch.autograd only strings the layers together (custom Functions) and differentiates the elementwise glue (SiLU, LeakyReLU,
 FiLM scale / shift and its three tiny sigma-MLPs, residual adds), which is <0.1 % of the step's arithmetic.
-Scope of the slice: GuidedResUnet / fp32 / one GPU; weights are re-packed on the host every step (fine at nf = 8 ... 32; a
-production loop would keep packed weights resident); DDP's gradient all-reduce (trainer_base.py:117-125) is not wired yet.
-Pinned by tests/golden/train.npz: loss, gradients and updated weights of the reference's own step on the same inputs."""
+Scope: GuidedResUnet / fp32; weights are re-packed on the host every step (fine at nf = 8 ... 32; a production loop would keep
+packed weights resident).  Data-parallel: one process per GPU, every rank steps on its own batches, `GradReducer` averages the
+gradients in two 25 MB buckets launched from backward's hooks (the only collective of training: 44.7 MB per step).
+Pinned by tests/golden/train.npz (loss, gradients and updated weights of the reference's own step on the same inputs) and
+tests/golden/train_sched.npz (the reference's schedules, a two-epoch run of its loop, its Charbonnier loss)."""
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -172,14 +179,23 @@ class _ConvT2x2(torch.autograd.Function):
 class TrainStep:
     """One optimisation step of a yond_public_amd.archs.GuidedResUnet (parameter names / shapes of the reference)."""
 
-    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, charbonnier=False, ddp=None):
+        """charbonnier: Unet_Loss(charbonnier=True) (losses/base_loss.py:82-85).  ddp: None -- average the gradients over the
+        ranks whenever a process group exists (the reference wraps the net in DDP whenever it sees more than one GPU,
+        trainer_AWGN.py:59-61); False -- never."""
+        from . import distributed as D
         self.m = module
         self.dev = next(module.parameters()).device
         self.plan = _plan(self.dev)
         self.lr, self.betas, self.eps = lr, betas, eps
+        self.charbonnier = bool(charbonnier)
         self.params = dict(module.named_parameters())
         self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in self.params.items()}
         self.t = 0
+        self.reducer = None
+        if ddp is not False and D._active():
+            D.broadcast_params(self.params.values(), src=0)         # DDP's constructor: every rank starts from rank 0's weights
+            self.reducer = D.GradReducer(self.params.values())
 
     # -- forward on padded NHWC tensors ------------------------------------------------------------------------------
     def _block(self, pre, x, xs, t, cp):
@@ -237,12 +253,20 @@ class TrainStep:
         lib = self.plan.lib
         for p in self.params.values():
             p.grad = None
+        if self.reducer is not None:
+            self.reducer.begin()
         pred = self.forward(imgs_lr, sigma).contiguous()
         tgt = imgs_hr.contiguous()
         loss_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
         dpred = torch.empty_like(pred)
-        L.check(lib.yond_l1_loss_f32(L.ptr(pred), L.ptr(tgt), pred.numel(), L.ptr(loss_sum), L.ptr(dpred), L.stream()), "yond_l1_loss_f32")
-        pred.backward(dpred)
+        if self.charbonnier:
+            L.check(lib.yond_charbonnier_loss_f32(L.ptr(pred), L.ptr(tgt), pred.numel(), 1e-6, L.ptr(loss_sum), L.ptr(dpred), L.stream()),
+                    "yond_charbonnier_loss_f32")
+        else:
+            L.check(lib.yond_l1_loss_f32(L.ptr(pred), L.ptr(tgt), pred.numel(), L.ptr(loss_sum), L.ptr(dpred), L.stream()), "yond_l1_loss_f32")
+        pred.backward(dpred)                                 # (the reducer's hooks launch a bucket's all-reduce as its last gradient lands)
+        if self.reducer is not None:
+            self.reducer.finish()                            # .grad = the mean over the ranks
         self.t += 1
         grads = {}
         for k, p in self.params.items():
@@ -254,3 +278,86 @@ class TrainStep:
                                            self.betas[1], self.eps, self.t, L.stream()), "yond_adam_step_f32")
         self.m._plan = None                                  # the inference plan's packed weights are stale now
         return float(loss_sum.item()) / pred.numel(), grads
+
+
+# -- learning-rate schedule (trainer_base.py:34-46, 138-167) -------------------------------------------------------------
+def get_cos_lr(step, period=1000, peak=20, lr=1e-4, ratio=0.4, coldstart=False):
+    """WarmUpCosine (trainer_base.py:148-157): linear warm-up over `peak` steps (skipped in the first period of a cold start),
+    cosine decay to `ratio`, the whole halved every period."""
+    T = step // period
+    decay = 2 ** T
+    step = step % period
+    if step <= peak and (not coldstart or T > 0):
+        mul = step / peak
+    else:
+        mul = (1 - ratio) * (np.cos((step - peak) / (period - peak) * math.pi) * 0.5 + 0.5) + ratio
+    return lr * mul / decay
+
+
+def get_multistep_lr(step, period=1000, lr=1e-4, milestone=(500, 900), gamma=(0.5, 0.1), decay_base=1):
+    """trainer_base.py:159-167."""
+    decay = decay_base ** (step // period)
+    step = step % period
+    mul = 1
+    for i in range(len(milestone), 0, -1):
+        if step > milestone[i - 1]:
+            mul = gamma[i - 1]
+            break
+    return lr * mul / decay
+
+
+def lr_lambda(hyper):
+    """Base_Trainer.get_lr_lambda_func (trainer_base.py:34-46) on the runfile's `hyper` block."""
+    num_of_epochs = hyper['stop_epoch'] - hyper['last_epoch']
+    step_size = hyper['step_size']
+    T = hyper['T'] if 'T' in hyper else 1
+    coldstart = True if 'coldstart' not in hyper else hyper['coldstart']
+    kind = hyper['lr_scheduler'].lower()
+    if 'cos' in kind:
+        return lambda x: get_cos_lr(x, period=num_of_epochs // T, lr=hyper['learning_rate'], peak=step_size, coldstart=coldstart)
+    if 'multi' in kind:
+        return lambda x: get_multistep_lr(x, period=num_of_epochs // T, decay_base=1, milestone=[step_size, step_size * 9 // 5],
+                                          gamma=[0.5, 0.1], lr=hyper['learning_rate'])
+    raise NotImplementedError(hyper['lr_scheduler'])
+
+
+class LambdaScheduler:
+    """trainer_base.py:138-146: torch's LambdaLR with get_lr = lmbda(last_epoch) -- the lambda returns the learning rate ITSELF,
+    not a factor of the optimiser's base rate.  Constructed at last_epoch 0; step() once per epoch (trainer_AWGN.py:153)."""
+
+    def __init__(self, train_step, lmbda):
+        self.ts, self.lmbda, self.last_epoch = train_step, lmbda, 0
+        self.ts.lr = float(self.lmbda(0))
+
+    def get_last_lr(self):
+        return [self.ts.lr]
+
+    def step(self):
+        self.last_epoch += 1
+        self.ts.lr = float(self.lmbda(self.last_epoch))
+
+
+class Trainer:
+    """The epoch loop of trainer_AWGN.py:78-155 over in-memory batches (data synthesis, checkpoints and plots stay out of scope):
+    per epoch every batch is one TrainStep.step, then scheduler.step(); with a process group every rank runs its own batches and
+    the gradients are averaged (DDP)."""
+
+    def __init__(self, module, hyper, charbonnier=False, ddp=None):
+        self.hyper = dict(hyper)
+        self.ts = TrainStep(module, lr=hyper['learning_rate'], charbonnier=charbonnier, ddp=ddp)
+        self.scheduler = LambdaScheduler(self.ts, lr_lambda(self.hyper))
+        self.history = []                                    # (epoch, learning rate, [losses])
+
+    def train(self, batches, epochs=None):
+        """batches: callable(epoch) -> iterable of (imgs_lr, imgs_hr, sigma) for THIS rank."""
+        from . import distributed as D
+        first = self.hyper['last_epoch'] + 1
+        last = self.hyper['stop_epoch'] if epochs is None else first + epochs - 1
+        for epoch in range(first, last + 1):
+            D.barrier()                                      # trainer_AWGN.py:85
+            lr = self.scheduler.get_last_lr()[0]
+            losses = [self.ts.step(*b)[0] for b in batches(epoch)]
+            self.scheduler.step()
+            D.barrier()                                      # :155
+            self.history.append((epoch, lr, losses))
+        return self.history

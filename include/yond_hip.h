@@ -26,7 +26,7 @@ extern "C" {
 #define YOND_EUNSUPPORTED (-2) /* valid request the kernels do not cover (e.g. channel count) */
 
 /* Library / device probe.  Returns the ABI version (this header: YOND_ABI_VERSION; the loader refuses a mismatch). */
-#define YOND_ABI_VERSION 3
+#define YOND_ABI_VERSION 4
 int yond_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -176,6 +176,10 @@ typedef struct YondConvDesc {
        elapsed 100 MHz reference ticks (s_memrealtime) to clk[1]: over many launches clk[0] / clk[1] * 100 MHz is the clock the
        chip really held inside these kernels (bench.py `gfx_clock.in_kernel_mhz`).  Two counter reads and two atomics per launch. */
     unsigned long long* clk;
+    /* Order in which the persistent workgroups of algo 3 / 4 walk the pixel tiles: 0 first row of tiles to last, 1 last to
+       first.  A chain of memory-bound layers alternates it: the consumer then starts with the rows its producer wrote (and read)
+       LAST, which are still in the 256 MB Infinity Cache, instead of the rows that were evicted first.  Results do not depend on it. */
+    int tile_order;
 } YondConvDesc;
 #define YOND_STATUS_HALF_OVERFLOW 1u
 #define YOND_FMT_NHWC_F32 0

@@ -9,13 +9,13 @@ arch = dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes
 net = A.GuidedResUnet(dict(arch)); net.load_state_dict(S.procedural_state_dict(net, 0)); net = net.to('cuda').eval()
 plan = P._plan_of(net, torch.device('cuda'))
 x = torch.rand(1, 1504, 2016, 4, device='cuda'); t = torch.full((1,), 0.03, device='cuda'); ub = x.reshape(1, -1).max(1).values.contiguous()
-CFG = {'nhwc': (False, False), 'tmp': (True, False), 'flow': (True, True)}
+CFG = {'nhwc': (False, False, False), 'tmp': (True, False, False), 'flow': (True, True, False), 'snake': (True, True, True)}   # snake: alternating tile order
 names = sys.argv[1:] or list(CFG)
 ref = None
 acc = {n: {} for n in names}
 for rep in range(9):
     for n in names:
-        E.SPLIT_PLANES, E.SP_FLOW = CFG[n]
+        E.SPLIT_PLANES, E.SP_FLOW, E.SNAKE_ORDER = CFG[n]
         plan.prof = [] if rep >= 2 else None
         y = plan.forward_nhwc4(x, t, ub=ub)
         torch.cuda.synchronize()

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOND_HIP_LIB", os.path.join(_HERE, "libyond_hip.so"))   # override: experiments only
 _lib = None
-ABI_VERSION = 3                     # include/yond_hip.h YOND_ABI_VERSION
+ABI_VERSION = 4                     # include/yond_hip.h YOND_ABI_VERSION
 
 vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 
@@ -23,7 +23,7 @@ class YondConvDesc(C.Structure):
                 ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
                 ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32),
                 ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp), ("status", vp),
-                ("in_fmt", i32), ("out_fmt", i32), ("res_fmt", i32), ("clk", vp)]
+                ("in_fmt", i32), ("out_fmt", i32), ("res_fmt", i32), ("clk", vp), ("tile_order", i32)]
 
 
 class YondFilmDesc(C.Structure):

@@ -203,12 +203,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         c.ty = b % nty; c.n = b / nty;
         return c;
     };
+    // (YondConvDesc.tile_order 1: the spatial digits are complemented -- the same tiles, last row of tiles first)
+    const bool rev = d.tile_order != 0;
     auto decode = [&](const Cur& c, Tile& T) {
-        const int n = c.n;
+        const int n = rev ? d.N - 1 - c.n : c.n;
         T.n = n;
         T.ct = c.ct;
-        T.ox0 = c.tx * 32;
-        T.oy0 = c.ty * TH;
+        T.ox0 = (rev ? ntx - 1 - c.tx : c.tx) * 32;
+        T.oy0 = (rev ? nty - 1 - c.ty : c.ty) * TH;
         if constexpr (ISP) {
 #pragma unroll
             for (int k = 0; k < NDI; ++k) {
@@ -1043,10 +1045,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             SDBG(7);
             zero_acc();
             if (cn.tile < total) {
-                cur.n = cn.n;
+                cur.n = rev ? d.N - 1 - cn.n : cn.n;
                 cur.ct = cn.ct;
-                cur.ox0 = cn.tx * 32;
-                cur.oy0 = cn.ty * TH;
+                cur.ox0 = (rev ? ntx - 1 - cn.tx : cn.tx) * 32;
+                cur.oy0 = (rev ? nty - 1 - cn.ty : cn.ty) * TH;
             }
         }
         SDBG(5);

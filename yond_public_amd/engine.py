@@ -45,6 +45,8 @@ WINO_DEFAULT = 'split'              # 'split': fp32-accurate split-operand fp16-
 SPLIT_PLANES = True
 SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
 FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
+SNAKE_ORDER = True                  # consecutive split-operand launches walk their tiles in opposite directions (YondConvDesc.tile_order):
+                                    # a consumer starts with what its producer touched last, i.e. what the Infinity Cache still holds
 
 
 def sp_plane_units(H, W):
@@ -349,6 +351,9 @@ class DenoiserPlan:
         status = getattr(self, 'status', None)                       # (bare plans of the kernel tests have none)
         d.status = status.data_ptr() + 4 * self.status_slot if status is not None else None
         d.in_fmt, d.out_fmt, d.res_fmt = in_fmt, out_fmt, res_fmt
+        if SNAKE_ORDER and d.algo in (3, 4):
+            self._tile_order = 1 - getattr(self, '_tile_order', 0)      # (the first layer, conv_in, runs first row to last)
+            d.tile_order = self._tile_order
         clk = getattr(self, 'clk', None)             # bench.py: in-kernel clock of the split-operand launches (int64[2] on the device)
         d.clk = clk.data_ptr() if (clk is not None and d.algo in (3, 4)) else None
         if (in_fmt or out_fmt or res_fmt) and d.algo != 3:
@@ -448,6 +453,7 @@ class DenoiserPlan:
         nets); ub: optional precomputed per-image maximum [N] (K1 provides it).  Returns [N][H][W][4]."""
         L.require_cuda(x4, "x")
         self._fwd_idx = getattr(self, '_fwd_idx', -1) + 1
+        self._tile_order = 0
         N, H, W, c4 = x4.shape
         if c4 != 4 or H % 16 or W % 16:
             raise L.YondHipError(f"input must be [N][H][W][4] with H, W multiples of 16, got {tuple(x4.shape)}")

@@ -9,13 +9,15 @@ arch = dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes
 net = A.GuidedResUnet(dict(arch)); net.load_state_dict(S.procedural_state_dict(net, 0)); net = net.to('cuda').eval()
 plan = P._plan_of(net, torch.device('cuda'))
 x = torch.rand(1, 1504, 2016, 4, device='cuda'); t = torch.full((1,), 0.03, device='cuda'); ub = x.reshape(1, -1).max(1).values.contiguous()
-CFG = {'nhwc': (False, False, False), 'tmp': (True, False, False), 'flow': (True, True, False), 'snake': (True, True, True)}   # snake: alternating tile order
+CFG = {'nhwc': (False, False, False, False), 'tmp': (True, False, False, False), 'flow': (True, True, False, False), 'snake': (True, True, True, False),
+       'sub2': (True, True, True, True)}   # snake: alternating tile order; sub2: + two sub-positions per tile in the 1->0 decoder GEMM
 names = sys.argv[1:] or list(CFG)
 ref = None
 acc = {n: {} for n in names}
+tags = {}
 for rep in range(9):
     for n in names:
-        E.SPLIT_PLANES, E.SP_FLOW, E.SNAKE_ORDER = CFG[n]
+        E.SPLIT_PLANES, E.SP_FLOW, E.SNAKE_ORDER, E.K1_SUB2 = CFG[n]
         plan.prof = [] if rep >= 2 else None
         y = plan.forward_nhwc4(x, t, ub=ub)
         torch.cuda.synchronize()
@@ -24,7 +26,8 @@ for rep in range(9):
             print(n, "max |out - first config| =", float((y - ref).abs().max()))
         if plan.prof:
             for i, (tag, fl, e0, e1) in enumerate(plan.prof):
-                acc[n].setdefault((i, tag), []).append(e0.elapsed_time(e1) * 1e3)
+                acc[n].setdefault(i, []).append(e0.elapsed_time(e1) * 1e3)
+                tags.setdefault(i, tag)
         plan.prof = None
 keys = sorted(acc[names[0]])
 tot = {n: 0.0 for n in names}
@@ -33,5 +36,5 @@ for k in keys:
     row = []
     for n in names:
         v = sorted(acc[n][k]); m = v[len(v) // 2]; tot[n] += m; row.append(m)
-    print("%2d %-31s" % k + "".join("%10.1f" % m for m in row))
+    print("%2d %-31s" % (k, tags[k]) + "".join("%10.1f" % m for m in row))
 print("%-34s" % "sum of conv launches (us)" + "".join("%10.1f" % tot[n] for n in names))

@@ -114,7 +114,20 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
             if (j - (l - 1) <= 0) mlo = 0;
             int mhi = j / pho;
             if (mhi > r) mhi = r;
-            for (int m = mlo; m <= mhi; ++m) cv = fma(s_p[m], s_g[j - pho * m], cv);
+            // eight terms per trip into four partial sums: a rolled loop exposes one LDS round trip and one dependent
+            // float64 FMA per term (up to 174 of them per grid point, three grid points per thread)
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+            int m = mlo;
+            for (; m + 7 <= mhi; m += 8) {
+                const double p0 = s_p[m], p1 = s_p[m + 1], p2 = s_p[m + 2], p3 = s_p[m + 3];
+                const double p4 = s_p[m + 4], p5 = s_p[m + 5], p6 = s_p[m + 6], p7 = s_p[m + 7];
+                const double g0 = s_g[j - pho * m], g1 = s_g[j - pho * (m + 1)], g2 = s_g[j - pho * (m + 2)], g3 = s_g[j - pho * (m + 3)];
+                const double g4 = s_g[j - pho * (m + 4)], g5 = s_g[j - pho * (m + 5)], g6 = s_g[j - pho * (m + 6)], g7 = s_g[j - pho * (m + 7)];
+                c0 = fma(p0, g0, c0); c1 = fma(p1, g1, c1); c2 = fma(p2, g2, c2); c3 = fma(p3, g3, c3);
+                c0 = fma(p4, g4, c0); c1 = fma(p5, g5, c1); c2 = fma(p6, g6, c2); c3 = fma(p7, g7, c3);
+            }
+            for (; m <= mhi; ++m) c0 = fma(s_p[m], s_g[j - pho * m], c0);
+            cv = (c0 + c1) + (c2 + c3);
         } else {
             const int jm = j - c;
             cv = (jm >= 0 && jm % pho == 0) ? s_p[jm / pho] : 0.0;

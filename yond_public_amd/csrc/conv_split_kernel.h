@@ -125,7 +125,11 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 // what the staging below would have written into LDS, stored once by the PRODUCER's epilogue (OSP) with the consumer's
 // pre-activation already applied; the consumer's step then has no vector work at all for its input: 2 x PARTS LDS-DMAs per
 // 16-channel chunk (out-of-image units come from the zero unit behind every plane).  Same bits as staging the fp32 tensor.
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false>
+// S2 (K1 with 32-channel output pixels, split-plane input): a 64-wide channel tile = the TWO sub-positions (dy, 0), (dy, 1) of a
+// low-resolution pixel.  The skip tensor's K range is laid out [channels at dx = 0 | the same channels at dx = 1 | one zero chunk]
+// (descriptor shuffle 2; the weights of a sub-position are zero in the other one's range), so the low-resolution input is
+// staged once for both sub-positions and a tile takes 3 steps where two 32-wide tiles took 4.
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
     // split-plane input: ISPM 1 (ISP) by LDS-DMA, one step ahead -- the layers whose steps are long enough to cover the DMA's
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     constexpr bool ISP = ISPM == 1, ISR = ISPM == 2;
     static_assert(ISPM == 0 || (!PRE && PARTS == 2), "split-plane input: the producer applied the activation; split precision only");
     static_assert(!OSP || (!O4 && !K1 && STRIDE == 1 && PARTS == 2), "split-plane output: 3x3 stride-1 layers at split precision");
+    static_assert(!S2 || (K1 && ISPM == 2 && TN == 64), "two sub-positions per tile: the decoder GEMM with register-staged split planes");
     constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
     constexpr int NIN = ISP ? 0 : C::NIN;                    // register-staged 16-byte items per thread and step
     constexpr int NINA = NIN > 0 ? NIN : 1;                  // (array extents)
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // source of a step's 16-channel chunks (K1: three of them, each from the low-resolution input or from the skip tensor)
     // (address of an item = src + pixel offset * A + B: [N][H][W][C] float32: A = C, B = chunk channel + 4 slot; planes of 4
     // channels, YOND_FMT_PLANES4 [N][C/4][H*W][4]: A = 4, B = 4 (plane index * H*W - n H*W): the pixel offset carries n H*W)
-    struct LoadSrc { const float* src[C::NPT]; int A[C::NPT], B[C::NPT]; bool hi[C::NPT]; };     // (B: 32 bits -- the dispatcher checks the extent)
+    struct LoadSrc { const float* src[C::NPT]; int A[C::NPT], B[C::NPT]; bool hi[C::NPT]; int dx[C::NPT]; };     // (B: 32 bits -- the dispatcher checks the extent)
     const bool in_p4 = d.in_fmt == YOND_FMT_PLANES4;
     auto load_src = [&](int ch, int n) {
         LoadSrc L;
@@ -269,9 +274,20 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         for (int t = 0; t < C::NPT; ++t) {
             const int c0 = (ch * C::NPT + t) * C::KC;
             const bool second = c0 >= d.C0;
-            const int Cs = second ? d.C1 : d.C0, cc = second ? c0 - d.C0 : c0;
+            int Cs = second ? d.C1 : d.C0, cc = second ? c0 - d.C0 : c0;
             L.src[t] = second ? d.src1 : d.src0;
             L.hi[t] = second && K1;
+            L.dx[t] = 0;
+            if constexpr (S2) {
+                if (second) {
+                    // [real channels at dx = 0 | the same at dx = 1 | one zero-weight chunk (any finite data: dx = 0, channel 0)]
+                    const int creal = (d.C1 - C::KC) / 2;
+                    const int q = cc / creal;
+                    L.dx[t] = q == 1 ? 1 : 0;
+                    cc = q < 2 ? cc - q * creal : 0;
+                    Cs = creal;
+                }
+            }
             if constexpr (ISR) {
                 // split planes: unit index inside the plane * 4 floats + the base of plane (n, chunk, channel half, part = the slot)
                 L.A[t] = 4;
@@ -293,6 +309,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         const bool ok = T.goff[k] >= 0;                        // outside the image: read pixel 0, zeroed at the LDS write
         int po = T.goff[k];
         if constexpr (K1) po = L.hi[t] ? T.goff1[k] : po;
+        if constexpr (S2) {
+            // the neighbouring output pixel (dx = 1) is the next unit; the zero unit of an outside pixel stays where it is
+            if (L.hi[t] && L.dx[t] && T.goff1[k] != 4 * d.H * d.W) po += 1;
+        }
         if (!(SPLIT_ABL & 1)) vin[P][k] = *(const f32x4*)(L.src[t] + (long long)(ok ? po : 0) * L.A[t] + L.B[t]);
         if (k == 0) vin_ok[P] = 0;
         vin_ok[P] |= (ok ? 1u : 0u) << k;
@@ -1081,12 +1101,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     }
 }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false, bool S2 = false>
 int launch_split(const YondConvDesc& d, hipStream_t st) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
     static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP>;
+    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP, S2>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -1128,5 +1148,6 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 #define SPLIT_GROUP_ISP_K1S2(X)                                                                         \
     X(1, 8, 32, 1, 2, 3, false, false, true, 2, false) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false) \
     X(2, 4, 64, 1, 2, 2, false, false, false, 2, false)
+#define SPLIT_GROUP_K1_SUB2(X) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, true)
 #define SPLIT_INSTANTIATE(...) template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);
 #define SPLIT_EXTERN(...) extern template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);

@@ -45,6 +45,7 @@ WINO_DEFAULT = 'split'              # 'split': fp32-accurate split-operand fp16-
 SPLIT_PLANES = True
 SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
 FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
+K1_SUB2 = True                      # the level 1 -> 0 decoder GEMM with two sub-positions per channel tile (YondConvDesc.shuffle 2)
 SNAKE_ORDER = True                  # consecutive split-operand launches walk their tiles in opposite directions (YondConvDesc.tile_order):
                                     # a consumer starts with what its producer touched last, i.e. what the Infinity Cache still holds
 
@@ -155,6 +156,44 @@ class _PackedConv:
         return self._packed[key]
 
 
+class _PackedUpSub2:
+    """The decoder GEMM of a level with 32-channel output pixels in the two-sub-positions-per-tile form (YondConvDesc.shuffle 2,
+    conv_split_kernel.h S2): K = [cur 2c | skip at dx = 0: c | skip at dx = 1: c | 16 zero columns], N = 4 sub-positions x c;
+    the skip weights of sub-position (dy, dx) sit in the dx range, the other range is zero."""
+
+    def __init__(self, dev, w_f, b_f, c):
+        """w_f: the folded ConvTranspose2d-layout weights [2c (cur) + c (skip)][c][2][2] of DenoiserPlan; b_f [c]."""
+        lib = L.load()
+        assert c == 32 and w_f.shape == (3 * c, c, 2, 2)
+        w = w_f.detach().to('cpu', torch.float32).numpy()
+        k = 2 * c + 2 * c + 16
+        m = np.zeros((4, c, k), np.float32)                            # [sp = 2 dy + dx][co][k]
+        for dy in range(2):
+            for dx in range(2):
+                sp = 2 * dy + dx
+                m[sp, :, :2 * c] = w[:2 * c, :, dy, dx].T
+                m[sp, :, 2 * c + dx * c:2 * c + (dx + 1) * c] = w[2 * c:, :, dy, dx].T
+        self._wp = np.ascontiguousarray(m.reshape(4 * c, k, 1, 1))
+        packed = np.empty(self._wp.size, np.float32)
+        rc = lib.yond_pack_conv_split_weight_f32(_np_ptr(self._wp), 4 * c, k, 1, 64, 2, _np_ptr(packed))
+        self.ok = rc == 0                                              # (-2: a weight outside fp16's range -> the plain form)
+        self.wpk = torch.from_numpy(packed).to(dev) if self.ok else None
+        b = torch.zeros(c, dtype=torch.float32)
+        b[:] = b_f.detach().to('cpu', torch.float32)
+        self.bias = b.to(dev)
+        self.psplits, self.gemm_n, self.coutp, self.cinp = [2 * c, 2 * c + 16], 4 * c, c, k
+        self.ksize, self.stride, self.shuffle = 1, 1, 2
+        self.cout_real_p = c
+        self.wmax = float(np.abs(self._wp).max())
+        self.macs_per_pixel = 2 * c * c * 4 + 2 * c * c * 4
+
+    def split(self, parts=2):
+        return (64, self.wpk) if (self.ok and parts == 2) else None
+
+    def wino(self):
+        return None
+
+
 class DenoiserPlan:
     """Packs a module's parameters once and runs forwards on NHWC4 device tensors."""
 
@@ -201,6 +240,10 @@ class DenoiserPlan:
                     blk['upsc'] = _PackedConv(dev, w_f, b_f, 1, 1, [2 * c, c], shuffle=True)
                     # algorithmic MACs of the two reference layers, per GEMM-M (low resolution) pixel
                     blk['upsc'].macs_per_pixel = 2 * c * c * 4 + 2 * c * c * 4
+                    if _rup(c) == 32 and c == 32:
+                        up2 = _PackedUpSub2(dev, w_f, b_f, c)
+                        if up2.ok:
+                            blk['upsc2'] = up2
                 if i <= 4:
                     blk['pool'] = _PackedConv(dev, sd[f'pool{i}.conv.weight'], sd[f'pool{i}.conv.bias'], 3, 2, [c])
                 self.blocks[i] = blk
@@ -491,7 +534,8 @@ class DenoiserPlan:
                 if i >= 6:
                     # ConvT 2x2 s2 + the block's 1x1 shortcut over [up, skip] as one GEMM with a pixel-shuffle store
                     xs = self._new(N, 2 * h, 2 * w, cp)
-                    self._conv(blk['upsc'], cur, skips[10 - i], N, h, w, xs, in_fmt=SP if flow else 0, out_fmt=xfmt)
+                    up = blk['upsc2'] if (flow and K1_SUB2 and 'upsc2' in blk) else blk['upsc']
+                    self._conv(up, cur, skips[10 - i], N, h, w, xs, in_fmt=SP if flow else 0, out_fmt=xfmt)
                     h, w = 2 * h, 2 * w
                     cur = xs
                 # z = conv2(SiLU(FiLM(conv1(SiLU(x))))) + x : the first SiLU runs in conv1's staging (x has other readers); the

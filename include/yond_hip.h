@@ -120,10 +120,12 @@ typedef struct YondConvDesc {
     int Cout;             /* GEMM-N extent (convT: 4 * real Cout), multiple of 32 */
     int ksize;            /* 1 or 3 */
     int stride;           /* 1 or 2 (2 only with ksize 3) */
-    int shuffle;          /* 1: convT 2x2 s2 store, dst is [N][2Ho][2Wo][Cout/4]; 2 (algo 3, split-plane inputs, Cout = 4 x 32):
-                             the same with TWO sub-positions (dy, 0), (dy, 1) per 64-wide channel tile -- the K range of src1 is
-                             [C1' channels read at dx = 0 | the same channels read at dx = 1 | 16 zero-weight channels], C1 = 2 C1' + 16,
-                             and the weight rows of a sub-position are zero in the other one's range: src0 is staged once for both */
+    int shuffle;          /* 1: convT 2x2 s2 store, dst is [N][2Ho][2Wo][Cout/4], GEMM column = sub-position * Cout/4 + channel;
+                             2 (algo 3, split-plane inputs, Cout/4 = Cr a multiple of 32): the same with TWO sub-positions (dy, 0),
+                             (dy, 1) per 64-wide channel tile -- GEMM columns ordered [dy][channel block of 32][dx][32]; the K range
+                             of src1 is [Cr channels read at dx = 0 | the same channels read at dx = 1 | zero-weight channels up to
+                             (C0 + C1) % 48 == 0], and the weight rows of a sub-position are zero in the other one's range:
+                             src0 is staged once for both */
     int pre_act;          /* 0 none, 1 SiLU applied to the staged input */
     int post_act;         /* 0 none, 1 SiLU (algo 3 / 4, 3x3 only: the stored tensor is the consumer's SiLU input), 2 LeakyReLU(slope) */
     float slope;

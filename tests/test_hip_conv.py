@@ -590,3 +590,49 @@ def test_conv_in_and_out_and_maxpool_and_film():
     mp = torch.empty(N, H // 2, W // 2, 32, device=DEV)
     L.check(lib.yond_maxpool2_f32(L.ptr(dst), N, H, W, 32, L.ptr(mp), L.stream()), "maxpool")
     assert torch.equal(nchw(mp.cpu()), F.max_pool2d(nchw(dst.cpu()), 2))
+
+
+@pytest.mark.parametrize("c,h,w", [(32, 24, 40), (64, 16, 32)])
+def test_decoder_gemm_two_subpositions_per_tile_bit_identical(c, h, w):
+    """YondConvDesc.shuffle 2 (the decoder GEMM with two sub-positions per 64-wide tile, K = [cur | skip dx0 | skip dx1 | 0]):
+    the same bits as the one-sub-position form (shuffle 1) on split-plane inputs -- products with zero weights add exact zeros."""
+    import torch
+    from yond_public_amd import engine as E
+    from yond_public_amd import _lib as L
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(c + h)
+    w_f = (torch.randn((3 * c, c, 2, 2), generator=g) * 0.1)
+    b_f = torch.randn(c, generator=g) * 0.1
+    plan = E.DenoiserPlan.__new__(E.DenoiserPlan)
+    plan.lib, plan.dev = L.load(), dev
+    one = E._PackedConv(dev, w_f, b_f, 1, 1, [2 * c, c], shuffle=True)
+    two = E._PackedUpSub2(dev, w_f, b_f, c)
+    assert two.ok and one.split(2) is not None
+    N = 1
+    # split-plane inputs: produced by a 3x3 identity-free route is overkill here -- build them on the host from float32 tensors
+    def to_sp(x):                                      # x [N][H][W][C] float32 -> split planes [N][C/16][2][2][units][8 halves]
+        n_, H, W, C_ = x.shape
+        hpart = x.to(torch.float16)
+        lpart = ((x - hpart.to(torch.float32)) * 2048.0).to(torch.float16)
+        units = E.sp_plane_units(H, W)
+        out = torch.zeros((n_, C_ // 16, 2, 2, units, 8), dtype=torch.float16)
+        for part, t in enumerate((hpart, lpart)):
+            v = t.reshape(n_, H * W, C_ // 16, 2, 8).permute(0, 2, 3, 1, 4)        # [n][c16][half][pixel][8]
+            out[:, :, :, part, :H * W, :] = v
+        return out.view(torch.float32).reshape(-1).contiguous().to(dev)
+    cur = torch.randn((N, h, w, 2 * c), generator=g)
+    skip = torch.randn((N, 2 * h, 2 * w, c), generator=g)
+    cur_sp, skip_sp = to_sp(cur), to_sp(skip)
+    outs = []
+    for pc in (one, two):
+        dst = torch.full((N, 2 * h, 2 * w, c), float('nan'), device=dev)
+        plan._conv(pc, cur_sp, skip_sp, N, h, w, dst, in_fmt=1, algo='split')
+        torch.cuda.synchronize()
+        outs.append(dst.cpu())
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1])
+    # ... and both equal the float64 layer to split precision
+    ref = torch.einsum('nyxi,iojk->nyjxko', cur.double(), w_f[:2 * c].double()).reshape(N, 2 * h, 2 * w, c)
+    ref += torch.einsum('nyjxki,iojk->nyjxko', skip.double().reshape(N, h, 2, w, 2, c), w_f[2 * c:].double()).reshape(N, 2 * h, 2 * w, c)
+    ref += b_f.double()
+    assert float((outs[1].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())

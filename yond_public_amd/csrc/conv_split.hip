@@ -67,15 +67,17 @@ extern "C" int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin
 int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     const int parts = d.algo == 3 ? 2 : 1;
     if (d.shuffle == 2) {
-        // the decoder GEMM with 32-channel output pixels, two sub-positions per 64-wide tile (conv_split_kernel.h, S2):
-        // src1's K range = [C channels at dx = 0 | the same at dx = 1 | 16 zero-weight channels], split-plane inputs
-        const int creal = (d.C1 - 16) / 2;
-        if (parts != 2 || d.ksize != 1 || d.stride != 1 || d.Cout != 128 || d.tn != 64 || d.C0 % 16 || creal <= 0 || creal % 16 || d.C1 != 2 * creal + 16 ||
+        // the decoder GEMM with two sub-positions per 64-wide tile (conv_split_kernel.h, S2): Cr = Cout / 4 output channels,
+        // GEMM columns ordered [dy][channel block of 32][dx][32]; src1's K range = [Cr channels at dx = 0 | the same at dx = 1 |
+        // zero-weight channels up to a multiple of 48], split-plane inputs
+        const int Cr = d.Cout / 4;
+        const int pad = d.C1 - 2 * Cr;
+        if (parts != 2 || d.ksize != 1 || d.stride != 1 || d.Cout % 128 || d.tn != 64 || d.C0 % 16 || pad < 0 || pad >= 48 || pad % 16 ||
             (d.C0 + d.C1) % 48 || d.in_fmt != YOND_FMT_SPLIT_PLANES || d.out_fmt == YOND_FMT_SPLIT_PLANES || d.res_fmt || d.pre_act || d.res ||
             d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W || !d.src1)
             return YOND_EUNSUPPORTED;
         const long long e0 = (long long)d.N * (d.C0 / 16) * 4 * YOND_SP_PLANE_UNITS(d.H, d.W) * 4;
-        const long long e1 = (long long)d.N * (creal / 16) * 4 * YOND_SP_PLANE_UNITS(2 * d.H, 2 * d.W) * 4;
+        const long long e1 = (long long)d.N * (Cr / 16) * 4 * YOND_SP_PLANE_UNITS(2 * d.H, 2 * d.W) * 4;
         if (e0 >= 0x7fffffffLL || e1 >= 0x7fffffffLL) return YOND_EUNSUPPORTED;
         return launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2, false, true>(d, st);
     }

@@ -128,7 +128,8 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 // S2 (K1 with 32-channel output pixels, split-plane input): a 64-wide channel tile = the TWO sub-positions (dy, 0), (dy, 1) of a
 // low-resolution pixel.  The skip tensor's K range is laid out [channels at dx = 0 | the same channels at dx = 1 | one zero chunk]
 // (descriptor shuffle 2; the weights of a sub-position are zero in the other one's range), so the low-resolution input is
-// staged once for both sub-positions and a tile takes 3 steps where two 32-wide tiles took 4.
+// staged once for both sub-positions: at 32 channels a tile takes 3 steps where two 32-wide tiles took 4, at 64 ... 256 channels
+// (64-wide tile = 32 channels x two sub-positions) 6 / 11 / 22 steps where two tiles took 8 / 16 / 32.
 template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
@@ -162,6 +163,18 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     const int Cin = d.C0 + d.C1;
     const int nchunk = Cin / C::KSTEP;                       // steps per tile
     const int Cr = K1 ? d.Cout / 4 : d.Cout;                 // K1: channels of an OUTPUT pixel (GEMM N = 4 sub-positions x Cr)
+    // K1: GEMM column cu of channel tile ct -> (sub-position, channel of the output pixel).  Plain: cu = sp * Cr + channel.
+    // S2: a 64-wide tile holds 32 channels (block cblk) of the sub-positions (dy, 0) and (dy, 1): ct = dy * (Cr / 32) + cblk,
+    // column inside the tile = dx * 32 + channel % 32.
+    const int cpb = S2 ? Cr / 32 : 1;
+    auto k1_sp = [&](int ct, int cu) -> int {
+        if constexpr (S2) return 2 * (ct / cpb) + ((cu >> 5) & 1);
+        return cu / Cr;
+    };
+    auto k1_cb = [&](int ct, int cu) -> int {
+        if constexpr (S2) return (ct % cpb) * 32 + (cu & 31);
+        return cu % Cr;
+    };
     const int my_sl = tid & 3;                               // the thread's 4-channel slot of a pixel (512 % 4 == 0)
     const int my_plane = (my_sl >> 1) * PARTS * C::PLANE + (my_sl & 1) * 2;
 
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
                 T.goff[k] = !valid ? -1 : (in ? gy * d.W + gx : d.H * d.W) * 16;
                 if constexpr (K1) {
-                    const int sp = (T.ct * TN) / Cr;
+                    const int sp = k1_sp(T.ct, T.ct * TN);
                     T.goff1[k] = !valid ? -1 : (in ? (2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1) : 4 * d.H * d.W) * 16;
                 }
             }
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             T.goff[k] = ok ? ((n * d.H + gy) * d.W + gx) : -1;
             if constexpr (ISR) T.goff[k] = ok ? gy * d.W + gx : d.H * d.W;      // unit inside a plane (n is in the plane base); outside: the zero unit
             if constexpr (K1) {
-                const int sp = (T.ct * TN) / Cr;               // a channel tile never straddles two sub-positions
+                const int sp = k1_sp(T.ct, T.ct * TN);         // a channel tile never straddles two sub-positions (S2: dx = 0 here, + 1 unit for dx = 1)
                 T.goff1[k] = ok ? ((n * 2 * d.H + 2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1)) : -1;
                 if constexpr (ISR) T.goff1[k] = ok ? (2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1) : 4 * d.H * d.W;
             }
@@ -280,8 +293,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             L.dx[t] = 0;
             if constexpr (S2) {
                 if (second) {
-                    // [real channels at dx = 0 | the same at dx = 1 | one zero-weight chunk (any finite data: dx = 0, channel 0)]
-                    const int creal = (d.C1 - C::KC) / 2;
+                    // [real channels at dx = 0 | the same at dx = 1 | zero-weight chunks up to a multiple of 48 (any finite data: dx = 0, channel 0)]
+                    const int creal = Cr;                      // (the skip tensor has the output pixels' channel count)
                     const int q = cc / creal;
                     L.dx[t] = q == 1 ? 1 : 0;
                     cc = q < 2 ? cc - q * creal : 0;
@@ -566,7 +579,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
         for (int nn = 0; nn < C::NW; ++nn) {
             const int cu = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
-            const int eoff = (d.ebatch ? T.n * Cr : 0) + (K1 ? cu % Cr : cu);
+            const int eoff = (d.ebatch ? T.n * Cr : 0) + (K1 ? k1_cb(T.ct, cu) : cu);
             // (no branch around the loads: an absent vector is read from the weights and never used)
             pes[nn] = *(const f32x4*)(d.escale ? d.escale + eoff : d.wpk);
             pet[nn] = *(const f32x4*)(d.eshift ? d.eshift + eoff : d.wpk);
@@ -633,7 +646,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             constexpr int nn = decltype(nc)::value;
             const int cu = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
             // K1: GEMM channel cu = sub-position sp x Cr + channel; the pixel goes to (2 y + sp/2, 2 x + sp%2) of the output
-            const int sp = K1 ? cu / Cr : 0, cb = K1 ? cu % Cr : cu;
+            const int sp = K1 ? k1_sp(T.ct, cu) : 0, cb = K1 ? k1_cb(T.ct, cu) : cu;
             const int pstep = K1 ? 2 * Cr : d.Cout;              // elements between horizontally adjacent pixels of the tile
             const int eoff = (d.ebatch ? T.n * Cr : 0) + cb;
             const f32x4 one = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -853,7 +866,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
         for (int nn = 0; nn < C::NW; ++nn) {
             const int cfull = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * lh;
-            const int sp = K1 ? cfull / Cr : 0, cbase = K1 ? cfull % Cr : cfull;     // K1: sub-position of the tile's channel block
+            const int sp = K1 ? k1_sp(T.ct, cfull) : 0, cbase = K1 ? k1_cb(T.ct, cfull) : cfull;     // K1: sub-position of the tile's channel block
             const int eoff = (d.ebatch ? T.n * Cr : 0) + cbase;
             f32x4 es[4], et[4];
 #pragma unroll

@@ -45,7 +45,7 @@ WINO_DEFAULT = 'split'              # 'split': fp32-accurate split-operand fp16-
 SPLIT_PLANES = True
 SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
 FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
-K1_SUB2 = True                      # the level 1 -> 0 decoder GEMM with two sub-positions per channel tile (YondConvDesc.shuffle 2)
+K1_SUB2 = True                      # the decoder GEMMs with two sub-positions per channel tile (YondConvDesc.shuffle 2)
 SNAKE_ORDER = True                  # consecutive split-operand launches walk their tiles in opposite directions (YondConvDesc.tile_order):
                                     # a consumer starts with what its producer touched last, i.e. what the Infinity Cache still holds
 
@@ -157,22 +157,23 @@ class _PackedConv:
 
 
 class _PackedUpSub2:
-    """The decoder GEMM of a level with 32-channel output pixels in the two-sub-positions-per-tile form (YondConvDesc.shuffle 2,
-    conv_split_kernel.h S2): K = [cur 2c | skip at dx = 0: c | skip at dx = 1: c | 16 zero columns], N = 4 sub-positions x c;
-    the skip weights of sub-position (dy, dx) sit in the dx range, the other range is zero."""
+    """A decoder GEMM in the two-sub-positions-per-tile form (YondConvDesc.shuffle 2, conv_split_kernel.h S2):
+    K = [cur 2c | skip at dx = 0: c | skip at dx = 1: c | zero columns up to a multiple of 48]; GEMM columns ordered
+    [dy][channel block of 32][dx][32]; the skip weights of sub-position (dy, dx) sit in the dx range, the other range is zero."""
 
     def __init__(self, dev, w_f, b_f, c):
         """w_f: the folded ConvTranspose2d-layout weights [2c (cur) + c (skip)][c][2][2] of DenoiserPlan; b_f [c]."""
         lib = L.load()
-        assert c == 32 and w_f.shape == (3 * c, c, 2, 2)
+        assert c % 32 == 0 and w_f.shape == (3 * c, c, 2, 2)
         w = w_f.detach().to('cpu', torch.float32).numpy()
-        k = 2 * c + 2 * c + 16
-        m = np.zeros((4, c, k), np.float32)                            # [sp = 2 dy + dx][co][k]
+        k = (4 * c + 47) // 48 * 48
+        m = np.zeros((2, c // 32, 2, 32, k), np.float32)               # [dy][channel block][dx][channel % 32][k]
         for dy in range(2):
             for dx in range(2):
-                sp = 2 * dy + dx
-                m[sp, :, :2 * c] = w[:2 * c, :, dy, dx].T
-                m[sp, :, 2 * c + dx * c:2 * c + (dx + 1) * c] = w[2 * c:, :, dy, dx].T
+                wc = w[:2 * c, :, dy, dx].T.reshape(c // 32, 32, 2 * c)             # [block][co % 32][cur channel]
+                ws = w[2 * c:, :, dy, dx].T.reshape(c // 32, 32, c)
+                m[dy, :, dx, :, :2 * c] = wc
+                m[dy, :, dx, :, 2 * c + dx * c:2 * c + (dx + 1) * c] = ws
         self._wp = np.ascontiguousarray(m.reshape(4 * c, k, 1, 1))
         packed = np.empty(self._wp.size, np.float32)
         rc = lib.yond_pack_conv_split_weight_f32(_np_ptr(self._wp), 4 * c, k, 1, 64, 2, _np_ptr(packed))
@@ -181,7 +182,7 @@ class _PackedUpSub2:
         b = torch.zeros(c, dtype=torch.float32)
         b[:] = b_f.detach().to('cpu', torch.float32)
         self.bias = b.to(dev)
-        self.psplits, self.gemm_n, self.coutp, self.cinp = [2 * c, 2 * c + 16], 4 * c, c, k
+        self.psplits, self.gemm_n, self.coutp, self.cinp = [2 * c, k - 2 * c], 4 * c, c, k
         self.ksize, self.stride, self.shuffle = 1, 1, 2
         self.cout_real_p = c
         self.wmax = float(np.abs(self._wp).max())
@@ -240,8 +241,8 @@ class DenoiserPlan:
                     blk['upsc'] = _PackedConv(dev, w_f, b_f, 1, 1, [2 * c, c], shuffle=True)
                     # algorithmic MACs of the two reference layers, per GEMM-M (low resolution) pixel
                     blk['upsc'].macs_per_pixel = 2 * c * c * 4 + 2 * c * c * 4
-                    if _rup(c) == 32 and c == 32:
-                        up2 = _PackedUpSub2(dev, w_f, b_f, c)
+                    if c == 32:                                      # (measured: 326 -> 256 us at 32 channels; at 64 / 128 / 256 the 1.33-1.5x
+                        up2 = _PackedUpSub2(dev, w_f, b_f, c)        #  longer K costs more than the shared staging saves: +35 ... +50 us)
                         if up2.ok:
                             blk['upsc2'] = up2
                 if i <= 4:

@@ -11,6 +11,7 @@ SPLIT_GROUP_ISP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP_K1S2(SPLIT_EXTERN)
 SPLIT_GROUP_K1_SUB2(SPLIT_EXTERN)
+SPLIT_GROUP_WRES(SPLIT_EXTERN)
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
 // ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has
@@ -124,6 +125,11 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.out4_dst && (tn != 32 || parts != 2)) return YOND_EUNSUPPORTED;
     if (op4) return YOND_EUNSUPPORTED;                          // (3x3 stride-1 layers store [N][H][W][C] or split planes)
     const long long tiles12 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
+    // 32 -> 32 channels: two weight slices in all -- on two buffers they stay resident in LDS (conv_split_kernel.h, wres)
+    const bool wres = parts == 2 && tn == 32 && d.Cout == 32 && d.C0 + d.C1 == 32 && yond_exp_long("YOND_SPLIT_WRES", 1) != 0;
+    if (wres && isp && osp && !d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, false, false, false, true, true>(d, st);
+    if (wres && isp && !osp && d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, false, true, false, true, false>(d, st);
+    if (wres && !isp && osp && d.pre_act && !d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, true, false, false, false, true>(d, st);
     if (isp || osp) {
         if (osp && d.out4_dst) return YOND_EUNSUPPORTED;
         if (isp && osp) {

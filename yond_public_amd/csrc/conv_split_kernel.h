@@ -332,8 +332,16 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
     // weight slice global -> LDS by LDS-DMA as inline assembly (a builtin DMA makes the compiler order every later LDS
     // access behind s_waitcnt vmcnt(0)); one instruction (k) moves 512 x 16 bytes; completion is awaited by a barrier
+    // Resident weights: a layer with two weight slices in all (32 -> 32 channels: two 16-channel chunks, one channel tile) on the
+    // two-buffer rotation finds slice s % 2 in buffer s % 2 for ever -- after the first step no weight DMA is issued at all (they
+    // were a third of the bytes such a layer's steps fetch into LDS).
+    // (not where the transposed epilogue uses the consumed weight buffer as its scratch: 64-wide stride-1 tiles storing [N][H][W][C])
+    constexpr bool W_IS_SCRATCH = TN == 64 && !K1 && STRIDE == 1 && !OSP;
+    const bool wres = NWB == 2 && !W_IS_SCRATCH && nchunk == 2 && nct == 1;
+    bool wskip = false;                                      // true once both slices have been fetched (uniform)
     auto issue_dma = [&](auto kc, const float* wsrc, float* wbuf) {
         constexpr int k = decltype(kc)::value;
+        if (wskip) return;
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)wbuf;
         const int it = tid + k * C::NT;
         const int it_wave = __builtin_amdgcn_readfirstlane(it - lane);
@@ -1086,6 +1094,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         }
         SDBG(5);
         ++dbg_step;
+        wskip = wres;
         if (cn.tile >= total) return false;
         cs = cn;
         cl = adv(cl);
@@ -1162,5 +1171,8 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
     X(1, 8, 32, 1, 2, 3, false, false, true, 2, false) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false) \
     X(2, 4, 64, 1, 2, 2, false, false, false, 2, false)
 #define SPLIT_GROUP_K1_SUB2(X) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, true)
+#define SPLIT_GROUP_WRES(X)                                                                             \
+    X(1, 16, 32, 2, 2, 2, true, false, false, false, true) X(1, 16, 32, 2, 2, 2, false, false, false, true, true) \
+    X(1, 16, 32, 2, 2, 2, false, true, false, true, false)
 #define SPLIT_INSTANTIATE(...) template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);
 #define SPLIT_EXTERN(...) extern template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);

@@ -43,8 +43,14 @@ def show(reader, title):
 for _ in range(3):
     plan._conv(pc, x, None, 1, h, w, tsp, escale=es, eshift=et, ebatch=1, pre_act=1, post_act=1, algo='split', out_fmt=1)
 torch.cuda.synchronize()
-show("yond_split_debug_read_osp", "conv1: register-staged input, split-plane store")
+show("yond_split_debug_read_wres" if Cc == 32 else "yond_split_debug_read_osp", "conv1: register-staged input, split-plane store")
 for _ in range(3):
     plan._conv(pc, tsp, None, 1, h, w, dst, escale=es, eshift=et, ebatch=1, res=x, algo='split', in_fmt=1)
 torch.cuda.synchronize()
 show("yond_split_debug_read_isp", "conv2: split-plane input by LDS-DMA, residual, NHWC store")
+out = plan._new_sp('o', 1, h, w, Cc)
+x4p = x.reshape(1, h * w, Cc // 4, 4).permute(0, 2, 1, 3).contiguous()
+for _ in range(3):
+    plan._conv(pc, tsp, None, 1, h, w, out, escale=es, eshift=et, ebatch=1, res=x4p, algo='split', in_fmt=1, out_fmt=1, res_fmt=2)
+torch.cuda.synchronize()
+show("yond_split_debug_read_wres" if Cc == 32 else "yond_split_debug_read_isp_osp", "conv2 of the flow: split-plane input, planes-of-4 residual, split-plane store")

@@ -477,6 +477,52 @@ def main(argv=None):
                   "frames": n2, "driver": "one frame at a time", "max_abs_output_difference_to_headline_path": dmax}
         del net2, r2, r1
 
+    # BASELINE.json's two other GPU configurations on the same line (one GPU, rank 0, >= 1 s each): configs[3] = UNetSeeInDark,
+    # batch 8 of 3000 x 4000 frames in ONE forward; configs[4] = 4000 x 6000 low-light frames without black-level clip on the
+    # fp16 MFMA path.  (`--cfg 4` / `--cfg 5` run them as the timed region proper.)
+    others = None
+    if a.cfg == 2 and a.mode == "once" and a.precision == "fp32" and not a.no_extras and not a.batch and world == 1 and stream_driver:
+        others = {}
+        arch4 = ARCHS['UNetSeeInDark']
+        net4 = getattr(A, arch4['name'])(dict(arch4, precision='fp32'))
+        net4.load_state_dict(S.denoising_state_dict(net4, 0))
+        net4 = net4.to(dev).eval()
+        batch8 = [frames[j % len(frames)] for j in range(8)]
+        P.IterDenoiseBatch(batch8, net4, arch4, pipe)
+        torch.cuda.synchronize()
+        t4, n4 = time.perf_counter(), 0
+        while n4 < 2 or time.perf_counter() - t4 < 1.0:
+            r4 = P.IterDenoiseBatch(batch8, net4, arch4, pipe)
+            torch.cuda.synchronize()
+            n4 += 1
+        el4 = time.perf_counter() - t4
+        others["cfg4_unet_batch8"] = {"value": round(n4 * 8 * H * W / 1e6 / el4, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el4 / (n4 * 8) * 1e3, 3),
+                                      "frames": n4 * 8, "workload": f"configs[3]: UNetSeeInDark(nf=32), {H}x{W} frames, per-frame NLE, ONE batched forward of 8"}
+        del net4, r4, batch8
+        torch.cuda.empty_cache()
+        H5, W5 = 4000, 6000
+        rng5 = np.random.default_rng(1997)
+        clean5 = (S.synth_clean(H5, W5) * 0.2).astype(np.float32)
+        noisy5 = ((rng5.poisson(clean5 * 959.0 / 4.0) * 4.0 + rng5.normal(0.0, 25.0, clean5.shape)) / 959.0).astype(np.float32)
+        f5 = torch.from_numpy(noisy5).to(dev)
+        del clean5, noisy5
+        net5 = make_net('fp16')
+        for _ in P.denoise_stream((f5 for _ in range(2)), net5, arch, pipe):
+            pass
+        torch.cuda.synchronize()
+        t5, n5 = time.perf_counter(), 0
+        while n5 < 12 or time.perf_counter() - t5 < 1.0:
+            for _ in P.denoise_stream((f5 for _ in range(6)), net5, arch, pipe):
+                pass
+            torch.cuda.synchronize()
+            n5 += 6
+        el5 = time.perf_counter() - t5
+        others["cfg5_fp16_4000x6000"] = {"value": round(n5 * H5 * W5 / 1e6 / el5, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el5 / n5 * 1e3, 3),
+                                         "frames": n5, "dtype": "f16 MFMA operands, f32 accumulate and tensors",
+                                         "workload": f"configs[4]: {H5}x{W5} low-light frames (no black-level clip, negative DN reach the VST), GuidedResUnet(nf=32), pipeline 'once'"}
+        del net5, f5
+        torch.cuda.empty_cache()
+
     # final metric reduction (the only collective of the eval path): PSNR of the last output vs the clean frame
     dn = res['raw_dns'][-1]
     dn = dn[-1] if dn.dim() == 3 else dn
@@ -519,6 +565,7 @@ def main(argv=None):
             "iter_pipeline": iter_leg,
             "without_kernel_events": noev,
             "fp32_mfma_path": strict,
+            "other_configs": others,
             "roofline_vst_nle": roof_hbm,
             "conv_stack": {"ms_per_frame": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
                            "share_of_frame": round(conv_ms / (elapsed / n_timed * 1e3), 3) if conv_ms else None,

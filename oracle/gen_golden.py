@@ -366,6 +366,23 @@ def gen_train(ref):
         out[f"w_chk/{k}"] = checks(p.detach().numpy())
         out[f"w/{k}"] = grad_sample(k, p.detach().numpy())
     print(f"train step: loss {float(loss):.6f}, {sum(p.numel() for p in net.parameters())} parameters")
+    # the other net the reference trains (runfiles/Gaussian/Unet_5to50_norm.yml): UNetSeeInDark, `pred = self.net(imgs_lr)` (:111)
+    arch_u = ARCHS["unet8"]
+    net = getattr(ref, arch_u['name'])(dict(arch_u))
+    net = ref.load_weights(net, O.procedural_state_dict(arch_u, 19), by_name=False).train()
+    opt = Adam(net.parameters(), lr=step)
+    opt.zero_grad()
+    pred = net(lr_img)
+    loss = loss_fn(pred, hr_img)
+    loss.backward()
+    out["u_loss"] = np.array(float(loss))
+    for k, p in net.named_parameters():
+        out[f"u_g_chk/{k}"] = checks(p.grad.detach().numpy())
+        out[f"u_g/{k}"] = grad_sample(k, p.grad.detach().numpy())
+    opt.step()
+    for k, p in net.named_parameters():
+        out[f"u_w/{k}"] = grad_sample(k, p.detach().numpy())
+    print(f"train step (UNetSeeInDark): loss {float(loss):.6f}")
     save("train", **out)
 
 

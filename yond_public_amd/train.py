@@ -16,7 +16,7 @@ to multiples of 32, with every convolution -- forward, data gradient and weight 
   * loss and optimiser: yond_l1_loss_f32, yond_adam_step_f32.
 torch.autograd only strings the layers together (custom Functions) and differentiates the elementwise glue (SiLU, LeakyReLU,
 FiLM scale / shift and its three tiny sigma-MLPs, residual adds), which is <0.1 % of the step's arithmetic.
-Scope: GuidedResUnet / fp32; weights are re-packed on the host every step (fine at nf = 8 ... 32; a production loop would keep
+Scope: GuidedResUnet and UNetSeeInDark (the two nets the reference's runfiles/Gaussian/*.yml train) / fp32; weights are re-packed on the host every step (fine at nf = 8 ... 32; a production loop would keep
 packed weights resident).  Data-parallel: one process per GPU, every rank steps on its own batches, `GradReducer` averages the
 gradients in two 25 MB buckets launched from backward's hooks (the only collective of training: 44.7 MB per step).
 Pinned by tests/golden/train.npz (loss, gradients and updated weights of the reference's own step on the same inputs) and
@@ -105,6 +105,38 @@ class _Conv3x3(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class _Conv3x3Cat(torch.autograd.Function):
+    """nn.Conv2d(c0 + c1, cout, 3, 1, 1) over torch.cat([x0, x1], channel) (UNetSeeInDark's conv{6..9}_1, archs/Unet.py:83-99):
+    the concatenation is never materialised -- forward as a two-source convolution, the weight gradient per source, each data
+    gradient a convolution of dy with that source's slice of the flipped, transposed weights."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, w, b, plan, c0):
+        N, H, W, _ = x0.shape
+        x0, x1 = x0.contiguous(), x1.contiguous()
+        c1 = w.shape[1] - c0
+        y = _conv_fwd(plan, w, b, 3, 1, [c0, c1], [x0, x1], N, H, W)
+        ctx.save_for_backward(x0, x1, w)
+        ctx.plan, ctx.c0 = plan, c0
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, w = ctx.saved_tensors
+        plan, c0 = ctx.plan, ctx.c0
+        dy = dy.contiguous()
+        N, H, W, _ = dy.shape
+        cout, c1 = w.shape[0], w.shape[1] - c0
+        dws, dxs = [], []
+        for x, lo, c in ((x0, 0, c0), (x1, c0, c1)):
+            dws.append(_wgrad(plan, x, dy, 0, 1, 9)[:, :cout, :c].permute(1, 2, 0).reshape(cout, c, 3, 3))
+            wt = w.detach()[:, lo:lo + c].flip(2, 3).transpose(0, 1).contiguous()        # [c][cout][2-ky][2-kx]
+            dx = _conv_fwd(plan, wt, None, 3, 1, [cout], [dy], N, H, W)
+            dxs.append(dx if dx.shape[-1] == x.shape[-1] else _pad_c(dx[..., :c], x.shape[-1]))
+        db = _colsum(plan, dy)[:cout]
+        return dxs[0], dxs[1], torch.cat(dws, 1), db, None, None
+
+
 class _Conv1x1(torch.autograd.Function):
     """nn.Conv2d(c0 + c1, cout, 1) over the channel concatenation of one or two tensors (torch.cat is not materialised)."""
 
@@ -177,7 +209,7 @@ class _ConvT2x2(torch.autograd.Function):
 
 
 class TrainStep:
-    """One optimisation step of a yond_public_amd.archs.GuidedResUnet (parameter names / shapes of the reference)."""
+    """One optimisation step of a yond_public_amd.archs.GuidedResUnet or UNetSeeInDark (parameter names / shapes of the reference)."""
 
     def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, charbonnier=False, ddp=None):
         """charbonnier: Unet_Loss(charbonnier=True) (losses/base_loss.py:82-85).  ddp: None -- average the gradients over the
@@ -217,8 +249,45 @@ class TrainStep:
         z = _Conv3x3.apply(z, P[pre + '.conv2.weight'], P[pre + '.conv2.bias'], self.plan, 1, True)
         return z + x
 
-    def forward(self, x_nchw, sigma):
+    def _forward_unet(self, x_nchw):
+        """UNetSeeInDark (archs/Unet.py:55-104): conv -> LeakyReLU(0.2) pairs, 2x2 max pooling, ConvTranspose2d + cat + conv; the
+        pooling and the activations are autograd's elementwise glue, every convolution runs on the HIP kernels."""
         m, P = self.m, self.params
+        x = x_nchw.permute(0, 2, 3, 1).contiguous()
+        B = x.shape[0]
+        ub = None
+        if m.norm:
+            ub = x.reshape(B, -1).max(1).values.detach()
+            x = x / ub[:, None, None, None]
+        act = lambda z: F.leaky_relu(z, 0.2)
+        pool = lambda z: F.max_pool2d(z.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+        cur = act(_Conv3x3.apply(_pad_c(x, 32), P['conv1_1.weight'], P['conv1_1.bias'], self.plan, 1, False))
+        cur = act(_Conv3x3.apply(cur, P['conv1_2.weight'], P['conv1_2.bias'], self.plan, 1, True))
+        skips = {1: cur}
+        for i in range(2, 6):
+            cur = pool(cur)
+            cur = act(_Conv3x3.apply(cur, P[f'conv{i}_1.weight'], P[f'conv{i}_1.bias'], self.plan, 1, True))
+            cur = act(_Conv3x3.apply(cur, P[f'conv{i}_2.weight'], P[f'conv{i}_2.bias'], self.plan, 1, True))
+            if i < 5:
+                skips[i] = cur
+        for i in range(6, 10):
+            up = _ConvT2x2.apply(cur, P[f'upv{i}.weight'], P[f'upv{i}.bias'], self.plan)
+            c0 = P[f'upv{i}.weight'].shape[1]
+            cur = act(_Conv3x3Cat.apply(up, skips[10 - i], P[f'conv{i}_1.weight'], P[f'conv{i}_1.bias'], self.plan, c0))
+            cur = act(_Conv3x3.apply(cur, P[f'conv{i}_2.weight'], P[f'conv{i}_2.bias'], self.plan, 1, True))
+        out = _Conv1x1.apply(cur, None, P['conv10_1.weight'], P['conv10_1.bias'], self.plan)[..., :4]
+        if m.res:
+            out = out + x[..., :4]
+        if m.norm:
+            out = out * ub[:, None, None, None]
+        return out.permute(0, 3, 1, 2)
+
+    def forward(self, x_nchw, sigma=None):
+        m, P = self.m, self.params
+        if type(m).__name__ == 'UNetSeeInDark':
+            return self._forward_unet(x_nchw)
+        if type(m).__name__ != 'GuidedResUnet':
+            raise NotImplementedError(f"TrainStep: {type(m).__name__} (GuidedResUnet and UNetSeeInDark are the nets the reference trains)")
         x = x_nchw.permute(0, 2, 3, 1).contiguous()
         B = x.shape[0]
         t = sigma.reshape(B).to(torch.float32)
@@ -248,8 +317,9 @@ class TrainStep:
         return out.permute(0, 3, 1, 2)
 
     # -- loss, backward, Adam ----------------------------------------------------------------------------------------
-    def step(self, imgs_lr, imgs_hr, sigma):
-        """trainer_AWGN.py:101-117 for one batch.  Returns (loss, {name: gradient})."""
+    def step(self, imgs_lr, imgs_hr, sigma=None):
+        """trainer_AWGN.py:101-117 for one batch (`pred = net(imgs_lr, sigma)` for a guided net, `net(imgs_lr)` otherwise).
+        Returns (loss, {name: gradient})."""
         lib = self.plan.lib
         for p in self.params.values():
             p.grad = None

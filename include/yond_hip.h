@@ -309,6 +309,7 @@ int yond_percentiles_f32(const float* data, size_t n, const double* q_host, int 
  *                           while it produces the maps.)
  *   yond_nle_threshold_f32  sweep 2 over lap + finish: the exact order statistics, np.percentile(lap, q, 'linear') ->
  *                           ths; with want_score: npeaks[i], score = ths / (q * npeaks), i* = argmin(score[1:]) + 1 -> sel.
+ *                           Needs sweep 1's state in `ws`; may be repeated on it (its own counters are reset when it ends).
  *   Results stay in the head of the workspace: yond_nle_state_layout gives the byte offsets of
  *   {ths double[32], sel double[4] = {i*, ths[i*], q[i*], score[i*]}, mom double[10], npeaks int32[32], frame_max_key};
  *   yond_nlf_moments_f32 can take th = ws + off[1] + 8 and mom = ws + off[2] directly. */
@@ -317,7 +318,9 @@ int yond_nle_stats_f32(const float* lap, const float* mean, size_t n, int width,
                        void* stream);
 int yond_nle_threshold_f32(const float* lap, size_t n, const double* q_host, int nq, int want_score, void* ws, void* stream);
 int yond_nle_state_layout(int* off /*[5]*/);
-/* K7b on that workspace: the moment sums below sel[1] into the workspace's mom (zeroed by the reset of sweep 1). */
+/* K7b on that workspace: the moment sums below sel[1] are ADDED to the workspace's mom, which the reset of sweep 1 zeroed (no
+ * memset launch of its own): ONE call per sweep 1 -- a second call on the same state would double the sums (use
+ * yond_nlf_moments_f32, which zeroes its destination, for anything else). */
 int yond_nle_moments_f32(const float* lap, const float* mean, const float* var, size_t n, void* ws, void* stream);
 
 /* K7a occupancy: one pass over (lap, mean), n elements laid out as rows of `width` (n % width == 0; pass the

@@ -467,3 +467,32 @@ def test_simple_nlf_fused_equals_unfused_full_frame():
         if box != 'plain':
             assert ib['frame_max'] == noisy.max()
     assert ia['frame_max'] == noisy.max()
+
+
+def test_threshold_can_be_repeated_on_one_workspace():
+    """yond_nle_threshold_f32 twice on the same sweep-1 state: sweep 2's fill counters and its arrival ticket are reset by the
+    call's last workgroup, so the second call selects the same thresholds (an advisor's finding: it used to append its
+    candidates behind the first call's and never fire the finishing workgroup)."""
+    import ctypes as C
+    from yond_public_amd import _lib as L
+    from yond_public_amd import pipeline as P
+    lib = L.load()
+    rng = np.random.default_rng(11)
+    h, w = 96, 160
+    lap = torch.from_numpy((rng.random((4, h, w), dtype=np.float32) * 0.05)).to(DEV)
+    mean = torch.from_numpy(rng.random((4, h, w), dtype=np.float32)).to(DEV)
+    n = 4 * h * w
+    q = np.ascontiguousarray(P.QUANTS)
+    qp = C.c_void_p(q.ctypes.data)
+    ws = P._nle_workspace(n, lap.device)
+    L.check(lib.yond_nle_stats_f32(L.ptr(lap), L.ptr(mean), n, w, qp, len(q), L.ptr(ws), L.stream()), "stats")
+    off = (C.c_int * 5)()
+    L.check(lib.yond_nle_state_layout(off), "layout")
+    heads = []
+    for _ in range(3):
+        L.check(lib.yond_nle_threshold_f32(L.ptr(lap), n, qp, len(q), 1, L.ptr(ws), L.stream()), "threshold")
+        torch.cuda.synchronize()
+        heads.append(ws[:off[2]].cpu().numpy().copy())              # ths + sel
+    assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2])
+    ths = heads[0][:8 * len(q)].view(np.float64)
+    np.testing.assert_array_equal(ths, np.percentile(lap.cpu().numpy().reshape(-1), q))

@@ -312,6 +312,10 @@ __global__ __launch_bounds__(NFF_THREADS) void nf_final_kernel(NleState* st, con
     }
     if (!nf_arrive_last(&st->ticket[1], gridDim.x)) return;
     // ---- last workgroup: np.percentile's lerp, npeaks, score 3 ----
+    // (every other workgroup has left: sweep 2's fill counters and arrival ticket go back to zero, so that the call can be
+    // repeated on the same workspace -- sweep 1's state is untouched)
+    if (tid < NF_MAXT) st->slot_fill[tid] = 0;
+    if (tid == 0) st->ticket[1] = 0;
     const int nq = a.nq;
     if (tid < nq) {
         // numpy _lerp: diff = b - a in the data dtype; a + diff*t (t < 0.5) or b - diff*(1-t) (t >= 0.5); b == a -> a

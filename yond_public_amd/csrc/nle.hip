@@ -53,8 +53,10 @@ __device__ __forceinline__ float std_from(float b1, float b2) {
 // eight consecutive outputs of one row: 16-byte stores where the row allows it
 __device__ __forceinline__ void box_store8(float* __restrict__ p, const float (&v)[BX_C], int nvalid, bool vec_ok) {
     if (vec_ok && nvalid >= BX_C) {
-        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        // (non-temporal: the maps stream out once and should not push the input rows -- which come back as "leaving" rows 19 / 29
+        // steps later -- out of the XCD's L2)
+        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4*)p);
+        __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, (f32x4*)(p + 4));
     } else {
 #pragma unroll
         for (int i = 0; i < BX_C; ++i)

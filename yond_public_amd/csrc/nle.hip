@@ -13,7 +13,7 @@
 // =====================================================================================================
 // A workgroup owns TWO planes (Bayer input: the two column phases dx = 0, 1 of one row parity, read together as one 8-byte
 // load per packed pixel; planar input: planes 2z, 2z + 1), a strip of <= 256 - 2R "virtual" columns (outputs plus the
-// reflected halo of R = k/2 on either side) and a segment of rows.  It walks down the rows BX_B at a time:
+// reflected halo of R = k/2 on either side) and a segment of rows.  It walks down the rows BB = 4 at a time (two barriers per batch):
 //   column phase   thread = virtual column: running k-row sums of its column in float64 registers (S += entering - leaving;
 //                  float32 data summed in float64 is exact, so add / subtract leaves no drift; the leaving row comes back
 //                  from L2), written to LDS;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(BX_T, MODE == 1 ? 4 : 2) void box_slide_kernel(BoxS
     const int nvalid = min(BX_C, ow - c0);
     const double* vb = s_v + (t_r * 2 + t_pl) * BX_VW + chunk * (BX_C + 1);   // + q * BB * 2 * BX_VW ; virtual column c0 + d at d + (d >> 3)
     constexpr int QS = BB * 2 * BX_VW;
-    const int t_plane = MODE == 1 ? 2 * z + t_pl : 2 * z + t_pl;  // output plane: Bayer (dy = z, dx = t_pl) -> 2 dy + dx
+    const int t_plane = 2 * z + t_pl;                            // output plane: Bayer (dy = z, dx = t_pl) -> 2 dy + dx; planar: 2 z + t_pl
     const bool vec_ok = (w % 4 == 0) && (ox0 % 4 == 0) && !(((uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2) & 15);
     load_batch(nxt, 0);
     for (int l0 = 0; l0 < nsteps; l0 += BB) {

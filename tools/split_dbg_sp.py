@@ -54,3 +54,10 @@ for _ in range(3):
     plan._conv(pc, tsp, None, 1, h, w, out, escale=es, eshift=et, ebatch=1, res=x4p, algo='split', in_fmt=1, out_fmt=1, res_fmt=2)
 torch.cuda.synchronize()
 show("yond_split_debug_read_wres" if Cc == 32 else "yond_split_debug_read_isp_osp", "conv2 of the flow: split-plane input, planes-of-4 residual, split-plane store")
+# the stride-2 layer of the same level in the flow: split planes in -> planes of 4 channels out
+pc2 = _PackedConv(plan.dev, torch.randn(2 * Cc, Cc, 3, 3, generator=g) / (3 * Cc ** 0.5), torch.randn(2 * Cc, generator=g), 3, 2, [Cc])
+nxt = torch.empty(1, h // 2, w // 2, 2 * Cc, device='cuda')
+for _ in range(3):
+    plan._conv(pc2, out, None, 1, h, w, nxt, algo='split', in_fmt=1, out_fmt=2)
+torch.cuda.synchronize()
+show("yond_split_debug_read_isp_k1s2", "stride 2: split-plane input through the register pipeline, planes-of-4 store")

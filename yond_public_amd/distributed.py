@@ -150,6 +150,7 @@ class GradReducer:
             for p, off, n in b["items"]:
                 self.where[id(p)] = (bi, off, n)
         self.hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in self.params] if _active() else []
+        self._copied = set()
 
     @staticmethod
     def _make(items, n):
@@ -158,6 +159,7 @@ class GradReducer:
 
     def begin(self):
         """Start of a step: nothing reduced yet."""
+        self._copied = set()
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"], b["work"] = len(b["items"]), None
@@ -172,6 +174,7 @@ class GradReducer:
         bi, off, n = self.where[id(p)]
         b = self.buckets[bi]
         b["flat"][off:off + n].copy_(p.grad.reshape(-1))
+        self._copied.add(id(p))
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -183,6 +186,10 @@ class GradReducer:
             return
         for b in self.buckets:
             if b["work"] is None:
+                # (a reducer built before the process group existed has no hooks: its gradients are gathered here)
+                for p, off, n in b["items"]:
+                    if id(p) not in self._copied and p.grad is not None:
+                        b["flat"][off:off + n].copy_(p.grad.reshape(-1))
                 self._launch(b)
         for b in self.buckets:
             b["work"].wait()

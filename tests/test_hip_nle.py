@@ -496,3 +496,51 @@ def test_threshold_can_be_repeated_on_one_workspace():
     assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2])
     ths = heads[0][:8 * len(q)].view(np.float64)
     np.testing.assert_array_equal(ths, np.percentile(lap.cpu().numpy().reshape(-1), q))
+
+
+@pytest.mark.parametrize("H,W,tile_w,k", [(2, 2, 0, 1), (4, 6, 0, 3), (30, 18, 0, 5), (58, 130, 0, 29), (64, 512, 16, 7), (130, 902, 0, 29),
+                                          (34, 2064, 0, 9)])
+def test_box_kernels_edge_geometries_vs_oracle(H, W, tile_w, k):
+    """The sliding-window box kernels (round 3) on the shapes the big tests do not reach -- a 1 x 1 packed image, windows larger
+    than the image (multiple reflections), widths that are no multiple of 4 (scalar stores), run-time window sizes (k != 29),
+    SIDD_256-style tiling with narrow tiles, strips whose last chunk is partial, one-row segments -- against the oracle's cv2.blur
+    restatement: mean / var / lap for self and collab, <= 1 float32 ulp-sized relative error where the value is not tiny."""
+    import yond_oracle as O
+    from yond_public_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(H * 131 + W)
+    lr = rng.random((H, W), dtype=np.float32)
+    hr = (rng.random((H, W), dtype=np.float32) * 0.5 + 0.25).astype(np.float32)
+    h, w = H // 2, W // 2
+    k2 = k // 3 * 2 + 1
+    planes = lambda a: np.ascontiguousarray(np.transpose(a, (2, 0, 1)))
+    def tiles(a):                                        # the oracle filters every tile_w-wide block on its own
+        if not tile_w:
+            return [a]
+        return np.split(a, a.shape[1] // tile_w, axis=1)
+    def filt(fn, a):
+        return np.concatenate([fn(t_) for t_ in tiles(a)], axis=1)
+    rl, rh = O.bayer2rggb(lr), O.bayer2rggb(hr)
+    want = {
+        "mean": filt(lambda a: O.box_blur(a, k), rl), "var": filt(lambda a: O.stdfilt(a, k) ** 2, rl),
+        "lap": filt(lambda a: O.stdfilt(O.box_blur(a, k2), k), rl),
+        "c.mean": filt(lambda a: O.box_blur(a, k), rh), "c.lap": filt(lambda a: O.stdfilt(a, k), rh),
+    }
+    want["c.var"] = filt(lambda a: O.stdfilt(a, k) ** 2, rl) - want["c.lap"] ** 2
+    t, c = torch.from_numpy(lr).to(DEV), torch.from_numpy(hr).to(DEV)
+    o = [torch.full((4, h, w), float('nan'), device=DEV) for _ in range(7)]
+    st = L.stream()
+    L.check(lib.yond_box_stats_self1_f32(L.ptr(t), H, W, k, k2, tile_w, L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), st), "self1")
+    L.check(lib.yond_box_stats_self2_f32(L.ptr(o[2]), h, w, k, tile_w, L.ptr(o[3]), st), "self2")
+    L.check(lib.yond_box_stats_collab_f32(L.ptr(t), L.ptr(c), H, W, k, tile_w, L.ptr(o[4]), L.ptr(o[5]), L.ptr(o[6]), st), "collab")
+    torch.cuda.synchronize()
+    got = {"mean": o[0], "var": o[1], "lap": o[3], "c.mean": o[4], "c.var": o[5], "c.lap": o[6]}
+    for name, g_ in got.items():
+        g_ = g_.cpu().numpy()
+        ref = planes(want[name]).astype(np.float64)
+        assert not np.isnan(g_).any(), (name, "unwritten outputs")
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        # var / lap are differences of nearly equal float32 numbers: an ulp of E[x^2] is the unit of their error
+        unit = 2.0 ** -23 * (1.0 if name.endswith("mean") else float(max(np.abs(planes(want["mean"])).max() ** 2, 1e-30)))
+        err = float(np.abs(g_.astype(np.float64) - ref).max())
+        assert err <= 4 * max(unit, 2.0 ** -23 * scale) if "lap" not in name else err <= 2e-3 * scale + 1e-6, (name, err, scale)

@@ -185,6 +185,12 @@ typedef struct YondConvDesc {
        first.  A chain of memory-bound layers alternates it: the consumer then starts with the rows its producer wrote (and read)
        LAST, which are still in the 256 MB Infinity Cache, instead of the rows that were evicted first.  Results do not depend on it. */
     int tile_order;
+    /* Second output of a stride-2 layer (algo 3 at split precision, split-plane input, out_fmt 2; NULL = none): SiLU of the
+       stored value in SPLIT PLANES -- the tensor the next residual block's conv1 would otherwise build in its own staging
+       (SiLU + split of every input pixel, once per output-channel tile: 4 / 8 times at 256 / 512 channels); with it that conv1
+       stages by LDS-DMA alone (in_fmt 1, pre_act 0).  Same bits as the consumer-side staging.  Zero pad as for every
+       split-plane tensor. */
+    float* dst2;
 } YondConvDesc;
 #define YOND_STATUS_HALF_OVERFLOW 1u
 #define YOND_FMT_NHWC_F32 0

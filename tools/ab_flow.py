@@ -9,15 +9,15 @@ arch = dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes
 net = A.GuidedResUnet(dict(arch)); net.load_state_dict(S.procedural_state_dict(net, 0)); net = net.to('cuda').eval()
 plan = P._plan_of(net, torch.device('cuda'))
 x = torch.rand(1, 1504, 2016, 4, device='cuda'); t = torch.full((1,), 0.03, device='cuda'); ub = x.reshape(1, -1).max(1).values.contiguous()
-CFG = {'nhwc': (False, False, False, False), 'tmp': (True, False, False, False), 'flow': (True, True, False, False), 'snake': (True, True, True, False),
-       'sub2': (True, True, True, True)}   # snake: alternating tile order; sub2: + two sub-positions per tile in the 1->0 decoder GEMM
+CFG = {'nhwc': (False, False, False, False, 99), 'tmp': (True, False, False, False, 99), 'flow': (True, True, False, False, 99), 'snake': (True, True, True, False, 99),
+       'sub2': (True, True, True, True, 99), 'c1dma3': (True, True, True, True, 3), 'c1dma2': (True, True, True, True, 2)}   # snake: alternating tile order; sub2: + two sub-positions per tile in the 1->0 decoder GEMM
 names = sys.argv[1:] or list(CFG)
 ref = None
 acc = {n: {} for n in names}
 tags = {}
 for rep in range(9):
     for n in names:
-        E.SPLIT_PLANES, E.SP_FLOW, E.SNAKE_ORDER, E.K1_SUB2 = CFG[n]
+        E.SPLIT_PLANES, E.SP_FLOW, E.SNAKE_ORDER, E.K1_SUB2, E.SP_CONV1_MIN_LEVEL = CFG[n]
         plan.prof = [] if rep >= 2 else None
         y = plan.forward_nhwc4(x, t, ub=ub)
         torch.cuda.synchronize()

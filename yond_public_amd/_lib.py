@@ -23,7 +23,7 @@ class YondConvDesc(C.Structure):
                 ("pre_act", i32), ("post_act", i32), ("slope", f32), ("wpk", vp), ("escale", vp),
                 ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32),
                 ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp), ("status", vp),
-                ("in_fmt", i32), ("out_fmt", i32), ("res_fmt", i32), ("clk", vp), ("tile_order", i32)]
+                ("in_fmt", i32), ("out_fmt", i32), ("res_fmt", i32), ("clk", vp), ("tile_order", i32), ("dst2", vp)]
 
 
 class YondFilmDesc(C.Structure):

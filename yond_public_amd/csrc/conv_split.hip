@@ -12,6 +12,7 @@ SPLIT_GROUP_ISP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP_K1S2(SPLIT_EXTERN)
 SPLIT_GROUP_K1_SUB2(SPLIT_EXTERN)
 SPLIT_GROUP_WRES(SPLIT_EXTERN)
+SPLIT_GROUP_D2(SPLIT_EXTERN)
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
 // ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has
@@ -93,6 +94,8 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if ((d.in_fmt || d.out_fmt || d.res_fmt) && parts != 2) return YOND_EUNSUPPORTED;
     if (d.res_fmt != YOND_FMT_NHWC_F32 && !rp4) return YOND_EINVAL;
     if (isp && d.pre_act) return YOND_EUNSUPPORTED;             // the producer applied the activation
+    // second output (SiLU in split planes): the stride-2 layers with split-plane input and planes-of-4 output
+    if (d.dst2 && !(parts == 2 && isp && op4 && d.ksize == 3 && d.stride == 2 && d.Cout % 16 == 0)) return YOND_EUNSUPPORTED;
     if (rp4 != (osp && d.res != nullptr)) return YOND_EUNSUPPORTED;   // a split-plane store reads its residual in planes of 4, nothing else does
     if (osp && d.res && !isp) return YOND_EUNSUPPORTED;              // ... and only conv2 of a block has one: split-plane input
     if (ip4 && (long long)d.N * (d.C0 > d.C1 ? d.C0 : d.C1) * d.H * d.W * (d.ksize == 1 ? 4 : 1) >= 0x7fffffffLL) return YOND_EUNSUPPORTED;   // 32-bit element offsets
@@ -118,6 +121,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         if (d.Ho != (d.H + 1) / 2 || d.Wo != (d.W + 1) / 2 || d.pre_act) return YOND_EINVAL;
         if (osp || ip4 || (op4 && d.res)) return YOND_EUNSUPPORTED;
         // stride 2: 4 x 32 output pixels read 9 x 65 input pixels -- two weight buffers fit beside the two input images
+        if (isp && d.dst2) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true>(d, st);
         if (isp) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2>(d, st);
         return parts == 2 ? launch_split<2, 4, 64, 1, 2, 2, false>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false>(d, st);
     }

@@ -130,7 +130,9 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 // (descriptor shuffle 2; the weights of a sub-position are zero in the other one's range), so the low-resolution input is
 // staged once for both sub-positions: at 32 channels a tile takes 3 steps where two 32-wide tiles took 4, at 64 ... 256 channels
 // (64-wide tile = 32 channels x two sub-positions) 6 / 11 / 22 steps where two tiles took 8 / 16 / 32.
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false>
+// D2 (stride 2): the layer also stores SiLU(value) in split planes (YondConvDesc.dst2), from the same epilogue loop -- an
+// instantiation of its own, so that the kernels without it keep their code and register allocation.
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false, bool D2 = false>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
     // split-plane input: ISPM 1 (ISP) by LDS-DMA, one step ahead -- the layers whose steps are long enough to cover the DMA's
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     static_assert(ISPM == 0 || (!PRE && PARTS == 2), "split-plane input: the producer applied the activation; split precision only");
     static_assert(!OSP || (!O4 && !K1 && STRIDE == 1 && PARTS == 2), "split-plane output: 3x3 stride-1 layers at split precision");
     static_assert(!S2 || (K1 && ISPM == 2 && TN == 64), "two sub-positions per tile: the decoder GEMM with register-staged split planes");
+    static_assert(!D2 || (PARTS == 2 && !OSP && !O4 && !K1 && STRIDE == 2), "second output: the stride-2 layers at split precision");
     constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
     constexpr int NIN = ISP ? 0 : C::NIN;                    // register-staged 16-byte items per thread and step
     constexpr int NINA = NIN > 0 ? NIN : 1;                  // (array extents)
@@ -916,6 +919,24 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                         v[e] = x + rr[m][g][e];
                     }
                     if (ok) *(f32x4*)(op + g * gstep) = v;
+                    if constexpr (D2) {
+                        // second output: SiLU(v) split into (h, l); a lane holds HALF a 16-byte unit (4 of a pixel's 8 consecutive
+                        // channels), as in epilogue_sp
+                        f32x4 a;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] = split_silu(v[e]);
+                        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+                        const f16x4 h = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3]};
+                        const f16x4 l = {(_Float16)((a[0] - (float)h[0]) * 2048.0f), (_Float16)((a[1] - (float)h[1]) * 2048.0f),
+                                         (_Float16)((a[2] - (float)h[2]) * 2048.0f), (_Float16)((a[3] - (float)h[3]) * 2048.0f)};
+                        const int c8 = cbase - 4 * lh + 8 * g;                          // first channel of the lane's unit
+                        const size_t PS2 = (size_t)yond_sp_plane_units(Hout, Wout);
+                        char* pp = (char*)d.dst2 + ((size_t)(((T.n * (Cr / 16) + (c8 >> 4)) * 2 + ((c8 >> 3) & 1)) * 2) * PS2 + (size_t)pixo) * 16 + lh * 8;
+                        if (ok) {
+                            *(f16x4*)pp = h;
+                            *(f16x4*)(pp + PS2 * 16) = l;
+                        }
+                    }
                 }
             }
         }
@@ -1123,12 +1144,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     }
 }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false, bool S2 = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false, bool S2 = false, bool D2 = false>
 int launch_split(const YondConvDesc& d, hipStream_t st) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
     static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP, S2>;
+    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP, S2, D2>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -1171,6 +1192,7 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
     X(1, 8, 32, 1, 2, 3, false, false, true, 2, false) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false) \
     X(2, 4, 64, 1, 2, 2, false, false, false, 2, false)
 #define SPLIT_GROUP_K1_SUB2(X) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, true)
+#define SPLIT_GROUP_D2(X) X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true)
 #define SPLIT_GROUP_WRES(X)                                                                             \
     X(1, 16, 32, 2, 2, 2, true, false, false, false, true) X(1, 16, 32, 2, 2, 2, false, false, false, true, true) \
     X(1, 16, 32, 2, 2, 2, false, true, false, true, false)

@@ -46,6 +46,8 @@ SPLIT_PLANES = True
 SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
 FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
 K1_SUB2 = True                      # the decoder GEMMs with two sub-positions per channel tile (YondConvDesc.shuffle 2)
+SP_CONV1_MIN_LEVEL = 3              # from this level down a stride-2 layer also stores SiLU(x) in split planes (YondConvDesc.dst2), so that the
+                                    # next block's conv1 stages by LDS-DMA alone (there conv1 would repeat the SiLU + split per output-channel tile)
 SNAKE_ORDER = True                  # consecutive split-operand launches walk their tiles in opposite directions (YondConvDesc.tile_order):
                                     # a consumer starts with what its producer touched last, i.e. what the Infinity Cache still holds
 
@@ -337,7 +339,7 @@ class DenoiserPlan:
         return cache[k]
 
     def _conv(self, pc, src0, src1, N, H, W, dst, escale=None, eshift=None, ebatch=0, res=None, pre_act=0, post_act=0,
-              slope=0.0, algo=None, out4=None, in_fmt=0, out_fmt=0, res_fmt=0):
+              slope=0.0, algo=None, out4=None, in_fmt=0, out_fmt=0, res_fmt=0, dst2=None):
         d = L.YondConvDesc()
         d.src0 = src0.data_ptr()
         d.src1 = src1.data_ptr() if src1 is not None else None
@@ -395,6 +397,7 @@ class DenoiserPlan:
         status = getattr(self, 'status', None)                       # (bare plans of the kernel tests have none)
         d.status = status.data_ptr() + 4 * self.status_slot if status is not None else None
         d.in_fmt, d.out_fmt, d.res_fmt = in_fmt, out_fmt, res_fmt
+        d.dst2 = dst2.data_ptr() if dst2 is not None else None
         if SNAKE_ORDER and d.algo in (3, 4):
             self._tile_order = 1 - getattr(self, '_tile_order', 0)      # (the first layer, conv_in, runs first row to last)
             d.tile_order = self._tile_order
@@ -526,6 +529,7 @@ class DenoiserPlan:
             skips = {}
             h, w = H, W
             cur = a
+            xsp = None                                           # SiLU(x) in split planes, stored by the stride-2 layer that produced x
             for i in range(1, 10):
                 blk = self.blocks[i]
                 cp = blk['Cp']
@@ -548,8 +552,14 @@ class DenoiserPlan:
                 sp = SP if (flow or (act_in_producer and SPLIT_PLANES and getattr(self, 'precision', 'fp32') == 'fp32'
                                       and sp_plane_units(h, w) * 64 < 2 ** 31)) else 0
                 tmp = self._new_sp(('tmp', i), N, h, w, cp) if sp else self._new(N, h, w, cp)
-                self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1,
-                           post_act=1 if act_in_producer else 0, in_fmt=xfmt, out_fmt=sp)
+                if xsp is not None and sp and act_in_producer:
+                    # conv1's input as the producer of x stored it: SiLU applied, split -- staged by LDS-DMA alone
+                    self._conv(blk['conv1'], xsp, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=0, post_act=1,
+                               in_fmt=SP, out_fmt=sp)
+                else:
+                    self._conv(blk['conv1'], cur, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1,
+                               post_act=1 if act_in_producer else 0, in_fmt=xfmt, out_fmt=sp)
+                xsp = None
                 pre2 = 0 if act_in_producer else 1
                 if last and self._out4_fusable(blk['conv2']):
                     # the last block's output feeds only the 1x1 output projection: computed in this epilogue, never stored
@@ -568,7 +578,8 @@ class DenoiserPlan:
                 if i <= 4:
                     skips[i] = cur
                     nxt = self._new(N, h // 2, w // 2, blk['pool'].coutp)
-                    self._conv(blk['pool'], cur, None, N, h, w, nxt, in_fmt=SP if flow else 0, out_fmt=P4 if flow else 0)
+                    xsp = self._new_sp(('xsp', i + 1), N, h // 2, w // 2, blk['pool'].coutp) if (flow and i >= SP_CONV1_MIN_LEVEL) else None   # (level of block i + 1 = i)
+                    self._conv(blk['pool'], cur, None, N, h, w, nxt, in_fmt=SP if flow else 0, out_fmt=P4 if flow else 0, dst2=xsp)
                     h, w = h // 2, w // 2
                     cur = nxt
             feat = cur

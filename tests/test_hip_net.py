@@ -136,3 +136,32 @@ def test_split_path_range_guard():
         warnings.simplefilter("always")
         P.VST_Denoiser(x, p, net2, arch, bias_corr='pre')
     assert not any("fp16's range" in str(w.message) for w in wlist)
+
+
+def test_engine_flow_switches_are_bit_identical():
+    """The data-flow variants of one GuidedResUnet forward -- every tensor [N][H][W][C]; split planes; + alternating tile order, two
+    sub-positions per tile in the last decoder GEMM, the stride-2 layers' second output (conv1 by LDS-DMA at the deep levels) --
+    give the same bits: they move the same float32 values through different layouts and orders."""
+    import torch
+    from yond_public_amd import engine as E
+    from yond_public_amd import pipeline as P
+    arch = ARCHS["gru32"]
+    net, _ = make_net(arch, 5)
+    plan = P._plan_of(net, torch.device(DEV))
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.rand((2, 160, 224, 4), device=DEV, generator=g)
+    t = torch.tensor([0.03, 0.08], device=DEV)
+    ub = x.reshape(2, -1).max(1).values.contiguous()
+    saved = (E.SPLIT_PLANES, E.SP_FLOW, E.SNAKE_ORDER, E.K1_SUB2, E.SP_CONV1_MIN_LEVEL)
+    outs = []
+    try:
+        for cfg in ((False, False, False, False, 99), (True, False, False, False, 99), (True, True, False, False, 99),
+                    (True, True, True, False, 99), (True, True, True, True, 99), (True, True, True, True, 3), (True, True, True, True, 2)):
+            E.SPLIT_PLANES, E.SP_FLOW, E.SNAKE_ORDER, E.K1_SUB2, E.SP_CONV1_MIN_LEVEL = cfg
+            outs.append(plan.forward_nhwc4(x, t, ub=ub).clone())
+    finally:
+        E.SPLIT_PLANES, E.SP_FLOW, E.SNAKE_ORDER, E.K1_SUB2, E.SP_CONV1_MIN_LEVEL = saved
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0]).all())
+    for i, o in enumerate(outs[1:], 1):
+        assert torch.equal(o, outs[0]), (i, float((o - outs[0]).abs().max()))

@@ -48,6 +48,7 @@ FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue 
 K1_SUB2 = True                      # the decoder GEMMs with two sub-positions per channel tile (YondConvDesc.shuffle 2)
 SP_CONV1_MIN_LEVEL = 3              # from this level down a stride-2 layer also stores SiLU(x) in split planes (YondConvDesc.dst2), so that the
                                     # next block's conv1 stages by LDS-DMA alone (there conv1 would repeat the SiLU + split per output-channel tile)
+UNET_SP = True                      # UNetSeeInDark: the tensor between the two convolutions of a stage in split planes (LeakyReLU applied by the producer)
 SNAKE_ORDER = True                  # consecutive split-operand launches walk their tiles in opposite directions (YondConvDesc.tile_order):
                                     # a consumer starts with what its producer touched last, i.e. what the Infinity Cache still holds
 
@@ -591,15 +592,26 @@ class DenoiserPlan:
             h, w = H, W
             cur = self._conv(cv['conv1_2'], a, None, N, h, w, self._new(N, h, w, cv['conv1_2'].coutp), post_act=2, slope=0.2)
             skips = {1: cur}
+
+            def first_of_pair(i, c1, c2, s0, s1):
+                """conv{i}_1 -> LeakyReLU: its one reader is conv{i}_2, so at split precision the tensor travels in split planes
+                (the producer applies the activation and the split, the consumer stages by LDS-DMA alone: the same bits).
+                Returns (tensor, in_fmt for conv{i}_2)."""
+                sp = (UNET_SP and SPLIT_PLANES and not getattr(self, 'strict', False) and getattr(self, 'conv_algo', WINO_DEFAULT) == 'split'
+                      and getattr(self, 'precision', 'fp32') == 'fp32' and c1.split(2) is not None and c2.split(2) is not None
+                      and N * sp_plane_units(h, w) * 64 < 2 ** 31)
+                dst = self._new_sp(('utmp', i), N, h, w, c1.coutp) if sp else self._new(N, h, w, c1.coutp)
+                self._conv(c1, s0, s1, N, h, w, dst, post_act=2, slope=0.2, out_fmt=1 if sp else 0)
+                return dst, (1 if sp else 0)
+
             for i in range(2, 6):
                 cpv = cur.shape[-1]
                 pooled = self._new(N, h // 2, w // 2, cpv)
                 L.check(lib.yond_maxpool2_f32(L.ptr(cur), N, h, w, cpv, L.ptr(pooled), st), "yond_maxpool2_f32")
                 h, w = h // 2, w // 2
-                c1 = cv[f'conv{i}_1']
-                cur = self._conv(c1, pooled, None, N, h, w, self._new(N, h, w, c1.coutp), post_act=2, slope=0.2)
-                c2 = cv[f'conv{i}_2']
-                cur = self._conv(c2, cur, None, N, h, w, self._new(N, h, w, c2.coutp), post_act=2, slope=0.2)
+                c1, c2 = cv[f'conv{i}_1'], cv[f'conv{i}_2']
+                cur, fmt = first_of_pair(i, c1, c2, pooled, None)
+                cur = self._conv(c2, cur, None, N, h, w, self._new(N, h, w, c2.coutp), post_act=2, slope=0.2, in_fmt=fmt)
                 if i < 5:
                     skips[i] = cur
             for i in range(6, 10):
@@ -607,15 +619,14 @@ class DenoiserPlan:
                 up = self._new(N, 2 * h, 2 * w, upc.cout_real_p)
                 self._conv(upc, cur, None, N, h, w, up)
                 h, w = 2 * h, 2 * w
-                c1 = cv[f'conv{i}_1']
-                cur = self._conv(c1, up, skips[10 - i], N, h, w, self._new(N, h, w, c1.coutp), post_act=2, slope=0.2)
-                c2 = cv[f'conv{i}_2']
+                c1, c2 = cv[f'conv{i}_1'], cv[f'conv{i}_2']
+                cur, fmt = first_of_pair(i, c1, c2, up, skips[10 - i])
                 if i == 9 and self._out4_fusable(c2):
                     out4 = self._new(N, H, W, 4)
-                    self._conv(c2, cur, None, N, h, w, None, post_act=2, slope=0.2,
+                    self._conv(c2, cur, None, N, h, w, None, post_act=2, slope=0.2, in_fmt=fmt,
                                out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4))
                     return out4
-                cur = self._conv(c2, cur, None, N, h, w, self._new(N, h, w, c2.coutp), post_act=2, slope=0.2)
+                cur = self._conv(c2, cur, None, N, h, w, self._new(N, h, w, c2.coutp), post_act=2, slope=0.2, in_fmt=fmt)
             feat = cur
         out4 = self._new(N, H, W, 4)
         L.check(lib.yond_conv_out_f32(L.ptr(feat), feat.shape[-1], L.ptr(self.w_out), L.ptr(self.b_out),

@@ -165,3 +165,26 @@ def test_engine_flow_switches_are_bit_identical():
     assert bool(torch.isfinite(outs[0]).all())
     for i, o in enumerate(outs[1:], 1):
         assert torch.equal(o, outs[0]), (i, float((o - outs[0]).abs().max()))
+
+
+def test_unet_split_plane_pairs_bit_identical():
+    """UNetSeeInDark with the stage-internal tensors in split planes (engine.UNET_SP) against every tensor [N][H][W][C]: same bits."""
+    import torch
+    from yond_public_amd import engine as E
+    from yond_public_amd import pipeline as P
+    arch = ARCHS["unet32"]
+    net, _ = make_net(arch, 3)
+    plan = P._plan_of(net, torch.device(DEV))
+    g = torch.Generator(device=DEV).manual_seed(10)
+    x = torch.rand((2, 96, 160, 4), device=DEV, generator=g)
+    ub = x.reshape(2, -1).max(1).values.contiguous()
+    saved = E.UNET_SP
+    try:
+        E.UNET_SP = False
+        a = plan.forward_nhwc4(x, None, ub=ub).clone()
+        E.UNET_SP = True
+        b = plan.forward_nhwc4(x, None, ub=ub).clone()
+    finally:
+        E.UNET_SP = saved
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b), float((a - b).abs().max())

@@ -334,6 +334,7 @@ class TrainStep:
                     "yond_charbonnier_loss_f32")
         else:
             L.check(lib.yond_l1_loss_f32(L.ptr(pred), L.ptr(tgt), pred.numel(), L.ptr(loss_sum), L.ptr(dpred), L.stream()), "yond_l1_loss_f32")
+        self.last_pred = pred.detach()                       # the trainer's running PSNR (trainer_AWGN.py:120-124)
         pred.backward(dpred)                                 # (the reducer's hooks launch a bucket's all-reduce as its last gradient lands)
         if self.reducer is not None:
             self.reducer.finish()                            # .grad = the mean over the ranks

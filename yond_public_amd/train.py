@@ -34,6 +34,8 @@ from .engine import DenoiserPlan, _PackedConv, _rup
 def _plan(dev):
     plan = DenoiserPlan.__new__(DenoiserPlan)
     plan.lib, plan.dev = L.load(), torch.device(dev)
+    plan.arena = None                # TrainStep: every parameter in one flat device buffer, element 0 a constant zero
+    plan.wcache = {}                 # (parameter, role, shape) -> packed-layout constants (_Packing), built once
     return plan
 
 
@@ -42,14 +44,54 @@ def _pad_c(x, cp):
     return x if x.shape[-1] == cp else F.pad(x, (0, cp - x.shape[-1]))
 
 
-def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False):
-    pc = _PackedConv(plan.dev, w.detach().cpu(), None if b is None else b.detach().cpu(), ksize, stride, splits, shuffle=shuffle)
+class _Packing:
+    """The device-side constants of one convolution whose weights live in the parameter arena: the kernel's packed weight layout
+    is a fixed gather of arena elements (index 0 = the arena's zero, for the channel padding), computed ONCE by pushing the
+    parameter's element numbers through the same re-indexing (`xf`) and the same host packer the weights themselves would take
+    (element numbers stay exact in float32: the largest layer has 2.4 M weights < 2^24).  Every step re-packs with one gather on
+    the device; nothing crosses the host."""
+
+    def __init__(self, plan, w, b, xf, ksize, stride, splits, shuffle, N, Ho, Wo):
+        arena = plan.arena
+        base = (w.data_ptr() - arena.data_ptr()) // 4
+        assert 0 < base and base + w.numel() <= arena.numel() and w.numel() < (1 << 24)
+        ids = torch.arange(1, w.numel() + 1, dtype=torch.float32).reshape(w.shape)
+        self.pc = _PackedConv(plan.dev, xf(ids), None, ksize, stride, splits, shuffle=shuffle)
+        tn, kc, packed_ids = self.pc.config(N, Ho, Wo)
+        ids = packed_ids.round().long()
+        self.key = (tn, kc, False)
+        self.wmap = torch.where(ids > 0, ids - 1 + base, torch.zeros_like(ids))
+        self.bmap = None
+        if b is not None:
+            bb = (b.data_ptr() - arena.data_ptr()) // 4
+            bm = torch.zeros(self.pc.coutp, dtype=torch.long)
+            bm[:b.numel()] = torch.arange(bb, bb + b.numel())
+            self.bmap = bm.to(plan.dev)
+
+    def refresh(self, arena):
+        self.pc._packed[self.key] = arena.index_select(0, self.wmap)
+        if self.bmap is not None:
+            self.pc.bias = arena.index_select(0, self.bmap)
+        return self.pc
+
+
+def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False, role='fwd', xf=None):
+    """One convolution launch with `xf(w)` as its OIHW weights (xf: the re-indexing that turns the parameter into this launch's
+    weights -- identity for a forward, flip + transpose for a data gradient; it must work on CPU and device tensors alike)."""
+    xf = xf if xf is not None else (lambda t: t)
+    Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W)
+    if plan.arena is not None:
+        key = (w.data_ptr(), role, ksize, stride, tuple(splits), bool(shuffle), N, H, W)
+        pk = plan.wcache.get(key)
+        if pk is None:
+            pk = plan.wcache[key] = _Packing(plan, w, b, xf, ksize, stride, splits, shuffle, N, Ho, Wo)
+        pc = pk.refresh(plan.arena)
+    else:                            # a bare plan (kernel tests): pack on the host
+        pc = _PackedConv(plan.dev, xf(w.detach()).cpu(), None if b is None else b.detach().cpu(), ksize, stride, splits, shuffle=shuffle)
     if shuffle:
         out = torch.empty((N, 2 * H, 2 * W, pc.cout_real_p), dtype=torch.float32, device=plan.dev)
-    elif stride == 2:
-        out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, pc.coutp), dtype=torch.float32, device=plan.dev)
     else:
-        out = torch.empty((N, H, W, pc.coutp), dtype=torch.float32, device=plan.dev)
+        out = torch.empty((N, Ho, Wo, pc.coutp), dtype=torch.float32, device=plan.dev)
     plan._conv(pc, srcs[0], srcs[1] if len(srcs) > 1 else None, N, H, W, out, algo=0)
     return out
 
@@ -99,8 +141,8 @@ class _Conv3x3(torch.autograd.Function):
             if stride == 2:                            # zero-interleave: the stride-2 layer's adjoint = a stride-1 one on this
                 g = torch.zeros((N, H, W, dy.shape[-1]), dtype=torch.float32, device=dy.device)
                 g[:, ::2, ::2] = dy
-            wt = w.detach().flip(2, 3).transpose(0, 1).contiguous()            # [cin][cout][2-ky][2-kx]
-            dx = _conv_fwd(plan, wt, None, 3, 1, [cout], [g], N, H, W)
+            dx = _conv_fwd(plan, w, None, 3, 1, [cout], [g], N, H, W, role='dgrad',
+                           xf=lambda t: t.flip(2, 3).transpose(0, 1).contiguous())          # [cin][cout][2-ky][2-kx]
             dx = _pad_c(dx[..., :cin], cin_p) if dx.shape[-1] != cin_p else dx
         return dx, dw, db, None, None, None
 
@@ -130,8 +172,8 @@ class _Conv3x3Cat(torch.autograd.Function):
         dws, dxs = [], []
         for x, lo, c in ((x0, 0, c0), (x1, c0, c1)):
             dws.append(_wgrad(plan, x, dy, 0, 1, 9)[:, :cout, :c].permute(1, 2, 0).reshape(cout, c, 3, 3))
-            wt = w.detach()[:, lo:lo + c].flip(2, 3).transpose(0, 1).contiguous()        # [c][cout][2-ky][2-kx]
-            dx = _conv_fwd(plan, wt, None, 3, 1, [cout], [dy], N, H, W)
+            dx = _conv_fwd(plan, w, None, 3, 1, [cout], [dy], N, H, W, role=('dgrad', lo),
+                           xf=lambda t, lo=lo, c=c: t[:, lo:lo + c].flip(2, 3).transpose(0, 1).contiguous())    # [c][cout][2-ky][2-kx]
             dxs.append(dx if dx.shape[-1] == x.shape[-1] else _pad_c(dx[..., :c], x.shape[-1]))
         db = _colsum(plan, dy)[:cout]
         return dxs[0], dxs[1], torch.cat(dws, 1), db, None, None
@@ -157,12 +199,11 @@ class _Conv1x1(torch.autograd.Function):
         dy = dy.contiguous()
         N, H, W, _ = dy.shape
         cout = w.shape[0]
-        w2 = w.detach()[:, :, 0, 0]
         dws, dxs, off = [], [], 0
         for x, s in zip(srcs, splits):
             dws.append(_wgrad(plan, x, dy, 2, 1, 1)[0, :cout, :s])
-            wt = w2[:, off:off + s].t().contiguous()[:, :, None, None]        # [s][cout][1][1]
-            dx = _conv_fwd(plan, wt, None, 1, 1, [cout], [dy], N, H, W)
+            dx = _conv_fwd(plan, w, None, 1, 1, [cout], [dy], N, H, W, role=('dgrad', off),
+                           xf=lambda t, off=off, s=s: t[:, off:off + s, 0, 0].t().contiguous()[:, :, None, None])   # [s][cout][1][1]
             dxs.append(dx if dx.shape[-1] == x.shape[-1] else _pad_c(dx[..., :s], x.shape[-1]))
             off += s
         dw = torch.cat(dws, 1)[:, :, None, None]
@@ -201,9 +242,12 @@ class _ConvT2x2(torch.autograd.Function):
         db = _colsum(plan, dy)[:cout]
         # adjoint: dx[y][x][ci] = sum_{dy,dx,co} g[2y+dy][2x+dx][co] W[ci][co][dy][dx] = a 1x1 GEMM on the pixel-unshuffled gradient
         gu = dy.reshape(N, H, 2, W, 2, cop).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, 4 * cop).contiguous()
-        m = torch.zeros((cin, 4, cop), dtype=torch.float32, device=w.device)
-        m[:, :, :cout] = w.detach().permute(0, 2, 3, 1).reshape(cin, 4, cout)
-        dx = _conv_fwd(plan, m.reshape(cin, 4 * cop, 1, 1), None, 1, 1, [4 * cop], [gu], N, H, W)
+
+        def xf(t):
+            m = torch.zeros((cin, 4, cop), dtype=torch.float32, device=t.device)
+            m[:, :, :cout] = t.permute(0, 2, 3, 1).reshape(cin, 4, cout)
+            return m.reshape(cin, 4 * cop, 1, 1)
+        dx = _conv_fwd(plan, w, None, 1, 1, [4 * cop], [gu], N, H, W, role='dgrad', xf=xf)
         dx = dx if dx.shape[-1] == cin_p else _pad_c(dx[..., :cin], cin_p)
         return dx, dw, db, None
 
@@ -222,7 +266,23 @@ class TrainStep:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.charbonnier = bool(charbonnier)
         self.params = dict(module.named_parameters())
-        self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in self.params.items()}
+        # the parameter arena: [0] a constant zero, then every parameter back to back; the Parameters become views of it (Adam
+        # is ONE launch over the arena, and every convolution's packed weights are a gather of it: _Packing)
+        n = sum(p.numel() for p in self.params.values())
+        self.arena = torch.zeros(n + 1, dtype=torch.float32, device=self.dev)
+        off = 1
+        self.slots = {}
+        for k, p in self.params.items():
+            if p.dtype != torch.float32 or p.device != self.arena.device:
+                raise L.YondHipError(f"TrainStep: parameter {k} must be a float32 tensor on {self.dev}")
+            self.arena[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.arena[off:off + p.numel()].view(p.shape)
+            self.slots[k] = (off, p.numel())
+            off += p.numel()
+        self.plan.arena = self.arena
+        self.adam_m, self.adam_v = torch.zeros_like(self.arena), torch.zeros_like(self.arena)
+        self.state = {k: (self.adam_m[o:o + c].view(self.params[k].shape), self.adam_v[o:o + c].view(self.params[k].shape))
+                      for k, (o, c) in self.slots.items()}
         self.t = 0
         self.reducer = None
         if ddp is not False and D._active():
@@ -339,14 +399,13 @@ class TrainStep:
         if self.reducer is not None:
             self.reducer.finish()                            # .grad = the mean over the ranks
         self.t += 1
-        grads = {}
-        for k, p in self.params.items():
-            g = p.grad if p.grad is not None else torch.zeros_like(p)
-            g = g.contiguous()
-            grads[k] = g
-            mstate, vstate = self.state[k]
-            L.check(lib.yond_adam_step_f32(L.ptr(p.data), L.ptr(g), L.ptr(mstate), L.ptr(vstate), p.numel(), self.lr, self.betas[0],
-                                           self.betas[1], self.eps, self.t, L.stream()), "yond_adam_step_f32")
+        zero = self.arena.new_zeros(1)
+        flat = torch.cat([zero] + [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params.values()])
+        grads = {k: flat[o:o + c].view(self.params[k].shape) for k, (o, c) in self.slots.items()}
+        if self.params[next(iter(self.params))].data_ptr() != self.arena.data_ptr() + 4:
+            raise L.YondHipError("TrainStep: the module's parameters were moved (.to / .float) after the step object was built")
+        L.check(lib.yond_adam_step_f32(L.ptr(self.arena), L.ptr(flat), L.ptr(self.adam_m), L.ptr(self.adam_v), self.arena.numel(),
+                                       self.lr, self.betas[0], self.betas[1], self.eps, self.t, L.stream()), "yond_adam_step_f32")
         self.m._plan = None                                  # the inference plan's packed weights are stale now
         return float(loss_sum.item()) / pred.numel(), grads
 

@@ -16,55 +16,165 @@ struct WgradGeom {
     int Ho, Wo, Cout;          // dY: [N][Ho][Wo][Cout]
     int mode;                  // 0: 3x3 pad 1 (stride s), 1: 2x2 stride-2 transposed (Ho = 2H, Wo = 2W), 2: 1x1
     int stride, taps;
-    int chunk;                 // GEMM-K pixels per wave
+    int chunk;                 // K-space rows per wave
 };
 
-// One wave per (tap, 32-wide co tile, 32-wide ci tile, pixel chunk).  MFMA 32x32x2: lane l supplies A[row l&31][k = l>>5]
-// and B[k = l>>5][col l&31]: A = dY (row = output channel), B = X (column = input channel), k = two consecutive pixels of
-// the chunk -- lanes 0..31 read 32 consecutive channels of one pixel, lanes 32..63 of the next (two 128-byte segments).
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, WgradGeom g,
-                                                    float* __restrict__ dw /* [taps][Cout][Cin], zeroed by the caller */) {
+// One wave per (NCO 32-wide co tiles, one 32-wide ci tile, chunk of K-space rows), ALL taps at once.  MFMA 32x32x2: lane l supplies
+// A[row l&31][k = l>>5] and B[k = l>>5][col l&31]: A = dY (row = output channel), B = X (column = input channel), k = two
+// neighbouring pixels of a row -- lanes 0..31 read 32 consecutive channels of one pixel, lanes 32..63 of the next (two 128-byte
+// segments).  Per pixel pair a 3x3 layer loads NCO values of dY and nine of X (the 3x3 neighbourhood; rows outside the image are
+// skipped wave-uniformly, columns outside it read as zero) and issues 9 NCO MFMAs into 9 NCO accumulators (AGPRs), so a loaded
+// operand feeds 9 (dY) or NCO (X) products instead of one; the transposed 2x2 layer is the mirror image (one X value, 4 NCO of dY).
+// The next pair's operands are fetched before the current pair's MFMAs are issued (one wave per SIMD: nothing else hides the
+// L2 latency), rows follow one another without draining that pipeline.  K-space rows: dY rows, or X rows for the transposed layer.
+template <int MODE, int NCO>
+__global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict__ x, const float* __restrict__ dy, WgradGeom g,
+                                                         float* __restrict__ dw /* [taps][Cout][Cin], zeroed by the caller */) {
+    // taps per wave: a 3x3 layer's kernel rows go to three different waves (grid x = ky-major): 3 NCO accumulators = 96 registers
+    // at NCO 2, two waves per SIMD -- nine taps in one wave (288 registers) left one wave per SIMD and nothing to hide latency with
+    constexpr int TAPS = MODE == 0 ? 3 : (MODE == 1 ? 4 : 1);
+    constexpr int NA = MODE == 1 ? 4 * NCO : NCO, NB = MODE == 0 ? 3 : 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lk = lane >> 5;
-    const int nci = g.Cin / 32, nco = g.Cout / 32;
-    int b = blockIdx.x;
-    const int cit = b % nci; b /= nci;
-    const int cot = b % nco; b /= nco;
-    const int tap = b;
-    // GEMM-K index space: for mode 1 the pixels of X (each pairs with ONE dY pixel per tap), else the pixels of dY
-    const long long npix = g.mode == 1 ? (long long)g.N * g.H * g.W : (long long)g.N * g.Ho * g.Wo;
-    const long long p0 = ((long long)blockIdx.y * 4 + wave) * g.chunk;
-    if (p0 >= npix) return;
-    const long long p1 = p0 + g.chunk < npix ? p0 + g.chunk : npix;
-    const int ky = g.mode == 0 ? tap / 3 : tap / 2, kx = g.mode == 0 ? tap % 3 : tap % 2;
-    f32x16 acc;
+    const int nci = g.Cin / 32, ntile = nci * (g.Cout / (32 * NCO));
+    const int ky = MODE == 0 ? blockIdx.x / ntile : 0;
+    const int tile = MODE == 0 ? blockIdx.x % ntile : blockIdx.x;
+    const int cit = tile % nci, cog = tile / nci;
+    const int Hk = MODE == 1 ? g.H : g.Ho, Wk = MODE == 1 ? g.W : g.Wo;
+    const long long rows = (long long)g.N * Hk;
+    const long long r0 = ((long long)blockIdx.y * 4 + wave) * g.chunk;
+    if (r0 >= rows) return;
+    const long long r1 = r0 + g.chunk < rows ? r0 + g.chunk : rows;
+    const float* xb = x + cit * 32 + li;
+    const float* dyb = dy + cog * (32 * NCO) + li;
+    const int s = g.stride;
+
+    f32x16 acc[TAPS][NCO];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (long long q = p0; q < p1; q += 2) {            // (wave-uniform trip count: the MFMA needs every lane)
-        const long long p = q + lk;
-        float a = 0.0f, bv = 0.0f;
-        if (p < p1) {
-            if (g.mode == 1) {
-                const int xq = (int)(p % g.W);
-                const long long t = p / g.W;
-                const int yq = (int)(t % g.H), n = (int)(t / g.H);
-                bv = x[p * g.Cin + cit * 32 + li];
-                a = dy[(((long long)n * g.Ho + 2 * yq + ky) * g.Wo + 2 * xq + kx) * g.Cout + cot * 32 + li];
-            } else {
-                const int xo = (int)(p % g.Wo);
-                const long long t = p / g.Wo;
-                const int yo = (int)(t % g.Ho), n = (int)(t / g.Ho);
-                a = dy[p * g.Cout + cot * 32 + li];
-                const int yi = g.mode == 0 ? yo * g.stride + ky - 1 : yo, xi = g.mode == 0 ? xo * g.stride + kx - 1 : xo;
-                if (yi >= 0 && yi < g.H && xi >= 0 && xi < g.W) bv = x[(((long long)n * g.H + yi) * g.W + xi) * g.Cin + cit * 32 + li];
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.0f;
+
+    // operands of the pixel pair (row, xo .. xo + 1); ymask: bit ky set = that input row lies inside the image (wave-uniform)
+    auto fetch = [&](long long row, int n, int y, int xo, float (&a)[NA], float (&b)[NB], unsigned& ymask) {
+        const int px = xo + lk;
+        const bool inb = px < Wk;
+        if constexpr (MODE == 0) {
+            // wave-uniform row bases (scalar registers) + 32-bit per-lane offsets
+            const float* dyr = dy + row * Wk * g.Cout;
+            const int aoff = px * g.Cout + cog * (32 * NCO) + li;
+            const int yi = y * s + ky - 1;
+            const bool yv = yi >= 0 && yi < g.H;                    // (wave-uniform: a row outside the image costs nothing)
+            ymask = yv ? 1u : 0u;
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) a[c] = (yv && inb) ? dyr[aoff + 32 * c] : 0.0f;
+            const float* xr = x + ((long long)n * g.H + (yv ? yi : 0)) * g.W * g.Cin;
+            const int xi0 = px * s - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xi = xi0 + kx;
+                const bool ok = yv && inb && xi >= 0 && xi < g.W;
+                b[kx] = ok ? xr[xi * g.Cin + cit * 32 + li] : 0.0f;
             }
+        } else if constexpr (MODE == 1) {
+            ymask = 7u;
+            b[0] = inb ? xb[(row * Wk + px) * g.Cin] : 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky) {
+                const float* dr = dyb + (((long long)n * g.Ho + 2 * y + ky) * g.Wo + 2 * px) * g.Cout;
+#pragma unroll
+                for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c) a[(ky * 2 + kx) * NCO + c] = inb ? dr[kx * g.Cout + 32 * c] : 0.0f;
+            }
+        } else {
+            ymask = 7u;
+            const long long p = row * Wk + px;
+            b[0] = inb ? xb[p * g.Cin] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) a[c] = inb ? dyb[p * g.Cout + 32 * c] : 0.0f;
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    };
+
+    // D pairs in flight: stage d holds the operands of position i + d; a stage is refilled (position i + D) right behind its MFMAs
+    constexpr int D = 4;
+    const int ppr = (Wk + 1) / 2;                                   // positions (pixel pairs) per row
+    const long long total = (r1 - r0) * ppr;
+    long long frow = r0;                                            // the fetch cursor
+    int fn = (int)(r0 / Hk), fy = (int)(r0 - (long long)fn * Hk), fxo = 0;
+    long long fetched = 0;
+    float pa[D][NA], pb[D][NB];
+    unsigned pm[D];
+    auto fetch_next = [&](float (&a)[NA], float (&b)[NB], unsigned& m) {
+        if (fetched < total) {
+            fetch(frow, fn, fy, fxo, a, b, m);
+            fxo += 2;
+            if (fxo >= Wk) {
+                fxo = 0;
+                ++frow;
+                if (++fy == Hk) { fy = 0; ++fn; }
+            }
+        } else {
+            m = 0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) a[i] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) b[i] = 0.0f;
+        }
+        ++fetched;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch_next(pa[d], pb[d], pm[d]);
+    for (long long i = 0; i < total; i += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if constexpr (MODE == 0) {
+                if (pm[d]) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c)
+                            acc[kx][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[d][c], pb[d][kx], acc[kx][c], 0, 0, 0);
+                }
+            } else {
+                if (pm[d]) {
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c)
+                            acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(MODE == 1 ? pa[d][t * NCO + c] : pa[d][c], pb[d][0], acc[t][c], 0, 0, 0);
+                }
+            }
+            fetch_next(pa[d], pb[d], pm[d]);
+        }
     }
     // D rows (output channel) (r&3) + 8 (r>>2) + 4 lk, column (input channel) li
-    float* out = dw + ((size_t)tap * g.Cout + cot * 32) * g.Cin + cit * 32 + li;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) atomicAdd(out + (size_t)((r & 3) + 8 * (r >> 2) + 4 * lk) * g.Cin, acc[r]);
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) {
+            float* out = dw + ((size_t)(MODE == 0 ? ky * 3 + t : t) * g.Cout + cog * (32 * NCO) + c * 32) * g.Cin + cit * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(out + (size_t)((r & 3) + 8 * (r >> 2) + 4 * lk) * g.Cin, acc[t][c][r]);
+        }
+}
+
+template <int MODE, int NCO>
+static void launch_wgrad(const float* x, const float* dy, WgradGeom g, float* dw, hipStream_t stream) {
+    const int Hk = MODE == 1 ? g.H : g.Ho, Wk = MODE == 1 ? g.W : g.Wo;
+    const long long rows = (long long)g.N * Hk;
+    const long long tiles = (long long)(g.Cout / (32 * NCO)) * (g.Cin / 32) * (MODE == 0 ? 3 : 1);
+    // one round of waves at the kernel's occupancy (256 CUs x 4 SIMDs x waves per SIMD), at least ~128 pixels per wave
+    const long long target = 1024 * (MODE == 0 ? (NCO == 2 ? 2 : 4) : (MODE == 1 ? 3 : 4));
+    long long chunks = (target + tiles - 1) / tiles;
+    long long min_rows = (128 + Wk - 1) / Wk;
+    long long chunk = (rows + chunks - 1) / chunks;
+    if (chunk < min_rows) chunk = min_rows;
+    g.chunk = (int)chunk;
+    chunks = (rows + chunk - 1) / chunk;
+    hipLaunchKernelGGL((wgrad_rows_kernel<MODE, NCO>), dim3((unsigned)tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, stream, x, dy, g, dw);
 }
 
 extern "C" int yond_conv_wgrad_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode,
@@ -75,18 +185,14 @@ extern "C" int yond_conv_wgrad_f32(const float* x, const float* dy, int N, int H
     if (mode == 1 && (Ho != 2 * H || Wo != 2 * W)) return YOND_EINVAL;
     if (mode == 2 && (Ho != H || Wo != W)) return YOND_EINVAL;
     WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, mode, stride, mode == 0 ? 9 : (mode == 1 ? 4 : 1), 0};
-    const long long npix = mode == 1 ? (long long)N * H * W : (long long)N * Ho * Wo;
-    // ~1024 waves over the pixel axis at most; chunks of an even number of pixels
-    long long chunk = (npix + 1023) / 1024;
-    if (chunk < 64) chunk = 64;
-    chunk += chunk & 1;
-    g.chunk = (int)chunk;
-    const long long waves = (npix + chunk - 1) / chunk;
-    const unsigned gy = (unsigned)((waves + 3) / 4);
     const size_t bytes = (size_t)g.taps * Cout * Cin * sizeof(float);
     hipError_t e = hipMemsetAsync(dw, 0, bytes, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(g.taps * (Cout / 32) * (Cin / 32)), gy), dim3(256), 0, (hipStream_t)stream, x, dy, g, dw);
+    const bool two = Cout % 64 == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) two ? launch_wgrad<0, 2>(x, dy, g, dw, st) : launch_wgrad<0, 1>(x, dy, g, dw, st);
+    else if (mode == 1) launch_wgrad<1, 1>(x, dy, g, dw, st);          // (two tiles per wave: 309 registers, one wave per SIMD)
+    else two ? launch_wgrad<2, 2>(x, dy, g, dw, st) : launch_wgrad<2, 1>(x, dy, g, dw, st);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

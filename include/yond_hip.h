@@ -26,7 +26,7 @@ extern "C" {
 #define YOND_EUNSUPPORTED (-2) /* valid request the kernels do not cover (e.g. channel count) */
 
 /* Library / device probe.  Returns the ABI version (this header: YOND_ABI_VERSION; the loader refuses a mismatch). */
-#define YOND_ABI_VERSION 4
+#define YOND_ABI_VERSION 5
 int yond_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -231,6 +231,11 @@ int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, fl
  * [4*cout][C0+C1] (archs/Unet.py:445-463, modules.py:163-196) -- in the same kernel, for (C0+C1) % 48 == 0 and cout % 64 == 0. */
 int yond_conv_split_supported(int ksize, int stride, int cin, int cout);
 int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst);
+/* The same packing on the device (w and dst are device pointers; asynchronous on `stream`): the training step re-packs the
+ * weights it has just updated without a host round trip.  A weight outside fp16's range sets bit 0 of *status (device int,
+ * may be NULL) instead of failing the call. */
+int yond_pack_conv_split_weight_dev_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst, int* status,
+                                        void* stream);
 
 /* First layer: 3x3, Cin=4 -> Cout=32k, input NHWC4, optional division by the per-image maximum
  * (data_normalize, archs/Unet.py:427-431) and LeakyReLU(slope).  wpk from yond_pack_conv_in_weight_f32. */

@@ -37,6 +37,7 @@ ap.add_argument('--net', default='GuidedResUnet')
 ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--nf', type=int, default=32)
+ap.add_argument('--conv', default='split')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 arch = dict(name=a.net, in_nc=4, out_nc=4, nf=a.nf, nframes=1, res=True, norm=True)
@@ -46,7 +47,7 @@ torch.manual_seed(0)
 net = getattr(A, a.net)(arch)
 A.initialize_weights(net)
 net = net.to(dev)
-ts = TrainStep(net, lr=1e-4, ddp=False)
+ts = TrainStep(net, lr=1e-4, ddp=False, conv=a.conv)
 g = torch.Generator(device='cpu').manual_seed(1)
 hr = torch.rand(a.batch, 4, 128, 128, generator=g).to(dev)
 sigma = (torch.rand(a.batch, 1, 1, 1, generator=g) * 0.18 + 0.02).to(dev)
@@ -61,6 +62,6 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / a.steps * 1e3
 fl = conv_flops(net, a.batch, 128, 128)
-print(json.dumps({"net": a.net, "nf": a.nf, "batch": a.batch, "ms_per_step": round(ms, 3), "patches_per_s": round(a.batch / ms * 1e3, 1),
+print(json.dumps({"net": a.net, "nf": a.nf, "conv": a.conv, "batch": a.batch, "ms_per_step": round(ms, 3), "patches_per_s": round(a.batch / ms * 1e3, 1),
                   "bayer_mp_per_s": round(a.batch * 256 * 256 / ms / 1e3, 1), "fwd_conv_gflop": round(fl / 1e9, 1),
                   "step_tflops_nominal": round(3 * fl / ms / 1e9, 1), "loss": loss}))

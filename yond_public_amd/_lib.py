@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOND_HIP_LIB", os.path.join(_HERE, "libyond_hip.so"))   # override: experiments only
 _lib = None
-ABI_VERSION = 4                     # include/yond_hip.h YOND_ABI_VERSION
+ABI_VERSION = 5                     # include/yond_hip.h YOND_ABI_VERSION
 
 vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 
@@ -56,6 +56,7 @@ PROTOTYPES = {
     "yond_pack_conv_weight_split_f32": [vp, i32, i32, i32, i32, i32, vp],
     "yond_conv_split_supported": [i32, i32, i32, i32],
     "yond_pack_conv_split_weight_f32": [vp, i32, i32, i32, i32, i32, vp],
+    "yond_pack_conv_split_weight_dev_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "yond_conv_in_f32": [vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, i32, vp],
     "yond_pack_conv_in_weight_f32": [vp, i32, vp],
     "yond_conv_out_f32": [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp],

@@ -66,6 +66,46 @@ extern "C" int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin
     return YOND_OK;
 }
 
+// The same packing on the device (training: the weights change every step and never leave HBM).  One thread per 8 halves of the
+// destination; a weight outside fp16's range sets bit 0 of *status (when given) instead of failing the call.
+__global__ __launch_bounds__(256) void pack_split_weight_kernel(const float* __restrict__ w, int cout, int cin, int taps, int tn, int parts,
+                                                                uint4* __restrict__ dst, size_t ngroups, int* __restrict__ status) {
+    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    size_t g = gi;
+    const int j = (int)(g % tn); g /= tn;
+    const int p = (int)(g % parts); g /= parts;
+    const int hh = (int)(g % 2); g /= 2;
+    const int tap = (int)(g % taps); g /= taps;
+    const int nch = cin / 16;
+    const int ch = (int)(g % nch), ct = (int)(g / nch);
+    const int co = ct * tn + j;
+    union { _Float16 h[8]; uint4 v; } u;
+    bool over = false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = ch * 16 + hh * 8 + e;
+        const float v = w[((size_t)co * cin + ci) * taps + tap];
+        over |= !(fabsf(v) <= 65504.0f);
+        const _Float16 h = (_Float16)v;
+        u.h[e] = p == 0 ? h : (_Float16)((v - (float)h) * 2048.0f);
+    }
+    dst[gi] = u.v;
+    if (over && status) atomicOr(status, 1);
+}
+
+extern "C" int yond_pack_conv_split_weight_dev_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst, int* status,
+                                                   void* stream) {
+    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
+    if (ksize == 1 && cin % 48 != 0) return YOND_EINVAL;
+    const int taps = ksize * ksize;
+    const size_t ngroups = (size_t)cout * cin * taps * parts / 8;
+    hipLaunchKernelGGL(pack_split_weight_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin, taps, tn,
+                       parts, (uint4*)dst, ngroups, status);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
 int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     const int parts = d.algo == 3 ? 2 : 1;
     if (d.shuffle == 2) {

@@ -61,6 +61,14 @@ class _Packing:
         ids = packed_ids.round().long()
         self.key = (tn, kc, False)
         self.wmap = torch.where(ids > 0, ids - 1 + base, torch.zeros_like(ids))
+        # the split-operand kernel (fp16 matrix cores, fp32-accurate products) where it takes the layer: its packing holds (h, l)
+        # half pairs, not a permutation -- the padded OIHW weights are gathered, then packed by yond_pack_conv_split_weight_dev_f32
+        self.split_tn = 0
+        if getattr(plan, 'train_conv', 'split') == 'split' and bool(shuffle) == (ksize == 1):
+            self.split_tn = int(plan.lib.yond_conv_split_supported(ksize, stride, self.pc.cinp, self.pc.gemm_n))
+        if self.split_tn:
+            oid = torch.from_numpy(self.pc._wp.reshape(-1)).round().long()
+            self.omap = torch.where(oid > 0, oid - 1 + base, torch.zeros_like(oid)).to(plan.dev)
         self.bmap = None
         if b is not None:
             bb = (b.data_ptr() - arena.data_ptr()) // 4
@@ -68,8 +76,15 @@ class _Packing:
             bm[:b.numel()] = torch.arange(bb, bb + b.numel())
             self.bmap = bm.to(plan.dev)
 
-    def refresh(self, arena):
-        self.pc._packed[self.key] = arena.index_select(0, self.wmap)
+    def refresh(self, arena, lib):
+        if self.split_tn:
+            wp = arena.index_select(0, self.omap)
+            packed = torch.empty_like(wp)
+            L.check(lib.yond_pack_conv_split_weight_dev_f32(L.ptr(wp), self.pc.gemm_n, self.pc.cinp, self.pc.ksize, self.split_tn, 2,
+                                                            L.ptr(packed), None, L.stream()), "yond_pack_conv_split_weight_dev_f32")
+            self.pc._packed[('split', 2)] = (self.split_tn, packed)
+        else:
+            self.pc._packed[self.key] = arena.index_select(0, self.wmap)
         if self.bmap is not None:
             self.pc.bias = arena.index_select(0, self.bmap)
         return self.pc
@@ -85,14 +100,16 @@ def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False, r
         pk = plan.wcache.get(key)
         if pk is None:
             pk = plan.wcache[key] = _Packing(plan, w, b, xf, ksize, stride, splits, shuffle, N, Ho, Wo)
-        pc = pk.refresh(plan.arena)
+        pc = pk.refresh(plan.arena, plan.lib)
+        algo = 'split' if pk.split_tn else 0
     else:                            # a bare plan (kernel tests): pack on the host
         pc = _PackedConv(plan.dev, xf(w.detach()).cpu(), None if b is None else b.detach().cpu(), ksize, stride, splits, shuffle=shuffle)
+        algo = 0
     if shuffle:
         out = torch.empty((N, 2 * H, 2 * W, pc.cout_real_p), dtype=torch.float32, device=plan.dev)
     else:
         out = torch.empty((N, Ho, Wo, pc.coutp), dtype=torch.float32, device=plan.dev)
-    plan._conv(pc, srcs[0], srcs[1] if len(srcs) > 1 else None, N, H, W, out, algo=0)
+    plan._conv(pc, srcs[0], srcs[1] if len(srcs) > 1 else None, N, H, W, out, algo=algo)
     return out
 
 
@@ -255,14 +272,19 @@ class _ConvT2x2(torch.autograd.Function):
 class TrainStep:
     """One optimisation step of a yond_public_amd.archs.GuidedResUnet or UNetSeeInDark (parameter names / shapes of the reference)."""
 
-    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, charbonnier=False, ddp=None):
-        """charbonnier: Unet_Loss(charbonnier=True) (losses/base_loss.py:82-85).  ddp: None -- average the gradients over the
+    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, charbonnier=False, ddp=None, conv='split'):
+        """conv: 'split' -- forward and data-gradient 3x3 convolutions as fp32-accurate split-operand products on the fp16 matrix
+        cores (the inference path's kernels; 22-bit operands, fp32 accumulation); 'fp32' -- every convolution on the fp32-input
+        MFMA kernels (exact fp32 products).  charbonnier: Unet_Loss(charbonnier=True) (losses/base_loss.py:82-85).  ddp: None -- average the gradients over the
         ranks whenever a process group exists (the reference wraps the net in DDP whenever it sees more than one GPU,
         trainer_AWGN.py:59-61); False -- never."""
         from . import distributed as D
         self.m = module
         self.dev = next(module.parameters()).device
         self.plan = _plan(self.dev)
+        if conv not in ('split', 'fp32'):
+            raise ValueError(f"conv must be 'split' or 'fp32', got {conv!r}")
+        self.plan.train_conv = conv
         self.lr, self.betas, self.eps = lr, betas, eps
         self.charbonnier = bool(charbonnier)
         self.params = dict(module.named_parameters())

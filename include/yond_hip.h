@@ -439,6 +439,12 @@ int yond_denorm_ivst_unpack_dev_f32(const float* net_out, int Hp, int Wp, int pa
  * yond_adam_step_f32: torch.optim.Adam's single-tensor update (no weight decay / amsgrad), step = 1, 2, ... */
 int yond_conv_wgrad_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode,
                         int stride, float* dw, void* stream);
+/* The same with a workspace: ws (device, yond_conv_wgrad_ws_bytes(...) bytes) takes the workgroups' partial sums, which a second
+ * kernel adds up -- the K axis (pixels) is split over thousands of waves, and float atomics onto the few addresses of a
+ * low-channel layer serialise at the memory side.  ws NULL: atomics, as yond_conv_wgrad_f32. */
+size_t yond_conv_wgrad_ws_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride);
+int yond_conv_wgrad_ws_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride,
+                           float* dw, float* ws, size_t ws_bytes, void* stream);
 int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, void* stream);
 int yond_l1_loss_f32(const float* pred, const float* target, size_t n, double* loss_sum, float* grad /* or NULL */, void* stream);
 /* L1_Charbonnier_loss (losses/base_loss.py:69-79; Unet_Loss(charbonnier=True), :82-85): loss_sum = sum sqrt(diff^2 + eps),

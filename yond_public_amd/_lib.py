@@ -83,6 +83,8 @@ PROTOTYPES = {
     "yond_block_metrics_f32": [vp, vp, i32, i32, i32, i32, vp, vp],
     "yond_clock_probe": [f64, vp, vp],
     "yond_conv_wgrad_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
+    "yond_conv_wgrad_ws_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp],
+    "yond_conv_wgrad_ws_bytes": [i32, i32, i32, i32, i32, i32, i32, i32, i32],
     "yond_colsum_f32": [vp, sz, i32, vp, vp],
     "yond_l1_loss_f32": [vp, vp, sz, vp, vp, vp],
     "yond_charbonnier_loss_f32": [vp, vp, sz, f64, vp, vp, vp],
@@ -103,7 +105,8 @@ EXPERIMENT_PROTOTYPES = {
     "yond_box_stats_self_fused_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
     "yond_box_stats_collab_fused_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
 }
-_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes", "yond_lut_ws_bytes", "yond_bias_lut_big_scratch", "yond_bias_points_scratch"}
+_SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes", "yond_lut_ws_bytes", "yond_bias_lut_big_scratch", "yond_bias_points_scratch",
+               "yond_conv_wgrad_ws_bytes"}
 
 
 class YondHipError(RuntimeError):

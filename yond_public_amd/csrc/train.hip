@@ -29,7 +29,8 @@ struct WgradGeom {
 // L2 latency), rows follow one another without draining that pipeline.  K-space rows: dY rows, or X rows for the transposed layer.
 template <int MODE, int NCO>
 __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict__ x, const float* __restrict__ dy, WgradGeom g,
-                                                         float* __restrict__ dw /* [taps][Cout][Cin], zeroed by the caller */) {
+                                                         float* __restrict__ dw /* [taps][Cout][Cin], zeroed by the caller */,
+                                                         float* __restrict__ ws /* partial sums per workgroup, or null: atomics */) {
     // taps per wave: a 3x3 layer's kernel rows go to three different waves (grid x = ky-major): 3 NCO accumulators = 96 registers
     // at NCO 2, two waves per SIMD -- nine taps in one wave (288 registers) left one wave per SIMD and nothing to hide latency with
     constexpr int TAPS = MODE == 0 ? 3 : (MODE == 1 ? 4 : 1);
@@ -43,8 +44,9 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
     const int Hk = MODE == 1 ? g.H : g.Ho, Wk = MODE == 1 ? g.W : g.Wo;
     const long long rows = (long long)g.N * Hk;
     const long long r0 = ((long long)blockIdx.y * 4 + wave) * g.chunk;
-    if (r0 >= rows) return;
-    const long long r1 = r0 + g.chunk < rows ? r0 + g.chunk : rows;
+    const bool idle = r0 >= rows;
+    if (idle && !ws) return;                                        // (with a workspace every wave takes part in the workgroup's sum)
+    const long long r1 = idle ? r0 : (r0 + g.chunk < rows ? r0 + g.chunk : rows);
     const float* xb = x + cit * 32 + li;
     const float* dyb = dy + cog * (32 * NCO) + li;
     const int s = g.stride;
@@ -56,6 +58,8 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         for (int c = 0; c < NCO; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.0f;
+    // (The bias gradient = the column sums of dY was tried as a by-product of these loads -- one add per loaded dY value in the
+    // waves of one input-channel tile: the launch slowed down by 40-50 %; it stays a kernel of its own, colsum_kernel.)
 
     // operands of the pixel pair (row, xo .. xo + 1); ymask: bit ky set = that input row lies inside the image (wave-uniform)
     auto fetch = [&](long long row, int n, int y, int xo, float (&a)[NA], float (&b)[NB], unsigned& ymask) {
@@ -151,6 +155,32 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         }
     }
     // D rows (output channel) (r&3) + 8 (r>>2) + 4 lk, column (input channel) li
+    if (ws) {
+        // The K axis is split over thousands of waves; their partial sums meet in few addresses (a 32 -> 32 channel layer has
+        // 9,216 weights), and memory-side float atomics onto the same address serialise: 1,368 of them in a row cost more than
+        // the MFMAs.  So: the four waves of a workgroup add up through LDS, the workgroup STORES its partial tile
+        // [workgroup chunk][tap][Cout][Cin], wgrad_reduce_kernel adds the chunks.
+        __shared__ float red[4][16][64];
+        const size_t per = (size_t)g.taps * g.Cout * g.Cin;                     // floats per workgroup chunk
+        float* wsc = ws + (size_t)blockIdx.y * per;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[t][c][r];
+                __syncthreads();
+                float* out = wsc + ((size_t)(MODE == 0 ? ky * 3 + t : t) * g.Cout + cog * (32 * NCO) + c * 32) * g.Cin + cit * 32 + li;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = wave * 4 + rr;
+                    const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+                    out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lk) * g.Cin] = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -161,40 +191,103 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         }
 }
 
+// dw[i] = the sum over the workgroup chunks of ws[chunk][i]; grid (elements / 256, S): S slices of the chunk range, combined with
+// one atomic each when S > 1 (dw zeroed by the caller then)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nchunk, size_t n, float* __restrict__ dw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int j = blockIdx.y;
+    const int S = gridDim.y;
+    for (; j + 3 * S < nchunk; j += 4 * S) {
+        a0 += ws[(size_t)j * n + i];
+        a1 += ws[(size_t)(j + S) * n + i];
+        a2 += ws[(size_t)(j + 2 * S) * n + i];
+        a3 += ws[(size_t)(j + 3 * S) * n + i];
+    }
+    for (; j < nchunk; j += S) a0 += ws[(size_t)j * n + i];
+    const float v = (a0 + a1) + (a2 + a3);
+    if (S > 1) atomicAdd(dw + i, v);
+    else dw[i] = v;
+}
+
+// chunk (K-space rows per wave) and workgroup chunks of a launch
 template <int MODE, int NCO>
-static void launch_wgrad(const float* x, const float* dy, WgradGeom g, float* dw, hipStream_t stream) {
+static void wgrad_split(const WgradGeom& g, long long& chunk, long long& wgchunks) {
     const int Hk = MODE == 1 ? g.H : g.Ho, Wk = MODE == 1 ? g.W : g.Wo;
     const long long rows = (long long)g.N * Hk;
     const long long tiles = (long long)(g.Cout / (32 * NCO)) * (g.Cin / 32) * (MODE == 0 ? 3 : 1);
-    // one round of waves at the kernel's occupancy (256 CUs x 4 SIMDs x waves per SIMD), at least ~128 pixels per wave
-    const long long target = 1024 * (MODE == 0 ? (NCO == 2 ? 2 : 4) : (MODE == 1 ? 3 : 4));
+    // about one round of waves at the kernel's occupancy (256 CUs x 4 SIMDs x waves per SIMD), at least ~128 pixels per wave
+    const long long target = 1024 * (MODE == 0 ? (NCO == 2 ? 2 : 3) : (MODE == 1 ? 2 : 4));
     long long chunks = (target + tiles - 1) / tiles;
-    long long min_rows = (128 + Wk - 1) / Wk;
-    long long chunk = (rows + chunks - 1) / chunks;
+    const long long min_rows = (128 + Wk - 1) / Wk;
+    chunk = (rows + chunks - 1) / chunks;
     if (chunk < min_rows) chunk = min_rows;
-    g.chunk = (int)chunk;
     chunks = (rows + chunk - 1) / chunk;
-    hipLaunchKernelGGL((wgrad_rows_kernel<MODE, NCO>), dim3((unsigned)tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, stream, x, dy, g, dw);
+    wgchunks = (chunks + 3) / 4;
+}
+
+template <int MODE, int NCO>
+static void launch_wgrad(const float* x, const float* dy, WgradGeom g, float* dw, float* ws, hipStream_t stream) {
+    const long long tiles = (long long)(g.Cout / (32 * NCO)) * (g.Cin / 32) * (MODE == 0 ? 3 : 1);
+    long long chunk, wgchunks;
+    wgrad_split<MODE, NCO>(g, chunk, wgchunks);
+    g.chunk = (int)chunk;
+    hipLaunchKernelGGL((wgrad_rows_kernel<MODE, NCO>), dim3((unsigned)tiles, (unsigned)wgchunks), dim3(256), 0, stream, x, dy, g, dw, ws);
+    if (ws) {
+        const size_t n = (size_t)g.taps * g.Cout * g.Cin;
+        const size_t nbx = (n + 255) / 256;
+        long long S = (2048 + (long long)nbx - 1) / (long long)nbx;               // ~2048 workgroups in all
+        if (S > wgchunks) S = wgchunks;
+        if (S > 64) S = 64;
+        if (S < 1) S = 1;
+        if (S > 1) hipMemsetAsync(dw, 0, n * sizeof(float), stream);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nbx, (unsigned)S), dim3(256), 0, stream, ws, (int)wgchunks, n, dw);
+    }
+}
+
+static bool wgrad_check(const float* x, const float* dy, const float* dw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride) {
+    if (!x || !dy || !dw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return false;
+    if (mode < 0 || mode > 2 || (mode == 0 && stride != 1 && stride != 2)) return false;
+    if (mode == 0 && (Ho != (H + stride - 1) / stride || Wo != (W + stride - 1) / stride)) return false;
+    if (mode == 1 && (Ho != 2 * H || Wo != 2 * W)) return false;
+    if (mode == 2 && (Ho != H || Wo != W)) return false;
+    return true;
+}
+
+// bytes of workspace yond_conv_wgrad_ws_f32 wants for this layer (0: invalid arguments)
+extern "C" size_t yond_conv_wgrad_ws_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride) {
+    if (!wgrad_check((const float*)1, (const float*)1, (const float*)1, N, H, W, Cin, Ho, Wo, Cout, mode, stride)) return 0;
+    WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, mode, stride, mode == 0 ? 9 : (mode == 1 ? 4 : 1), 0};
+    long long chunk, wgchunks;
+    const bool two = Cout % 64 == 0;
+    if (mode == 0) two ? wgrad_split<0, 2>(g, chunk, wgchunks) : wgrad_split<0, 1>(g, chunk, wgchunks);
+    else if (mode == 1) wgrad_split<1, 1>(g, chunk, wgchunks);
+    else two ? wgrad_split<2, 2>(g, chunk, wgchunks) : wgrad_split<2, 1>(g, chunk, wgchunks);
+    return (size_t)wgchunks * (size_t)g.taps * Cout * Cin * sizeof(float);
+}
+
+extern "C" int yond_conv_wgrad_ws_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode,
+                                      int stride, float* dw, float* ws, size_t ws_bytes, void* stream) {
+    if (!wgrad_check(x, dy, dw, N, H, W, Cin, Ho, Wo, Cout, mode, stride)) return YOND_EINVAL;
+    if (ws && ws_bytes < yond_conv_wgrad_ws_bytes(N, H, W, Cin, Ho, Wo, Cout, mode, stride)) return YOND_EINVAL;
+    WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, mode, stride, mode == 0 ? 9 : (mode == 1 ? 4 : 1), 0};
+    hipStream_t st = (hipStream_t)stream;
+    if (!ws) {                                                       // the atomics path sums into a zeroed output
+        hipError_t e = hipMemsetAsync(dw, 0, (size_t)g.taps * Cout * Cin * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const bool two = Cout % 64 == 0;
+    if (mode == 0) two ? launch_wgrad<0, 2>(x, dy, g, dw, ws, st) : launch_wgrad<0, 1>(x, dy, g, dw, ws, st);
+    else if (mode == 1) launch_wgrad<1, 1>(x, dy, g, dw, ws, st);           // (two tiles per wave: 309 registers, one wave per SIMD)
+    else two ? launch_wgrad<2, 2>(x, dy, g, dw, ws, st) : launch_wgrad<2, 1>(x, dy, g, dw, ws, st);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
 }
 
 extern "C" int yond_conv_wgrad_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode,
                                    int stride, float* dw, void* stream) {
-    if (!x || !dy || !dw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return YOND_EINVAL;
-    if (mode < 0 || mode > 2 || (mode == 0 && stride != 1 && stride != 2)) return YOND_EINVAL;
-    if (mode == 0 && (Ho != (H + stride - 1) / stride || Wo != (W + stride - 1) / stride)) return YOND_EINVAL;
-    if (mode == 1 && (Ho != 2 * H || Wo != 2 * W)) return YOND_EINVAL;
-    if (mode == 2 && (Ho != H || Wo != W)) return YOND_EINVAL;
-    WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, mode, stride, mode == 0 ? 9 : (mode == 1 ? 4 : 1), 0};
-    const size_t bytes = (size_t)g.taps * Cout * Cin * sizeof(float);
-    hipError_t e = hipMemsetAsync(dw, 0, bytes, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    const bool two = Cout % 64 == 0;
-    hipStream_t st = (hipStream_t)stream;
-    if (mode == 0) two ? launch_wgrad<0, 2>(x, dy, g, dw, st) : launch_wgrad<0, 1>(x, dy, g, dw, st);
-    else if (mode == 1) launch_wgrad<1, 1>(x, dy, g, dw, st);          // (two tiles per wave: 309 registers, one wave per SIMD)
-    else two ? launch_wgrad<2, 2>(x, dy, g, dw, st) : launch_wgrad<2, 1>(x, dy, g, dw, st);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
+    return yond_conv_wgrad_ws_f32(x, dy, N, H, W, Cin, Ho, Wo, Cout, mode, stride, dw, nullptr, 0, stream);
 }
 
 // db[c] = sum over pixels of dY[p][c]  (C a multiple of 32; float64 partial sums per workgroup, one float atomic each)

@@ -114,12 +114,17 @@ def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False, r
 
 
 def _wgrad(plan, x, dy, mode, stride, taps):
-    """[taps][Cout_p][Cin_p] float32 (x, dy: padded NHWC)."""
+    """[taps][Cout_p][Cin_p] float32 (x, dy: padded NHWC).  The workgroups' partial sums go through one workspace that grows to the
+    largest layer's need (stream order keeps its uses apart)."""
     N, H, W, ci = x.shape
     _, Ho, Wo, co = dy.shape
     dw = torch.empty((taps, co, ci), dtype=torch.float32, device=x.device)
-    L.check(plan.lib.yond_conv_wgrad_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, Ho, Wo, co, mode, stride, L.ptr(dw), L.stream()),
-            "yond_conv_wgrad_f32")
+    need = int(plan.lib.yond_conv_wgrad_ws_bytes(N, H, W, ci, Ho, Wo, co, mode, stride))
+    ws = getattr(plan, 'wgrad_ws', None)
+    if ws is None or ws.numel() * 4 < need:
+        ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    L.check(plan.lib.yond_conv_wgrad_ws_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, Ho, Wo, co, mode, stride, L.ptr(dw), L.ptr(ws), ws.numel() * 4,
+                                            L.stream()), "yond_conv_wgrad_ws_f32")
     return dw
 
 

@@ -47,8 +47,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
     const bool idle = r0 >= rows;
     if (idle && !ws) return;                                        // (with a workspace every wave takes part in the workgroup's sum)
     const long long r1 = idle ? r0 : (r0 + g.chunk < rows ? r0 + g.chunk : rows);
-    const float* xb = x + cit * 32 + li;
-    const float* dyb = dy + cog * (32 * NCO) + li;
+    const long long rsafe = idle ? 0 : r0;                          // a row every wave may read (an idle wave's r0 lies past the tensor)
     const int s = g.stride;
 
     f32x16 acc[TAPS][NCO];
@@ -60,47 +59,6 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.0f;
     // (The bias gradient = the column sums of dY was tried as a by-product of these loads -- one add per loaded dY value in the
     // waves of one input-channel tile: the launch slowed down by 40-50 %; it stays a kernel of its own, colsum_kernel.)
-
-    // operands of the pixel pair (row, xo .. xo + 1); ymask: bit ky set = that input row lies inside the image (wave-uniform)
-    auto fetch = [&](long long row, int n, int y, int xo, float (&a)[NA], float (&b)[NB], unsigned& ymask) {
-        const int px = xo + lk;
-        const bool inb = px < Wk;
-        if constexpr (MODE == 0) {
-            // wave-uniform row bases (scalar registers) + 32-bit per-lane offsets
-            const float* dyr = dy + row * Wk * g.Cout;
-            const int aoff = px * g.Cout + cog * (32 * NCO) + li;
-            const int yi = y * s + ky - 1;
-            const bool yv = yi >= 0 && yi < g.H;                    // (wave-uniform: a row outside the image costs nothing)
-            ymask = yv ? 1u : 0u;
-#pragma unroll
-            for (int c = 0; c < NCO; ++c) a[c] = (yv && inb) ? dyr[aoff + 32 * c] : 0.0f;
-            const float* xr = x + ((long long)n * g.H + (yv ? yi : 0)) * g.W * g.Cin;
-            const int xi0 = px * s - 1;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xi = xi0 + kx;
-                const bool ok = yv && inb && xi >= 0 && xi < g.W;
-                b[kx] = ok ? xr[xi * g.Cin + cit * 32 + li] : 0.0f;
-            }
-        } else if constexpr (MODE == 1) {
-            ymask = 7u;
-            b[0] = inb ? xb[(row * Wk + px) * g.Cin] : 0.0f;
-#pragma unroll
-            for (int ky = 0; ky < 2; ++ky) {
-                const float* dr = dyb + (((long long)n * g.Ho + 2 * y + ky) * g.Wo + 2 * px) * g.Cout;
-#pragma unroll
-                for (int kx = 0; kx < 2; ++kx)
-#pragma unroll
-                    for (int c = 0; c < NCO; ++c) a[(ky * 2 + kx) * NCO + c] = inb ? dr[kx * g.Cout + 32 * c] : 0.0f;
-            }
-        } else {
-            ymask = 7u;
-            const long long p = row * Wk + px;
-            b[0] = inb ? xb[p * g.Cin] : 0.0f;
-#pragma unroll
-            for (int c = 0; c < NCO; ++c) a[c] = inb ? dyb[p * g.Cout + 32 * c] : 0.0f;
-        }
-    };
 
     if constexpr (MODE == 0) {
         // The 3x3 pipeline is STRAIGHT-LINE code: D pixel pairs in flight, stage d refilled right behind its MFMAs, and no branch
@@ -123,8 +81,8 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
             const bool live = fetched < total;
             const int yi = fy * s + ky - 1;
             const bool yv = yi >= 0 && yi < g.H;
-            const long long rowc = live ? frow : r0;                // (past the end: any valid row)
-            const int nc = live ? fn : (int)(r0 / Hk);
+            const long long rowc = live ? frow : rsafe;             // (past the end of the chunk: any valid row)
+            const int nc = live ? fn : (int)(rsafe / Hk);
             const char* dyr = (const char*)(dy + rowc * Wk * g.Cout + cog * (32 * NCO));
             const char* xr = (const char*)(x + ((long long)nc * g.H + (yv && live ? yi : 0)) * g.W * g.Cin + cit * 32);
             const int px = fxo + lk;
@@ -170,56 +128,61 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
             }
         }
     } else {
-    // D pairs in flight: stage d holds the operands of position i + d; a stage is refilled (position i + D) right behind its MFMAs
-        constexpr int D = 4;
-        const int ppr = (Wk + 1) / 2;                                   // positions (pixel pairs) per row
+        // 1x1 and transposed 2x2 layers: the same straight-line pipeline; one X value per pair, NA values of dY (the transposed layer:
+        // its four taps); a pair outside the row / the chunk is silenced by zeroing the X operand alone
+        constexpr int D = MODE == 1 ? 4 : 8;
+        const int ppr = (Wk + 1) / 2;
         const long long total = (r1 - r0) * ppr;
-        long long frow = r0;                                            // the fetch cursor
+        long long frow = r0;
         int fn = (int)(r0 / Hk), fy = (int)(r0 - (long long)fn * Hk), fxo = 0;
         long long fetched = 0;
-        float pa[D][NA], pb[D][NB];
-        unsigned pm[D];
-        auto fetch_next = [&](float (&a)[NA], float (&b)[NB], unsigned& m) {
-            if (fetched < total) {
-                fetch(frow, fn, fy, fxo, a, b, m);
-                fxo += 2;
-                if (fxo >= Wk) {
-                    fxo = 0;
-                    ++frow;
-                    if (++fy == Hk) { fy = 0; ++fn; }
+        float pa[D][NA], pb[D];
+        int pxo[D];
+        const unsigned cout4 = (unsigned)g.Cout * 4u, cin4 = (unsigned)g.Cin * 4u;
+        const unsigned lane4 = (unsigned)li * 4u;
+        auto fetch12 = [&](float (&a)[NA], float& b, int& sxo) {
+            const bool live = fetched < total;
+            const long long rowc = live ? frow : rsafe;
+            const int nc = live ? fn : (int)(rsafe / Hk), yc = live ? fy : (int)(rsafe % Hk);
+            const int px = fxo + lk;
+            const unsigned pxc = (unsigned)(px < Wk ? px : Wk - 1);
+            b = *(const float*)((const char*)(x + rowc * Wk * g.Cin + cit * 32) + __umul24(pxc, cin4) + lane4);
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty) {
+                    const char* dr = (const char*)(dy + (((long long)nc * g.Ho + 2 * yc + ty) * g.Wo) * g.Cout + cog * (32 * NCO));
+#pragma unroll
+                    for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c)
+                            a[(ty * 2 + tx) * NCO + c] = *(const float*)(dr + __umul24(2u * pxc + tx, cout4) + lane4 + 128u * c);
                 }
             } else {
-                m = 0;
-    #pragma unroll
-                for (int i = 0; i < NA; ++i) a[i] = 0.0f;
-    #pragma unroll
-                for (int i = 0; i < NB; ++i) b[i] = 0.0f;
+                const char* dr = (const char*)(dy + rowc * Wk * g.Cout + cog * (32 * NCO));
+#pragma unroll
+                for (int c = 0; c < NCO; ++c) a[c] = *(const float*)(dr + __umul24(pxc, cout4) + lane4 + 128u * c);
             }
+            sxo = live ? fxo : -1;
+            const bool wrap = fxo + 2 >= Wk;
+            fxo = wrap ? 0 : fxo + 2;
+            const bool ywrap = wrap && fy + 1 == Hk;
+            frow += wrap ? 1 : 0;
+            fy = wrap ? (ywrap ? 0 : fy + 1) : fy;
+            fn += ywrap ? 1 : 0;
             ++fetched;
         };
-    #pragma unroll
-        for (int d = 0; d < D; ++d) fetch_next(pa[d], pb[d], pm[d]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) fetch12(pa[d], pb[d], pxo[d]);
         for (long long i = 0; i < total; i += D) {
-    #pragma unroll
+#pragma unroll
             for (int d = 0; d < D; ++d) {
-                if constexpr (MODE == 0) {
-                    if (pm[d]) {
-    #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx)
-    #pragma unroll
-                            for (int c = 0; c < NCO; ++c)
-                                acc[kx][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[d][c], pb[d][kx], acc[kx][c], 0, 0, 0);
-                    }
-                } else {
-                    if (pm[d]) {
-    #pragma unroll
-                        for (int t = 0; t < TAPS; ++t)
-    #pragma unroll
-                            for (int c = 0; c < NCO; ++c)
-                                acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(MODE == 1 ? pa[d][t * NCO + c] : pa[d][c], pb[d][0], acc[t][c], 0, 0, 0);
-                    }
-                }
-                fetch_next(pa[d], pb[d], pm[d]);
+                const float bv = (pxo[d] >= 0 && pxo[d] + lk < Wk) ? pb[d] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c)
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(MODE == 1 ? pa[d][t * NCO + c] : pa[d][c], bv, acc[t][c], 0, 0, 0);
+                fetch12(pa[d], pb[d], pxo[d]);
             }
         }
     }
@@ -287,7 +250,7 @@ static void wgrad_split(const WgradGeom& g, long long& chunk, long long& wgchunk
     const long long rows = (long long)g.N * Hk;
     const long long tiles = (long long)(g.Cout / (32 * NCO)) * (g.Cin / 32) * (MODE == 0 ? 3 : 1);
     // about one round of waves at the kernel's occupancy (256 CUs x 4 SIMDs x waves per SIMD), at least ~128 pixels per wave
-    const long long target = 1024 * (MODE == 0 ? 3 : (MODE == 1 ? 2 : 4));
+    const long long target = 1024 * (MODE == 0 ? 3 : 4);
     long long chunks = (target + tiles - 1) / tiles;
     const long long min_rows = (128 + Wk - 1) / Wk;
     chunk = (rows + chunks - 1) / chunks;
@@ -359,8 +322,38 @@ extern "C" int yond_conv_wgrad_f32(const float* x, const float* dy, int N, int H
     return yond_conv_wgrad_ws_f32(x, dy, N, H, W, Cin, Ho, Wo, Cout, mode, stride, dw, nullptr, 0, stream);
 }
 
-// db[c] = sum over pixels of dY[p][c]  (C a multiple of 32; float64 partial sums per workgroup, one float atomic each)
+// db[c] = sum over pixels of dY[p][c]  (C a multiple of 32).  A thread owns four channels (one 16-byte load per pixel), a workgroup
+// strides over the pixels with 256 / (C / 4) of them per pass (C <= 1024) -- float64 partial sums per thread, added up through LDS,
+// one float atomic per channel and workgroup.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, long long npix, int C, float* __restrict__ db) {
+    __shared__ double s[256][4];
+    const int c4 = C / 4;                                   // threads per pixel
+    const int ppw = 256 / c4;                               // pixels per workgroup pass (c4 divides 256 for C = 32 ... 1024: see the launcher)
+    const int cl = threadIdx.x % c4, pr = threadIdx.x / c4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const long long stride = (long long)gridDim.x * ppw;
+    long long p = (long long)blockIdx.x * ppw + pr;
+    for (; p + stride < npix; p += 2 * stride) {            // two loads in flight
+        const float4 u = *(const float4*)(dy + p * C + cl * 4);
+        const float4 v = *(const float4*)(dy + (p + stride) * C + cl * 4);
+        a0 += (double)u.x + (double)v.x; a1 += (double)u.y + (double)v.y; a2 += (double)u.z + (double)v.z; a3 += (double)u.w + (double)v.w;
+    }
+    if (p < npix) {
+        const float4 u = *(const float4*)(dy + p * C + cl * 4);
+        a0 += (double)u.x; a1 += (double)u.y; a2 += (double)u.z; a3 += (double)u.w;
+    }
+    s[threadIdx.x][0] = a0; s[threadIdx.x][1] = a1; s[threadIdx.x][2] = a2; s[threadIdx.x][3] = a3;
+    __syncthreads();
+    if (threadIdx.x < C) {                                  // thread = channel: add the ppw pixel rows
+        const int t = threadIdx.x >> 2, e = threadIdx.x & 3;
+        double acc = 0.0;
+        for (int r = 0; r < ppw; ++r) acc += s[r * c4 + t][e];
+        atomicAdd(db + threadIdx.x, (float)acc);
+    }
+}
+
+// the general form (any C that is a multiple of 32): 32 channels x 8 pixel rows per workgroup
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ dy, long long npix, int C, float* __restrict__ db) {
     __shared__ double s[8][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), row = threadIdx.x >> 5;
     double acc = 0.0;
@@ -379,9 +372,18 @@ extern "C" int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, v
     if (!dy || !db || npix == 0 || C <= 0 || C % 32) return YOND_EINVAL;
     hipError_t e = hipMemsetAsync(db, 0, (size_t)C * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    size_t gy = (npix + 8 * 64 - 1) / (8 * 64);
-    if (gy > 256) gy = 256;
-    hipLaunchKernelGGL(colsum_kernel, dim3(C / 32, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, dy, (long long)npix, C, db);
+    const int c4 = C / 4;
+    if (C <= 256 && 256 % c4 == 0) {                         // C = 32, 64, 128, 256: the 16-byte form (thread = channel needs C <= 256)
+        const int ppw = 256 / c4;
+        size_t nb = (npix + (size_t)ppw * 8 - 1) / ((size_t)ppw * 8);      // >= 8 pixels per thread
+        if (nb > 1024) nb = 1024;
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, (long long)npix, C, db);
+    } else {
+        size_t gy = (npix + 8 * 64 - 1) / (8 * 64);
+        if (gy > 256) gy = 256;
+        hipLaunchKernelGGL(colsum_wide_kernel, dim3(C / 32, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, dy, (long long)npix, C, db);
+    }
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

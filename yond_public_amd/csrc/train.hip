@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
     // at NCO 2, two waves per SIMD -- nine taps in one wave (288 registers) left one wave per SIMD and nothing to hide latency with
     constexpr int TAPS = MODE == 0 ? 3 : (MODE == 1 ? 4 : 1);
     constexpr int NA = MODE == 1 ? 4 * NCO : NCO, NB = MODE == 0 ? 3 : 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform, and everything derived
+    // from it -- the row cursor, the 64-bit row bases -- would be computed on the vector ALU, whose time ADDS to the fp32 MFMAs')
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lk = lane >> 5;
     const int nci = g.Cin / 32, ntile = nci * (g.Cout / (32 * NCO));
     const int ky = MODE == 0 ? blockIdx.x / ntile : 0;
@@ -48,6 +50,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
     if (idle && !ws) return;                                        // (with a workspace every wave takes part in the workgroup's sum)
     const long long r1 = idle ? r0 : (r0 + g.chunk < rows ? r0 + g.chunk : rows);
     const long long rsafe = idle ? 0 : r0;                          // a row every wave may read (an idle wave's r0 lies past the tensor)
+    const int nsafe = (int)(rsafe / Hk), ysafe = (int)(rsafe - (long long)nsafe * Hk);      // (divisions: once, not per stage)
     const int s = g.stride;
 
     f32x16 acc[TAPS][NCO];
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         const int ppr = (Wk + 1) / 2;                               // positions (pixel pairs) per row
         const long long total = (r1 - r0) * ppr;
         long long frow = r0;                                        // the fetch cursor (all scalar)
-        int fn = (int)(r0 / Hk), fy = (int)(r0 - (long long)fn * Hk), fxo = 0;
+        int fn = nsafe, fy = ysafe, fxo = 0;                         // (an idle wave fetches nothing that counts)
         long long fetched = 0;
         float pa[D][NCO], pb[D][3];
         int pxo[D];                                                 // the stage's first pixel, or -1: nothing to count
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
             const int yi = fy * s + ky - 1;
             const bool yv = yi >= 0 && yi < g.H;
             const long long rowc = live ? frow : rsafe;             // (past the end of the chunk: any valid row)
-            const int nc = live ? fn : (int)(rsafe / Hk);
+            const int nc = live ? fn : nsafe;
             const char* dyr = (const char*)(dy + rowc * Wk * g.Cout + cog * (32 * NCO));
             const char* xr = (const char*)(x + ((long long)nc * g.H + (yv && live ? yi : 0)) * g.W * g.Cin + cit * 32);
             const int px = fxo + lk;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         const int ppr = (Wk + 1) / 2;
         const long long total = (r1 - r0) * ppr;
         long long frow = r0;
-        int fn = (int)(r0 / Hk), fy = (int)(r0 - (long long)fn * Hk), fxo = 0;
+        int fn = nsafe, fy = ysafe, fxo = 0;                         // (an idle wave fetches nothing that counts)
         long long fetched = 0;
         float pa[D][NA], pb[D];
         int pxo[D];
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         auto fetch12 = [&](float (&a)[NA], float& b, int& sxo) {
             const bool live = fetched < total;
             const long long rowc = live ? frow : rsafe;
-            const int nc = live ? fn : (int)(rsafe / Hk), yc = live ? fy : (int)(rsafe % Hk);
+            const int nc = live ? fn : nsafe, yc = live ? fy : ysafe;
             const int px = fxo + lk;
             const unsigned pxc = (unsigned)(px < Wk ? px : Wk - 1);
             b = *(const float*)((const char*)(x + rowc * Wk * g.Cin + cit * 32) + __umul24(pxc, cin4) + lane4);

@@ -446,6 +446,13 @@ size_t yond_conv_wgrad_ws_bytes(int N, int H, int W, int Cin, int Ho, int Wo, in
 int yond_conv_wgrad_ws_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride,
                            float* dw, float* ws, size_t ws_bytes, void* stream);
 int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, void* stream);
+/* The guided block's middle (archs/modules.py:186-196) for training: out = SiLU(z * tk[n][c] + tb[n][c]) over z [N][P][C] with
+ * per-image vectors tk, tb [N][C], and its backward in one pass: dz, dtk[n][c] = sum_p g z, dtb[n][c] = sum_p g with
+ * g = dout * SiLU'(z tk + tb).  C in {32, 64, 128, 256} (yond_film_silu_supported); other widths stay with the caller. */
+int yond_film_silu_supported(int C);
+int yond_film_silu_f32(const float* z, const float* tk, const float* tb, float* out, int N, size_t P, int C, void* stream);
+int yond_film_silu_bwd_f32(const float* z, const float* tk, const float* tb, const float* dout, float* dz, float* dtk, float* dtb, int N,
+                           size_t P, int C, void* stream);
 int yond_l1_loss_f32(const float* pred, const float* target, size_t n, double* loss_sum, float* grad /* or NULL */, void* stream);
 /* L1_Charbonnier_loss (losses/base_loss.py:69-79; Unet_Loss(charbonnier=True), :82-85): loss_sum = sum sqrt(diff^2 + eps),
  * grad = diff / sqrt(diff^2 + eps) / n in the float32 steps of torch's backward */

@@ -86,6 +86,9 @@ PROTOTYPES = {
     "yond_conv_wgrad_ws_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp],
     "yond_conv_wgrad_ws_bytes": [i32, i32, i32, i32, i32, i32, i32, i32, i32],
     "yond_colsum_f32": [vp, sz, i32, vp, vp],
+    "yond_film_silu_supported": [i32],
+    "yond_film_silu_f32": [vp, vp, vp, vp, i32, sz, i32, vp],
+    "yond_film_silu_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, i32, sz, i32, vp],
     "yond_l1_loss_f32": [vp, vp, sz, vp, vp, vp],
     "yond_charbonnier_loss_f32": [vp, vp, sz, f64, vp, vp, vp],
     "yond_adam_step_f32": [vp, vp, vp, vp, sz, f64, f64, f64, f64, i32, vp],

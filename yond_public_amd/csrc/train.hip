@@ -391,6 +391,94 @@ extern "C" int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, v
     return YOND_OK;
 }
 
+// The guided block's middle (archs/modules.py:186-196): out = SiLU(z * tk[n][c] + tb[n][c]) over [N][P pixels][C] with per-image
+// (scale, shift) vectors, and its backward in ONE pass over the tensors: with u = z tk + tb, s = sigmoid(u), g = dout * s (1 + u (1 - s)):
+// dz = g tk, dtk[n][c] = sum_p g z, dtb[n][c] = sum_p g.  A thread owns four channels (16-byte accesses), a workgroup strides over
+// the pixels of one image; the two per-image sums go through LDS and one float atomic per channel and workgroup.
+__global__ __launch_bounds__(256) void film_silu_fwd_kernel(const float* __restrict__ z, const float* __restrict__ tk, const float* __restrict__ tb,
+                                                            float* __restrict__ out, long long P, int C) {
+    const int c4 = C / 4, n = blockIdx.y;
+    const long long groups = P * c4;                                   // float4 groups of this image
+    const float4* zi = (const float4*)(z + (size_t)n * P * C);
+    float4* oi = (float4*)(out + (size_t)n * P * C);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < groups; i += (long long)gridDim.x * 256) {
+        const int cl = (int)(i % c4);
+        const float4 k = *(const float4*)(tk + (size_t)n * C + cl * 4), b = *(const float4*)(tb + (size_t)n * C + cl * 4);
+        const float4 v = zi[i];
+        float4 o;
+        o.x = silu_f(v.x * k.x + b.x); o.y = silu_f(v.y * k.y + b.y); o.z = silu_f(v.z * k.z + b.z); o.w = silu_f(v.w * k.w + b.w);
+        oi[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void film_silu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ tk, const float* __restrict__ tb,
+                                                            const float* __restrict__ dout, float* __restrict__ dz, float* __restrict__ dtk,
+                                                            float* __restrict__ dtb, long long P, int C) {
+    __shared__ float sk[256][4], sb[256][4];
+    const int c4 = C / 4, n = blockIdx.y;
+    const int ppw = 256 / c4;                                          // pixels per workgroup pass (c4 divides 256: see the launcher)
+    const int cl = threadIdx.x % c4, pr = threadIdx.x / c4;
+    const float4 k = *(const float4*)(tk + (size_t)n * C + cl * 4), b = *(const float4*)(tb + (size_t)n * C + cl * 4);
+    const float* zi = z + (size_t)n * P * C;
+    const float* gi = dout + (size_t)n * P * C;
+    float* di = dz + (size_t)n * P * C;
+    float ak[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ab[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (long long p = (long long)blockIdx.x * ppw + pr; p < P; p += (long long)gridDim.x * ppw) {
+        const float4 v = *(const float4*)(zi + p * C + cl * 4), go = *(const float4*)(gi + p * C + cl * 4);
+        const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {go.x, go.y, go.z, go.w}, kk[4] = {k.x, k.y, k.z, k.w}, bb[4] = {b.x, b.y, b.z, b.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = vv[e] * kk[e] + bb[e];
+            const float s = 1.0f / (1.0f + expf(-u));
+            const float g = gg[e] * (s * (1.0f + u * (1.0f - s)));
+            o[e] = g * kk[e];
+            ak[e] += g * vv[e];
+            ab[e] += g;
+        }
+        *(float4*)(di + p * C + cl * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sk[threadIdx.x][e] = ak[e]; sb[threadIdx.x][e] = ab[e]; }
+    __syncthreads();
+    if (threadIdx.x < C) {                                             // thread = channel: add the ppw pixel rows
+        const int t = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float a = 0.0f, c = 0.0f;
+        for (int r = 0; r < ppw; ++r) { a += sk[r * c4 + t][e]; c += sb[r * c4 + t][e]; }
+        atomicAdd(dtk + (size_t)n * C + threadIdx.x, a);
+        atomicAdd(dtb + (size_t)n * C + threadIdx.x, c);
+    }
+}
+
+static bool film_silu_shape_ok(int N, long long P, int C) { return N > 0 && P > 0 && C >= 32 && C <= 256 && C % 32 == 0 && 256 % (C / 4) == 0; }
+
+// 1 when the fused kernels take this channel count (32, 64, 128, 256), else 0 (the caller keeps its elementwise form)
+extern "C" int yond_film_silu_supported(int C) { return film_silu_shape_ok(1, 1, C) ? 1 : 0; }
+
+extern "C" int yond_film_silu_f32(const float* z, const float* tk, const float* tb, float* out, int N, size_t P, int C, void* stream) {
+    if (!z || !tk || !tb || !out || !film_silu_shape_ok(N, (long long)P, C)) return YOND_EINVAL;
+    size_t nb = (P * (size_t)(C / 4) + 256 * 8 - 1) / (256 * 8);
+    if (nb > 2048 / (size_t)N + 1) nb = 2048 / (size_t)N + 1;
+    hipLaunchKernelGGL(film_silu_fwd_kernel, dim3((unsigned)nb, (unsigned)N), dim3(256), 0, (hipStream_t)stream, z, tk, tb, out, (long long)P, C);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+extern "C" int yond_film_silu_bwd_f32(const float* z, const float* tk, const float* tb, const float* dout, float* dz, float* dtk, float* dtb,
+                                      int N, size_t P, int C, void* stream) {
+    if (!z || !tk || !tb || !dout || !dz || !dtk || !dtb || !film_silu_shape_ok(N, (long long)P, C)) return YOND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dtk, 0, (size_t)N * C * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(dtb, 0, (size_t)N * C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const int ppw = 256 / (C / 4);
+    size_t nb = (P + (size_t)ppw * 8 - 1) / ((size_t)ppw * 8);
+    if (nb > 2048 / (size_t)N + 1) nb = 2048 / (size_t)N + 1;
+    hipLaunchKernelGGL(film_silu_bwd_kernel, dim3((unsigned)nb, (unsigned)N), dim3(256), 0, st, z, tk, tb, dout, dz, dtk, dtb, (long long)P, C);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
 // F.l1_loss (mean reduction) and its gradient: loss_sum += sum |pred - target| (float64), grad = sign(pred - target) * gscale
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ pred, const float* __restrict__ target, size_t n, float gscale,
                                                  double* __restrict__ loss_sum, float* __restrict__ grad) {

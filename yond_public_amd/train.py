@@ -233,6 +233,32 @@ class _Conv1x1(torch.autograd.Function):
         return dxs[0], (dxs[1] if ctx.two else None), dw, db, None
 
 
+class _FilmSilu(torch.autograd.Function):
+    """SiLU(z * tk + tb) with per-image (scale, shift) vectors (archs/modules.py:186-196), forward and backward as one kernel each
+    (yond_film_silu_f32 / yond_film_silu_bwd_f32) instead of autograd's multiply, add, SiLU and their five backward passes.
+    z [N][H][W][C]; tk, tb [N][C]."""
+
+    @staticmethod
+    def forward(ctx, z, tk, tb, plan):
+        z, tk, tb = z.contiguous(), tk.contiguous(), tb.contiguous()
+        N, H, W, C = z.shape
+        out = torch.empty_like(z)
+        L.check(plan.lib.yond_film_silu_f32(L.ptr(z), L.ptr(tk), L.ptr(tb), L.ptr(out), N, H * W, C, L.stream()), "yond_film_silu_f32")
+        ctx.save_for_backward(z, tk, tb)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, tk, tb = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, H, W, C = z.shape
+        dz, dtk, dtb = torch.empty_like(z), torch.empty_like(tk), torch.empty_like(tb)
+        L.check(ctx.plan.lib.yond_film_silu_bwd_f32(L.ptr(z), L.ptr(tk), L.ptr(tb), L.ptr(dout), L.ptr(dz), L.ptr(dtk), L.ptr(dtb), N, H * W, C,
+                                                    L.stream()), "yond_film_silu_bwd_f32")
+        return dz, dtk, dtb, None
+
+
 def ctx_splits(w, x0, x1):
     """Real channel counts of the two sources of a two-source 1x1 layer: GuidedResUnet's decoder concatenates `up` (c) and the
     skip tensor (c) into 2c channels (archs/Unet.py:447-461)."""
@@ -329,10 +355,13 @@ class TrainStep:
         h = F.silu(t[:, None] * w1[None] + b1[None])                              # [B][C]
         tk = (h[:, None, :] * w2[None]).sum(-1) + b2[None]
         tb = (F.silu(tk)[:, None, :] * w3[None]).sum(-1) + b3[None]
-        tk, tb = _pad_c(tk, cp)[:, None, None, :], _pad_c(tb, cp)[:, None, None, :]
+        tk, tb = _pad_c(tk, cp), _pad_c(tb, cp)
         z = F.silu(x)
         z = _Conv3x3.apply(z, P[pre + '.conv1.weight'], P[pre + '.conv1.bias'], self.plan, 1, True)
-        z = F.silu(z * tk + tb)
+        if self.plan.lib.yond_film_silu_supported(cp):
+            z = _FilmSilu.apply(z, tk, tb, self.plan)
+        else:                                                # (512 channels: 8 x 8 pixels per patch -- autograd's elementwise form)
+            z = F.silu(z * tk[:, None, None, :] + tb[:, None, None, :])
         z = _Conv3x3.apply(z, P[pre + '.conv2.weight'], P[pre + '.conv2.bias'], self.plan, 1, True)
         return z + x
 

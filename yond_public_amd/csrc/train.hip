@@ -27,6 +27,24 @@ struct WgradGeom {
 // operand feeds 9 (dY) or NCO (X) products instead of one; the transposed 2x2 layer is the mirror image (one X value, 4 NCO of dY).
 // The next pair's operands are fetched before the current pair's MFMAs are issued (one wave per SIMD: nothing else hides the
 // L2 latency), rows follow one another without draining that pipeline.  K-space rows: dY rows, or X rows for the transposed layer.
+// A buffer descriptor whose inputs the compiler can SEE are wave-uniform (readfirstlane on the pointer halves and the size: without
+// it the loop-carried row cursor counts as divergent and every buffer load becomes a waterfall loop)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 uniform_srd(const void* p, int bytes) {         // the same four words for inline-asm buffer loads
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));  // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ auto uniform_rsrc(const void* p, int bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 template <int MODE, int NCO>
 __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict__ x, const float* __restrict__ dy, WgradGeom g,
                                                          float* __restrict__ dw /* [taps][Cout][Cin], zeroed by the caller */,
@@ -67,9 +85,8 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         // The 3x3 pipeline is STRAIGHT-LINE code: D pixel pairs in flight, stage d refilled right behind its MFMAs, and no branch
         // anywhere in the loop body -- a uniform `if` around a stage (a row outside the image, the ends of a row, the end of the
         // chunk) makes the compiler drain every outstanding load at the join (s_waitcnt vmcnt(0)) and the prefetch depth is gone:
-        // measured +40-50 % per launch for each such branch.  So every load is issued unconditionally from a clamped address, and
-        // what must not count is zeroed by selects when it is consumed (dY for a pair outside the row / the image / the chunk, the
-        // two outer X columns at the ends of a row); a kernel row outside the image still issues its MFMAs on zeros.
+        // measured +40-50 % per launch for each such branch.  So every load is issued unconditionally and what must not count reads
+        // as zero (below); a kernel row outside the image still issues its MFMAs, on zeros.
         constexpr int D = NCO == 2 ? 6 : 8;
         const int ppr = (Wk + 1) / 2;                               // positions (pixel pairs) per row
         const long long total = (r1 - r0) * ppr;
@@ -77,30 +94,36 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         int fn = nsafe, fy = ysafe, fxo = 0;                         // (an idle wave fetches nothing that counts)
         long long fetched = 0;
         float pa[D][NCO], pb[D][3];
-        int pxo[D];                                                 // the stage's first pixel, or -1: nothing to count
         const unsigned cout4 = (unsigned)g.Cout * 4u, cin4 = (unsigned)g.Cin * 4u;
         const unsigned lane4 = (unsigned)li * 4u;
-        auto fetch0 = [&](float (&a)[NCO], float (&b)[3], int& sxo) {
+        // Operands come through BUFFER loads: a descriptor per image row (built on the scalar unit: base = the row's first byte
+        // of this wave's channel tile, size = the bytes left in the row) and a 32-bit per-lane byte offset.  The range check of the
+        // buffer path returns 0 for every byte outside the row -- column -1 (the offset wraps), column W, the second pixel of an
+        // odd row's last pair -- and a size of 0 silences a whole stage (a kernel row outside the image, a pair past the end of
+        // the chunk): no clamps, no selects, no 64-bit per-lane addresses; what is left on the vector ALU per pair is six
+        // instructions of offset arithmetic.  (fp32 MFMA time and vector-ALU time add on gfx950.)
+        auto fetch0 = [&](float (&a)[NCO], float (&b)[3]) {
             const bool live = fetched < total;
             const int yi = fy * s + ky - 1;
-            const bool yv = yi >= 0 && yi < g.H;
+            const bool on = live && yi >= 0 && yi < g.H;
             const long long rowc = live ? frow : rsafe;             // (past the end of the chunk: any valid row)
             const int nc = live ? fn : nsafe;
-            const char* dyr = (const char*)(dy + rowc * Wk * g.Cout + cog * (32 * NCO));
-            const char* xr = (const char*)(x + ((long long)nc * g.H + (yv && live ? yi : 0)) * g.W * g.Cin + cit * 32);
-            const int px = fxo + lk;
-            const unsigned pxc = (unsigned)(px < Wk ? px : Wk - 1);
-            const unsigned aoff = __umul24(pxc, cout4) + lane4;
-#pragma unroll
-            for (int c = 0; c < NCO; ++c) a[c] = *(const float*)(dyr + aoff + 128u * c);
-            const int xi0 = (int)pxc * s - 1;
+            const float* dyr = dy + rowc * Wk * g.Cout + cog * (32 * NCO);
+            const float* xr = x + ((long long)nc * g.H + (on ? yi : 0)) * g.W * g.Cin + cit * 32;
+            const i32x4 ra = uniform_srd(dyr, on ? (int)(Wk * cout4 - cog * (128u * NCO)) : 0);
+            const i32x4 rb = uniform_srd(xr, on ? (int)(g.W * cin4 - cit * 128u) : 0);
+            const unsigned px = (unsigned)(fxo + lk);
+            const unsigned aoff = __umul24(px, cout4) + lane4;
+            // (inline asm: the compiler's own wait placement drains ALL loads at the top of the loop -- vmcnt(0) -- whatever the
+            // order of the stages; these loads are invisible to it and waited for by the counted s_waitcnt in front of their stage)
+            asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a[0]) : "v"(aoff), "s"(ra) : "memory");
+            if constexpr (NCO == 2) asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:128" : "=v"(a[1]) : "v"(aoff), "s"(ra) : "memory");
+            const unsigned boff = __umul24(px * (unsigned)s, cin4) + lane4 - cin4;          // column px s - 1 (wraps below column 0)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                int xi = xi0 + kx;
-                xi = xi < 0 ? 0 : (xi > g.W - 1 ? g.W - 1 : xi);
-                b[kx] = *(const float*)(xr + __umul24((unsigned)xi, cin4) + lane4);
+                const unsigned bo = boff + cin4 * kx;
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(b[kx]) : "v"(bo), "s"(rb) : "memory");
             }
-            sxo = (live && yv) ? fxo : -1;
             // advance (selects, no branches)
             const bool wrap = fxo + 2 >= Wk;
             fxo = wrap ? 0 : fxo + 2;
@@ -111,25 +134,26 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
             ++fetched;
         };
 #pragma unroll
-        for (int d = 0; d < D; ++d) fetch0(pa[d], pb[d], pxo[d]);
+        for (int d = 0; d < D; ++d) fetch0(pa[d], pb[d]);
         for (long long i = 0; i < total; i += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const int px = pxo[d] + lk;
-                const bool aok = pxo[d] >= 0 && px < Wk;
-                float av[NCO], bv[3];
-#pragma unroll
-                for (int c = 0; c < NCO; ++c) av[c] = aok ? pa[d][c] : 0.0f;
-                bv[0] = px > 0 ? pb[d][0] : 0.0f;
-                bv[1] = pb[d][1];
-                bv[2] = px * s + 1 < g.W ? pb[d][2] : 0.0f;
+                // this stage's NCO + 3 loads are the oldest of the D (NCO + 3) in flight; the operands pass through the wait so that
+                // the MFMAs cannot be scheduled in front of it
+                if constexpr (NCO == 2)
+                    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(pa[d][0]), "+v"(pa[d][1]), "+v"(pb[d][0]), "+v"(pb[d][1]), "+v"(pb[d][2]) : "n"((D - 1) * 5));
+                else
+                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(pa[d][0]), "+v"(pb[d][0]), "+v"(pb[d][1]), "+v"(pb[d][2]) : "n"((D - 1) * 4));
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                    for (int c = 0; c < NCO; ++c) acc[kx][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[kx], acc[kx][c], 0, 0, 0);
-                fetch0(pa[d], pb[d], pxo[d]);
+                    for (int c = 0; c < NCO; ++c) acc[kx][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[d][c], pb[d][kx], acc[kx][c], 0, 0, 0);
+                fetch0(pa[d], pb[d]);
+                __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler issues all 36 MFMAs, then all 30 loads)
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the D stages past the end (empty descriptors) still write their registers
+
     } else {
         // 1x1 and transposed 2x2 layers: the same straight-line pipeline; one X value per pair, NA values of dY (the transposed layer:
         // its four taps); a pair outside the row / the chunk is silenced by zeroing the X operand alone

@@ -27,10 +27,11 @@ struct WgradGeom {
 // operand feeds 9 (dY) or NCO (X) products instead of one; the transposed 2x2 layer is the mirror image (one X value, 4 NCO of dY).
 // The next pair's operands are fetched before the current pair's MFMAs are issued (one wave per SIMD: nothing else hides the
 // L2 latency), rows follow one another without draining that pipeline.  K-space rows: dY rows, or X rows for the transposed layer.
-// A buffer descriptor whose inputs the compiler can SEE are wave-uniform (readfirstlane on the pointer halves and the size: without
-// it the loop-carried row cursor counts as divergent and every buffer load becomes a waterfall loop)
+// A buffer descriptor (base, stride 0, size in bytes, raw 32-bit format) whose words are PROVABLY wave-uniform: readfirstlane on the
+// pointer halves and the size -- without it the loop-carried row cursor counts as divergent and every buffer load is wrapped in a
+// waterfall loop.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 uniform_srd(const void* p, int bytes) {         // the same four words for inline-asm buffer loads
+__device__ __forceinline__ i32x4 uniform_srd(const void* p, int bytes) {
     const unsigned long long a = (unsigned long long)p;
     i32x4 r;
     r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
@@ -38,11 +39,6 @@ __device__ __forceinline__ i32x4 uniform_srd(const void* p, int bytes) {        
     r[2] = __builtin_amdgcn_readfirstlane(bytes);
     r[3] = 0x00020000;
     return r;
-}
-__device__ __forceinline__ auto uniform_rsrc(const void* p, int bytes) {
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
 template <int MODE, int NCO>

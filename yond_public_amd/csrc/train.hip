@@ -112,13 +112,16 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
             const unsigned aoff = __umul24(px, cout4) + lane4;
             // (inline asm: the compiler's own wait placement drains ALL loads at the top of the loop -- vmcnt(0) -- whatever the
             // order of the stages; these loads are invisible to it and waited for by the counted s_waitcnt in front of their stage)
-            asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a[0]) : "v"(aoff), "s"(ra) : "memory");
-            if constexpr (NCO == 2) asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:128" : "=v"(a[1]) : "v"(aoff), "s"(ra) : "memory");
+            // s_nop 4 in front of every load: a descriptor word may have been written by the vector ALU just before (readfirstlane,
+            // the readlane of a spilled scalar) and "VALU writes SGPR -> VMEM reads it" needs five wait states; the compiler's hazard
+            // recognizer does not look into inline asm.  (Found with a deeper pipeline whose scalar spills made it bite: 25 % error.)
+            asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(a[0]) : "v"(aoff), "s"(ra) : "memory");
+            if constexpr (NCO == 2) asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen offset:128" : "=v"(a[1]) : "v"(aoff), "s"(ra) : "memory");
             const unsigned boff = __umul24(px * (unsigned)s, cin4) + lane4 - cin4;          // column px s - 1 (wraps below column 0)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const unsigned bo = boff + cin4 * kx;
-                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(b[kx]) : "v"(bo), "s"(rb) : "memory");
+                asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(b[kx]) : "v"(bo), "s"(rb) : "memory");
             }
             // advance (selects, no branches)
             const bool wrap = fxo + 2 >= Wk;

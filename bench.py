@@ -522,6 +522,35 @@ def main(argv=None):
                                          "workload": f"configs[4]: {H5}x{W5} low-light frames (no black-level clip, negative DN reach the VST), GuidedResUnet(nf=32), pipeline 'once'"}
         del net5, f5
         torch.cuda.empty_cache()
+        # SURVEY 8(f) N4 on the same line: one training step at the reference's training shape (runfiles/Gaussian/GRU_5to50_norm_mix.yml:
+        # GuidedResUnet nf 32, batch 64 of 256 x 256 Bayer patches), forward + backward + Adam on the HIP kernels (yond_public_amd/train.py)
+        try:
+            from yond_public_amd.train import TrainStep
+            torch.manual_seed(0)
+            net6 = getattr(A, arch['name'])(dict(arch, precision='fp32'))
+            A.initialize_weights(net6)
+            ts6 = TrainStep(net6.to(dev), lr=1e-4, ddp=False)
+            g6 = torch.Generator().manual_seed(1)
+            hr6 = torch.rand(64, 4, 128, 128, generator=g6).to(dev)
+            sg6 = (torch.rand(64, 1, 1, 1, generator=g6) * 0.18 + 0.02).to(dev)
+            lr6 = (hr6 + torch.randn(hr6.shape, generator=g6).to(dev) * sg6).clamp(0, 1)
+            for _ in range(2):
+                ts6.step(lr6, hr6, sg6)
+            torch.cuda.synchronize()
+            t6, n6 = time.perf_counter(), 0
+            while n6 < 10 or time.perf_counter() - t6 < 1.0:
+                loss6, _ = ts6.step(lr6, hr6, sg6)
+                n6 += 1
+            torch.cuda.synchronize()
+            el6 = time.perf_counter() - t6
+            others["training_step"] = {"ms_per_step": round(el6 / n6 * 1e3, 3), "patches_per_s": round(n6 * 64 / el6, 1),
+                                       "bayer_mp_per_s": round(n6 * 64 * 256 * 256 / 1e6 / el6, 1), "steps": n6, "loss": round(float(loss6), 6),
+                                       "workload": "SURVEY 8(f) N4: GuidedResUnet(nf=32), batch 64 x [4][128][128] (256 x 256 Bayer patches), L1 loss, Adam; "
+                                                   "forward / data gradients of the 3x3 layers on the split-operand kernels, weight gradients on the fp32 MFMA"}
+            del ts6, net6, hr6, lr6, sg6
+        except Exception as e:                      # (a reported extra: it must not take the headline line down with it)
+            others["training_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
 
     # final metric reduction (the only collective of the eval path): PSNR of the last output vs the clean frame
     dn = res['raw_dns'][-1]

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
 
     } else {
         // 1x1 and transposed 2x2 layers: the same straight-line pipeline; one X value per pair, NA values of dY (the transposed layer:
-        // its four taps); a pair outside the row / the chunk is silenced by zeroing the X operand alone
+        // its four taps)
         constexpr int D = MODE == 1 ? 4 : 8;
         const int ppr = (Wk + 1) / 2;
         const long long total = (r1 - r0) * ppr;
@@ -163,32 +163,41 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         int fn = nsafe, fy = ysafe, fxo = 0;                         // (an idle wave fetches nothing that counts)
         long long fetched = 0;
         float pa[D][NA], pb[D];
-        int pxo[D];
         const unsigned cout4 = (unsigned)g.Cout * 4u, cin4 = (unsigned)g.Cin * 4u;
         const unsigned lane4 = (unsigned)li * 4u;
-        auto fetch12 = [&](float (&a)[NA], float& b, int& sxo) {
+        // (buffer loads through row descriptors, as above: a pixel past the row's end reads as zero, an empty descriptor silences a
+        // pair past the end of the chunk)
+        auto bload = [](float& dst, unsigned off, const i32x4& r) {
+            asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(off), "s"(r) : "memory");
+        };
+        auto bload128 = [](float& dst, unsigned off, const i32x4& r) {
+            asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen offset:128" : "=v"(dst) : "v"(off), "s"(r) : "memory");
+        };
+        auto fetch12 = [&](float (&a)[NA], float& b) {
             const bool live = fetched < total;
             const long long rowc = live ? frow : rsafe;
             const int nc = live ? fn : nsafe, yc = live ? fy : ysafe;
-            const int px = fxo + lk;
-            const unsigned pxc = (unsigned)(px < Wk ? px : Wk - 1);
-            b = *(const float*)((const char*)(x + rowc * Wk * g.Cin + cit * 32) + __umul24(pxc, cin4) + lane4);
+            const unsigned px = (unsigned)(fxo + lk);
+            const i32x4 rb = uniform_srd(x + rowc * Wk * g.Cin + cit * 32, live ? (int)(Wk * cin4 - cit * 128u) : 0);
+            bload(b, __umul24(px, cin4) + lane4, rb);
             if constexpr (MODE == 1) {
 #pragma unroll
                 for (int ty = 0; ty < 2; ++ty) {
-                    const char* dr = (const char*)(dy + (((long long)nc * g.Ho + 2 * yc + ty) * g.Wo) * g.Cout + cog * (32 * NCO));
+                    const i32x4 ra = uniform_srd(dy + (((long long)nc * g.Ho + 2 * yc + ty) * g.Wo) * g.Cout + cog * (32 * NCO),
+                                                 live ? (int)(g.Wo * cout4 - cog * (128u * NCO)) : 0);
 #pragma unroll
-                    for (int tx = 0; tx < 2; ++tx)
-#pragma unroll
-                        for (int c = 0; c < NCO; ++c)
-                            a[(ty * 2 + tx) * NCO + c] = *(const float*)(dr + __umul24(2u * pxc + tx, cout4) + lane4 + 128u * c);
+                    for (int tx = 0; tx < 2; ++tx) {
+                        const unsigned ao = __umul24(2u * px + tx, cout4) + lane4;
+                        bload(a[(ty * 2 + tx) * NCO], ao, ra);
+                        if constexpr (NCO == 2) bload128(a[(ty * 2 + tx) * NCO + 1], ao, ra);
+                    }
                 }
             } else {
-                const char* dr = (const char*)(dy + rowc * Wk * g.Cout + cog * (32 * NCO));
-#pragma unroll
-                for (int c = 0; c < NCO; ++c) a[c] = *(const float*)(dr + __umul24(pxc, cout4) + lane4 + 128u * c);
+                const i32x4 ra = uniform_srd(dy + rowc * Wk * g.Cout + cog * (32 * NCO), live ? (int)(Wk * cout4 - cog * (128u * NCO)) : 0);
+                const unsigned ao = __umul24(px, cout4) + lane4;
+                bload(a[0], ao, ra);
+                if constexpr (NCO == 2) bload128(a[1], ao, ra);
             }
-            sxo = live ? fxo : -1;
             const bool wrap = fxo + 2 >= Wk;
             fxo = wrap ? 0 : fxo + 2;
             const bool ywrap = wrap && fy + 1 == Hk;
@@ -198,19 +207,27 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
             ++fetched;
         };
 #pragma unroll
-        for (int d = 0; d < D; ++d) fetch12(pa[d], pb[d], pxo[d]);
+        for (int d = 0; d < D; ++d) fetch12(pa[d], pb[d]);
         for (long long i = 0; i < total; i += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const float bv = (pxo[d] >= 0 && pxo[d] + lk < Wk) ? pb[d] : 0.0f;
+                // (NA + 1 loads per stage; the operands pass through the wait: no MFMA above it)
+                if constexpr (NA == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pa[d][0]), "+v"(pb[d]) : "n"((D - 1) * 2));
+                else if constexpr (NA == 2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(pa[d][0]), "+v"(pa[d][1]), "+v"(pb[d]) : "n"((D - 1) * 3));
+                else {
+                    static_assert(NA == 4, "the transposed layer runs with one output-channel tile per wave");
+                    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(pa[d][0]), "+v"(pa[d][1]), "+v"(pa[d][2]), "+v"(pa[d][3]), "+v"(pb[d]) : "n"((D - 1) * 5));
+                }
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t)
 #pragma unroll
                     for (int c = 0; c < NCO; ++c)
-                        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(MODE == 1 ? pa[d][t * NCO + c] : pa[d][c], bv, acc[t][c], 0, 0, 0);
-                fetch12(pa[d], pb[d], pxo[d]);
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(MODE == 1 ? pa[d][t * NCO + c] : pa[d][c], pb[d], acc[t][c], 0, 0, 0);
+                fetch12(pa[d], pb[d]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // D rows (output channel) (r&3) + 8 (r>>2) + 4 lk, column (input channel) li
     if (ws) {

@@ -58,13 +58,15 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
     const int tile = MODE == 0 ? blockIdx.x % ntile : blockIdx.x;
     const int cit = tile % nci, cog = tile / nci;
     const int Hk = MODE == 1 ? g.H : g.Ho, Wk = MODE == 1 ? g.W : g.Wo;
-    const long long rows = (long long)g.N * Hk;
-    const long long r0 = ((long long)blockIdx.y * 4 + wave) * g.chunk;
+    // (32-bit cursors: rows, positions and row sizes are checked on the host to stay below 2^31 -- 64-bit counters put multiplies,
+    // compares and carries of the cursor on the vector ALU)
+    const int rows = g.N * Hk;
+    const int r0 = ((int)blockIdx.y * 4 + wave) * g.chunk;
     const bool idle = r0 >= rows;
     if (idle && !ws) return;                                        // (with a workspace every wave takes part in the workgroup's sum)
-    const long long r1 = idle ? r0 : (r0 + g.chunk < rows ? r0 + g.chunk : rows);
-    const long long rsafe = idle ? 0 : r0;                          // a row every wave may read (an idle wave's r0 lies past the tensor)
-    const int nsafe = (int)(rsafe / Hk), ysafe = (int)(rsafe - (long long)nsafe * Hk);      // (divisions: once, not per stage)
+    const int r1 = idle ? r0 : (r0 + g.chunk < rows ? r0 + g.chunk : rows);
+    const int rsafe = idle ? 0 : r0;                          // a row every wave may read (an idle wave's r0 lies past the tensor)
+    const int nsafe = rsafe / Hk, ysafe = rsafe - nsafe * Hk;      // (divisions: once, not per stage)
     const int s = g.stride;
 
     f32x16 acc[TAPS][NCO];
@@ -85,11 +87,12 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         // as zero (below); a kernel row outside the image still issues its MFMAs, on zeros.
         constexpr int D = NCO == 2 ? 6 : 8;
         const int ppr = (Wk + 1) / 2;                               // positions (pixel pairs) per row
-        const long long total = (r1 - r0) * ppr;
-        long long frow = r0;                                        // the fetch cursor (all scalar)
+        const int total = (r1 - r0) * ppr;
+        int frow = r0;                                              // the fetch cursor (all scalar)
         int fn = nsafe, fy = ysafe, fxo = 0;                         // (an idle wave fetches nothing that counts)
-        long long fetched = 0;
+        int fetched = 0;
         float pa[D][NCO], pb[D][3];
+        const unsigned rowA = (unsigned)(Wk * g.Cout), rowB = (unsigned)(g.W * g.Cin);     // elements per image row
         const unsigned cout4 = (unsigned)g.Cout * 4u, cin4 = (unsigned)g.Cin * 4u;
         const unsigned lane4 = (unsigned)li * 4u;
         // Operands come through BUFFER loads: a descriptor per image row (built on the scalar unit: base = the row's first byte
@@ -102,10 +105,10 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
             const bool live = fetched < total;
             const int yi = fy * s + ky - 1;
             const bool on = live && yi >= 0 && yi < g.H;
-            const long long rowc = live ? frow : rsafe;             // (past the end of the chunk: any valid row)
+            const int rowc = live ? frow : rsafe;                   // (past the end of the chunk: any valid row)
             const int nc = live ? fn : nsafe;
-            const float* dyr = dy + rowc * Wk * g.Cout + cog * (32 * NCO);
-            const float* xr = x + ((long long)nc * g.H + (on ? yi : 0)) * g.W * g.Cin + cit * 32;
+            const float* dyr = dy + (unsigned long long)(unsigned)rowc * rowA + cog * (32 * NCO);          // (32 x 32 -> 64 bit: two scalar multiplies)
+            const float* xr = x + (unsigned long long)(unsigned)(nc * g.H + (on ? yi : 0)) * rowB + cit * 32;
             const i32x4 ra = uniform_srd(dyr, on ? (int)(Wk * cout4 - cog * (128u * NCO)) : 0);
             const i32x4 rb = uniform_srd(xr, on ? (int)(g.W * cin4 - cit * 128u) : 0);
             const unsigned px = (unsigned)(fxo + lk);
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         };
 #pragma unroll
         for (int d = 0; d < D; ++d) fetch0(pa[d], pb[d]);
-        for (long long i = 0; i < total; i += D) {
+        for (int i = 0; i < total; i += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 // this stage's NCO + 3 loads are the oldest of the D (NCO + 3) in flight; the operands pass through the wait so that
@@ -158,11 +161,12 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         // its four taps)
         constexpr int D = MODE == 1 ? 4 : 8;
         const int ppr = (Wk + 1) / 2;
-        const long long total = (r1 - r0) * ppr;
-        long long frow = r0;
+        const int total = (r1 - r0) * ppr;
+        int frow = r0;
         int fn = nsafe, fy = ysafe, fxo = 0;                         // (an idle wave fetches nothing that counts)
-        long long fetched = 0;
+        int fetched = 0;
         float pa[D][NA], pb[D];
+        const unsigned rowA = (unsigned)((MODE == 1 ? g.Wo : Wk) * g.Cout), rowB = (unsigned)(Wk * g.Cin);
         const unsigned cout4 = (unsigned)g.Cout * 4u, cin4 = (unsigned)g.Cin * 4u;
         const unsigned lane4 = (unsigned)li * 4u;
         // (buffer loads through row descriptors, as above: a pixel past the row's end reads as zero, an empty descriptor silences a
@@ -175,15 +179,15 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         };
         auto fetch12 = [&](float (&a)[NA], float& b) {
             const bool live = fetched < total;
-            const long long rowc = live ? frow : rsafe;
+            const int rowc = live ? frow : rsafe;
             const int nc = live ? fn : nsafe, yc = live ? fy : ysafe;
             const unsigned px = (unsigned)(fxo + lk);
-            const i32x4 rb = uniform_srd(x + rowc * Wk * g.Cin + cit * 32, live ? (int)(Wk * cin4 - cit * 128u) : 0);
+            const i32x4 rb = uniform_srd(x + (unsigned long long)(unsigned)rowc * rowB + cit * 32, live ? (int)(Wk * cin4 - cit * 128u) : 0);
             bload(b, __umul24(px, cin4) + lane4, rb);
             if constexpr (MODE == 1) {
 #pragma unroll
                 for (int ty = 0; ty < 2; ++ty) {
-                    const i32x4 ra = uniform_srd(dy + (((long long)nc * g.Ho + 2 * yc + ty) * g.Wo) * g.Cout + cog * (32 * NCO),
+                    const i32x4 ra = uniform_srd(dy + (unsigned long long)(unsigned)(nc * g.Ho + 2 * yc + ty) * rowA + cog * (32 * NCO),
                                                  live ? (int)(g.Wo * cout4 - cog * (128u * NCO)) : 0);
 #pragma unroll
                     for (int tx = 0; tx < 2; ++tx) {
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
                     }
                 }
             } else {
-                const i32x4 ra = uniform_srd(dy + rowc * Wk * g.Cout + cog * (32 * NCO), live ? (int)(Wk * cout4 - cog * (128u * NCO)) : 0);
+                const i32x4 ra = uniform_srd(dy + (unsigned long long)(unsigned)rowc * rowA + cog * (32 * NCO), live ? (int)(Wk * cout4 - cog * (128u * NCO)) : 0);
                 const unsigned ao = __umul24(px, cout4) + lane4;
                 bload(a[0], ao, ra);
                 if constexpr (NCO == 2) bload128(a[1], ao, ra);
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         };
 #pragma unroll
         for (int d = 0; d < D; ++d) fetch12(pa[d], pb[d]);
-        for (long long i = 0; i < total; i += D) {
+        for (int i = 0; i < total; i += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 // (NA + 1 loads per stage; the operands pass through the wait: no MFMA above it)
@@ -323,6 +327,9 @@ static void launch_wgrad(const float* x, const float* dy, WgradGeom g, float* dw
 
 static bool wgrad_check(const float* x, const float* dy, const float* dw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride) {
     if (!x || !dy || !dw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return false;
+    // the kernel's 32-bit cursors and row offsets: rows, row sizes in bytes and pixel pairs per wave chunk below 2^31
+    const long long hk = mode == 1 ? H : Ho, big = 0x7fffffffLL;
+    if ((long long)N * (hk > Ho ? hk : Ho) >= big / 4 || (long long)Wo * Cout * 4 >= big || (long long)W * Cin * 4 >= big || (long long)N * H * W >= big) return false;
     if (mode < 0 || mode > 2 || (mode == 0 && stride != 1 && stride != 2)) return false;
     if (mode == 0 && (Ho != (H + stride - 1) / stride || Wo != (W + stride - 1) / stride)) return false;
     if (mode == 1 && (Ho != 2 * H || Wo != 2 * W)) return false;

@@ -76,17 +76,27 @@ class _Packing:
             bm[:b.numel()] = torch.arange(bb, bb + b.numel())
             self.bmap = bm.to(plan.dev)
 
-    def refresh(self, arena, lib):
+    def maps(self):
+        """The gathers of this layer: the weight map and, when the layer has one, the bias map (TrainStep batches them)."""
+        return [self.omap if self.split_tn else self.wmap] + ([self.bmap] if self.bmap is not None else [])
+
+    def refresh(self, arena, lib, batch=None):
+        """batch: (buffer, {id(map): (offset, length)}) -- the step's ONE gather of every layer's maps; None: gather here."""
+        def gathered(m):
+            if batch is not None and id(m) in batch[1]:
+                o, n = batch[1][id(m)]
+                return batch[0][o:o + n]
+            return arena.index_select(0, m)
         if self.split_tn:
-            wp = arena.index_select(0, self.omap)
+            wp = gathered(self.omap)
             packed = torch.empty_like(wp)
             L.check(lib.yond_pack_conv_split_weight_dev_f32(L.ptr(wp), self.pc.gemm_n, self.pc.cinp, self.pc.ksize, self.split_tn, 2,
                                                             L.ptr(packed), None, L.stream()), "yond_pack_conv_split_weight_dev_f32")
             self.pc._packed[('split', 2)] = (self.split_tn, packed)
         else:
-            self.pc._packed[self.key] = arena.index_select(0, self.wmap)
+            self.pc._packed[self.key] = gathered(self.wmap)
         if self.bmap is not None:
-            self.pc.bias = arena.index_select(0, self.bmap)
+            self.pc.bias = gathered(self.bmap)
         return self.pc
 
 
@@ -100,7 +110,7 @@ def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False, r
         pk = plan.wcache.get(key)
         if pk is None:
             pk = plan.wcache[key] = _Packing(plan, w, b, xf, ksize, stride, splits, shuffle, N, Ho, Wo)
-        pc = pk.refresh(plan.arena, plan.lib)
+        pc = pk.refresh(plan.arena, plan.lib, getattr(plan, 'wbatch', None))
         algo = 'split' if pk.split_tn else 0
     else:                            # a bare plan (kernel tests): pack on the host
         pc = _PackedConv(plan.dev, xf(w.detach()).cpu(), None if b is None else b.detach().cpu(), ksize, stride, splits, shuffle=shuffle)
@@ -432,6 +442,26 @@ class TrainStep:
             out = out * ub[:, None, None, None]
         return out.permute(0, 3, 1, 2)
 
+    def _gather_weights(self):
+        """ONE gather for the maps of every convolution met so far (forward and data-gradient roles, biases): ~100 small launches
+        per step otherwise.  Layers first met during this step gather on their own and join the batch at the next step."""
+        plan = self.plan
+        packs = list(plan.wcache.values())
+        if not packs:
+            plan.wbatch = None
+            return
+        if getattr(self, '_wb_count', -1) != len(packs):
+            slots, maps, off = {}, [], 0
+            for pk in packs:
+                for m in pk.maps():
+                    slots[id(m)] = (off, m.numel())
+                    maps.append(m)
+                    off += m.numel()
+            self._wb_map, self._wb_slots, self._wb_count = torch.cat(maps), slots, len(packs)
+            self._wb_buf = torch.empty(off, dtype=torch.float32, device=self.dev)
+        torch.index_select(self.arena, 0, self._wb_map, out=self._wb_buf)
+        plan.wbatch = (self._wb_buf, self._wb_slots)
+
     # -- loss, backward, Adam ----------------------------------------------------------------------------------------
     def step(self, imgs_lr, imgs_hr, sigma=None):
         """trainer_AWGN.py:101-117 for one batch (`pred = net(imgs_lr, sigma)` for a guided net, `net(imgs_lr)` otherwise).
@@ -441,6 +471,7 @@ class TrainStep:
             p.grad = None
         if self.reducer is not None:
             self.reducer.begin()
+        self._gather_weights()
         pred = self.forward(imgs_lr, sigma).contiguous()
         tgt = imgs_hr.contiguous()
         loss_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
@@ -462,6 +493,7 @@ class TrainStep:
             raise L.YondHipError("TrainStep: the module's parameters were moved (.to / .float) after the step object was built")
         L.check(lib.yond_adam_step_f32(L.ptr(self.arena), L.ptr(flat), L.ptr(self.adam_m), L.ptr(self.adam_v), self.arena.numel(),
                                        self.lr, self.betas[0], self.betas[1], self.eps, self.t, L.stream()), "yond_adam_step_f32")
+        self.plan.wbatch = None                              # (the gathered weights are those of before this update)
         self.m._plan = None                                  # the inference plan's packed weights are stale now
         return float(loss_sum.item()) / pred.numel(), grads
 

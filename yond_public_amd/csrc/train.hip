@@ -47,15 +47,19 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
                                                          float* __restrict__ ws /* partial sums per workgroup, or null: atomics */) {
     // taps per wave: a 3x3 layer's kernel rows go to three different waves (grid x = ky-major): 3 NCO accumulators = 96 registers
     // at NCO 2, two waves per SIMD -- nine taps in one wave (288 registers) left one wave per SIMD and nothing to hide latency with
-    constexpr int TAPS = MODE == 0 ? 3 : (MODE == 1 ? 4 : 1);
-    constexpr int NA = MODE == 1 ? 4 * NCO : NCO, NB = MODE == 0 ? 3 : 1;
+    // With ONE output-channel tile (the 32-channel level) a wave takes all three kernel rows instead: nine accumulators (144
+    // registers), one dY and nine X values per pixel pair for nine MFMAs -- the per-pair cursor, descriptor and offset work is
+    // shared by three times as many MFMAs (three MFMAs per pair left the launch bound by exactly that work).
+    constexpr bool ALLKY = MODE == 0 && NCO == 1;
+    constexpr int TAPS = MODE == 0 ? (ALLKY ? 9 : 3) : (MODE == 1 ? 4 : 1);
+    constexpr int NA = MODE == 1 ? 4 * NCO : NCO;
     // (the wave index through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform, and everything derived
     // from it -- the row cursor, the 64-bit row bases -- would be computed on the vector ALU, whose time ADDS to the fp32 MFMAs')
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lk = lane >> 5;
     const int nci = g.Cin / 32, ntile = nci * (g.Cout / (32 * NCO));
-    const int ky = MODE == 0 ? blockIdx.x / ntile : 0;
-    const int tile = MODE == 0 ? blockIdx.x % ntile : blockIdx.x;
+    const int ky = (MODE == 0 && !ALLKY) ? blockIdx.x / ntile : 0;
+    const int tile = (MODE == 0 && !ALLKY) ? blockIdx.x % ntile : blockIdx.x;
     const int cit = tile % nci, cog = tile / nci;
     const int Hk = MODE == 1 ? g.H : g.Ho, Wk = MODE == 1 ? g.W : g.Wo;
     // (32-bit cursors: rows, positions and row sizes are checked on the host to stay below 2^31 -- 64-bit counters put multiplies,
@@ -85,13 +89,14 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         // chunk) makes the compiler drain every outstanding load at the join (s_waitcnt vmcnt(0)) and the prefetch depth is gone:
         // measured +40-50 % per launch for each such branch.  So every load is issued unconditionally and what must not count reads
         // as zero (below); a kernel row outside the image still issues its MFMAs, on zeros.
-        constexpr int D = NCO == 2 ? 6 : 8;
+        constexpr int NKY = ALLKY ? 3 : 1, NBV = 3 * NKY;              // kernel rows per wave, X values per pixel pair
+        constexpr int D = 6;                                        // (D (NCO + NBV) loads in flight: 30 / 60 of the counter's 63)
         const int ppr = (Wk + 1) / 2;                               // positions (pixel pairs) per row
         const int total = (r1 - r0) * ppr;
         int frow = r0;                                              // the fetch cursor (all scalar)
         int fn = nsafe, fy = ysafe, fxo = 0;                         // (an idle wave fetches nothing that counts)
         int fetched = 0;
-        float pa[D][NCO], pb[D][3];
+        float pa[D][NCO], pb[D][NBV];
         const unsigned rowA = (unsigned)(Wk * g.Cout), rowB = (unsigned)(g.W * g.Cin);     // elements per image row
         const unsigned cout4 = (unsigned)g.Cout * 4u, cin4 = (unsigned)g.Cin * 4u;
         const unsigned lane4 = (unsigned)li * 4u;
@@ -101,16 +106,14 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         // odd row's last pair -- and a size of 0 silences a whole stage (a kernel row outside the image, a pair past the end of
         // the chunk): no clamps, no selects, no 64-bit per-lane addresses; what is left on the vector ALU per pair is six
         // instructions of offset arithmetic.  (fp32 MFMA time and vector-ALU time add on gfx950.)
-        auto fetch0 = [&](float (&a)[NCO], float (&b)[3]) {
+        auto fetch0 = [&](float (&a)[NCO], float (&b)[NBV]) {
             const bool live = fetched < total;
-            const int yi = fy * s + ky - 1;
-            const bool on = live && yi >= 0 && yi < g.H;
             const int rowc = live ? frow : rsafe;                   // (past the end of the chunk: any valid row)
             const int nc = live ? fn : nsafe;
+            const int yi0 = fy * s + ky - 1;                         // the (first) kernel row's input row
+            const bool aon = ALLKY ? live : (live && yi0 >= 0 && yi0 < g.H);
             const float* dyr = dy + (unsigned long long)(unsigned)rowc * rowA + cog * (32 * NCO);          // (32 x 32 -> 64 bit: two scalar multiplies)
-            const float* xr = x + (unsigned long long)(unsigned)(nc * g.H + (on ? yi : 0)) * rowB + cit * 32;
-            const i32x4 ra = uniform_srd(dyr, on ? (int)(Wk * cout4 - cog * (128u * NCO)) : 0);
-            const i32x4 rb = uniform_srd(xr, on ? (int)(g.W * cin4 - cit * 128u) : 0);
+            const i32x4 ra = uniform_srd(dyr, aon ? (int)(Wk * cout4 - cog * (128u * NCO)) : 0);
             const unsigned px = (unsigned)(fxo + lk);
             const unsigned aoff = __umul24(px, cout4) + lane4;
             // (inline asm: the compiler's own wait placement drains ALL loads at the top of the loop -- vmcnt(0) -- whatever the
@@ -122,9 +125,16 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
             if constexpr (NCO == 2) asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen offset:128" : "=v"(a[1]) : "v"(aoff), "s"(ra) : "memory");
             const unsigned boff = __umul24(px * (unsigned)s, cin4) + lane4 - cin4;          // column px s - 1 (wraps below column 0)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const unsigned bo = boff + cin4 * kx;
-                asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(b[kx]) : "v"(bo), "s"(rb) : "memory");
+            for (int r = 0; r < NKY; ++r) {
+                const int yi = yi0 + r;
+                const bool on = live && yi >= 0 && yi < g.H;       // (a kernel row outside the image: an empty descriptor)
+                const float* xr = x + (unsigned long long)(unsigned)(nc * g.H + (on ? yi : 0)) * rowB + cit * 32;
+                const i32x4 rb = uniform_srd(xr, on ? (int)(g.W * cin4 - cit * 128u) : 0);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const unsigned bo = boff + cin4 * kx;
+                    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(b[r * 3 + kx]) : "v"(bo), "s"(rb) : "memory");
+                }
             }
             // advance (selects, no branches)
             const bool wrap = fxo + 2 >= Wk;
@@ -145,11 +155,12 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
                 if constexpr (NCO == 2)
                     asm volatile("s_waitcnt vmcnt(%5)" : "+v"(pa[d][0]), "+v"(pa[d][1]), "+v"(pb[d][0]), "+v"(pb[d][1]), "+v"(pb[d][2]) : "n"((D - 1) * 5));
                 else
-                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(pa[d][0]), "+v"(pb[d][0]), "+v"(pb[d][1]), "+v"(pb[d][2]) : "n"((D - 1) * 4));
+                    asm volatile("s_waitcnt vmcnt(%10)" : "+v"(pa[d][0]), "+v"(pb[d][0]), "+v"(pb[d][1]), "+v"(pb[d][2]), "+v"(pb[d][3]), "+v"(pb[d][4]),
+                                 "+v"(pb[d][5]), "+v"(pb[d][6]), "+v"(pb[d][7]), "+v"(pb[d][8]) : "n"((D - 1) * 10));
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                for (int t = 0; t < NBV; ++t)
 #pragma unroll
-                    for (int c = 0; c < NCO; ++c) acc[kx][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[d][c], pb[d][kx], acc[kx][c], 0, 0, 0);
+                    for (int c = 0; c < NCO; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[d][c], pb[d][t], acc[t][c], 0, 0, 0);
                 fetch0(pa[d], pb[d]);
                 __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler issues all 36 MFMAs, then all 30 loads)
             }
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
 #pragma unroll
                 for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[t][c][r];
                 __syncthreads();
-                float* out = wsc + ((size_t)(MODE == 0 ? ky * 3 + t : t) * g.Cout + cog * (32 * NCO) + c * 32) * g.Cin + cit * 32 + li;
+                float* out = wsc + ((size_t)((MODE == 0 && !ALLKY) ? ky * 3 + t : t) * g.Cout + cog * (32 * NCO) + c * 32) * g.Cin + cit * 32 + li;
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int r = wave * 4 + rr;
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int c = 0; c < NCO; ++c) {
-            float* out = dw + ((size_t)(MODE == 0 ? ky * 3 + t : t) * g.Cout + cog * (32 * NCO) + c * 32) * g.Cin + cit * 32 + li;
+            float* out = dw + ((size_t)((MODE == 0 && !ALLKY) ? ky * 3 + t : t) * g.Cout + cog * (32 * NCO) + c * 32) * g.Cin + cit * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) atomicAdd(out + (size_t)((r & 3) + 8 * (r >> 2) + 4 * lk) * g.Cin, acc[t][c][r]);
         }
@@ -295,9 +306,9 @@ template <int MODE, int NCO>
 static void wgrad_split(const WgradGeom& g, long long& chunk, long long& wgchunks) {
     const int Hk = MODE == 1 ? g.H : g.Ho, Wk = MODE == 1 ? g.W : g.Wo;
     const long long rows = (long long)g.N * Hk;
-    const long long tiles = (long long)(g.Cout / (32 * NCO)) * (g.Cin / 32) * (MODE == 0 ? 3 : 1);
+    const long long tiles = (long long)(g.Cout / (32 * NCO)) * (g.Cin / 32) * ((MODE == 0 && NCO == 2) ? 3 : 1);
     // about one round of waves at the kernel's occupancy (256 CUs x 4 SIMDs x waves per SIMD), at least ~128 pixels per wave
-    const long long target = 1024 * (MODE == 0 ? 3 : 4);
+    const long long target = 1024 * (MODE == 0 ? (NCO == 2 ? 3 : 2) : 4);
     long long chunks = (target + tiles - 1) / tiles;
     const long long min_rows = (128 + Wk - 1) / Wk;
     chunk = (rows + chunks - 1) / chunks;
@@ -308,7 +319,7 @@ static void wgrad_split(const WgradGeom& g, long long& chunk, long long& wgchunk
 
 template <int MODE, int NCO>
 static void launch_wgrad(const float* x, const float* dy, WgradGeom g, float* dw, float* ws, hipStream_t stream) {
-    const long long tiles = (long long)(g.Cout / (32 * NCO)) * (g.Cin / 32) * (MODE == 0 ? 3 : 1);
+    const long long tiles = (long long)(g.Cout / (32 * NCO)) * (g.Cin / 32) * ((MODE == 0 && NCO == 2) ? 3 : 1);
     long long chunk, wgchunks;
     wgrad_split<MODE, NCO>(g, chunk, wgchunks);
     g.chunk = (int)chunk;

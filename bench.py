@@ -51,9 +51,11 @@ def parse_args(argv=None):
                     help="frames per step and GPU (0 = default: 24 for 'once', 12 for 'iter', the batch size with --batch)")
     ap.add_argument("--mode", default="once", choices=["once", "iter"])
     ap.add_argument("--arch", default="GuidedResUnet", choices=list(ARCHS))
-    ap.add_argument("--cfg", type=int, default=2, choices=[2, 4, 5],
-                    help="BASELINE.json config: 2 (headline) one 3000x4000 frame at a time, SNR-Net; 4 UNetSeeInDark, batch 8 of "
-                         "3000x4000 in one forward; 5 low light, no black-level clip, 4000x6000, fp16 MFMA conv path")
+    ap.add_argument("--cfg", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config: 2 (headline) one 3000x4000 frame at a time, SNR-Net; 3 SIDD-validation-shaped items "
+                         "(YOND_SIDD.py eval: 3000x5328 frame for the round-1 estimate, 32 blocks of 256x256, pipeline 'iter', batch-32 "
+                         "forwards, block metrics); 4 UNetSeeInDark, batch 8 of 3000x4000 in one forward; 5 low light, no black-level "
+                         "clip, 4000x6000, fp16 MFMA conv path")
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0, help="frames per batched forward (cfg 4: 8)")
@@ -70,6 +72,11 @@ def parse_args(argv=None):
                     help="fp32 (headline): fp32 results, 3x3 convolutions as fp32-accurate split-operand products on the fp16 MFMA; "
                          "fp32-mfma: every convolution on the fp32-input MFMA; fp16: BASELINE cfg 5 (not the headline configuration)")
     a = ap.parse_args(argv)
+    if a.cfg == 3:
+        a.mode = "iter"                                # the shipped SIDD runfile (runfiles/YOND/SIDD_simple+full_pre_grumix.yml)
+        a.height, a.width = 256, 8192                  # the 32 blocks of an item side by side: the denoised Bayer pixels
+        a.frames_per_step = a.frames_per_step or 8
+        a.no_extras = True
     if a.cfg == 4:
         a.arch = 'UNetSeeInDark'
         a.batch = a.batch or 8
@@ -166,28 +173,36 @@ def cpu_baseline_and_parity(a, arch, dev, net_factory):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import yond_oracle as O
     from yond_public_amd import pipeline as P
-    H, W = (a.height, a.width) if a.cfg == 2 else (2048, 3072)      # the headline's own 3000x4000 frame (bounded sample: one frame)
-    noisy, clean = O.synth_noisy(H, W, 4.0, 6.0, 0, clip=(a.cfg != 5))
+    H, W = (a.height, a.width) if a.cfg in (2, 3) else (2048, 3072)      # the headline's own 3000x4000 frame (bounded sample: one frame)
+    noisy, clean = O.synth_noisy(H, W, 4.0, 6.0, 100 if a.cfg == 3 else 0, clip=(a.cfg != 5))
     sd = O.denoising_state_dict(arch, 0) if a.weights == "denoising" else O.procedural_state_dict(arch, 0)
     pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': a.mode, 'max_iter': 1, 'full_dn': True,
             'collab_sidd256': False}
+    lr_full = None
+    if a.cfg == 3:                                  # one SIDD-shaped item: [32][256][256] blocks + the full frame of the round-1 estimate
+        pipe = dict(SIDD_PIPE)
+        lr_full, _ = O.synth_noisy(SIDD_FULL[0], SIDD_FULL[1], 4.0, 6.0, 500)
+        noisy = np.array(np.split(noisy, 32, axis=-1))
     old = torch.get_num_threads()
     ncores = host_cores()
     runs = {}
     for threads in (1, ncores):
         torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        ref = O.IterDenoise(noisy, arch, sd, pipe)
+        ref = O.IterDenoise(noisy, arch, sd, pipe, lr_full=lr_full)
         runs[threads] = time.perf_counter() - t0
     torch.set_num_threads(old)
     what = (f"one {H}x{W} synthetic Bayer frame, same pipeline ('{a.mode}', {len(ref['raw_dns'])} pass(es)) and weights, "
             f"oracle/yond_oracle.py (NumPy/SciPy + PyTorch-CPU)")
+    if a.cfg == 3:
+        what = (f"one SIDD-shaped item ({SIDD_FULL[0]}x{SIDD_FULL[1]} estimate frame + 32 blocks of 256x256), IterDenoise of the shipped SIDD "
+                f"pipeline ({len(ref['raw_dns'])} passes, 64 batch-1 forwards as in the reference), oracle/yond_oracle.py")
     base = {"value": round(H * W / 1e6 / runs[1], 4), "unit": "Bayer MP/s", "cores": 1, "kind": "port",
             "sample": f"{what}, {runs[1]:.1f} s",
             "all_cores": {"value": round(H * W / 1e6 / runs[ncores], 4), "unit": "Bayer MP/s", "cores": ncores,
                           "sample": f"the same, torch.set_num_threads({ncores}), {runs[ncores]:.1f} s"}}
     net = net_factory(a.precision)
-    res = P.IterDenoise(torch.from_numpy(noisy).to(dev), net, arch, pipe)
+    res = P.IterDenoise(torch.from_numpy(noisy).to(dev), net, arch, pipe, lr_full=None if lr_full is None else torch.from_numpy(lr_full).to(dev))
     parity = {"sample": f"{H}x{W} frame of cpu_baseline", "passes": len(res['raw_dns'])}
     if len(res['raw_dns']) != len(ref['raw_dns']):
         parity["error"] = f"HIP ran {len(res['raw_dns'])} passes, oracle {len(ref['raw_dns'])}"
@@ -218,6 +233,87 @@ def pmc_traffic(kernel):
     return None
 
 
+SIDD_FULL = (3000, 5328)          # SURVEY 8d cfg 3: synthetic stand-ins of the SIDD full frames
+SIDD_PIPE = {'data_type': 'SIDD', 'full_est': True, 'est_type': 'simple+full', 'k': 29, 'full_dn': False, 'vst_type': 'exact',
+             'bias_corr': 'pre', 'denoiser_type': 'gru32n', 'iter': 'iter', 'max_iter': 1, 'clip': False}     # the shipped runfile's `pipeline`
+REF_SIDD_S_PER_IMAGE = 5.1        # logs/log_YOND_SIDD_simple+full_pre_grumix_iter.log:10,130 (204 s / 40 images; other hardware: context only)
+
+
+def sidd_items(n, dev, rank=0):
+    """n SIDD-validation-shaped synthetic items resident on the device (reference: YOND_SIDD.py:507-514 hands IterDenoise
+    `lr` [32][256][256], the ground truth and the full-resolution frame the round-1 estimate is taken from)."""
+    import numpy as np
+    import torch
+    from yond_public_amd import synthetic as S
+    items = []
+    for k in range(n):
+        noisy, clean = S.synth_noisy(256, 8192, 4.0, 6.0, 100 + 1000 * rank + k)
+        full, _ = S.synth_noisy(SIDD_FULL[0], SIDD_FULL[1], 4.0, 6.0, 500 + 1000 * rank + k)
+        items.append({'lr': torch.from_numpy(np.array(np.split(noisy, 32, axis=-1))).to(dev), 'hr': torch.from_numpy(clean).to(dev),
+                      'lr_full': torch.from_numpy(full).to(dev)})
+    return items
+
+
+def sidd_eval_item(item, net, arch, P):
+    """One image of YOND_SIDD.eval (:507-536): IterDenoise (full-frame self NLE, bias LUT, 32 blocks as ONE batch-32 forward,
+    collaborative NLE with the SIDD_256 re-tiling, second pass) + per-block PSNR / SSIM of both rounds on the device."""
+    res = P.IterDenoise(item['lr'], net, arch, SIDD_PIPE, lr_full=item['lr_full'])
+    if len(res['raw_dns']) != 2:
+        raise SystemExit(f"bench.py: the SIDD pipeline ran {len(res['raw_dns'])} pass(es), expected 2 (regs {res['regs']})")
+    res['metrics'] = [P.block_metrics(dn, item['hr']) for dn in res['raw_dns']]
+    return res
+
+
+def timed_region(run_step, steps, sync, D, dev):
+    """EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides; returns (the MAX over ranks of the
+    elapsed time, every rank's time for its own K steps -- taken before the closing barrier -- in rank order)."""
+    sync()
+    D.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step()
+    sync()
+    own = time.perf_counter() - t0                   # this rank's own K steps (before it waits for the others)
+    D.barrier()
+    sync()
+    local = time.perf_counter() - t0
+    return D.max_over_ranks(local, dev), D.gather_over_ranks(own, dev)
+
+
+def check_world(a, D):
+    """The process group's own world size must be the N of --gpus (a job launched with another --nproc-per-node, or ranks
+    that did not all join, would otherwise report an aggregate over the wrong number of GPUs)."""
+    gw = D.group_world_size()
+    if gw is not None and gw != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group ({D.STATS['backend']}) has {gw} rank(s)")
+    if gw is None and a.gpus != 1:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} without a process group")
+    return gw
+
+
+def stub_main(a):
+    """Tests only (YOND_BENCH_STUB=1; tests/test_bench_launcher.py): the launcher, the rendezvous, the timed-region protocol
+    (barriers, max over ranks, per-rank gather) and rank 0's line with the hot path replaced by a sleep, on gloo -- so that the
+    N > 1 plumbing of `bench.py --gpus N` runs on a CPU-only box.  Never a measurement: the line says so."""
+    from yond_public_amd import distributed as D
+    rank, local, world = D.init(backend="gloo")
+    gw = check_world(a, D)
+    step_s = float(os.environ.get("YOND_BENCH_STUB_STEP_S", "0.01")) * (1 + rank)      # (uneven ranks: the max must win)
+    elapsed, per_rank = timed_region(lambda: time.sleep(step_s), a.steps, lambda: None, D, None)
+    if os.environ.get("YOND_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    if rank == 0:
+        mp = a.height * a.width / 1e6
+        n_timed = a.steps * a.frames_per_step
+        print(json.dumps({"metric": "STUB (no GPU work: launcher / rendezvous / reduction plumbing only)", "value": round(world * n_timed * mp / elapsed, 2),
+                          "unit": "Bayer MP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+                          "data": "stub", "collectives": dict(D.STATS, world_size=gw,
+                                                               per_rank_mp_per_s=[round(n_timed * mp / t, 2) for t in per_rank])}), flush=True)
+    D.barrier()
+    D.finalize()
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     a = parse_args(argv)
@@ -226,6 +322,8 @@ def main(argv=None):
         sys.exit(spawn_ranks(a, argv))
     if env_world is not None and int(env_world) != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={env_world}; launch with --nproc-per-node {a.gpus}")
+    if os.environ.get("YOND_BENCH_STUB") == "1":
+        return stub_main(a)
 
     import numpy as np
     import torch
@@ -238,6 +336,7 @@ def main(argv=None):
     rank, local, world = D.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    group_world = check_world(a, D)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     L.load()
@@ -254,7 +353,10 @@ def main(argv=None):
     clip = a.cfg != 5                                     # cfg 5: no black-level clip (negative DN reach the VST)
     expo = 0.2 if a.cfg == 5 else 1.0                     # cfg 5: low light
     frames, cleans = [], []
-    for i in range(max(1, a.distinct_frames)):
+    if a.cfg == 3:
+        frames = sidd_items(max(1, min(a.distinct_frames, 2)), dev, rank)
+        cleans = [it['hr'] for it in frames]
+    for i in range(max(1, a.distinct_frames) if a.cfg != 3 else 0):
         if a.cfg == 5:
             rng = np.random.default_rng(1997 + 1000 * rank + i)
             clean = (S.synth_clean(H, W) * expo).astype(np.float32)
@@ -270,6 +372,8 @@ def main(argv=None):
     F = a.frames_per_step
 
     def one(frame, netx=None):
+        if a.cfg == 3:
+            return sidd_eval_item(frame, netx or net, arch, P)
         res = P.IterDenoise(frame, netx or net, arch, pipe)
         if len(res['raw_dns']) != n_pass:
             raise SystemExit(f"bench.py: pipeline '{a.mode}' ran {len(res['raw_dns'])} pass(es), expected {n_pass} "
@@ -318,13 +422,12 @@ def main(argv=None):
     # region cannot be used: these kernels take every vector register of their CUs, so a single foreign wave keeps one of the
     # 256 persistent workgroups waiting for a CU -- measured: every launch 1.45x longer.)
     plan.clk = torch.zeros(2, dtype=torch.int64, device=dev)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        res = run(F)
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    last_res = {}
+
+    def run_step():
+        last_res['res'] = run(F)
+    elapsed, per_rank_s = timed_region(run_step, a.steps, torch.cuda.synchronize, D, dev)
+    res = last_res['res']
     sclk_res = sclk.result() if sclk else None
     clk_c, clk_r = (int(v) for v in plan.clk.cpu())
     plan.clk = None
@@ -339,6 +442,7 @@ def main(argv=None):
     n_timed = a.steps * F
     last_frame = frames[(n_timed - 1) % len(frames)]
     last_clean = cleans[(n_timed - 1) % len(frames)]
+    last_noisy = torch.cat(list(last_frame['lr']), dim=-1) if a.cfg == 3 else last_frame
 
     # one frame at a time (wall time from 'noisy frame resident' to 'denoised frame resident')
     seq = None
@@ -448,7 +552,12 @@ def main(argv=None):
     if stage_ms:
         tot_ms = sum(stage_ms.values()) / inst_frames
         bpp = 24.0 if a.mode == "once" else 56.0
-        gbs = bpp * H * W / (tot_ms * 1e-3) / 1e9
+        alg_bytes = bpp * H * W
+        if a.cfg == 3:
+            # self NLE on the full frame (8 B per pixel), two K1 + K4 passes and the collaborative NLE on the 32 blocks (16 + 16 + 16 B)
+            alg_bytes = 8.0 * SIDD_FULL[0] * SIDD_FULL[1] + 48.0 * H * W
+            bpp = alg_bytes / (H * W)
+        gbs = alg_bytes / (tot_ms * 1e-3) / 1e9
         roof_hbm = {"stage": "VST+NLE (K1, K4, K5-K7)", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBPS, 4), "algorithmic_bytes_per_bayer_px": bpp, "ms_per_frame": round(tot_ms, 4),
                     "stage_ms_per_frame": {k: round(v / inst_frames, 4) for k, v in stage_ms.items()},
@@ -499,6 +608,30 @@ def main(argv=None):
         others["cfg4_unet_batch8"] = {"value": round(n4 * 8 * H * W / 1e6 / el4, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el4 / (n4 * 8) * 1e3, 3),
                                       "frames": n4 * 8, "workload": f"configs[3]: UNetSeeInDark(nf=32), {H}x{W} frames, per-frame NLE, ONE batched forward of 8"}
         del net4, r4, batch8
+        torch.cuda.empty_cache()
+        # configs[2] (the reference's only shipped entry point, YOND_SIDD.py eval): per image the full-frame self NLE, two rounds of
+        # batch-32 forwards over the 32 blocks, the collaborative NLE, per-block PSNR / SSIM of both rounds (`--cfg 3` times it as
+        # the region proper; the reference's log shows 5.1 s per image on its authors' GPU)
+        try:
+            it3 = sidd_items(2, dev)
+            sidd_eval_item(it3[0], net, arch, P)
+            torch.cuda.synchronize()
+            t3, n3 = time.perf_counter(), 0
+            while n3 < 8 or time.perf_counter() - t3 < 1.0:
+                r3 = sidd_eval_item(it3[n3 % 2], net, arch, P)
+                n3 += 1
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t3
+            others["cfg3_sidd_eval"] = {"images_per_s": round(n3 / el3, 2), "ms_per_image": round(el3 / n3 * 1e3, 3),
+                                        "value": round(n3 * 256 * 8192 / 1e6 / el3, 2), "unit": "Bayer MP/s (denoised blocks: 2.097 MP per image)",
+                                        "full_frame_mp_per_s": round(n3 * SIDD_FULL[0] * SIDD_FULL[1] / 1e6 / el3, 1), "images": n3,
+                                        "psnr_iter0_iter1": [round(float(np.mean(m[0])), 3) for m in r3['metrics']],
+                                        "reference_s_per_image": REF_SIDD_S_PER_IMAGE,
+                                        "workload": f"configs[2]: SIDD-shaped synthetic items ({SIDD_FULL[0]}x{SIDD_FULL[1]} estimate frame + 32 blocks of 256x256), "
+                                                    "YOND_SIDD.eval's loop body (IterDenoise 'iter' with batch-32 forwards + block metrics), one image at a time"}
+            del it3, r3
+        except Exception as e:
+            others["cfg3_sidd_eval"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         torch.cuda.empty_cache()
         H5, W5 = 4000, 6000
         rng5 = np.random.default_rng(1997)
@@ -556,16 +689,18 @@ def main(argv=None):
     dn = res['raw_dns'][-1]
     dn = dn[-1] if dn.dim() == 3 else dn
     mse = torch.mean((dn.double() - last_clean.double()) ** 2).item()
-    mse_in = torch.mean((last_frame.double() - last_clean.double()) ** 2).item()
+    mse_in = torch.mean((last_noisy.double() - last_clean.double()) ** 2).item()
     sums = D.MetricSums(1)
     sums.update([10 * np.log10(1.0 / mse)], [0.0])
     red = sums.reduce(dev)
 
     if rank == 0:
         mp = H * W / 1e6
-        cfg_idx = {2: 1, 4: 3, 5: 4}[a.cfg]
+        cfg_idx = {2: 1, 3: 2, 4: 3, 5: 4}[a.cfg]
         if a.batch:
             driver = f"IterDenoiseBatch: per-frame NLE, ONE batched forward of {a.batch} frames"
+        elif a.cfg == 3:
+            driver = "YOND_SIDD.eval's loop body per image: IterDenoise (batch-32 forwards) + block metrics, one image at a time"
         elif stream_driver:
             driver = "denoise_stream: NLE of frame k+1 on a second HIP stream while the convolutions of frame k run"
         else:
@@ -580,7 +715,12 @@ def main(argv=None):
                               "f32 accumulate; error vs float64 <= the f32-MFMA kernels')",
                       "fp32-mfma": "f32", "fp16": "f16 MFMA operands, f32 accumulate and tensors (cfg 5)"}[a.precision],
             "data": "synthetic",
-            "config": {"workload": f"configs[{cfg_idx}]: {H}x{W} synthetic Poisson-Gaussian Bayer frames"
+            "config": {"workload": (f"configs[{cfg_idx}]: SIDD-validation-shaped synthetic items ({SIDD_FULL[0]}x{SIDD_FULL[1]} frame for the round-1 "
+                                    f"estimate + 32 blocks of 256x256 Bayer), {F} per step and GPU, each through YOND_SIDD.eval's loop body: "
+                                    f"self NLE on the full frame, bias LUT, batch-32 {a.arch}(nf=32) forward, collaborative NLE (SIDD_256), second "
+                                    f"pass, per-block PSNR/SSIM of both rounds; `value` counts the {H * W / 1e6:.3f} MP of denoised blocks per image")
+                                   if a.cfg == 3 else
+                                   f"configs[{cfg_idx}]: {H}x{W} synthetic Poisson-Gaussian Bayer frames"
                                    f"{'' if clip else ' (low light, no black-level clip)'}, {F} per step and GPU, each through the full "
                                    f"NLE+VST+{a.arch}(nf=32)+iVST, pipeline '{a.mode}' ({n_pass} pass(es) per frame), bias_corr=pre, k=29",
                        "frames_per_step_per_gpu": F, "ms_per_frame": round(elapsed / n_timed * 1e3, 3),
@@ -601,9 +741,16 @@ def main(argv=None):
                            "measured": "HIP events around every convolution launch, one instrumented pass after the timed region"},
             "psnr_vs_clean_db": {"denoised": round(red["psnr_last"], 3), "noisy_input": round(10 * np.log10(1.0 / mse_in), 3)},
             "estimated_K_sigma": [[round(float(v), 4) for v in pr] for pr in (res['params'] if not a.batch else res['params'][-1])],
+            **({"images_per_s": round(world * n_timed / elapsed, 2), "ms_per_image": round(elapsed / n_timed * 1e3, 3),
+                "full_frame_mp_per_s": round(world * n_timed * SIDD_FULL[0] * SIDD_FULL[1] / 1e6 / elapsed, 1),
+                "block_metrics_last": {"psnr_iter0": round(float(np.mean(res['metrics'][0][0])), 3), "psnr_iter1": round(float(np.mean(res['metrics'][1][0])), 3),
+                                       "ssim_iter0": round(float(np.mean(res['metrics'][0][1])), 4), "ssim_iter1": round(float(np.mean(res['metrics'][1][1])), 4)},
+                "reference_s_per_image": {"value": REF_SIDD_S_PER_IMAGE, "source": "logs/log_YOND_SIDD_simple+full_pre_grumix_iter.log:10,130 "
+                                          "(204 s / 40 images on the authors' unnamed GPU: context, not a baseline for this hardware)"}} if a.cfg == 3 else {}),
             # torch.distributed traffic of this run (a process group exists whenever the torchrun environment is set,
             # world size 1 included): barrier + max-over-ranks of the timing + the PSNR reduction
-            "collectives": dict(D.STATS),
+            "collectives": dict(D.STATS, world_size=group_world,
+                                per_rank_mp_per_s=[round(a.steps * F * H * W / 1e6 / t, 2) for t in per_rank_s]),
         }
         if world == 1 and not a.no_cpu_baseline and not a.batch:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline_and_parity(a, arch, dev, make_net)

@@ -386,6 +386,50 @@ def gen_train(ref):
     save("train", **out)
 
 
+def train32_case():
+    """Inputs of the nf = 32 training fixture (regenerated from seeds by the tests): four 4 x 128 x 128 patches -- the patch size
+    and width of the shipped training runfile (runfiles/Gaussian/GRU_5to50_norm_mix.yml: nf 32, 256 x 256 Bayer crops), so that
+    the 256- and 512-channel layers and the bottleneck at 8 x 8 pixels meet the reference; sigma in the runfile's 5..50 / 255."""
+    g = torch.Generator().manual_seed(3232)
+    hr = torch.rand((4, 4, 128, 128), generator=g) * 0.8 + 0.05
+    sigma = torch.tensor([5.0, 17.0, 31.0, 50.0]).view(-1, 1, 1, 1) / 255.0
+    lr = (hr + torch.randn((4, 4, 128, 128), generator=g) * sigma).clamp(0, 1)
+    arch = ARCHS["gru32"]
+    return lr, hr, sigma, arch, O.procedural_state_dict(arch, 23), 1e-4
+
+
+def grad_sample32(t, n=1024):
+    a = np.asarray(t, np.float32).reshape(-1)
+    return a if a.size <= n else a[::a.size // n][:n]
+
+
+def gen_train32(ref):
+    """N4 at the width the reference trains (nf = 32; VERDICT round 3, missing #2): ONE step of trainer_AWGN.py:101-117 on
+    GuidedResUnet(nf = 32), batch 4 x [4][128][128]: loss, prediction, every parameter's gradient (checksums + 1024-element
+    samples) and the Adam-updated weights.  dpred = 1 / 262,144 here: the back-propagated values are of the size the reference's
+    batch-64 step produces to within a factor of 16 (fp16 subnormal territory for an unscaled split-operand data gradient)."""
+    from torch.optim import Adam
+    lr_img, hr_img, sigma, arch, sd, step = train32_case()
+    net = getattr(ref, arch['name'])(dict(arch))
+    net = ref.load_weights(net, sd, by_name=False).train()
+    loss_fn = ref.Unet_Loss()
+    opt = Adam(net.parameters(), lr=step)
+    opt.zero_grad()
+    pred = net(lr_img, sigma)
+    loss = loss_fn(pred, hr_img)
+    loss.backward()
+    out = {"loss": np.array(float(loss)), "pred_chk": checks(pred.detach().numpy()), "pred_sample": grad_sample32(pred.detach().numpy(), 4096)}
+    for k, p in net.named_parameters():
+        g = p.grad.detach().numpy()
+        out[f"g_chk/{k}"] = checks(g)
+        out[f"g/{k}"] = grad_sample32(g)
+    opt.step()
+    for k, p in net.named_parameters():
+        out[f"w/{k}"] = grad_sample32(p.detach().numpy())
+    print(f"train step nf=32: loss {float(loss):.6f}, {sum(p.numel() for p in net.parameters())} parameters")
+    save("train32", **out)
+
+
 def small_bias_grids():
     """A reduced (x, sigma) grid with the structure of the shipped one (linear head + log tail; utils/isp_algos.py:168-177)."""
     x_lut = np.concatenate((np.linspace(0, 2 ** -4, 4, endpoint=False), np.exp(np.linspace(np.log(2 ** -4), np.log(2 ** 10), 57))))
@@ -565,7 +609,7 @@ def gen_train_sched(ref):
 
 GENS = dict(rot=gen_rot, pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
             vst_denoiser=gen_vst_denoiser, iter=gen_iter, biaslut=gen_biaslut, ssim=gen_ssim, nle_full=gen_nle_full,
-            iter_full=gen_iter_full, train=gen_train, train_sched=gen_train_sched)
+            iter_full=gen_iter_full, train=gen_train, train_sched=gen_train_sched, train32=gen_train32)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

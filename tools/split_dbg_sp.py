@@ -5,7 +5,7 @@ workgroup 0, waves 0 and 4, for conv1 (register-staged input, split-plane store:
 import ctypes as C, os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-DBG = os.path.join(HERE, "probe", "libyond_sdbg.so")
+DBG = os.environ.get("SDBG_LIB", os.path.join(HERE, "probe", "libyond_sdbg.so"))      # (SDBG_LIB: another debug build, e.g. -DYOND_SPLIT_ASYM=0)
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     from yond_public_amd.build import build_lib
     print(build_lib(extra_flags=["-DSPLIT_DBG=1"], lib=DBG))
@@ -32,12 +32,15 @@ def show(reader, title):
     t = buf.astype(np.int64)
     print(title)
     for wv in range(2):
-        print(" wave", wv * 4, ": step | head  mfma-stretch (quarters)  barrier  tail | total")
+        print(" wave", wv * 4, ": step | head  mfma-stretch (quarters)  post(staging/epilogue)  barrier  tail | total")
+        tot = []
         for sidx in range(2, 26):
             r = t[wv, sidx]; nxt = t[wv, sidx + 1][0]
             epi = "   epilogue %d + barrier %d" % (r[6] - r[4], r[7] - r[6]) if r[6] > r[4] and r[5] - r[4] > 600 else ""
-            print("   %3d | %5d  %6d (%5d %5d %5d %5d)  %5d  %5d | %6d%s" % (sidx, r[1] - r[0], r[2] - r[1], r[8] - r[1], r[9] - r[8], r[10] - r[9],
-                  r[2] - r[10], r[4] - r[2], r[5] - r[4], nxt - r[0], epi))
+            tot.append(nxt - r[0])
+            print("   %3d | %5d  %6d (%5d %5d %5d %5d)  %5d  %5d  %5d | %6d%s" % (sidx, r[1] - r[0], r[2] - r[1], r[8] - r[1], r[9] - r[8], r[10] - r[9],
+                  r[2] - r[10], r[3] - r[2], r[4] - r[3], r[5] - r[4], nxt - r[0], epi))
+        print("   mean cycles per step: %.0f" % (sum(tot) / len(tot)))
 
 
 for _ in range(3):

@@ -40,17 +40,18 @@ def log(string, log=None, notime=False):
 
 class SyntheticSIDD:
     """Stand-in for SIDD_Dataset (data_process/yond_datasets.py:767-868): items with 'lr', 'hr' of shape
-    (32, 256, 256), 'lr_full' (the frame used for the round-1 estimate), 'name'."""
+    (32, 256, 256), 'lr_full' (the frame used for the round-1 estimate: 3000 x 5328, the size SURVEY 8d names for the
+    stand-ins of the SIDD full frames), 'name'."""
 
-    def __init__(self, n=8, K=4.0, sigma=6.0):
-        self.n, self.K, self.sigma = n, K, sigma
+    def __init__(self, n=40, K=4.0, sigma=6.0, full_hw=(3000, 5328)):
+        self.n, self.K, self.sigma, self.full_hw = n, K, sigma, full_hw
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, k):
         noisy, clean = S.synth_noisy(256, 8192, self.K, self.sigma, 100 + k)
-        full, _ = S.synth_noisy(1024, 1536, self.K, self.sigma, 500 + k)
+        full, _ = S.synth_noisy(self.full_hw[0], self.full_hw[1], self.K, self.sigma, 500 + k)
         return {'lr': np.array(np.split(noisy, 32, axis=-1)), 'hr': np.array(np.split(clean, 32, axis=-1)),
                 'lr_full': full, 'name': f'synthetic_{k:03d}', 'meta': None, 'cfa': 'rggb'}
 
@@ -241,7 +242,8 @@ class YONDParser:
         a.add_argument('--nofig', action='store_true', default=True, help="don't save plots (no sRGB rendering in this build)")
         a.add_argument('--nohost', action='store_true', default=False)
         a.add_argument('--gpu', default="0", help="kept for CLI compatibility; ranks pick their device from LOCAL_RANK")
-        a.add_argument('--synthetic', type=int, default=8, help="number of synthetic stand-in images when no dataset is found")
+        a.add_argument('--synthetic', type=int, default=40, help="number of synthetic stand-in images when no dataset is found "
+                       "(40 = the SIDD validation set's size; each with a 3000 x 5328 frame for the round-1 estimate)")
         a.add_argument('--verbose', action='store_true', default=False)
         return a.parse_args(args)
 

@@ -17,7 +17,7 @@ def env_world():
 
 # collectives this process has issued through this module (tests and bench.py report it: a one-rank torchrun job
 # exercises the same RCCL calls as an eight-rank one)
-STATS = {"all_reduce": 0, "barrier": 0, "broadcast": 0, "grad_all_reduce": 0, "grad_bytes": 0, "backend": None}
+STATS = {"all_reduce": 0, "all_gather": 0, "barrier": 0, "broadcast": 0, "grad_all_reduce": 0, "grad_bytes": 0, "backend": None}
 
 
 def launched_by_torchrun():
@@ -119,6 +119,24 @@ def max_over_ranks(x, device=None):
         STATS["all_reduce"] += 1
         return float(t.item())
     return float(x)
+
+
+def gather_over_ranks(x, device=None):
+    """Every rank's value of the scalar x, in rank order (all_gather; [x] without a process group)."""
+    if _active():
+        t = torch.tensor([x], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        STATS["all_gather"] = STATS.get("all_gather", 0) + 1
+        return [float(o.item()) for o in out]
+    return [float(x)]
+
+
+def group_world_size():
+    """World size the process group itself reports (None without one): what bench.py checks against --gpus."""
+    return dist.get_world_size() if _active() else None
 
 
 class GradReducer:

@@ -36,6 +36,10 @@ def _plan(dev):
     plan.lib, plan.dev = L.load(), torch.device(dev)
     plan.arena = None                # TrainStep: every parameter in one flat device buffer, element 0 a constant zero
     plan.wcache = {}                 # (parameter, role, shape) -> packed-layout constants (_Packing), built once
+    # range guard of the split-operand kernels (bit 0: a staged activation / gradient, bit 1 here: a weight left fp16's range):
+    # word 0 is what the convolution launches and the weight packer report into; TrainStep reads it once per step
+    plan.status = torch.zeros(4, dtype=torch.int32, device=plan.dev)
+    plan.status_slot = 0
     return plan
 
 
@@ -69,6 +73,7 @@ class _Packing:
         if self.split_tn:
             oid = torch.from_numpy(self.pc._wp.reshape(-1)).round().long()
             self.omap = torch.where(oid > 0, oid - 1 + base, torch.zeros_like(oid)).to(plan.dev)
+        self.status = plan.status[1:2] if getattr(plan, 'status', None) is not None else None    # (word 1: weights out of range)
         self.bmap = None
         if b is not None:
             bb = (b.data_ptr() - arena.data_ptr()) // 4
@@ -90,8 +95,9 @@ class _Packing:
         if self.split_tn:
             wp = gathered(self.omap)
             packed = torch.empty_like(wp)
+            st = getattr(self, 'status', None)
             L.check(lib.yond_pack_conv_split_weight_dev_f32(L.ptr(wp), self.pc.gemm_n, self.pc.cinp, self.pc.ksize, self.split_tn, 2,
-                                                            L.ptr(packed), None, L.stream()), "yond_pack_conv_split_weight_dev_f32")
+                                                            L.ptr(packed), L.ptr(st), L.stream()), "yond_pack_conv_split_weight_dev_f32")
             self.pc._packed[('split', 2)] = (self.split_tn, packed)
         else:
             self.pc._packed[self.key] = gathered(self.wmap)
@@ -313,10 +319,16 @@ class _ConvT2x2(torch.autograd.Function):
 class TrainStep:
     """One optimisation step of a yond_public_amd.archs.GuidedResUnet or UNetSeeInDark (parameter names / shapes of the reference)."""
 
-    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, charbonnier=False, ddp=None, conv='split'):
+    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, charbonnier=False, ddp=None, conv='split', loss_scale=None):
         """conv: 'split' -- forward and data-gradient 3x3 convolutions as fp32-accurate split-operand products on the fp16 matrix
         cores (the inference path's kernels; 22-bit operands, fp32 accumulation); 'fp32' -- every convolution on the fp32-input
-        MFMA kernels (exact fp32 products).  charbonnier: Unet_Loss(charbonnier=True) (losses/base_loss.py:82-85).  ddp: None -- average the gradients over the
+        MFMA kernels (exact fp32 products).
+        loss_scale: the split-operand kernels stage every operand as two fp16 halves, which is fp32-accurate only while the
+        operand is in fp16's NORMAL range (|a| >= 6.1e-5); the back-propagated values of a mean loss over n = 4.2 M elements
+        (the reference's batch: dpred = +-1/n = 2.4e-7) are far below it.  So dpred is multiplied by a power of two S before
+        backward() and the flat gradient by 1/S before the reduction and Adam -- both exact in float32; None: S = the power of
+        two that puts S/n into (1/16, 1/8]; 1: no scaling.  A gradient or activation that leaves fp16's range (|a| > 65504)
+        is reported by the kernels' status word, read once per step: the step is redone at S/256, twice at most.  charbonnier: Unet_Loss(charbonnier=True) (losses/base_loss.py:82-85).  ddp: None -- average the gradients over the
         ranks whenever a process group exists (the reference wraps the net in DDP whenever it sees more than one GPU,
         trainer_AWGN.py:59-61); False -- never."""
         from . import distributed as D
@@ -326,6 +338,7 @@ class TrainStep:
         if conv not in ('split', 'fp32'):
             raise ValueError(f"conv must be 'split' or 'fp32', got {conv!r}")
         self.plan.train_conv = conv
+        self.loss_scale = loss_scale
         self.lr, self.betas, self.eps = lr, betas, eps
         self.charbonnier = bool(charbonnier)
         self.params = dict(module.named_parameters())
@@ -463,14 +476,19 @@ class TrainStep:
         plan.wbatch = (self._wb_buf, self._wb_slots)
 
     # -- loss, backward, Adam ----------------------------------------------------------------------------------------
-    def step(self, imgs_lr, imgs_hr, sigma=None):
-        """trainer_AWGN.py:101-117 for one batch (`pred = net(imgs_lr, sigma)` for a guided net, `net(imgs_lr)` otherwise).
-        Returns (loss, {name: gradient})."""
+    def _scale_for(self, n):
+        if self.loss_scale is not None:
+            return float(self.loss_scale)
+        return 2.0 ** (math.ceil(math.log2(max(n, 1))) - 3) if self.plan.train_conv == 'split' else 1.0
+
+    def _fwd_bwd(self, imgs_lr, imgs_hr, sigma, S):
+        """Forward, loss, backward with dpred scaled by S.  Returns (pred, loss sum [1] float64 on the device)."""
         lib = self.plan.lib
         for p in self.params.values():
             p.grad = None
         if self.reducer is not None:
             self.reducer.begin()
+        self.plan.status.zero_()
         self._gather_weights()
         pred = self.forward(imgs_lr, sigma).contiguous()
         tgt = imgs_hr.contiguous()
@@ -481,21 +499,56 @@ class TrainStep:
                     "yond_charbonnier_loss_f32")
         else:
             L.check(lib.yond_l1_loss_f32(L.ptr(pred), L.ptr(tgt), pred.numel(), L.ptr(loss_sum), L.ptr(dpred), L.stream()), "yond_l1_loss_f32")
-        self.last_pred = pred.detach()                       # the trainer's running PSNR (trainer_AWGN.py:120-124)
+        if S != 1.0:
+            dpred.mul_(S)                                    # (a power of two: exact)
         pred.backward(dpred)                                 # (the reducer's hooks launch a bucket's all-reduce as its last gradient lands)
+        return pred, loss_sum
+
+    # -- loss, backward, Adam ----------------------------------------------------------------------------------------
+    def step(self, imgs_lr, imgs_hr, sigma=None):
+        """trainer_AWGN.py:101-117 for one batch (`pred = net(imgs_lr, sigma)` for a guided net, `net(imgs_lr)` otherwise).
+        Returns (loss, {name: gradient})."""
+        lib = self.plan.lib
+        n_out = imgs_hr.numel()
+        S = self._scale_for(n_out)
+        for attempt in range(3):
+            pred, loss_sum = self._fwd_bwd(imgs_lr, imgs_hr, sigma, S)
+            if self.reducer is not None:
+                # every rank must take the same branch below (a retry re-issues the gradient all-reduces): the ranks' words OR-ed
+                import torch.distributed as dist
+                dist.all_reduce(self.plan.status, op=dist.ReduceOp.MAX)
+            st = self.plan.status.cpu()                      # ONE read per step (it also is the step's synchronisation point)
+            if int(st[1]) & 1:
+                raise L.YondHipError("TrainStep: a weight left fp16's range (|w| > 65504): the split-operand kernels cannot take it "
+                                     "(TrainStep(conv='fp32') keeps every convolution on the fp32-input MFMA)")
+            if not (int(st[0]) & 1):
+                break
+            if attempt == 2 or S == 1.0 and self.loss_scale is not None:
+                raise L.YondHipError("TrainStep: an activation or gradient left fp16's range (|a| > 65504) in the split-operand "
+                                     f"convolutions (loss scale {S:g}); TrainStep(conv='fp32') has no such limit")
+            if self.reducer is not None:
+                self.reducer.finish()                        # (drain the all-reduces of the abandoned attempt)
+            S = max(S / 256.0, 1.0)                          # a gradient overflowed at this scale: redo the step lower
+        self.last_scale = S
+        self.last_pred = pred.detach()                       # the trainer's running PSNR (trainer_AWGN.py:120-124)
         if self.reducer is not None:
             self.reducer.finish()                            # .grad = the mean over the ranks
         self.t += 1
         zero = self.arena.new_zeros(1)
         flat = torch.cat([zero] + [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params.values()])
+        if S != 1.0:
+            flat.mul_(1.0 / S)                               # exact
         grads = {k: flat[o:o + c].view(self.params[k].shape) for k, (o, c) in self.slots.items()}
         if self.params[next(iter(self.params))].data_ptr() != self.arena.data_ptr() + 4:
             raise L.YondHipError("TrainStep: the module's parameters were moved (.to / .float) after the step object was built")
+        loss = float(loss_sum.item()) / pred.numel()
+        if not math.isfinite(loss):
+            raise L.YondHipError(f"TrainStep: the loss is {loss}: no update applied")
         L.check(lib.yond_adam_step_f32(L.ptr(self.arena), L.ptr(flat), L.ptr(self.adam_m), L.ptr(self.adam_v), self.arena.numel(),
                                        self.lr, self.betas[0], self.betas[1], self.eps, self.t, L.stream()), "yond_adam_step_f32")
         self.plan.wbatch = None                              # (the gathered weights are those of before this update)
         self.m._plan = None                                  # the inference plan's packed weights are stale now
-        return float(loss_sum.item()) / pred.numel(), grads
+        return loss, grads
 
 
 # -- learning-rate schedule (trainer_base.py:34-46, 138-167) -------------------------------------------------------------

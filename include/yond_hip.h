@@ -26,7 +26,7 @@ extern "C" {
 #define YOND_EUNSUPPORTED (-2) /* valid request the kernels do not cover (e.g. channel count) */
 
 /* Library / device probe.  Returns the ABI version (this header: YOND_ABI_VERSION; the loader refuses a mismatch). */
-#define YOND_ABI_VERSION 5
+#define YOND_ABI_VERSION 6
 int yond_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -445,6 +445,13 @@ int yond_conv_wgrad_f32(const float* x, const float* dy, int N, int H, int W, in
 size_t yond_conv_wgrad_ws_bytes(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride);
 int yond_conv_wgrad_ws_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride,
                            float* dw, float* ws, size_t ws_bytes, void* stream);
+/* The weight gradient of a 3x3 stride-1 pad-1 layer on the fp16 matrix cores with fp32-accurate split operands (csrc/wgrad_split.hip;
+ * the pixel axis is the MFMA's K axis, both tensors staged as fp16 halves and read transposed from LDS).  dw as above
+ * ([9][Cout][Cin]); needs |dy| < 32 (bit 0 of *status is set otherwise: TrainStep's loss scale keeps it there).
+ * yond_conv_wgrad_split_ws_bytes returns 0 for a layer the kernel does not take (the caller keeps yond_conv_wgrad_ws_f32). */
+size_t yond_conv_wgrad_split_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, float* dw, float* ws,
+                              size_t ws_bytes, int* status, void* stream);
 int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, void* stream);
 /* The guided block's middle (archs/modules.py:186-196) for training: out = SiLU(z * tk[n][c] + tb[n][c]) over z [N][P][C] with
  * per-image vectors tk, tb [N][C], and its backward in one pass: dz, dtk[n][c] = sum_p g z, dtb[n][c] = sum_p g with

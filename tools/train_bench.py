@@ -64,4 +64,4 @@ ms = (time.perf_counter() - t0) / a.steps * 1e3
 fl = conv_flops(net, a.batch, 128, 128)
 print(json.dumps({"net": a.net, "nf": a.nf, "conv": a.conv, "batch": a.batch, "ms_per_step": round(ms, 3), "patches_per_s": round(a.batch / ms * 1e3, 1),
                   "bayer_mp_per_s": round(a.batch * 256 * 256 / ms / 1e3, 1), "fwd_conv_gflop": round(fl / 1e9, 1),
-                  "step_tflops_nominal": round(3 * fl / ms / 1e9, 1), "loss": loss}))
+                  "step_tflops_nominal": round(3 * fl / ms / 1e9, 1), "loss": loss, "loss_scale": getattr(ts, 'last_scale', None)}))

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOND_HIP_LIB", os.path.join(_HERE, "libyond_hip.so"))   # override: experiments only
 _lib = None
-ABI_VERSION = 5                     # include/yond_hip.h YOND_ABI_VERSION
+ABI_VERSION = 6                     # include/yond_hip.h YOND_ABI_VERSION
 
 vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 
@@ -85,6 +85,8 @@ PROTOTYPES = {
     "yond_conv_wgrad_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "yond_conv_wgrad_ws_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp],
     "yond_conv_wgrad_ws_bytes": [i32, i32, i32, i32, i32, i32, i32, i32, i32],
+    "yond_conv_wgrad_split_ws_bytes": [i32, i32, i32, i32, i32],
+    "yond_conv_wgrad_split_f32": [vp, vp, i32, i32, i32, i32, i32, vp, vp, sz, vp, vp],
     "yond_colsum_f32": [vp, sz, i32, vp, vp],
     "yond_film_silu_supported": [i32],
     "yond_film_silu_f32": [vp, vp, vp, vp, i32, sz, i32, vp],
@@ -109,7 +111,7 @@ EXPERIMENT_PROTOTYPES = {
     "yond_box_stats_collab_fused_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
 }
 _SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes", "yond_lut_ws_bytes", "yond_bias_lut_big_scratch", "yond_bias_points_scratch",
-               "yond_conv_wgrad_ws_bytes"}
+               "yond_conv_wgrad_ws_bytes", "yond_conv_wgrad_split_ws_bytes"}
 
 
 class YondHipError(RuntimeError):

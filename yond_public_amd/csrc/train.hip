@@ -301,6 +301,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     else dw[i] = v;
 }
 
+// (wgrad_split.hip: the split-operand weight-gradient kernel stores slices of the same form)
+int yond_wgrad_reduce_launch(const float* ws, int nchunk, size_t n, float* dw, hipStream_t st) {
+    const unsigned nbx = (unsigned)((n + 255) / 256);
+    long long S = 1024 / (long long)nbx;                        // about one round of workgroups
+    if (S > nchunk / 4) S = nchunk / 4;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    if (S > 1) {
+        hipError_t e = hipMemsetAsync(dw, 0, n * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nbx, (unsigned)S), dim3(256), 0, st, ws, nchunk, n, dw);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
 // chunk (K-space rows per wave) and workgroup chunks of a launch
 template <int MODE, int NCO>
 static void wgrad_split(const WgradGeom& g, long long& chunk, long long& wgchunks) {

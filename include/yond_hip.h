@@ -455,11 +455,21 @@ int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N, int H, int
 int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, void* stream);
 /* The guided block's middle (archs/modules.py:186-196) for training: out = SiLU(z * tk[n][c] + tb[n][c]) over z [N][P][C] with
  * per-image vectors tk, tb [N][C], and its backward in one pass: dz, dtk[n][c] = sum_p g z, dtb[n][c] = sum_p g with
- * g = dout * SiLU'(z tk + tb).  C in {32, 64, 128, 256} (yond_film_silu_supported); other widths stay with the caller. */
+ * g = dout * SiLU'(z tk + tb).  C in {32, 64, 128, 256, 512, 1024} (yond_film_silu_supported); other widths stay with the caller. */
 int yond_film_silu_supported(int C);
 int yond_film_silu_f32(const float* z, const float* tk, const float* tb, float* out, int N, size_t P, int C, void* stream);
 int yond_film_silu_bwd_f32(const float* z, const float* tk, const float* tb, const float* dout, float* dz, float* dtk, float* dtb, int N,
                            size_t P, int C, void* stream);
+/* The sigma-conditioning MLPs of a guided block for training (archs/modules.py:170-178): a = t w1 + b1, h = SiLU(a), tk = W2 h + b2,
+ * tb = W3 SiLU(tk) + b3 for t [B]; w1, b1, b2, b3 [C]; W2, W3 [C][C] (Conv2d 1x1 weights).  fwd writes tk, tb at row stride ld >= C
+ * (zero beyond C).  bwd: from the gradients dtk, dtb (row stride ld) the parameter gradients; scratch
+ * 2 B C floats.  yond_silu_bwd_add_f32: dx = dres + dz SiLU'(x) (a residual block's input gradient in one pass). */
+int yond_film_mlp_fwd_f32(const float* t, const float* w1, const float* b1, const float* W2, const float* b2, const float* W3,
+                          const float* b3, int B, int C, int ld, float* tk, float* tb, void* stream);
+int yond_film_mlp_bwd_f32(const float* t, const float* w1, const float* b1, const float* W2, const float* W3, const float* tk,
+                          const float* dtk, const float* dtb, int B, int C, int ld, float* scratch, float* dw1, float* db1,
+                          float* dW2, float* db2, float* dW3, float* db3, void* stream);
+int yond_silu_bwd_add_f32(const float* x, const float* dz, const float* dres, float* dx, size_t n, void* stream);
 int yond_l1_loss_f32(const float* pred, const float* target, size_t n, double* loss_sum, float* grad /* or NULL */, void* stream);
 /* L1_Charbonnier_loss (losses/base_loss.py:69-79; Unet_Loss(charbonnier=True), :82-85): loss_sum = sum sqrt(diff^2 + eps),
  * grad = diff / sqrt(diff^2 + eps) / n in the float32 steps of torch's backward */

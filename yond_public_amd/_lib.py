@@ -91,6 +91,9 @@ PROTOTYPES = {
     "yond_film_silu_supported": [i32],
     "yond_film_silu_f32": [vp, vp, vp, vp, i32, sz, i32, vp],
     "yond_film_silu_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, i32, sz, i32, vp],
+    "yond_film_mlp_fwd_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
+    "yond_film_mlp_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "yond_silu_bwd_add_f32": [vp, vp, vp, vp, sz, vp],
     "yond_l1_loss_f32": [vp, vp, sz, vp, vp, vp],
     "yond_charbonnier_loss_f32": [vp, vp, sz, f64, vp, vp, vp],
     "yond_adam_step_f32": [vp, vp, vp, vp, sz, f64, f64, f64, f64, i32, vp],

@@ -515,18 +515,18 @@ __global__ __launch_bounds__(256) void film_silu_bwd_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 4; ++e) { sk[threadIdx.x][e] = ak[e]; sb[threadIdx.x][e] = ab[e]; }
     __syncthreads();
-    if (threadIdx.x < C) {                                             // thread = channel: add the ppw pixel rows
-        const int t = threadIdx.x >> 2, e = threadIdx.x & 3;
+    for (int ch = threadIdx.x; ch < C; ch += 256) {                    // thread = channel: add the ppw pixel rows
+        const int t = ch >> 2, e = ch & 3;
         float a = 0.0f, c = 0.0f;
         for (int r = 0; r < ppw; ++r) { a += sk[r * c4 + t][e]; c += sb[r * c4 + t][e]; }
-        atomicAdd(dtk + (size_t)n * C + threadIdx.x, a);
-        atomicAdd(dtb + (size_t)n * C + threadIdx.x, c);
+        atomicAdd(dtk + (size_t)n * C + ch, a);
+        atomicAdd(dtb + (size_t)n * C + ch, c);
     }
 }
 
-static bool film_silu_shape_ok(int N, long long P, int C) { return N > 0 && P > 0 && C >= 32 && C <= 256 && C % 32 == 0 && 256 % (C / 4) == 0; }
+static bool film_silu_shape_ok(int N, long long P, int C) { return N > 0 && P > 0 && C >= 32 && C <= 1024 && C % 32 == 0 && 256 % (C / 4) == 0; }
 
-// 1 when the fused kernels take this channel count (32, 64, 128, 256), else 0 (the caller keeps its elementwise form)
+// 1 when the fused kernels take this channel count (32, 64, 128, 256, 512, 1024), else 0 (the caller keeps its elementwise form)
 extern "C" int yond_film_silu_supported(int C) { return film_silu_shape_ok(1, 1, C) ? 1 : 0; }
 
 extern "C" int yond_film_silu_f32(const float* z, const float* tk, const float* tb, float* out, int N, size_t P, int C, void* stream) {
@@ -549,6 +549,177 @@ extern "C" int yond_film_silu_bwd_f32(const float* z, const float* tk, const flo
     size_t nb = (P + (size_t)ppw * 8 - 1) / ((size_t)ppw * 8);
     if (nb > 2048 / (size_t)N + 1) nb = 2048 / (size_t)N + 1;
     hipLaunchKernelGGL(film_silu_bwd_kernel, dim3((unsigned)nb, (unsigned)N), dim3(256), 0, st, z, tk, tb, dout, dz, dtk, dtb, (long long)P, C);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// ---- the sigma-conditioning of a guided block for training (archs/modules.py:170-178, 186-196) ------------------------------------
+//   gamma: Conv2d(1, C, 1) -> SiLU -> Conv2d(C, C, 1);  beta: SiLU -> Conv2d(C, C, 1), applied to t [B][1][1][1]:
+//   a = t w1 + b1, h = SiLU(a), tk = W2 h + b2, s = SiLU(tk), tb = W3 s + b3          (three tiny linear layers per block)
+// torch.autograd ran them as ~8 broadcast / reduce kernels forward and ~16 backward per block over [B][C][C] temporaries (67 MB at
+// C = 512): 1.2 ms of a 16 ms step.  Here they are six small matrix products (M, N <= 512, K <= 512) on one LDS-tiled kernel with
+// the element functions (SiLU of the operand, SiLU' in the epilogue) folded in: two launches forward, five backward.  (A first
+// version with a workgroup per batch item and a wave per output row was latency bound: 430 us per call.)  tk / tb are written at
+// row stride ld >= C, zero beyond C (channel padding).
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float dsilu_f(float u) {
+    const float s = 1.0f / (1.0f + expf(-u));
+    return s * (1.0f + u * (1.0f - s));
+}
+
+// One tile kernel for the six small products of the MLPs: out[m][n] = sum_k A(m, k) B(k, n), 16 x 16 outputs per workgroup
+// (thread = one output), K in chunks of 64 through LDS; the operands' element functions and the epilogue are chosen by MODE:
+//   0  tk[b][j]      = sum_k SiLU(t_b w1_k + b1_k) W2[j][k] + b2[j]                     (M = B, N = C, K = C)
+//   1  tb[b][j]      = sum_k SiLU(tk[b][k])        W3[j][k] + b3[j]
+//   2  dtk_tot[b][k] = dtk[b][k] + SiLU'(tk[b][k]) sum_j dtb[b][j] W3[j][k]
+//   3  da[b][k]      = SiLU'(t_b w1_k + b1_k)      sum_j dtk_tot[b][j] W2[j][k]
+//   4  dW3[j][k]     = sum_b dtb[b][j] SiLU(tk[b][k])                                    (M = C, N = C, K = B)
+//   5  dW2[j][k]     = sum_b dtk_tot[b][j] SiLU(t_b w1_k + b1_k)
+struct FilmMlpArgs {
+    const float *t, *w1, *b1, *W2, *b2, *W3, *b3;     // parameters ([C], [C][C])
+    const float *tk, *dtk, *dtb;                        // [B][ld]
+    const float *dtk_tot;                               // [B][C]
+    float* out;
+    int B, C, ld;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void film_mlp_tile_kernel(const FilmMlpArgs a) {
+    __shared__ float As[16][65], Bs[64][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int M = MODE < 4 ? a.B : a.C, N = a.C, K = MODE < 4 ? a.C : a.B;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    auto hval = [&](int b, int k) { return silu_f(a.t[b] * a.w1[k] + a.b1[k]); };
+    auto A_at = [&](int m, int k) -> float {
+        if (m >= M || k >= K) return 0.0f;
+        if constexpr (MODE == 0) return hval(m, k);
+        if constexpr (MODE == 1) return silu_f(a.tk[(size_t)m * a.ld + k]);
+        if constexpr (MODE == 2) return a.dtb[(size_t)m * a.ld + k];
+        if constexpr (MODE == 3) return a.dtk_tot[(size_t)m * a.C + k];
+        if constexpr (MODE == 4) return a.dtb[(size_t)k * a.ld + m];
+        return a.dtk_tot[(size_t)k * a.C + m];
+    };
+    auto B_at = [&](int k, int n) -> float {
+        if (n >= N || k >= K) return 0.0f;
+        if constexpr (MODE == 0) return a.W2[(size_t)n * a.C + k];
+        if constexpr (MODE == 1) return a.W3[(size_t)n * a.C + k];
+        if constexpr (MODE == 2) return a.W3[(size_t)k * a.C + n];
+        if constexpr (MODE == 3) return a.W2[(size_t)k * a.C + n];
+        if constexpr (MODE == 4) return silu_f(a.tk[(size_t)k * a.ld + n]);
+        return hval(k, n);
+    };
+    float acc = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = threadIdx.x + e * 256;
+            // A chunk [16 m][64 k]: consecutive threads along k for the row-major operands (modes 0-3), along m for the batch-major ones
+            if constexpr (MODE < 4) As[i >> 6][i & 63] = A_at(m0 + (i >> 6), k0 + (i & 63));
+            else As[i & 15][i >> 4] = A_at(m0 + (i & 15), k0 + (i >> 4));
+            // B chunk [64 k][16 n]: W[n][k] (modes 0, 1) is contiguous along k, the others along n
+            if constexpr (MODE < 2) Bs[i & 63][i >> 6] = B_at(k0 + (i & 63), n0 + (i >> 6));
+            else Bs[i >> 4][i & 15] = B_at(k0 + (i >> 4), n0 + (i & 15));
+        }
+        __syncthreads();
+#pragma unroll 16
+        for (int k = 0; k < 64; ++k) acc += As[ty][k] * Bs[k][tx];
+        __syncthreads();
+    }
+    const int m = m0 + ty, n = n0 + tx;
+    if (m >= M || n >= N) return;
+    if constexpr (MODE == 0) a.out[(size_t)m * a.ld + n] = acc + a.b2[n];
+    else if constexpr (MODE == 1) a.out[(size_t)m * a.ld + n] = acc + a.b3[n];
+    else if constexpr (MODE == 2) a.out[(size_t)m * a.C + n] = a.dtk[(size_t)m * a.ld + n] + acc * dsilu_f(a.tk[(size_t)m * a.ld + n]);
+    else if constexpr (MODE == 3) a.out[(size_t)m * a.C + n] = acc * dsilu_f(a.t[m] * a.w1[n] + a.b1[n]);
+    else a.out[(size_t)m * a.C + n] = acc;
+}
+
+// the five parameter vectors' gradients (sums over the batch) and the zero padding of tk / tb rows
+__global__ __launch_bounds__(256) void film_mlp_vec_kernel(const float* __restrict__ t, const float* __restrict__ dtb, const float* __restrict__ dtk_tot,
+                                                           const float* __restrict__ da, int B, int C, int ld, float* __restrict__ db3,
+                                                           float* __restrict__ db2, float* __restrict__ dw1, float* __restrict__ db1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C) return;
+    float s3 = 0.0f, s2 = 0.0f, sw = 0.0f, sb = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        s3 += dtb[(size_t)b * ld + i];
+        s2 += dtk_tot[(size_t)b * C + i];
+        const float d = da[(size_t)b * C + i];
+        sw += d * t[b];
+        sb += d;
+    }
+    db3[i] = s3; db2[i] = s2; dw1[i] = sw; db1[i] = sb;
+}
+__global__ __launch_bounds__(256) void film_mlp_pad_kernel(float* __restrict__ tk, float* __restrict__ tb, int B, int C, int ld) {
+    const int i = blockIdx.x * 256 + threadIdx.x, w = ld - C;
+    if (w <= 0 || i >= B * w) return;
+    const int b = i / w, j = C + i % w;
+    tk[(size_t)b * ld + j] = 0.0f;
+    tb[(size_t)b * ld + j] = 0.0f;
+}
+
+template <int MODE>
+static void film_mlp_launch(const FilmMlpArgs& a, hipStream_t st) {
+    const int M = MODE < 4 ? a.B : a.C;
+    hipLaunchKernelGGL(film_mlp_tile_kernel<MODE>, dim3((unsigned)((a.C + 15) / 16), (unsigned)((M + 15) / 16)), dim3(256), 0, st, a);
+}
+
+extern "C" int yond_film_mlp_fwd_f32(const float* t, const float* w1, const float* b1, const float* W2, const float* b2, const float* W3,
+                                     const float* b3, int B, int C, int ld, float* tk, float* tb, void* stream) {
+    if (!t || !w1 || !b1 || !W2 || !b2 || !W3 || !b3 || !tk || !tb || B <= 0 || C <= 0 || ld < C) return YOND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    FilmMlpArgs a{t, w1, b1, W2, b2, W3, b3, tk, nullptr, nullptr, nullptr, tk, B, C, ld};
+    if (ld > C) hipLaunchKernelGGL(film_mlp_pad_kernel, dim3((unsigned)((B * (ld - C) + 255) / 256)), dim3(256), 0, st, tk, tb, B, C, ld);
+    film_mlp_launch<0>(a, st);
+    a.out = tb;
+    film_mlp_launch<1>(a, st);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// scratch: 2 * B * C floats (dtk_tot, da)
+extern "C" int yond_film_mlp_bwd_f32(const float* t, const float* w1, const float* b1, const float* W2, const float* W3, const float* tk,
+                                     const float* dtk, const float* dtb, int B, int C, int ld, float* scratch, float* dw1, float* db1,
+                                     float* dW2, float* db2, float* dW3, float* db3, void* stream) {
+    if (!t || !w1 || !b1 || !W2 || !W3 || !tk || !dtk || !dtb || !scratch || !dw1 || !db1 || !dW2 || !db2 || !dW3 || !db3 || B <= 0 || C <= 0 ||
+        ld < C)
+        return YOND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float* dtk_tot = scratch;
+    float* da = scratch + (size_t)B * C;
+    FilmMlpArgs a{t, w1, b1, W2, nullptr, W3, nullptr, tk, dtk, dtb, dtk_tot, dtk_tot, B, C, ld};
+    film_mlp_launch<2>(a, st);
+    a.out = da;
+    film_mlp_launch<3>(a, st);
+    a.out = dW3;
+    film_mlp_launch<4>(a, st);
+    a.out = dW2;
+    film_mlp_launch<5>(a, st);
+    hipLaunchKernelGGL(film_mlp_vec_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, t, dtb, dtk_tot, da, B, C, ld, db3, db2, dw1, db1);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// A residual block's input side in backward: dx = dres + dz SiLU'(x) in one pass (the block computes conv1(SiLU(x)) and adds x to its
+// output: autograd ran silu_backward and the accumulation of the two gradients as two kernels over three / three tensors)
+__global__ __launch_bounds__(256) void silu_bwd_add_kernel(const float4* __restrict__ x, const float4* __restrict__ dz, const float4* __restrict__ dres,
+                                                           float4* __restrict__ dx, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 xv = x[i], g = dz[i], r = dres[i];
+        float4 o;
+        o.x = r.x + g.x * dsilu_f(xv.x); o.y = r.y + g.y * dsilu_f(xv.y); o.z = r.z + g.z * dsilu_f(xv.z); o.w = r.w + g.w * dsilu_f(xv.w);
+        dx[i] = o;
+    }
+}
+extern "C" int yond_silu_bwd_add_f32(const float* x, const float* dz, const float* dres, float* dx, size_t n, void* stream) {
+    if (!x || !dz || !dres || !dx || n == 0 || n % 4) return YOND_EINVAL;
+    size_t nb = (n / 4 + 256 * 4 - 1) / (256 * 4);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(silu_bwd_add_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)dz,
+                       (const float4*)dres, (float4*)dx, n / 4);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

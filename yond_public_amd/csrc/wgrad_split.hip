@@ -124,9 +124,9 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
         *(f16x4*)dst_h = h;
         *(f16x4*)dst_l = l;
     };
-    auto x_dst = [&](int tile, int part, int pos, int c4) -> char* { return xr + ((size_t)((tile * 2 + part) * g.ring + pos) * 32 + c4 * 4) * 2; };
+    auto x_dst = [&](int tile, int part, int pos, int c4) -> char* { return xr + (unsigned)(((tile * 2 + part) * g.ring + pos) * 64 + c4 * 8); };
     auto d_dst = [&](int buf, int tile, int part, int o, int c4) -> char* {
-        return dyb + ((size_t)(((buf * PA + tile) * 3 + part) * SK + o) * 32 + c4 * 4) * 2;
+        return dyb + (unsigned)((((buf * PA + tile) * 3 + part) * SK + o) * 64 + c4 * 8);
     };
     auto stage_dy = [&](const f32x4& v, int buf, int tile, int o, int c4) {
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -191,12 +191,14 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
     auto rd = [&](const char* p) -> v4s { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)p); };
     union Frag { v4s s[2]; f16x8 h; };
 
-    int wbase = 0;                                               // ring position of stream index g_s - lead
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        // global loads of the next step (X: the SK pixels in front of the ring; dY: the next batch), consumed behind the MFMAs
-        f32x4 vx[NX], vd[ND];
-        bool okx[NX], okd[ND];
+    // Step s (one barrier): the MFMAs of batch s; the staging of batch s + 1 (X: the SK pixels in front of the ring; dY: the other
+    // buffer) from registers that were loaded during step s - 1; the loads of batch s + 2 into those registers.  The two waves
+    // of a SIMD take these in OPPOSITE order -- waves 4-7 stage and load first and multiply last, waves 0-3 multiply first --
+    // so that one wave's vector / memory work runs under its partner's MFMAs instead of both waves' at the same time.
+    const bool wave_hi = wave >= 4;
+    f32x4 vx[NX], vd[ND];
+    bool okx[NX], okd[ND];
+    auto issue_loads = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             int po, tile, c4;
@@ -213,23 +215,51 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
             if (!(g.abl & 1)) vd[k] = load_raw(g.dy, g.Co, dp[k], (a0 + tile) * 32 + c4 * 4, okd[k]);
             else vd[k] = f32x4{0.5f, 0.25f, -0.5f, 1.0f};
         }
+    };
+    issue_loads();                                               // batch 1 (staged during step 0)
+    int wbase = 0;                                               // ring position of stream index g_s - lead
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        auto stage_and_load = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                int po, tile, c4;
+                x_item(tid + k * C::NT, po, tile, c4);
+                if (!(g.abl & 4)) split_x(masked(vx[k], okx[k]), x_dst(tile, 0, xpos[k], c4), x_dst(tile, 1, xpos[k], c4));
+                xpos[k] += SK;
+                xpos[k] -= xpos[k] >= g.ring ? g.ring : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                int po, tile, c4;
+                d_item(tid + k * C::NT, po, tile, c4);
+                if (!(g.abl & 4)) stage_dy(masked(vd[k], okd[k]), buf ^ 1, tile, po, c4);
+            }
+            // (the cursors behind the consumers: their carry loops are branches)
+#pragma unroll
+            for (int k = 0; k < NX; ++k) stream_advance(xp[k], SK, g.W2, g.H2);
+#pragma unroll
+            for (int k = 0; k < ND; ++k) stream_advance(dp[k], SK, g.W2, g.H2);
+            issue_loads();
+        };
+        if (wave_hi) stage_and_load();
         // ---- the step's products ----
-        // Software pipeline over (K step, kernel row): the fragments of the NEXT kernel row (and, at a K step's last row, the
-        // next K step's dY fragments) are requested before the nine MFMAs of the current row are issued, and those nine go
-        // tap-interleaved (three accumulators in turn), so neither an LDS latency nor a dependent accumulator sits in front of
-        // an MFMA.  (Scheduling fences keep the compiler from moving the reads back behind the MFMAs.)
+        // Software pipeline over (K step, kernel row): the fragments of the NEXT kernel row are requested before the nine MFMAs
+        // of the current row are issued, and those nine go tap-interleaved (three accumulators in turn), so neither an LDS
+        // latency nor a dependent accumulator sits in front of an MFMA.  (Scheduling fences keep the reads where they are.)
         Frag A[1][3], Bh[2][3], Bl[2][3];                         // (one set of dY fragments: a second one spills)
+        const unsigned abase = (unsigned)((((buf * PA + wa) * 3) * SK + frag_px) * 64) + frag_ch;
         auto load_A = [&](int kp, int set) {
             const int o = 16 * (ks * KPW + kp);                  // first pixel of the wave's K step inside the batch
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                const char* p = dyb + ((size_t)(((buf * PA + wa) * 3 + part) * SK + o + frag_px) * 32) * 2 + frag_ch;
+                const char* p = dyb + abase + (unsigned)((part * SK + o) * 64);
                 A[set][part].s[0] = rd(p);
                 A[set][part].s[1] = rd(p + 4 * 64);
             }
         };
-        const char* const ph = xr + ((size_t)(wb * 2 + 0) * g.ring) * 64 + frag_ch;
-        const char* const pl = xr + ((size_t)(wb * 2 + 1) * g.ring) * 64 + frag_ch;
+        const char* const ph = xr + (unsigned)((wb * 2 + 0) * g.ring * 64) + frag_ch;
+        const char* const pl = xr + (unsigned)((wb * 2 + 1) * g.ring * 64) + frag_ch;
         auto load_B = [&](int kp, int ky, int set) {
             const int o = 16 * (ks * KPW + kp);
             // ring position of the K step's first pixel for tap (ky, 0): stream index g_s + o + (ky - 1) W2 - 1
@@ -237,12 +267,12 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int rel = rel0 + kx, rel1 = rel + 4;
-                const int r0 = rel >= g.ring ? rel - g.ring : rel;
-                const int r1 = rel1 >= g.ring ? rel1 - g.ring : rel1;
-                Bh[set][kx].s[0] = rd(ph + (size_t)r0 * 64);
-                Bh[set][kx].s[1] = rd(ph + (size_t)r1 * 64);
-                Bl[set][kx].s[0] = rd(pl + (size_t)r0 * 64);
-                Bl[set][kx].s[1] = rd(pl + (size_t)r1 * 64);
+                const unsigned r0 = (unsigned)(rel >= g.ring ? rel - g.ring : rel) * 64u;
+                const unsigned r1 = (unsigned)(rel1 >= g.ring ? rel1 - g.ring : rel1) * 64u;
+                Bh[set][kx].s[0] = rd(ph + r0);
+                Bh[set][kx].s[1] = rd(ph + r1);
+                Bl[set][kx].s[0] = rd(pl + r0);
+                Bl[set][kx].s[1] = rd(pl + r1);
             }
         };
         if (!(g.abl & 2)) {
@@ -263,30 +293,12 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
             __builtin_amdgcn_sched_barrier(0);
         });
         }
-        // ---- split and store what was loaded: X in front of the ring, dY into the other buffer; advance the cursors ----
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            int po, tile, c4;
-            x_item(tid + k * C::NT, po, tile, c4);
-            if (!(g.abl & 4)) split_x(masked(vx[k], okx[k]), x_dst(tile, 0, xpos[k], c4), x_dst(tile, 1, xpos[k], c4));
-            xpos[k] += SK;
-            xpos[k] -= xpos[k] >= g.ring ? g.ring : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < ND; ++k) {
-            int po, tile, c4;
-            d_item(tid + k * C::NT, po, tile, c4);
-            if (!(g.abl & 4)) stage_dy(masked(vd[k], okd[k]), buf ^ 1, tile, po, c4);
-        }
-        // (the cursors last: their carry loops are branches, and every load of the step has been consumed by now)
-#pragma unroll
-        for (int k = 0; k < NX; ++k) stream_advance(xp[k], SK, g.W2, g.H2);
-#pragma unroll
-        for (int k = 0; k < ND; ++k) stream_advance(dp[k], SK, g.W2, g.H2);
+        if (!wave_hi) stage_and_load();
         wbase += SK;
         if (wbase >= g.ring) wbase -= g.ring;
         __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the loads of the batches past the end)
     if (g.status && !(amax < 31.9f)) atomicOr(g.status, 1);      // a P part (2^11 dy) left fp16's range
 
     // ---- the workgroup's partial tiles -> ws[slice][tap][Co][Ci] (x 2^-11: the products' common factor) ----

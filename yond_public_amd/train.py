@@ -106,7 +106,7 @@ class _Packing:
         return self.pc
 
 
-def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False, role='fwd', xf=None):
+def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False, role='fwd', xf=None, res=None):
     """One convolution launch with `xf(w)` as its OIHW weights (xf: the re-indexing that turns the parameter into this launch's
     weights -- identity for a forward, flip + transpose for a data gradient; it must work on CPU and device tensors alike)."""
     xf = xf if xf is not None else (lambda t: t)
@@ -125,7 +125,7 @@ def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False, r
         out = torch.empty((N, 2 * H, 2 * W, pc.cout_real_p), dtype=torch.float32, device=plan.dev)
     else:
         out = torch.empty((N, Ho, Wo, pc.coutp), dtype=torch.float32, device=plan.dev)
-    plan._conv(pc, srcs[0], srcs[1] if len(srcs) > 1 else None, N, H, W, out, algo=algo)
+    plan._conv(pc, srcs[0], srcs[1] if len(srcs) > 1 else None, N, H, W, out, algo=algo, res=res)
     return out
 
 
@@ -166,13 +166,15 @@ class _Conv3x3(torch.autograd.Function):
     """nn.Conv2d(cin, cout, 3, stride, 1): x [N][H][W][cin_p] -> [N][Ho][Wo][cout_p]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, plan, stride, need_dx):
+    def forward(ctx, x, w, b, plan, stride, need_dx, res=None):
+        """res: a tensor of the output's shape added in the convolution's epilogue (the residual of a guided block: `z += x`,
+        archs/modules.py:195) -- its gradient is dy itself."""
         N, H, W, _ = x.shape
         cout, cin = w.shape[0], w.shape[1]
         x = x.contiguous()
-        y = _conv_fwd(plan, w, b, 3, stride, [cin], [x], N, H, W)
+        y = _conv_fwd(plan, w, b, 3, stride, [cin], [x], N, H, W, res=None if res is None else res.contiguous())
         ctx.save_for_backward(x, w)
-        ctx.plan, ctx.stride, ctx.need_dx = plan, stride, need_dx
+        ctx.plan, ctx.stride, ctx.need_dx, ctx.has_res = plan, stride, need_dx, res is not None
         return y
 
     @staticmethod
@@ -193,7 +195,7 @@ class _Conv3x3(torch.autograd.Function):
             dx = _conv_fwd(plan, w, None, 3, 1, [cout], [g], N, H, W, role='dgrad',
                            xf=lambda t: t.flip(2, 3).transpose(0, 1).contiguous())          # [cin][cout][2-ky][2-kx]
             dx = _pad_c(dx[..., :cin], cin_p) if dx.shape[-1] != cin_p else dx
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, (dy if ctx.has_res else None)
 
 
 class _Conv3x3Cat(torch.autograd.Function):
@@ -284,6 +286,66 @@ class _FilmSilu(torch.autograd.Function):
         L.check(ctx.plan.lib.yond_film_silu_bwd_f32(L.ptr(z), L.ptr(tk), L.ptr(tb), L.ptr(dout), L.ptr(dz), L.ptr(dtk), L.ptr(dtb), N, H * W, C,
                                                     L.stream()), "yond_film_silu_bwd_f32")
         return dz, dtk, dtb, None
+
+
+class _FilmMLP(torch.autograd.Function):
+    """The sigma-conditioning of a guided block (archs/modules.py:170-178: gamma = Conv2d(1, C, 1) -> SiLU -> Conv2d(C, C, 1),
+    beta = SiLU -> Conv2d(C, C, 1) on t [B][1][1][1]) as ONE kernel forward and two backward (yond_film_mlp_fwd_f32 / _bwd_f32)
+    instead of autograd's ~24 broadcast / reduce launches over [B][C][C] temporaries.  Returns (tk, tb) [B][cp], zero beyond C."""
+
+    @staticmethod
+    def forward(ctx, t, w1, b1, w2, b2, w3, b3, plan, cp):
+        B, C = t.shape[0], w1.shape[0]
+        t = t.contiguous()
+        ws = [p if p.is_contiguous() else p.contiguous() for p in (w1, b1, w2, b2, w3, b3)]
+        tk = torch.empty((B, cp), dtype=torch.float32, device=t.device)
+        tb = torch.empty((B, cp), dtype=torch.float32, device=t.device)
+        L.check(plan.lib.yond_film_mlp_fwd_f32(L.ptr(t), *(L.ptr(p) for p in ws), B, C, cp, L.ptr(tk), L.ptr(tb), L.stream()),
+                "yond_film_mlp_fwd_f32")
+        ctx.save_for_backward(t, ws[0], ws[1], ws[2], ws[4], tk)
+        ctx.plan, ctx.shapes = plan, (w1.shape, w2.shape, w3.shape)
+        return tk, tb
+
+    @staticmethod
+    def backward(ctx, dtk, dtb):
+        t, w1, b1, w2, w3, tk = ctx.saved_tensors
+        B, C = t.shape[0], w1.shape[0]
+        cp = tk.shape[1]
+        dev = t.device
+        dtk = torch.zeros_like(tk) if dtk is None else dtk.contiguous()
+        dtb = torch.zeros_like(tk) if dtb is None else dtb.contiguous()
+        scratch = torch.empty(2 * B * C, dtype=torch.float32, device=dev)
+        dw1, db1, db2, db3 = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+        dW2, dW3 = (torch.empty((C, C), dtype=torch.float32, device=dev) for _ in range(2))
+        L.check(ctx.plan.lib.yond_film_mlp_bwd_f32(L.ptr(t), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(w3), L.ptr(tk), L.ptr(dtk), L.ptr(dtb),
+                                                   B, C, cp, L.ptr(scratch), L.ptr(dw1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.ptr(dW3), L.ptr(db3),
+                                                   L.stream()), "yond_film_mlp_bwd_f32")
+        s1, s2, s3 = ctx.shapes
+        return None, dw1.view(s1), db1, dW2.view(s2), db2, dW3.view(s3), db3, None, None
+
+
+class _SiluRes(torch.autograd.Function):
+    """A guided block's input: returns (SiLU(x), x) -- conv1's operand and the tensor the block adds to its output.  Backward joins
+    the two gradients in one pass, dx = dres + dz SiLU'(x) (yond_silu_bwd_add_f32), where autograd ran silu_backward and then an
+    accumulation kernel."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.plan = plan
+        return F.silu(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dz, dres):
+        x, = ctx.saved_tensors
+        if dz is None or dres is None:
+            g = dres if dz is None else dz * (torch.sigmoid(x) * (1 + x * (1 - torch.sigmoid(x))))
+            return g, None
+        dz, dres = dz.contiguous(), dres.contiguous()
+        dx = torch.empty_like(x)
+        L.check(ctx.plan.lib.yond_silu_bwd_add_f32(L.ptr(x), L.ptr(dz), L.ptr(dres), L.ptr(dx), x.numel(), L.stream()), "yond_silu_bwd_add_f32")
+        return dx, None
 
 
 def ctx_splits(w, x0, x1):
@@ -382,22 +444,17 @@ class TrainStep:
         if xs is not None:                                   # decoder: short_cut = 1x1 over cat(up, skip)
             x = _Conv1x1.apply(x, xs, P[pre + '.short_cut.0.weight'], P[pre + '.short_cut.0.bias'], self.plan)
         c = P[pre + '.conv1.weight'].shape[0]
-        # gamma / beta: 1x1 convolutions on a (B, 1, 1, 1) tensor = three tiny linear layers (archs/modules.py:170-178)
-        w1, b1 = P[pre + '.gamma.0.weight'][:, 0, 0, 0], P[pre + '.gamma.0.bias']
-        w2, b2 = P[pre + '.gamma.2.weight'][:, :, 0, 0], P[pre + '.gamma.2.bias']
-        w3, b3 = P[pre + '.beta.1.weight'][:, :, 0, 0], P[pre + '.beta.1.bias']
-        h = F.silu(t[:, None] * w1[None] + b1[None])                              # [B][C]
-        tk = (h[:, None, :] * w2[None]).sum(-1) + b2[None]
-        tb = (F.silu(tk)[:, None, :] * w3[None]).sum(-1) + b3[None]
-        tk, tb = _pad_c(tk, cp), _pad_c(tb, cp)
-        z = F.silu(x)
+        # gamma / beta: 1x1 convolutions on a (B, 1, 1, 1) tensor = three tiny linear layers (archs/modules.py:170-178), one kernel
+        tk, tb = _FilmMLP.apply(t, P[pre + '.gamma.0.weight'], P[pre + '.gamma.0.bias'], P[pre + '.gamma.2.weight'], P[pre + '.gamma.2.bias'],
+                                P[pre + '.beta.1.weight'], P[pre + '.beta.1.bias'], self.plan, cp)
+        z, xr = _SiluRes.apply(x, self.plan)                 # SiLU(x) for conv1, x itself for the residual (gradients joined in one pass)
         z = _Conv3x3.apply(z, P[pre + '.conv1.weight'], P[pre + '.conv1.bias'], self.plan, 1, True)
         if self.plan.lib.yond_film_silu_supported(cp):
             z = _FilmSilu.apply(z, tk, tb, self.plan)
-        else:                                                # (512 channels: 8 x 8 pixels per patch -- autograd's elementwise form)
+        else:
             z = F.silu(z * tk[:, None, None, :] + tb[:, None, None, :])
-        z = _Conv3x3.apply(z, P[pre + '.conv2.weight'], P[pre + '.conv2.bias'], self.plan, 1, True)
-        return z + x
+        # z = conv2(z) + x with the residual in the convolution's epilogue (archs/modules.py:194-195)
+        return _Conv3x3.apply(z, P[pre + '.conv2.weight'], P[pre + '.conv2.bias'], self.plan, 1, True, xr)
 
     def _forward_unet(self, x_nchw):
         """UNetSeeInDark (archs/Unet.py:55-104): conv -> LeakyReLU(0.2) pairs, 2x2 max pooling, ConvTranspose2d + cat + conv; the

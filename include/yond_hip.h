@@ -236,6 +236,11 @@ int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize
  * may be NULL) instead of failing the call. */
 int yond_pack_conv_split_weight_dev_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst, int* status,
                                         void* stream);
+/* The same for several layers in one launch (a training step re-packs every layer): desc (device) holds 7 int64 per layer -- source
+ * offset in src (floats), cout, cin, taps (ksize^2), tn, destination offset in dst (floats), index of the layer's first 16-byte
+ * group among all layers' groups (cout * cin * taps / 4 groups per layer at parts = 2); ngroups = their total. */
+int yond_pack_conv_split_weights_batch_dev_f32(const float* src, const long long* desc, int nlayers, float* dst, size_t ngroups,
+                                               int* status, void* stream);
 
 /* First layer: 3x3, Cin=4 -> Cout=32k, input NHWC4, optional division by the per-image maximum
  * (data_normalize, archs/Unet.py:427-431) and LeakyReLU(slope).  wpk from yond_pack_conv_in_weight_f32. */
@@ -450,8 +455,9 @@ int yond_conv_wgrad_ws_f32(const float* x, const float* dy, int N, int H, int W,
  * ([9][Cout][Cin]); needs |dy| < 32 (bit 0 of *status is set otherwise: TrainStep's loss scale keeps it there).
  * yond_conv_wgrad_split_ws_bytes returns 0 for a layer the kernel does not take (the caller keeps yond_conv_wgrad_ws_f32). */
 size_t yond_conv_wgrad_split_ws_bytes(int N, int H, int W, int Cin, int Cout);
-int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, float* dw, float* ws,
-                              size_t ws_bytes, int* status, void* stream);
+int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, float* dw,
+                              int with_bias /* dw then has 9 Cout Cin + Cout floats: the last Cout = db[co] = sum_p dy[p][co] */,
+                              float* ws, size_t ws_bytes, int* status, void* stream);
 int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, void* stream);
 /* The guided block's middle (archs/modules.py:186-196) for training: out = SiLU(z * tk[n][c] + tb[n][c]) over z [N][P][C] with
  * per-image vectors tk, tb [N][C], and its backward in one pass: dz, dtk[n][c] = sum_p g z, dtb[n][c] = sum_p g with

@@ -38,7 +38,12 @@ ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--nf', type=int, default=32)
 ap.add_argument('--conv', default='split')
+ap.add_argument('--set', action='append', default=[], help='A/B: NAME=VALUE module attributes of yond_public_amd.train (e.g. WGRAD_BIAS=0)')
 a = ap.parse_args()
+import yond_public_amd.train as _T
+for kv in a.set:
+    k, v = kv.split('=')
+    setattr(_T, k, type(getattr(_T, k))(int(v)))
 dev = torch.device('cuda', 0)
 arch = dict(name=a.net, in_nc=4, out_nc=4, nf=a.nf, nframes=1, res=True, norm=True)
 if a.net != 'UNetSeeInDark':

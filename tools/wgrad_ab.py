@@ -15,7 +15,7 @@ for lvl in range(5):
     ws0 = torch.empty(n0 // 4, device='cuda'); ws1 = torch.empty(max(n1, 4) // 4, device='cuda')
     st = torch.zeros(1, dtype=torch.int32, device='cuda')
     f0 = lambda: lib.yond_conv_wgrad_ws_f32(L.ptr(x), L.ptr(dy), N, H, H, C, H, H, C, 0, 1, L.ptr(dw), L.ptr(ws0), n0, L.stream())
-    f1 = lambda: lib.yond_conv_wgrad_split_f32(L.ptr(x), L.ptr(dy), N, H, H, C, C, L.ptr(dw2), L.ptr(ws1), n1, L.ptr(st), L.stream())
+    f1 = lambda: lib.yond_conv_wgrad_split_f32(L.ptr(x), L.ptr(dy), N, H, H, C, C, L.ptr(dw2), 0, L.ptr(ws1), n1, L.ptr(st), L.stream())
 
     def t(fn, reps=20):
         for _ in range(3): fn()

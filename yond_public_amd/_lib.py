@@ -57,6 +57,7 @@ PROTOTYPES = {
     "yond_conv_split_supported": [i32, i32, i32, i32],
     "yond_pack_conv_split_weight_f32": [vp, i32, i32, i32, i32, i32, vp],
     "yond_pack_conv_split_weight_dev_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp],
+    "yond_pack_conv_split_weights_batch_dev_f32": [vp, vp, i32, vp, sz, vp, vp],
     "yond_conv_in_f32": [vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, i32, vp],
     "yond_pack_conv_in_weight_f32": [vp, i32, vp],
     "yond_conv_out_f32": [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp],
@@ -86,7 +87,7 @@ PROTOTYPES = {
     "yond_conv_wgrad_ws_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp],
     "yond_conv_wgrad_ws_bytes": [i32, i32, i32, i32, i32, i32, i32, i32, i32],
     "yond_conv_wgrad_split_ws_bytes": [i32, i32, i32, i32, i32],
-    "yond_conv_wgrad_split_f32": [vp, vp, i32, i32, i32, i32, i32, vp, vp, sz, vp, vp],
+    "yond_conv_wgrad_split_f32": [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp, vp],
     "yond_colsum_f32": [vp, sz, i32, vp, vp],
     "yond_film_silu_supported": [i32],
     "yond_film_silu_f32": [vp, vp, vp, vp, i32, sz, i32, vp],

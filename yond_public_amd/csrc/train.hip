@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         // The K axis is split over thousands of waves; their partial sums meet in few addresses (a 32 -> 32 channel layer has
         // 9,216 weights), and memory-side float atomics onto the same address serialise: 1,368 of them in a row cost more than
         // the MFMAs.  So: the four waves of a workgroup add up through LDS, the workgroup STORES its partial tile
-        // [workgroup chunk][tap][Cout][Cin], wgrad_reduce_kernel adds the chunks.
+        // [workgroup chunk][tap][Cout][Cin], wgrad_reduce64_kernel adds the chunks.
         __shared__ float red[4][16][64];
         const size_t per = (size_t)g.taps * g.Cout * g.Cin;                     // floats per workgroup chunk
         float* wsc = ws + (size_t)blockIdx.y * per;
@@ -281,38 +281,30 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
         }
 }
 
-// dw[i] = the sum over the workgroup chunks of ws[chunk][i]; grid (elements / 256, S): S slices of the chunk range, combined with
-// one atomic each when S > 1 (dw zeroed by the caller then)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nchunk, size_t n, float* __restrict__ dw) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int j = blockIdx.y;
-    const int S = gridDim.y;
-    for (; j + 3 * S < nchunk; j += 4 * S) {
-        a0 += ws[(size_t)j * n + i];
-        a1 += ws[(size_t)(j + S) * n + i];
-        a2 += ws[(size_t)(j + 2 * S) * n + i];
-        a3 += ws[(size_t)(j + 3 * S) * n + i];
-    }
-    for (; j < nchunk; j += S) a0 += ws[(size_t)j * n + i];
-    const float v = (a0 + a1) + (a2 + a3);
-    if (S > 1) atomicAdd(dw + i, v);
-    else dw[i] = v;
-}
-
 // (wgrad_split.hip: the split-operand weight-gradient kernel stores slices of the same form)
-int yond_wgrad_reduce_launch(const float* ws, int nchunk, size_t n, float* dw, hipStream_t st) {
-    const unsigned nbx = (unsigned)((n + 255) / 256);
-    long long S = 1024 / (long long)nbx;                        // about one round of workgroups
-    if (S > nchunk / 4) S = nchunk / 4;
-    if (S > 64) S = 64;
-    if (S < 1) S = 1;
-    if (S > 1) {
-        hipError_t e = hipMemsetAsync(dw, 0, n * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+// dw[i] = sum over the slices of ws[slice][i], no atomics and no zeroed output: a workgroup owns 64 consecutive elements, its four
+// waves take every fourth slice and meet in LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce64_kernel(const float* __restrict__ ws, int nchunk, size_t n, float* __restrict__ dw) {
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + e;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (i < n) {
+        int j = q;
+        for (; j + 4 < nchunk; j += 8) {
+            a0 += ws[(size_t)j * n + i];
+            a1 += ws[(size_t)(j + 4) * n + i];
+        }
+        for (; j < nchunk; j += 4) a0 += ws[(size_t)j * n + i];
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nbx, (unsigned)S), dim3(256), 0, st, ws, nchunk, n, dw);
+    part[q][e] = a0 + a1;
+    __syncthreads();
+    if (q == 0 && i < n) {
+        dw[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    }
+}
+int yond_wgrad_reduce_launch(const float* ws, int nchunk, size_t n, float* dw, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, ws, nchunk, n, dw);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -340,16 +332,7 @@ static void launch_wgrad(const float* x, const float* dy, WgradGeom g, float* dw
     wgrad_split<MODE, NCO>(g, chunk, wgchunks);
     g.chunk = (int)chunk;
     hipLaunchKernelGGL((wgrad_rows_kernel<MODE, NCO>), dim3((unsigned)tiles, (unsigned)wgchunks), dim3(256), 0, stream, x, dy, g, dw, ws);
-    if (ws) {
-        const size_t n = (size_t)g.taps * g.Cout * g.Cin;
-        const size_t nbx = (n + 255) / 256;
-        long long S = (2048 + (long long)nbx - 1) / (long long)nbx;               // ~2048 workgroups in all
-        if (S > wgchunks) S = wgchunks;
-        if (S > 64) S = 64;
-        if (S < 1) S = 1;
-        if (S > 1) hipMemsetAsync(dw, 0, n * sizeof(float), stream);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nbx, (unsigned)S), dim3(256), 0, stream, ws, (int)wgchunks, n, dw);
-    }
+    if (ws) yond_wgrad_reduce_launch(ws, (int)wgchunks, (size_t)g.taps * g.Cout * g.Cin, dw, stream);
 }
 
 static bool wgrad_check(const float* x, const float* dy, const float* dw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride) {
@@ -638,20 +621,28 @@ __global__ __launch_bounds__(256) void film_mlp_tile_kernel(const FilmMlpArgs a)
 }
 
 // the five parameter vectors' gradients (sums over the batch) and the zero padding of tk / tb rows
+// (a workgroup = 64 channels x 4 quarters of the batch, joined in LDS: one thread per channel over the whole batch was latency bound)
 __global__ __launch_bounds__(256) void film_mlp_vec_kernel(const float* __restrict__ t, const float* __restrict__ dtb, const float* __restrict__ dtk_tot,
                                                            const float* __restrict__ da, int B, int C, int ld, float* __restrict__ db3,
                                                            float* __restrict__ db2, float* __restrict__ dw1, float* __restrict__ db1) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= C) return;
+    __shared__ float part[4][4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + e;
     float s3 = 0.0f, s2 = 0.0f, sw = 0.0f, sb = 0.0f;
-    for (int b = 0; b < B; ++b) {
-        s3 += dtb[(size_t)b * ld + i];
-        s2 += dtk_tot[(size_t)b * C + i];
-        const float d = da[(size_t)b * C + i];
-        sw += d * t[b];
-        sb += d;
+    if (i < C)
+        for (int b = q; b < B; b += 4) {
+            s3 += dtb[(size_t)b * ld + i];
+            s2 += dtk_tot[(size_t)b * C + i];
+            const float d = da[(size_t)b * C + i];
+            sw += d * t[b];
+            sb += d;
+        }
+    part[q][0][e] = s3; part[q][1][e] = s2; part[q][2][e] = sw; part[q][3][e] = sb;
+    __syncthreads();
+    if (i < C && q < 4) {
+        const float v = (part[0][q][e] + part[1][q][e]) + (part[2][q][e] + part[3][q][e]);
+        (q == 0 ? db3 : q == 1 ? db2 : q == 2 ? dw1 : db1)[i] = v;
     }
-    db3[i] = s3; db2[i] = s2; dw1[i] = sw; db1[i] = sb;
 }
 __global__ __launch_bounds__(256) void film_mlp_pad_kernel(float* __restrict__ tk, float* __restrict__ tb, int B, int C, int ld) {
     const int i = blockIdx.x * 256 + threadIdx.x, w = ld - C;
@@ -698,7 +689,7 @@ extern "C" int yond_film_mlp_bwd_f32(const float* t, const float* w1, const floa
     film_mlp_launch<4>(a, st);
     a.out = dW2;
     film_mlp_launch<5>(a, st);
-    hipLaunchKernelGGL(film_mlp_vec_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, t, dtb, dtk_tot, da, B, C, ld, db3, db2, dw1, db1);
+    hipLaunchKernelGGL(film_mlp_vec_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, t, dtb, dtk_tot, da, B, C, ld, db3, db2, dw1, db1);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

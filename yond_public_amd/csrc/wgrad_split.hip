@@ -33,7 +33,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 struct WgsGeom {
     const float* x;            // [N][H][W][Ci]
     const float* dy;           // [N][H][W][Co]
-    float* ws;                 // [nslices][9][Co][Ci]
+    float* ws;                 // [nslices][9 Co Ci (+ Co: the slice's column sums of dY, with_bias)]
+    int with_bias;
     int* status;
     int N, H, W, Ci, Co;
     int W2, H2, Ls;            // W + 2, H + 2, H2 * W2
@@ -94,6 +95,13 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
         if (nsteps > left) nsteps = left;
     }
     float amax = 0.0f;
+    // with_bias: the bias gradient db[co] = sum over pixels of dY rides along -- every dY value passes through stage_dy exactly
+    // once per output-channel group, so the workgroups of input-channel group 0 add up what they stage (a pass of its own over
+    // dY cost 27 us per layer)
+    const bool sum_dy = g.with_bias && (group % gb_n) == 0;
+    f32x4 dsum[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) dsum[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     // ---- staging: one item = 4 consecutive channels of one pixel (16 bytes of float32 -> 8 bytes per fp16 part) ----
     // stream index of an item is (batch start) + po, po = it / (8 tiles); the item's position (n, r, c) advances by SK per step
@@ -128,8 +136,9 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
     auto d_dst = [&](int buf, int tile, int part, int o, int c4) -> char* {
         return dyb + (unsigned)((((buf * PA + tile) * 3 + part) * SK + o) * 64 + c4 * 8);
     };
-    auto stage_dy = [&](const f32x4& v, int buf, int tile, int o, int c4) {
+    auto stage_dy = [&](const f32x4& v, int buf, int tile, int o, int c4, f32x4& sum, bool count) {
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        if (count) { sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3]; }
         const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         const f16x4 P = {(_Float16)(v[0] * 2048.0f), (_Float16)(v[1] * 2048.0f), (_Float16)(v[2] * 2048.0f), (_Float16)(v[3] * 2048.0f)};
         const f16x4 l = {(_Float16)((v[0] - (float)h[0]) * 2048.0f), (_Float16)((v[1] - (float)h[1]) * 2048.0f),
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
         d_item(tid + k * C::NT, po, tile, c4);
         dp[k] = stream_pos(G0 + po, g.Ls, g.W2);
         const f32x4 v = load_px(g.dy, g.Co, dp[k], (a0 + tile) * 32 + c4 * 4);
-        stage_dy(v, 0, tile, po, c4);
+        stage_dy(v, 0, tile, po, c4, dsum[k], true);
         stream_advance(dp[k], SK, g.W2, g.H2);
     }
     __syncthreads();
@@ -233,7 +242,8 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
             for (int k = 0; k < ND; ++k) {
                 int po, tile, c4;
                 d_item(tid + k * C::NT, po, tile, c4);
-                if (!(g.abl & 4)) stage_dy(masked(vd[k], okd[k]), buf ^ 1, tile, po, c4);
+                // (the batch staged by the slice's last step belongs to the next slice: not this one's to count)
+                if (!(g.abl & 4)) stage_dy(masked(vd[k], okd[k]), buf ^ 1, tile, po, c4, dsum[k], s + 1 < nsteps);
             }
             // (the cursors behind the consumers: their carry loops are branches)
 #pragma unroll
@@ -247,7 +257,10 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
         // Software pipeline over (K step, kernel row): the fragments of the NEXT kernel row are requested before the nine MFMAs
         // of the current row are issued, and those nine go tap-interleaved (three accumulators in turn), so neither an LDS
         // latency nor a dependent accumulator sits in front of an MFMA.  (Scheduling fences keep the reads where they are.)
-        Frag A[1][3], Bh[2][3], Bl[2][3];                         // (one set of dY fragments: a second one spills)
+        // (register budget: one set of dY fragments, two of the h halves of X -- the next kernel row's are requested a row ahead --
+        // and ONE of the l halves, requested at the top of their own row: the three h_a h_x MFMAs in front of their first use
+        // cover the LDS latency)
+        Frag A[1][3], Bh[2][3], Bl[1][3];
         const unsigned abase = (unsigned)((((buf * PA + wa) * 3) * SK + frag_px) * 64) + frag_ch;
         auto load_A = [&](int kp, int set) {
             const int o = 16 * (ks * KPW + kp);                  // first pixel of the wave's K step inside the batch
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
         };
         const char* const ph = xr + (unsigned)((wb * 2 + 0) * g.ring * 64) + frag_ch;
         const char* const pl = xr + (unsigned)((wb * 2 + 1) * g.ring * 64) + frag_ch;
-        auto load_B = [&](int kp, int ky, int set) {
+        auto load_B = [&](int kp, int ky, int set, bool low) {
             const int o = 16 * (ks * KPW + kp);
             // ring position of the K step's first pixel for tap (ky, 0): stream index g_s + o + (ky - 1) W2 - 1
             const int rel0 = wbase + g.lead + o + (ky - 1) * g.W2 - 1 + frag_px;
@@ -269,25 +282,29 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
                 const int rel = rel0 + kx, rel1 = rel + 4;
                 const unsigned r0 = (unsigned)(rel >= g.ring ? rel - g.ring : rel) * 64u;
                 const unsigned r1 = (unsigned)(rel1 >= g.ring ? rel1 - g.ring : rel1) * 64u;
-                Bh[set][kx].s[0] = rd(ph + r0);
-                Bh[set][kx].s[1] = rd(ph + r1);
-                Bl[set][kx].s[0] = rd(pl + r0);
-                Bl[set][kx].s[1] = rd(pl + r1);
+                if (low) {
+                    Bl[0][kx].s[0] = rd(pl + r0);
+                    Bl[0][kx].s[1] = rd(pl + r1);
+                } else {
+                    Bh[set][kx].s[0] = rd(ph + r0);
+                    Bh[set][kx].s[1] = rd(ph + r1);
+                }
             }
         };
         if (!(g.abl & 2)) {
         load_A(0, 0);
-        load_B(0, 0, 0);
+        load_B(0, 0, 0, false);
         static_for<0, KPW * 3>([&](auto ic) {
             constexpr int i = decltype(ic)::value, kp = i / 3, ky = i % 3;
-            if constexpr (i + 1 < KPW * 3) load_B((i + 1) / 3, (i + 1) % 3, (i + 1) & 1);
+            load_B(kp, ky, 0, true);
+            if constexpr (i + 1 < KPW * 3) load_B((i + 1) / 3, (i + 1) % 3, (i + 1) & 1, false);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int part = 0; part < 3; ++part)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
                     // part 0: 2^11 h_a h_x ; 1: h_a (2^11 l_x) ; 2: (2^11 l_a) h_x
-                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][part].h, part == 1 ? Bl[i & 1][kx].h : Bh[i & 1][kx].h,
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][part].h, part == 1 ? Bl[0][kx].h : Bh[i & 1][kx].h,
                                                                              acc[ky * 3 + kx], 0, 0, 0);
             if constexpr (ky == 2 && i + 1 < KPW * 3) load_A(kp + 1, 0);      // (behind the K step's last MFMAs: its readers)
             __builtin_amdgcn_sched_barrier(0);
@@ -306,11 +323,27 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WgsGeom g) {
     // wave-instruction would move 2 x 128 bytes, and 144 of them per wave made the write-out longer than the main loop (store
     // issue, not bandwidth).  So, tap by tap, every wave puts its tile into LDS (the rings are dead now), the KS waves of a
     // tile are added up there, and each thread stores 16 bytes: a wave-instruction covers eight whole 128-byte rows.
-    float* const wsl = g.ws + (size_t)slice * 9 * g.Co * g.Ci;
+    const size_t slice_floats = (size_t)9 * g.Co * g.Ci + (g.with_bias ? g.Co : 0);
+    float* const wsl = g.ws + (size_t)slice * slice_floats;
     const int li = lane & 31, lk = lane >> 5;
     float* const red = (float*)smem;                             // [2 buffers][8 waves][32 co][32 ci]
     constexpr int NP = PA * PB;
     __syncthreads();
+    if (g.with_bias) {                                           // (uniform over the workgroup: the barriers below are safe)
+        // the threads' column sums -> LDS, item-major (item it holds channels (tile, c4) of pixel it / (8 PA)) -> one thread per
+        // channel adds its column -> the slice's db block.  (LDS float atomics here cost 50 us per launch.)
+        float* cs = red;                                         // [ND * NT items][4]; the tile buffers are not in use yet
+#pragma unroll
+        for (int k = 0; k < ND; ++k) *(f32x4*)(cs + (size_t)(tid + k * C::NT) * 4) = dsum[k];
+        __syncthreads();
+        if (sum_dy && tid < PA * 32) {
+            const int tile = tid >> 5, c4 = (tid >> 2) & 7, e = tid & 3;
+            float a = 0.0f;
+            for (int po = 0; po < SK; ++po) a += cs[(size_t)(((po * PA + tile) << 3) + c4) * 4 + e];
+            wsl[(size_t)9 * g.Co * g.Ci + a0 * 32 + tid] = a;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         float* rb = red + (t & 1) * 8 * 1024;
@@ -368,9 +401,9 @@ static WgsPlan wgs_plan(int N, int H, int W, int Ci, int Co) {
     if ((long long)N * H * W * (Ci > Co ? Ci : Co) >= 0x7fffffffLL) return p;
     const int pairs = (Ci / 32) * (Co / 32);
     if (pairs == 1 && wgs_try<1, 1, 8, 1>(N, H, W, Ci, Co, 1, p)) return p;
-    if (pairs == 4 && wgs_try<2, 2, 2, 2>(N, H, W, Ci, Co, 2, p)) return p;
+    if (pairs == 4 && wgs_try<2, 2, 2, 1>(N, H, W, Ci, Co, 2, p)) return p;
     if (wgs_try<2, 4, 1, 2>(N, H, W, Ci, Co, 3, p)) return p;
-    if (wgs_try<2, 2, 2, 2>(N, H, W, Ci, Co, 2, p)) return p;
+    if (wgs_try<2, 2, 2, 1>(N, H, W, Ci, Co, 2, p)) return p;
     if (wgs_try<2, 1, 4, 1>(N, H, W, Ci, Co, 4, p)) return p;
     if (wgs_try<1, 2, 4, 1>(N, H, W, Ci, Co, 5, p)) return p;
     if (wgs_try<1, 1, 8, 1>(N, H, W, Ci, Co, 1, p)) return p;
@@ -381,7 +414,7 @@ static WgsPlan wgs_plan(int N, int H, int W, int Ci, int Co) {
 // bytes of workspace yond_conv_wgrad_split_f32 needs (0: the layer does not fit this kernel -- the caller keeps yond_conv_wgrad_ws_f32)
 extern "C" size_t yond_conv_wgrad_split_ws_bytes(int N, int H, int W, int Cin, int Cout) {
     const WgsPlan p = wgs_plan(N, H, W, Cin, Cout);
-    return p.cfg ? (size_t)p.nslices * 9 * Cout * Cin * sizeof(float) : 0;
+    return p.cfg ? (size_t)p.nslices * ((size_t)9 * Cout * Cin + Cout) * sizeof(float) : 0;
 }
 
 template <int PA, int PB, int KS, int KPW>
@@ -402,14 +435,16 @@ static int wgs_launch(const WgsGeom& g, const WgsPlan& p, hipStream_t st) {
 int yond_wgrad_reduce_launch(const float* ws, int nchunk, size_t n, float* dw, hipStream_t st);     // train.hip
 
 // dw[9][Cout][Cin] of a 3x3 stride-1 pad-1 convolution from x [N][H][W][Cin], dy [N][H][W][Cout] (float32, channels multiples of 32)
-extern "C" int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, float* dw, float* ws,
-                                         size_t ws_bytes, int* status, void* stream) {
+// with_bias != 0: dw has 9 Cout Cin + Cout floats, the last Cout = db[co] = the sum over all pixels of dy (the bias gradient)
+extern "C" int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, float* dw, int with_bias,
+                                         float* ws, size_t ws_bytes, int* status, void* stream) {
     if (!x || !dy || !dw || !ws) return YOND_EINVAL;
     const WgsPlan p = wgs_plan(N, H, W, Cin, Cout);
     if (!p.cfg) return YOND_EUNSUPPORTED;
-    if (ws_bytes < (size_t)p.nslices * 9 * Cout * Cin * sizeof(float)) return YOND_EINVAL;
+    const size_t slice_floats = (size_t)9 * Cout * Cin + (with_bias ? Cout : 0);
+    if (ws_bytes < (size_t)p.nslices * slice_floats * sizeof(float)) return YOND_EINVAL;
     WgsGeom g;
-    g.x = x; g.dy = dy; g.ws = ws; g.status = status;
+    g.x = x; g.dy = dy; g.ws = ws; g.status = status; g.with_bias = with_bias ? 1 : 0;
     g.N = N; g.H = H; g.W = W; g.Ci = Cin; g.Co = Cout;
     g.W2 = W + 2; g.H2 = H + 2; g.Ls = g.W2 * g.H2;
     g.total = N * g.Ls;
@@ -420,11 +455,11 @@ extern "C" int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N,
     int rc;
     switch (p.cfg) {
         case 1: rc = wgs_launch<1, 1, 8, 1>(g, p, st); break;
-        case 2: rc = wgs_launch<2, 2, 2, 2>(g, p, st); break;
+        case 2: rc = wgs_launch<2, 2, 2, 1>(g, p, st); break;
         case 3: rc = wgs_launch<2, 4, 1, 2>(g, p, st); break;
         case 4: rc = wgs_launch<2, 1, 4, 1>(g, p, st); break;
         default: rc = wgs_launch<1, 2, 4, 1>(g, p, st); break;
     }
     if (rc != YOND_OK) return rc;
-    return yond_wgrad_reduce_launch(ws, p.nslices, (size_t)9 * Cout * Cin, dw, st);
+    return yond_wgrad_reduce_launch(ws, p.nslices, slice_floats, dw, st);
 }

@@ -31,6 +31,10 @@ from . import _lib as L
 from .engine import DenoiserPlan, _PackedConv, _rup
 
 
+WGRAD_BIAS = True                # the bias gradient of a 3x3 stride-1 layer rides along in the split-operand weight-gradient kernel
+                                 # (module attribute: tools/ flip it for A/B runs)
+
+
 def _plan(dev):
     plan = DenoiserPlan.__new__(DenoiserPlan)
     plan.lib, plan.dev = L.load(), torch.device(dev)
@@ -92,7 +96,9 @@ class _Packing:
                 o, n = batch[1][id(m)]
                 return batch[0][o:o + n]
             return arena.index_select(0, m)
-        if self.split_tn:
+        if self.split_tn and batch is not None and len(batch) > 2 and id(self) in batch[2]:
+            pass                                             # packed by the step's one batched launch (TrainStep._gather_weights)
+        elif self.split_tn:
             wp = gathered(self.omap)
             packed = torch.empty_like(wp)
             st = getattr(self, 'status', None)
@@ -129,9 +135,24 @@ def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False, r
     return out
 
 
-def _wgrad(plan, x, dy, mode, stride, taps):
+def _wgrad(plan, x, dy, mode, stride, taps, with_bias=False):
     """[taps][Cout_p][Cin_p] float32 (x, dy: padded NHWC).  The workgroups' partial sums go through one workspace that grows to the
-    largest layer's need (stream order keeps its uses apart)."""
+    largest layer's need (stream order keeps its uses apart).  with_bias: returns (dw, db [Cout_p]) -- the split-operand kernel adds
+    up dy's columns on the way, the other layers take yond_colsum_f32."""
+    if with_bias:
+        N, H, W, ci = x.shape
+        co = dy.shape[-1]
+        if mode == 0 and stride == 1 and getattr(plan, 'train_conv', 'split') == 'split':
+            need = int(plan.lib.yond_conv_wgrad_split_ws_bytes(N, H, W, ci, co))
+            if need:
+                ws = getattr(plan, 'wgrad_ws', None)
+                if ws is None or ws.numel() * 4 < need:
+                    ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+                buf = torch.empty(taps * co * ci + co, dtype=torch.float32, device=x.device)
+                L.check(plan.lib.yond_conv_wgrad_split_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, co, L.ptr(buf), 1, L.ptr(ws), ws.numel() * 4,
+                                                           L.ptr(getattr(plan, 'status', None)), L.stream()), "yond_conv_wgrad_split_f32")
+                return buf[:taps * co * ci].view(taps, co, ci), buf[taps * co * ci:]
+        return _wgrad(plan, x, dy, mode, stride, taps), _colsum(plan, dy)
     N, H, W, ci = x.shape
     _, Ho, Wo, co = dy.shape
     dw = torch.empty((taps, co, ci), dtype=torch.float32, device=x.device)
@@ -143,7 +164,7 @@ def _wgrad(plan, x, dy, mode, stride, taps):
             if ws is None or ws.numel() * 4 < need:
                 ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
             st = getattr(plan, 'status', None)
-            L.check(plan.lib.yond_conv_wgrad_split_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, co, L.ptr(dw), L.ptr(ws), ws.numel() * 4,
+            L.check(plan.lib.yond_conv_wgrad_split_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, co, L.ptr(dw), 0, L.ptr(ws), ws.numel() * 4,
                                                        L.ptr(st), L.stream()), "yond_conv_wgrad_split_f32")
             return dw
     need = int(plan.lib.yond_conv_wgrad_ws_bytes(N, H, W, ci, Ho, Wo, co, mode, stride))
@@ -184,8 +205,12 @@ class _Conv3x3(torch.autograd.Function):
         dy = dy.contiguous()
         N, H, W, cin_p = x.shape
         cout, cin = w.shape[0], w.shape[1]
-        dw = _wgrad(plan, x, dy, 0, stride, 9)[:, :cout, :cin].permute(1, 2, 0).reshape(cout, cin, 3, 3)
-        db = _colsum(plan, dy)[:cout]
+        if WGRAD_BIAS:
+            dw, db = _wgrad(plan, x, dy, 0, stride, 9, with_bias=True)
+        else:
+            dw, db = _wgrad(plan, x, dy, 0, stride, 9), _colsum(plan, dy)
+        dw = dw[:, :cout, :cin].permute(1, 2, 0).reshape(cout, cin, 3, 3)
+        db = db[:cout]
         dx = None
         if ctx.need_dx:
             g = dy
@@ -540,8 +565,28 @@ class TrainStep:
                     off += m.numel()
             self._wb_map, self._wb_slots, self._wb_count = torch.cat(maps), slots, len(packs)
             self._wb_buf = torch.empty(off, dtype=torch.float32, device=self.dev)
+            # the split-operand layers' packing as ONE launch: descriptor table + one destination buffer whose slices the layers keep
+            desc, off_g, off_d, self._pk_ids = [], 0, 0, set()
+            for pk in packs:
+                if pk.split_tn:
+                    so, n = slots[id(pk.omap)]
+                    taps = pk.pc.ksize * pk.pc.ksize
+                    desc.append([so, pk.pc.gemm_n, pk.pc.cinp, taps, pk.split_tn, off_d, off_g])
+                    off_g += n // 4
+                    off_d += n
+                    self._pk_ids.add(id(pk))
+            self._pk_groups = off_g
+            if desc:
+                self._pk_desc = torch.tensor(desc, dtype=torch.int64, device=self.dev)
+                self._pk_buf = torch.empty(off_d, dtype=torch.float32, device=self.dev)
+                for pk, dsc in zip([q for q in packs if q.split_tn], desc):
+                    pk.pc._packed[('split', 2)] = (pk.split_tn, self._pk_buf[dsc[5]:dsc[5] + dsc[1] * dsc[2] * dsc[3]])
         torch.index_select(self.arena, 0, self._wb_map, out=self._wb_buf)
-        plan.wbatch = (self._wb_buf, self._wb_slots)
+        if self._pk_groups:
+            L.check(plan.lib.yond_pack_conv_split_weights_batch_dev_f32(L.ptr(self._wb_buf), L.ptr(self._pk_desc), self._pk_desc.shape[0],
+                                                                        L.ptr(self._pk_buf), self._pk_groups, L.ptr(plan.status[1:2]), L.stream()),
+                    "yond_pack_conv_split_weights_batch_dev_f32")
+        plan.wbatch = (self._wb_buf, self._wb_slots, self._pk_ids)
 
     # -- loss, backward, Adam ----------------------------------------------------------------------------------------
     def _scale_for(self, n):

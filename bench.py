@@ -676,10 +676,22 @@ def main(argv=None):
                 n6 += 1
             torch.cuda.synchronize()
             el6 = time.perf_counter() - t6
+            # algorithmic work of a step: forward + data gradient + weight gradient = 3 x the forward's 2 * 201,984 MAC per packed pixel
+            # (SURVEY 8d), against the peak of the MFMA the step's dominant kernels issue (fp16, split operands: 3 MFMAs per product)
+            fl6 = 3 * 2.0 * 201984 * 64 * 128 * 128
+            tf6 = fl6 / (el6 / n6) / 1e12
             others["training_step"] = {"ms_per_step": round(el6 / n6 * 1e3, 3), "patches_per_s": round(n6 * 64 / el6, 1),
                                        "bayer_mp_per_s": round(n6 * 64 * 256 * 256 / 1e6 / el6, 1), "steps": n6, "loss": round(float(loss6), 6),
+                                       "loss_scale": getattr(ts6, "last_scale", None),
+                                       "roofline": {"bound": "mfma", "achieved": round(tf6, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                    "frac": round(tf6 / PEAK_F16_MFMA_TFLOPS, 4), "algorithmic_tflop_per_step": round(fl6 / 1e12, 3),
+                                                    "definition": "3 x forward FLOPs (forward, data gradient, weight gradient) / step time, whole step "
+                                                                  "(wall clock, host included)"},
+                                       "collectives": {"grad_all_reduce": D.STATS["grad_all_reduce"], "grad_bytes": D.STATS["grad_bytes"],
+                                                       "note": "one rank: no gradient exchange; under torchrun two 25 MB buckets per step (distributed.GradReducer)"},
                                        "workload": "SURVEY 8(f) N4: GuidedResUnet(nf=32), batch 64 x [4][128][128] (256 x 256 Bayer patches), L1 loss, Adam; "
-                                                   "forward / data gradients of the 3x3 layers on the split-operand kernels, weight gradients on the fp32 MFMA"}
+                                                   "forward / data gradients and the weight gradients of the 3x3 stride-1 layers on the split-operand "
+                                                   "fp16-MFMA kernels (loss-scaled), the other layers on the fp32 MFMA"}
             del ts6, net6, hr6, lr6, sg6
         except Exception as e:                      # (a reported extra: it must not take the headline line down with it)
             others["training_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}

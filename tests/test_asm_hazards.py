@@ -15,3 +15,13 @@ def test_train_kernels_have_no_valu_sgpr_vmem_hazard():
     last = out.stdout.strip().splitlines()[-1]
     n = int(last.split()[0])
     assert n >= 100 and " 0 with a vector-ALU write" in last, last          # (the scan really saw the asm loads)
+
+
+def test_wgrad_kernels_keep_their_pipeline_assumptions():
+    """the counted-wait pipeline of wgrad_rows_kernel holds only without scratch traffic and with every MFMA behind
+    the wait that covers its operands; the split-operand weight-gradient kernels must not spill (tools/asm_pipeline_scan.py)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_pipeline_scan.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    assert "5 wgrad_rows_kernel + 5 wgrad_split_kernel" in last and last.endswith(" 0 findings"), last
+    assert int(last.split(",")[1].split()[0]) >= 100, last                   # (the replay really saw the asm loads)

@@ -21,7 +21,8 @@ def sources():
 
 
 def headers():
-    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "yond_hip.h")]
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "yond_hip.h"),
+                                                   os.path.join(HERE, "..", "include", "yond_hip_experiments.h")]
 
 
 def _obj(src, extra_flags=()):
@@ -45,8 +46,21 @@ def _deps(src):
     return seen
 
 
-def _stale(target, deps):
-    return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
+def _dep_hash(src, extra_flags=()):
+    """Content hash of what an object file is compiled from: the flags, the source and every header it includes."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS + list(extra_flags)).encode())
+    for f in sorted(_deps(src)):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def _stale(obj, src, extra_flags=()):
+    """An object is reused only if the stamp beside it holds the hash of the flags and of its source + headers (content, not
+    modification times: a changed FLAGS list or an edited header under an old mtime recompiles)."""
+    stamp = obj + ".hash"
+    return not (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == _dep_hash(src, extra_flags))
 
 
 STAMP = os.path.join(HERE, "libyond_hip.stamp")      # sha256 of (flags, sources, headers) the library was built from
@@ -78,13 +92,18 @@ def build_lib(force=False, verbose=True, extra_flags=(), lib=None):
             print(f"yond_public_amd.build: {LIB} matches the hash of every source: reused", flush=True)
         return LIB, "reused"
     os.makedirs(os.path.dirname(_obj("x.hip", extra_flags)), exist_ok=True)
-    todo = [s for s in sources() if force or _stale(_obj(s, extra_flags), _deps(s))]
+    todo = [s for s in sources() if force or _stale(_obj(s, extra_flags), s, extra_flags)]
 
     def cc(src):
-        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", src, "-o", _obj(src, extra_flags)]
+        obj = _obj(src, extra_flags)
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
+        if os.path.exists(obj + ".hash"):
+            os.remove(obj + ".hash")
         subprocess.run(cmd, check=True)
+        with open(obj + ".hash", "w") as f:
+            f.write(_dep_hash(src, extra_flags) + "\n")
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
         list(ex.map(cc, todo))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [_obj(s, extra_flags) for s in sources()]

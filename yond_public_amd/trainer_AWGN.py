@@ -313,13 +313,13 @@ class AWGN_Trainer:
                     f'PSNR={self.train_psnr.avg:.2f}, {time.perf_counter() - t0:.2f} s', log=self.logfile)
                 if epoch % self.hyper['save_freq'] == 0:
                     sd = self.state_dict()
-                    torch.save(sd, os.path.join(self.model_dir, '%s_e%04d.pth' % (self.model_name, epoch // pf * pf)))
-                    torch.save(sd, f'{self.fast_ckpt}/{self.model_name}_last_model.pth')
+                    _atomic_save(sd, os.path.join(self.model_dir, '%s_e%04d.pth' % (self.model_name, epoch // pf * pf)))
+                    _atomic_save(sd, f'{self.fast_ckpt}/{self.model_name}_last_model.pth')
                 if epoch % pf == 0:                             # fast eval
                     log(f"learning_rate: {lr:.3e}")
                     self.dst_eval.sigma = self.args['dst_eval']['sigma_list'][1] / 255.
                     self.eval(epoch=epoch)
-                    torch.save(self.state_dict(), f'{self.fast_ckpt}/{self.model_name}_last_model.pth')
+                    _atomic_save(self.state_dict(), f'{self.fast_ckpt}/{self.model_name}_last_model.pth')
             lr = self.scheduler.get_last_lr()[0]
         return self.trainer.history
 
@@ -348,12 +348,20 @@ class AWGN_Trainer:
         if self.eval_psnr.avg >= self.best_psnr and epoch > 0:
             self.best_psnr = self.eval_psnr.avg
             log(f"Best PSNR is {self.best_psnr} now!!")
-            torch.save(self.state_dict(), f'{self.fast_ckpt}/{self.model_name}_best_model.pth')
+            _atomic_save(self.state_dict(), f'{self.fast_ckpt}/{self.model_name}_best_model.pth')
         log(f"Epoch {epoch}: PSNR={self.eval_psnr.avg:.2f}, SSIM={self.eval_ssim.avg:.4f}", log=self.logfile)
         if epoch < 0:
             with open(metrics_path, 'wb') as f:
                 pkl.dump(metrics, f)
         return metrics
+
+
+def _atomic_save(obj, path):
+    """torch.save to a temporary file beside `path`, then os.replace: a reader (another rank, a resumed run) never sees a
+    half-written checkpoint."""
+    tmp = f"{path}.tmp{os.getpid()}"
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
 
 
 def main(argv=None):
@@ -363,6 +371,7 @@ def main(argv=None):
         out = {}
         if trainer.mode == 'train':
             out['history'] = trainer.train()
+            D.barrier()                     # rank 0 may still be inside the last epoch's save / eval block: no rank loads before it is done
             trainer.mode = 'evaltest'
         best = f'{trainer.fast_ckpt}/{trainer.model_name}_best_model.pth'
         if not os.path.exists(best):

@@ -76,6 +76,17 @@ int yond_denorm_ivst_unpack_f32(const float* net_out, int Hp, int Wp, int pad_t,
                                 float* bayer_out, int mode, double scale, double gain, double sigma,
                                 double lo, double hi, int clip01, void* stream);
 
+/* K1 / K4 for B equally sized frames that share every constant and the bias LUT -- the 32 blocks of a SIDD image, which the
+ * reference sends through VST_Denoiser one by one with the same p and bias_func (YOND_SIDD.py:392-407): ONE launch each.
+ *   bayer [B][H][W] -> out [B][Hp][Wp][4], img_max [B];   net_out [B][Hp][Wp][4] -> bayer_out [B][2h][2w].
+ *   biaslut != 0: lut_y is float64, the merged row of the 2-D table (as yond_pack_vst_norm_biaslut_f32). */
+int yond_pack_vst_norm_batch_f32(const float* bayer, int B, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
+                                 double scale, double gain, double sigma, double lo, double hi, const double* lut_x,
+                                 const void* lut_y, int lut_n, int biaslut, float* img_max, void* stream);
+int yond_denorm_ivst_unpack_batch_f32(const float* net_out, int B, int Hp, int Wp, int pad_t, int pad_l, int h, int w,
+                                      float* bayer_out, int mode, double scale, double gain, double sigma,
+                                      double lo, double hi, int clip01, void* stream);
+
 /* Stand-alone elementwise VST / inverse VST on flat arrays (utils/isp_algos.py:5-14, 17-33) for the function
  * seam; the hot path uses the fused K1 / K4 above.  float32 -> float64 and float64 -> float64 as NumPy stages
  * them with np.float64 noise parameters. */

@@ -258,3 +258,38 @@ def test_manual_est_type_and_refused_est_types():
     for bad in ('foi', 'pge+full', 'liu'):
         with pytest.raises(NotImplementedError):
             P.IterDenoise(noisy, net, arch, dict(pipe, est_type=bad), device=DEV)
+
+
+def test_batched_k1_k4_equal_the_per_frame_kernels():
+    """yond_pack_vst_norm_batch_f32 / yond_denorm_ivst_unpack_batch_f32 (one launch for the 32 blocks of a SIDD image) against 32
+    calls of the per-frame kernels: every bit of the packed tensor, of the per-block maxima and of the unpacked frames."""
+    import yond_oracle as O
+    from yond_public_amd import _lib as L, pipeline as P
+    lib = L.load()
+    B, H, W = 5, 64, 96
+    rng = np.random.default_rng(4)
+    lr = torch.from_numpy(rng.random((B, H, W), dtype=np.float32)).to(DEV)
+    K, sig, scale = np.float64(4.37), np.float64(6.27), 959.0
+    f = P.get_bias(np.float32(lr.max().item()) * np.float32(scale), sig, K, device=DEV)
+    lower, upper = P.vst_scalar(0, sig, K), P.vst_scalar(scale, sig, K)
+    p2d = P.get_p2d((1, 4, H // 2, W // 2), base=32)
+    Hp, Wp = H // 2 + p2d[2] + p2d[3], W // 2 + p2d[0] + p2d[1]
+    st = L.stream()
+    xa, ma = torch.zeros(B, Hp, Wp, 4, device=DEV), torch.zeros(B, device=DEV)
+    xb, mb = torch.ones(B, Hp, Wp, 4, device=DEV), torch.ones(B, device=DEV)
+    for i in range(B):
+        L.check(lib.yond_pack_vst_norm_f32(L.ptr(lr[i]), H, W, L.ptr(xa[i]), p2d[0], p2d[1], p2d[2], p2d[3], 1, scale, float(K), float(sig),
+                                           float(lower), float(upper), L.ptr(f.x), L.ptr(f.y), len(f), L.ptr(ma[i:i + 1]), st), "k1")
+    L.check(lib.yond_pack_vst_norm_batch_f32(L.ptr(lr), B, H, W, L.ptr(xb), p2d[0], p2d[1], p2d[2], p2d[3], scale, float(K), float(sig),
+                                             float(lower), float(upper), L.ptr(f.x), L.ptr(f.y), len(f), 0, L.ptr(mb), st), "k1 batch")
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb) and torch.equal(ma, mb)
+    oa, ob = torch.zeros(B, H, W, device=DEV), torch.ones(B, H, W, device=DEV)
+    y = torch.from_numpy(rng.random((B, Hp, Wp, 4), dtype=np.float32)).to(DEV)
+    for i in range(B):
+        L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y[i]), Hp, Wp, p2d[2], p2d[0], H // 2, W // 2, L.ptr(oa[i]), 1, scale, float(K), float(sig),
+                                                float(lower), float(upper), 1, st), "k4")
+    L.check(lib.yond_denorm_ivst_unpack_batch_f32(L.ptr(y), B, Hp, Wp, p2d[2], p2d[0], H // 2, W // 2, L.ptr(ob), 1, scale, float(K), float(sig),
+                                                  float(lower), float(upper), 1, st), "k4 batch")
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob)

@@ -1,4 +1,5 @@
-"""Per-launch times of one SNR-Net forward at the cfg-2 shape (HIP events around every convolution launch)."""
+"""Per-launch times of one SNR-Net forward (HIP events around every convolution launch): at the cfg-2 shape by default,
+`python tools/layer_times.py B H W` for a batch of B packed [H][W] inputs (cfg 3: 32 128 128)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,7 +7,8 @@ from yond_public_amd import archs as A, synthetic as S, pipeline as P
 arch = dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True)
 net = A.GuidedResUnet(dict(arch)); net.load_state_dict(S.procedural_state_dict(net, 0)); net = net.to('cuda').eval()
 plan = P._plan_of(net, torch.device('cuda'))
-x = torch.rand(1, 1504, 2016, 4, device='cuda'); t = torch.full((1,), 0.03, device='cuda'); ub = x.reshape(1, -1).max(1).values.contiguous()
+B, Hh, Ww = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (1, 1504, 2016)
+x = torch.rand(B, Hh, Ww, 4, device='cuda'); t = torch.full((B,), 0.03, device='cuda'); ub = x.reshape(B, -1).max(1).values.contiguous()
 for _ in range(3): plan.forward_nhwc4(x, t, ub=ub)
 torch.cuda.synchronize()
 acc = {}

@@ -40,6 +40,8 @@ PROTOTYPES = {
     "yond_pack_vst_norm_biaslut_f32": [vp, i32, i32, vp, i32, i32, i32, i32, f64, f64, f64, f64, f64, vp, vp, i32, vp, vp],
     "yond_bias_eval_f32": [vp, sz, vp, vp, i32, i32, i32, f64, f64, vp, vp],
     "yond_denorm_ivst_unpack_f32": [vp, i32, i32, i32, i32, i32, i32, vp, i32, f64, f64, f64, f64, f64, i32, vp],
+    "yond_pack_vst_norm_batch_f32": [vp, i32, i32, i32, vp, i32, i32, i32, i32, f64, f64, f64, f64, f64, vp, vp, i32, i32, vp, vp],
+    "yond_denorm_ivst_unpack_batch_f32": [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, f64, f64, f64, f64, f64, i32, vp],
     "yond_vst_elem_f32": [vp, sz, f64, f64, f64, vp, vp],
     "yond_ivst_elem_f64": [vp, sz, f64, f64, i32, vp, vp],
     "yond_bayer2rggb_f32": [vp, i32, i32, vp, vp],

@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
                                                             double lo, double hi, const double* __restrict__ lut_x,
                                                             const void* __restrict__ lut_y, int lut_n, int lut_flags,
                                                             unsigned int* __restrict__ img_max,
-                                                            const double* __restrict__ prm, const void* __restrict__ lut_ws, int lut_cap) {
+                                                            const double* __restrict__ prm, const void* __restrict__ lut_ws, int lut_cap,
+                                                            int B) {
+    // B frames of the same size that share every constant and the LUT (the 32 blocks of a SIDD image, YOND_SIDD.py:392-407):
+    // bayer [B][H][W], out [B][Hp][Wp][4], img_max [B]; a workgroup takes a contiguous range of the B * Hp output rows
     extern __shared__ __attribute__((aligned(16))) unsigned char lut_raw[];
     __shared__ LutLds L;
     __shared__ float s_red[4];
@@ -231,15 +234,34 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
     const double two_over_gain = 2.0 / gain;
     const double inv_span = 1.0 / (hi - lo);
     float vmax = 0.0f;
-    // rows over the workgroups, columns over the threads: no 64-bit divisions per pixel
-    for (int yp = blockIdx.x; yp < Hp; yp += gridDim.x)
+    // the frame's maximum: per frame, flushed whenever the workgroup's row range moves on to the next frame
+    auto flush_max = [&](int b) {
+        if (!img_max || b < 0) return;
+        const float m0 = wave_max(vmax);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+            atomicMax(img_max + b, __float_as_uint(m));                  // values are >= 0: uint order == float order
+        }
+    };
+    // rows over the workgroups (a contiguous range each), columns over the threads: no 64-bit divisions per pixel
+    const int rows_all = B * Hp, per = (rows_all + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int row_lo = blockIdx.x * per, row_hi = row_lo + per < rows_all ? row_lo + per : rows_all;
+    int cur_b = -1;
+    for (int row = row_lo; row < row_hi; ++row) {
+    const int bi = row / Hp, yp = row - bi * Hp;
+    if (bi != cur_b) { flush_max(cur_b); vmax = 0.0f; cur_b = bi; }
+    const float* bayer_b = bayer + (size_t)bi * H * W;
+    float* out_b = out + (size_t)bi * Hp * Wp * 4;
     for (int xp = threadIdx.x; xp < Wp; xp += 256) {
         const size_t p = (size_t)yp * Wp + xp;
         int sy = yp - pad_t, sx = xp - pad_l;
         if ((unsigned)sy >= (unsigned)h) sy = reflect101(sy, h);            // (uniform)
         if ((unsigned)sx >= (unsigned)w) sx = reflect101(sx, w);
-        const f32x2 r0 = *(const f32x2*)(bayer + (size_t)(2 * sy) * W + 2 * sx);
-        const f32x2 r1 = *(const f32x2*)(bayer + (size_t)(2 * sy + 1) * W + 2 * sx);
+        const f32x2 r0 = *(const f32x2*)(bayer_b + (size_t)(2 * sy) * W + 2 * sx);
+        const f32x2 r1 = *(const f32x2*)(bayer_b + (size_t)(2 * sy + 1) * W + 2 * sx);
         float q[4] = {r0[0], r0[1], r1[0], r1[1]};
         f32x4 o;
 #pragma unroll
@@ -260,23 +282,16 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
             o[c] = u;
             vmax = fmaxf(vmax, u);
         }
-        *(f32x4*)(out + p * 4) = o;
+        *(f32x4*)(out_b + p * 4) = o;
     }
-    if (img_max) {
-        vmax = wave_max(vmax);
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = vmax;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-            atomicMax(img_max, __float_as_uint(m));                      // values are >= 0: uint order == float order
-        }
     }
+    flush_max(cur_b);
 }
 
 static int launch_pack_vst(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b, int mode,
                            double scale, double gain, double sigma, double lo, double hi, const double* lut_x, const void* lut_y,
-                           int lut_n, int lut_flags, float* img_max, void* stream) {
-    if (!bayer || !out || H < 2 || W < 2 || (H & 1) || (W & 1)) return YOND_EINVAL;
+                           int lut_n, int lut_flags, float* img_max, void* stream, int B = 1) {
+    if (!bayer || !out || H < 2 || W < 2 || (H & 1) || (W & 1) || B < 1) return YOND_EINVAL;
     if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0) return YOND_EINVAL;
     if (mode != 0 && mode != 1) return YOND_EINVAL;
     if (lut_n < 0 || lut_n > LUT_MAX || lut_n == 1 || (lut_n > 0 && (!lut_x || !lut_y))) return YOND_EINVAL;
@@ -285,10 +300,10 @@ static int launch_pack_vst(const float* bayer, int H, int W, float* out, int pad
     hipStream_t st = (hipStream_t)stream;
     const int Hp = H / 2 + pad_t + pad_b, Wp = W / 2 + pad_l + pad_r;
     if (img_max) {
-        hipError_t e = hipMemsetAsync(img_max, 0, sizeof(float), st);
+        hipError_t e = hipMemsetAsync(img_max, 0, (size_t)B * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    size_t nb = (size_t)Hp;
+    size_t nb = (size_t)Hp * B;
     if (nb > 1536) nb = 1536;                       // every workgroup prepares the LUT once: keep them few and long-lived
     static bool attr = false;
     if (!attr) {
@@ -299,7 +314,7 @@ static int launch_pack_vst(const float* bayer, int H, int W, float* out, int pad
     const int use_lut = mode == 1 ? lut_n : 0;
     hipLaunchKernelGGL(pack_vst_norm_kernel, dim3((unsigned)nb), dim3(256), (size_t)use_lut * LUT_BYTES_PER_KNOT, st, bayer, H, W, out,
                        pad_l, pad_t, Hp, Wp, mode, (float)scale, gain, sigma, lo, hi, lut_x, lut_y, use_lut, lut_flags, (unsigned int*)img_max,
-                       (const double*)nullptr, (const void*)nullptr, 0);
+                       (const double*)nullptr, (const void*)nullptr, 0, B);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -376,7 +391,7 @@ extern "C" int yond_pack_vst_norm_dev_f32(const float* bayer, int H, int W, floa
     // (LDS: the coefficients of the caller's knot capacity: 1536 knots = 24 KB, six workgroups per CU)
     hipLaunchKernelGGL(pack_vst_norm_kernel, dim3(nb), dim3(256), lut_ws ? (size_t)lut_cap * sizeof(double2) : 0, st, bayer, H, W, out,
                        pad_l, pad_t, Hp, Wp, 1, (float)scale, 1.0, 0.0, 0.0, 1.0, (const double*)nullptr, (const void*)nullptr, 0, 0,
-                       (unsigned int*)img_max, prm, lut_ws, lut_cap);
+                       (unsigned int*)img_max, prm, lut_ws, lut_cap, 1);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -395,6 +410,17 @@ extern "C" int yond_pack_vst_norm_biaslut_f32(const float* bayer, int H, int W, 
     if (lut_n < 2) return YOND_EINVAL;
     return launch_pack_vst(bayer, H, W, out, pad_l, pad_r, pad_t, pad_b, 1, scale, gain, sigma, lo, hi, lut_x, lut_y, lut_n,
                            LUT_Y64 | LUT_BIASLUT, img_max, stream);
+}
+
+// B equally sized frames with shared constants and LUT in ONE launch (the 32 blocks of a SIDD image: 32 launches of ~15 us before,
+// each workgroup of each preparing the LUT): bayer [B][H][W] -> out [B][Hp][Wp][4], img_max [B].  biaslut != 0: lut_y is float64
+// and holds the merged row of the 2-D table (as yond_pack_vst_norm_biaslut_f32).
+extern "C" int yond_pack_vst_norm_batch_f32(const float* bayer, int B, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
+                                            double scale, double gain, double sigma, double lo, double hi, const double* lut_x,
+                                            const void* lut_y, int lut_n, int biaslut, float* img_max, void* stream) {
+    if (biaslut && lut_n < 2) return YOND_EINVAL;
+    return launch_pack_vst(bayer, H, W, out, pad_l, pad_r, pad_t, pad_b, 1, scale, gain, sigma, lo, hi, lut_x, lut_y, lut_n,
+                           biaslut ? (LUT_Y64 | LUT_BIASLUT) : 0, img_max, stream, B);
 }
 
 // the LUT alone, per element (function seam: the interp1d object of get_bias / BiasLUT.get_lut called on an array)
@@ -433,7 +459,8 @@ extern "C" int yond_bias_eval_f32(const float* x, size_t n, const double* lut_x,
 __global__ __launch_bounds__(256) void denorm_ivst_unpack_kernel(const float* __restrict__ net_out, int Wp, int pad_t,
                                                                  int pad_l, int h, int w, float* __restrict__ bayer,
                                                                  int mode, double scale, double gain, double sigma,
-                                                                 double lo, double hi, int clip01, const double* __restrict__ prm) {
+                                                                 double lo, double hi, int clip01, const double* __restrict__ prm,
+                                                                 int B, int Hp) {
     if (prm) {
         const int fl = (int)prm[YOND_PRM_FLAGS];
         if (fl & (YOND_PRM_FLAG_BAD_ESTIMATE | YOND_PRM_FLAG_LUT_CAPACITY | YOND_PRM_FLAG_NO_FLAT_AREA)) return;
@@ -443,9 +470,12 @@ __global__ __launch_bounds__(256) void denorm_ivst_unpack_kernel(const float* __
     const double sg = sigma / gain;                 // inverse_VST: sigma = sigma / gain
     const double sg2 = sg * sg;
     const double r32 = sqrt(1.5);                   // (3/2)**0.5
-    for (int y = blockIdx.x; y < h; y += gridDim.x)
+    for (int row = blockIdx.x; row < B * h; row += gridDim.x) {
+    const int bi = row / h, y = row - bi * h;                          // (B frames [Hp][Wp][4] -> [B][2h][2w], shared constants)
+    const float* net_b = net_out + (size_t)bi * Hp * Wp * 4;
+    float* bayer_b = bayer + (size_t)bi * (2 * h) * (2 * w);
     for (int x = threadIdx.x; x < w; x += 256) {
-        const f32x4 v = *(const f32x4*)(net_out + ((size_t)(y + pad_t) * Wp + x + pad_l) * 4);
+        const f32x4 v = *(const f32x4*)(net_b + ((size_t)(y + pad_t) * Wp + x + pad_l) * 4);
         float o[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -467,24 +497,37 @@ __global__ __launch_bounds__(256) void denorm_ivst_unpack_kernel(const float* __
             o[c] = (float)r;
         }
         f32x2 r0 = {o[0], o[1]}, r1 = {o[2], o[3]};
-        *(f32x2*)(bayer + (size_t)(2 * y) * (2 * w) + 2 * x) = r0;
-        *(f32x2*)(bayer + (size_t)(2 * y + 1) * (2 * w) + 2 * x) = r1;
+        *(f32x2*)(bayer_b + (size_t)(2 * y) * (2 * w) + 2 * x) = r0;
+        *(f32x2*)(bayer_b + (size_t)(2 * y + 1) * (2 * w) + 2 * x) = r1;
     }
+    }
+}
+
+static int launch_ivst(const float* net_out, int B, int Hp, int Wp, int pad_t, int pad_l, int h, int w, float* bayer_out, int mode, double scale,
+                       double gain, double sigma, double lo, double hi, int clip01, void* stream) {
+    if (!net_out || !bayer_out || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0 || B < 1) return YOND_EINVAL;
+    if (pad_t + h > Hp || pad_l + w > Wp) return YOND_EINVAL;
+    if (mode < 0 || mode > 2) return YOND_EINVAL;
+    if (mode != 0 && (!(gain > 0.0) || !(scale > 0.0))) return YOND_EINVAL;
+    size_t nb = (size_t)h * B;
+    if (nb > 256 * 16) nb = 256 * 16;
+    hipLaunchKernelGGL(denorm_ivst_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, net_out, Wp, pad_t,
+                       pad_l, h, w, bayer_out, mode, scale, gain, sigma, lo, hi, clip01, (const double*)nullptr, B, Hp);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
 }
 
 extern "C" int yond_denorm_ivst_unpack_f32(const float* net_out, int Hp, int Wp, int pad_t, int pad_l, int h, int w,
                                            float* bayer_out, int mode, double scale, double gain, double sigma,
                                            double lo, double hi, int clip01, void* stream) {
-    if (!net_out || !bayer_out || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0) return YOND_EINVAL;
-    if (pad_t + h > Hp || pad_l + w > Wp) return YOND_EINVAL;
-    if (mode < 0 || mode > 2) return YOND_EINVAL;
-    if (mode != 0 && (!(gain > 0.0) || !(scale > 0.0))) return YOND_EINVAL;
-    size_t nb = (size_t)h;
-    if (nb > 256 * 16) nb = 256 * 16;
-    hipLaunchKernelGGL(denorm_ivst_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, net_out, Wp, pad_t,
-                       pad_l, h, w, bayer_out, mode, scale, gain, sigma, lo, hi, clip01, (const double*)nullptr);
-    YOND_LAUNCH_CHECK();
-    return YOND_OK;
+    return launch_ivst(net_out, 1, Hp, Wp, pad_t, pad_l, h, w, bayer_out, mode, scale, gain, sigma, lo, hi, clip01, stream);
+}
+
+// B equally sized frames with shared constants in one launch: net_out [B][Hp][Wp][4] -> bayer_out [B][2h][2w]
+extern "C" int yond_denorm_ivst_unpack_batch_f32(const float* net_out, int B, int Hp, int Wp, int pad_t, int pad_l, int h, int w,
+                                                 float* bayer_out, int mode, double scale, double gain, double sigma,
+                                                 double lo, double hi, int clip01, void* stream) {
+    return launch_ivst(net_out, B, Hp, Wp, pad_t, pad_l, h, w, bayer_out, mode, scale, gain, sigma, lo, hi, clip01, stream);
 }
 
 extern "C" int yond_denorm_ivst_unpack_dev_f32(const float* net_out, int Hp, int Wp, int pad_t, int pad_l, int h, int w,
@@ -494,7 +537,7 @@ extern "C" int yond_denorm_ivst_unpack_dev_f32(const float* net_out, int Hp, int
     size_t nb = (size_t)h;
     if (nb > 256 * 16) nb = 256 * 16;
     hipLaunchKernelGGL(denorm_ivst_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, net_out, Wp, pad_t,
-                       pad_l, h, w, bayer_out, mode, scale, 1.0, 0.0, 0.0, 1.0, clip01, prm);
+                       pad_l, h, w, bayer_out, mode, scale, 1.0, 0.0, 0.0, 1.0, clip01, prm, 1, Hp);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

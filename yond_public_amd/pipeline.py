@@ -669,8 +669,23 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
     img_max = torch.empty(B, dtype=torch.float32, device=lr.device)
     st = L.stream()
     consts, t_host = [], []
+    # a stack whose frames share p and the LUT (the 32 blocks of a SIDD image): K1 and K4 as ONE launch each
+    shared = B > 1 and not per_frame and all(f is funcs[0] for f in funcs)
+    if shared and not lr.is_contiguous():
+        lr = lr.contiguous()
     with _stage("vst_pack"):
-        for i in range(B):
+        if shared:
+            scale, gain, sigma = float(ps[0]['scale']), np.float64(ps[0]['gain']), np.float64(ps[0]['sigma'])
+            lower, upper = vst_scalar(0, sigma, gain), vst_scalar(scale, sigma, gain)
+            consts = [(scale, gain, sigma, lower, upper)] * B
+            t_host = [float(np.float32(1 / (upper - lower) * (1.03 if bias_corr == 'pre' else 1.00)))] * B     # :284-285
+            f = funcs[0]
+            lut_n = len(f) if bias_corr is not None else 0
+            L.check(lib.yond_pack_vst_norm_batch_f32(L.ptr(lr), B, H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], scale, float(gain),
+                                                     float(sigma), float(lower), float(upper), L.ptr(f.x) if lut_n else None,
+                                                     L.ptr(f.y) if lut_n else None, lut_n, int(bool(lut_n) and isinstance(f, DeviceBiasRow)),
+                                                     L.ptr(img_max), st), "yond_pack_vst_norm_batch_f32")
+        for i in range(0 if shared else B):
             scale, gain, sigma = float(ps[i]['scale']), np.float64(ps[i]['gain']), np.float64(ps[i]['sigma'])
             lower, upper = vst_scalar(0, sigma, gain), vst_scalar(scale, sigma, gain)
             consts.append((scale, gain, sigma, lower, upper))
@@ -697,7 +712,12 @@ def VST_Denoiser(lr_raw, p, net, arch, bias_corr='pre', bias_func=None, vst_type
         y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
         out = torch.empty((B, H, W), dtype=torch.float32, device=lr.device)
         with _stage("ivst_unpack"):
-            for i in range(B):
+            if shared:
+                scale, gain, sigma, lower, upper = consts[0]
+                L.check(lib.yond_denorm_ivst_unpack_batch_f32(L.ptr(y4), B, Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out),
+                                                              2 if exact_inverse else 1, scale, float(gain), float(sigma), float(lower),
+                                                              float(upper), int(clip01), st), "yond_denorm_ivst_unpack_batch_f32")
+            for i in range(0 if shared else B):
                 scale, gain, sigma, lower, upper = consts[i]
                 L.check(lib.yond_denorm_ivst_unpack_f32(L.ptr(y4[i]), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out[i]),
                                                         2 if exact_inverse else 1, scale, float(gain), float(sigma), float(lower),

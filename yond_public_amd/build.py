@@ -63,6 +63,40 @@ def _stale(obj, src, extra_flags=()):
     return not (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == _dep_hash(src, extra_flags))
 
 
+def _write_resource_report(remarks, path):
+    import json
+    import re
+    out, cur = [], None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = {"name": m.group(1)}
+            out.append(cur)
+            continue
+        if cur is None:
+            if "warning" in line or "error" in line:
+                sys.stderr.write(line + "\n")
+            continue
+        for key, tag in (("vgprs", "VGPRs:"), ("vgpr_spill", "VGPRs Spill:"), ("sgpr_spill", "SGPRs Spill:"), ("scratch", "ScratchSize [bytes/lane]:"),
+                         ("lds", "LDS Size [bytes/block]:")):
+            m = re.search(re.escape(tag) + r"\s*(\d+)", line)
+            if m and "remark:     " + tag in line:
+                cur[key] = int(m.group(1))
+    with open(path, "w") as f:
+        json.dump(out, f)
+
+
+def resource_report():
+    """[{name (mangled), vgprs, vgpr_spill, sgpr_spill, scratch, lds}] of every kernel of the product build (from the objects' reports)."""
+    import json
+    rep = []
+    for s in sources():
+        p = _obj(s) + ".res.json"
+        if os.path.exists(p):
+            rep += json.load(open(p))
+    return rep
+
+
 STAMP = os.path.join(HERE, "libyond_hip.stamp")      # sha256 of (flags, sources, headers) the library was built from
 
 
@@ -101,7 +135,13 @@ def build_lib(force=False, verbose=True, extra_flags=(), lib=None):
             print(" ".join(cmd), flush=True)
         if os.path.exists(obj + ".hash"):
             os.remove(obj + ".hash")
-        subprocess.run(cmd, check=True)
+        # the compiler's per-kernel resource remarks ride along: registers, spills, scratch of every kernel -> <obj>.res.json
+        # (tests/test_build_report.py: no kernel the networks launch may spill)
+        r = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+        if r.returncode:
+            sys.stderr.write(r.stderr)
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        _write_resource_report(r.stderr, obj + ".res.json")
         with open(obj + ".hash", "w") as f:
             f.write(_dep_hash(src, extra_flags) + "\n")
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:

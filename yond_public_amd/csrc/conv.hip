@@ -544,7 +544,7 @@ static int launch_conv(const YondConvDesc& d, hipStream_t st) {
 //   A: 16-channel chunks, one persistent workgroup per CU, deferred epilogue   (long K loops)
 //   B:  8-channel chunks, two workgroups per CU covering each other's bubbles   (measured +8 % where it fits)
 // and between 32- / 64-wide channel tiles, by how well the tile count fills the last round of the persistent
-// grid (256 or 512 slots).  The factors are measured relative throughputs on MI355X (tools/conv_bench.py).
+// grid (256 or 512 slots).  The factors are measured relative throughputs on MI355X (round 1).
 extern "C" int yond_conv_config(int ksize, int stride, int cin, int cout, int shuffle, int N, int Ho, int Wo, int* tn,
                                 int* kc) {
     if (!((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1))) return YOND_EUNSUPPORTED;

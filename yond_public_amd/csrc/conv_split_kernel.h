@@ -57,9 +57,6 @@ extern "C" int SPLIT_DBG_READER(unsigned long long* host) {
 #else
 #define SDBG(slot) do {} while (0)
 #endif
-#ifndef SPLIT_ABL
-#define SPLIT_ABL 0          // timing-only ablations: 1 no global loads, 2 no weight DMA, 4 no epilogue, 8 no staging writes, 16 no MFMA
-#endif
 
 __host__ __device__ constexpr int yond_sp_plane_units(int H, int W) { return YOND_SP_PLANE_UNITS(H, W); }
 
@@ -109,6 +106,7 @@ struct SplitCfg {
 };
 
 // output rows m of a wave that read input row r (taps dy = r - m*stride in 0..2)
+constexpr int split_gcd(int a, int b) { return b == 0 ? a : split_gcd(b, a % b); }
 constexpr int split_pairs(int mw, int stride, int r) {
     int n = 0;
     for (int m = 0; m < mw; ++m) n += (r - m * stride >= 0 && r - m * stride <= 2) ? 1 : 0;
@@ -147,7 +145,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     constexpr int NIN = ISP ? 0 : C::NIN;                    // register-staged 16-byte items per thread and step
     constexpr int NINA = NIN > 0 ? NIN : 1;                  // (array extents)
     constexpr int NDI = ISP ? C::NDI : 0;                    // input LDS-DMAs per wave and step
-    constexpr int NG = ISP ? NDI : NIN;                      // per-tile offsets a thread keeps
+    // (K1: a thread's items k and k + PIX_ITEMS / NT are the SAME pixel of different 16-channel chunks -- one offset serves both)
+    constexpr int KD = K1 ? C::PIX_ITEMS / C::NT : NIN;      // distinct pixels among a thread's register-staged items
+    // (LDS-DMA input: a slot's unit offset inside its plane depends on the slot's position in the plane only -- slots k and k + DPER
+    // of a wave address the same units of different planes)
+    constexpr int DPER = C::WPP / split_gcd(C::WPP, 8);
+    constexpr int NG = ISP ? (NDI < DPER ? NDI : DPER) : KD;  // per-tile offsets a thread keeps
     constexpr int NOPS = C::NWT + NIN + NDI;                 // vector-memory instructions per thread and step
     constexpr int KEEP = ISP ? (C::WAHEAD == 2 ? C::NWT_MIN : 0) : C::KEEP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -234,12 +237,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         T.oy0 = (rev ? nty - 1 - c.ty : c.ty) * TH;
         if constexpr (ISP) {
 #pragma unroll
-            for (int k = 0; k < NDI; ++k) {
+            for (int k = 0; k < NG; ++k) {
                 const int sid = k * 8 + wave_s;                 // DMA wave-slot: plane sid / WPP, units (sid % WPP) * 64 ...
                 const int q = (sid % C::WPP) * 64 + lane;       // the lane's unit of the plane's LDS image
                 const int py = q / C::TWP, rem = q % C::TWP;
                 const int px = STRIDE == 2 ? 2 * (rem % C::HALF) + rem / C::HALF : rem;      // stride 2: even columns first
-                const bool valid = sid < C::NDS && q < C::UPP && px < C::IW;
+                const bool valid = q < C::UPP && px < C::IW;    // (slots past the step's last plane are refused at issue)
                 const int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
                 const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
                 T.goff[k] = !valid ? -1 : (in ? gy * d.W + gx : d.H * d.W) * 16;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             }
         } else {
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) {
+        for (int k = 0; k < KD; ++k) {
             const int it = tid + k * C::NT;
             const int pix = (it % C::PIX_ITEMS) / 4;
             const int py = pix / C::IW, px = pix % C::IW;
@@ -272,10 +275,6 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     constexpr int NSET = MW >= 3 ? 2 : 3;                     // (three rows per wave: 96 accumulator registers leave room for two sets)
     static_assert(NSET == 3 || C::WAHEAD == 1, "the two-set pipeline goes with two weight buffers");
     f32x4 vin[NSET][NINA];
-    if (SPLIT_ABL & 1) {
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) { const f32x4 z = {0.5f, 0.25f, -0.5f, 0.125f}; vin[0][k] = z; vin[1][k] = z; vin[NSET - 1][k] = z; }
-    }
     unsigned vin_ok[NSET] = {};
     float amax = 0.0f;                                         // largest |activation| this thread has staged (range guard)
     // one 16-byte load of a set (item k); the source of the chunk is selected once per step (LoadSrc)
@@ -322,14 +321,15 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     auto issue_load = [&](auto pc, auto kc, const Tile& T, const LoadSrc& L) {
         constexpr int P = decltype(pc)::value, k = decltype(kc)::value;
         constexpr int t = K1 ? (k * C::NT) / C::PIX_ITEMS : 0;  // the item's chunk (K1: PIX_ITEMS is a multiple of the thread count)
-        const bool ok = T.goff[k] >= 0;                        // outside the image: read pixel 0, zeroed at the LDS write
-        int po = T.goff[k];
-        if constexpr (K1) po = L.hi[t] ? T.goff1[k] : po;
+        constexpr int kd = k % KD;                             // (K1: the item's pixel)
+        const bool ok = T.goff[kd] >= 0;                       // outside the image: read pixel 0, zeroed at the LDS write
+        int po = T.goff[kd];
+        if constexpr (K1) po = L.hi[t] ? T.goff1[kd] : po;
         if constexpr (S2) {
             // the neighbouring output pixel (dx = 1) is the next unit; the zero unit of an outside pixel stays where it is
-            if (L.hi[t] && L.dx[t] && T.goff1[k] != 4 * d.H * d.W) po += 1;
+            if (L.hi[t] && L.dx[t] && T.goff1[kd] != 4 * d.H * d.W) po += 1;
         }
-        if (!(SPLIT_ABL & 1)) vin[P][k] = *(const f32x4*)(L.src[t] + (long long)(ok ? po : 0) * L.A[t] + L.B[t]);
+        vin[P][k] = *(const f32x4*)(L.src[t] + (long long)(ok ? po : 0) * L.A[t] + L.B[t]);
         if (k == 0) vin_ok[P] = 0;
         vin_ok[P] |= (ok ? 1u : 0u) << k;
     };
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         const int it_wave = __builtin_amdgcn_readfirstlane(it - lane);
         const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)it_wave * 16u);
         const unsigned voff = (unsigned)it * 16u;
-        if (!(SPLIT_ABL & 2) && (C::NWV % C::NT == 0 || it_wave < C::NWV))
+        if (C::NWV % C::NT == 0 || it_wave < C::NWV)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(wsrc) : "memory");
     };
     // ISP: the planes of a step's chunk(s), wave-uniform: [n][chunk][half][part][PS units]; DMA slot k of this wave moves the
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         // (wave-uniform: the DMA takes it in SGPRs.  readfirstlane returns int: through unsigned, or the low half sign-extends)
         const unsigned ga_lo = __builtin_amdgcn_readfirstlane((unsigned)ga), ga_hi = __builtin_amdgcn_readfirstlane((unsigned)(ga >> 32));
         const char* gb = (const char*)(uintptr_t)(((unsigned long long)ga_hi << 32) | ga_lo);
-        int voff = T.goff[k];
-        if constexpr (K1) voff = hi ? T.goff1[k] : voff;
-        if (voff >= 0)
+        int voff = T.goff[k % NG];
+        if constexpr (K1) voff = hi ? T.goff1[k % NG] : voff;
+        if (sid < C::NDS && voff >= 0)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(gb) : "memory");
     };
     auto weight_src = [&](int ct, int ch) {                  // wave-uniform: handed to the DMA in scalar registers
@@ -416,11 +416,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             const f32x4 v = vin[P][k];
             amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));   // two v_max3
             const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-            if (!(SPLIT_ABL & 8)) *(f16x4*)(ob + in_lds[k]) = h;
+            *(f16x4*)(ob + in_lds[k]) = h;
             if constexpr (PARTS == 2) {
                 const f16x4 l = {(_Float16)((v[0] - (float)h[0]) * 2048.0f), (_Float16)((v[1] - (float)h[1]) * 2048.0f),
                                  (_Float16)((v[2] - (float)h[2]) * 2048.0f), (_Float16)((v[3] - (float)h[3]) * 2048.0f)};
-                if (!(SPLIT_ABL & 8)) *(f16x4*)(ob + in_lds[k] + C::PLANE) = l;
+                *(f16x4*)(ob + in_lds[k] + C::PLANE) = l;
             }
         }
     };
@@ -498,19 +498,17 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             if constexpr (q + 2 < NQ) loadX(IntC<q + 2>{});
             if constexpr (wpre) loadW(IntC<dx + 1>{});
             constexpr int nmf = (PARTS == 2 ? 3 : 1) * C::NW * (K1 ? 1 : split_pairs(MW, STRIDE, r));
-            if (!(SPLIT_ABL & 16)) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {                  // 0: h_w l_x   1: h_w h_x   2: l_w h_x
-                    if (PARTS == 1 && a != 1) continue;
+            for (int a = 0; a < 3; ++a) {                  // 0: h_w l_x   1: h_w h_x   2: l_w h_x
+                if (PARTS == 1 && a != 1) continue;
 #pragma unroll
-                    for (int m = 0; m < MW; ++m) {
-                        const int dy = K1 ? (m == r ? 0 : -1) : r - m * STRIDE;
-                        if (dy < 0 || dy > 2) continue;
+                for (int m = 0; m < MW; ++m) {
+                    const int dy = K1 ? (m == r ? 0 : -1) : r - m * STRIDE;
+                    if (dy < 0 || dy > 2) continue;
 #pragma unroll
-                        for (int nn = 0; nn < C::NW; ++nn)
-                            acc[a == 1 ? 0 : 1][m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                wt[dx % WS][dy][nn][a == 2 ? PARTS - 1 : 0], xr[q % XD][a == 0 ? PARTS - 1 : 0], acc[a == 1 ? 0 : 1][m][nn], 0, 0, 0);   // D = W . X^T
-                    }
+                    for (int nn = 0; nn < C::NW; ++nn)
+                        acc[a == 1 ? 0 : 1][m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            wt[dx % WS][dy][nn][a == 2 ? PARTS - 1 : 0], xr[q % XD][a == 0 ? PARTS - 1 : 0], acc[a == 1 ? 0 : 1][m][nn], 0, 0, 0);   // D = W . X^T
                 }
             }
             if constexpr (wrep) loadW1(IntC<dx + 1>{}, IntC<wdy>{});          // behind this group's MFMAs (its last readers)
@@ -592,8 +590,15 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             const int cu = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
             const int eoff = (d.ebatch ? T.n * Cr : 0) + (K1 ? k1_cb(T.ct, cu) : cu);
             // (no branch around the loads: an absent vector is read from the weights and never used)
-            pes[nn] = *(const f32x4*)(d.escale ? d.escale + eoff : d.wpk);
-            pet[nn] = *(const f32x4*)(d.eshift ? d.eshift + eoff : d.wpk);
+            if constexpr (OSP) {
+                // the split-plane epilogue redistributes the vectors through LDS: lanes 0-7 fetch the scale, lanes 8-15 the shift,
+                // ONE register quad per block instead of two
+                const float* src = (lane & 8) ? d.eshift : d.escale;
+                pes[nn] = *(const f32x4*)(src ? src + eoff : d.wpk);
+            } else {
+                pes[nn] = *(const f32x4*)(d.escale ? d.escale + eoff : d.wpk);
+                pet[nn] = *(const f32x4*)(d.eshift ? d.eshift + eoff : d.wpk);
+            }
         }
     };
     // Residual prefetch (split-plane input kernels: their steps need no staging registers).  In-kernel stamps showed the
@@ -815,12 +820,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                     for (int g = 0; g < 4; ++g) lrr[mm - LR0][nn][g] = *(const f32x4*)res4_addr(T, nn, mm, g);
         }
         float* fw = smem + C::FILM_OFF + wave * (C::NW * 64);
-        if (lane < 8) {
+        if (lane < 16) {
 #pragma unroll
-            for (int nn = 0; nn < C::NW; ++nn) {
-                *(f32x4*)(fw + nn * 64 + 4 * lane) = pes[nn];
-                *(f32x4*)(fw + nn * 64 + 32 + 4 * lane) = pet[nn];
-            }
+            for (int nn = 0; nn < C::NW; ++nn) *(f32x4*)(fw + nn * 64 + ((lane & 8) ? 32 : 0) + 4 * (lane & 7)) = pes[nn];
         }
         const int PSo = yond_sp_plane_units(d.Ho, d.Wo);
         const int nc16o = d.Cout / 16;
@@ -1067,7 +1069,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         if (last_ch) {
             // scratch: weights(s) / input(s), which no wave reads any more; the barrier behind the epilogue keeps the next
             // step's DMA and staging writes (of OTHER waves) out of it until every wave has read its block back
-            if (computes && (!(SPLIT_ABL & 4) || d.N < 0)) {
+            if (computes) {
                 if constexpr (OSP) {
                     // straight-line variants: the residual blocks' conv1 (FiLM + SiLU) and conv2 (FiLM + residual), a plain layer
                     // with LeakyReLU; the rest generic

@@ -29,22 +29,6 @@
 // 16-byte slot of half kh = kq >> 1 (any pairing works as long as U and V agree).
 #include "common.h"
 
-#ifndef WINO_DBG
-#define WINO_DBG 0      // 1: timestamps of workgroup 0, waves 0 and 4 -> g_wino_dbg (read with yond_wino_debug_read)
-#endif
-#if WINO_DBG
-__device__ unsigned long long g_wino_dbg[2][64][8];
-extern "C" int yond_wino_debug_read(unsigned long long* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_dbg), sizeof(g_wino_dbg));
-}
-#define WDBG(slot)                                                                                  \
-    do {                                                                                            \
-        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && dbg_step < 64)              \
-            g_wino_dbg[wave >> 2][dbg_step][slot] = __builtin_readcyclecounter();                   \
-    } while (0)
-#else
-#define WDBG(slot) do {} while (0)
-#endif
 #ifndef WINO_ABL
 #define WINO_ABL 0      // timing-only ablations: 1 no input loads, 2 no weight DMA, 4 no epilogue, 8 no transform, 16 no MFMA
 #endif
@@ -407,10 +391,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
     // MFMA stretch (measured 3850 vs 1200 cycles for the same instructions).
     if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
     // one step; P = s & 1 selects the register set.  Returns false after the last step.
-    int dbg_step = 0;
-    (void)dbg_step;
     auto step = [&](auto pc) -> bool {
-        WDBG(0);
         const bool last_ch = (cs.ch + 1 == nchunk);
         const Cur cn = adv(cs);
         if (last_ch && cn.tile < total) next_ct = (cn.tile % tiles_per_img) % nct;
@@ -427,11 +408,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         // stretch: barrier-synchronised waves running the same order leave the matrix pipe idle during the ~450
         // other instructions of every step (measured: 50 % MFMA busy).  In both orders the DMA is issued before the
         // step's global loads, which is what the end-of-step wait relies on.
-        WDBG(1);
         if constexpr (VB == 1) {
             // one V image: all waves multiply, then (behind a barrier) all waves build the next image
             if (computes) mfma_all(vb, ubf);
-            WDBG(2);
             barrier_lds_only();                                 // every wave is done reading V(s)
             dma();
             if (!(WINO_ABL & 8)) { transform_load(rawA); transform_store(vn); }
@@ -440,7 +419,6 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
         } else if (wave < 4) {
             dma();
             if (computes) mfma_all(vb, ubf);
-            WDBG(2);
             if (!(WINO_ABL & 8)) { transform_load(rawA); transform_store(vn); }
             if (!(WINO_ABL & 128)) write_raw(pc, rawB);
             loads_for(pc, cl);                                  // step s+4, into the set that was just written out
@@ -449,14 +427,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
             if (!(WINO_ABL & 128)) write_raw(pc, rawB);
             dma();
             loads_for(pc, cl);
-            WDBG(2);
             if (computes) mfma_all(vb, ubf);
         }
-        WDBG(3);
         // V(s+1), U(s+1), raw(s+2) complete.  The DMA is older than this step's loads only: the loads of the previous
         // step (other register set) are waited for as well -- they have had a whole step.
         barrier_lds_keep_loads<C::NIN>();
-        WDBG(4);
         if (last_ch) {
             if (computes && (!(WINO_ABL & 4) || d.N < 0)) epilogue(cur);
             zero_acc();
@@ -470,8 +445,6 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const YondConvDesc d) {
                 cur.oy0 = (bq / ntx) * TH;
             }
         }
-        WDBG(5);
-        ++dbg_step;
         if (cn.tile >= total) return false;
         cs = cn;
         cl = adv(cl);

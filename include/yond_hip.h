@@ -467,7 +467,8 @@ int yond_conv_wgrad_ws_f32(const float* x, const float* dy, int N, int H, int W,
  * yond_conv_wgrad_split_ws_bytes returns 0 for a layer the kernel does not take (the caller keeps yond_conv_wgrad_ws_f32). */
 size_t yond_conv_wgrad_split_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, float* dw,
-                              int with_bias /* dw then has 9 Cout Cin + Cout floats: the last Cout = db[co] = sum_p dy[p][co] */,
+                              int with_bias /* bit 0: dw has 9 Cout Cin + Cout floats, the last Cout = db[co] = sum_p dy[p][co];
+                                               bit 1: the weight gradient in OIHW order, dw[co][ci][tap] */,
                               float* ws, size_t ws_bytes, int* status, void* stream);
 int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, void* stream);
 /* The guided block's middle (archs/modules.py:186-196) for training: out = SiLU(z * tk[n][c] + tb[n][c]) over z [N][P][C] with
@@ -487,6 +488,9 @@ int yond_film_mlp_bwd_f32(const float* t, const float* w1, const float* b1, cons
                           const float* dtk, const float* dtb, int B, int C, int ld, float* scratch, float* dw1, float* db1,
                           float* dW2, float* db2, float* dW3, float* db3, void* stream);
 int yond_silu_bwd_add_f32(const float* x, const float* dz, const float* dres, float* dx, size_t n, void* stream);
+/* g [N][H][W][C] = dy [N][ceil(H/2)][ceil(W/2)][C] at the even pixels, 0 elsewhere (the stride-2 layers' data gradient runs as a
+ * stride-1 convolution over it). */
+int yond_zero_interleave_f32(const float* dy, int N, int Ho, int Wo, int C, int H, int W, float* g, void* stream);
 int yond_l1_loss_f32(const float* pred, const float* target, size_t n, double* loss_sum, float* grad /* or NULL */, void* stream);
 /* L1_Charbonnier_loss (losses/base_loss.py:69-79; Unet_Loss(charbonnier=True), :82-85): loss_sum = sum sqrt(diff^2 + eps),
  * grad = diff / sqrt(diff^2 + eps) / n in the float32 steps of torch's backward */
@@ -494,6 +498,10 @@ int yond_charbonnier_loss_f32(const float* pred, const float* target, size_t n, 
                               void* stream);
 int yond_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps,
                        int step, void* stream);
+/* The same with the step's scalars on the device (hyp[0] = lr / (1 - beta1^step), hyp[1] = 1 / sqrt(1 - beta2^step) as float32), for a
+ * step captured in a hipGraph; status (two words, optional): no update when bit 0 of either is set. */
+int yond_adam_step_dev_f32(float* p, const float* g, float* m, float* v, size_t n, double beta1, double beta2, double eps,
+                           const float* hyp, const int* status, void* stream);
 
 /* Measurement aid (bench.py; not on the reference's path): one wave sleeps for `us` microseconds (<= 5 s) of wall time and
  * writes out[0] = elapsed shader cycles (s_memtime), out[1] = elapsed 100 MHz reference ticks (s_memrealtime): the clock

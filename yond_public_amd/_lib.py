@@ -97,9 +97,11 @@ PROTOTYPES = {
     "yond_film_mlp_fwd_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
     "yond_film_mlp_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "yond_silu_bwd_add_f32": [vp, vp, vp, vp, sz, vp],
+    "yond_zero_interleave_f32": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "yond_l1_loss_f32": [vp, vp, sz, vp, vp, vp],
     "yond_charbonnier_loss_f32": [vp, vp, sz, f64, vp, vp, vp],
     "yond_adam_step_f32": [vp, vp, vp, vp, sz, f64, f64, f64, f64, i32, vp],
+    "yond_adam_step_dev_f32": [vp, vp, vp, vp, sz, f64, f64, f64, vp, vp, vp],
     "yond_frame_params_f64": [vp, vp, i32, f64, f64, f64, i32, vp, vp, vp, vp],
     "yond_bias_lut_dev_f64": [vp, i32, vp, vp, vp],
     "yond_bias_lut_big_scratch": [f64, f64, i32],

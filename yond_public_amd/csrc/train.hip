@@ -283,8 +283,11 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict
 
 // (wgrad_split.hip: the split-operand weight-gradient kernel stores slices of the same form)
 // dw[i] = sum over the slices of ws[slice][i], no atomics and no zeroed output: a workgroup owns 64 consecutive elements, its four
-// waves take every fourth slice and meet in LDS.
-__global__ __launch_bounds__(256) void wgrad_reduce64_kernel(const float* __restrict__ ws, int nchunk, size_t n, float* __restrict__ dw) {
+// waves take every fourth slice and meet in LDS.  taps > 0: the first taps * cc elements ([tap][co][ci]) are written as
+// [co][ci][tap] -- the OIHW order of an nn.Conv2d weight, so that the caller needs no permute / copy pass -- the rest (the bias
+// gradient behind them) where it is.
+__global__ __launch_bounds__(256) void wgrad_reduce64_kernel(const float* __restrict__ ws, int nchunk, size_t n, float* __restrict__ dw, int taps,
+                                                             size_t cc) {
     __shared__ float part[4][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + e;
@@ -300,11 +303,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce64_kernel(const float* __rest
     part[q][e] = a0 + a1;
     __syncthreads();
     if (q == 0 && i < n) {
-        dw[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        const float v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        size_t o = i;
+        if (taps > 0 && i < (size_t)taps * cc) o = (i % cc) * taps + i / cc;
+        dw[o] = v;
     }
 }
-int yond_wgrad_reduce_launch(const float* ws, int nchunk, size_t n, float* dw, hipStream_t st) {
-    hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, ws, nchunk, n, dw);
+int yond_wgrad_reduce_launch(const float* ws, int nchunk, size_t n, float* dw, hipStream_t st, int oihw_taps, size_t cc) {
+    hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, ws, nchunk, n, dw, oihw_taps, cc);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -332,7 +338,7 @@ static void launch_wgrad(const float* x, const float* dy, WgradGeom g, float* dw
     wgrad_split<MODE, NCO>(g, chunk, wgchunks);
     g.chunk = (int)chunk;
     hipLaunchKernelGGL((wgrad_rows_kernel<MODE, NCO>), dim3((unsigned)tiles, (unsigned)wgchunks), dim3(256), 0, stream, x, dy, g, dw, ws);
-    if (ws) yond_wgrad_reduce_launch(ws, (int)wgchunks, (size_t)g.taps * g.Cout * g.Cin, dw, stream);
+    if (ws) yond_wgrad_reduce_launch(ws, (int)wgchunks, (size_t)g.taps * g.Cout * g.Cin, dw, stream, 0, 0);
 }
 
 static bool wgrad_check(const float* x, const float* dy, const float* dw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int mode, int stride) {
@@ -715,6 +721,32 @@ extern "C" int yond_silu_bwd_add_f32(const float* x, const float* dz, const floa
     return YOND_OK;
 }
 
+// The data gradient of a stride-2 layer is a stride-1 convolution over the gradient with zeros between its pixels (train.py): g[n][y][x] =
+// dy[n][y / 2][x / 2] at even (y, x), 0 elsewhere -- ONE pass (torch: a zero fill of g plus a strided copy).
+__global__ __launch_bounds__(256) void zero_interleave_kernel(const float4* __restrict__ dy, int Ho, int Wo, int H, int W, int c4, size_t n4,
+                                                              float4* __restrict__ g) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % c4);
+        size_t p = i / c4;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const size_t n = p / H;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!(x & 1) && !(y & 1)) v = dy[((n * Ho + (y >> 1)) * Wo + (x >> 1)) * c4 + c];
+        g[i] = v;
+    }
+}
+extern "C" int yond_zero_interleave_f32(const float* dy, int N, int Ho, int Wo, int C, int H, int W, float* g, void* stream) {
+    if (!dy || !g || N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || C % 4 || Ho != (H + 1) / 2 || Wo != (W + 1) / 2) return YOND_EINVAL;
+    const size_t n4 = (size_t)N * H * W * (C / 4);
+    size_t nb = (n4 + 256 * 4 - 1) / (256 * 4);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(zero_interleave_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4*)dy, Ho, Wo, H, W, C / 4, n4,
+                       (float4*)g);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
 // F.l1_loss (mean reduction) and its gradient: loss_sum += sum |pred - target| (float64), grad = sign(pred - target) * gscale
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ pred, const float* __restrict__ target, size_t n, float gscale,
                                                  double* __restrict__ loss_sum, float* __restrict__ grad) {
@@ -793,6 +825,36 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float denom = __fadd_rn(__fmul_rn(__fsqrt_rn(vi), inv_bc2_sqrt), eps);
         p[i] = __fsub_rn(p[i], __fmul_rn(step_size, __fdiv_rn(mi, denom)));
     }
+}
+
+// The same update with the step's two scalars read from the device -- hyp[0] = lr / (1 - beta1^t), hyp[1] = 1 / sqrt(1 - beta2^t), computed
+// by the host in float64 exactly as below and rounded to float32 -- so that a CAPTURED step (hipGraph) can be replayed with another
+// learning rate and step count; status (optional, two words): the update is skipped when bit 0 of either is set (a gradient or a
+// weight left fp16's range in the split-operand kernels: the host lowers the loss scale and redoes the step).
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, size_t n, float b1, float b2, const float* __restrict__ hyp, float eps,
+                                                       const int* __restrict__ status) {
+    if (status && ((status[0] | status[1]) & 1)) return;
+    const float step_size = hyp[0], inv_bc2_sqrt = hyp[1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = __fadd_rn(m[i], __fmul_rn(1.0f - b1, __fsub_rn(gi, m[i])));
+        const float vi = __fadd_rn(__fmul_rn(v[i], b2), __fmul_rn(__fmul_rn(gi, gi), 1.0f - b2));
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = __fadd_rn(__fmul_rn(__fsqrt_rn(vi), inv_bc2_sqrt), eps);
+        p[i] = __fsub_rn(p[i], __fmul_rn(step_size, __fdiv_rn(mi, denom)));
+    }
+}
+extern "C" int yond_adam_step_dev_f32(float* p, const float* g, float* m, float* v, size_t n, double beta1, double beta2, double eps,
+                                      const float* hyp, const int* status, void* stream) {
+    if (!p || !g || !m || !v || !hyp || n == 0) return YOND_EINVAL;
+    size_t nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)beta1, (float)beta2, hyp,
+                       (float)eps, status);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
 }
 
 extern "C" int yond_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps,

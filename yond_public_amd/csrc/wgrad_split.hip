@@ -432,12 +432,15 @@ static int wgs_launch(const WgsGeom& g, const WgsPlan& p, hipStream_t st) {
     return YOND_OK;
 }
 
-int yond_wgrad_reduce_launch(const float* ws, int nchunk, size_t n, float* dw, hipStream_t st);     // train.hip
+int yond_wgrad_reduce_launch(const float* ws, int nchunk, size_t n, float* dw, hipStream_t st, int oihw_taps, size_t cc);     // train.hip
 
 // dw[9][Cout][Cin] of a 3x3 stride-1 pad-1 convolution from x [N][H][W][Cin], dy [N][H][W][Cout] (float32, channels multiples of 32)
-// with_bias != 0: dw has 9 Cout Cin + Cout floats, the last Cout = db[co] = the sum over all pixels of dy (the bias gradient)
+// with_bias != 0: dw has 9 Cout Cin + Cout floats, the last Cout = db[co] = the sum over all pixels of dy (the bias gradient);
+// with_bias & 2: the weight gradient is written in OIHW order, dw[co][ci][tap] (an nn.Conv2d weight's), instead of [tap][co][ci]
 extern "C" int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, float* dw, int with_bias,
                                          float* ws, size_t ws_bytes, int* status, void* stream) {
+    const int oihw = (with_bias & 2) ? 9 : 0;
+    with_bias &= 1;
     if (!x || !dy || !dw || !ws) return YOND_EINVAL;
     const WgsPlan p = wgs_plan(N, H, W, Cin, Cout);
     if (!p.cfg) return YOND_EUNSUPPORTED;
@@ -461,5 +464,5 @@ extern "C" int yond_conv_wgrad_split_f32(const float* x, const float* dy, int N,
         default: rc = wgs_launch<1, 2, 4, 1>(g, p, st); break;
     }
     if (rc != YOND_OK) return rc;
-    return yond_wgrad_reduce_launch(ws, p.nslices, slice_floats, dw, st);
+    return yond_wgrad_reduce_launch(ws, p.nslices, slice_floats, dw, st, oihw, (size_t)Cout * Cin);
 }

@@ -135,7 +135,7 @@ def _conv_fwd(plan, w, b, ksize, stride, splits, srcs, N, H, W, shuffle=False, r
     return out
 
 
-def _wgrad(plan, x, dy, mode, stride, taps, with_bias=False):
+def _wgrad(plan, x, dy, mode, stride, taps, with_bias=False, oihw=False):
     """[taps][Cout_p][Cin_p] float32 (x, dy: padded NHWC).  The workgroups' partial sums go through one workspace that grows to the
     largest layer's need (stream order keeps its uses apart).  with_bias: returns (dw, db [Cout_p]) -- the split-operand kernel adds
     up dy's columns on the way, the other layers take yond_colsum_f32."""
@@ -149,10 +149,14 @@ def _wgrad(plan, x, dy, mode, stride, taps, with_bias=False):
                 if ws is None or ws.numel() * 4 < need:
                     ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
                 buf = torch.empty(taps * co * ci + co, dtype=torch.float32, device=x.device)
-                L.check(plan.lib.yond_conv_wgrad_split_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, co, L.ptr(buf), 1, L.ptr(ws), ws.numel() * 4,
-                                                           L.ptr(getattr(plan, 'status', None)), L.stream()), "yond_conv_wgrad_split_f32")
+                L.check(plan.lib.yond_conv_wgrad_split_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, co, L.ptr(buf), 3 if oihw else 1, L.ptr(ws),
+                                                           ws.numel() * 4, L.ptr(getattr(plan, 'status', None)), L.stream()),
+                        "yond_conv_wgrad_split_f32")
+                if oihw:                                     # [co][ci][3][3], the parameter's own order: no permute / copy pass
+                    return buf[:taps * co * ci].view(co, ci, 3, 3), buf[taps * co * ci:]
                 return buf[:taps * co * ci].view(taps, co, ci), buf[taps * co * ci:]
-        return _wgrad(plan, x, dy, mode, stride, taps), _colsum(plan, dy)
+        dw = _wgrad(plan, x, dy, mode, stride, taps)
+        return (dw.permute(1, 2, 0).reshape(co, ci, 3, 3) if oihw else dw), _colsum(plan, dy)
     N, H, W, ci = x.shape
     _, Ho, Wo, co = dy.shape
     dw = torch.empty((taps, co, ci), dtype=torch.float32, device=x.device)
@@ -206,17 +210,19 @@ class _Conv3x3(torch.autograd.Function):
         N, H, W, cin_p = x.shape
         cout, cin = w.shape[0], w.shape[1]
         if WGRAD_BIAS:
-            dw, db = _wgrad(plan, x, dy, 0, stride, 9, with_bias=True)
+            dw, db = _wgrad(plan, x, dy, 0, stride, 9, with_bias=True, oihw=True)
+            dw = dw if (dw.shape[0] == cout and dw.shape[1] == cin) else dw[:cout, :cin].contiguous()
         else:
             dw, db = _wgrad(plan, x, dy, 0, stride, 9), _colsum(plan, dy)
-        dw = dw[:, :cout, :cin].permute(1, 2, 0).reshape(cout, cin, 3, 3)
+            dw = dw[:, :cout, :cin].permute(1, 2, 0).reshape(cout, cin, 3, 3)
         db = db[:cout]
         dx = None
         if ctx.need_dx:
             g = dy
             if stride == 2:                            # zero-interleave: the stride-2 layer's adjoint = a stride-1 one on this
-                g = torch.zeros((N, H, W, dy.shape[-1]), dtype=torch.float32, device=dy.device)
-                g[:, ::2, ::2] = dy
+                g = torch.empty((N, H, W, dy.shape[-1]), dtype=torch.float32, device=dy.device)
+                L.check(plan.lib.yond_zero_interleave_f32(L.ptr(dy), N, dy.shape[1], dy.shape[2], dy.shape[-1], H, W, L.ptr(g), L.stream()),
+                        "yond_zero_interleave_f32")
             dx = _conv_fwd(plan, w, None, 3, 1, [cout], [g], N, H, W, role='dgrad',
                            xf=lambda t: t.flip(2, 3).transpose(0, 1).contiguous())          # [cin][cout][2-ky][2-kx]
             dx = _pad_c(dx[..., :cin], cin_p) if dx.shape[-1] != cin_p else dx

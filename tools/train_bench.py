@@ -38,6 +38,7 @@ ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--nf', type=int, default=32)
 ap.add_argument('--conv', default='split')
+ap.add_argument('--graph', type=int, default=1)
 ap.add_argument('--set', action='append', default=[], help='A/B: NAME=VALUE module attributes of yond_public_amd.train (e.g. WGRAD_BIAS=0)')
 a = ap.parse_args()
 import yond_public_amd.train as _T
@@ -52,13 +53,13 @@ torch.manual_seed(0)
 net = getattr(A, a.net)(arch)
 A.initialize_weights(net)
 net = net.to(dev)
-ts = TrainStep(net, lr=1e-4, ddp=False, conv=a.conv)
+ts = TrainStep(net, lr=1e-4, ddp=False, conv=a.conv, graph=bool(a.graph))
 g = torch.Generator(device='cpu').manual_seed(1)
 hr = torch.rand(a.batch, 4, 128, 128, generator=g).to(dev)
 sigma = (torch.rand(a.batch, 1, 1, 1, generator=g) * 0.18 + 0.02).to(dev)
 lr = (hr + torch.randn(hr.shape, generator=g).to(dev) * sigma).clamp(0, 1)
 sg = sigma if 'guided' in arch else None
-for _ in range(2):
+for _ in range(4):                                           # (two eager steps, the capture, one replay)
     ts.step(lr, hr, sg)
 torch.cuda.synchronize()
 t0 = time.perf_counter()

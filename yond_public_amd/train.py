@@ -22,6 +22,7 @@ gradients in two 25 MB buckets launched from backward's hooks (the only collecti
 Pinned by tests/golden/train.npz (loss, gradients and updated weights of the reference's own step on the same inputs) and
 tests/golden/train_sched.npz (the reference's schedules, a two-epoch run of its loop, its Charbonnier loss)."""
 import math
+import types
 
 import numpy as np
 import torch
@@ -423,7 +424,7 @@ class _ConvT2x2(torch.autograd.Function):
 class TrainStep:
     """One optimisation step of a yond_public_amd.archs.GuidedResUnet or UNetSeeInDark (parameter names / shapes of the reference)."""
 
-    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, charbonnier=False, ddp=None, conv='split', loss_scale=None):
+    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, charbonnier=False, ddp=None, conv='split', loss_scale=None, graph=True):
         """conv: 'split' -- forward and data-gradient 3x3 convolutions as fp32-accurate split-operand products on the fp16 matrix
         cores (the inference path's kernels; 22-bit operands, fp32 accumulation); 'fp32' -- every convolution on the fp32-input
         MFMA kernels (exact fp32 products).
@@ -434,8 +435,14 @@ class TrainStep:
         two that puts S/n into (1/16, 1/8]; 1: no scaling.  A gradient or activation that leaves fp16's range (|a| > 65504)
         is reported by the kernels' status word, read once per step: the step is redone at S/256, twice at most.  charbonnier: Unet_Loss(charbonnier=True) (losses/base_loss.py:82-85).  ddp: None -- average the gradients over the
         ranks whenever a process group exists (the reference wraps the net in DDP whenever it sees more than one GPU,
-        trainer_AWGN.py:59-61); False -- never."""
+        trainer_AWGN.py:59-61); False -- never.
+        graph: replay the step (gather, forward, loss, backward, unscale, Adam: ~500 launches) as ONE hipGraph from the third step of
+        a given batch shape on -- single process only (a gradient all-reduce inside a captured region is not attempted).  The
+        inputs are copied into the graph's fixed buffers; the returned gradients and `last_pred` are then the graph's own buffers,
+        overwritten by the next step."""
         from . import distributed as D
+        self.graph = bool(graph)
+        self._graphs, self._seen = {}, {}
         self.m = module
         self.dev = next(module.parameters()).device
         self.plan = _plan(self.dev)
@@ -634,6 +641,66 @@ class TrainStep:
         pred.backward(dpred)                                 # (the reducer's hooks launch a bucket's all-reduce as its last gradient lands)
         return pred, loss_sum
 
+    # -- the step as one hipGraph ------------------------------------------------------------------------------------
+    def _hyp(self, t):
+        """The two scalars of Adam step t, in float64 as yond_adam_step_f32 computes them (csrc/train.hip)."""
+        return [self.lr / (1.0 - self.betas[0] ** t), 1.0 / math.sqrt(1.0 - self.betas[1] ** t)]
+
+    def _flat_grad(self, S):
+        zero = self.arena.new_zeros(1)
+        flat = torch.cat([zero] + [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params.values()])
+        if S != 1.0:
+            flat.mul_(1.0 / S)                               # exact
+        return flat
+
+    def _capture(self, imgs_lr, imgs_hr, sigma, S):
+        """Capture gather + forward + loss + backward + unscale + Adam at loss scale S for this batch shape.  Adam reads its step
+        scalars from g.hyp and does nothing when the step's status words report a range trip or a non-finite loss (word 2), so a
+        replay never writes a bad update: the host then redoes the step at a lower scale, as the eager path does."""
+        g = types.SimpleNamespace(S=S)
+        g.lr_in, g.hr_in = imgs_lr.detach().clone(), imgs_hr.detach().clone()
+        g.sigma = None if sigma is None else sigma.detach().clone()
+        g.hyp = torch.zeros(2, dtype=torch.float32, device=self.dev)
+        lib = self.plan.lib
+        g.graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.dev)
+        with torch.cuda.graph(g.graph):
+            g.pred, g.loss_sum = self._fwd_bwd(g.lr_in, g.hr_in, g.sigma, S)
+            self.plan.status[2:3].copy_(torch.logical_not(torch.isfinite(g.loss_sum)).to(torch.int32))
+            g.flat = self._flat_grad(S)
+            L.check(lib.yond_adam_step_dev_f32(L.ptr(self.arena), L.ptr(g.flat), L.ptr(self.adam_m), L.ptr(self.adam_v), self.arena.numel(),
+                                               self.betas[0], self.betas[1], self.eps, L.ptr(g.hyp), L.ptr(self.plan.status), L.stream()),
+                    "yond_adam_step_dev_f32")
+        return g
+
+    def _graph_step(self, key, imgs_lr, imgs_hr, sigma, S):
+        """One replay.  Returns (loss, grads) or None when the step tripped the range guard (no update was applied)."""
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = self._capture(imgs_lr, imgs_hr, sigma, S)
+        g.lr_in.copy_(imgs_lr)
+        g.hr_in.copy_(imgs_hr)
+        if sigma is not None:
+            g.sigma.copy_(sigma)
+        g.hyp.copy_(torch.tensor(self._hyp(self.t + 1), dtype=torch.float64).to(torch.float32), non_blocking=False)
+        g.graph.replay()
+        st = self.plan.status.cpu()                          # (the step's synchronisation point)
+        if int(st[1]) & 1:
+            raise L.YondHipError("TrainStep: a weight left fp16's range (|w| > 65504): the split-operand kernels cannot take it "
+                                 "(TrainStep(conv='fp32') keeps every convolution on the fp32-input MFMA)")
+        if int(st[0]) & 1:
+            return None
+        loss = float(g.loss_sum.item()) / g.pred.numel()
+        if not math.isfinite(loss):
+            raise L.YondHipError(f"TrainStep: the loss is {loss}: no update applied")
+        self.t += 1
+        self.last_scale = S
+        self._clean_steps = getattr(self, '_clean_steps', 0) + 1
+        self.last_pred = g.pred.detach()
+        self.plan.wbatch = None
+        self.m._plan = None
+        return loss, {k: g.flat[o:o + c].view(self.params[k].shape) for k, (o, c) in self.slots.items()}
+
     # -- loss, backward, Adam ----------------------------------------------------------------------------------------
     def step(self, imgs_lr, imgs_hr, sigma=None):
         """trainer_AWGN.py:101-117 for one batch (`pred = net(imgs_lr, sigma)` for a guided net, `net(imgs_lr)` otherwise).
@@ -641,6 +708,13 @@ class TrainStep:
         lib = self.plan.lib
         n_out = imgs_hr.numel()
         S = self._scale_for(n_out)
+        if self.graph and self.reducer is None and self.dev.type == 'cuda':
+            key = (tuple(imgs_lr.shape), tuple(imgs_hr.shape), None if sigma is None else tuple(sigma.shape), S)
+            self._seen[key] = self._seen.get(key, 0) + 1
+            if self._seen[key] > 2:                          # (two eager steps first: every lazily built buffer exists by then)
+                out = self._graph_step(key, imgs_lr, imgs_hr, sigma, S)
+                if out is not None:
+                    return out                               # (else: a range trip, nothing updated -- the eager path lowers the scale)
         for attempt in range(3):
             pred, loss_sum = self._fwd_bwd(imgs_lr, imgs_hr, sigma, S)
             if self.reducer is not None:
@@ -667,10 +741,7 @@ class TrainStep:
         if self.reducer is not None:
             self.reducer.finish()                            # .grad = the mean over the ranks
         self.t += 1
-        zero = self.arena.new_zeros(1)
-        flat = torch.cat([zero] + [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params.values()])
-        if S != 1.0:
-            flat.mul_(1.0 / S)                               # exact
+        flat = self._flat_grad(S)
         grads = {k: flat[o:o + c].view(self.params[k].shape) for k, (o, c) in self.slots.items()}
         if self.params[next(iter(self.params))].data_ptr() != self.arena.data_ptr() + 4:
             raise L.YondHipError("TrainStep: the module's parameters were moved (.to / .float) after the step object was built")

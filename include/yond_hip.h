@@ -419,6 +419,12 @@ int yond_block_metrics_f32(const float* dn, const float* hr, int H, int W, int b
 int yond_frame_params_f64(const void* nle_ws, const float* max_dev, int mode,
                           double scale_est /* wp - bl: beta -> (K, sigma) in DN, :356 */, double scale /* p['scale'] = (wp - bl) / ratio: the VST's DN scale, :251 */,
                           double tfac, int lut_cap, double* prm, float* t_out, double* lut_x, void* stream);
+/* The frame chain as ONE launch: yond_frame_params_f64 + yond_bias_lut_dev_f64 + yond_lut_table_f64 (same block, knots, ordinates,
+ * table and flags).  Every workgroup derives the parameters itself, integrates one knot, and the last to arrive writes the table.
+ * nle_ws: the estimator's workspace after yond_nle_moments_f32 (its arrival counter, word 2 of the state's tickets, is left at zero);
+ * lut_y [lut_cap] float32, lut_ws yond_lut_ws_bytes(lut_cap) bytes. */
+int yond_frame_chain_f64(void* nle_ws, const float* max_dev, int mode, double scale_est, double scale, double tfac, int lut_cap,
+                         double* prm, float* t_out, double* lut_x, float* lut_y, void* lut_ws, void* stream);
 /* Row H for large K * sigma (14-bit sensors at a digital gain: the Gaussian table of the integration exceeds the LDS and
  * yond_bias_lut_f64 returns YOND_EUNSUPPORTED): the same integration with the table in a caller-provided scratch buffer of
  * yond_bias_lut_big_scratch(gain, sigma, nwg) doubles, nwg workgroups striding over the knots.  Seconds, not microseconds. */
@@ -442,6 +448,12 @@ int yond_lut_table_f64(const double* lut_x, const float* lut_y, int n, const dou
 int yond_pack_vst_norm_dev_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
                                double scale, const double* prm, const void* lut_ws /* NULL: no bias correction */,
                                int lut_cap /* the capacity lut_ws was prepared for */, float* img_max, void* stream);
+/* K1 of the device chain proper: as yond_pack_vst_norm_dev_f32 for the table yond_frame_chain_f64 / yond_lut_table_f64 prepared from
+ * get_bias' knot grid (<= 3 evenly spaced runs of non-zero width), with the affine tail of the normalisation folded into the table's coefficients
+ * (6 float64 operations per element instead of 11; the float32 result differs from yond_pack_vst_norm_dev_f32's for about one element
+ * in 1e8, by one ulp).  prm is also written: a table of another shape sets YOND_PRM_FLAG_LUT_CAPACITY and nothing is computed. */
+int yond_pack_vst_norm_chain_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
+                                 double scale, double* prm, const void* lut_ws, int lut_cap, float* img_max, void* stream);
 int yond_denorm_ivst_unpack_dev_f32(const float* net_out, int Hp, int Wp, int pad_t, int pad_l, int h, int w, float* bayer,
                                     int mode, double scale, const double* prm, int clip01, void* stream);
 

@@ -132,6 +132,88 @@ def test_device_knot_grid_bit_identical(ub):
     assert np.array_equal(lut_x.cpu().numpy()[:n], want)
 
 
+@pytest.mark.parametrize("ub,mom,mode", [(961.0, [100, 30, 0.3, 10, 0.1] * 2, 0), (137.0, [5e5, 1.2e5, 900.0, 4.1e4, 310.0, 4e5, 1.0e5, 800.0, 3.5e4, 260.0], 1),
+                                         (17.0, [100, 30, 0.3, 10, 0.1] * 2, 0), (2500.0, [100, 30, 0.3, 10, 0.1] * 2, 0),
+                                         (961.0, [100, 30, -0.3, 10, -0.1] * 2, 0), (961.0, [0.0] * 10, 0)])
+def test_frame_chain_one_launch_equals_three(ub, mom, mode):
+    """yond_frame_chain_f64 (parameters + knots + bias LUT + prepared table in one launch) against the three launches it replaces:
+    the same parameter block, knots, ordinates and table, bit for bit -- also for the flagged frames (more knots than the capacity,
+    K <= 0, no flat area) and when called twice on the same workspace (the arrival counter goes back to zero)."""
+    from yond_public_amd import _lib as L
+    from yond_public_amd import pipeline as P
+    lib = L.load()
+    mx = np.float32(ub - 1.0) - np.float32(0.3)
+    ws = torch.zeros(int(lib.yond_nle_ws_bytes(1024)), dtype=torch.uint8, device=DEV)
+    off_mom = P._nle_layout()[2]
+    ws[off_mom:off_mom + 80] = torch.from_numpy(np.array(mom, np.float64).view(np.uint8)).to(DEV)
+    mxd = torch.tensor([float(mx) / 959.0], dtype=torch.float32, device=DEV)
+
+    def bufs():
+        return (torch.full((16,), -7.0, dtype=torch.float64, device=DEV), torch.zeros(1, dtype=torch.float32, device=DEV),
+                torch.zeros(P.LUT_CAP, dtype=torch.float64, device=DEV), torch.zeros(P.LUT_CAP, dtype=torch.float32, device=DEV),
+                torch.zeros(int(lib.yond_lut_ws_bytes(P.LUT_CAP)), dtype=torch.uint8, device=DEV))
+    prm, t, lx, ly, lw = bufs()
+    L.check(lib.yond_frame_params_f64(L.ptr(ws), L.ptr(mxd), mode, 959.0, 959.0, 1.03, P.LUT_CAP, L.ptr(prm), L.ptr(t), L.ptr(lx), L.stream()), "params")
+    L.check(lib.yond_bias_lut_dev_f64(L.ptr(lx), P.LUT_CAP, L.ptr(prm), L.ptr(ly), L.stream()), "lut")
+    L.check(lib.yond_lut_table_f64(L.ptr(lx), L.ptr(ly), -1, L.ptr(prm), L.ptr(lw), L.stream()), "table")
+    for rep in range(2):
+        prm2, t2, lx2, ly2, lw2 = bufs()
+        L.check(lib.yond_frame_chain_f64(L.ptr(ws), L.ptr(mxd), mode, 959.0, 959.0, 1.03, P.LUT_CAP, L.ptr(prm2), L.ptr(t2), L.ptr(lx2),
+                                         L.ptr(ly2), L.ptr(lw2), L.stream()), "chain")
+        torch.cuda.synchronize()
+        a, b = prm.cpu().numpy(), prm2.cpu().numpy()
+        print(f"[parity] frame chain ub {ub}: flags {int(a[P.PRM['flags']])}, {int(a[P.PRM['lut_n']])} knots, K {a[P.PRM['gain']]:.4f}")
+        assert np.array_equal(a[:14].view(np.uint64), b[:14].view(np.uint64))
+        assert torch.equal(t.view(torch.int32), t2.view(torch.int32)) and torch.equal(lx, lx2) and torch.equal(ly, ly2)     # (t may be NaN)
+        n = int(a[P.PRM['lut_n']]) if not (int(a[P.PRM['flags']]) & 10) else 0
+        hd, hd2 = lw[:144].cpu().numpy(), lw2[:144].cpu().numpy()
+        assert np.array_equal(hd[:16], hd2[:16])                 # n, nseg, nbreak
+        if n >= 2:
+            ns = int(hd[4:8].view(np.int32)[0])                     # (entries beyond the runs in use are whatever the LDS held)
+            for o, cnt in ((16, ns), (48, ns), (80, ns + 1)):
+                assert np.array_equal(hd[o:o + 4 * cnt], hd2[o:o + 4 * cnt])
+            ab0, x0 = 144, 144 + 4096 * 16
+            assert torch.equal(lw[ab0:ab0 + 16 * n], lw2[ab0:ab0 + 16 * n]) and torch.equal(lw[x0:x0 + 8 * n], lw2[x0:x0 + 8 * n])
+
+
+@pytest.mark.parametrize("H,W,K,sg,expo", [(512, 768, 4.0, 6.0, 1.0), (130, 258, 1.0, 12.0, 0.2), (64, 2100, 9.0, 2.0, 0.04)])
+def test_chain_k1_equals_general_k1(H, W, K, sg, expo):
+    """yond_pack_vst_norm_chain_f32 (affine tail folded into the table's coefficients, runs in registers, branch-free root) against
+    yond_pack_vst_norm_dev_f32 on the same parameter block and table: the float64 value moves by ~1e-16, so after the one rounding to
+    float32 at most a handful of elements differ, by one ulp; one, two and three runs of knots (frame maxima below 50, below 500, above)."""
+    import yond_oracle as O
+    from yond_public_amd import _lib as L
+    from yond_public_amd import pipeline as P
+    lib = L.load()
+    noisy, _ = O.synth_noisy(H, W, K, sg, 7)
+    x = torch.from_numpy((noisy * expo).astype(np.float32)).to(DEV)
+    x[0, :8] = -0.01                                             # (negative input: the VST argument clamps at zero)
+    pipe = {'k': 29}
+    p = {'wp': 1023.0, 'bl': 64.0, 'scale': 959.0}
+    buf = P._chain_buffers(x.device, 0)
+    P._chain_estimate(x, None, 'self', pipe, p, buf)
+    h, w = H // 2, W // 2
+    p2d = P.get_p2d((1, 4, h, w), base=32)
+    Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
+    outs, maxes = [], []
+    for fn in (lib.yond_pack_vst_norm_dev_f32, lib.yond_pack_vst_norm_chain_f32):
+        o = torch.full((Hp, Wp, 4), -1.0, dtype=torch.float32, device=DEV)
+        mx = torch.zeros(1, dtype=torch.float32, device=DEV)
+        L.check(fn(L.ptr(x), H, W, L.ptr(o), p2d[0], p2d[1], p2d[2], p2d[3], 959.0, L.ptr(buf.prm), L.ptr(buf.lut_ws), P.LUT_CAP, L.ptr(mx),
+                   L.stream()), "K1")
+        outs.append(o)
+        maxes.append(mx)
+    torch.cuda.synchronize()
+    prm = buf.prm.cpu().numpy()
+    assert int(prm[P.PRM['flags']]) == 0
+    a, b = outs[0].cpu().numpy(), outs[1].cpu().numpy()
+    diff = np.abs(a - b)
+    ndiff = int((diff > 0).sum())
+    print(f"[parity] chain K1 vs general K1 {H}x{W}: {int(prm[P.PRM['lut_n']])} knots, {ndiff} of {a.size} elements differ, max {diff.max():.2e}")
+    assert a.min() >= 0.0 and diff.max() <= 6e-8 and ndiff <= max(2, a.size // 1000000)
+    assert abs(float(maxes[0]) - float(maxes[1])) <= 6e-8
+
+
 def test_block_metrics_vs_oracle():
     import yond_oracle as O
     from yond_public_amd import pipeline as P

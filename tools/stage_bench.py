@@ -62,6 +62,8 @@ print("  of it: frame params %.1f us, bias LUT %.1f us, table %.1f us" % (
     t(lambda: lib.yond_frame_params_f64(L.ptr(ws), None, 0, 959.0, 959.0, 1.03, P.LUT_CAP, L.ptr(buf.prm), L.ptr(buf.t), L.ptr(buf.lut_x), st)),
     t(lambda: lib.yond_bias_lut_dev_f64(L.ptr(buf.lut_x), P.LUT_CAP, L.ptr(buf.prm), L.ptr(buf.lut_y), st)),
     t(lambda: lib.yond_lut_table_f64(L.ptr(buf.lut_x), L.ptr(buf.lut_y), -1, L.ptr(buf.prm), L.ptr(buf.lut_ws), st))))
+print("device chain as ONE launch (yond_frame_chain_f64): %.1f us" % t(lambda: lib.yond_frame_chain_f64(
+    L.ptr(ws), None, 0, 959.0, 959.0, 1.03, P.LUT_CAP, L.ptr(buf.prm), L.ptr(buf.t), L.ptr(buf.lut_x), L.ptr(buf.lut_y), L.ptr(buf.lut_ws), st)))
 torch.cuda.synchronize()
 prm = buf.prm.cpu().numpy()
 print("  parameter block: flags %d, K %.4f, sigma %.4f, %d knots" % (int(prm[P.PRM['flags']]), prm[P.PRM['gain']], prm[P.PRM['sigma']], int(prm[P.PRM['lut_n']])))
@@ -72,6 +74,7 @@ x4 = torch.empty(Hp, Wp, 4, device='cuda')
 mx = torch.empty(1, device='cuda')
 out = torch.empty(H, W, device='cuda')
 print("K1 (prepared table, constants from the block): %.1f us" % t(lambda: lib.yond_pack_vst_norm_dev_f32(L.ptr(x), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], 959.0, L.ptr(buf.prm), L.ptr(buf.lut_ws), P.LUT_CAP, L.ptr(mx), st)))
+print("K1 (the chain's kernel: folded coefficients, runs in registers): %.1f us" % t(lambda: lib.yond_pack_vst_norm_chain_f32(L.ptr(x), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], 959.0, L.ptr(buf.prm), L.ptr(buf.lut_ws), P.LUT_CAP, L.ptr(mx), st)))
 lut = P.get_bias(np.float32(noisy.max()) * np.float32(959.0), np.float64(6.0), np.float64(4.0), device=x.device)
 lo, hi = P.vst_scalar(0, np.float64(6.0), np.float64(4.0)), P.vst_scalar(959.0, np.float64(6.0), np.float64(4.0))
 print("K1 (host-side entry: table derived per workgroup): %.1f us" % t(lambda: lib.yond_pack_vst_norm_f32(L.ptr(x), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], 1, 959.0, 4.0, 6.0, float(lo), float(hi), L.ptr(lut.x), L.ptr(lut.y), len(lut), L.ptr(mx), st)))

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "yond_adam_step_f32": [vp, vp, vp, vp, sz, f64, f64, f64, f64, i32, vp],
     "yond_adam_step_dev_f32": [vp, vp, vp, vp, sz, f64, f64, f64, vp, vp, vp],
     "yond_frame_params_f64": [vp, vp, i32, f64, f64, f64, i32, vp, vp, vp, vp],
+    "yond_frame_chain_f64": [vp, vp, i32, f64, f64, f64, i32, vp, vp, vp, vp, vp, vp],
     "yond_bias_lut_dev_f64": [vp, i32, vp, vp, vp],
     "yond_bias_lut_big_scratch": [f64, f64, i32],
     "yond_bias_points_scratch": [f64, f64, i32, i32, f64, i32],
@@ -111,6 +112,7 @@ PROTOTYPES = {
     "yond_lut_ws_bytes": [i32],
     "yond_lut_table_f64": [vp, vp, i32, vp, vp, vp],
     "yond_pack_vst_norm_dev_f32": [vp, i32, i32, vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, vp],
+    "yond_pack_vst_norm_chain_f32": [vp, i32, i32, vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, vp],
     "yond_denorm_ivst_unpack_dev_f32": [vp, i32, i32, i32, i32, i32, i32, vp, i32, f64, vp, i32, vp],
 }
 # experiment builds only (include/yond_hip_experiments.h): bound when the loaded library has them

@@ -11,6 +11,22 @@
 // exact (separately rounded multiply and add) because scipy's poisson.pmf is zero wherever x_j is not
 // exactly an integer -- a rounding artefact of the reference that has to be reproduced, not fixed.
 #include "common.h"
+#include "frame_params.h"
+#include "lut_table.h"
+
+// The frame chain as ONE launch (yond_frame_chain_f64): every workgroup derives the frame's parameters from the estimator's moment
+// sums itself (a few hundred scalar float64 operations: cheaper than a launch of their own), integrates its knot, and the workgroup
+// that arrives last turns knots and ordinates into K1's prepared table.  st == nullptr: the plain LUT kernel.
+struct FrameChain {
+    const NleState* st;
+    const float* max_dev;
+    double scale_est, scale, tfac;
+    double* lut_x;
+    float* t_out;
+    void* lut_ws;
+    unsigned int* ticket;
+    int mode, lut_cap, smem_bytes;
+};
 
 __device__ __forceinline__ double linspace_pt(int j, int l, double start, double stop, double step) {
     if (j == l - 1) return stop;
@@ -35,10 +51,39 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
 __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict__ lams, int n, double K, double sigma,
                                                        double th, int pho, int lmax, float* __restrict__ bias,
                                                        double* __restrict__ prm, int smem_doubles, double* __restrict__ gbuf,
-                                                       double* __restrict__ bias64 = nullptr) {
+                                                       double* __restrict__ bias64, FrameChain fc) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double s_red[4];
-    if (prm) {
+    __shared__ FrameParams s_fp;
+    const bool chain = fc.st != nullptr;
+    if (chain) {
+        if (threadIdx.x == 0) {
+            frame_params_compute(s_fp, fc.st, fc.max_dev, fc.mode, fc.scale_est, fc.scale, fc.tfac, fc.lut_cap);
+            // the derived constants as the host entry computes them; more LDS than this launch has: host path
+            K = s_fp.gain; sigma = s_fp.sigma;
+            if (!(s_fp.flags & (YOND_PRM_FLAG_BAD_ESTIMATE | YOND_PRM_FLAG_LUT_CAPACITY))) {
+                int ph = (int)sqrt(K);
+                if (ph < 1) ph = 1;
+                const double t = K < 1.0 ? 50.0 * K : 50.0 * sqrt(K);
+                const int rmax = (int)(t * (1.0 / K) * 2.0 + sigma * 2.0 + t + 10.0) + 1;
+                if (2 * ph * rmax + 1 + rmax + 2 > smem_doubles) s_fp.flags |= YOND_PRM_FLAG_LUT_CAPACITY;
+            }
+            if (blockIdx.x == 0) frame_params_store(s_fp, prm, fc.t_out);
+        }
+        __syncthreads();
+        K = s_fp.gain; sigma = s_fp.sigma;
+        n = (s_fp.flags & (YOND_PRM_FLAG_BAD_ESTIMATE | YOND_PRM_FLAG_LUT_CAPACITY)) ? 0 : s_fp.nk;
+        if (n > 0) {
+            pho = (int)sqrt(K);
+            if (pho < 1) pho = 1;
+            th = K < 1.0 ? 50.0 * K : 50.0 * sqrt(K);
+            const int rmax = (int)(th * (1.0 / K) * 2.0 + sigma * 2.0 + th + 10.0) + 1;
+            lmax = 2 * pho * rmax + 1;
+        }
+        // (the knots: what the last workgroup and the host read -- stored past this XCD's L2, like the ordinates below)
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < s_fp.nk; i += 256) __hip_atomic_store(&fc.lut_x[i], frame_knot(s_fp, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (prm) {
         // (n, K, sigma) from the frame's parameter block (frame_chain.hip); the derived constants as the host entry computes them
         const int fl = (int)prm[YOND_PRM_FLAGS];
         n = (int)prm[YOND_PRM_LUT_N];
@@ -62,7 +107,7 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
     const int tid = threadIdx.x;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
     __syncthreads();                       // (the tables of the previous knot are no longer read)
-    const double lam = lams[i];
+    const double lam = chain ? frame_knot(s_fp, i) : lams[i];
     if (lam > th) {
         if (tid == 0) {
             // close_form_bias (utils/isp_algos.py:84-96)
@@ -73,7 +118,9 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
             const double m2 = y / (yh2 * yh);
             const double m3 = (y + 3.0 * (y + sg * sg) * (y + sg * sg)) / (yh2 * yh2);
             const double cf = 2.0 * sqrt(yh) * (-1.0 / 8.0 * m1 + 1.0 / 16.0 * m2 - 5.0 / 128.0 * m3);
-            if (bias64) bias64[i] = cf; else bias[i] = (float)cf;
+            if (bias64) bias64[i] = cf;
+            else if (chain) __hip_atomic_store(&bias[i], (float)cf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else bias[i] = (float)cf;
         }
         continue;
     }
@@ -142,15 +189,41 @@ __global__ __launch_bounds__(256) void bias_lut_kernel(const double* __restrict_
     if (tid == 0) {
         // p = conv / (sum/pho);  bias = sum(p * V / pho) - VST(lam)
         const double e = spv / (sp / (double)pho) / (double)pho;
-        if (bias64) bias64[i] = e - vst_d(lam, sigma, K); else bias[i] = (float)(e - vst_d(lam, sigma, K));
+        if (bias64) bias64[i] = e - vst_d(lam, sigma, K);
+        else if (chain) __hip_atomic_store(&bias[i], (float)(e - vst_d(lam, sigma, K)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else bias[i] = (float)(e - vst_d(lam, sigma, K));
     }
     }
+    if (!chain) return;
+    // ---- the workgroup that arrives last: K1's prepared table (yond_lut_table_f64's kernel, vst.hip) ----
+    if (!nf_arrive_last(fc.ticket, gridDim.x)) return;
+    if (tid == 0) *fc.ticket = 0;                                  // (the workspace can take the next call)
+    __shared__ LutLds L;
+    LutHeader* hd = (LutHeader*)fc.lut_ws;
+    if (n < 2 || (size_t)n * LUT_BYTES_PER_KNOT > (size_t)fc.smem_bytes) {
+        if (tid == 0) {
+            hd->n = 0; hd->nseg = 0; hd->nbreak = 0;
+            if (n >= 2) prm[YOND_PRM_FLAGS] = (double)(s_fp.flags | YOND_PRM_FLAG_LUT_CAPACITY);
+        }
+        return;
+    }
+    if (tid == 0) {
+        L.ab = (double2*)sm;
+        L.x = (double*)(L.ab + n);
+    }
+    __syncthreads();
+    lut_prepare(L, fc.lut_x, bias, n, 0);
+    lut_table_store(L, fc.lut_ws, n);
+    // K1 keeps only the coefficients in LDS and finds the interval from the run table: a grid that is not a few evenly spaced
+    // runs (never the case for these grids) goes back to the host path
+    if (tid == 0 && L.nseg == 0) prm[YOND_PRM_FLAGS] = (double)(s_fp.flags | YOND_PRM_FLAG_LUT_CAPACITY);
 }
 
+#define BIAS_LDS_MAX (160 * 1024 - 512)      // dynamic LDS the kernel may ask for (the CU has 160 KB; ~300 bytes are static)
 static int bias_lut_attr() {                 // the kernel may use the whole LDS of a CU (set once for both entry points)
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)bias_lut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        hipError_t e = hipFuncSetAttribute((const void*)bias_lut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIAS_LDS_MAX);
         if (e != hipSuccess) return (int)e;
         done = true;
     }
@@ -167,10 +240,10 @@ extern "C" int yond_bias_lut_f64(const double* lams, int n, double gain, double 
     const int rmax = (int)(th * (1.0 / K) * 2.0 + sigma * 2.0 + th + 10.0) + 1;
     const int lmax = 2 * pho * rmax + 1;
     const size_t smem = ((size_t)lmax + rmax + 2) * sizeof(double);
-    if (smem > 160 * 1024 - 64) return YOND_EUNSUPPORTED;
+    if (smem > BIAS_LDS_MAX) return YOND_EUNSUPPORTED;
     if (int e = bias_lut_attr()) return e;
     hipLaunchKernelGGL(bias_lut_kernel, dim3(n), dim3(256), smem, (hipStream_t)stream, lams, n, K, sigma, th, pho, lmax, bias,
-                       (double*)nullptr, 0, (double*)nullptr);
+                       (double*)nullptr, 0, (double*)nullptr, (double*)nullptr, FrameChain{});
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -184,7 +257,27 @@ extern "C" int yond_bias_lut_dev_f64(const double* lams, int lut_cap, double* pr
     const size_t smem = (size_t)BIAS_DEV_SMEM_DOUBLES * sizeof(double);
     if (int e = bias_lut_attr()) return e;
     hipLaunchKernelGGL(bias_lut_kernel, dim3(lut_cap), dim3(256), smem, (hipStream_t)stream, lams, 0, 1.0, 0.0, 0.0, 1, 0, bias, prm,
-                       BIAS_DEV_SMEM_DOUBLES, (double*)nullptr);
+                       BIAS_DEV_SMEM_DOUBLES, (double*)nullptr, (double*)nullptr, FrameChain{});
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// The whole frame chain in one launch: parameters (yond_frame_params_f64) + knots + bias LUT (yond_bias_lut_dev_f64) + prepared
+// table (yond_lut_table_f64); same results, same flags.  nle_ws: the estimator's workspace after yond_nle_moments_f32 (its ticket
+// word 2 counts the arrivals and is left at zero).
+extern "C" int yond_frame_chain_f64(void* nle_ws, const float* max_dev, int mode, double scale_est, double scale, double tfac, int lut_cap,
+                                    double* prm, float* t_out, double* lut_x, float* lut_y, void* lut_ws, void* stream) {
+    if (!nle_ws || !prm || !lut_x || !lut_y || !lut_ws || (mode != 0 && mode != 1) || !(scale > 0.0) || !(scale_est > 0.0)) return YOND_EINVAL;
+    if (lut_cap < 2 || lut_cap > LUT_MAX) return YOND_EINVAL;
+    size_t smem = (size_t)BIAS_DEV_SMEM_DOUBLES * sizeof(double);
+    if (smem < (size_t)lut_cap * LUT_BYTES_PER_KNOT) smem = (size_t)lut_cap * LUT_BYTES_PER_KNOT;
+    if (int e = bias_lut_attr()) return e;
+    FrameChain fc;
+    fc.st = (const NleState*)nle_ws; fc.max_dev = max_dev; fc.scale_est = scale_est; fc.scale = scale; fc.tfac = tfac;
+    fc.lut_x = lut_x; fc.t_out = t_out; fc.lut_ws = lut_ws; fc.ticket = &((NleState*)nle_ws)->ticket[2];
+    fc.mode = mode; fc.lut_cap = lut_cap; fc.smem_bytes = (int)smem;
+    hipLaunchKernelGGL(bias_lut_kernel, dim3(lut_cap), dim3(256), smem, (hipStream_t)stream, (const double*)nullptr, 0, 1.0, 0.0, 0.0, 1, 0,
+                       lut_y, prm, BIAS_DEV_SMEM_DOUBLES, (double*)nullptr, (double*)nullptr, fc);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -225,7 +318,7 @@ extern "C" int yond_bias_points_f64(const double* lams, int n, double gain, doub
     const int lmax = 2 * pho * rmax + 1;
     if (int e = bias_lut_attr()) return e;
     hipLaunchKernelGGL(bias_lut_kernel, dim3(nwg < n ? nwg : n), dim3(256), ((size_t)rmax + 2) * sizeof(double), (hipStream_t)stream, lams, n, gain,
-                       sigma, th, pho, lmax, bias32, (double*)nullptr, 0, scratch, bias64);
+                       sigma, th, pho, lmax, bias32, (double*)nullptr, 0, scratch, bias64, FrameChain{});
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

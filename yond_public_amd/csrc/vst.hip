@@ -8,139 +8,7 @@
 #include <stdlib.h>
 #include "common.h"
 
-#define LUT_MAX 4096
-#define LUT_MAXSEG 8
-#define LUT_BYTES_PER_KNOT 24
-
-// The bias LUT (utils/isp_algos.py:103-108, 128: interp1d over knots that are runs of evenly spaced values, step 0.1 /
-// 1 / 10) is a continuous piecewise-linear function, evaluated per pixel as a + b * x with the interval's coefficients
-//   b_i = (y_i - y_{i-1}) / (x_i - x_{i-1})   (the float32 difference of the float32 ordinates, as interp1d forms it),
-//   a_i = y_{i-1} - b_i x_{i-1}                (float64)
-// from a 16-byte LDS entry.  The interval index comes from the run's spacing with one multiply; because the function is
-// continuous, landing in the neighbouring interval when x sits within rounding distance of a knot changes the value by
-// < 1e-12, far below the float32 rounding of K1's output -- so no search / repair against the knots is needed (the first
-// version spent most of K1's time there, in float64 sqrt and in the float64 divide).  Knots that are not <= 8 evenly
-// spaced runs fall back to bisection.
-struct LutLds {
-    double* x;                   // [n]  knots (bisection fallback)
-    double2* ab;                 // [n]  coefficients of the interval that ENDS at knot i (i >= 1)
-    float seg_x[LUT_MAXSEG], seg_inv[LUT_MAXSEG];
-    int seg_i[LUT_MAXSEG + 1];
-    int nseg;                    // 0: bisection
-    int nbreak;
-};
-
-// flags: bit 0 -- ordinates are float64 (the 2-D BiasLUT's merged row) instead of float32 (get_bias' interp1d knots);
-//        bit 1 -- BiasLUT semantics beyond the last knot (utils/isp_algos.py:188-194, 226-230): the last ordinate up to one
-//                 more interval, Foi's closed form (float32-rounded, as the reference stores it) further out
-#define LUT_Y64 1
-#define LUT_BIASLUT 2
-__device__ __forceinline__ void lut_prepare(LutLds& L, const double* __restrict__ lut_x, const void* __restrict__ lut_yv, int n,
-                                            int flags) {
-    const int tid = threadIdx.x;
-    const float* lut_y = (const float*)lut_yv;
-    const double* lut_y64 = (const double*)lut_yv;
-    for (int i = tid; i < n; i += 256) L.x[i] = lut_x[i];
-    if (tid == 0) { L.nbreak = 0; L.nseg = 0; }
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        if (i >= 1) {
-            double dy, y0;
-            if (flags & LUT_Y64) { dy = lut_y64[i] - lut_y64[i - 1]; y0 = lut_y64[i - 1]; }
-            else { dy = (double)(lut_y[i] - lut_y[i - 1]); y0 = (double)lut_y[i - 1]; }   // float32 difference, as interp1d forms it
-            double dx = L.x[i] - L.x[i - 1];
-            if (dx == 0.0 && i >= 2) {
-                // a repeated knot (get_bias concatenates its runs, so 50 and 500 appear twice): searchsorted('left') never
-                // selects the empty interval -- a query equal to the knot belongs to the interval that ENDS at its first copy
-                dx = L.x[i - 1] - L.x[i - 2];
-                if (flags & LUT_Y64) { dy = lut_y64[i - 1] - lut_y64[i - 2]; y0 = lut_y64[i - 2]; }
-                else { dy = (double)(lut_y[i - 1] - lut_y[i - 2]); y0 = (double)lut_y[i - 2]; }
-                const double b = dy / dx;
-                L.ab[i] = make_double2(y0 - b * L.x[i - 2], b);
-            } else {
-                const double b = dy / dx;
-                L.ab[i] = make_double2(y0 - b * L.x[i - 1], b);
-            }
-        }
-        if (i >= 1 && i + 1 < n) {
-            const double d0 = L.x[i] - L.x[i - 1], d1 = L.x[i + 1] - L.x[i];
-            if (fabs(d1 - d0) > 1e-3 * fabs(d0)) {                 // the spacing changes at knot i
-                const int slot = atomicAdd(&L.nbreak, 1);
-                if (slot < LUT_MAXSEG - 1) L.seg_i[slot + 1] = i;
-            }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const int nb = L.nbreak;
-        if (nb <= LUT_MAXSEG - 1 && n >= 2) {
-            L.seg_i[0] = 0;
-            for (int a = 2; a <= nb; ++a) {                        // insertion sort of <= 7 break indices
-                const int v = L.seg_i[a];
-                int j = a - 1;
-                while (j >= 1 && L.seg_i[j] > v) { L.seg_i[j + 1] = L.seg_i[j]; --j; }
-                L.seg_i[j + 1] = v;
-            }
-            L.seg_i[nb + 1] = n - 1;
-            bool ok = true;
-            for (int sgm = 0; sgm <= nb; ++sgm) {
-                const int i0 = L.seg_i[sgm];
-                L.seg_x[sgm] = (float)L.x[i0];
-                L.seg_inv[sgm] = (float)(1.0 / (L.x[i0 + 1] - L.x[i0]));
-                ok = ok && ((double)L.seg_x[sgm] == L.x[i0]);      // run starts must be float32 values (0, 50, 500 are)
-            }
-            L.nseg = ok ? nb + 1 : 0;
-        }
-    }
-    __syncthreads();
-    // The index guess of lut_eval trusts that every run is EVENLY spaced.  The break detection above compares neighbouring
-    // intervals with a relative tolerance, so a slowly drifting grid (a log grid of ratio < 1.001) would pass as one run:
-    // check every knot against its run's ideal position x[i0] + (i - i0) * step and fall back to the bisection (exact for
-    // any spacing) if one is off by more than 1e-3 of a step.  (float64 np.linspace knots are exact to ~1e-13 of a step;
-    // the float32 ones NumPy 2 produces for a float32 maximum -- 500 ... ub in steps of ~9.8 -- to 6e-6 of a step; a query
-    // that close to a knot may be evaluated on the neighbouring interval, which differs from the right one by the change of
-    // slope times that distance: < 1e-9 on these tables.  A drifting grid is off by whole steps after a few hundred knots.)
-    const int nseg = L.nseg;
-    if (nseg > 0) {
-        bool bad = false;
-        for (int i = tid; i < n; i += 256) {
-            int sgm = 0;
-            for (int a = 1; a < nseg; ++a) sgm += (i > L.seg_i[a]) ? 1 : 0;
-            const int i0 = L.seg_i[sgm];
-            const double step = L.x[i0 + 1] - L.x[i0];
-            // (a repeated knot -- get_bias' 50 and 500 -- opens a run: i0 is its second copy, the first copy closes the previous run)
-            const double dev = fabs(L.x[i] - (L.x[i0] + (double)(i - i0) * step));
-            bad = bad || !(dev <= 1e-3 * fabs(step));          // (the zero-width run between the two copies: dev = 0)
-        }
-        if (__syncthreads_or(bad ? 1 : 0)) {
-            if (tid == 0) L.nseg = 0;
-        }
-        __syncthreads();
-    }
-}
-
-// ---- the prepared table in global memory (yond_lut_table_f64): header, coefficients, knots ----
-struct LutHeader {
-    int n, nseg, nbreak, pad;
-    float seg_x[LUT_MAXSEG], seg_inv[LUT_MAXSEG];
-    int seg_i[LUT_MAXSEG + 1];
-    int pad2[7];
-};
-static_assert(sizeof(LutHeader) == 144, "LutHeader layout");
-__device__ __forceinline__ void lut_load(LutLds& L, const void* __restrict__ ws, int& n_out) {
-    // plain copy of the image yond_lut_table_f64 stored: no arithmetic per workgroup
-    const LutHeader* hd = (const LutHeader*)ws;
-    const int n = hd->n;
-    const double2* ab = (const double2*)((const char*)ws + sizeof(LutHeader));
-    const double* x = (const double*)(ab + LUT_MAX);
-    (void)x;                                          // (the knots themselves stay in global memory: the table's runs are even,
-    for (int i = threadIdx.x; i < n; i += blockDim.x) L.ab[i] = ab[i];      //  yond_lut_table_f64 flags a grid that is not)
-    if (threadIdx.x < LUT_MAXSEG) { L.seg_x[threadIdx.x] = hd->seg_x[threadIdx.x]; L.seg_inv[threadIdx.x] = hd->seg_inv[threadIdx.x]; }
-    if (threadIdx.x <= LUT_MAXSEG) L.seg_i[threadIdx.x] = hd->seg_i[threadIdx.x];
-    if (threadIdx.x == 0) { L.nseg = hd->nseg; L.nbreak = hd->nbreak; }
-    n_out = n;
-    __syncthreads();
-}
+#include "lut_table.h"
 
 __device__ __forceinline__ double lut_eval(const LutLds& L, int n, float xq) {
     // scipy interp1d(kind='linear')._call_linear: hi = clip(searchsorted(x, xq, 'left'), 1, n-1)
@@ -288,6 +156,117 @@ __global__ __launch_bounds__(256) void pack_vst_norm_kernel(const float* __restr
     flush_max(cur_b);
 }
 
+// K1 for the frames of the device chain (constants from the parameter block, the table the chain prepared: <= 3 evenly spaced runs).
+// The same function as pack_vst_norm_kernel with the affine tail folded into the coefficients,
+//     u = (2/K sqrt(fz) - (a + b x) - lo) / (hi - lo)  =  A sqrt(fz) - (a' + b' x),   A = 2 / (K (hi - lo)), a' = (a + lo) / (hi - lo), b' = b / (hi - lo),
+// and the runs held in registers: 11 float64 operations per element become 6, the interval lookup reads LDS once, and the kernel fits
+// 64 registers (eight waves per SIMD: the loop is a chain of dependent conversions and float64 operations behind two loads).
+// The float64 result moves by a few 1e-16 (another association of the same terms): after the one rounding to float32 a different value
+// for about one element in 1e8.  A table that is not <= 3 runs is flagged (YOND_PRM_FLAG_LUT_CAPACITY: the host path takes the frame).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void pack_vst_chain_kernel(const float* __restrict__ bayer, int H, int W, float* __restrict__ out, int pad_l, int pad_t, int Hp, int Wp,
+                           float scale_f, unsigned int* __restrict__ img_max, double* __restrict__ prm, const void* __restrict__ lut_ws,
+                           int lut_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lut_raw[];
+    __shared__ LutLds L;
+    __shared__ float s_red[4];
+    const int fl = (int)prm[YOND_PRM_FLAGS];
+    if (fl & (YOND_PRM_FLAG_BAD_ESTIMATE | YOND_PRM_FLAG_LUT_CAPACITY | YOND_PRM_FLAG_NO_FLAT_AREA)) return;
+    const double gain = prm[YOND_PRM_GAIN], sigma = prm[YOND_PRM_SIGMA], lo = prm[YOND_PRM_LO], hi = prm[YOND_PRM_HI];
+    int lut_n = (int)prm[YOND_PRM_LUT_N];
+    if (lut_n > lut_cap) return;                              // (cannot happen: the block's producer checked the same capacity)
+    if (threadIdx.x == 0) { L.ab = (double2*)lut_raw; L.x = nullptr; }
+    __syncthreads();
+    lut_load(L, lut_ws, lut_n);
+    // the runs a query can land in: a repeated knot (get_bias concatenates its runs: 50 and 500 appear twice) opens a zero-width run that
+    // lut_eval's count of run starts <= x always steps over -- drop those, keep (start, 1 / step, first knot, last knot) of the others
+    float rx[3] = {0.f, INFINITY, INFINITY}, rv[3] = {0.f, 0.f, 0.f};
+    int ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
+    int kept = 0;
+    const int ns = L.nseg;
+    for (int i = 0; i < ns; ++i) {
+        if (i + 1 < ns && L.seg_x[i + 1] == L.seg_x[i]) continue;
+        if (kept < 3) { rx[kept] = L.seg_x[i]; rv[kept] = L.seg_inv[i]; ra[kept] = L.seg_i[i]; rb[kept] = L.seg_i[i + 1]; }
+        ++kept;
+    }
+    if (lut_n < 2 || ns < 1 || kept > 3) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) prm[YOND_PRM_FLAGS] = (double)(fl | YOND_PRM_FLAG_LUT_CAPACITY);
+        return;
+    }
+    const int h = H / 2, w = W / 2;
+    const double inv_span = 1.0 / (hi - lo);
+    const double fA = 2.0 / gain * inv_span, fC = 0.375 * gain * gain + sigma * sigma;
+    for (int i = threadIdx.x; i < lut_n; i += 256) {
+        const double2 c = L.ab[i];
+        L.ab[i] = make_double2((c.x + lo) * inv_span, c.y * inv_span);
+    }
+    // the kept runs in LDS, one 16-byte entry each: {start, 1 / step, first knot, last knot}; a run that is not there starts at +inf
+    __shared__ f32x4 s_run[3];
+    if (threadIdx.x < 3) {
+        f32x4 e;
+        e[0] = rx[threadIdx.x]; e[1] = rv[threadIdx.x]; e[2] = __int_as_float(ra[threadIdx.x]); e[3] = __int_as_float(rb[threadIdx.x]);
+        s_run[threadIdx.x] = e;
+    }
+    const float fx1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rx[1])));
+    const float fx2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rx[2])));
+    const double2* tab = (const double2*)lut_raw;
+    __syncthreads();
+    const int nm1 = lut_n - 1;
+    float vmax = 0.0f;
+    const int per = (Hp + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int row_lo = blockIdx.x * per, row_hi = row_lo + per < Hp ? row_lo + per : Hp;
+    for (int yp = row_lo; yp < row_hi; ++yp) {
+        int sy = yp - pad_t;
+        if ((unsigned)sy >= (unsigned)h) sy = reflect101(sy, h);                // (uniform)
+        const float* row0 = bayer + (size_t)(2 * sy) * W;
+        float* orow = out + (size_t)yp * Wp * 4;
+        // two pixels per trip: four loads in flight ahead of ~90 dependent operations
+        for (int xp = threadIdx.x; xp < Wp; xp += 512) {
+            const int xp2 = xp + 256;
+            const bool two = xp2 < Wp;
+            int sx = xp - pad_l, sx2 = (two ? xp2 : xp) - pad_l;
+            if ((unsigned)sx >= (unsigned)w) sx = reflect101(sx, w);
+            if ((unsigned)sx2 >= (unsigned)w) sx2 = reflect101(sx2, w);
+            const f32x2 r0 = *(const f32x2*)(row0 + 2 * sx), r1 = *(const f32x2*)(row0 + W + 2 * sx);
+            const f32x2 r2 = *(const f32x2*)(row0 + 2 * sx2), r3 = *(const f32x2*)(row0 + W + 2 * sx2);
+            const float q[8] = {r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
+            float o[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float x32 = q[c] * scale_f;                           // float32 * python float -> float32
+                const double xd = (double)x32;
+                const double fz = fmax(fma(gain, xd, fC), 0.0);
+                // sqrt_newton without its branches: an argument below 1e-30 is taken as 1e-30 (the root, < 1e-15, times A ~ 1e-2 is far
+                // below the float32 result's ulp either way)
+                const float af = fmaxf((float)fz, 1e-30f);
+                const float s0f = __builtin_amdgcn_sqrtf(af);
+                const double s0 = (double)s0f;
+                const double sq = fma(fma(-s0, s0, fz), (double)(0.5f * __builtin_amdgcn_rcpf(s0f)), s0);
+                // the interval, as lut_eval finds it (searchsorted 'left' on evenly spaced runs)
+                const float xq = fmaxf(x32, 0.0f);
+                const f32x4 run = s_run[(xq >= fx1 ? 1 : 0) + (xq >= fx2 ? 1 : 0)];
+                const float t = (xq - run[0]) * run[1];
+                const int off = (int)fminf(fmaxf(ceilf(t), 0.0f), 16777216.0f);
+                const int g = min(__float_as_int(run[2]) + off, __float_as_int(run[3]));
+                const double2 cf = tab[max(1, min(g, nm1))];
+                const double tl = fma(cf.y, fmax(xd, 0.0), cf.x);
+                float u = (float)fma(fA, sq, -tl);
+                u = fminf(fmaxf(u, 0.0f), 1.0f);
+                o[c] = u;
+                vmax = fmaxf(vmax, u);
+            }
+            *(f32x4*)(orow + (size_t)xp * 4) = f32x4{o[0], o[1], o[2], o[3]};
+            if (two) *(f32x4*)(orow + (size_t)xp2 * 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+    }
+    if (img_max) {
+        const float m0 = wave_max(vmax);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m0;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(img_max, __float_as_uint(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]))));
+    }
+}
+
 static int launch_pack_vst(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b, int mode,
                            double scale, double gain, double sigma, double lo, double hi, const double* lut_x, const void* lut_y,
                            int lut_n, int lut_flags, float* img_max, void* stream, int B = 1) {
@@ -336,13 +315,8 @@ __global__ __launch_bounds__(256) void lut_table_kernel(const double* __restrict
     }
     __syncthreads();
     lut_prepare(L, lut_x, lut_y, n, 0);
-    double2* ab = (double2*)((char*)ws + sizeof(LutHeader));
-    double* x = (double*)(ab + LUT_MAX);
-    for (int i = threadIdx.x; i < n; i += 256) { ab[i] = i >= 1 ? L.ab[i] : make_double2(0.0, 0.0); x[i] = L.x[i]; }
-    if (threadIdx.x < LUT_MAXSEG) { hd->seg_x[threadIdx.x] = L.seg_x[threadIdx.x]; hd->seg_inv[threadIdx.x] = L.seg_inv[threadIdx.x]; }
-    if (threadIdx.x <= LUT_MAXSEG) hd->seg_i[threadIdx.x] = L.seg_i[threadIdx.x];
+    lut_table_store(L, ws, n);
     if (threadIdx.x == 0) {
-        hd->n = n; hd->nseg = L.nseg; hd->nbreak = L.nbreak;
         // K1 keeps only the coefficients in LDS and finds the interval from the run table: a grid that is not a few evenly
         // spaced runs (never the case for yond_frame_params_f64's grids) goes back to the host path
         if (prm_rw && L.nseg == 0) prm_rw[YOND_PRM_FLAGS] = (double)((int)prm_rw[YOND_PRM_FLAGS] | YOND_PRM_FLAG_LUT_CAPACITY);
@@ -392,6 +366,34 @@ extern "C" int yond_pack_vst_norm_dev_f32(const float* bayer, int H, int W, floa
     hipLaunchKernelGGL(pack_vst_norm_kernel, dim3(nb), dim3(256), lut_ws ? (size_t)lut_cap * sizeof(double2) : 0, st, bayer, H, W, out,
                        pad_l, pad_t, Hp, Wp, 1, (float)scale, 1.0, 0.0, 0.0, 1.0, (const double*)nullptr, (const void*)nullptr, 0, 0,
                        (unsigned int*)img_max, prm, lut_ws, lut_cap, 1);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// The chain's own K1 (pack_vst_chain_kernel): as yond_pack_vst_norm_dev_f32 for a table yond_frame_chain_f64 prepared; prm is also
+// WRITTEN (a table of another shape is flagged, nothing is computed).
+extern "C" int yond_pack_vst_norm_chain_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
+                                            double scale, double* prm, const void* lut_ws, int lut_cap, float* img_max, void* stream) {
+    if (!bayer || !out || !prm || !lut_ws || H < 2 || W < 2 || (H & 1) || (W & 1)) return YOND_EINVAL;
+    if (lut_cap < 2 || lut_cap > LUT_MAX) return YOND_EINVAL;
+    if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 || !(scale > 0.0)) return YOND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int Hp = H / 2 + pad_t + pad_b, Wp = W / 2 + pad_l + pad_r;
+    if (img_max) {
+        hipError_t e = hipMemsetAsync(img_max, 0, sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    static bool attr = false;
+    if (!attr) {
+        if (int e = lut_smem_attr((const void*)pack_vst_chain_kernel)) return e;
+        attr = true;
+    }
+    // three workgroups per CU, two rows each at the cfg-2 size: every workgroup copies and rescales the table once (measured, same box:
+    // 256 workgroups 38.0 us, 512 30.2, 768 29.5, 1024 30.3, 1536 33.1)
+    const long cap = yond_exp_long("YOND_K1_WGS", 768);
+    const unsigned nb = Hp < (int)cap ? (unsigned)Hp : (unsigned)cap;
+    hipLaunchKernelGGL(pack_vst_chain_kernel, dim3(nb), dim3(256), (size_t)lut_cap * sizeof(double2), st, bayer, H, W, out, pad_l, pad_t, Hp, Wp,
+                       (float)scale, (unsigned int*)img_max, prm, lut_ws, lut_cap);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -778,6 +778,10 @@ def chain_applies(lr, net, arch, pipe, biaslut=None):
 
 
 DEVICE_CHAIN = True                 # (module attribute: tools / tests switch the host-side chain back on for A/B)
+CHAIN_ONE_LAUNCH = False            # parameters + bias LUT + table as ONE launch (yond_frame_chain_f64): same results, fewer launches, but
+                                    # measured 36 us against 31 us for the three launches (every workgroup re-derives the parameters,
+                                    # the table is a serial tail) -- off by default
+CHAIN_K1 = True                     # the chain's own K1 (yond_pack_vst_norm_chain_f32: 29.5 us against 45.5); False: the general kernel
 
 
 def _chain_estimate(lr, hr, mode, pipe, p, buf, lr_max_dev=None):
@@ -801,10 +805,16 @@ def _chain_estimate(lr, hr, mode, pipe, p, buf, lr_max_dev=None):
                 "yond_nle_moments_f32")
     with _stage("frame_params_lut"):
         # (round 2 reads the frame maximum round 1's estimator collected: the collab kernels read the same noisy frame)
-        L.check(lib.yond_frame_params_f64(L.ptr(ws), L.ptr(lr_max_dev) if lr_max_dev is not None else None, 0 if mode == 'self' else 1,
-                                          scale_est, scale, 1.03, LUT_CAP, L.ptr(buf.prm), L.ptr(buf.t), L.ptr(buf.lut_x), st), "yond_frame_params_f64")
-        L.check(lib.yond_bias_lut_dev_f64(L.ptr(buf.lut_x), LUT_CAP, L.ptr(buf.prm), L.ptr(buf.lut_y), st), "yond_bias_lut_dev_f64")
-        L.check(lib.yond_lut_table_f64(L.ptr(buf.lut_x), L.ptr(buf.lut_y), -1, L.ptr(buf.prm), L.ptr(buf.lut_ws), st), "yond_lut_table_f64")
+        mx = L.ptr(lr_max_dev) if lr_max_dev is not None else None
+        md = 0 if mode == 'self' else 1
+        if CHAIN_ONE_LAUNCH:
+            L.check(lib.yond_frame_chain_f64(L.ptr(ws), mx, md, scale_est, scale, 1.03, LUT_CAP, L.ptr(buf.prm), L.ptr(buf.t), L.ptr(buf.lut_x),
+                                             L.ptr(buf.lut_y), L.ptr(buf.lut_ws), st), "yond_frame_chain_f64")
+        else:
+            L.check(lib.yond_frame_params_f64(L.ptr(ws), mx, md, scale_est, scale, 1.03, LUT_CAP, L.ptr(buf.prm), L.ptr(buf.t), L.ptr(buf.lut_x), st),
+                    "yond_frame_params_f64")
+            L.check(lib.yond_bias_lut_dev_f64(L.ptr(buf.lut_x), LUT_CAP, L.ptr(buf.prm), L.ptr(buf.lut_y), st), "yond_bias_lut_dev_f64")
+            L.check(lib.yond_lut_table_f64(L.ptr(buf.lut_x), L.ptr(buf.lut_y), -1, L.ptr(buf.prm), L.ptr(buf.lut_ws), st), "yond_lut_table_f64")
     buf.ws = ws                                              # (kept alive until the buffers' next use)
 
 
@@ -819,8 +829,9 @@ def _chain_denoise(lr, net, arch, p, buf, guard_slot):
     Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
     x4 = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=lr.device)
     with _stage("vst_pack"):
-        L.check(lib.yond_pack_vst_norm_dev_f32(L.ptr(lr), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], scale, L.ptr(buf.prm),
-                                               L.ptr(buf.lut_ws), LUT_CAP, L.ptr(buf.img_max), st), "yond_pack_vst_norm_dev_f32")
+        k1 = lib.yond_pack_vst_norm_chain_f32 if CHAIN_K1 else lib.yond_pack_vst_norm_dev_f32
+        L.check(k1(L.ptr(lr), H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], scale, L.ptr(buf.prm), L.ptr(buf.lut_ws), LUT_CAP,
+                   L.ptr(buf.img_max), st), "yond_pack_vst_norm_chain_f32")
     plan = _plan_of(net, lr.device)
     t_dev = buf.t if 'guided' in arch else None
 

@@ -24,12 +24,14 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES --output-format csv -d $O/pmc_mfma -o m -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_lds -o l -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -o t -- python3 $R/tools/train_bench.py --steps 4 > $O/train_trace_bench.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/frame_trace -o f -- python3 $R/tools/frame_trace.py > /dev/null 2>&1
 cd $R
 python tools/kmedians.py $O/trace > $O/r04_bench_once_kernel_medians.txt 2>&1
+python tools/frame_trace_summary.py $O/frame_trace > $O/r04_frame_launches.txt 2>&1
 cp $O/trace/t_kernel_stats.csv $O/r04_bench_once_kernel_stats.csv
 cp $O/train_trace/t_kernel_stats.csv $O/r04_train_step_kernel_stats.csv
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/r04_pmc_traffic.json | head -40 > $O/r04_pmc_traffic_top.txt
 python tools/pmc_kernel_means.py $O/pmc_mfma > $O/r04_pmc_mfma.txt 2>&1
 python tools/pmc_kernel_means.py $O/pmc_lds > $O/r04_pmc_lds.txt 2>&1
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_lds $O/trace/*trace* $O/train_trace/*trace* 2>/dev/null
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_lds $O/frame_trace $O/trace/*trace* $O/train_trace/*trace* 2>/dev/null
 ls -la $O

@@ -667,7 +667,7 @@ def main(argv=None):
             hr6 = torch.rand(64, 4, 128, 128, generator=g6).to(dev)
             sg6 = (torch.rand(64, 1, 1, 1, generator=g6) * 0.18 + 0.02).to(dev)
             lr6 = (hr6 + torch.randn(hr6.shape, generator=g6).to(dev) * sg6).clamp(0, 1)
-            for _ in range(2):
+            for _ in range(4):                      # (two eager steps, the hipGraph capture, one replay)
                 ts6.step(lr6, hr6, sg6)
             torch.cuda.synchronize()
             t6, n6 = time.perf_counter(), 0
@@ -691,7 +691,8 @@ def main(argv=None):
                                                        "note": "one rank: no gradient exchange; under torchrun two 25 MB buckets per step (distributed.GradReducer)"},
                                        "workload": "SURVEY 8(f) N4: GuidedResUnet(nf=32), batch 64 x [4][128][128] (256 x 256 Bayer patches), L1 loss, Adam; "
                                                    "forward / data gradients and the weight gradients of the 3x3 stride-1 layers on the split-operand "
-                                                   "fp16-MFMA kernels (loss-scaled), the other layers on the fp32 MFMA"}
+                                                   "fp16-MFMA kernels (loss-scaled), the other layers on the fp32 MFMA; the step replayed as one hipGraph",
+                                       "graph": bool(getattr(ts6, "_graphs", None))}
             del ts6, net6, hr6, lr6, sg6
         except Exception as e:                      # (a reported extra: it must not take the headline line down with it)
             others["training_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -28,5 +28,5 @@ for lvl in range(5):
     a, b = t(f0), t(f1)
     gf = 2 * 9 * C * C * N * H * H / 1e9
     err = float((dw2 - dw).abs().max() / dw.abs().max())
-    print(f"level {lvl}: C {C:3d} {H:3d}x{H:<3d} {gf:5.1f} GFLOP  fp32-MFMA {a:7.1f} us ({gf / a * 1e-3:6.1f} TF/s)   split fp16-MFMA {b:7.1f} us ({gf / b * 1e-3:6.1f} TF/s)"
+    print(f"level {lvl}: C {C:3d} {H:3d}x{H:<3d} {gf:5.1f} GFLOP  fp32-MFMA {a:7.1f} us ({gf / a * 1e3:6.1f} TF/s)   split fp16-MFMA {b:7.1f} us ({gf / b * 1e3:6.1f} TF/s)"
           f"   x{a / b:.2f}   ws {n1 / 2**20:.0f} MiB  max rel diff {err:.1e}  status {int(st.item())}", flush=True)

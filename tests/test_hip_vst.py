@@ -237,8 +237,8 @@ def test_get_bias_points_and_biaslut_leftovers(golden):
 
 
 def test_manual_est_type_and_refused_est_types():
-    """YOND_SIDD.py:349-351: est_type 'manual' runs round 1 at (K, sigma) = (14, 20) DN; the est_types that read other methods'
-    estimates from files are refused loudly instead of being ignored."""
+    """YOND_SIDD.py:349-351: est_type 'manual' runs round 1 at (K, sigma) = (14, 20) DN; the est_type that needs a second network is
+    refused loudly, and so is a file est_type without the directory to read from."""
     import yond_oracle as O
     from hip_common import ARCHS
     from yond_public_amd import archs as A
@@ -255,9 +255,56 @@ def test_manual_est_type_and_refused_est_types():
     torch.set_num_threads(8)
     ref = O.IterDenoise(noisy, arch, S.denoising_state_dict(net, 3), pipe)
     assert float(np.abs(res['raw_dns'][0].cpu().numpy() - ref['raw_dns'][0]).max()) <= 1e-5
-    for bad in ('foi', 'pge+full', 'liu'):
-        with pytest.raises(NotImplementedError):
-            P.IterDenoise(noisy, net, arch, dict(pipe, est_type=bad), device=DEV)
+    with pytest.raises(NotImplementedError):                    # a second network (NeuralNLF): not built, refused loudly
+        P.IterDenoise(noisy, net, arch, dict(pipe, est_type='ours'), device=DEV)
+    from yond_public_amd._lib import YondHipError
+    with pytest.raises(YondHipError):                           # a file est_type without the dataset directory to read from
+        P.IterDenoise(noisy, net, arch, dict(pipe, est_type='foi'), device=DEV)
+
+
+def test_file_lookup_est_types_run_round_one_at_the_stored_estimate(tmp_path):
+    """YOND_SIDD.py:316-337: est_types 'foi' / 'liu' / 'zou' / 'pge' and pipe['cal_est'] take round 1's (beta1, beta2) from files.  With
+    the files holding 'manual''s fixed estimate (14, 20 DN) every one of them must reproduce the 'manual' run bit for bit; round 2 of
+    'iter' then estimates collaboratively as usual."""
+    import pickle
+    import scipy.io as sio
+    import yond_oracle as O
+    from hip_common import ARCHS
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    from yond_public_amd import synthetic as S
+    arch = ARCHS["gru8"]
+    net = A.GuidedResUnet(dict(arch))
+    net.load_state_dict(S.denoising_state_dict(net, 3))
+    net = net.to(DEV).eval()
+    noisy, _ = O.synth_noisy(256, 384, 14.0, 20.0, 5)
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': True, 'est_type': 'manual'}
+    want = P.IterDenoise(noisy, net, arch, pipe, device=DEV)
+    scale = 1023.0 - 64.0
+    b1, b2 = 14 / scale, (20 / scale) ** 2
+    raw = tmp_path / 'SIDD_Validation_Raw'
+    raw.mkdir()
+    table = np.zeros((5, 2))
+    table[3] = (b1, b2)
+    sio.savemat(str(raw / 'FoiEst_fullPict.mat'), {'return_params': table})
+    sio.savemat(str(raw / 'LiuEst_fullPict.mat'), {'return_params': table})
+    np.save(str(raw / 'Zou_fullPict.npy'), table)
+    pge = table.copy()
+    pge[3, 1] = np.sqrt(b2)                                     # (PGE stores a standard deviation, :337)
+    np.save(str(raw / 'PGE_fullPict.npy'), pge)
+    cal = tmp_path / 'cal.pkl'
+    with open(cal, 'wb') as f:
+        pickle.dump({'sfrn': {'GP_00800': (b1, b2)}, 'beta1': {'GP': [0.0, b1]}, 'beta2': {'GP': [0.0, b2]}}, f)
+    est = {'root_dir': str(tmp_path), 'img_id': 3, 'name': '0001_001_GP_00800_00350_3200_N'}
+    runs = [dict(pipe, est_type=t) for t in ('foi', 'liu', 'zou', 'pge')] + [dict(pipe, est_type='simple', cal_est=str(cal))]
+    ests = [est] * 4 + [est, dict(est, name='0001_001_GP_00100_00350_3200_N')]      # (the last: an ISO without a record -> the polynomials)
+    runs.append(dict(pipe, est_type='simple', cal_est=str(cal)))
+    for pp, e in zip(runs, ests):
+        got = P.IterDenoise(noisy, net, arch, pp, device=DEV, est=e)
+        assert len(got['raw_dns']) == len(want['raw_dns']) == 2
+        np.testing.assert_allclose(got['regs'][0], want['regs'][0], rtol=1e-12)
+        for a_, b_ in zip(got['raw_dns'], want['raw_dns']):
+            assert float((a_ - b_).abs().max()) <= 1e-6, pp
 
 
 def test_batched_k1_k4_equal_the_per_frame_kernels():

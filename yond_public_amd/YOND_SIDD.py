@@ -143,7 +143,9 @@ class YOND_SIDD:
         # pipe['full_dn'], for the denoiser (:388); the collaborative estimate re-tiles per block (SIDD_256, :431)
         res = P.IterDenoise(data['lr'], self.net, self.arch, self.pipe, lr_full=data.get('lr_full'), p=params['p'],
                             device=self.device, log=(lambda s: log(s, self.logfile)) if self.parser.verbose else None,
-                            biaslut=self.biaslut)
+                            biaslut=self.biaslut,
+                            est={'root_dir': (getattr(self, 'dst', None) or {}).get('root_dir'), 'img_id': params.get('img_id'),
+                                 'name': data.get('name')})
         res['lr_raw'] = np.concatenate(data['lr'], axis=-1)
         res['hr_raw'] = np.concatenate(data['hr'], axis=-1) if 'hr' in data else None
         return res

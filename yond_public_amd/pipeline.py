@@ -13,6 +13,8 @@ pass over pixels is a kernel launch through the C ABI of libyond_hip.so.
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -959,13 +961,58 @@ def default_params():
     return p
 
 
-def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=None, biaslut=None):
+def file_estimate(pipe, est=None):
+    """The est_types that READ an estimate instead of computing one (YOND_SIDD.py:316-337): (beta1, beta2) of image est['img_id'] /
+    est['name'] from the files other methods left in the dataset tree est['root_dir'], or from the calibration record pipe['cal_est'].
+        cal_est         pickle {'sfrn': {'<camera>_<iso:05d>': (b1, b2)}, 'beta1': {camera: poly}, 'beta2': {camera: poly}}; camera and ISO
+                        are fields 2 and 3 of the image name; an ISO without a record evaluates the camera's polynomials (:316-323)
+        foi / liu       SIDD_Validation_Raw/{FoiEst,LiuEst}_fullPict.mat, variable 'return_params' (:324-327)
+        zou             SIDD_Validation_Raw/Zou_fullPict.npy (:328-329)
+        pge             SIDD_Validation_Raw/PGE_fullPict.npy; its second column is a standard deviation (:330-337)
+    Returns None for the est_types that compute ('simple', 'manual').  Host-side file reads: nothing here touches the GPU."""
+    est = est or {}
+    est_type = str(pipe.get('est_type', 'simple'))
+
+    def need(key):
+        if est.get(key) is None:
+            raise L.YondHipError(f"est_type {est_type!r} / cal_est reads a precomputed estimate: IterDenoise needs est={{'{key}': ...}} "
+                                 "(YOND_SIDD.py:307-308, 316-337)")
+        return est[key]
+    if 'cal_est' in pipe:
+        import pickle as pkl
+        with open(pipe['cal_est'], 'rb') as f:
+            record = pkl.load(f)
+        name = need('name')
+        ct, iso = name.split('_')[2], int(name.split('_')[3])
+        if f'{ct}_{iso:05d}' not in record['sfrn']:
+            return (np.poly1d(record['beta1'][ct])(iso), np.poly1d(record['beta2'][ct])(iso))
+        r = record['sfrn'][f'{ct}_{iso:05d}']
+        return (r[0], r[1])
+    raw_dir = lambda: os.path.join(str(need('root_dir')), 'SIDD_Validation_Raw')
+    if 'foi' in est_type or 'liu' in est_type:
+        import scipy.io as sio
+        fn = 'FoiEst_fullPict.mat' if 'foi' in est_type else 'LiuEst_fullPict.mat'
+        r = sio.loadmat(os.path.join(raw_dir(), fn))['return_params'][need('img_id')]
+        return (r[0], r[1])
+    if 'zou' in est_type:
+        r = np.load(os.path.join(raw_dir(), 'Zou_fullPict.npy'))[need('img_id')]
+        return (r[0], r[1])
+    if 'pge' in est_type:
+        if est.get('est_net') is not None:
+            raise NotImplementedError("est_type 'pge' with an estimation network (YOND_SIDD.py:333-335) is not built: the file form only")
+        r = np.array(np.load(os.path.join(raw_dir(), 'PGE_fullPict.npy'))[need('img_id')], dtype=np.float64)
+        return (r[0], r[1] ** 2)
+    return None
+
+
+def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=None, biaslut=None, est=None):
     """Round 1: self-calibrated NLE -> VST -> denoise -> inverse VST; round 2 (pipe['iter']=='iter'):
     collaborative NLE from (noisy, denoised) -> guards -> second pass.  lr_raw: the SIDD layout [32][256][256]
     (denoised block by block, or -- pipe['full_dn'] -- as its 256 x 8192 concatenation, :387-389) or one Bayer
     frame [H][W] (needs pipe['full_dn']).  The collaborative estimate re-tiles into 32 vertical tiles (SIDD_256, which :431
     hard-codes) wherever the reference's split can run (packed width divisible by 32); pipe['collab_sidd256'] overrides.  Returns dict(raw_dns, regs, params) with
-    device tensors in raw_dns (each [H][W], for SIDD the 256 x 8192 concatenation as in the reference)."""
+    device tensors in raw_dns (each [H][W], for SIDD the 256 x 8192 concatenation as in the reference).
+    est: {'root_dir', 'img_id', 'name'} for the est_types that read round 1's estimate from files (file_estimate)."""
     p = dict(p or default_params())
     k = pipe.get('k', 29)
     bias_corr = pipe.get('bias_corr', 'pre')
@@ -1011,13 +1058,14 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     # lr.max() for the bias LUT grid: the estimator's first kernel collects it when it reads the same frame; else a
     # reduction queued ahead of the NLE and read after the NLE's own host sync
     est_type = str(pipe.get('est_type', 'simple'))
-    for other in ('foi', 'liu', 'zou', 'pge', 'ours'):                                 # :322-346: precomputed estimates of other
-        if other in est_type:                                                          # methods, read from the dataset directory
-            raise NotImplementedError(f"est_type {est_type!r}: the reference reads the {other!r} estimates from files of its dataset "
-                                      "tree / a second network (YOND_SIDD.py:322-346); this build estimates with 'simple' or takes 'manual'")
-    if 'cal_est' in pipe:
-        raise NotImplementedError("pipe['cal_est'] (a pickled calibration table, YOND_SIDD.py:316-321) is not built")
-    if 'simple' in est_type:
+    if 'ours' in est_type and 'cal_est' not in pipe:                                   # :342-348: NeuralNLF, a second network
+        raise NotImplementedError(f"est_type {est_type!r}: the reference estimates with a second network (NeuralNLF, YOND_SIDD.py:342-348); "
+                                  "this build estimates with 'simple', takes 'manual' or reads the other methods' files")
+    looked_up = file_estimate(pipe, est)                                               # :316-337 (cal_est first, as the reference's chain)
+    if looked_up is not None:
+        reg = (np.float64(looked_up[0]), np.float64(looked_up[1]))
+        lr_max_dev, nle_info = _frame_max(lr_cat), {}
+    elif 'simple' in est_type:
         lr_max_dev = _frame_max(lr_cat) if lr_full is not None else None
         reg, nle_info = SimpleNLF(raw4est, k=k, setting={'mode': 'self'}, full=True)   # :341
     elif 'manual' in est_type:                                                         # :349-351: a fixed (K, sigma) = (14, 20) DN

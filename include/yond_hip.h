@@ -499,6 +499,19 @@ int yond_film_mlp_fwd_f32(const float* t, const float* w1, const float* b1, cons
 int yond_film_mlp_bwd_f32(const float* t, const float* w1, const float* b1, const float* W2, const float* W3, const float* tk,
                           const float* dtk, const float* dtb, int B, int C, int ld, float* scratch, float* dw1, float* db1,
                           float* dW2, float* db2, float* dW3, float* db3, void* stream);
+/* The same for ALL guided blocks of a network at once (n <= 12; the MLPs depend on sigma and the weights only): 2 launches forward,
+ * 5 backward, instead of that many per block.  d: HOST array.  Forward reads t, w1 .. b3 and writes tk, tb ([B][ld]; columns beyond C
+ * must already be zero); backward reads t, w1, b1, W2, W3, tk, dtk, dtb, uses scratch (2 * B * C floats) and writes dw1 .. db3. */
+typedef struct YondFilmMlpDesc {
+    const float *t, *w1, *b1, *W2, *b2, *W3, *b3;
+    float *tk, *tb;
+    const float *dtk, *dtb;
+    float* scratch;
+    float *dw1, *db1, *dW2, *db2, *dW3, *db3;
+    int B, C, ld, pad_;
+} YondFilmMlpDesc;
+int yond_film_mlp_fwd_multi_f32(const YondFilmMlpDesc* d, int n, void* stream);
+int yond_film_mlp_bwd_multi_f32(const YondFilmMlpDesc* d, int n, void* stream);
 int yond_silu_bwd_add_f32(const float* x, const float* dz, const float* dres, float* dx, size_t n, void* stream);
 /* g [N][H][W][C] = dy [N][ceil(H/2)][ceil(W/2)][C] at the even pixels, 0 elsewhere (the stride-2 layers' data gradient runs as a
  * stride-1 convolution over it). */

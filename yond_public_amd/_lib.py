@@ -96,6 +96,8 @@ PROTOTYPES = {
     "yond_film_silu_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, i32, sz, i32, vp],
     "yond_film_mlp_fwd_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
     "yond_film_mlp_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "yond_film_mlp_fwd_multi_f32": [vp, i32, vp],
+    "yond_film_mlp_bwd_multi_f32": [vp, i32, vp],
     "yond_silu_bwd_add_f32": [vp, vp, vp, vp, sz, vp],
     "yond_zero_interleave_f32": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "yond_l1_loss_f32": [vp, vp, sz, vp, vp, vp],
@@ -178,6 +180,12 @@ def require_cuda(t, name="tensor"):
     if not t.is_contiguous():
         raise YondHipError(f"{name} must be contiguous")
     return t
+
+
+class FilmMlpDesc(C.Structure):
+    """YondFilmMlpDesc of include/yond_hip.h (one guided block's sigma-MLPs for the multi-block entries)."""
+    _fields_ = [(k, C.c_void_p) for k in ('t', 'w1', 'b1', 'W2', 'b2', 'W3', 'b3', 'tk', 'tb', 'dtk', 'dtb', 'scratch',
+                                          'dw1', 'db1', 'dW2', 'db2', 'dW3', 'db3')] + [(k, C.c_int) for k in ('B', 'C', 'ld', 'pad_')]
 
 
 def ptr(t):

@@ -576,11 +576,11 @@ struct FilmMlpArgs {
     int B, C, ld;
 };
 template <int MODE>
-__global__ __launch_bounds__(256) void film_mlp_tile_kernel(const FilmMlpArgs a) {
+__device__ __forceinline__ void film_mlp_tile_body(const FilmMlpArgs& a, int bx, int by) {
     __shared__ float As[16][65], Bs[64][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int M = MODE < 4 ? a.B : a.C, N = a.C, K = MODE < 4 ? a.C : a.B;
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int m0 = by * 16, n0 = bx * 16;
     auto hval = [&](int b, int k) { return silu_f(a.t[b] * a.w1[k] + a.b1[k]); };
     auto A_at = [&](int m, int k) -> float {
         if (m >= M || k >= K) return 0.0f;
@@ -625,15 +625,40 @@ __global__ __launch_bounds__(256) void film_mlp_tile_kernel(const FilmMlpArgs a)
     else if constexpr (MODE == 3) a.out[(size_t)m * a.C + n] = acc * dsilu_f(a.t[m] * a.w1[n] + a.b1[n]);
     else a.out[(size_t)m * a.C + n] = acc;
 }
+template <int MODE>
+__global__ __launch_bounds__(256) void film_mlp_tile_kernel(const FilmMlpArgs a) {
+    film_mlp_tile_body<MODE>(a, blockIdx.x, blockIdx.y);
+}
+// ... and for ALL guided blocks of a network in one launch (their MLPs depend on sigma and the weights only: every block's forward
+// can run before the first convolution, every block's backward after the last): nine blocks x (2 + 5) launches of ~12 us each -- latency,
+// not work -- become 2 + 5 launches as long as the largest block's.  The descriptors travel in the kernel arguments.
+#define FILM_MULTI_MAX 12
+struct FilmMlpMulti {
+    FilmMlpArgs a[FILM_MULTI_MAX];
+    int tile0[FILM_MULTI_MAX + 1];                      // first workgroup of entry e (prefix sums of the entries' tile counts)
+    int n;
+};
+__device__ __forceinline__ int film_multi_entry(const FilmMlpMulti& mm, int wg) {
+    int e = 0;
+    for (int i = 1; i < mm.n; ++i) e += (wg >= mm.tile0[i]) ? 1 : 0;
+    return e;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void film_mlp_tile_multi_kernel(const FilmMlpMulti mm) {
+    const int e = film_multi_entry(mm, blockIdx.x);
+    const int local = blockIdx.x - mm.tile0[e];
+    const int nx = (mm.a[e].C + 15) / 16;
+    film_mlp_tile_body<MODE>(mm.a[e], local % nx, local / nx);
+}
 
 // the five parameter vectors' gradients (sums over the batch) and the zero padding of tk / tb rows
 // (a workgroup = 64 channels x 4 quarters of the batch, joined in LDS: one thread per channel over the whole batch was latency bound)
-__global__ __launch_bounds__(256) void film_mlp_vec_kernel(const float* __restrict__ t, const float* __restrict__ dtb, const float* __restrict__ dtk_tot,
-                                                           const float* __restrict__ da, int B, int C, int ld, float* __restrict__ db3,
-                                                           float* __restrict__ db2, float* __restrict__ dw1, float* __restrict__ db1) {
+__device__ __forceinline__ void film_mlp_vec_body(const float* __restrict__ t, const float* __restrict__ dtb, const float* __restrict__ dtk_tot,
+                                                  const float* __restrict__ da, int B, int C, int ld, float* __restrict__ db3,
+                                                  float* __restrict__ db2, float* __restrict__ dw1, float* __restrict__ db1, int bx) {
     __shared__ float part[4][4][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + e;
+    const int i = bx * 64 + e;
     float s3 = 0.0f, s2 = 0.0f, sw = 0.0f, sb = 0.0f;
     if (i < C)
         for (int b = q; b < B; b += 4) {
@@ -649,6 +674,24 @@ __global__ __launch_bounds__(256) void film_mlp_vec_kernel(const float* __restri
         const float v = (part[0][q][e] + part[1][q][e]) + (part[2][q][e] + part[3][q][e]);
         (q == 0 ? db3 : q == 1 ? db2 : q == 2 ? dw1 : db1)[i] = v;
     }
+}
+__global__ __launch_bounds__(256) void film_mlp_vec_kernel(const float* __restrict__ t, const float* __restrict__ dtb, const float* __restrict__ dtk_tot,
+                                                           const float* __restrict__ da, int B, int C, int ld, float* __restrict__ db3,
+                                                           float* __restrict__ db2, float* __restrict__ dw1, float* __restrict__ db1) {
+    film_mlp_vec_body(t, dtb, dtk_tot, da, B, C, ld, db3, db2, dw1, db1, blockIdx.x);
+}
+struct FilmVecMulti {
+    const float *t[FILM_MULTI_MAX], *dtb[FILM_MULTI_MAX], *dtk_tot[FILM_MULTI_MAX], *da[FILM_MULTI_MAX];
+    float *db3[FILM_MULTI_MAX], *db2[FILM_MULTI_MAX], *dw1[FILM_MULTI_MAX], *db1[FILM_MULTI_MAX];
+    int B[FILM_MULTI_MAX], C[FILM_MULTI_MAX], ld[FILM_MULTI_MAX];
+    int tile0[FILM_MULTI_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void film_mlp_vec_multi_kernel(const FilmVecMulti vm) {
+    int e = 0;
+    for (int i = 1; i < vm.n; ++i) e += ((int)blockIdx.x >= vm.tile0[i]) ? 1 : 0;
+    film_mlp_vec_body(vm.t[e], vm.dtb[e], vm.dtk_tot[e], vm.da[e], vm.B[e], vm.C[e], vm.ld[e], vm.db3[e], vm.db2[e], vm.dw1[e], vm.db1[e],
+                      (int)blockIdx.x - vm.tile0[e]);
 }
 __global__ __launch_bounds__(256) void film_mlp_pad_kernel(float* __restrict__ tk, float* __restrict__ tb, int B, int C, int ld) {
     const int i = blockIdx.x * 256 + threadIdx.x, w = ld - C;
@@ -696,6 +739,66 @@ extern "C" int yond_film_mlp_bwd_f32(const float* t, const float* w1, const floa
     a.out = dW2;
     film_mlp_launch<5>(a, st);
     hipLaunchKernelGGL(film_mlp_vec_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, t, dtb, dtk_tot, da, B, C, ld, db3, db2, dw1, db1);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// The same for n <= 12 blocks at once (host array of descriptors; tk / tb rows beyond C must be zero already: the caller clears them).
+template <int MODE>
+static void film_mlp_launch_multi(const YondFilmMlpDesc* d, int n, hipStream_t st) {
+    FilmMlpMulti mm;
+    int tiles = 0;
+    for (int e = 0; e < n; ++e) {
+        const YondFilmMlpDesc& q = d[e];
+        float* dtk_tot = q.scratch;
+        float* da = q.scratch ? q.scratch + (size_t)q.B * q.C : nullptr;
+        float* out = MODE == 0 ? q.tk : MODE == 1 ? q.tb : MODE == 2 ? dtk_tot : MODE == 3 ? da : MODE == 4 ? q.dW3 : q.dW2;
+        mm.a[e] = FilmMlpArgs{q.t, q.w1, q.b1, q.W2, q.b2, q.W3, q.b3, q.tk, q.dtk, q.dtb, dtk_tot, out, q.B, q.C, q.ld};
+        mm.tile0[e] = tiles;
+        const int M = MODE < 4 ? q.B : q.C;
+        tiles += ((q.C + 15) / 16) * ((M + 15) / 16);
+    }
+    mm.tile0[n] = tiles;
+    mm.n = n;
+    hipLaunchKernelGGL(film_mlp_tile_multi_kernel<MODE>, dim3((unsigned)tiles), dim3(256), 0, st, mm);
+}
+static int film_multi_check(const YondFilmMlpDesc* d, int n, bool bwd) {
+    if (!d || n < 1 || n > FILM_MULTI_MAX) return YOND_EINVAL;
+    for (int e = 0; e < n; ++e) {
+        const YondFilmMlpDesc& q = d[e];
+        if (!q.t || !q.w1 || !q.b1 || !q.W2 || !q.W3 || !q.tk || q.B <= 0 || q.C <= 0 || q.ld < q.C) return YOND_EINVAL;
+        if (!bwd && (!q.b2 || !q.b3 || !q.tb)) return YOND_EINVAL;
+        if (bwd && (!q.dtk || !q.dtb || !q.scratch || !q.dw1 || !q.db1 || !q.dW2 || !q.db2 || !q.dW3 || !q.db3)) return YOND_EINVAL;
+    }
+    return YOND_OK;
+}
+extern "C" int yond_film_mlp_fwd_multi_f32(const YondFilmMlpDesc* d, int n, void* stream) {
+    if (int rc = film_multi_check(d, n, false)) return rc;
+    film_mlp_launch_multi<0>(d, n, (hipStream_t)stream);
+    film_mlp_launch_multi<1>(d, n, (hipStream_t)stream);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+extern "C" int yond_film_mlp_bwd_multi_f32(const YondFilmMlpDesc* d, int n, void* stream) {
+    if (int rc = film_multi_check(d, n, true)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    film_mlp_launch_multi<2>(d, n, st);
+    film_mlp_launch_multi<3>(d, n, st);
+    film_mlp_launch_multi<4>(d, n, st);
+    film_mlp_launch_multi<5>(d, n, st);
+    FilmVecMulti vm;
+    int tiles = 0;
+    for (int e = 0; e < n; ++e) {
+        const YondFilmMlpDesc& q = d[e];
+        vm.t[e] = q.t; vm.dtb[e] = q.dtb; vm.dtk_tot[e] = q.scratch; vm.da[e] = q.scratch + (size_t)q.B * q.C;
+        vm.db3[e] = q.db3; vm.db2[e] = q.db2; vm.dw1[e] = q.dw1; vm.db1[e] = q.db1;
+        vm.B[e] = q.B; vm.C[e] = q.C; vm.ld[e] = q.ld;
+        vm.tile0[e] = tiles;
+        tiles += (q.C + 63) / 64;
+    }
+    vm.tile0[n] = tiles;
+    vm.n = n;
+    hipLaunchKernelGGL(film_mlp_vec_multi_kernel, dim3((unsigned)tiles), dim3(256), 0, st, vm);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -21,6 +21,7 @@ packed weights resident).  Data-parallel: one process per GPU, every rank steps 
 gradients in two 25 MB buckets launched from backward's hooks (the only collective of training: 44.7 MB per step).
 Pinned by tests/golden/train.npz (loss, gradients and updated weights of the reference's own step on the same inputs) and
 tests/golden/train_sched.npz (the reference's schedules, a two-epoch run of its loop, its Charbonnier loss)."""
+import ctypes as C
 import math
 import types
 
@@ -33,6 +34,7 @@ from .engine import DenoiserPlan, _PackedConv, _rup
 
 
 WGRAD_BIAS = True                # the bias gradient of a 3x3 stride-1 layer rides along in the split-operand weight-gradient kernel
+FILM_ALL = True                     # the guided blocks' sigma-MLPs in one forward and one backward call for the whole net (False: per block)
                                  # (module attribute: tools/ flip it for A/B runs)
 
 
@@ -45,6 +47,7 @@ def _plan(dev):
     # word 0 is what the convolution launches and the weight packer report into; TrainStep reads it once per step
     plan.status = torch.zeros(4, dtype=torch.int32, device=plan.dev)
     plan.status_slot = 0
+    plan.gen = 0                     # bumped whenever a buffer the step's launches point at is replaced: captured steps are then stale
     return plan
 
 
@@ -148,7 +151,7 @@ def _wgrad(plan, x, dy, mode, stride, taps, with_bias=False, oihw=False):
             if need:
                 ws = getattr(plan, 'wgrad_ws', None)
                 if ws is None or ws.numel() * 4 < need:
-                    ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+                    ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device); plan.gen += 1   # (captured steps hold the old one)
                 buf = torch.empty(taps * co * ci + co, dtype=torch.float32, device=x.device)
                 L.check(plan.lib.yond_conv_wgrad_split_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, co, L.ptr(buf), 3 if oihw else 1, L.ptr(ws),
                                                            ws.numel() * 4, L.ptr(getattr(plan, 'status', None)), L.stream()),
@@ -167,7 +170,7 @@ def _wgrad(plan, x, dy, mode, stride, taps, with_bias=False, oihw=False):
         if need:
             ws = getattr(plan, 'wgrad_ws', None)
             if ws is None or ws.numel() * 4 < need:
-                ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+                ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device); plan.gen += 1   # (captured steps hold the old one)
             st = getattr(plan, 'status', None)
             L.check(plan.lib.yond_conv_wgrad_split_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, co, L.ptr(dw), 0, L.ptr(ws), ws.numel() * 4,
                                                        L.ptr(st), L.stream()), "yond_conv_wgrad_split_f32")
@@ -175,7 +178,7 @@ def _wgrad(plan, x, dy, mode, stride, taps, with_bias=False, oihw=False):
     need = int(plan.lib.yond_conv_wgrad_ws_bytes(N, H, W, ci, Ho, Wo, co, mode, stride))
     ws = getattr(plan, 'wgrad_ws', None)
     if ws is None or ws.numel() * 4 < need:
-        ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        ws = plan.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device); plan.gen += 1   # (captured steps hold the old one)
     L.check(plan.lib.yond_conv_wgrad_ws_f32(L.ptr(x), L.ptr(dy), N, H, W, ci, Ho, Wo, co, mode, stride, L.ptr(dw), L.ptr(ws), ws.numel() * 4,
                                             L.stream()), "yond_conv_wgrad_ws_f32")
     return dw
@@ -356,6 +359,73 @@ class _FilmMLP(torch.autograd.Function):
         return None, dw1.view(s1), db1, dW2.view(s2), db2, dW3.view(s3), db3, None, None
 
 
+class _FilmMLPAll(torch.autograd.Function):
+    """_FilmMLP for ALL guided blocks of the net in one call: the MLPs depend on sigma and their own weights only, so every block's
+    forward runs before the first convolution (2 launches) and every block's backward after the last (5 launches) -- per block they
+    were 2 + 5 launches of ~12 us of latency each, 63 per step.  apply(t, plan, cps, *params) with six parameters per block in _FilmMLP's
+    order; returns (tk_0, tb_0, tk_1, tb_1, ...), views of one zero-initialised buffer."""
+
+    @staticmethod
+    def forward(ctx, t, plan, cps, *params):
+        nb = len(cps)
+        B = t.shape[0]
+        t = t.contiguous()
+        params = [q if q.is_contiguous() else q.contiguous() for q in params]
+        buf = torch.zeros(2 * B * sum(cps), dtype=torch.float32, device=t.device)
+        outs, off = [], 0
+        descs = (L.FilmMlpDesc * nb)()
+        for i, cp in enumerate(cps):
+            w1, b1, w2, b2, w3, b3 = params[6 * i:6 * i + 6]
+            tk = buf[off:off + B * cp].view(B, cp)
+            tb = buf[off + B * cp:off + 2 * B * cp].view(B, cp)
+            off += 2 * B * cp
+            d = descs[i]
+            d.t, d.w1, d.b1, d.W2, d.b2, d.W3, d.b3 = (q.data_ptr() for q in (t, w1, b1, w2, b2, w3, b3))
+            d.tk, d.tb = tk.data_ptr(), tb.data_ptr()
+            d.B, d.C, d.ld = B, w1.shape[0], cp
+            outs += [tk, tb]
+        L.check(plan.lib.yond_film_mlp_fwd_multi_f32(C.cast(descs, C.c_void_p), nb, L.stream()), "yond_film_mlp_fwd_multi_f32")
+        ctx.save_for_backward(t, *params, *outs[0::2])       # (outputs go through save_for_backward: a plain attribute would keep the
+        ctx.plan, ctx.cps = plan, tuple(cps)                 #  step's autograd graph alive into the next step -- and into a graph capture)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        nb = len(ctx.cps)
+        t, *rest = ctx.saved_tensors
+        params, tks = rest[:6 * nb], rest[6 * nb:]
+        B, dev = t.shape[0], t.device
+        Cs = [params[6 * i].shape[0] for i in range(nb)]
+        need = sum(2 * B * c + 4 * c + 2 * c * c for c in Cs)
+        buf = torch.empty(need, dtype=torch.float32, device=dev)
+        descs = (L.FilmMlpDesc * nb)()
+        keep, out, off = [], [], 0
+
+        def take(n, shape):
+            nonlocal off
+            v = buf[off:off + n].view(shape)
+            off += n
+            return v
+        for i, (cp, c) in enumerate(zip(ctx.cps, Cs)):
+            w1, b1, w2, b2, w3, b3 = params[6 * i:6 * i + 6]
+            tk = tks[i]
+            dtk, dtb = grads[2 * i], grads[2 * i + 1]
+            dtk = torch.zeros_like(tk) if dtk is None else dtk.contiguous()
+            dtb = torch.zeros_like(tk) if dtb is None else dtb.contiguous()
+            keep += [dtk, dtb]
+            scratch = take(2 * B * c, (2 * B * c,))
+            dw1, db1, db2, db3 = take(c, w1.shape), take(c, (c,)), take(c, (c,)), take(c, (c,))
+            dW2, dW3 = take(c * c, w2.shape), take(c * c, w3.shape)
+            d = descs[i]
+            d.t, d.w1, d.b1, d.W2, d.W3 = (q.data_ptr() for q in (t, w1, b1, w2, w3))
+            d.tk, d.dtk, d.dtb, d.scratch = tk.data_ptr(), dtk.data_ptr(), dtb.data_ptr(), scratch.data_ptr()
+            d.dw1, d.db1, d.dW2, d.db2, d.dW3, d.db3 = (q.data_ptr() for q in (dw1, db1, dW2, db2, dW3, db3))
+            d.B, d.C, d.ld = B, c, cp
+            out += [dw1, db1, dW2, db2, dW3, db3]
+        L.check(ctx.plan.lib.yond_film_mlp_bwd_multi_f32(C.cast(descs, C.c_void_p), nb, L.stream()), "yond_film_mlp_bwd_multi_f32")
+        return (None, None, None) + tuple(out)
+
+
 class _SiluRes(torch.autograd.Function):
     """A guided block's input: returns (SiLU(x), x) -- conv1's operand and the tensor the block adds to its output.  Backward joins
     the two gradients in one pass, dx = dres + dz SiLU'(x) (yond_silu_bwd_add_f32), where autograd ran silu_backward and then an
@@ -483,8 +553,11 @@ class TrainStep:
             x = _Conv1x1.apply(x, xs, P[pre + '.short_cut.0.weight'], P[pre + '.short_cut.0.bias'], self.plan)
         c = P[pre + '.conv1.weight'].shape[0]
         # gamma / beta: 1x1 convolutions on a (B, 1, 1, 1) tensor = three tiny linear layers (archs/modules.py:170-178), one kernel
-        tk, tb = _FilmMLP.apply(t, P[pre + '.gamma.0.weight'], P[pre + '.gamma.0.bias'], P[pre + '.gamma.2.weight'], P[pre + '.gamma.2.bias'],
-                                P[pre + '.beta.1.weight'], P[pre + '.beta.1.bias'], self.plan, cp)
+        if isinstance(t, dict):                              # every block's MLPs at once (forward: _FilmMLPAll)
+            tk, tb = t[pre]
+        else:
+            tk, tb = _FilmMLP.apply(t, P[pre + '.gamma.0.weight'], P[pre + '.gamma.0.bias'], P[pre + '.gamma.2.weight'],
+                                    P[pre + '.gamma.2.bias'], P[pre + '.beta.1.weight'], P[pre + '.beta.1.bias'], self.plan, cp)
         z, xr = _SiluRes.apply(x, self.plan)                 # SiLU(x) for conv1, x itself for the residual (gradients joined in one pass)
         z = _Conv3x3.apply(z, P[pre + '.conv1.weight'], P[pre + '.conv1.bias'], self.plan, 1, True)
         if self.plan.lib.yond_film_silu_supported(cp):
@@ -542,6 +615,14 @@ class TrainStep:
             x = x / ub[:, None, None, None]
             t = t / ub
         nf = P['conv_in.weight'].shape[0]
+        if FILM_ALL and self.reducer is None:                # the sigma-MLPs of all nine blocks up front (they depend on t only); not under DDP:
+                                                             # their gradients would all land last and hold back every bucket's all-reduce
+            pres = [f'conv{i}' for i in range(1, 10)]
+            cps = [_rup(nf * 2 ** (min(i, 10 - i) - 1)) for i in range(1, 10)]
+            flat = [P[pre + k] for pre in pres for k in ('.gamma.0.weight', '.gamma.0.bias', '.gamma.2.weight', '.gamma.2.bias',
+                                                         '.beta.1.weight', '.beta.1.bias')]
+            outs = _FilmMLPAll.apply(t, self.plan, cps, *flat)
+            t = {pre: (outs[2 * i], outs[2 * i + 1]) for i, pre in enumerate(pres)}
         a = _Conv3x3.apply(_pad_c(x, 32), P['conv_in.weight'], P['conv_in.bias'], self.plan, 1, False)
         cur = F.leaky_relu(a, 0.01)
         skips = {}
@@ -576,6 +657,7 @@ class TrainStep:
                     slots[id(m)] = (off, m.numel())
                     maps.append(m)
                     off += m.numel()
+            plan.gen += 1
             self._wb_map, self._wb_slots, self._wb_count = torch.cat(maps), slots, len(packs)
             self._wb_buf = torch.empty(off, dtype=torch.float32, device=self.dev)
             # the split-operand layers' packing as ONE launch: descriptor table + one destination buffer whose slices the layers keep
@@ -663,7 +745,9 @@ class TrainStep:
         g.hyp = torch.zeros(2, dtype=torch.float32, device=self.dev)
         lib = self.plan.lib
         g.graph = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize(self.dev)
+        self._gather_weights()                               # (tables and buffers for every layer met so far are built HERE, not while capturing:
+        torch.cuda.synchronize(self.dev)                     #  a host-to-device copy inside a capture is not allowed)
+        gen0 = self.plan.gen
         with torch.cuda.graph(g.graph):
             g.pred, g.loss_sum = self._fwd_bwd(g.lr_in, g.hr_in, g.sigma, S)
             self.plan.status[2:3].copy_(torch.logical_not(torch.isfinite(g.loss_sum)).to(torch.int32))
@@ -671,11 +755,15 @@ class TrainStep:
             L.check(lib.yond_adam_step_dev_f32(L.ptr(self.arena), L.ptr(g.flat), L.ptr(self.adam_m), L.ptr(self.adam_v), self.arena.numel(),
                                                self.betas[0], self.betas[1], self.eps, L.ptr(g.hyp), L.ptr(self.plan.status), L.stream()),
                     "yond_adam_step_dev_f32")
+        g.gen = self.plan.gen if self.plan.gen == gen0 else -1     # (a buffer replaced DURING the capture: use this graph once at most)
         return g
 
     def _graph_step(self, key, imgs_lr, imgs_hr, sigma, S):
         """One replay.  Returns (loss, grads) or None when the step tripped the range guard (no update was applied)."""
         g = self._graphs.get(key)
+        if g is not None and g.gen != self.plan.gen:         # a workspace / packed-weight buffer its launches point at has been replaced since
+            del self._graphs[key]                            # (another batch shape met new layers): capture again
+            g = None
         if g is None:
             g = self._graphs[key] = self._capture(imgs_lr, imgs_hr, sigma, S)
         g.lr_in.copy_(imgs_lr)

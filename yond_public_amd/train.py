@@ -765,6 +765,8 @@ class TrainStep:
             del self._graphs[key]                            # (another batch shape met new layers): capture again
             g = None
         if g is None:
+            while len(self._graphs) >= 4:                    # (every graph keeps its own activations: a handful of batch shapes at most)
+                del self._graphs[next(iter(self._graphs))]
             g = self._graphs[key] = self._capture(imgs_lr, imgs_hr, sigma, S)
         g.lr_in.copy_(imgs_lr)
         g.hr_in.copy_(imgs_hr)

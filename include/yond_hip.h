@@ -524,7 +524,8 @@ int yond_charbonnier_loss_f32(const float* pred, const float* target, size_t n, 
 int yond_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps,
                        int step, void* stream);
 /* The same with the step's scalars on the device (hyp[0] = lr / (1 - beta1^step), hyp[1] = 1 / sqrt(1 - beta2^step) as float32), for a
- * step captured in a hipGraph; status (two words, optional): no update when bit 0 of either is set. */
+ * step captured in a hipGraph; status (three int words, optional): no update when bit 0 of any is set (the kernels' two range words and one
+ * of the caller's, e.g. a non-finite loss). */
 int yond_adam_step_dev_f32(float* p, const float* g, float* m, float* v, size_t n, double beta1, double beta2, double eps,
                            const float* hyp, const int* status, void* stream);
 

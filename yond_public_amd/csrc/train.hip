@@ -932,12 +932,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 // The same update with the step's two scalars read from the device -- hyp[0] = lr / (1 - beta1^t), hyp[1] = 1 / sqrt(1 - beta2^t), computed
 // by the host in float64 exactly as below and rounded to float32 -- so that a CAPTURED step (hipGraph) can be replayed with another
-// learning rate and step count; status (optional, two words): the update is skipped when bit 0 of either is set (a gradient or a
-// weight left fp16's range in the split-operand kernels: the host lowers the loss scale and redoes the step).
+// learning rate and step count; status (optional, three words): the update is skipped when bit 0 of any is set (a gradient, a weight left
+// fp16's range in the split-operand kernels; the caller's own word, e.g. a non-finite loss: the host lowers the loss scale and redoes the step).
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, size_t n, float b1, float b2, const float* __restrict__ hyp, float eps,
                                                        const int* __restrict__ status) {
-    if (status && ((status[0] | status[1]) & 1)) return;
+    if (status && ((status[0] | status[1] | status[2]) & 1)) return;
     const float step_size = hyp[0], inv_bc2_sqrt = hyp[1];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float gi = g[i];

@@ -214,7 +214,10 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
     if (d.out4_dst && (tn != 32 || parts != 2)) return YOND_EUNSUPPORTED;
     if (op4) return YOND_EUNSUPPORTED;                          // (3x3 stride-1 layers store [N][H][W][C] or split planes)
-    const long long tiles12 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
+    long long tiles12 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
+    // ... unless 12-row tiles pad the image's rows >= 1.3x more than 8-row tiles do: images of 8 and 16 rows (the deep levels of a batch of
+    // 128 x 128 patches: training, the SIDD blocks) are 1.5x the rows in 12-row tiles and exact in 8-row tiles
+    if (((d.Ho + 11) / 12) * 12 * 10 >= ((d.Ho + 7) / 8) * 8 * 13) tiles12 = 0;
     // 32 -> 32 channels: two weight slices in all -- on two buffers they stay resident in LDS (conv_split_kernel.h, wres)
     const bool wres = parts == 2 && tn == 32 && d.Cout == 32 && d.C0 + d.C1 == 32 && yond_exp_long("YOND_SPLIT_WRES", 1) != 0;
     if (wres && isp && osp && !d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, false, false, false, true, true>(d, st);

@@ -214,10 +214,17 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
     if (d.out4_dst && (tn != 32 || parts != 2)) return YOND_EUNSUPPORTED;
     if (op4) return YOND_EUNSUPPORTED;                          // (3x3 stride-1 layers store [N][H][W][C] or split planes)
+    // 12-row or 8-row tiles (64-channel kernels): 256 persistent workgroups walk the tiles in rounds, so a launch costs
+    // rounds x rows per tile; a row of a 12-row tile is ~10 % cheaper (0.59 instead of 0.78 KiB of LDS fragments per MFMA, 1.5x the MFMA
+    // work per barrier).  The full frames' levels (94 / 188 / 376 / 752 rows) fill whole rounds of 12-row tiles; batches of small
+    // images do not: 8- and 16-row images are padded 1.5x by 12-row tiles and are exact in 8-row tiles, 32-row images of a batch of 64
+    // take 1.5 rounds of 12-row tiles.  8-row tiles when they are >= 7 % cheaper by that count; fewer than 256 tiles: 8-row, as before.
     long long tiles12 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
-    // ... unless 12-row tiles pad the image's rows >= 1.3x more than 8-row tiles do: images of 8 and 16 rows (the deep levels of a batch of
-    // 128 x 128 patches: training, the SIDD blocks) are 1.5x the rows in 12-row tiles and exact in 8-row tiles
-    if (((d.Ho + 11) / 12) * 12 * 10 >= ((d.Ho + 7) / 8) * 8 * 13) tiles12 = 0;
+    {
+        const long long tiles8 = (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 7) / 8) * d.N;
+        const long long r12 = (tiles12 + 255) / 256, r8 = (tiles8 + 255) / 256;
+        if (8000 * r8 < 10044 * r12) tiles12 = 0;                 // cost8 = 8 r8 < 0.93 x cost12 = 0.93 x 10.8 r12
+    }
     // 32 -> 32 channels: two weight slices in all -- on two buffers they stay resident in LDS (conv_split_kernel.h, wres)
     const bool wres = parts == 2 && tn == 32 && d.Cout == 32 && d.C0 + d.C1 == 32 && yond_exp_long("YOND_SPLIT_WRES", 1) != 0;
     if (wres && isp && osp && !d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, false, false, false, true, true>(d, st);

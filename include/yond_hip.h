@@ -456,6 +456,12 @@ int yond_pack_vst_norm_chain_f32(const float* bayer, int H, int W, float* out, i
                                  double scale, double* prm, const void* lut_ws, int lut_cap, float* img_max, void* stream);
 int yond_denorm_ivst_unpack_dev_f32(const float* net_out, int Hp, int Wp, int pad_t, int pad_l, int h, int w, float* bayer,
                                     int mode, double scale, const double* prm, int clip01, void* stream);
+/* K1 / K4 of the device chain for B equally sized frames that share the parameter block and the table (the 32 blocks of a SIDD image,
+ * YOND_SIDD.py:392-407): bayer [B][H][W] -> out [B][Hp][Wp][4], img_max [B];  net_out [B][Hp][Wp][4] -> bayer_out [B][2h][2w]. */
+int yond_pack_vst_norm_batch_dev_f32(const float* bayer, int B, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
+                                     double scale, const double* prm, const void* lut_ws, int lut_cap, float* img_max, void* stream);
+int yond_denorm_ivst_unpack_batch_dev_f32(const float* net_out, int B, int Hp, int Wp, int pad_t, int pad_l, int h, int w,
+                                          float* bayer_out, int mode, double scale, const double* prm, int clip01, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * N4, first slice: what one training step needs beyond the forward kernels (trainer_AWGN.py:101-117, losses/base_loss.py:81-113,

@@ -105,6 +105,48 @@ def test_device_chain_equals_host_chain():
             assert np.array_equal(ys_d[it], f.y.cpu().numpy())
 
 
+@pytest.mark.parametrize("with_full", [False, True])
+def test_sidd_layout_device_chain_equals_host_chain(with_full):
+    """The SIDD layout ([32][H][W] blocks, block-wise denoising, round 1's estimate on the blocks' concatenation or on a separate full
+    frame, YOND_SIDD.py:312-470) on the device chain -- batched K1 / K4 reading the parameter block, no host round trip between the
+    rounds -- against the host-side chain: estimates to the order of the float64 atomics, outputs to 2e-7, and the path really taken."""
+    import yond_oracle as O
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    from yond_public_amd import synthetic as S
+    arch = ARCHS["gru8"]
+    net = A.GuidedResUnet(dict(arch))
+    net.load_state_dict(S.denoising_state_dict(net, 3))
+    net = net.to(DEV).eval()
+    noisy, _ = O.synth_noisy(64, 32 * 96, 4.0, 6.0, 21)
+    blocks = torch.from_numpy(np.stack(np.split(noisy, 32, axis=-1))).to(DEV)
+    full = torch.from_numpy(O.synth_noisy(320, 512, 4.0, 6.0, 22)[0]).to(DEV) if with_full else None
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': False}
+    p = P.default_params()
+    assert P.chain_applies_sidd(blocks, full, net, arch, pipe, p)
+    calls = []
+    orig = P._iter_denoise_chain_sidd
+    P._iter_denoise_chain_sidd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        res_d = P.IterDenoise(blocks, net, arch, pipe, lr_full=full)
+    finally:
+        P._iter_denoise_chain_sidd = orig
+    assert calls and 'nle_info' in res_d                        # (the device chain ran and was not handed back to the host path)
+    P.CHAIN_SIDD = False
+    try:
+        res_h = P.IterDenoise(blocks, net, arch, pipe, lr_full=full)
+    finally:
+        P.CHAIN_SIDD = True
+    assert len(res_d['raw_dns']) == len(res_h['raw_dns']) >= 1          # (round 2 may end at the reference's beta1 < 0 guard: on both paths alike)
+    print(f"[parity] SIDD layout: {len(res_d['raw_dns'])} round(s), regs {res_d['regs']}")
+    for rd, rh in zip(res_d['regs'], res_h['regs']):
+        np.testing.assert_allclose(rd[0], rh[0], rtol=1e-10)
+        np.testing.assert_allclose(rd[1], rh[1], rtol=1e-9, atol=1e-20)
+    for it, (a, b) in enumerate(zip(res_d['raw_dns'], res_h['raw_dns'])):
+        assert a.shape == b.shape == (64, 32 * 96)
+        assert report(f"SIDD layout, device chain vs host chain, round {it}", a.cpu().numpy(), b.cpu().numpy()) <= 2e-7
+
+
 @pytest.mark.parametrize("ub", [3.0, 17.0, 49.0, 50.0, 51.0, 137.0, 499.0, 500.0, 501.0, 509.0, 510.0, 961.0, 1024.0, 1475.0])
 def test_device_knot_grid_bit_identical(ub):
     """yond_frame_params_f64's knot grid against the reference's np.linspace calls (utils/isp_algos.py:101-108, pipeline._bias_knots)

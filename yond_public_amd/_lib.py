@@ -114,8 +114,10 @@ PROTOTYPES = {
     "yond_lut_ws_bytes": [i32],
     "yond_lut_table_f64": [vp, vp, i32, vp, vp, vp],
     "yond_pack_vst_norm_dev_f32": [vp, i32, i32, vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, vp],
+    "yond_pack_vst_norm_batch_dev_f32": [vp, i32, i32, i32, vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, vp],
     "yond_pack_vst_norm_chain_f32": [vp, i32, i32, vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, vp],
     "yond_denorm_ivst_unpack_dev_f32": [vp, i32, i32, i32, i32, i32, i32, vp, i32, f64, vp, i32, vp],
+    "yond_denorm_ivst_unpack_batch_dev_f32": [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, f64, vp, i32, vp],
 }
 # experiment builds only (include/yond_hip_experiments.h): bound when the loaded library has them
 EXPERIMENT_PROTOTYPES = {

@@ -370,6 +370,32 @@ extern "C" int yond_pack_vst_norm_dev_f32(const float* bayer, int H, int W, floa
     return YOND_OK;
 }
 
+// ... and B frames that share the parameter block and the table (img_max [B])
+extern "C" int yond_pack_vst_norm_batch_dev_f32(const float* bayer, int B, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
+                                          double scale, const double* prm, const void* lut_ws, int lut_cap, float* img_max, void* stream) {
+    if (!bayer || !out || !prm || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return YOND_EINVAL;
+    if (lut_ws && (lut_cap < 2 || lut_cap > LUT_MAX)) return YOND_EINVAL;
+    if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 || !(scale > 0.0)) return YOND_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int Hp = H / 2 + pad_t + pad_b, Wp = W / 2 + pad_l + pad_r;
+    if (img_max) {
+        hipError_t e = hipMemsetAsync(img_max, 0, (size_t)B * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    static bool attr = false;
+    if (!attr) {
+        if (int e = lut_smem_attr((const void*)pack_vst_norm_kernel)) return e;
+        attr = true;
+    }
+    const unsigned nb = (long long)Hp * B < 1536 ? (unsigned)(Hp * B) : 1536u;       // (the table is copied, not derived, per workgroup)
+    // (LDS: the coefficients of the caller's knot capacity: 1536 knots = 24 KB, six workgroups per CU)
+    hipLaunchKernelGGL(pack_vst_norm_kernel, dim3(nb), dim3(256), lut_ws ? (size_t)lut_cap * sizeof(double2) : 0, st, bayer, H, W, out,
+                       pad_l, pad_t, Hp, Wp, 1, (float)scale, 1.0, 0.0, 0.0, 1.0, (const double*)nullptr, (const void*)nullptr, 0, 0,
+                       (unsigned int*)img_max, prm, lut_ws, lut_cap, B);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
 // The chain's own K1 (pack_vst_chain_kernel): as yond_pack_vst_norm_dev_f32 for a table yond_frame_chain_f64 prepared; prm is also
 // WRITTEN (a table of another shape is flagged, nothing is computed).
 extern "C" int yond_pack_vst_norm_chain_f32(const float* bayer, int H, int W, float* out, int pad_l, int pad_r, int pad_t, int pad_b,
@@ -540,6 +566,19 @@ extern "C" int yond_denorm_ivst_unpack_dev_f32(const float* net_out, int Hp, int
     if (nb > 256 * 16) nb = 256 * 16;
     hipLaunchKernelGGL(denorm_ivst_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, net_out, Wp, pad_t,
                        pad_l, h, w, bayer_out, mode, scale, 1.0, 0.0, 0.0, 1.0, clip01, prm, 1, Hp);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
+// ... and B frames that share the parameter block (the 32 blocks of a SIDD image on the device chain)
+extern "C" int yond_denorm_ivst_unpack_batch_dev_f32(const float* net_out, int B, int Hp, int Wp, int pad_t, int pad_l, int h, int w,
+                                                     float* bayer_out, int mode, double scale, const double* prm, int clip01, void* stream) {
+    if (!net_out || !bayer_out || !prm || B < 1 || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0) return YOND_EINVAL;
+    if (pad_t + h > Hp || pad_l + w > Wp || (mode != 1 && mode != 2) || !(scale > 0.0)) return YOND_EINVAL;
+    size_t nb = (size_t)h * B;
+    if (nb > 256 * 16) nb = 256 * 16;
+    hipLaunchKernelGGL(denorm_ivst_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, net_out, Wp, pad_t,
+                       pad_l, h, w, bayer_out, mode, scale, 1.0, 0.0, 0.0, 1.0, clip01, prm, B, Hp);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }

@@ -910,6 +910,94 @@ def _iter_denoise_chain(lr, net, arch, pipe, p, log=None):
     return dict(raw_dns=raw_dns, regs=regs, params=params, nle_info=info1)
 
 
+def chain_applies_sidd(lr, lr_full, net, arch, pipe, p, biaslut=None):
+    """The SIDD layout on the device chain: the [32][256][256] stack denoised block-wise (one batch-32 forward per round), the estimate
+    on the stack's concatenation or on the full frame lr_full, bias_corr 'pre' with the 1-D LUT, est_type 'simple', no rot_cfa."""
+    return (isinstance(lr, torch.Tensor) and lr.is_cuda and lr.dim() == 3 and lr.shape[0] == 32 and not pipe.get('full_dn', False)
+            and biaslut is None and pipe.get('bias_corr', 'pre') == 'pre' and pipe.get('full_est', True) and DEVICE_CHAIN and CHAIN_SIDD
+            and 'simple' in str(pipe.get('est_type', 'simple')) and 'cal_est' not in pipe and 'rot_cfa' not in p
+            and (lr_full is None or (isinstance(lr_full, torch.Tensor) and lr_full.is_cuda and lr_full.dim() == 2)))
+
+
+CHAIN_SIDD = True                   # (False: the SIDD layout on the host-side chain, for A/B)
+
+
+def _chain_denoise_blocks(blocks, net, arch, p, buf, guard_slot):
+    """_chain_denoise for B blocks that share the round's parameter block and table: batched K1 -> ONE batch-B forward -> batched K4
+    (YOND_SIDD.py:392-407 runs the blocks one by one with the same p and bias_func).  Returns ([B][H][W], guard)."""
+    lib = L.load()
+    B, H, W = blocks.shape
+    h, w = H // 2, W // 2
+    scale = float(p['scale'])
+    st = L.stream()
+    p2d = get_p2d((1, 4, h, w), base=32)
+    Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
+    x4 = torch.empty((B, Hp, Wp, 4), dtype=torch.float32, device=blocks.device)
+    img_max = torch.empty(B, dtype=torch.float32, device=blocks.device)
+    with _stage("vst_pack"):
+        L.check(lib.yond_pack_vst_norm_batch_dev_f32(L.ptr(blocks), B, H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], scale, L.ptr(buf.prm),
+                                                     L.ptr(buf.lut_ws), LUT_CAP, L.ptr(img_max), st), "yond_pack_vst_norm_batch_dev_f32")
+    plan = _plan_of(net, blocks.device)
+    t_dev = buf.t.expand(B).contiguous() if 'guided' in arch else None
+
+    def forward_and_invert():
+        y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
+        out = torch.empty((B, H, W), dtype=torch.float32, device=blocks.device)
+        with _stage("ivst_unpack"):
+            L.check(lib.yond_denorm_ivst_unpack_batch_dev_f32(L.ptr(y4), B, Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 1, scale, L.ptr(buf.prm),
+                                                              1, st), "yond_denorm_ivst_unpack_batch_dev_f32")
+        return out
+
+    watch = _Guard(plan, guard_slot) if plan.uses_half_operands() else None
+    out = forward_and_invert()
+    if watch is not None:
+        watch.arm(forward_and_invert)
+    buf.prm_host.copy_(buf.prm, non_blocking=True)
+    return out, watch
+
+
+def _iter_denoise_chain_sidd(blocks, lr_full, net, arch, pipe, p, log=None):
+    """IterDenoise for the SIDD layout on the device chain (YOND_SIDD.py:312-470, est_type 'simple', block-wise denoising): round 1's
+    estimate on lr_full (or the blocks' concatenation, :340), the LUT grid from the blocks' maximum (:393), the 32 blocks through one
+    batch-32 forward; round 2's collaborative estimate on the concatenations with the SIDD_256 re-tiling (:431); both rounds queued
+    back to back, ONE synchronisation.  None when a round took a branch the chain leaves to the host-side path."""
+    two = pipe.get('iter', 'iter') == 'iter' and pipe.get('max_iter', 1) >= 1
+    if two and pipe.get('max_iter', 1) > 1:
+        return None
+    blocks = blocks.contiguous()
+    lr_cat = torch.cat(list(blocks), dim=-1).contiguous()                              # :315
+    mx = _frame_max(lr_cat)                                                            # upper_bound = lr_raw.max() * (wp - bl), :393
+    b1 = _chain_buffers(blocks.device, 0)
+    _chain_estimate(lr_cat if lr_full is None else lr_full, None, 'self', pipe, p, b1, lr_max_dev=mx)
+    o1, g1 = _chain_denoise_blocks(blocks, net, arch, p, b1, 0)
+    out1 = torch.cat(list(o1), dim=-1).contiguous()                                    # :408
+    if two:
+        b2 = _chain_buffers(blocks.device, 1)
+        _chain_estimate(lr_cat, out1, 'collab', dict(pipe, collab_sidd256=pipe.get('collab_sidd256', True)), p, b2, lr_max_dev=mx)
+        o2, g2 = _chain_denoise_blocks(blocks, net, arch, p, b2, 1)
+        out2 = torch.cat(list(o2), dim=-1).contiguous()
+    torch.cuda.current_stream().synchronize()
+    reg1, par1, fl1, info1 = _chain_result(b1)
+    if fl1 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE) or (g1 is not None and g1.tripped()):
+        return None
+    if log:
+        log(f"Self Est: K={par1[0]:.4f}, b={par1[1]:.4f} (beta1={reg1[0]:.3e}, beta2={reg1[1]:.3e})")
+    raw_dns, regs, params = [out1], [reg1], [par1]
+    if two:
+        reg2, par2, fl2, info2 = _chain_result(b2)
+        if fl2 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY):
+            return None
+        if log:
+            log(f"Iter 1 Est: K={par2[0]:.4f}, sigma={par2[1]:.4f} (beta1={reg2[0]:.3e}, beta2={reg2[1]:.3e})")
+        if not (fl2 & PRM_ROUND_ABORTED):                # :445-447: beta1 < 0 ends the image after round 1
+            if fl2 & PRM_BAD_ESTIMATE or (g2 is not None and g2.tripped()):
+                return None
+            raw_dns.append(out2)
+            regs.append(reg2)
+            params.append(par2)
+    return dict(raw_dns=raw_dns, regs=regs, params=params, nle_info=info1)
+
+
 def _frame_max(x):
     """Maximum of a device tensor as a 1-element device tensor (yond_image_max_f32: two launches, deterministic)."""
     lib = L.load()
@@ -1023,6 +1111,13 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
         lr_c = _dev(lr_raw, device)
         if chain_applies(lr_c, net, arch, pipe, biaslut):
             res = _iter_denoise_chain(lr_c, net, arch, pipe, p, log=log)
+            if res is not None:
+                return res
+    if 'rot_cfa' not in p:
+        lr_c = _dev(lr_raw, device)
+        lf_c = None if lr_full is None else _dev(lr_full, lr_c.device)
+        if chain_applies_sidd(lr_c, lf_c, net, arch, pipe, p, biaslut):
+            res = _iter_denoise_chain_sidd(lr_c, lf_c, net, arch, pipe, dict(p), log=log)
             if res is not None:
                 return res
     sidd = not full_dn

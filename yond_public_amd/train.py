@@ -35,6 +35,7 @@ from .engine import DenoiserPlan, _PackedConv, _rup
 
 WGRAD_BIAS = True                # the bias gradient of a 3x3 stride-1 layer rides along in the split-operand weight-gradient kernel
 FILM_ALL = True                     # the guided blocks' sigma-MLPs in one forward and one backward call for the whole net (False: per block)
+FLAT_1X1 = True                  # 1x1 convolutions over images narrower than 32 pixels run on a [1][P/32][32][C] view of the same memory
                                  # (module attribute: tools/ flip it for A/B runs)
 
 
@@ -265,24 +266,34 @@ class _Conv3x3Cat(torch.autograd.Function):
         return dxs[0], dxs[1], torch.cat(dws, 1), db, None, None
 
 
+def _flat32(t):
+    """A 1x1 convolution has no spatial structure: images narrower than the kernels' 32-pixel tile rows (the deep levels of a batch of
+    small patches: 16 and 8 pixels wide) are handed over as ONE image of 32-pixel rows -- a view of the same contiguous memory -- so
+    that no tile is half or three quarters padding."""
+    N, H, W, C = t.shape
+    P = N * H * W
+    return t.view(1, P // 32, 32, C) if (FLAT_1X1 and W < 32 and P % 32 == 0 and t.is_contiguous()) else t
+
+
 class _Conv1x1(torch.autograd.Function):
     """nn.Conv2d(c0 + c1, cout, 1) over the channel concatenation of one or two tensors (torch.cat is not materialised)."""
 
     @staticmethod
     def forward(ctx, x0, x1, w, b, plan):
-        N, H, W, _ = x0.shape
-        srcs = [x0.contiguous()] + ([x1.contiguous()] if x1 is not None else [])
+        shape = x0.shape
+        srcs = [_flat32(x0.contiguous())] + ([_flat32(x1.contiguous())] if x1 is not None else [])
+        N, H, W, _ = srcs[0].shape
         splits = [w.shape[1]] if x1 is None else list(ctx_splits(w, x0, x1))
         y = _conv_fwd(plan, w, b, 1, 1, splits, srcs, N, H, W)
         ctx.save_for_backward(*srcs, w)
-        ctx.plan, ctx.splits, ctx.two = plan, splits, x1 is not None
-        return y
+        ctx.plan, ctx.splits, ctx.two, ctx.shape = plan, splits, x1 is not None, shape
+        return y.view(shape[0], shape[1], shape[2], y.shape[-1])
 
     @staticmethod
     def backward(ctx, dy):
         *srcs, w = ctx.saved_tensors
-        plan, splits = ctx.plan, ctx.splits
-        dy = dy.contiguous()
+        plan, splits, shape = ctx.plan, ctx.splits, ctx.shape
+        dy = _flat32(dy.contiguous()) if srcs[0].shape[:3] != shape[:3] else dy.contiguous()      # (the geometry the forward ran in)
         N, H, W, _ = dy.shape
         cout = w.shape[0]
         dws, dxs, off = [], [], 0
@@ -290,7 +301,8 @@ class _Conv1x1(torch.autograd.Function):
             dws.append(_wgrad(plan, x, dy, 2, 1, 1)[0, :cout, :s])
             dx = _conv_fwd(plan, w, None, 1, 1, [cout], [dy], N, H, W, role=('dgrad', off),
                            xf=lambda t, off=off, s=s: t[:, off:off + s, 0, 0].t().contiguous()[:, :, None, None])   # [s][cout][1][1]
-            dxs.append(dx if dx.shape[-1] == x.shape[-1] else _pad_c(dx[..., :s], x.shape[-1]))
+            dx = dx if dx.shape[-1] == x.shape[-1] else _pad_c(dx[..., :s], x.shape[-1])
+            dxs.append(dx.view(shape[0], shape[1], shape[2], dx.shape[-1]))
             off += s
         dw = torch.cat(dws, 1)[:, :, None, None]
         db = _colsum(plan, dy)[:cout]
@@ -486,9 +498,10 @@ class _ConvT2x2(torch.autograd.Function):
             m = torch.zeros((cin, 4, cop), dtype=torch.float32, device=t.device)
             m[:, :, :cout] = t.permute(0, 2, 3, 1).reshape(cin, 4, cout)
             return m.reshape(cin, 4 * cop, 1, 1)
-        dx = _conv_fwd(plan, w, None, 1, 1, [4 * cop], [gu], N, H, W, role='dgrad', xf=xf)
+        guf = _flat32(gu)                                    # (a 1x1 GEMM: narrow images as 32-pixel rows)
+        dx = _conv_fwd(plan, w, None, 1, 1, [4 * cop], [guf], guf.shape[0], guf.shape[1], guf.shape[2], role='dgrad', xf=xf)
         dx = dx if dx.shape[-1] == cin_p else _pad_c(dx[..., :cin], cin_p)
-        return dx, dw, db, None
+        return dx.view(N, H, W, dx.shape[-1]), dw, db, None
 
 
 class TrainStep:

@@ -400,8 +400,15 @@ static WgsPlan wgs_plan(int N, int H, int W, int Ci, int Co) {
     if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 32 || Co % 32) return p;
     if ((long long)N * H * W * (Ci > Co ? Ci : Co) >= 0x7fffffffLL) return p;
     const int pairs = (Ci / 32) * (Co / 32);
+    const long force = yond_exp_long("YOND_WGS_CFG", 0);      // (experiment builds: try one configuration first)
+    if (force == 2 && wgs_try<2, 2, 2, 1>(N, H, W, Ci, Co, 2, p)) return p;
+    if (force == 4 && wgs_try<2, 1, 4, 1>(N, H, W, Ci, Co, 4, p)) return p;
+    if (force == 5 && wgs_try<1, 2, 4, 1>(N, H, W, Ci, Co, 5, p)) return p;
+    if (force == 1 && wgs_try<1, 1, 8, 1>(N, H, W, Ci, Co, 1, p)) return p;
     if (pairs == 1 && wgs_try<1, 1, 8, 1>(N, H, W, Ci, Co, 1, p)) return p;
-    if (pairs == 4 && wgs_try<2, 2, 2, 1>(N, H, W, Ci, Co, 2, p)) return p;
+    // 2 x 2 tile pairs per workgroup up to 256 x 256 channels: half the slice workspace of 2 x 4 (36 instead of 72 MB written and re-read by the
+    // reduction) outweighs its extra staging per MFMA -- 128 ch 194 vs 178 TF/s, 256 ch 187 vs 176; at 512 ch 2 x 4 wins (153 vs 149)
+    if (pairs <= 64 && wgs_try<2, 2, 2, 1>(N, H, W, Ci, Co, 2, p)) return p;
     if (wgs_try<2, 4, 1, 2>(N, H, W, Ci, Co, 3, p)) return p;
     if (wgs_try<2, 2, 2, 1>(N, H, W, Ci, Co, 2, p)) return p;
     if (wgs_try<2, 1, 4, 1>(N, H, W, Ci, Co, 4, p)) return p;

@@ -508,6 +508,22 @@ int yond_film_mlp_bwd_f32(const float* t, const float* w1, const float* b1, cons
 /* The same for ALL guided blocks of a network at once (n <= 12; the MLPs depend on sigma and the weights only): 2 launches forward,
  * 5 backward, instead of that many per block.  d: HOST array.  Forward reads t, w1 .. b3 and writes tk, tb ([B][ld]; columns beyond C
  * must already be zero); backward reads t, w1, b1, W2, W3, tk, dtk, dtb, uses scratch (2 * B * C floats) and writes dw1 .. db3. */
+/* The plain GEMMs of a training step on the fp16 matrix cores with fp32-accurate split operands (csrc/gemm_split.hip): 1x1 convolutions
+ * over one or two sources, their data gradients, ConvTranspose2d 2x2 (pixel-shuffle store) and its data gradient
+ * (archs/Unet.py:447-461, archs/modules.py:142-147; backward of trainer_AWGN.py:116):
+ *     y[p][n] = sum_s sum_k x_s[p][k] * B_s(k, n) (+ bias[n % nblk]),
+ *     B_s(k, n) = w_s[(k % kblk) sk_lo + (k / kblk) sk_hi + (n % nblk) sn_lo + (n / nblk) sn_hi], zero where k % kblk >= k_real or n % nblk >= n_real
+ * -- the float32 parameter itself, read through strides and split when staged (no packing pass).  x_s: [P][ld] float32, k (a multiple
+ * of 32) channels taken; y: [P][ldy], n_p (a multiple of 32) channels written; shuffle != 0: y is [N][2H][2W][ldy], P = N H W,
+ * n = j (n_p / 4) + co goes to pixel (2 yy + j / 2, 2 xx + j % 2), channel co (nblk must be n_p / 4).  Needs |w| < 32 (bit 0 of *status). */
+typedef struct YondGemmSrc {
+    const float* x;
+    const float* w;
+    long long sk_lo, sk_hi;
+    int ld, k, kblk, k_real;
+} YondGemmSrc;
+int yond_gemm_split_f32(const YondGemmSrc* src /* host array */, int nsrc /* 1 or 2 */, size_t P, int n_p, int n_real, long long sn_lo, long long sn_hi,
+                        int nblk, const float* bias /* or NULL */, float* y, int ldy, int shuffle, int H, int W, int* status, void* stream);
 typedef struct YondFilmMlpDesc {
     const float *t, *w1, *b1, *W2, *b2, *W3, *b3;
     float *tk, *tb;

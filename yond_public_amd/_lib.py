@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("YOND_HIP_LIB", os.path.join(_HERE, "libyond_hip.so"))
 _lib = None
 ABI_VERSION = 6                     # include/yond_hip.h YOND_ABI_VERSION
 
-vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+vp, i32, f32, f64, sz, i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_longlong
 
 
 class YondConvDesc(C.Structure):
@@ -97,6 +97,7 @@ PROTOTYPES = {
     "yond_film_mlp_fwd_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
     "yond_film_mlp_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "yond_film_mlp_fwd_multi_f32": [vp, i32, vp],
+    "yond_gemm_split_f32": [vp, i32, sz, i32, i32, i64, i64, i32, vp, vp, i32, i32, i32, i32, vp, vp],
     "yond_film_mlp_bwd_multi_f32": [vp, i32, vp],
     "yond_silu_bwd_add_f32": [vp, vp, vp, vp, sz, vp],
     "yond_zero_interleave_f32": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
@@ -182,6 +183,12 @@ def require_cuda(t, name="tensor"):
     if not t.is_contiguous():
         raise YondHipError(f"{name} must be contiguous")
     return t
+
+
+class GemmSrc(C.Structure):
+    """YondGemmSrc of include/yond_hip.h (one source of yond_gemm_split_f32)."""
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('sk_lo', C.c_longlong), ('sk_hi', C.c_longlong),
+                ('ld', C.c_int), ('k', C.c_int), ('kblk', C.c_int), ('k_real', C.c_int)]
 
 
 class FilmMlpDesc(C.Structure):

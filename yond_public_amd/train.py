@@ -36,6 +36,8 @@ from .engine import DenoiserPlan, _PackedConv, _rup
 WGRAD_BIAS = True                # the bias gradient of a 3x3 stride-1 layer rides along in the split-operand weight-gradient kernel
 FILM_ALL = True                     # the guided blocks' sigma-MLPs in one forward and one backward call for the whole net (False: per block)
 FLAT_1X1 = True                  # 1x1 convolutions over images narrower than 32 pixels run on a [1][P/32][32][C] view of the same memory
+GEMM_SPLIT = True                # 1x1 / transposed convolutions and their data gradients as split-operand GEMMs on the fp16 matrix cores (False: fp32 MFMA)
+GEMM_MIN_K = 256                 # ... from this many input channels on (the compute-bound levels)
                                  # (module attribute: tools/ flip it for A/B runs)
 
 
@@ -266,6 +268,27 @@ class _Conv3x3Cat(torch.autograd.Function):
         return dxs[0], dxs[1], torch.cat(dws, 1), db, None, None
 
 
+def _gemm_split(plan, srcs, P, n_p, n_real, sn_lo, sn_hi, nblk, bias, y, ldy, shuffle=0, H=0, W=0):
+    """yond_gemm_split_f32: y[p][n] = sum_s sum_k x_s[p][k] B_s(k, n) (+ bias) with the float32 parameter read in place through strides
+    (include/yond_hip.h).  srcs: (x, w_ptr, sk_lo, sk_hi, ld, k, kblk, k_real) per source; a weight beyond +-32 sets the plan's weight word."""
+    arr = (L.GemmSrc * len(srcs))()
+    for d, (x, wp, sk_lo, sk_hi, ld, k, kblk, k_real) in zip(arr, srcs):
+        d.x, d.w, d.sk_lo, d.sk_hi, d.ld, d.k, d.kblk, d.k_real = x.data_ptr(), wp, sk_lo, sk_hi, ld, k, kblk, k_real
+    L.check(plan.lib.yond_gemm_split_f32(C.cast(arr, C.c_void_p), len(srcs), P, n_p, n_real, sn_lo, sn_hi, nblk, None if bias is None else L.ptr(bias),
+                                         L.ptr(y), ldy, shuffle, H, W, L.ptr(plan.status[1:2]), L.stream()), "yond_gemm_split_f32")
+    return y
+
+
+def _use_gemm(plan, K):
+    """The split-operand GEMM where it measures faster than the fp32-MFMA convolution path (tools/gemm_ab.py, device times at the training
+    shape): the deep, compute-bound levels -- at least GEMM_MIN_K input channels in all (a 1x1 over 2 x 256: 42 vs 69 us, the transposed
+    512 -> 256: 43 vs 184 us); the wide, shallow levels (K <= 128: 2-4 K steps per tile) stay where they are (74 vs 66, 132 vs 112 us)."""
+    return GEMM_SPLIT and K >= GEMM_MIN_K and plan.arena is not None and getattr(plan, 'train_conv', 'split') == 'split'
+
+
+_BIG = 1 << 30
+
+
 def _flat32(t):
     """A 1x1 convolution has no spatial structure: images narrower than the kernels' 32-pixel tile rows (the deep levels of a batch of
     small patches: 16 and 8 pixels wide) are handed over as ONE image of 32-pixel rows -- a view of the same contiguous memory -- so
@@ -281,9 +304,21 @@ class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, w, b, plan):
         shape = x0.shape
+        splits = [w.shape[1]] if x1 is None else list(ctx_splits(w, x0, x1))
+        if _use_gemm(plan, sum(t.shape[-1] for t in (x0, x1) if t is not None)):   # a plain GEMM over the pixels: split operands on the fp16 matrix cores
+            srcs = [x0.contiguous()] + ([x1.contiguous()] if x1 is not None else [])
+            cout, P = w.shape[0], shape[0] * shape[1] * shape[2]
+            n_p, off, gs = _rup(cout), 0, []
+            for x, c in zip(srcs, splits):
+                gs.append((x, w.data_ptr() + 4 * off, 1, 0, x.shape[-1], x.shape[-1], _BIG, c))
+                off += c
+            y = torch.empty((shape[0], shape[1], shape[2], n_p), dtype=torch.float32, device=x0.device)
+            _gemm_split(plan, gs, P, n_p, cout, w.shape[1], 0, _BIG, b, y, n_p)
+            ctx.save_for_backward(*srcs, w)
+            ctx.plan, ctx.splits, ctx.two, ctx.shape = plan, splits, x1 is not None, shape
+            return y
         srcs = [_flat32(x0.contiguous())] + ([_flat32(x1.contiguous())] if x1 is not None else [])
         N, H, W, _ = srcs[0].shape
-        splits = [w.shape[1]] if x1 is None else list(ctx_splits(w, x0, x1))
         y = _conv_fwd(plan, w, b, 1, 1, splits, srcs, N, H, W)
         ctx.save_for_backward(*srcs, w)
         ctx.plan, ctx.splits, ctx.two, ctx.shape = plan, splits, x1 is not None, shape
@@ -293,6 +328,22 @@ class _Conv1x1(torch.autograd.Function):
     def backward(ctx, dy):
         *srcs, w = ctx.saved_tensors
         plan, splits, shape = ctx.plan, ctx.splits, ctx.shape
+        if _use_gemm(plan, dy.shape[-1]):
+            dy = dy.contiguous()
+            cout, P, n_p = w.shape[0], shape[0] * shape[1] * shape[2], dy.shape[-1]
+            dws, dxs, off = [], [], 0
+            srcs = [x.view(shape[0], shape[1], shape[2], x.shape[-1]) for x in srcs]    # (the forward may have run on the flat view)
+            xf, dyf = [_flat32(x) for x in srcs], _flat32(dy)                       # (the weight gradient's rows: 32 pixels wide)
+            for x, xw, c in zip(srcs, xf, splits):
+                dws.append(_wgrad(plan, xw, dyf, 2, 1, 1)[0, :cout, :c])
+                dx = torch.empty_like(x)                                            # dx[p][ci] = sum_co dy[p][co] w[co][off + ci]
+                _gemm_split(plan, [(dy, w.data_ptr() + 4 * off, w.shape[1], 0, n_p, n_p, _BIG, cout)], P, x.shape[-1], c, 1, 0, _BIG, None,
+                            dx, x.shape[-1])
+                dxs.append(dx)
+                off += c
+            dw = torch.cat(dws, 1)[:, :, None, None]
+            db = _colsum(plan, dy)[:cout]
+            return dxs[0], (dxs[1] if ctx.two else None), dw, db, None
         dy = _flat32(dy.contiguous()) if srcs[0].shape[:3] != shape[:3] else dy.contiguous()      # (the geometry the forward ran in)
         N, H, W, _ = dy.shape
         cout = w.shape[0]
@@ -476,7 +527,14 @@ class _ConvT2x2(torch.autograd.Function):
     def forward(ctx, x, w, b, plan):
         N, H, W, _ = x.shape
         x = x.contiguous()
-        y = _conv_fwd(plan, w, b, 1, 1, [w.shape[0]], [x], N, H, W, shuffle=True)
+        if _use_gemm(plan, x.shape[-1]):                     # a GEMM [P][cin] x [cin][4 cout] with a pixel-shuffle store
+            cin, cout = w.shape[0], w.shape[1]
+            cop = _rup(cout)
+            y = torch.empty((N, 2 * H, 2 * W, cop), dtype=torch.float32, device=x.device)
+            _gemm_split(plan, [(x, w.data_ptr(), 4 * cout, 0, x.shape[-1], x.shape[-1], _BIG, cin)], N * H * W, 4 * cop, cout, 4, 1, cop, b, y, cop,
+                        1, H, W)
+        else:
+            y = _conv_fwd(plan, w, b, 1, 1, [w.shape[0]], [x], N, H, W, shuffle=True)
         ctx.save_for_backward(x, w)
         ctx.plan = plan
         return y
@@ -498,6 +556,10 @@ class _ConvT2x2(torch.autograd.Function):
             m = torch.zeros((cin, 4, cop), dtype=torch.float32, device=t.device)
             m[:, :, :cout] = t.permute(0, 2, 3, 1).reshape(cin, 4, cout)
             return m.reshape(cin, 4 * cop, 1, 1)
+        if _use_gemm(plan, 4 * cop):                         # dx[p][ci] = sum_{j, co} gu[p][j cop + co] w[ci][co][j]
+            dx = torch.empty((N, H, W, cin_p), dtype=torch.float32, device=dy.device)
+            _gemm_split(plan, [(gu, w.data_ptr(), 4, 1, 4 * cop, 4 * cop, cop, cout)], N * H * W, cin_p, cin, 4 * cout, 0, _BIG, None, dx, cin_p)
+            return dx, dw, db, None
         guf = _flat32(gu)                                    # (a 1x1 GEMM: narrow images as 32-pixel rows)
         dx = _conv_fwd(plan, w, None, 1, 1, [4 * cop], [guf], guf.shape[0], guf.shape[1], guf.shape[2], role='dgrad', xf=xf)
         dx = dx if dx.shape[-1] == cin_p else _pad_c(dx[..., :cin], cin_p)

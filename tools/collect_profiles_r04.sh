@@ -15,6 +15,7 @@ python bench.py --steps 6 --warmup 2 --precision fp32-mfma --no-cpu-baseline 2>/
 python tools/stage_bench.py > $O/r04_stage_kernels.txt 2>&1
 python tools/layer_times.py > $O/r04_layer_times.txt 2>&1
 python tools/wgrad_ab.py > $O/r04_wgrad_ab.txt 2>&1
+python tools/gemm_ab.py > $O/r04_gemm_ab.txt 2>&1
 python tools/train_bench.py --steps 30 > $O/r04_train_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 2 --warmup 1 --frames-per-step 4 --no-cpu-baseline --no-extras --min-warmup-s 0"

@@ -440,7 +440,8 @@ extern "C" int yond_nle_threshold_f32(const float* lap, size_t n, const double* 
     if (head > n) head = n;
     const size_t nvec = (n - head) / 4;
     size_t nb = (nvec + (size_t)NFC_THREADS * NFC_UNROLL - 1) / ((size_t)NFC_THREADS * NFC_UNROLL);
-    if (nb > 256) nb = 256;
+    const size_t ccap = (size_t)yond_exp_long("YOND_COLLECT_WGS", 512);  // two workgroups per CU: 128 / 256 / 384 / 512 / 768 -> 111.5 / 102.0 / 99.5 / 97.5 / 99.1 us for the three launches
+    if (nb > ccap) nb = ccap;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(nf_collect_kernel, dim3((unsigned)nb), dim3(NFC_THREADS), 0, st, lap, head, nvec, n, (NleState*)ws, cand);
     YOND_LAUNCH_CHECK();

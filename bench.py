@@ -254,6 +254,35 @@ def sidd_items(n, dev, rank=0):
     return items
 
 
+def leg_roofline(plan, run_once, sync, fp16_operands=False):
+    """The dominant 3x3 stride-1 convolution kernel of one more, instrumented pass of a bench leg: HIP event pairs around every such
+    launch of `run_once()`; algorithmic FLOPs per launch / mean launch time against the peak of the MFMA the kernel issues."""
+    is33 = lambda t: t.startswith("conv_mfma_kernel<3,1") or t.startswith("conv_wino_kernel") or t.startswith("conv_split_kernel<1,")
+    old = (getattr(plan, 'prof', None), getattr(plan, 'prof_only', None), getattr(plan, 'prof_every', 1))
+    plan.prof, plan.prof_only, plan.prof_every = [], is33, 1
+    try:
+        run_once()
+        sync()
+        prof = plan.prof
+    finally:
+        plan.prof, plan.prof_only, plan.prof_every = old
+    per = {}
+    for tag, flops, e0, e1 in prof:
+        k = per.setdefault(tag, [0, 0.0, 0.0])
+        k[0] += 1
+        k[1] += e0.elapsed_time(e1)
+        k[2] += flops
+    dom = max((t for t in per if is33(t)), key=lambda t: per[t][1], default=None)
+    if dom is None:
+        return None
+    n, ms, fl = per[dom]
+    peak = PEAK_F16_MFMA_TFLOPS if (fp16_operands or dom.startswith("conv_split_kernel")) else PEAK_F32_MFMA_TFLOPS
+    ach = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "launches": n, "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
+            "measured": "HIP events around every 3x3 stride-1 launch of one instrumented pass behind the leg's timed loop"}
+
+
 def sidd_eval_item(item, net, arch, P):
     """One image of YOND_SIDD.eval (:507-536): IterDenoise (full-frame self NLE, bias LUT, 32 blocks as ONE batch-32 forward,
     collaborative NLE with the SIDD_256 re-tiling, second pass) + per-block PSNR / SSIM of both rounds on the device."""
@@ -607,6 +636,11 @@ def main(argv=None):
         el4 = time.perf_counter() - t4
         others["cfg4_unet_batch8"] = {"value": round(n4 * 8 * H * W / 1e6 / el4, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el4 / (n4 * 8) * 1e3, 3),
                                       "frames": n4 * 8, "workload": f"configs[3]: UNetSeeInDark(nf=32), {H}x{W} frames, per-frame NLE, ONE batched forward of 8"}
+        try:
+            others["cfg4_unet_batch8"]["roofline"] = leg_roofline(P._plan_of(net4, dev), lambda: P.IterDenoiseBatch(batch8, net4, arch4, pipe),
+                                                                  torch.cuda.synchronize)
+        except Exception as e:
+            others["cfg4_unet_batch8"]["roofline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         del net4, r4, batch8
         torch.cuda.empty_cache()
         # configs[2] (the reference's only shipped entry point, YOND_SIDD.py eval): per image the full-frame self NLE, two rounds of
@@ -629,6 +663,7 @@ def main(argv=None):
                                         "reference_s_per_image": REF_SIDD_S_PER_IMAGE,
                                         "workload": f"configs[2]: SIDD-shaped synthetic items ({SIDD_FULL[0]}x{SIDD_FULL[1]} estimate frame + 32 blocks of 256x256), "
                                                     "YOND_SIDD.eval's loop body (IterDenoise 'iter' with batch-32 forwards + block metrics), one image at a time"}
+            others["cfg3_sidd_eval"]["roofline"] = leg_roofline(plan, lambda: sidd_eval_item(it3[0], net, arch, P), torch.cuda.synchronize)
             del it3, r3
         except Exception as e:
             others["cfg3_sidd_eval"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -653,6 +688,11 @@ def main(argv=None):
         others["cfg5_fp16_4000x6000"] = {"value": round(n5 * H5 * W5 / 1e6 / el5, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el5 / n5 * 1e3, 3),
                                          "frames": n5, "dtype": "f16 MFMA operands, f32 accumulate and tensors",
                                          "workload": f"configs[4]: {H5}x{W5} low-light frames (no black-level clip, negative DN reach the VST), GuidedResUnet(nf=32), pipeline 'once'"}
+        try:
+            others["cfg5_fp16_4000x6000"]["roofline"] = leg_roofline(P._plan_of(net5, dev), lambda: P.IterDenoise(f5, net5, arch, pipe),
+                                                                     torch.cuda.synchronize, fp16_operands=True)
+        except Exception as e:
+            others["cfg5_fp16_4000x6000"]["roofline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         del net5, f5
         torch.cuda.empty_cache()
         # SURVEY 8(f) N4 on the same line: one training step at the reference's training shape (runfiles/Gaussian/GRU_5to50_norm_mix.yml:

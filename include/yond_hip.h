@@ -535,6 +535,8 @@ typedef struct YondFilmMlpDesc {
 int yond_film_mlp_fwd_multi_f32(const YondFilmMlpDesc* d, int n, void* stream);
 int yond_film_mlp_bwd_multi_f32(const YondFilmMlpDesc* d, int n, void* stream);
 int yond_silu_bwd_add_f32(const float* x, const float* dz, const float* dres, float* dx, size_t n, void* stream);
+/* y = SiLU(x), n (a multiple of 4) floats. */
+int yond_silu_f32(const float* x, float* y, size_t n, void* stream);
 /* g [N][H][W][C] = dy [N][ceil(H/2)][ceil(W/2)][C] at the even pixels, 0 elsewhere (the stride-2 layers' data gradient runs as a
  * stride-1 convolution over it). */
 int yond_zero_interleave_f32(const float* dy, int N, int Ho, int Wo, int C, int H, int W, float* g, void* stream);

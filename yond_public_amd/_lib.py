@@ -100,6 +100,7 @@ PROTOTYPES = {
     "yond_gemm_split_f32": [vp, i32, sz, i32, i32, i64, i64, i32, vp, vp, i32, i32, i32, i32, vp, vp],
     "yond_film_mlp_bwd_multi_f32": [vp, i32, vp],
     "yond_silu_bwd_add_f32": [vp, vp, vp, vp, sz, vp],
+    "yond_silu_f32": [vp, vp, sz, vp],
     "yond_zero_interleave_f32": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "yond_l1_loss_f32": [vp, vp, sz, vp, vp, vp],
     "yond_charbonnier_loss_f32": [vp, vp, sz, f64, vp, vp, vp],

@@ -803,6 +803,22 @@ extern "C" int yond_film_mlp_bwd_multi_f32(const YondFilmMlpDesc* d, int n, void
     return YOND_OK;
 }
 
+// y = SiLU(x) (the operand of a guided block's first convolution, archs/modules.py:186-188)
+__global__ __launch_bounds__(256) void silu_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = x[i];
+        y[i] = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+    }
+}
+extern "C" int yond_silu_f32(const float* x, float* y, size_t n, void* stream) {
+    if (!x || !y || n == 0 || n % 4) return YOND_EINVAL;
+    size_t nb = (n / 4 + 256 * 4 - 1) / (256 * 4);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)y, n / 4);
+    YOND_LAUNCH_CHECK();
+    return YOND_OK;
+}
+
 // A residual block's input side in backward: dx = dres + dz SiLU'(x) in one pass (the block computes conv1(SiLU(x)) and adds x to its
 // output: autograd ran silu_backward and the accumulation of the two gradients as two kernels over three / three tensors)
 __global__ __launch_bounds__(256) void silu_bwd_add_kernel(const float4* __restrict__ x, const float4* __restrict__ dz, const float4* __restrict__ dres,

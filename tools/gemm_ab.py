@@ -35,6 +35,7 @@ for lvl, i in ((0, 9), (1, 8), (2, 7), (3, 6)):
     with torch.no_grad():
         for flag in (1, 0):
             T.GEMM_SPLIT = bool(flag)
+            T.GEMM_MIN_K = 0                                   # (every level on the GEMM kernel: what train.GEMM_MIN_K decides)
             y = T._Conv1x1.apply(up, sk, w, b, ts.plan)
             f1 = timeit(lambda: T._Conv1x1.apply(up, sk, w, b, ts.plan))
             yt = T._ConvT2x2.apply(xin, wt, bt, ts.plan)

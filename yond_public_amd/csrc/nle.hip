@@ -68,15 +68,19 @@ __device__ __forceinline__ void box_store8(float* __restrict__ p, const float (&
 // 2: collab (mean, var, lap from noisy + denoised Bayer frames)
 // STATS (MODE 0): stage 1 reads every pixel of the frame as an entering pixel, so it also collects the frame maximum
 // (lr.max() for the bias LUT grid, YOND_SIDD.py:256/393) into st->frame_max_key.
-template <int MODE, int KT, int K2T, bool STATS, int BB>
-__global__ __launch_bounds__(BX_T, MODE == 1 ? 4 : 2) void box_slide_kernel(BoxSrc a, BoxSrc b, BoxGeom g, float* __restrict__ o0,
+// ROLES (experiment): 512 threads -- waves 0-3 only walk the columns (running sums of batch i into LDS buffer i & 1), waves 4-7 only
+// run the task phase (window sums of batch i - 1 from the other buffer): the two phases of consecutive batches overlap inside one
+// workgroup behind ONE barrier per batch, at twice the LDS (one workgroup per CU instead of two).
+template <int MODE, int KT, int K2T, bool STATS, int BB, bool ROLES = false>
+__global__ __launch_bounds__(ROLES ? 512 : BX_T, ROLES ? 1 : (MODE == 1 ? 4 : 2)) void box_slide_kernel(BoxSrc a, BoxSrc b, BoxGeom g, float* __restrict__ o0,
                                                         float* __restrict__ o1, float* __restrict__ o2, NleState* st) {
     static_assert(!STATS || MODE == 0, "only stage 1 collects the frame maximum");
     constexpr int NQ = MODE == 0 ? 3 : (MODE == 1 ? 2 : 4);      // running sums per column and plane
     constexpr int NI = MODE == 2 ? 2 : 1;                        // input frames
     constexpr int NL = MODE == 0 ? 3 : 2;                        // loads per input and row: entering, leaving (k), leaving (k2)
-    extern __shared__ __attribute__((aligned(16))) double s_v[]; // [NQ][BB][2][BX_VW]
-    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double s_v[]; // [NQ][BB][2][BX_VW]   (ROLES: two of them)
+    const int role = ROLES ? (int)(threadIdx.x >> 8) : -1;       // (wave-uniform) 0: column waves, 1: task waves
+    const int tid = ROLES ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
     const int h = g.h, w = g.w;
     const int k = KT > 0 ? KT : g.k, k2 = MODE == 0 ? (K2T > 0 ? K2T : g.k2) : k;
     const int R = k / 2, R2 = k2 / 2;
@@ -146,12 +150,12 @@ __global__ __launch_bounds__(BX_T, MODE == 1 ? 4 : 2) void box_slide_kernel(BoxS
     const int c0 = chunk * BX_C;                                 // first output column of the chunk (strip-relative)
     const bool t_on = c0 < ow && (tid >> 5) < 2 * BB;
     const int nvalid = min(BX_C, ow - c0);
-    const double* vb = s_v + (t_r * 2 + t_pl) * BX_VW + chunk * (BX_C + 1);   // + q * BB * 2 * BX_VW ; virtual column c0 + d at d + (d >> 3)
+    const int vb_off = (t_r * 2 + t_pl) * BX_VW + chunk * (BX_C + 1);         // + q * BB * 2 * BX_VW ; virtual column c0 + d at d + (d >> 3)
     constexpr int QS = BB * 2 * BX_VW;
     const int t_plane = 2 * z + t_pl;                            // output plane: Bayer (dy = z, dx = t_pl) -> 2 dy + dx; planar: 2 z + t_pl
     const bool vec_ok = (w % 4 == 0) && (ox0 % 4 == 0) && !(((uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2) & 15);
-    load_batch(nxt, 0);
-    for (int l0 = 0; l0 < nsteps; l0 += BB) {
+    // the two phases of a batch (l0: its first local row; sv: the LDS buffer of its sums)
+    auto col_phase = [&](int l0, double* __restrict__ sv) __attribute__((always_inline)) -> bool {      // true: a warm-up batch, nothing written
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(BX_T, MODE == 1 ? 4 : 2) void box_slide_kernel(BoxS
                     if (STATS) fmax_ = fmaxf(fmax_, fmaxf(xn[0], xn[1]));
                 }
             }
-            continue;
+            return true;
         }
 #pragma unroll
         for (int r = 0; r < BB; ++r) {
@@ -194,11 +198,13 @@ __global__ __launch_bounds__(BX_T, MODE == 1 ? 4 : 2) void box_slide_kernel(BoxS
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                s_v[((q * BB + r) * 2 + 0) * BX_VW + pv] = S[q][0];
-                s_v[((q * BB + r) * 2 + 1) * BX_VW + pv] = S[q][1];
+                sv[((q * BB + r) * 2 + 0) * BX_VW + pv] = S[q][0];
+                sv[((q * BB + r) * 2 + 1) * BX_VW + pv] = S[q][1];
             }
         }
-        __syncthreads();
+        return false;
+    };
+    auto task_phase = [&](int l0, const double* __restrict__ sv) __attribute__((always_inline)) {
         {
             const int l = l0 + t_r;
             const int oy = oy0 + l - 2 * R;                                       // k-window centred here is complete
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(BX_T, MODE == 1 ? 4 : 2) void box_slide_kernel(BoxS
             // window sums of quantity q over virtual columns [c0 + i + off, c0 + i + off + kk), i = 0 .. 7, by sliding; each sum
             // is handed to `use` as soon as it exists (no array of float64 sums stays live)
             auto slide = [&](int q, int off, int kk, auto&& use) {
-                const double* v = vb + q * QS;
+                const double* v = sv + vb_off + q * QS;
                 // (four partial sums: a chain of 29 dependent float64 additions is ~300 cycles a wave cannot hide;
                 // compile-time bounds for the shipped k)
                 double wsum = 0.0;
@@ -270,9 +276,32 @@ __global__ __launch_bounds__(BX_T, MODE == 1 ? 4 : 2) void box_slide_kernel(BoxS
                 box_store8(o2 + ((size_t)t_plane * h + oy2) * w + ox0 + c0, r2, nvalid, vec_ok);
             }
         }
-        __syncthreads();
+    };
+    if constexpr (ROLES) {
+        constexpr int BUF = NQ * BB * 2 * BX_VW;                 // doubles per buffer
+        const int nbatch = (nsteps + BB - 1) / BB;
+        if (role == 0) load_batch(nxt, 0);
+        for (int i = 0; i <= nbatch; ++i) {
+            if (role == 0) {
+                if (i < nbatch) col_phase(i * BB, s_v + (i & 1) * BUF);
+            } else if (i >= 1) {
+                const int l0 = (i - 1) * BB;
+                const bool warm = l0 + BB <= kl_min && l0 + BB <= first_out;
+                if (!warm) task_phase(l0, s_v + ((i - 1) & 1) * BUF);
+            }
+            __syncthreads();
+        }
+    } else {
+        load_batch(nxt, 0);
+        for (int l0 = 0; l0 < nsteps; l0 += BB) {
+            if (col_phase(l0, s_v)) continue;
+            __syncthreads();
+            task_phase(l0, s_v);
+            __syncthreads();
+        }
     }
     if constexpr (STATS) {
+        if (ROLES && role != 0) return;                           // (the column waves saw the pixels)
         fmax_ = wave_max(fmax_);
         // a few thousand waves, one word: look first (a coherent load) -- after the first few arrivals nearly nobody has to write
         if ((tid & 63) == 0 && fmax_ > -INFINITY) {
@@ -291,19 +320,19 @@ static int box_args_ok(int h, int w, int k, int tile_w) {
     return YOND_OK;
 }
 
-template <int MODE, int KT, int K2T, bool STATS, int BB>
+template <int MODE, int KT, int K2T, bool STATS, int BB, bool ROLES = false>
 static int launch_box_k(const BoxSrc& a, const BoxSrc& b, const BoxGeom& g, dim3 grid, float* o0, float* o1, float* o2, hipStream_t st,
                         NleState* state) {
     constexpr int NQ = MODE == 0 ? 3 : (MODE == 1 ? 2 : 4);
-    constexpr size_t smem = (size_t)NQ * BB * 2 * BX_VW * sizeof(double);
+    constexpr size_t smem = (size_t)NQ * BB * 2 * BX_VW * sizeof(double) * (ROLES ? 2 : 1);
     static bool attr_set = false;
-    auto kern = box_slide_kernel<MODE, KT, K2T, STATS, BB>;
+    auto kern = box_slide_kernel<MODE, KT, K2T, STATS, BB, ROLES>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(BX_T), smem, st, a, b, g, o0, o1, o2, state);
+    hipLaunchKernelGGL(kern, grid, dim3(ROLES ? 512 : BX_T), smem, st, a, b, g, o0, o1, o2, state);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -321,7 +350,8 @@ static int launch_box(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_
     g.ow_nom = (((bw + g.nstrip - 1) / g.nstrip) + BX_C - 1) / BX_C * BX_C;
     if (g.ow_nom > maxow) g.ow_nom = maxow;
     // row segments: one round of the workgroups the chip holds (two per CU); longer segments re-read fewer halo rows
-    const long target = yond_exp_long("YOND_BOX_WGS", MODE == 1 ? 1024 : 512);
+    const bool roles = MODE != 2 && yond_exp_long("YOND_BOX_ROLES", 0) != 0;      // (experiment builds: the role-split form)
+    const long target = yond_exp_long("YOND_BOX_WGS", roles ? (MODE == 1 ? 512 : 256) : (MODE == 1 ? 1024 : 512));
     const long cols = 2L * nblk * g.nstrip;
     long nseg = (target + cols / 2) / cols;
     if (nseg < 1) nseg = 1;
@@ -333,6 +363,10 @@ static int launch_box(BoxSrc a, BoxSrc b, int h, int w, int k, int k2, int tile_
     // rows per batch: 4 (LDS per workgroup 55 / 37 / 74 KB: two / four / two workgroups per CU).  Two rows per batch and more
     // workgroups measured slower (self stage 1: 101 us against 70): the task phase is latency bound per wave, and half the lanes idle
     constexpr int BB = 4;
+#ifdef YOND_EXPERIMENTS
+    if constexpr (MODE != 2)
+        if (roles && k == 29 && (MODE != 0 || k2 == 19)) return launch_box_k<MODE, 29, 19, STATS, BB, true>(a, b, g, grid, o0, o1, o2, st, state);
+#endif
     if (k == 29 && (MODE != 0 || k2 == 19)) return launch_box_k<MODE, 29, 19, STATS, BB>(a, b, g, grid, o0, o1, o2, st, state);
     return launch_box_k<MODE, 0, 0, STATS, BB>(a, b, g, grid, o0, o1, o2, st, state);
 }

@@ -607,9 +607,192 @@ def gen_train_sched(ref):
     save("train_sched", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json's configurations at their REAL sizes (configs[1], [3], [4]) through the reference itself.  What is kept of a
+# 12-24 MP output: three 64 x 64 crops (a corner, the centre, a window across the last tile rows / columns), a strided sample
+# of the whole frame and float64 checksums.
+FULL_PIPE = {'data_type': 'SIDD', 'full_est': True, 'est_type': 'simple+full', 'k': 29, 'vst_type': 'exact', 'full_dn': True,
+             'bias_corr': 'pre', 'denoiser_type': 'gru32n', 'max_iter': 1, 'clip': False}
+
+
+def full_crops(dn):
+    dn = np.asarray(dn)
+    H, W = dn.shape
+    return (dn[:64, :64].astype(np.float32), dn[H // 2 - 32:H // 2 + 32, W // 2 - 32:W // 2 + 32].astype(np.float32),
+            dn[H - 64:, W - 64:].astype(np.float32), dn[7::64, 11::64].astype(np.float32))
+
+
+def full_p(pipe):
+    p = dict(pipe)
+    p.update({'K': 8.74253, 'sigGs': 12.81, 'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0})
+    p['scale'] = (p['wp'] - p['bl']) / p['ratio']
+    return p
+
+
+def full_store(out, tag, dn):
+    a, b, c, d = full_crops(dn)
+    out[f"{tag}_a"], out[f"{tag}_b"], out[f"{tag}_c"], out[f"{tag}_sub"] = a, b, c, d
+    out[f"{tag}_chk"] = checks(dn)
+
+
+def full_cfg2_case():
+    """configs[1]: the 3000 x 4000 frame bench.py times (synth_noisy idx 0, K = 4, sigma = 6 DN), GuidedResUnet nf 32, denoising weights."""
+    noisy, clean = O.synth_noisy(3000, 4000, 4.0, 6.0, 0)
+    arch = ARCHS["gru32"]
+    return noisy, clean, arch, O.denoising_state_dict(arch, 7)
+
+
+def full_cfg2w_case():
+    """A 12.3 MP frame whose packed width divides by 32 (3000 x 4096), so that the reference's IterDenoise runs BOTH rounds as shipped."""
+    noisy, clean = O.synth_noisy(3000, 4096, 2.0, 20.0, 3)
+    arch = ARCHS["gru32"]
+    return noisy, clean, arch, O.denoising_state_dict(arch, 8)
+
+
+def full_cfg4_case(i):
+    noisy, clean = O.synth_noisy(3000, 4000, 4.0, 6.0, 70 + i)
+    arch = ARCHS["unet32"]
+    return noisy, clean, arch, O.denoising_state_dict(arch, 9)
+
+
+def full_cfg5_case():
+    """configs[4]: a 4000 x 6000 low-light frame (0.2 of full exposure) WITHOUT black-level clip: negative DN reach the VST."""
+    rng = np.random.default_rng(1997 + 55)
+    K, s = 2.0, 25.0
+    clean = (O.synth_clean(4000, 6000) * 0.2).astype(np.float32)
+    noisy = ((rng.poisson(clean * 959.0 / K) * K + rng.normal(0.0, s, clean.shape)) / 959.0).astype(np.float32)
+    arch = ARCHS["gru32"]
+    return noisy, clean, arch, O.denoising_state_dict(arch, 10)
+
+
+def ref_round1_composed(ref, obj, noisy, p):
+    """Round 1 of a full_dn run put together from the reference's own functions, as YOND_SIDD.py:341, :356, :384-389 do -- for frames
+    whose width does not divide by 32, where IterDenoise's `np.split(lr_raw, 32, axis=-1)` (:354) raises before anything is denoised."""
+    reg = ref.SimpleNLF(noisy, k=obj.pipe['k'], setting={'mode': 'self', 'print_log': False})
+    p['gain'], p['sigma'] = reg[0] * (p['wp'] - p['bl']), np.sqrt(max(reg[1], 0)) * (p['wp'] - p['bl'])
+    p['stage'] = 'self'
+    dn = ref.YOND_SIDD.VST_Denoiser(obj, noisy, None, obj.pipe['bias_corr'], denoiser=obj.pipe['denoiser_type'], p=p).clip(0, 1)
+    return reg, dn
+
+
+def ref_round2_composed(ref, obj, noisy, dn, p):
+    """Round 2 from the reference's own functions in IterDenoise's order (:431 without the SIDD_256 re-tiling -- its np.split(., 32, axis=-2)
+    needs a packed width that divides by 32 --, guards :438-447, :450-458).  Returns (reg, dn2) or (reg, None) at the beta1 < 0 guard."""
+    reg = ref.SimpleNLF(noisy, dn, k=obj.pipe['k'], setting={'mode': 'collab', 'print_log': False, 'SIDD_256': False})
+    if reg[1] < 0:
+        reg = (reg[0], reg[0] ** 2)
+    p['stage'] = 'collab'
+    p['gain'], p['sigma'] = reg[0] * (p['wp'] - p['bl']), np.sqrt(reg[1]) * (p['wp'] - p['bl'])
+    if reg[0] < 0:
+        return reg, None
+    bias_func = ref.get_bias(noisy.max() * (p['wp'] - p['bl']), p['sigma'], p['gain'], post=False)
+    dn2 = ref.YOND_SIDD.VST_Denoiser(obj, noisy, dn, bias_corr=obj.pipe['bias_corr'], bias_func=bias_func,
+                                     denoiser=obj.pipe['denoiser_type'], p=p).clip(0, 1)
+    return reg, dn2
+
+
+def gen_full_cfg2(ref):
+    """(1) the 3000 x 4000 frame through the reference's IterDenoise ('once': round 1 as shipped) and round 2 composed from its own
+    functions (the shipped round 2 raises at this width, see ref_round2_composed); (2) a 3000 x 4096 frame through IterDenoise 'iter' as shipped."""
+    import time
+    out = {}
+    noisy, clean, arch, sd = full_cfg2_case()
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "f.npy")
+    np.save(path, noisy)
+    pipe = dict(FULL_PIPE, iter='once')
+    obj, _ = fake_self(ref, arch, 7, pipe)
+    obj.net = ref.load_weights(obj.net, sd, by_name=False).eval()
+    p = full_p(pipe)
+    data = {'lr_path_full': path, 'lr': np.array(np.split(noisy, 32, axis=-1)), 'hr': np.array(np.split(clean, 32, axis=-1)),
+            'meta': None, 'name': 'frame_000'}
+    t0 = time.time()
+    res = obj.IterDenoise(data, {'p': p, 'img_id': 0})
+    print(f"3000x4000 once: {time.time() - t0:.1f} s  regs={np.asarray(res['regs'], np.float64).tolist()}  K={p['gain']:.5f} sigma={p['sigma']:.5f}")
+    assert len(res['raw_dns']) == 1
+    dn0 = np.asarray(res['raw_dns'][0])
+    out["a_sha"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
+    out["a_reg0"] = np.asarray(res['regs'][0], np.float64)
+    out["a_params0"] = np.array([p['gain'], p['sigma']], np.float64)
+    full_store(out, "a_dn0", dn0)
+    t0 = time.time()
+    reg1, dn1 = ref_round2_composed(ref, obj, noisy, dn0, p)
+    print(f"3000x4000 round 2 (composed): {time.time() - t0:.1f} s  reg={np.asarray(reg1, np.float64).tolist()}  K={p['gain']:.5f} sigma={p['sigma']:.5f}")
+    assert dn1 is not None
+    out["a_reg1"] = np.asarray(reg1, np.float64)
+    out["a_params1"] = np.array([p['gain'], p['sigma']], np.float64)
+    full_store(out, "a_dn1", dn1)
+    mse = lambda u: float(((np.asarray(u, np.float64) - clean) ** 2).mean())
+    out["a_psnr"] = np.array([10 * np.log10(1 / mse(noisy)), 10 * np.log10(1 / mse(dn0)), 10 * np.log10(1 / mse(dn1))])
+    print("3000x4000 PSNR noisy / round 1 / round 2:", out["a_psnr"].tolist())
+
+    noisy, clean, arch, sd = full_cfg2w_case()
+    np.save(path, noisy)
+    pipe = dict(FULL_PIPE, iter='iter')
+    obj, _ = fake_self(ref, arch, 8, pipe)
+    obj.net = ref.load_weights(obj.net, sd, by_name=False).eval()
+    p = full_p(pipe)
+    data = {'lr_path_full': path, 'lr': np.array(np.split(noisy, 32, axis=-1)), 'hr': np.array(np.split(clean, 32, axis=-1)),
+            'meta': None, 'name': 'frame_001'}
+    t0 = time.time()
+    res = obj.IterDenoise(data, {'p': p, 'img_id': 0})
+    regs = np.array([np.asarray(r, np.float64) for r in res['regs']])
+    print(f"3000x4096 iter: {time.time() - t0:.1f} s  regs={regs.tolist()} n_out={len(res['raw_dns'])}")
+    out["b_sha"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
+    out["b_regs"], out["b_nout"] = regs, np.array(len(res['raw_dns']))
+    for it, dn in enumerate(res['raw_dns']):
+        full_store(out, f"b_dn{it}", dn)
+    save("full_cfg2", **out)
+
+
+def gen_full_cfg4(ref):
+    """configs[3]: UNetSeeInDark, two 3000 x 4000 frames, 'once', full_dn -- each through the reference's IterDenoise as shipped."""
+    import time
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for i in range(2):
+        noisy, clean, arch, sd = full_cfg4_case(i)
+        path = os.path.join(tmp, f"f{i}.npy")
+        np.save(path, noisy)
+        pipe = dict(FULL_PIPE, iter='once')
+        obj, _ = fake_self(ref, arch, 9, pipe)
+        obj.net = ref.load_weights(obj.net, sd, by_name=False).eval()
+        p = full_p(pipe)
+        data = {'lr_path_full': path, 'lr': np.array(np.split(noisy, 32, axis=-1)), 'hr': np.array(np.split(clean, 32, axis=-1)),
+                'meta': None, 'name': f'frame_{i:03d}'}
+        t0 = time.time()
+        res = obj.IterDenoise(data, {'p': p, 'img_id': 0})
+        print(f"cfg4 frame {i}: {time.time() - t0:.1f} s  regs={np.asarray(res['regs'], np.float64).tolist()}")
+        out[f"sha_{i}"] = np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8)
+        out[f"reg_{i}"] = np.asarray(res['regs'][0], np.float64)
+        out[f"params_{i}"] = np.array([p['gain'], p['sigma']], np.float64)
+        full_store(out, f"dn_{i}", res['raw_dns'][0])
+    save("full_cfg4", **out)
+
+
+def gen_full_cfg5(ref):
+    """configs[4]'s input side on the float32 path: 4000 x 6000, no black-level clip; 6000 does not divide by 32, so round 1 is composed
+    from the reference's own SimpleNLF and VST_Denoiser (ref_round1_composed)."""
+    import time
+    noisy, clean, arch, sd = full_cfg5_case()
+    assert float(noisy.min()) < 0
+    pipe = dict(FULL_PIPE, iter='once')
+    obj, _ = fake_self(ref, arch, 10, pipe)
+    obj.net = ref.load_weights(obj.net, sd, by_name=False).eval()
+    p = full_p(pipe)
+    t0 = time.time()
+    reg, dn = ref_round1_composed(ref, obj, noisy, p)
+    print(f"cfg5 4000x6000: {time.time() - t0:.1f} s  reg={np.asarray(reg, np.float64).tolist()} K={p['gain']:.5f} sigma={p['sigma']:.5f} min={noisy.min():.4f}")
+    out = {"sha": np.frombuffer(bytes.fromhex(sha(noisy)), np.uint8), "reg": np.asarray(reg, np.float64),
+           "params": np.array([p['gain'], p['sigma']], np.float64)}
+    full_store(out, "dn", dn)
+    save("full_cfg5", **out)
+
+
 GENS = dict(rot=gen_rot, pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
             vst_denoiser=gen_vst_denoiser, iter=gen_iter, biaslut=gen_biaslut, ssim=gen_ssim, nle_full=gen_nle_full,
-            iter_full=gen_iter_full, train=gen_train, train_sched=gen_train_sched, train32=gen_train32)
+            iter_full=gen_iter_full, train=gen_train, train_sched=gen_train_sched, train32=gen_train32,
+            full_cfg2=gen_full_cfg2, full_cfg4=gen_full_cfg4, full_cfg5=gen_full_cfg5)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

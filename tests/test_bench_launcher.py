@@ -109,3 +109,20 @@ def test_cfg3_shortcut():
     a = bench.parse_args(["--cfg", "3"])
     assert a.mode == "iter" and (a.height, a.width) == (256, 8192) and a.frames_per_step == 8
     assert bench.SIDD_PIPE['full_dn'] is False and bench.SIDD_PIPE['iter'] == 'iter' and bench.SIDD_FULL == (3000, 5328)
+
+
+def test_spawn_ranks_end_to_end_eight_gloo_ranks():
+    """The same REAL launcher path at the width the scaling node has: `bench.py --gpus 8` starts eight ranks (gloo on CPU), the
+    barriers / max over ranks / per-rank gather run over all eight, rank 0 alone prints the line, and the line says that no
+    hardware scaling curve stands behind it (`scaling_measured`)."""
+    import json
+    r = _run_stub(["--gpus", "8", "--steps", "4", "--warmup", "1"], timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    c = out["collectives"]
+    assert out["n_gpus"] == 8 and c["world_size"] == 8 and c["backend"] == "gloo" and len(c["per_rank_mp_per_s"]) == 8
+    # rank 1 sleeps twice as long: value = 8 x the slowest rank's rate
+    assert abs(out["value"] - 8 * min(c["per_rank_mp_per_s"])) <= 0.08 * out["value"]
+    assert len(c["per_rank"]) == 8 and all("rank" in q and "mp_per_s" in q for q in c["per_rank"])

@@ -142,3 +142,72 @@ def test_lrid_and_any_datasets(tmp_path, monkeypatch):
     a.change_eval_ratio(2)
     assert len(a) == 2 and 'hr' not in a[0] and 'hr' in a[1] and a[1]['name'] == 'f1_x02'
     np.testing.assert_array_equal(a[0]['lr'], ((np.load(frames / "f0.npy").astype(np.float32) - 63) * 2 / 960).astype(np.float32))
+
+
+def test_greedy_shard_on_five_size_classes():
+    """the SIDD validation set is 8 scenes from each of five phones with different frame sizes; the ranks get
+    the images longest-first onto the least-loaded rank, from sizes known BEFORE anything is loaded (scene names / .npy headers)."""
+    from yond_public_amd import data as Dt
+    from yond_public_amd import distributed as D
+
+    class Scenes:
+        def __init__(self):
+            phones = ['S6', 'GP', 'N6', 'G4', 'IP']
+            self.infos = [{'name': f'{i:04d}_{i % 10:03d}_{phones[i % 5]}_00800_00350_3200_L', 'lr_path': None} for i in range(40)]
+
+        def __len__(self):
+            return len(self.infos)
+    ds = Scenes()
+    sizes = Dt.item_sizes(ds)
+    assert len(sizes) == 40 and len(set(sizes)) == 5 and sizes[0] == 3000 * 5328
+    world = 8
+    shards = [D.shard_dataset(ds, r, world) for r in range(world)]
+    assert sorted(i for s in shards for i in s) == list(range(40))                  # a partition
+    loads = [sum(sizes[i] for i in s) for s in shards]
+    rr = [sum(sizes[i] for i in range(r, 40, world)) for r in range(world)]         # round-robin's loads
+    assert max(loads) <= max(rr) and max(loads) - min(loads) <= max(sizes)          # never worse, and within one frame of even
+    assert max(loads) / (sum(loads) / world) <= 1.06
+    # unknown sizes -> round-robin; one rank -> everything
+    ds.infos[3]['name'] = 'unknown'
+    assert Dt.item_sizes(ds) is None and D.shard_dataset(ds, 1, 8) == list(range(1, 40, 8))
+    assert D.shard_dataset(ds, 0, 1) == list(range(40))
+
+
+def test_npy_header_gives_the_item_size(tmp_path):
+    from yond_public_amd import data as Dt
+
+    class One:
+        infos = []
+
+        def __len__(self):
+            return len(self.infos)
+    p = str(tmp_path / "frame.npy")
+    np.save(p, np.zeros((30, 52), np.float32))
+    One.infos = [{'name': 'x', 'lr_path': p}]
+    assert Dt.item_sizes(One()) == [30 * 52]
+
+
+def test_prefetcher_orders_items_and_relays_errors():
+    """The loader threads deliver the items in the order asked for, whatever order they finish in, as float32 tensors; an exception
+    inside a worker surfaces at ITS item."""
+    import time
+    import torch
+    from yond_public_amd.data import Prefetcher
+
+    class Slow:
+        def __len__(self):
+            return 12
+
+        def __getitem__(self, k):
+            time.sleep(0.03 if k % 3 == 0 else 0.0)
+            if k == 7:
+                raise RuntimeError("item 7 is broken")
+            return {'lr': np.full((2, 3), k, np.uint16), 'hr': None, 'name': f'i{k}'}
+    got = []
+    with pytest.raises(RuntimeError, match="item 7"):
+        for k, d in Prefetcher(Slow(), [5, 0, 3, 9, 1, 7, 2], 'cpu', workers=3, depth=3):
+            assert isinstance(d['lr'], torch.Tensor) and d['lr'].dtype == torch.float32 and float(d['lr'][0, 0]) == k and d['name'] == f'i{k}'
+            got.append(k)
+    assert got == [5, 0, 3, 9, 1]
+    assert [k for k, _ in Prefetcher(Slow(), [0, 1, 2, 3], 'cpu', workers=8, depth=1)] == [0, 1, 2, 3]
+    assert list(Prefetcher(Slow(), [], 'cpu')) == []

@@ -636,3 +636,65 @@ def test_decoder_gemm_two_subpositions_per_tile_bit_identical(c, h, w):
     ref += torch.einsum('nyjxki,iojk->nyjxko', skip.double().reshape(N, h, 2, w, 2, c), w_f[2 * c:].double()).reshape(N, 2 * h, 2 * w, c)
     ref += b_f.double()
     assert float((outs[1].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("N,H,W,in_nhwc,out4", [(2, 50, 75, False, False), (1, 37, 70, True, True), (1, 24, 64, False, False), (2, 13, 33, True, False),
+                                                 (1, 100, 36, False, True), (1, 130, 200, False, False)])
+def test_block0_fused_equals_the_two_launches(N, H, W, in_nhwc, out4):
+    """csrc/block0_fused.hip: a level-0 residual block (32 -> 32 -> 32 channels) in ONE launch -- conv1 on the tile's halo region, SiLU(FiLM(.))
+    split into LDS, conv2 from there, residual, split-plane store or the fused output projection -- against the two split-operand launches
+    it replaces (same split arithmetic, another summation order inside the MFMA: agreement to float32 rounding) and against the float64
+    block (archs/modules.py:186-196); ragged tiles (H, W no multiples of 12 / 32), batch, both input formats, the zero pads untouched."""
+    from yond_public_amd.engine import _PackedConv, DenoiserPlan
+    from yond_public_amd import _lib as L
+    C = 32
+    g = torch.Generator().manual_seed(7 * H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w1 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    f = [torch.randn(N, C, generator=g).to(DEV) for _ in range(4)]
+    xn = nhwc(x)
+    xd = xn.to(DEV)
+    xin = xd if in_nhwc else to_p4(xn)
+    plan = DenoiserPlan.__new__(DenoiserPlan)
+    plan.lib, plan.dev = L.load(), torch.device(DEV)
+    plan.status, plan.status_slot = torch.zeros(4, dtype=torch.int32, device=DEV), 0
+    pc1 = _PackedConv(plan.dev, w1, None, 3, 1, [C])
+    pc2 = _PackedConv(plan.dev, w2, None, 3, 1, [C])
+    # the two launches: conv1 -> split planes -> conv2 (+ residual)
+    t_sp = plan._new_sp('t', N, H, W, C)
+    plan._conv(pc1, xd, None, N, H, W, t_sp, escale=f[0], eshift=f[1], ebatch=1, pre_act=1, post_act=1, algo='split', out_fmt=1)
+    kw2 = dict(escale=f[2], eshift=f[3], ebatch=1, res=xd, algo='split', in_fmt=1)
+    z = F.conv2d(F.silu(x.double()), w1.double(), padding=1) * f[0].cpu().double()[:, :, None, None] + f[1].cpu().double()[:, :, None, None]
+    ref = F.conv2d(F.silu(z), w2.double(), padding=1) * f[2].cpu().double()[:, :, None, None] + f[3].cpu().double()[:, :, None, None] + x.double()
+    if out4:
+        w4 = (torch.randn(4, C, generator=g) / C ** 0.5).to(DEV)
+        b4 = torch.randn(4, generator=g).to(DEV)
+        x4 = torch.rand(N, H, W, 4, generator=g).to(DEV)
+        ub = (torch.rand(N, generator=g) + 0.5).to(DEV)
+        o_two = torch.full((N, H, W, 4), float('nan'), device=DEV)
+        o_one = torch.full((N, H, W, 4), float('nan'), device=DEV)
+        plan._conv(pc2, t_sp, None, N, H, W, None, out4=(w4, b4, x4, ub, o_two), **kw2)
+        plan._block0(pc1, pc2, xin, N, H, W, f, 0 if in_nhwc else 2, out4=(w4, b4, x4, ub, o_one))
+        torch.cuda.synchronize()
+        u = ub.cpu().double()[:, None, None, None]
+        ref4 = (torch.einsum('nchw,qc->nhwq', ref, w4.cpu().double()) + b4.cpu().double() + x4.cpu().double() / u) * u
+        assert report(f"fused level-0 block + output projection {H}x{W} vs two launches", o_one.cpu(), o_two.cpu()) <= 4e-6 * float(ref4.abs().max())
+        assert report(f"fused level-0 block + output projection {H}x{W} vs float64", o_one.cpu(), ref4) <= 6e-5 * max(1.0, float(ref4.abs().max()))
+    else:
+        o_two = torch.full((N, H, W, C), float('nan'), device=DEV)
+        plan._conv(pc2, t_sp, None, N, H, W, o_two, **kw2)
+        o_sp = plan._new_sp('o', N, H, W, C)
+        plan._block0(pc1, pc2, xin, N, H, W, f, 0 if in_nhwc else 2, dst=o_sp)
+        torch.cuda.synchronize()
+        val, pads = sp_decode(o_sp, N, C, H, W)
+        assert not pads.view(torch.int16).any()
+        scale = float(ref.abs().max())
+        assert report(f"fused level-0 block {H}x{W} vs two launches", val, nchw(o_two.cpu()).double()) <= 4e-6 * scale
+        assert report(f"fused level-0 block {H}x{W} vs float64", val, ref) <= 6e-5 * max(1.0, scale)
+    assert int(plan.status[0]) == 0
+    # the range guard: an input beyond fp16's range after SiLU is reported
+    big = xin.clone()
+    big.view(-1)[5] = 1e6
+    plan._block0(pc1, pc2, big, N, H, W, f, 0 if in_nhwc else 2, dst=plan._new_sp('o2', N, H, W, C))
+    assert int(plan.status[0]) & 1

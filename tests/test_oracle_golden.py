@@ -2,6 +2,7 @@
 the reference itself (oracle/gen_golden.py).  These pin the oracle; see its header for the one
 unpinned boundary (cv2.blur)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -349,3 +350,58 @@ def test_nle_full_frame_3000x4000(golden):
     np.testing.assert_allclose(infoc['th'], thc, rtol=1e-6)
     np.testing.assert_allclose(regc[0], c1, rtol=1e-6)
     np.testing.assert_allclose(regc[1], c2, rtol=0, atol=1e-6 * abs(c1) + 1e-10)
+
+
+# ---- BASELINE.json's configurations at their real sizes (tests/golden/full_cfg{2,4,5}.npz, oracle/gen_golden.py gen_full_*) ----
+FULL_PIPE = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'max_iter': 1, 'full_dn': True}
+
+
+def full_crops(dn):
+    dn = np.asarray(dn)
+    H, W = dn.shape
+    return (dn[:64, :64].astype(np.float32), dn[H // 2 - 32:H // 2 + 32, W // 2 - 32:W // 2 + 32].astype(np.float32),
+            dn[H - 64:, W - 64:].astype(np.float32), dn[7::64, 11::64].astype(np.float32))
+
+
+def full_case(which, i=0):
+    """Inputs of the full-size fixtures, regenerated from seeds (the generating script's full_cfg*_case functions)."""
+    if which == "cfg2":
+        noisy, clean = O.synth_noisy(3000, 4000, 4.0, 6.0, 0)
+        arch, seed = ARCHS["gru32"], 7
+    elif which == "cfg2w":
+        noisy, clean = O.synth_noisy(3000, 4096, 2.0, 20.0, 3)
+        arch, seed = ARCHS["gru32"], 8
+    elif which == "cfg4":
+        noisy, clean = O.synth_noisy(3000, 4000, 4.0, 6.0, 70 + i)
+        arch, seed = ARCHS["unet32"], 9
+    else:
+        rng = np.random.default_rng(1997 + 55)
+        clean = (O.synth_clean(4000, 6000) * 0.2).astype(np.float32)
+        noisy = ((rng.poisson(clean * 959.0 / 2.0) * 2.0 + rng.normal(0.0, 25.0, clean.shape)) / 959.0).astype(np.float32)
+        arch, seed = ARCHS["gru32"], 10
+    return noisy, clean, arch, O.denoising_state_dict(arch, seed)
+
+
+def test_full_size_fixture_inputs_regenerate(golden):
+    """The full-size fixtures hold outputs only; their inputs come back bit for bit from the seeds, and the reference's round-1
+    estimate on the 3000 x 4000 frame inside IterDenoise is the number its stand-alone SimpleNLF gave (nle_full.npz)."""
+    g2, g4, g5 = golden("full_cfg2"), golden("full_cfg4"), golden("full_cfg5")
+    assert np.array_equal(sha(full_case("cfg2")[0]), g2["a_sha"])
+    assert np.array_equal(sha(full_case("cfg2w")[0]), g2["b_sha"])
+    for i in range(2):
+        assert np.array_equal(sha(full_case("cfg4", i)[0]), g4[f"sha_{i}"])
+    n5 = full_case("cfg5")[0]
+    assert np.array_equal(sha(n5), g5["sha"]) and float(n5.min()) < 0
+    np.testing.assert_allclose(g2["a_reg0"], golden("nle_full")["self"][2:], rtol=1e-12)
+    assert g2["a_psnr"][1] > g2["a_psnr"][0] + 7 and int(g2["b_nout"]) == 2
+
+
+@pytest.mark.skipif(not os.environ.get("YOND_SLOW"), reason="minutes of CPU: the oracle's full-size forward (YOND_SLOW=1)")
+def test_oracle_full_cfg2_round1(golden):
+    g = golden("full_cfg2")
+    noisy, clean, arch, sd = full_case("cfg2")
+    torch.set_num_threads(8)
+    res = O.IterDenoise(noisy, arch, sd, dict(FULL_PIPE, iter='once'))
+    np.testing.assert_allclose(res['regs'][0], g["a_reg0"], rtol=1e-5)
+    for got, tag in zip(full_crops(res['raw_dns'][0]), ("a", "b", "c", "sub")):
+        np.testing.assert_allclose(got, g[f"a_dn0_{tag}"], rtol=0, atol=2e-5)

@@ -43,17 +43,26 @@ class SyntheticSIDD:
     (32, 256, 256), 'lr_full' (the frame used for the round-1 estimate: 3000 x 5328, the size SURVEY 8d names for the
     stand-ins of the SIDD full frames), 'name'."""
 
-    def __init__(self, n=40, K=4.0, sigma=6.0, full_hw=(3000, 5328)):
-        self.n, self.K, self.sigma, self.full_hw = n, K, sigma, full_hw
+    def __init__(self, n=40, K=4.0, sigma=6.0, full_hw=(3000, 5328), distinct=8):
+        """distinct: item k is the synthesis of seed k % distinct, kept once made (a 16 MP Poisson draw takes ~1 s of NumPy -- 300 x the
+        GPU time of the image; a real dataset's items come from files, which the loader threads overlap with the GPU)."""
+        self.n, self.K, self.sigma, self.full_hw, self.distinct = n, K, sigma, full_hw, max(1, distinct)
+        self._made = {}
 
     def __len__(self):
         return self.n
 
+    def item_size(self, k):
+        return self.full_hw[0] * self.full_hw[1]
+
     def __getitem__(self, k):
-        noisy, clean = S.synth_noisy(256, 8192, self.K, self.sigma, 100 + k)
-        full, _ = S.synth_noisy(self.full_hw[0], self.full_hw[1], self.K, self.sigma, 500 + k)
-        return {'lr': np.array(np.split(noisy, 32, axis=-1)), 'hr': np.array(np.split(clean, 32, axis=-1)),
-                'lr_full': full, 'name': f'synthetic_{k:03d}', 'meta': None, 'cfa': 'rggb'}
+        j = k % self.distinct
+        if j not in self._made:
+            noisy, clean = S.synth_noisy(256, 8192, self.K, self.sigma, 100 + j)
+            full, _ = S.synth_noisy(self.full_hw[0], self.full_hw[1], self.K, self.sigma, 500 + j)
+            self._made[j] = (np.array(np.split(noisy, 32, axis=-1)), np.array(np.split(clean, 32, axis=-1)), full)
+        lr, hr, full = self._made[j]
+        return {'lr': lr, 'hr': hr, 'lr_full': full, 'name': f'synthetic_{k:03d}', 'meta': None, 'cfa': 'rggb'}
 
 
 class NpySIDD:
@@ -146,8 +155,9 @@ class YOND_SIDD:
                             biaslut=self.biaslut,
                             est={'root_dir': (getattr(self, 'dst', None) or {}).get('root_dir'), 'img_id': params.get('img_id'),
                                  'name': data.get('name')})
-        res['lr_raw'] = np.concatenate(data['lr'], axis=-1)
-        res['hr_raw'] = np.concatenate(data['hr'], axis=-1) if 'hr' in data else None
+        cat = lambda a: torch.cat(list(a), dim=-1) if isinstance(a, torch.Tensor) else np.concatenate(a, axis=-1)   # (:480-481)
+        res['lr_raw'] = cat(data['lr'])
+        res['hr_raw'] = cat(data['hr']) if data.get('hr') is not None else None
         return res
 
     def eval(self, epoch=-1):
@@ -156,20 +166,22 @@ class YOND_SIDD:
         p = dict(self.pipe)
         p.update({'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0})          # YOND_SIDD.py:504
         p['scale'] = (p['wp'] - p['bl']) / p['ratio']
-        mine = D.shard_indices(len(self.dst_eval), self.rank, self.world)
+        mine = D.shard_dataset(self.dst_eval, self.rank, self.world)        # size-aware (five phones, five frame sizes) where sizes are known
         self.metrics = {}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         t_path = 0.0
-        for k in mine:
-            data = self.dst_eval[k]                                                     # (host side: file reads / synthesis)
+        # the items are read and uploaded by loader threads ahead of the GPU (the reference reads each in front of its IterDenoise,
+        # :507-514): file reads, the float32 conversion and the 64 MB upload of the full frame overlap the previous images' kernels
+        from .data import Prefetcher
+        for k, data in Prefetcher(self.dst_eval, mine, self.device, depth=self.parser.prefetch, workers=self.parser.loaders):
             p['cfa'] = data.get('cfa', [[1, 2], [2, 3]])                                # YOND_SIDD.py:510
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             res = self.IterDenoise(data, {'p': p, 'img_id': k})
             psnrs, ssims = [], []
             if res['hr_raw'] is not None:
-                hr = torch.from_numpy(res['hr_raw']).to(self.device)
+                hr = res['hr_raw'] if isinstance(res['hr_raw'], torch.Tensor) else torch.from_numpy(res['hr_raw']).to(self.device)
                 for dn in res['raw_dns']:
                     ps, ss = P.block_metrics(dn, hr)                                   # :649-652 per 256x256 block
                     psnrs.append(float(np.mean(ps)))
@@ -190,7 +202,9 @@ class YOND_SIDD:
                 log(f"Iter{it}: PSNR={red[f'psnr_iter{it}']:.2f}, SSIM={red[f'ssim_iter{it}']:.4f}", self.logfile)
             log(f"Iter_last: PSNR={red['psnr_last']:.2f}, SSIM={red['ssim_last']:.4f}", self.logfile)
             log(f"{red['count']} images on {self.world} GPU(s) in {dt:.2f} s "
-                f"(rank 0: {t_path / max(len(mine), 1) * 1e3:.1f} ms per image in IterDenoise + metrics, the rest is data loading)", self.logfile)
+                f"(rank 0: {dt / max(len(mine), 1) * 1e3:.1f} ms wall per image, {t_path / max(len(mine), 1) * 1e3:.1f} ms of it in IterDenoise + metrics; "
+                f"the rest is waiting for the {self.parser.loaders} loader threads)", self.logfile)
+            self.last_timing = {'wall_ms_per_image': dt / max(len(mine), 1) * 1e3, 'path_ms_per_image': t_path / max(len(mine), 1) * 1e3}
             log(f"collectives: backend={D.STATS['backend']}, all_reduce={D.STATS['all_reduce']}, barrier={D.STATS['barrier']}", self.logfile)
         return red
 
@@ -208,11 +222,11 @@ class YOND_SIDD:
         p.update({'wp': 1023, 'bl': 64, 'ratio': 1, 'gain': 1, 'sigma': 0})                  # :586
         p['scale'] = (p['wp'] - p['bl']) / p['ratio']
         self.metrics = getattr(self, 'metrics', None) or {}
-        mine = D.shard_indices(n, self.rank, self.world)
+        mine = D.shard_dataset(self.dst_eval, self.rank, self.world)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in mine:
-            data = self.dst_eval[k]
+        from .data import Prefetcher
+        for k, data in Prefetcher(self.dst_eval, mine, self.device, depth=self.parser.prefetch, workers=self.parser.loaders):
             p['cfa'] = data.get('cfa', [[1, 2], [2, 3]])
             res = self.IterDenoise(data, {'p': p, 'img_id': k})
             self.metrics.setdefault(data['name'], {})['reg_test'] = res['regs']                   # :597
@@ -247,6 +261,8 @@ class YONDParser:
         a.add_argument('--synthetic', type=int, default=40, help="number of synthetic stand-in images when no dataset is found "
                        "(40 = the SIDD validation set's size; each with a 3000 x 5328 frame for the round-1 estimate)")
         a.add_argument('--verbose', action='store_true', default=False)
+        a.add_argument('--loaders', type=int, default=4, help="loader threads that read and upload the items ahead of the GPU")
+        a.add_argument('--prefetch', type=int, default=4, help="items the loader threads may be ahead of the GPU")
         return a.parse_args(args)
 
 

@@ -123,11 +123,12 @@ class YOND_Full:
             ds = self.dst_eval
             wp, bl = float(getattr(ds, 'wp', self.dst.get('wp', 1023))), float(getattr(ds, 'bl', self.dst.get('bl', 64)))
             sums = D.MetricSums(n_it)
-            mine = D.shard_indices(len(ds), self.rank, self.world)
+            mine = D.shard_dataset(ds, self.rank, self.world)
             torch.cuda.synchronize()
             t0, t_path, npix = time.perf_counter(), 0.0, 0
-            for k in mine:
-                data = ds[k]
+            from .data import Prefetcher                     # loader threads read / convert / upload the frames ahead of the GPU
+            for k, data in Prefetcher(ds, mine, self.device, upload=('lr', 'hr'), depth=getattr(self.parser, 'prefetch', 4),
+                                      workers=getattr(self.parser, 'loaders', 4)):
                 p = dict(self.pipe)
                 p.update({'wp': wp, 'bl': bl, 'ratio': data.get('ratio', 1), 'gain': 1, 'sigma': 0})           # YOND_SIDD.py:503-505
                 p['scale'] = (p['wp'] - p['bl']) / p['ratio']
@@ -136,7 +137,7 @@ class YOND_Full:
                 res = self.IterDenoise(data, {'p': p, 'img_id': k})
                 psnrs, ssims = [], []
                 if data.get('hr') is not None:
-                    hr = torch.from_numpy(np.ascontiguousarray(data['hr'], np.float32)).to(self.device)
+                    hr = data['hr'] if isinstance(data['hr'], torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data['hr'], np.float32)).to(self.device)
                     H, W = hr.shape
                     for dn in res['raw_dns']:
                         ps, ss = P.block_metrics(dn, hr.clamp(0, 1), bh=H, bw=W)          # whole-frame PSNR / SSIM (data range 1)
@@ -145,7 +146,7 @@ class YOND_Full:
                     sums.update(psnrs, ssims)
                 torch.cuda.synchronize()
                 t_path += time.perf_counter() - t1
-                npix += int(np.prod(data['lr'].shape))
+                npix += int(np.prod(tuple(data['lr'].shape)))
                 self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
                 log(f"[rank {self.rank}] {data['name']}: " + (f"PSNR={psnrs[-1]:.2f}, SSIM={ssims[-1]:.4f}" if psnrs else "denoised (no reference frame)")
                     + f", K={res['params'][-1][0]:.3f}, sigma={res['params'][-1][1]:.3f}", self.logfile)

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOND_HIP_LIB", os.path.join(_HERE, "libyond_hip.so"))   # override: experiments only
 _lib = None
-ABI_VERSION = 6                     # include/yond_hip.h YOND_ABI_VERSION
+ABI_VERSION = 7                     # include/yond_hip.h YOND_ABI_VERSION
 
 vp, i32, f32, f64, sz, i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_longlong
 
@@ -24,6 +24,12 @@ class YondConvDesc(C.Structure):
                 ("eshift", vp), ("ebatch", i32), ("res", vp), ("dst", vp), ("tn", i32), ("kc", i32), ("algo", i32),
                 ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp), ("status", vp),
                 ("in_fmt", i32), ("out_fmt", i32), ("res_fmt", i32), ("clk", vp), ("tile_order", i32), ("dst2", vp)]
+
+
+class YondBlock0Desc(C.Structure):
+    _fields_ = [("x", vp), ("in_fmt", i32), ("N", i32), ("H", i32), ("W", i32), ("w1", vp), ("w2", vp),
+                ("s1", vp), ("t1", vp), ("s2", vp), ("t2", vp), ("ebatch", i32), ("dst", vp),
+                ("out4_w", vp), ("out4_b", vp), ("out4_x", vp), ("out4_ub", vp), ("out4_dst", vp), ("status", vp)]
 
 
 class YondFilmDesc(C.Structure):
@@ -84,6 +90,8 @@ PROTOTYPES = {
     "yond_bias_lut_f64": [vp, i32, f64, f64, vp, vp],
     "yond_block_metrics_tiles": [i32, i32],
     "yond_block_metrics_f32": [vp, vp, i32, i32, i32, i32, vp, vp],
+    "yond_block0_fused_f32": [C.POINTER(YondBlock0Desc), vp],
+    "yond_pack_block0_weight_f32": [vp, i32, i32, vp],
     "yond_clock_probe": [f64, vp, vp],
     "yond_conv_wgrad_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "yond_conv_wgrad_ws_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp],

@@ -67,15 +67,24 @@ def _write_resource_report(remarks, path):
     import json
     import re
     out, cur = [], None
+    show, held = False, []                       # inside a warning / error / note (its excerpt lines follow); "In file included from" lines held for it
     for line in remarks.splitlines():
         m = re.search(r"remark: Function Name: (\S+)", line)
         if m:
             cur = {"name": m.group(1)}
             out.append(cur)
-            continue
-        if cur is None:
-            if "warning" in line or "error" in line:
-                sys.stderr.write(line + "\n")
+        if "remark:" in line:
+            show, held = False, []
+        elif re.search(r"(warning|error|note):", line) or re.match(r"^\d+ (warning|error)s? generated", line.strip()):
+            # compiler diagnostics go through wherever they stand (they used to be dropped behind the first kernel's remarks)
+            show = True
+            sys.stderr.write("".join(h + "\n" for h in held) + line + "\n")
+            held = []
+        elif line.startswith("In file included from"):
+            held.append(line)
+        elif show and line.strip():
+            sys.stderr.write(line + "\n")        # the diagnostic's source excerpt / caret
+        if "remark:" not in line or cur is None:
             continue
         for key, tag in (("vgprs", "VGPRs:"), ("vgpr_spill", "VGPRs Spill:"), ("sgpr_spill", "SGPRs Spill:"), ("scratch", "ScratchSize [bytes/lane]:"),
                          ("lds", "LDS Size [bytes/block]:")):
@@ -89,15 +98,21 @@ def _write_resource_report(remarks, path):
 def resource_report():
     """[{name (mangled), vgprs, vgpr_spill, sgpr_spill, scratch, lds}] of every kernel of the product build (from the objects' reports)."""
     import json
-    rep = []
+    rep, missing = [], 0
     for s in sources():
         p = _obj(s) + ".res.json"
         if os.path.exists(p):
             rep += json.load(open(p))
+        else:
+            missing += 1
+    if missing and os.path.exists(RES_STAMP) and not needs_build():
+        # a shipped library (reused by its stamp) without its object directory: the report written when it was linked
+        return json.load(open(RES_STAMP))
     return rep
 
 
 STAMP = os.path.join(HERE, "libyond_hip.stamp")      # sha256 of (flags, sources, headers) the library was built from
+RES_STAMP = os.path.join(HERE, "libyond_hip.res.stamp")   # the kernels' resource report (JSON) as of that link: travels with the library
 
 
 def source_hash(extra_flags=()):
@@ -154,6 +169,9 @@ def build_lib(force=False, verbose=True, extra_flags=(), lib=None):
     if lib == LIB:
         with open(STAMP, "w") as f:
             f.write(f"{source_hash(extra_flags)} {mode}\n")
+        import json
+        with open(RES_STAMP, "w") as f:
+            json.dump(resource_report(), f)
     if verbose:
         print(f"yond_public_amd.build: {mode}, linked {lib}", flush=True)
     return lib, mode

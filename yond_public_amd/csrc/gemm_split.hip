@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GsArgs a) {
     int nst[GS_MAXSRC];
     int nsteps = 0;
     for (int s = 0; s < a.nsrc; ++s) { nst[s] = a.src[s].k / 32; nsteps += nst[s]; }
-    float wmax = 0.0f;
+    float wmax = 0.0f, xmax = 0.0f;
+    bool wbad = false, xbad = false;
 
     // ---- staging ----
     // pixels: 128 x 32 channels = 1024 items of 16 bytes, 4 per thread: item i -> pixel i / 8, channels 4 (i % 8) ..
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GsArgs a) {
         for (int j = 0; j < 4; ++j) {
             const int i = tid + j * 256;
             const f32x4 v = vx[rs][j];
+            // (range guard: fmaxf drops a NaN operand, so a NaN is caught by its own test -- v != v -- and counted as out of range)
+            xbad |= (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]);
+            xmax = fmaxf(xmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
             const gs_f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             const gs_f16x4 l = {(_Float16)((v[0] - (float)h[0]) * 2048.0f), (_Float16)((v[1] - (float)h[1]) * 2048.0f),
                                 (_Float16)((v[2] - (float)h[2]) * 2048.0f), (_Float16)((v[3] - (float)h[3]) * 2048.0f)};
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GsArgs a) {
         for (int j = 0; j < TN; ++j) {
             const int gi = tid + j * 256;
             const f32x4 v = vw[rs][j];
+            wbad |= (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]);
             wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
             const gs_f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             const gs_f16x4 P = {(_Float16)(v[0] * 2048.0f), (_Float16)(v[1] * 2048.0f), (_Float16)(v[2] * 2048.0f), (_Float16)(v[3] * 2048.0f)};
@@ -175,7 +180,10 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GsArgs a) {
         body(st, std::integral_constant<int, 0>{});
         if (st + 1 < nsteps) body(st + 1, std::integral_constant<int, 1>{});
     }
-    if (a.status && !(wmax < 31.9f)) atomicOr(a.status, 1);     // a P part (2^11 w) left fp16's range
+    // status[0] bit 0: a staged x part left fp16's range (|x| > 65504) or is NaN -- the word the training step's retry / the graph's Adam
+    // gate read (an activation, or a loss-scaled gradient in the data-gradient uses); status[1] bit 0: a P part (2^11 w) did (|w| >= 32)
+    if (a.status && (xbad || !(xmax <= 65504.0f))) atomicOr(a.status, 1);
+    if (a.status && (wbad || !(wmax < 31.9f))) atomicOr(a.status + 1, 1);
 
     // ---- epilogue: accumulator layout: lane l holds pixel (column) l % 32, output channels (rows) (r & 3) + 8 (r >> 2) + 4 (l / 32) ----
     const long long p = p0 + wave * 32 + fr;

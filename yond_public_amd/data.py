@@ -276,3 +276,115 @@ class Any_Dataset:
             if 'hr' in data:
                 data['hr'] = data['hr'].clip(0, 1)
         return data
+
+
+# ------------------------------------------------------------------------------------------------
+# Feeding the GPU (YOND_SIDD.py:507-514 reads every item in front of its IterDenoise call: tens of milliseconds of file reads and a
+# 64 MB upload against a few milliseconds of GPU time per image).
+SIDD_FRAME_HW = {'S6': (3000, 5328), 'GP': (3044, 4048), 'N6': (3120, 4208), 'G4': (2988, 5312), 'IP': (3024, 4032)}   # the five phones of the SIDD scenes
+
+
+def item_sizes(ds):
+    """Pixel counts of the items' full frames WITHOUT loading them (what the size-aware sharding needs before launch):
+    a dataset's own `item_size(k)`, the header of a `.npy` full frame, the phone code in a SIDD scene name (0009_001_S6_...);
+    None where nothing is known (the caller then shards round-robin)."""
+    out = []
+    for k in range(len(ds)):
+        n = None
+        if hasattr(ds, 'item_size'):
+            n = ds.item_size(k)
+        elif hasattr(ds, 'infos'):
+            info = ds.infos[k]
+            path, name = info.get('lr_path'), str(info.get('name', ''))
+            if path and path.endswith('.npy') and os.path.exists(path):
+                shp = np.load(path, mmap_mode='r').shape
+                n = int(shp[-1]) * int(shp[-2])
+            else:
+                parts = name.split('_')
+                if len(parts) > 2 and parts[2] in SIDD_FRAME_HW:
+                    n = SIDD_FRAME_HW[parts[2]][0] * SIDD_FRAME_HW[parts[2]][1]
+        if n is None:
+            return None
+        out.append(int(n))
+    return out
+
+
+class Prefetcher:
+    """`for k, data in Prefetcher(ds, indices, device)`: the items `ds[k]` in the order of `indices`, read by `workers` background
+    threads up to `depth` items ahead; every numpy array under the keys of `upload` arrives as a float32 DEVICE tensor (copied into
+    a reused pinned buffer, sent on the worker's own copy stream; the consumer's current stream is made to wait for the copy's event,
+    so no host synchronisation happens on the consumer's side).  Everything else in the item is passed through.  An exception in a
+    worker is re-raised at the item it belongs to."""
+
+    def __init__(self, ds, indices, device, upload=('lr', 'hr', 'lr_full'), depth=4, workers=4):
+        import queue
+        import threading
+        import torch
+        self.ds, self.indices, self.device, self.upload = ds, list(indices), torch.device(device), tuple(upload)
+        self.workers = max(1, min(int(workers), len(self.indices) or 1))
+        self.depth = max(self.workers, int(depth))
+        self._slots = [queue.Queue(maxsize=1) for _ in self.indices]        # one-shot mailboxes, filled out of order, read in order
+        self._gate = threading.Semaphore(self.depth)                        # items loaded but not yet consumed
+        self._stop = False
+        self._threads = [threading.Thread(target=self._work, args=(w,), daemon=True) for w in range(self.workers)]
+        for t in self._threads:
+            t.start()
+
+    def _work(self, w):
+        import torch
+        stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        pool = {}                                                           # (key, shape) -> [pinned buffer, event of its last copy] x 2
+        turn = {}
+        for pos in range(w, len(self.indices), self.workers):
+            self._gate.acquire()
+            if self._stop:
+                return
+            k = self.indices[pos]
+            try:
+                data = dict(self.ds[k])
+                ev = None
+                for key in self.upload:
+                    a = data.get(key)
+                    if not isinstance(a, np.ndarray):
+                        continue
+                    if stream is None:
+                        data[key] = torch.from_numpy(np.ascontiguousarray(a, np.float32))
+                        continue
+                    pk = (key, a.shape)
+                    bufs = pool.setdefault(pk, [])
+                    i = turn.get(pk, 0)
+                    turn[pk] = i + 1
+                    if len(bufs) < 2:
+                        bufs.append([torch.empty(a.shape, dtype=torch.float32).pin_memory(), None])
+                    buf = bufs[i % 2]
+                    if buf[1] is not None:
+                        buf[1].synchronize()                                # the buffer's previous upload has left it
+                    buf[0].numpy()[...] = a                                 # (converts to float32 on the way)
+                    with torch.cuda.stream(stream):
+                        data[key] = buf[0].to(self.device, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                    buf[1] = ev
+                self._slots[pos].put((k, data, ev, None))
+            except BaseException as e:                                      # noqa: BLE001 -- handed to the consumer
+                self._slots[pos].put((k, None, None, e))
+
+    def __iter__(self):
+        import torch
+        try:
+            for pos in range(len(self.indices)):
+                k, data, ev, err = self._slots[pos].get()
+                self._gate.release()
+                if err is not None:
+                    raise err
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    for key in self.upload:
+                        if isinstance(data.get(key), torch.Tensor) and data[key].is_cuda:
+                            data[key].record_stream(cur)
+                yield k, data
+        finally:
+            self._stop = True
+            for _ in self._threads:
+                self._gate.release()

@@ -63,6 +63,17 @@ def shard_indices(n_items, rank, world, sizes=None):
     return sorted(mine)
 
 
+def shard_dataset(ds, rank, world):
+    """The indices of `ds` this rank evaluates: longest-first greedy on the items' full-frame pixel counts where they are known before
+    loading (data.item_sizes: the SIDD validation set is 8 scenes from each of five phones with different frame sizes) and
+    differ; round-robin otherwise."""
+    from .data import item_sizes
+    sizes = item_sizes(ds) if world > 1 else None
+    if sizes is not None and len(set(sizes)) > 1:
+        return shard_indices(len(ds), rank, world, sizes=sizes)
+    return shard_indices(len(ds), rank, world)
+
+
 class MetricSums:
     """Per-rank sums of the per-image metrics, reduced once at the end.
     Layout mirrors the reference's meters: [psnr_it0, ssim_it0, ..., psnr_last, ssim_last, count]."""

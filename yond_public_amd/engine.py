@@ -45,6 +45,9 @@ WINO_DEFAULT = 'split'              # 'split': fp32-accurate split-operand fp16-
 SPLIT_PLANES = True
 SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
 FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
+FUSE_BLOCK0 = False                 # the two level-0 residual blocks as ONE launch each (csrc/block0_fused.hip: the tensor between the convolutions stays in
+                                    # LDS).  Built, parity-tested, measured (round 5): 1.16 GB less HBM traffic per block and +1.0 % per forward -- level 0 is
+                                    # bound by its vector work (SiLU + split three times per block), not by bytes: profiles/r05_experiments/README.md.  Off.
 K1_SUB2 = True                      # the decoder GEMMs with two sub-positions per channel tile (YondConvDesc.shuffle 2)
 SP_CONV1_MIN_LEVEL = 3              # from this level down a stride-2 layer also stores SiLU(x) in split planes (YondConvDesc.dst2), so that the
                                     # next block's conv1 stages by LDS-DMA alone (there conv1 would repeat the SiLU + split per output-channel tile)
@@ -440,6 +443,51 @@ class DenoiserPlan:
             prof.append((tag, 2.0 * pc.macs_per_pixel * N * d.Ho * d.Wo, e0, e1))
         return dst
 
+    def _block0_weights(self, pc):
+        """A 32 -> 32 3x3 layer's weights in the fused level-0 kernel's LDS order (yond_pack_block0_weight_f32), cached on the layer."""
+        w = getattr(pc, '_b0', None)
+        if w is None:
+            if not (pc.ksize == 3 and pc.stride == 1 and pc.gemm_n == 32 and pc.cinp == 32 and len(pc.psplits) == 1):
+                return None
+            host = np.zeros(9 * 2 * 4 * 32 * 8, np.float16)
+            if self.lib.yond_pack_block0_weight_f32(_np_ptr(pc._wp), 32, 32, _np_ptr(host)) != 0:
+                return None                                  # (a weight beyond fp16's range: the two-launch path's packers decide)
+            w = pc._b0 = torch.from_numpy(host.view(np.float32)).to(pc._dev)
+        return w
+
+    def _block0(self, pc1, pc2, x, N, H, W, f, in_fmt, dst=None, out4=None):
+        """One level-0 residual block in ONE launch (csrc/block0_fused.hip): out = conv2(SiLU(conv1(SiLU(x)) * f0 + f1)) * f2 + f3 + x.
+        x: planes of 4 channels (in_fmt 2) or [N][H][W][32] (0); dst: split planes, or out4 = (w4, b4, x4, ub, destination NHWC4)."""
+        w1, w2 = self._block0_weights(pc1), self._block0_weights(pc2)
+        d = L.YondBlock0Desc()
+        d.x, d.in_fmt, d.N, d.H, d.W = x.data_ptr(), in_fmt, N, H, W
+        d.w1, d.w2 = w1.data_ptr(), w2.data_ptr()
+        d.s1, d.t1, d.s2, d.t2 = (None if v is None else v.data_ptr() for v in f)
+        d.ebatch = 1
+        d.dst = dst.data_ptr() if dst is not None else None
+        if out4 is not None:
+            w4, b4, x4, ub4, o4 = out4
+            d.out4_w, d.out4_b = w4.data_ptr(), (b4.data_ptr() if b4 is not None else None)
+            d.out4_x = x4.data_ptr() if x4 is not None else None
+            d.out4_ub = ub4.data_ptr() if ub4 is not None else None
+            d.out4_dst = o4.data_ptr()
+        status = getattr(self, 'status', None)
+        d.status = status.data_ptr() + 4 * self.status_slot if status is not None else None
+        prof = getattr(self, 'prof', None)
+        if prof is not None:
+            tag = "block0_fused_kernel" + ("<o4>" if out4 is not None else "")
+            only = getattr(self, 'prof_only', None)
+            if (only is not None and not only(tag)) or (getattr(self, 'prof_every', 1) > 1 and getattr(self, '_fwd_idx', 0) % getattr(self, 'prof_every', 1)):
+                prof = None
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(self.lib.yond_block0_fused_f32(C.byref(d), L.stream()), "yond_block0_fused_f32")
+        if prof is not None:
+            e1.record()
+            prof.append((tag, 2.0 * (pc1.macs_per_pixel + pc2.macs_per_pixel) * N * H * W, e0, e1))
+        return dst
+
     def _film(self, t_dev, ub, N):
         """All nine blocks' (scale, shift) epilogue vectors in one launch."""
         key = N
@@ -549,6 +597,23 @@ class DenoiserPlan:
                 # would repeat it once per output-channel tile (bit-identical: the same fp32 function of the same value).
                 # At split precision tmp is stored in SPLIT PLANES: conv1 writes the (h, l) halves conv2 would have staged,
                 # conv2 stages them by LDS-DMA alone (the same bits again)
+                if flow and FUSE_BLOCK0 and h == H and cp == 32 and self._block0_weights(blk['conv1']) is not None and self._block0_weights(blk['conv2']) is not None:
+                    # level 0: the whole block in one launch -- tmp never leaves the chip (csrc/block0_fused.hip)
+                    if last and self._out4_fusable(blk['conv2']):
+                        out4 = self._new(N, H, W, 4)
+                        self._block0(blk['conv1'], blk['conv2'], cur, N, h, w, f, xfmt, out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4))
+                        return out4
+                    if not last:
+                        out = self._new_sp(('out', i), N, h, w, cp)
+                        self._block0(blk['conv1'], blk['conv2'], cur, N, h, w, f, xfmt, dst=out)
+                        cur = out
+                        skips[i] = cur
+                        nxt = self._new(N, h // 2, w // 2, blk['pool'].coutp)
+                        xsp = self._new_sp(('xsp', i + 1), N, h // 2, w // 2, blk['pool'].coutp) if (flow and i >= SP_CONV1_MIN_LEVEL) else None
+                        self._conv(blk['pool'], cur, None, N, h, w, nxt, in_fmt=SP, out_fmt=P4, dst2=xsp)
+                        h, w = h // 2, w // 2
+                        cur = nxt
+                        continue
                 act_in_producer = self._split_pair(blk['conv1'], blk['conv2'])
                 sp = SP if (flow or (act_in_producer and SPLIT_PLANES and getattr(self, 'precision', 'fp32') == 'fp32'
                                       and sp_plane_units(h, w) * 64 < 2 ** 31)) else 0

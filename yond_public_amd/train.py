@@ -107,7 +107,11 @@ class _Packing:
             pass                                             # packed by the step's one batched launch (TrainStep._gather_weights)
         elif self.split_tn:
             wp = gathered(self.omap)
-            packed = torch.empty_like(wp)
+            # pack INTO the tensor the layer already reads when there is one: it may be a slice of the step's batched destination buffer
+            # (TrainStep._gather_weights re-points the slices only when the set of layers changes), and a private replacement would leave
+            # the kernels on stale weights from the next batched pack on
+            cur = self.pc._packed.get(('split', 2))
+            packed = cur[1] if cur is not None and cur[0] == self.split_tn and cur[1].numel() == wp.numel() else torch.empty_like(wp)
             st = getattr(self, 'status', None)
             L.check(lib.yond_pack_conv_split_weight_dev_f32(L.ptr(wp), self.pc.gemm_n, self.pc.cinp, self.pc.ksize, self.split_tn, 2,
                                                             L.ptr(packed), L.ptr(st), L.stream()), "yond_pack_conv_split_weight_dev_f32")
@@ -275,7 +279,7 @@ def _gemm_split(plan, srcs, P, n_p, n_real, sn_lo, sn_hi, nblk, bias, y, ldy, sh
     for d, (x, wp, sk_lo, sk_hi, ld, k, kblk, k_real) in zip(arr, srcs):
         d.x, d.w, d.sk_lo, d.sk_hi, d.ld, d.k, d.kblk, d.k_real = x.data_ptr(), wp, sk_lo, sk_hi, ld, k, kblk, k_real
     L.check(plan.lib.yond_gemm_split_f32(C.cast(arr, C.c_void_p), len(srcs), P, n_p, n_real, sn_lo, sn_hi, nblk, None if bias is None else L.ptr(bias),
-                                         L.ptr(y), ldy, shuffle, H, W, L.ptr(plan.status[1:2]), L.stream()), "yond_gemm_split_f32")
+                                         L.ptr(y), ldy, shuffle, H, W, L.ptr(plan.status[0:2]), L.stream()), "yond_gemm_split_f32")
     return y
 
 
@@ -283,7 +287,8 @@ def _use_gemm(plan, K):
     """The split-operand GEMM where it measures faster than the fp32-MFMA convolution path (tools/gemm_ab.py, device times at the training
     shape): the deep, compute-bound levels -- at least GEMM_MIN_K input channels in all (a 1x1 over 2 x 256: 42 vs 69 us, the transposed
     512 -> 256: 43 vs 184 us); the wide, shallow levels (K <= 128: 2-4 K steps per tile) stay where they are (74 vs 66, 132 vs 112 us)."""
-    return GEMM_SPLIT and K >= GEMM_MIN_K and plan.arena is not None and getattr(plan, 'train_conv', 'split') == 'split'
+    return (GEMM_SPLIT and K >= GEMM_MIN_K and plan.arena is not None and getattr(plan, 'train_conv', 'split') == 'split'
+            and not getattr(plan, 'gemm_off', False))      # (gemm_off: a weight with |w| >= 32 met the GEMM's 2^11 w part -- see _weight_trip)
 
 
 _BIG = 1 << 30
@@ -580,8 +585,10 @@ class TrainStep:
         loss_scale: the split-operand kernels stage every operand as two fp16 halves, which is fp32-accurate only while the
         operand is in fp16's NORMAL range (|a| >= 6.1e-5); the back-propagated values of a mean loss over n = 4.2 M elements
         (the reference's batch: dpred = +-1/n = 2.4e-7) are far below it.  So dpred is multiplied by a power of two S before
-        backward() and the flat gradient by 1/S before the reduction and Adam -- both exact in float32; None: S = the power of
-        two that puts S/n into (1/16, 1/8]; 1: no scaling.  A gradient or activation that leaves fp16's range (|a| > 65504)
+        backward() and the flat gradient by 1/S behind the (data-parallel) reduction, in front of Adam -- both exact in float32; None: S = the power of
+        two that puts S/n into [1/8, 1/4) (2^ceil(log2 n) / 8); 1: no scaling.  Under data parallelism the buckets are all-reduced at scale S and
+        unscaled afterwards, so S must be the same on every rank (equal local batch sizes; the overflow history is shared because the retry
+        decision is collective): checked collectively the first time a batch shape is seen.  A gradient or activation that leaves fp16's range (|a| > 65504)
         is reported by the kernels' status word, read once per step: the step is redone at S/256, twice at most.  charbonnier: Unet_Loss(charbonnier=True) (losses/base_loss.py:82-85).  ddp: None -- average the gradients over the
         ranks whenever a process group exists (the reference wraps the net in DDP whenever it sees more than one GPU,
         trainer_AWGN.py:59-61); False -- never.
@@ -592,6 +599,7 @@ class TrainStep:
         from . import distributed as D
         self.graph = bool(graph)
         self._graphs, self._seen = {}, {}
+        self._scale_checked = set()
         self.m = module
         self.dev = next(module.parameters()).device
         self.plan = _plan(self.dev)
@@ -762,9 +770,24 @@ class TrainStep:
                     "yond_pack_conv_split_weights_batch_dev_f32")
         plan.wbatch = (self._wb_buf, self._wb_slots, self._pk_ids)
 
+    def _weight_trip(self):
+        """Status word 1: a weight beyond what a split-operand kernel can stage.  The 3x3 kernels and the weight packers take |w| <= 65504;
+        the GEMM (1x1 / transposed layers, csrc/gemm_split.hip) stages 2^11 w and therefore needs |w| < 32 -- a limit the reference does
+        not have.  The first trip moves those layers back to the fp32-input MFMA path for this plan (and drops the captured graphs, which
+        hold GEMM launches); a trip without GEMMs in the step is a weight no fp16 part can hold."""
+        plan = self.plan
+        if GEMM_SPLIT and not getattr(plan, 'gemm_off', False) and getattr(plan, 'train_conv', 'split') == 'split':
+            plan.gemm_off = True
+            self._graphs.clear()
+            self._seen.clear()
+            plan.status.zero_()
+            return
+        raise L.YondHipError("TrainStep: a weight is NaN or beyond the split-operand kernels' range (|w| > 65504; |w| >= 32 in a 1x1 / "
+                             "transposed layer on the split GEMM): TrainStep(conv='fp32') keeps every convolution on the fp32-input MFMA")
+
     # -- loss, backward, Adam ----------------------------------------------------------------------------------------
     def _scale_for(self, n):
-        """The step's loss scale: the fixed one, or the automatic one -- S / n in (1/16, 1/8], lowered (and kept lower) whenever
+        """The step's loss scale: the fixed one, or the automatic one -- S / n in [1/8, 1/4), lowered (and kept lower) whenever
         a step overflowed, raised again by a factor of two after 500 clean steps (the usual dynamic loss scaling)."""
         if self.loss_scale is not None:
             return float(self.loss_scale)
@@ -855,8 +878,8 @@ class TrainStep:
         g.graph.replay()
         st = self.plan.status.cpu()                          # (the step's synchronisation point)
         if int(st[1]) & 1:
-            raise L.YondHipError("TrainStep: a weight left fp16's range (|w| > 65504): the split-operand kernels cannot take it "
-                                 "(TrainStep(conv='fp32') keeps every convolution on the fp32-input MFMA)")
+            self._weight_trip()                              # (raises unless the GEMM's narrower limit can be lifted)
+            return None                                      # the eager path redoes the step without the split-operand GEMMs
         if int(st[0]) & 1:
             return None
         loss = float(g.loss_sum.item()) / g.pred.numel()
@@ -884,7 +907,18 @@ class TrainStep:
                 out = self._graph_step(key, imgs_lr, imgs_hr, sigma, S)
                 if out is not None:
                     return out                               # (else: a range trip, nothing updated -- the eager path lowers the scale)
-        for attempt in range(3):
+        if self.reducer is not None:
+            skey = (tuple(imgs_hr.shape), S)
+            if skey not in self._scale_checked:                  # the ranks all-reduce S-scaled gradients: S must agree (see __init__)
+                import torch.distributed as dist
+                t = torch.tensor([S, -S], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                if float(t[0]) != S or float(t[1]) != -S:
+                    raise L.YondHipError(f"TrainStep: the ranks' loss scales differ (this rank {S:g}, maximum {float(t[0]):g}, minimum {-float(t[1]):g}): "
+                                         "give every rank the same local batch size or a fixed loss_scale")
+                self._scale_checked.add(skey)
+        attempt = 0
+        while True:
             pred, loss_sum = self._fwd_bwd(imgs_lr, imgs_hr, sigma, S)
             if self.reducer is not None:
                 # every rank must take the same branch below (a retry re-issues the gradient all-reduces): the ranks' words OR-ed
@@ -892,15 +926,18 @@ class TrainStep:
                 dist.all_reduce(self.plan.status, op=dist.ReduceOp.MAX)
             st = self.plan.status.cpu()                      # ONE read per step (it also is the step's synchronisation point)
             if int(st[1]) & 1:
-                raise L.YondHipError("TrainStep: a weight left fp16's range (|w| > 65504): the split-operand kernels cannot take it "
-                                     "(TrainStep(conv='fp32') keeps every convolution on the fp32-input MFMA)")
+                self._weight_trip()                          # (raises the second time: at most one such redo per plan)
+                if self.reducer is not None:
+                    self.reducer.finish()
+                continue                                     # redone without the split-operand GEMMs; nothing has been applied
             if not (int(st[0]) & 1):
                 break
             if attempt == 2 or S == 1.0 and self.loss_scale is not None:
-                raise L.YondHipError("TrainStep: an activation or gradient left fp16's range (|a| > 65504) in the split-operand "
-                                     f"convolutions (loss scale {S:g}); TrainStep(conv='fp32') has no such limit")
+                raise L.YondHipError("TrainStep: an activation or gradient is NaN or left fp16's range (|a| > 65504) in the split-operand "
+                                     f"kernels (loss scale {S:g}); TrainStep(conv='fp32') has no such limit")
             if self.reducer is not None:
                 self.reducer.finish()                        # (drain the all-reduces of the abandoned attempt)
+            attempt += 1
             S = max(S / 256.0, 1.0)                          # a gradient overflowed at this scale: redo the step lower
             if self.loss_scale is None:
                 self._auto_scale, self._clean_steps = S, 0   # ... and keep the lower scale for the steps that follow

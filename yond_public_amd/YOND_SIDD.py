@@ -49,6 +49,15 @@ class SyntheticSIDD:
         self.n, self.K, self.sigma, self.full_hw, self.distinct = n, K, sigma, full_hw, max(1, distinct)
         self._made = {}
 
+    def prepare(self, indices=None, workers=8):
+        """Synthesise the distinct items up front, in parallel -- the counterpart of SIDD_Dataset.__init__ reading the validation blocks
+        before the evaluation loop starts (data_process/yond_datasets.py:797-806); afterwards an item costs no host arithmetic."""
+        from concurrent.futures import ThreadPoolExecutor
+        need = sorted({k % self.distinct for k in (indices if indices is not None else range(self.n))} - set(self._made))
+        if need:
+            with ThreadPoolExecutor(max_workers=min(workers, len(need))) as ex:
+                list(ex.map(self.__getitem__, need))
+
     def __len__(self):
         return self.n
 
@@ -168,9 +177,12 @@ class YOND_SIDD:
         p['scale'] = (p['wp'] - p['bl']) / p['ratio']
         mine = D.shard_dataset(self.dst_eval, self.rank, self.world)        # size-aware (five phones, five frame sizes) where sizes are known
         self.metrics = {}
+        if hasattr(self.dst_eval, 'prepare'):
+            self.dst_eval.prepare(mine)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         t_path = 0.0
+        marks = []                                          # (wall clock, path seconds so far) behind every image: the steady state is the second half
         # the items are read and uploaded by loader threads ahead of the GPU (the reference reads each in front of its IterDenoise,
         # :507-514): file reads, the float32 conversion and the 64 MB upload of the full frame overlap the previous images' kernels
         from .data import Prefetcher
@@ -188,7 +200,8 @@ class YOND_SIDD:
                     ssims.append(float(np.mean(ss)))
                 sums.update(psnrs, ssims)        # iterations that did not run count -1 in their own meter (:644-647)
             torch.cuda.synchronize()
-            t_path += time.perf_counter() - t1              # estimate + denoise (+ metrics) of this image, uploads included
+            t_path += time.perf_counter() - t1              # estimate + denoise (+ metrics) of this image
+            marks.append((time.perf_counter(), t_path))
             self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
             log(f"[rank {self.rank}] {data['name']}: PSNR={psnrs[-1] if psnrs else float('nan'):.2f}, "
                 f"SSIM={ssims[-1] if ssims else float('nan'):.4f}", self.logfile)
@@ -205,6 +218,13 @@ class YOND_SIDD:
                 f"(rank 0: {dt / max(len(mine), 1) * 1e3:.1f} ms wall per image, {t_path / max(len(mine), 1) * 1e3:.1f} ms of it in IterDenoise + metrics; "
                 f"the rest is waiting for the {self.parser.loaders} loader threads)", self.logfile)
             self.last_timing = {'wall_ms_per_image': dt / max(len(mine), 1) * 1e3, 'path_ms_per_image': t_path / max(len(mine), 1) * 1e3}
+            if len(marks) >= 8:
+                h = len(marks) // 2                           # second half: lazily built plans / buffers and the loaders' start-up are behind us
+                wall2 = (marks[-1][0] - marks[h - 1][0]) / (len(marks) - h) * 1e3
+                path2 = (marks[-1][1] - marks[h - 1][1]) / (len(marks) - h) * 1e3
+                self.last_timing.update(steady_wall_ms_per_image=wall2, steady_path_ms_per_image=path2)
+                log(f"steady state (second half of rank 0's images): {wall2:.2f} ms wall per image, {path2:.2f} ms of it in IterDenoise + metrics "
+                    f"(x{wall2 / max(path2, 1e-9):.2f})", self.logfile)
             log(f"collectives: backend={D.STATS['backend']}, all_reduce={D.STATS['all_reduce']}, barrier={D.STATS['barrier']}", self.logfile)
         return red
 

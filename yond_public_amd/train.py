@@ -770,6 +770,21 @@ class TrainStep:
                     "yond_pack_conv_split_weights_batch_dev_f32")
         plan.wbatch = (self._wb_buf, self._wb_slots, self._pk_ids)
 
+    def _gemm_fallback(self):
+        """Move the plan's 1x1 / transposed layers from the split-operand GEMM back to the fp32-input MFMA path (which has no operand
+        range limit), once: True if that changed anything.  Called when a range trip survives every loss scale -- then it is a forward
+        activation, and the GEMM's x operand is the one such tensor no 3x3 kernel had looked at before."""
+        plan = self.plan
+        if not (GEMM_SPLIT and not getattr(plan, 'gemm_off', False) and getattr(plan, 'train_conv', 'split') == 'split'):
+            return False
+        import warnings
+        warnings.warn("TrainStep: a range trip at every loss scale: the split-operand GEMMs are switched off for this plan (fp32-input MFMA instead)")
+        plan.gemm_off = True
+        self._graphs.clear()
+        self._seen.clear()
+        plan.status.zero_()
+        return True
+
     def _weight_trip(self):
         """Status word 1: a weight beyond what a split-operand kernel can stage.  The 3x3 kernels and the weight packers take |w| <= 65504;
         the GEMM (1x1 / transposed layers, csrc/gemm_split.hip) stages 2^11 w and therefore needs |w| < 32 -- a limit the reference does
@@ -933,6 +948,13 @@ class TrainStep:
             if not (int(st[0]) & 1):
                 break
             if attempt == 2 or S == 1.0 and self.loss_scale is not None:
+                if self._gemm_fallback():
+                    # an x operand of a split GEMM (a 1x1 / transposed layer's input, e.g. the ConvTranspose output that only the 1x1
+                    # shortcut reads) is what cannot be lowered by the loss scale: those layers go back to the fp32-input MFMA
+                    if self.reducer is not None:
+                        self.reducer.finish()
+                    attempt = 0
+                    continue
                 raise L.YondHipError("TrainStep: an activation or gradient is NaN or left fp16's range (|a| > 65504) in the split-operand "
                                      f"kernels (loss scale {S:g}); TrainStep(conv='fp32') has no such limit")
             if self.reducer is not None:

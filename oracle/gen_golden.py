@@ -129,6 +129,7 @@ ARCHS = {
     "gru8": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
     "gru32_nonorm": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=False, norm=False),
     "snr32": dict(name='SNRnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+    "snr8": dict(name='SNRnet', guided=True, in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
     "unet32": dict(name='UNetSeeInDark', in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
     "unet8": dict(name='UNetSeeInDark', in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
 }
@@ -384,6 +385,30 @@ def gen_train(ref):
         out[f"u_w/{k}"] = grad_sample(k, p.detach().numpy())
     print(f"train step (UNetSeeInDark): loss {float(loss):.6f}")
     save("train", **out)
+
+
+def gen_train_snr(ref):
+    """N4 for the third sigma-conditioned net: ONE step of the reference's loop (trainer_AWGN.py:101-117) on SNRnet nf = 8 (archs/Unet.py:288-378,
+    SNR_Block archs/modules.py:198-233) with the inputs of train_case: loss, every gradient, the Adam-updated weights."""
+    from torch.optim import Adam
+    lr_img, hr_img, sigma, _, _, step = train_case()
+    arch = ARCHS["snr8"]
+    net = getattr(ref, arch['name'])(dict(arch))
+    net = ref.load_weights(net, O.procedural_state_dict(arch, 23), by_name=False).train()
+    opt = Adam(net.parameters(), lr=step)
+    opt.zero_grad()
+    pred = net(lr_img, sigma)
+    loss = ref.Unet_Loss()(pred, hr_img)
+    loss.backward()
+    out = {"loss": np.array(float(loss)), "pred_sample": grad_sample("pred", pred.detach().numpy())}
+    for k, p in net.named_parameters():
+        out[f"g_chk/{k}"] = checks(p.grad.detach().numpy())
+        out[f"g/{k}"] = grad_sample(k, p.grad.detach().numpy())
+    opt.step()
+    for k, p in net.named_parameters():
+        out[f"w/{k}"] = grad_sample(k, p.detach().numpy())
+    print(f"train step (SNRnet): loss {float(loss):.6f}, {sum(p.numel() for p in net.parameters())} parameters")
+    save("train_snr", **out)
 
 
 def train32_case():
@@ -792,7 +817,7 @@ def gen_full_cfg5(ref):
 GENS = dict(rot=gen_rot, pack=gen_pack, vst=gen_vst, bias=gen_bias, nle=gen_nle, net=gen_net,
             vst_denoiser=gen_vst_denoiser, iter=gen_iter, biaslut=gen_biaslut, ssim=gen_ssim, nle_full=gen_nle_full,
             iter_full=gen_iter_full, train=gen_train, train_sched=gen_train_sched, train32=gen_train32,
-            full_cfg2=gen_full_cfg2, full_cfg4=gen_full_cfg4, full_cfg5=gen_full_cfg5)
+            full_cfg2=gen_full_cfg2, full_cfg4=gen_full_cfg4, full_cfg5=gen_full_cfg5, train_snr=gen_train_snr)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -15,6 +15,7 @@ ARCHS = {
     "gru8": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
     "gru32_nonorm": dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=False, norm=False),
     "snr32": dict(name='SNRnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
+    "snr8": dict(name='SNRnet', guided=True, in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
     "unet32": dict(name='UNetSeeInDark', in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True),
     "unet8": dict(name='UNetSeeInDark', in_nc=4, out_nc=4, nf=8, nframes=1, res=True, norm=True),
 }

@@ -654,6 +654,30 @@ class TrainStep:
         # z = conv2(z) + x with the residual in the convolution's epilogue (archs/modules.py:194-195)
         return _Conv3x3.apply(z, P[pre + '.conv2.weight'], P[pre + '.conv2.bias'], self.plan, 1, True, xr)
 
+    def _block_snr(self, pre, x, xs, t, cp):
+        """SNR_Block (archs/modules.py:198-233): z = conv2(SiLU(conv1(SiLU(x)) * a1)) * a2 + x with two multiplicative gates
+        a = sfm(t) = W2 . SiLU(W1 t + b1) + b2 (1x1 convolutions on a (B, 1, 1, 1) tensor: tiny linear layers, autograd's own).  The 3x3
+        convolutions and the SiLU-with-scale kernel are the guided block's; the second gate and the residual are elementwise glue."""
+        P = self.params
+        if xs is not None:
+            x = _Conv1x1.apply(x, xs, P[pre + '.short_cut.0.weight'], P[pre + '.short_cut.0.bias'], self.plan)
+        c = P[pre + '.conv1.weight'].shape[0]
+
+        def gate(name):
+            w1, b1 = P[f'{pre}.{name}.0.weight'].reshape(c), P[f'{pre}.{name}.0.bias']
+            w2, b2 = P[f'{pre}.{name}.2.weight'].reshape(c, c), P[f'{pre}.{name}.2.bias']
+            a = F.linear(F.silu(t[:, None] * w1[None, :] + b1[None, :]), w2, b2)          # [B][c]
+            return _pad_c(a, cp) if cp != c else a
+        a1, a2 = gate('sfm1'), gate('sfm2')
+        z, xr = _SiluRes.apply(x, self.plan)
+        z = _Conv3x3.apply(z, P[pre + '.conv1.weight'], P[pre + '.conv1.bias'], self.plan, 1, True)
+        if self.plan.lib.yond_film_silu_supported(cp):
+            z = _FilmSilu.apply(z, a1, torch.zeros_like(a1), self.plan)
+        else:
+            z = F.silu(z * a1[:, None, None, :])
+        z = _Conv3x3.apply(z, P[pre + '.conv2.weight'], P[pre + '.conv2.bias'], self.plan, 1, True)
+        return z * a2[:, None, None, :] + xr
+
     def _forward_unet(self, x_nchw):
         """UNetSeeInDark (archs/Unet.py:55-104): conv -> LeakyReLU(0.2) pairs, 2x2 max pooling, ConvTranspose2d + cat + conv; the
         pooling and the activations are autograd's elementwise glue, every convolution runs on the HIP kernels."""
@@ -691,8 +715,10 @@ class TrainStep:
         m, P = self.m, self.params
         if type(m).__name__ == 'UNetSeeInDark':
             return self._forward_unet(x_nchw)
-        if type(m).__name__ != 'GuidedResUnet':
-            raise NotImplementedError(f"TrainStep: {type(m).__name__} (GuidedResUnet and UNetSeeInDark are the nets the reference trains)")
+        snr = type(m).__name__ == 'SNRnet'                   # the same skeleton with SNR_Blocks (archs/Unet.py:288-378)
+        if type(m).__name__ != 'GuidedResUnet' and not snr:
+            raise NotImplementedError(f"TrainStep: {type(m).__name__} (GuidedResUnet, SNRnet and UNetSeeInDark are built)")
+        block = self._block_snr if snr else self._block
         x = x_nchw.permute(0, 2, 3, 1).contiguous()
         B = x.shape[0]
         t = sigma.reshape(B).to(torch.float32)
@@ -702,7 +728,7 @@ class TrainStep:
             x = x / ub[:, None, None, None]
             t = t / ub
         nf = P['conv_in.weight'].shape[0]
-        if FILM_ALL and self.reducer is None:                # the sigma-MLPs of all nine blocks up front (they depend on t only); not under DDP:
+        if FILM_ALL and self.reducer is None and not snr:    # the sigma-MLPs of all nine blocks up front (they depend on t only); not under DDP:
                                                              # their gradients would all land last and hold back every bucket's all-reduce
             pres = [f'conv{i}' for i in range(1, 10)]
             cps = [_rup(nf * 2 ** (min(i, 10 - i) - 1)) for i in range(1, 10)]
@@ -715,13 +741,13 @@ class TrainStep:
         skips = {}
         for i in range(1, 5):
             cp = _rup(nf * 2 ** (i - 1))
-            cur = self._block(f'conv{i}', cur, None, t, cp)
+            cur = block(f'conv{i}', cur, None, t, cp)
             skips[i] = cur
             cur = _Conv3x3.apply(cur, P[f'pool{i}.conv.weight'], P[f'pool{i}.conv.bias'], self.plan, 2, True)
-        cur = self._block('conv5', cur, None, t, _rup(nf * 16))
+        cur = block('conv5', cur, None, t, _rup(nf * 16))
         for i in range(6, 10):
             up = _ConvT2x2.apply(cur, P[f'upv{i}.weight'], P[f'upv{i}.bias'], self.plan)
-            cur = self._block(f'conv{i}', up, skips[10 - i], t, _rup(nf * 2 ** (9 - i)))
+            cur = block(f'conv{i}', up, skips[10 - i], t, _rup(nf * 2 ** (9 - i)))
         out = _Conv1x1.apply(cur, None, P['conv10.weight'], P['conv10.bias'], self.plan)[..., :4]
         if m.res:
             out = out + x[..., :4]

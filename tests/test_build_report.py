@@ -35,4 +35,4 @@ def test_flow_kernels_do_not_spill():
     assert len(wg) >= 10 and not [r for r in wg if r.get("vgpr_spill", 0) or r.get("scratch", 0)], wg
     # the [N][H][W][C]-path instantiations (training forward / data gradients, UNetSeeInDark's unfused layers) keep a few spilled
     # registers (prologue stores + reloads at the tile's end): bounded here so that a regression shows
-    assert max(r.get("vgpr_spill", 0) for r in other) <= 32, [r for r in other if r.get("vgpr_spill", 0) > 32]
+    assert max(r.get("vgpr_spill", 0) for r in other) <= 24, [r for r in other if r.get("vgpr_spill", 0) > 24]

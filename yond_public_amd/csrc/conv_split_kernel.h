@@ -252,9 +252,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 }
             }
         } else {
+        // ([N][H][W][C]-path instantiations -- training, UNetSeeInDark, the unfused first / last layers: the per-item pixel geometry is a
+        // loop invariant that the compiler hoists out of the tile loop and then SPILLS (8-31 registers, reloaded at every tile); formed
+        // from an opaque copy of the thread index it is recomputed per tile instead: a few integer operations per item)
+        int tid_g = tid;
+        if constexpr (ISPM == 0 && !OSP && !K1) asm volatile("" : "+v"(tid_g));
 #pragma unroll
         for (int k = 0; k < KD; ++k) {
-            const int it = tid + k * C::NT;
+            const int it = tid_g + k * C::NT;
             const int pix = (it % C::PIX_ITEMS) / 4;
             const int py = pix / C::IW, px = pix % C::IW;
             const int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;

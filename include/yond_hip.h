@@ -235,7 +235,7 @@ int yond_pack_conv_wino_weight_f32(const float* w, int cout, int cin, int tn, fl
  * l = fp16((a - h) * 2^11); a*w = h_a h_w + 2^-11 (h_a l_w + l_a h_w) on v_mfma_f32_32x32x16_f16 with fp32
  * accumulation -- 22-23 significant bits per operand, error vs a float64 convolution no larger than the fp32 kernels'.
  * Precondition: |activations|, |weights| <= 65504 -- enforced: the packing functions return YOND_EUNSUPPORTED for a weight
- * outside that range and the kernels report an activation outside it through YondConvDesc.status.  yond_conv_split_supported: channel-tile width (64, 32) or 0.
+ * outside that range and the kernels report an activation outside it through YondConvDesc.status.  yond_conv_split_supported: channel-tile width (64, 32) or 0; h-only weights (parts = 1) of a 3x3 stride-1 layer whose output channels divide by 128 may also be packed for tn = 128 (YondConvDesc.tn = 128, algo 4, plain tensors).
  * Weights: w OIHW [cout][cin][3][3] -> dst, cout*cin*9*parts/2 floats (packed halves).
  * ksize 1 (descriptor: ksize 1, shuffle 1, algo 3): the decoder's pixel-shuffle GEMM -- ConvTranspose2d 2x2 (src0, C0, low
  * resolution) + the skip tensor (src1, C1, at the OUTPUT resolution) + 1x1 shortcut folded into one weight matrix

@@ -444,6 +444,36 @@ def test_conv3x3_half_staged_path():
     assert report("half-staged conv3x3", got, ref) < 5e-3
 
 
+@pytest.mark.parametrize("C,Co,N,H,W", [(128, 128, 1, 400, 230), (64, 256, 2, 37, 70), (256, 128, 1, 24, 64), (128, 384, 1, 13, 33)])
+def test_conv3x3_half_128_channel_tiles(C, Co, N, H, W):
+    """algo 4 with 128-channel tiles (h-only operands leave one accumulator per block: a wave owns TWO 32-channel blocks; the fp16 path's
+    layers with >= 128 output channels, engine.HALF_TN128): both tile heights (12-row tiles from 256 tiles on, else 8-row), SiLU staging,
+    FiLM + residual epilogue, ragged edges, batch -- equal to the 64-channel-tile form of the same arithmetic to accumulation order, and
+    at fp16 level from float64."""
+    from yond_public_amd import engine as E
+    g = torch.Generator().manual_seed(C + Co + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(Co, generator=g)
+    es, et = torch.randn(N, Co, generator=g).to(DEV), torch.randn(N, Co, generator=g).to(DEV)
+    r = torch.randn(N, H, W, Co, generator=g).to(DEV)
+    xd = nhwc(x).to(DEV)
+    out = {}
+    for flag in (True, False):
+        E.HALF_TN128 = flag
+        try:
+            out[flag] = (run_conv(w, b, 3, 1, [C], [xd], N, H, W, algo='half'),
+                         run_conv(w, None, 3, 1, [C], [xd], N, H, W, algo='half', pre_act=1, escale=es, eshift=et, ebatch=1, res=r))
+        finally:
+            E.HALF_TN128 = True
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref2 = F.conv2d(F.silu(x.double()), w.double(), padding=1) * es.cpu().double()[:, :, None, None] + et.cpu().double()[:, :, None, None] + nchw(r.cpu()).double()
+    assert report(f"half conv3x3, 128-channel tiles C{C}->{Co} {H}x{W} vs 64-channel tiles", out[True][0], out[False][0]) <= 2e-5 * float(ref.abs().max())
+    assert report(f"half conv3x3, 128-channel tiles, SiLU + FiLM + residual vs 64-channel tiles", out[True][1], out[False][1]) <= 2e-5 * float(ref2.abs().max())
+    assert report(f"half conv3x3, 128-channel tiles vs float64", nchw(out[True][0]), ref) < 5e-3 * max(1.0, float(ref.abs().max()))
+    assert report(f"half conv3x3, 128-channel tiles, fused vs float64", nchw(out[True][1]), ref2) < 5e-3 * max(1.0, float(ref2.abs().max()))
+
+
 @pytest.mark.parametrize("ks,st,C,Co", [(3, 1, 64, 64), (3, 1, 32, 32), (3, 2, 32, 64), (1, 1, 64, 32)])
 def test_conv_fp16_mfma_path(ks, st, C, Co):
     """algo 'fp16' (descriptor algo 2, BASELINE cfg 5): operands rounded to half at the matrix core, fp32 accumulate.

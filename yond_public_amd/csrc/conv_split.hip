@@ -6,6 +6,8 @@ SPLIT_GROUP_K1S2(SPLIT_EXTERN)
 SPLIT_GROUP_S1_64(SPLIT_EXTERN)
 SPLIT_GROUP_S1_32(SPLIT_EXTERN)
 SPLIT_GROUP_HALF(SPLIT_EXTERN)
+SPLIT_GROUP_HALF128(SPLIT_EXTERN)
+SPLIT_GROUP_HALF_TALL(SPLIT_EXTERN)
 SPLIT_GROUP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP_OSP(SPLIT_EXTERN)
@@ -32,7 +34,7 @@ extern "C" int yond_conv_split_supported(int ksize, int stride, int cin, int cou
 // ksize 1 (w = the re-indexed [4*cout][cin][1][1] matrix of a transposed convolution): [cout tile][step of 48 channels]
 // [chunk of 16][channel half][part][tn][8 halves].
 extern "C" int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst) {
-    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
+    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && parts == 1 && ksize == 3)) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
     _Float16* o = (_Float16*)dst;
     for (size_t i = 0, n = (size_t)cout * cin * ksize * ksize; i < n; ++i)
         if (!(fabsf(w[i]) <= 65504.0f)) return YOND_EUNSUPPORTED;          // its h half would be +-inf
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void pack_split_weight_kernel(const float* __r
 
 extern "C" int yond_pack_conv_split_weight_dev_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst, int* status,
                                                    void* stream) {
-    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
+    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && parts == 1 && ksize == 3)) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
     if (ksize == 1 && cin % 48 != 0) return YOND_EINVAL;
     const int taps = ksize * ksize;
     const size_t ngroups = (size_t)cout * cin * taps * parts / 8;
@@ -171,7 +173,10 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     }
     const int tn = yond_conv_split_supported(d.ksize, d.stride, d.C0 + d.C1, d.Cout);
     if (!tn || d.C0 % 16 != 0 || d.C1 % 16 != 0 || (d.shuffle != 0) != (d.ksize == 1)) return YOND_EUNSUPPORTED;
-    if (d.tn != tn) return YOND_EINVAL;                         // the layout the weights were packed for
+    // h-only operands (algo 4) may be packed for 128-channel tiles: 3x3 stride-1 layers with plain tensors (conv_split_kernel.h, HALF128)
+    const bool half128 = parts == 1 && d.tn == 128 && tn == 64 && d.ksize == 3 && d.stride == 1 && d.Cout % 128 == 0 && !d.in_fmt && !d.out_fmt &&
+                         !d.res_fmt && !d.out4_dst && !d.dst2;
+    if (d.tn != tn && !half128) return YOND_EINVAL;             // the layout the weights were packed for
     if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
     // tensor formats (include/yond_hip.h): split planes in (LDS-DMA staging) / out (stored from the accumulator layout), planes
     // of 4 channels for the float32 tensors that are read as residuals
@@ -247,6 +252,14 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         if (d.out4_dst) return launch_split<1, 16, 32, 2, 2, 3, false, true, false, true>(d, st);
         return launch_split<1, 16, 32, 2, 2, 3, false, false, false, true>(d, st);
     }
+    if (half128) {
+        if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
+        long long t12 = (long long)(d.Cout / 128) * ((d.Wo + 31) / 32) * ((d.Ho + 11) / 12) * d.N;
+        const long long t8 = (long long)(d.Cout / 128) * ((d.Wo + 31) / 32) * ((d.Ho + 7) / 8) * d.N;
+        if (8000 * ((t8 + 255) / 256) < 10044 * ((t12 + 255) / 256)) t12 = 0;
+        if (t12 >= 256) return d.pre_act ? launch_split<1, 12, 128, 3, 1, 2, true>(d, st) : launch_split<1, 12, 128, 3, 1, 2, false>(d, st);
+        return d.pre_act ? launch_split<1, 8, 128, 2, 1, 3, true>(d, st) : launch_split<1, 8, 128, 2, 1, 3, false>(d, st);
+    }
     if (tn == 64) {
         // 12 x 32-pixel tiles, three rows per wave: 0.59 instead of 0.78 KiB of LDS fragments per MFMA, 1.5x the MFMA work per
         // step (and per barrier), and 94 / 188 / 376 / 752 rows fill 256 workgroups in whole rounds (1 / 2 / 4 / 8)
@@ -258,5 +271,8 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (parts == 2 && d.out4_dst)      // the last convolution of the network with the 1x1 output projection in its epilogue
         return d.pre_act ? launch_split<1, 16, 32, 2, 2, 3, true, true>(d, st) : launch_split<1, 16, 32, 2, 2, 3, false, true>(d, st);
     if (parts == 2) return d.pre_act ? launch_split<1, 16, 32, 2, 2, 3, true>(d, st) : launch_split<1, 16, 32, 2, 2, 3, false>(d, st);
+    // h only, 32 channels: 32-row tiles where they fill the 256 persistent workgroups
+    if ((long long)((d.Wo + 31) / 32) * ((d.Ho + 31) / 32) * d.N >= 256)
+        return d.pre_act ? launch_split<1, 32, 32, 4, 1, 2, true>(d, st) : launch_split<1, 32, 32, 4, 1, 2, false>(d, st);
     return d.pre_act ? launch_split<1, 16, 32, 2, 1, 3, true>(d, st) : launch_split<1, 16, 32, 2, 1, 3, false>(d, st);
 }

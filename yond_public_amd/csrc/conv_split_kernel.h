@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // two-buffer rotation finds slice s % 2 in buffer s % 2 for ever -- after the first step no weight DMA is issued at all (they
     // were a third of the bytes such a layer's steps fetch into LDS).
     // (not where the transposed epilogue uses the consumed weight buffer as its scratch: 64-wide stride-1 tiles storing [N][H][W][C])
-    constexpr bool W_IS_SCRATCH = TN == 64 && !K1 && STRIDE == 1 && !OSP;
+    constexpr bool W_IS_SCRATCH = TN >= 64 && !K1 && STRIDE == 1 && !OSP;
     const bool wres = NWB == 2 && !W_IS_SCRATCH && nchunk == 2 && nct == 1;
     bool wskip = false;                                      // true once both slices have been fetched (uniform)
     auto issue_dma = [&](auto kc, const float* wsrc, float* wbuf) {
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     constexpr int EPS = 36;                                   // floats per pixel of the scratch
     constexpr int EP_FLOATS = 8 * 32 * EPS;                   // 36,864 bytes: one weight buffer (TN 64) or part of an input image
     // (stride 2: short steps, no residual -- measured slower with the transpose and its extra barrier: 211 vs 175 us at level 0)
-    constexpr bool EP_IN_W = TN == 64 && !K1;                 // scratch = the weight buffer just consumed; else the input image
+    constexpr bool EP_IN_W = TN >= 64 && !K1;                 // scratch = the weight buffer just consumed; else the input image
     constexpr bool EP_FIT = STRIDE == 1 && EP_FLOATS <= (EP_IN_W ? C::W_FLOATS : C::IN_FLOATS);
     // Straight-line on purpose: a branch around a load (`res ? load : 0`) makes the compiler lose count of the outstanding
     // memory operations and wait with vmcnt(0) before EVERY store -- i.e. for the previous store (measured: 3.4-4.9
@@ -1185,6 +1185,18 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 #define SPLIT_GROUP_HALF(X)                                                                             \
     X(1, 8, 64, 2, 1, 3, true, false, false, false, false) X(1, 8, 64, 2, 1, 3, false, false, false, false, false) \
     X(1, 16, 32, 2, 1, 3, true, false, false, false, false) X(1, 16, 32, 2, 1, 3, false, false, false, false, false)
+// h-only operands (the fp16 path, BASELINE cfg 5) leave ONE accumulator per block: a wave can own two 32-channel blocks in the registers
+// the split form spends on its second accumulator -- 128-channel tiles: every pixel fragment read from LDS serves two blocks, twice the
+// MFMAs per staged input, per weight DMA and per barrier
+#define SPLIT_GROUP_HALF128(X)                                                                          \
+    X(1, 12, 128, 3, 1, 2, true, false, false, false, false) X(1, 12, 128, 3, 1, 2, false, false, false, false, false) \
+    X(1, 8, 128, 2, 1, 3, true, false, false, false, false) X(1, 8, 128, 2, 1, 3, false, false, false, false, false)
+// ... and, for the 32-channel layers, 32-row tiles (four rows per wave; the input image of this shape is also the first of the h-only path
+// large enough to serve as the transposed epilogue's scratch -- the 16-row form stores from the accumulator layout, 32 cache lines per
+// instruction).  (12 rows x 64 channels with h-only operands compiles to 704 bytes of scratch per lane and runs 13x slower than the
+// 8-row form: not instantiated.)
+#define SPLIT_GROUP_HALF_TALL(X)                                                                        \
+    X(1, 32, 32, 4, 1, 2, true, false, false, false, false) X(1, 32, 32, 4, 1, 2, false, false, false, false, false)
 #define SPLIT_GROUP_OSP(X)                                                                              \
     X(1, 12, 64, 3, 2, 2, true, false, false, false, true) X(1, 12, 64, 3, 2, 2, false, false, false, false, true) \
     X(1, 8, 64, 2, 2, 3, true, false, false, false, true) X(1, 8, 64, 2, 2, 3, false, false, false, false, true) \

@@ -44,6 +44,7 @@ WINO_DEFAULT = 'split'              # 'split': fp32-accurate split-operand fp16-
 # (Module attribute, not an environment switch: tools/ flip it for A/B runs.)
 SPLIT_PLANES = True
 SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
+HALF_TN128 = True                   # fp16 path (precision='fp16', BASELINE cfg 5): 128-channel tiles for the 3x3 stride-1 layers with >= 128 output channels
 FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
 FUSE_BLOCK0 = False                 # the two level-0 residual blocks as ONE launch each (csrc/block0_fused.hip: the tensor between the convolutions stays in
                                     # LDS).  Built, parity-tested, measured (round 5): 1.16 GB less HBM traffic per block and +1.0 % per forward -- level 0 is
@@ -150,6 +151,8 @@ class _PackedConv:
         tn = int(lib.yond_conv_split_supported(self.ksize, self.stride, self.cinp, self.gemm_n))
         if not tn:
             return None
+        if parts == 1 and HALF_TN128 and tn == 64 and self.ksize == 3 and self.stride == 1 and self.gemm_n % 128 == 0:
+            tn = 128                        # h-only operands: one accumulator per block leaves room for two blocks per wave (conv_split_kernel.h)
         key = ('split', parts)
         if key not in self._packed:
             packed = np.empty(self._wp.size * parts // 2, np.float32)

@@ -266,6 +266,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         const bool th12 = tiles12 >= 256;
         if (parts == 2 && th12) return d.pre_act ? launch_split<1, 12, 64, 3, 2, 2, true>(d, st) : launch_split<1, 12, 64, 3, 2, 2, false>(d, st);
         if (parts == 2) return d.pre_act ? launch_split<1, 8, 64, 2, 2, 3, true>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false>(d, st);
+        if (th12) return d.pre_act ? launch_split<1, 12, 64, 3, 1, 2, true>(d, st) : launch_split<1, 12, 64, 3, 1, 2, false>(d, st);
         return d.pre_act ? launch_split<1, 8, 64, 2, 1, 3, true>(d, st) : launch_split<1, 8, 64, 2, 1, 3, false>(d, st);
     }
     if (parts == 2 && d.out4_dst)      // the last convolution of the network with the 1x1 output projection in its epilogue

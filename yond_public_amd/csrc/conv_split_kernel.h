@@ -874,7 +874,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
 
     // (plain form, lane = pixel: kept for the shapes whose free buffer is smaller than the scratch -- the h-only fp16 path)
-    auto epilogue_direct = [&](const Tile& T) {
+    auto epilogue_direct = [&](const Tile& T) __attribute__((always_inline)) {      // (left to the inliner, the two call sites of a two-set kernel became real calls in one instantiation: the descriptor went to scratch memory, 13x slower)
         // lane = pixel: NHWC stores from here touch 32 lines with 32 bytes each; into PLANES OF 4 CHANNELS (out_fmt 2) the 32
         // pixels of a fragment are 512 contiguous bytes (K1: every other 16-byte unit of the pixel-shuffled row)
         const int ox = T.ox0 + li;
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // awaits weights(s+1) only -- vmcnt counts in order: loads(s-1), DMA(s-1), loads(s), DMA(s): the last two stay in
     // flight.  Loads before DMA because the compiler (which does not see the DMA) makes the next step wait for every
     // outstanding operation before it touches the staged set: the youngest are then L2-resident weight slices.
-    auto step = [&](auto sc) -> bool {
+    auto step = [&](auto sc) __attribute__((always_inline)) -> bool {
         constexpr int S = decltype(sc)::value;
         SDBG(0);
         const bool last_ch = (cs.ch + 1 == nchunk);
@@ -1191,11 +1191,11 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 #define SPLIT_GROUP_HALF128(X)                                                                          \
     X(1, 12, 128, 3, 1, 2, true, false, false, false, false) X(1, 12, 128, 3, 1, 2, false, false, false, false, false) \
     X(1, 8, 128, 2, 1, 3, true, false, false, false, false) X(1, 8, 128, 2, 1, 3, false, false, false, false, false)
-// ... and, for the 32-channel layers, 32-row tiles (four rows per wave; the input image of this shape is also the first of the h-only path
-// large enough to serve as the transposed epilogue's scratch -- the 16-row form stores from the accumulator layout, 32 cache lines per
-// instruction).  (12 rows x 64 channels with h-only operands compiles to 704 bytes of scratch per lane and runs 13x slower than the
-// 8-row form: not instantiated.)
+// ... and, for the layers with 64 / 32 output channels, taller tiles than the split form's registers allow: 12 rows x 64 channels (three
+// rows per wave) and 32 rows x 32 channels (four rows per wave; its input image is also the first of this path large enough to serve as
+// the transposed epilogue's scratch -- the 16-row form stores from the accumulator layout, 32 cache lines per instruction)
 #define SPLIT_GROUP_HALF_TALL(X)                                                                        \
+    X(1, 12, 64, 3, 1, 2, true, false, false, false, false) X(1, 12, 64, 3, 1, 2, false, false, false, false, false) \
     X(1, 32, 32, 4, 1, 2, true, false, false, false, false) X(1, 32, 32, 4, 1, 2, false, false, false, false, false)
 #define SPLIT_GROUP_OSP(X)                                                                              \
     X(1, 12, 64, 3, 2, 2, true, false, false, false, true) X(1, 12, 64, 3, 2, 2, false, false, false, false, true) \

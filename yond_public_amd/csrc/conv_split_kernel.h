@@ -92,7 +92,12 @@ struct SplitCfg {
     static constexpr int W4_OFF = 2 * IN_FLOATS + NWB * W_FLOATS;   // floats: 4 x 32 weights of the fused output projection
     static constexpr int FILM_OFF = W4_OFF + (TN == 32 ? 128 : 0);  // floats: per wave and 32-channel block {scale[32], shift[32]} (split-plane epilogue)
     static constexpr int FILM_FLOATS = 8 * NW * 64;
-    static constexpr int SMEM_BYTES = (FILM_OFF + FILM_FLOATS) * 4;  // (W4: the O4 instantiation only; FILM: the split-plane epilogue only)
+    // h-only operands (PARTS 1) leave the transposed epilogue no consumed buffer large enough for its scratch (8 waves x 32 pixels x 36 floats):
+    // their kernels use little LDS, so the scratch gets a region of its own behind everything else
+    static constexpr int EP_FLOATS_C = 8 * 32 * 36;
+    static constexpr bool EP_OWN = PARTS == 1 && STRIDE == 1 && !K1 && EP_FLOATS_C > (TN >= 64 ? W_FLOATS : IN_FLOATS);
+    static constexpr int EP_OFF = FILM_OFF + FILM_FLOATS;
+    static constexpr int SMEM_BYTES = (EP_OFF + (EP_OWN ? EP_FLOATS_C : 0)) * 4;  // (W4: the O4 instantiation only; FILM: the split-plane epilogue only)
     // input in SPLIT PLANES (YondConvDesc.in_fmt 1): a step's 2 x PARTS x NPT planes arrive by LDS-DMA alone, one 16-byte unit
     // per lane, a wave-instruction per 64 consecutive units of a plane's LDS image
     static constexpr int UPP = IH * TWP;                            // units of a plane's LDS image
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     constexpr int EP_FLOATS = 8 * 32 * EPS;                   // 36,864 bytes: one weight buffer (TN 64) or part of an input image
     // (stride 2: short steps, no residual -- measured slower with the transpose and its extra barrier: 211 vs 175 us at level 0)
     constexpr bool EP_IN_W = TN >= 64 && !K1;                 // scratch = the weight buffer just consumed; else the input image
-    constexpr bool EP_FIT = STRIDE == 1 && EP_FLOATS <= (EP_IN_W ? C::W_FLOATS : C::IN_FLOATS);
+    constexpr bool EP_FIT = STRIDE == 1 && (C::EP_OWN || EP_FLOATS <= (EP_IN_W ? C::W_FLOATS : C::IN_FLOATS));
     // Straight-line on purpose: a branch around a load (`res ? load : 0`) makes the compiler lose count of the outstanding
     // memory operations and wait with vmcnt(0) before EVERY store -- i.e. for the previous store (measured: 3.4-4.9
     // thousand cycles per tile).  So the variant (residual / scale / shift present) is chosen by ONE uniform switch
@@ -1093,7 +1098,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 } else if (K1 && d.out_fmt == YOND_FMT_PLANES4) {
                     epilogue_direct(cur);                          // (planes of 4 channels: stored from the accumulator layout)
                 } else if constexpr (EP_FIT) {
-                    float* scr = EP_IN_W ? w0 : ibuf;
+                    float* scr = C::EP_OWN ? smem + C::EP_OFF : (EP_IN_W ? w0 : ibuf);
                     const int flags = (d.res ? 1 : 0) | (d.escale ? 2 : 0) | (d.eshift ? 4 : 0);
                     // straight-line variants for what the networks launch: conv2 of a residual block (FiLM + residual), conv1
                     // with its SiLU, a plain layer with bias (+ LeakyReLU); every other combination: generic

@@ -1169,7 +1169,8 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
     }
     const long long total = (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
     if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
-    const int grid = total < 256 ? (int)total : 256;            // one persistent workgroup per CU
+    const int gmax = (int)yond_exp_long("YOND_SPLIT_GRID", 256);  // (experiment builds: fewer workgroups than CUs, leaving CUs to a side stream's kernels)
+    const int grid = total < gmax ? (int)total : gmax;            // one persistent workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::SMEM_BYTES, st, d);
     YOND_LAUNCH_CHECK();
     return YOND_OK;

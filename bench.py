@@ -573,6 +573,10 @@ def main(argv=None):
             roof["algorithm"] = ("direct 3x3, fp32 operands split into two fp16 halves when staged into LDS (22-23 significant "
                                  "bits), 3 v_mfma_f32_32x32x16_f16 per fp32 product block, fp32 accumulate")
             roof["mfma_issued_tflops"] = round(3.0 * ach, 2)
+            # what the chip can ISSUE of this pattern at all: a bare loop of the three MFMAs and their LDS fragment reads (no global memory,
+            # no barriers, random data, full occupancy) reaches 0.60 of the peak and drops the clock to 1.69 GHz doing it (power cap)
+            roof["bare_loop_ceiling"] = {"issued_frac": 0.60, "algorithmic_frac": 0.20, "in_kernel_mhz": 1690,
+                                         "source": "tools/probe/mfma_shape_probe.hip, profiles/r05_experiments/mfma_shape_probe.txt"}
             roof["mfma_issued_frac"] = round(3.0 * ach / PEAK_F16_MFMA_TFLOPS, 4)
         others = {t: {"launches": v[0], "avg_launch_ms": round(v[1] / v[0], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
                   for t, v in per.items() if t != dom and is33(t)}

@@ -363,3 +363,28 @@ def test_yond_sidd_benchmark_mode(tmp_path, monkeypatch):
     last = np.load(tmp_path / "npy" / "YOND_SIDD_simple+full_pre_grumix_iter" / "benchmark_results.npy")
     assert init.shape == last.shape == (2, 32, 256, 256)
     assert np.isfinite(last).all() and float(np.abs(last - init).max()) > 0          # round 2 ran and changed the result
+
+
+def test_prefetcher_uploads_through_pinned_buffers_in_order():
+    """data.Prefetcher on the GPU box: items read by loader threads, copied into reused pinned buffers and uploaded on the workers' own streams; the
+    consumer's stream waits on each copy's event -- values, order and device placement are checked while the consumer keeps the GPU busy, with
+    more items than pinned buffers per worker (each buffer is reused only after its previous upload has left it)."""
+    import numpy as np
+    from yond_public_amd.data import Prefetcher
+
+    class Items:
+        def __len__(self):
+            return 24
+
+        def __getitem__(self, k):
+            rng = np.random.default_rng(k)
+            return {'lr': rng.random((32, 64, 64), dtype=np.float32), 'hr': np.full((5, 7), k, np.uint16), 'lr_full': None, 'name': f'i{k}', 'k': k}
+    busy = torch.zeros(1 << 24, device='cuda:0')
+    seen = []
+    for k, d in Prefetcher(Items(), list(range(24)), 'cuda:0', workers=3, depth=5):
+        busy.add_(1.0)                                                     # (work on the consumer's stream between the items)
+        assert d['lr'].is_cuda and d['lr'].dtype == torch.float32 and d['hr'].is_cuda and d['lr_full'] is None and d['k'] == k
+        want = np.random.default_rng(k).random((32, 64, 64), dtype=np.float32)
+        assert np.array_equal(d['lr'].cpu().numpy(), want) and float(d['hr'].max()) == k and float(d['hr'].min()) == k
+        seen.append(k)
+    assert seen == list(range(24)) and float(busy[0]) == 24.0

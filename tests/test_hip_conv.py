@@ -207,7 +207,7 @@ def sp_decode(sp, N, C, H, W):
 
 
 @pytest.mark.parametrize("C,N,H,W,out4", [(64, 2, 40, 70, False), (128, 1, 380, 100, False), (32, 2, 50, 75, False), (32, 1, 37, 70, True),
-                                          (256, 1, 30, 61, False)])
+                                          (256, 1, 30, 61, False), (64, 5, 16, 16, False), (128, 3, 8, 8, False), (64, 3, 13, 11, False), (64, 7, 6, 5, False)])
 def test_conv3x3_split_planes_pair(C, N, H, W, out4):
     """The block-internal tensor of a residual block in SPLIT PLANES: conv1 stores SiLU(FiLM(conv1)) as the (h, l) halves its
     consumer would stage (out_fmt 1), conv2 stages them by LDS-DMA alone (in_fmt 1).  The pair must equal the float32-NHWC
@@ -304,7 +304,9 @@ def bare_plan():
     return plan
 
 
-@pytest.mark.parametrize("C,N,H,W", [(64, 2, 40, 70), (128, 1, 380, 100), (32, 2, 50, 75)])
+@pytest.mark.parametrize("C,N,H,W", [(64, 2, 40, 70), (128, 1, 380, 100), (32, 2, 50, 75),
+                                     # images at most 16 pixels wide: folded tiles (two 16-column sub-tiles per MFMA row, of one image or of two)
+                                     (64, 5, 16, 16), (128, 3, 8, 8), (256, 8, 16, 16), (64, 3, 24, 16), (64, 1, 13, 11), (128, 1, 8, 16), (512, 7, 8, 8), (64, 2, 5, 6)])
 def test_conv3x3_split_plane_flow_block(C, N, H, W):
     """The residual block in the formats of the default data flow: x in planes of 4 channels (conv1's staged input, conv2's
     residual), tmp and out in split planes.  Every tensor must hold exactly what the [N][H][W][C] float32 path computes: tmp and

@@ -8,6 +8,7 @@ SPLIT_GROUP_S1_32(SPLIT_EXTERN)
 SPLIT_GROUP_HALF(SPLIT_EXTERN)
 SPLIT_GROUP_HALF128(SPLIT_EXTERN)
 SPLIT_GROUP_HALF_TALL(SPLIT_EXTERN)
+SPLIT_GROUP_FOLD(SPLIT_EXTERN)
 SPLIT_GROUP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP_OSP(SPLIT_EXTERN)
@@ -237,12 +238,29 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (wres && !isp && osp && d.pre_act && !d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, true, false, false, false, true>(d, st);
     if (isp || osp) {
         if (osp && d.out4_dst) return YOND_EUNSUPPORTED;
+        // images at most 16 pixels wide (the deepest level of a batch of small blocks): a 32-pixel MFMA row would be half padding -- two
+        // 16-column sub-tiles (of one image or of two) share it instead (conv_split_kernel.h, FOLD)
+        // Folded kernels: 4-row tiles, one row per wave (half the MFMAs per step and workgroup of the 8-row kernel: ~0.67x its step time, the
+        // fragments of a single row are not shared between kernel rows); taken when the rounds of 256 workgroups say it is cheaper.
+        int fold = 0;
+        if (osp && (isp || d.pre_act) && tn == 64 && parts == 2 && d.Wo <= 16 && d.Wo == d.W && d.Ho == d.H && !d.src1 && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
+            const int f = d.Wo <= 8 ? 4 : 2;
+            const long long subs = (long long)d.N * ((d.Ho + 3) / 4) * ((d.Wo + 32 / f - 1) / (32 / f));
+            const long long tiles_f = (long long)(d.Cout / 64) * ((subs + f - 1) / f), tiles8 = (long long)(d.Cout / 64) * ((d.Ho + 7) / 8) * d.N;
+            // (a sub-tile of another image is addressed from sub-tile 0's plane base: at most f - 1 images further, in 32 bits)
+            const bool fits = (long long)d.H * d.W * (d.C0 > d.Cout ? d.C0 : d.Cout) * 4 * f < (1LL << 31);
+            if (fits && 2 * ((tiles_f + 255) / 256) < 3 * ((tiles8 + 255) / 256)) fold = f;
+        }
         if (isp && osp) {
+            if (fold == 2) return launch_split<1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 2>(d, st);
+            if (fold == 4) return launch_split<1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 4>(d, st);
             if (tn == 64 && tiles12 >= 256) return launch_split<1, 12, 64, 3, 2, 2, false, false, false, true, true>(d, st);
             if (tn == 64) return launch_split<1, 8, 64, 2, 2, 3, false, false, false, true, true>(d, st);
             return launch_split<1, 16, 32, 2, 2, 3, false, false, false, true, true>(d, st);
         }
         if (osp) {
+            if (fold == 2) return launch_split<1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 2>(d, st);
+            if (fold == 4) return launch_split<1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 4>(d, st);
             if (tn == 64 && tiles12 >= 256) return d.pre_act ? launch_split<1, 12, 64, 3, 2, 2, true, false, false, false, true>(d, st) : launch_split<1, 12, 64, 3, 2, 2, false, false, false, false, true>(d, st);
             if (tn == 64) return d.pre_act ? launch_split<1, 8, 64, 2, 2, 3, true, false, false, false, true>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false, false, false, false, true>(d, st);
             return d.pre_act ? launch_split<1, 16, 32, 2, 2, 3, true, false, false, false, true>(d, st) : launch_split<1, 16, 32, 2, 2, 3, false, false, false, false, true>(d, st);

@@ -60,7 +60,7 @@ extern "C" int SPLIT_DBG_READER(unsigned long long* host) {
 
 __host__ __device__ constexpr int yond_sp_plane_units(int H, int W) { return YOND_SP_PLANE_UNITS(H, W); }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool K1 = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool K1 = false, int FOLD = 0>
 struct SplitCfg {
     static constexpr int NT = 512;
     static constexpr int KC = 16;
@@ -70,7 +70,9 @@ struct SplitCfg {
     static constexpr int KSTEP = KC * NPT;
     static constexpr int TAPS = K1 ? NPT : 9;
     static constexpr int IH = K1 ? TH : (TH - 1) * STRIDE + 3;
-    static constexpr int IW = K1 ? 32 : 31 * STRIDE + 3;
+    // FOLD = 2 / 4 (images at most 16 / 8 pixels wide -- the deep levels of a batch of small blocks): the MFMA's 32 pixels are FOLD sub-tiles of 32 / FOLD
+    // columns side by side, each with its own halo columns: an LDS row = [1 + 16 + 1 | 1 + 16 + 1] units
+    static constexpr int IW = K1 ? 32 : (FOLD ? 32 + 2 * FOLD : 31 * STRIDE + 3);
     static constexpr int HALF = (IW + 1) / 2;
     static constexpr int TWP = STRIDE == 2 ? 2 * HALF : IW;
     static constexpr int PLANE = IH * TWP * 4 + 4;                  // floats; the last 16 bytes take the staging items past the tile
@@ -91,7 +93,7 @@ struct SplitCfg {
     static constexpr int KEEP = WAHEAD == 2 ? NIN + NWT_MIN : NIN;  // memory operations that may stay in flight across a barrier
     static constexpr int W4_OFF = 2 * IN_FLOATS + NWB * W_FLOATS;   // floats: 4 x 32 weights of the fused output projection
     static constexpr int FILM_OFF = W4_OFF + (TN == 32 ? 128 : 0);  // floats: per wave and 32-channel block {scale[32], shift[32]} (split-plane epilogue)
-    static constexpr int FILM_FLOATS = 8 * NW * 64;
+    static constexpr int FILM_FLOATS = 8 * NW * 64 * (FOLD ? FOLD : 1);     // (FOLD: every sub-tile may belong to another image)
     // h-only operands (PARTS 1) leave the transposed epilogue no consumed buffer large enough for its scratch (8 waves x 32 pixels x 36 floats):
     // their kernels use little LDS, so the scratch gets a region of its own behind everything else
     static constexpr int EP_FLOATS_C = 8 * 32 * 36;
@@ -108,6 +110,7 @@ struct SplitCfg {
     static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
     static_assert(!K1 || (STRIDE == 1 && PIX_ITEMS % NT == 0), "1x1 mode: whole chunks per pass of the staging threads");
     static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
+    static_assert(FOLD == 0 || ((FOLD == 2 || FOLD == 4) && STRIDE == 1 && !K1), "folded tiles: 3x3 stride-1 layers, two or four sub-tiles");
 };
 
 // output rows m of a wave that read input row r (taps dy = r - m*stride in 0..2)
@@ -135,9 +138,10 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 // (64-wide tile = 32 channels x two sub-positions) 6 / 11 / 22 steps where two tiles took 8 / 16 / 32.
 // D2 (stride 2): the layer also stores SiLU(value) in split planes (YondConvDesc.dst2), from the same epilogue loop -- an
 // instantiation of its own, so that the kernels without it keep their code and register allocation.
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false, bool D2 = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD>;
+    static_assert(!FOLD || (ISPM != 2 && OSP && !O4 && !D2 && !S2), "folded tiles: the split-plane data flow's 3x3 kernels (LDS-DMA or register-staged input, split-plane store)");
     // split-plane input: ISPM 1 (ISP) by LDS-DMA, one step ahead -- the layers whose steps are long enough to cover the DMA's
     // latency; ISPM 2 (ISR) through the three register sets of the staging pipeline (a load has two steps to arrive), written to LDS
     // as whole 16-byte units with no arithmetic -- the stride-2 layers and the decoder GEMMs, whose steps hold 9-27 MFMAs per wave
@@ -162,13 +166,32 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    // FOLD: lane li of a fragment = column li % FSW of sub-tile li / FSW; in the LDS row every sub-tile has its own two halo columns
+    constexpr int FSW = FOLD ? 32 / FOLD : 32;
+    const int fsub = FOLD ? li / FSW : 0, fcol = FOLD ? li % FSW : li, flds = FOLD ? li + 2 * fsub : li;
     const int rg = wave % C::RG, cg = wave / C::RG;
 
     const int nct = d.Cout / TN;
     const bool computes = d.Cout > 0;                        // always true; opaque to the compiler (keeps the MFMA stretch a block of its own)
-    const int ntx = (d.Wo + 31) / 32, nty = (d.Ho + TH - 1) / TH;
+    // FOLD: the sub-tiles (image n, row band of TH rows, column band of FSW) are numbered through the whole batch and taken FOLD at a time: the
+    // cursor's tx digit is the pair, its ty and n digits have one value each
+    const int fnsx = (d.Wo + FSW - 1) / FSW, fnsy = (d.Ho + TH - 1) / TH;
+    const int fper = fnsy * fnsx, fsubs = d.N * fper;
+    struct FGeo { int n, oy0, ox0; };
+    auto fold_geo = [&](int u) {                // sub-tile u: image, first row (Ho: past the last sub-tile -- nothing stored, zeros staged), first column
+        FGeo g;
+        const bool ok = u < fsubs;
+        const int uu = ok ? u : fsubs - 1;
+        g.n = uu / fper;
+        const int r = uu - g.n * fper, ry = r / fnsx;
+        g.oy0 = ok ? ry * TH : d.Ho;
+        g.ox0 = (r - ry * fnsx) * FSW;
+        return g;
+    };
+    const int ntx = FOLD ? (fsubs + FOLD - 1) / FOLD : (d.Wo + 31) / 32, nty = FOLD ? 1 : (d.Ho + TH - 1) / TH;
+    const int Neff = FOLD ? 1 : d.N;
     const int tiles_per_img = nct * ntx * nty;
-    const int total = tiles_per_img * d.N;
+    const int total = tiles_per_img * Neff;
     const int G = gridDim.x;
     const int lslot = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;   // XCD-contiguous runs
     const int Cin = d.C0 + d.C1;
@@ -204,6 +227,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 
     struct Tile {
         int ct, n, ox0, oy0;
+        int fu0;                               // FOLD: the group's first sub-tile (n, ox0, oy0 are its geometry; the others': fold_geo)
         int goff[NG];                          // pixel offset into the NHWC source (-1: outside the image -> zeros)
         int goff1[K1 ? NG : 1];                // K1: pixel offset into src1, the skip tensor at the OUTPUT resolution, read at
     };                                         // the sub-position (dy, dx) this tile's channel block stores to
@@ -234,12 +258,21 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
     // (YondConvDesc.tile_order 1: the spatial digits are complemented -- the same tiles, last row of tiles first)
     const bool rev = d.tile_order != 0;
-    auto decode = [&](const Cur& c, Tile& T) {
-        const int n = rev ? d.N - 1 - c.n : c.n;
-        T.n = n;
+    auto tile_origin = [&](const Cur& c, Tile& T) {
+        T.n = rev ? Neff - 1 - c.n : c.n;
         T.ct = c.ct;
         T.ox0 = (rev ? ntx - 1 - c.tx : c.tx) * 32;
         T.oy0 = (rev ? nty - 1 - c.ty : c.ty) * TH;
+        T.fu0 = 0;
+        if constexpr (FOLD != 0) {
+            T.fu0 = FOLD * (rev ? ntx - 1 - c.tx : c.tx);
+            const FGeo g = fold_geo(T.fu0);
+            T.n = g.n; T.oy0 = g.oy0; T.ox0 = g.ox0;
+        }
+    };
+    auto decode = [&](const Cur& c, Tile& T) {
+        tile_origin(c, T);
+        const int n = T.n;
         if constexpr (ISP) {
 #pragma unroll
             for (int k = 0; k < NG; ++k) {
@@ -248,9 +281,18 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 const int py = q / C::TWP, rem = q % C::TWP;
                 const int px = STRIDE == 2 ? 2 * (rem % C::HALF) + rem / C::HALF : rem;      // stride 2: even columns first
                 const bool valid = q < C::UPP && px < C::IW;    // (slots past the step's last plane are refused at issue)
-                const int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
+                int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
+                int nshift = 0;                                 // FOLD: byte distance of the sub-tile's image from sub-tile 0's (whose plane bases the DMA uses)
+                if constexpr (FOLD != 0) {
+                    const int sb = px / (FSW + 2), lx = px - (FSW + 2) * sb;
+                    const FGeo g = fold_geo(T.fu0 + sb);
+                    gy = g.oy0 >= d.Ho ? -1 : g.oy0 - 1 + py;     // (past the last sub-tile: zeros)
+                    gx = g.ox0 - 1 + lx;
+                    // (a column beyond the sub-tile's that belongs to the NEXT column band is a real neighbour; rows / columns outside the image: zero)
+                    nshift = (g.n - T.n) * ((d.C0 / 16) * (2 * PARTS) * PS0 * 16);
+                }
                 const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-                T.goff[k] = !valid ? -1 : (in ? gy * d.W + gx : d.H * d.W) * 16;
+                T.goff[k] = !valid ? -1 : (in ? (gy * d.W + gx) * 16 + nshift : (d.H * d.W) * 16);
                 if constexpr (K1) {
                     const int sp = k1_sp(T.ct, T.ct * TN);
                     T.goff1[k] = !valid ? -1 : (in ? (2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1) : 4 * d.H * d.W) * 16;
@@ -267,9 +309,18 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             const int it = tid_g + k * C::NT;
             const int pix = (it % C::PIX_ITEMS) / 4;
             const int py = pix / C::IW, px = pix % C::IW;
-            const int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
+            int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
+            int nb = n * d.H * d.W;                                // the image's first pixel
+            if constexpr (FOLD != 0) {
+                const int sb = px / (FSW + 2), lx = px - (FSW + 2) * sb;
+                const FGeo g = fold_geo(T.fu0 + sb);
+                gy = g.oy0 >= d.Ho ? -1 : g.oy0 - 1 + py;         // (past the last sub-tile: zeros)
+                gx = g.ox0 - 1 + lx;
+                // the sub-tile's image: [N][H][W][C]: its pixels; planes of 4 channels: the plane base (load_src) is sub-tile 0's image's, C0/4 planes per image
+                nb = d.in_fmt == YOND_FMT_PLANES4 ? nb + (g.n - n) * (d.C0 / 4) * d.H * d.W : g.n * d.H * d.W;
+            }
             const bool ok = it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-            T.goff[k] = ok ? ((n * d.H + gy) * d.W + gx) : -1;
+            T.goff[k] = ok ? (nb + gy * d.W + gx) : -1;
             if constexpr (ISR) T.goff[k] = ok ? gy * d.W + gx : d.H * d.W;      // unit inside a plane (n is in the plane base); outside: the zero unit
             if constexpr (K1) {
                 const int sp = k1_sp(T.ct, T.ct * TN);         // a channel tile never straddles two sub-positions (S2: dx = 0 here, + 1 unit for dx = 1)
@@ -455,7 +506,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // weight fragments (dy) of a column held in registers and fetched one column ahead, pixel fragments two ahead.
     // MFMA order inside a group: h_w l_x, then h_w h_x, then l_w h_x -- the two that share an accumulator are never
     // back to back (the dependent-issue latency of v_mfma_f32_32x32x16_f16 exceeds its 32 cycles).
-    const int x_off = (lh * PARTS) * C::PLANE + ((rg * MW * (K1 ? 1 : STRIDE)) * C::TWP + li) * 4;
+    const int x_off = (lh * PARTS) * C::PLANE + ((rg * MW * (K1 ? 1 : STRIDE)) * C::TWP + flds) * 4;
     const int w_off = ((lh * PARTS) * TN + (cg * C::NW) * 32 + li) * 4;
     // (the step's cursor arithmetic -- `prep`, which sets wsrc_s / ls_s and may decode the next tile -- runs after the
     // first groups of MFMAs have been issued; memory instructions and staging start at group Q0)
@@ -598,7 +649,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
         for (int nn = 0; nn < C::NW; ++nn) {
             const int cu = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * u;
-            const int eoff = (d.ebatch ? T.n * Cr : 0) + (K1 ? k1_cb(T.ct, cu) : cu);
+            int eoff = (d.ebatch ? T.n * Cr : 0) + (K1 ? k1_cb(T.ct, cu) : cu);
+            if constexpr (FOLD != 0) eoff = (d.ebatch ? fold_geo(T.fu0 + (lane >> 4)).n * Cr : 0) + cu;     // lanes 16 s ... 16 s + 15: sub-tile s's image
             // (no branch around the loads: an absent vector is read from the weights and never used)
             if constexpr (OSP) {
                 // the split-plane epilogue redistributes the vectors through LDS: lanes 0-7 fetch the scale, lanes 8-15 the shift,
@@ -798,21 +850,31 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // step, like the FiLM vectors.
     constexpr bool ORP = OSP && ISP;
     f32x4 qrr[ORP ? PFR : 1][C::NW][4];
-    auto res4_addr = [&](const Tile& T, int nn, int m, int g) -> const float* {
-        const int oy = T.oy0 + rg * MW + m, ox = T.ox0 + li;
+    auto lane_geo = [&](const Tile& T) {          // the lane's pixel column: image, first row of the (sub-)tile, column
+        FGeo g;
+        g.n = T.n; g.oy0 = T.oy0; g.ox0 = T.ox0 + li;
+        if constexpr (FOLD != 0) {
+            g = fold_geo(T.fu0 + fsub);
+            g.ox0 += fcol;
+        }
+        return g;
+    };
+    auto res4_addr = [&](const Tile& T, const FGeo& lg, int nn, int m, int g) -> const float* {
+        const int oy = lg.oy0 + rg * MW + m, ox = lg.ox0;
         const bool ok = d.res && oy < d.Ho && ox < d.Wo;
         const int c4 = (T.ct * TN + (cg * C::NW + nn) * 32 + 8 * g) / 4 + lh;
-        const long long off = (((long long)T.n * (d.Cout / 4) + c4) * d.Ho * d.Wo + (long long)oy * d.Wo + ox) * 4;
+        const long long off = (((long long)lg.n * (d.Cout / 4) + c4) * d.Ho * d.Wo + (long long)oy * d.Wo + ox) * 4;
         return (d.res ? d.res : d.wpk) + (ok ? off : 0);
     };
     auto res4_prefetch = [&](const Tile& T) __attribute__((always_inline)) {
         if constexpr (ORP) {
+            const FGeo lg = lane_geo(T);
 #pragma unroll
             for (int mm = 0; mm < PFR; ++mm)
 #pragma unroll
                 for (int nn = 0; nn < C::NW; ++nn)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) qrr[mm][nn][g] = *(const f32x4*)res4_addr(T, nn, mm, g);
+                    for (int g = 0; g < 4; ++g) qrr[mm][nn][g] = *(const f32x4*)res4_addr(T, lg, nn, mm, g);
         }
     };
     auto epilogue_sp = [&](auto hr, auto actc, const Tile& T) __attribute__((always_inline)) {
@@ -821,23 +883,26 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         // residual rows that were not prefetched: requested first, ahead of all arithmetic
         constexpr int LR0 = ORP ? PFR : 0;
         f32x4 lrr[HAS_RES && MW > LR0 ? MW - LR0 : 1][C::NW][4];
+        const FGeo lg = lane_geo(T);
         if constexpr (HAS_RES && MW > LR0) {
 #pragma unroll
             for (int mm = LR0; mm < MW; ++mm)
 #pragma unroll
                 for (int nn = 0; nn < C::NW; ++nn)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) lrr[mm - LR0][nn][g] = *(const f32x4*)res4_addr(T, nn, mm, g);
+                    for (int g = 0; g < 4; ++g) lrr[mm - LR0][nn][g] = *(const f32x4*)res4_addr(T, lg, nn, mm, g);
         }
-        float* fw = smem + C::FILM_OFF + wave * (C::NW * 64);
-        if (lane < 16) {
+        float* fw = smem + C::FILM_OFF + wave * (C::NW * 64 * (FOLD ? FOLD : 1));
+        if (lane < (FOLD ? 16 * FOLD : 16)) {
 #pragma unroll
-            for (int nn = 0; nn < C::NW; ++nn) *(f32x4*)(fw + nn * 64 + ((lane & 8) ? 32 : 0) + 4 * (lane & 7)) = pes[nn];
+            for (int nn = 0; nn < C::NW; ++nn) *(f32x4*)(fw + (FOLD ? (lane >> 4) * (C::NW * 64) : 0) + nn * 64 + ((lane & 8) ? 32 : 0) + 4 * (lane & 7)) = pes[nn];
         }
+        if constexpr (FOLD != 0) fw += fsub * (C::NW * 64);        // the lane's sub-tile reads its own image's vectors
         const int PSo = yond_sp_plane_units(d.Ho, d.Wo);
         const int nc16o = d.Cout / 16;
-        const int ox = T.ox0 + li;
+        const int ox = lg.ox0;
         const bool col_ok = ox < d.Wo;
+        const int e_n = lg.n, e_oy0 = lg.oy0;
 #pragma unroll
         for (int nn = 0; nn < C::NW; ++nn) {
             const int cb = T.ct * TN + (cg * C::NW + nn) * 32;
@@ -848,10 +913,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 if constexpr (HAS_SCALE) es = *(const f32x4*)(fw + nn * 64 + 8 * g + 4 * lh);
                 if constexpr (HAS_SHIFT) et = *(const f32x4*)(fw + nn * 64 + 32 + 8 * g + 4 * lh);
                 const int c16 = (cb + 8 * g) >> 4, hh = g & 1;
-                char* pb = (char*)d.dst + (size_t)(((T.n * nc16o + c16) * 2 + hh) * PARTS) * (size_t)PSo * 16 + lh * 8;
+                char* pb = (char*)d.dst + (size_t)(((e_n * nc16o + c16) * 2 + hh) * PARTS) * (size_t)PSo * 16 + lh * 8;
 #pragma unroll
                 for (int m = 0; m < MW; ++m) {
-                    const int oy = T.oy0 + rg * MW + m;
+                    const int oy = e_oy0 + rg * MW + m;
                     const bool ok = col_ok && oy < d.Ho;
                     f32x4 v;
 #pragma unroll
@@ -1119,10 +1184,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             SDBG(7);
             zero_acc();
             if (cn.tile < total) {
-                cur.n = rev ? d.N - 1 - cn.n : cn.n;
-                cur.ct = cn.ct;
-                cur.ox0 = (rev ? ntx - 1 - cn.tx : cn.tx) * 32;
-                cur.oy0 = (rev ? nty - 1 - cn.ty : cn.ty) * TH;
+                tile_origin(cn, cur);
             }
         }
         SDBG(5);
@@ -1156,18 +1218,20 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     }
 }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false, bool S2 = false, bool D2 = false>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0>
 int launch_split(const YondConvDesc& d, hipStream_t st) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1>;
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD>;
     static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP, S2, D2>;
+    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP, S2, D2, FOLD>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const long long total = (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
+    constexpr int FSWL = FOLD ? 32 / FOLD : 32;
+    const long long total = FOLD ? (long long)(d.Cout / TN) * (((long long)d.N * ((d.Ho + TH - 1) / TH) * ((d.Wo + FSWL - 1) / FSWL) + FOLD - 1) / (FOLD ? FOLD : 1))
+                                 : (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
     if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
     const int gmax = (int)yond_exp_long("YOND_SPLIT_GRID", 256);  // (experiment builds: fewer workgroups than CUs, leaving CUs to a side stream's kernels)
     const int grid = total < gmax ? (int)total : gmax;            // one persistent workgroup per CU
@@ -1217,6 +1281,10 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
     X(1, 8, 32, 1, 2, 3, false, false, true, 2, false) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false) \
     X(2, 4, 64, 1, 2, 2, false, false, false, 2, false)
 #define SPLIT_GROUP_K1_SUB2(X) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, true)
+// folded tiles (images at most 16 pixels wide): the 8-row kernel of the split-plane data flow with two 16-column sub-tiles per MFMA row
+#define SPLIT_GROUP_FOLD(X)                                                                             \
+    X(1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 2) X(1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 2)         \
+    X(1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 4) X(1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 4)
 #define SPLIT_GROUP_D2(X) X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true)
 #define SPLIT_GROUP_WRES(X)                                                                             \
     X(1, 16, 32, 2, 2, 2, true, false, false, false, true) X(1, 16, 32, 2, 2, 2, false, false, false, true, true) \

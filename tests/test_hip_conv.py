@@ -341,10 +341,13 @@ def test_conv3x3_split_plane_flow_block(C, N, H, W):
         plan._conv(pc2, t_sp, None, N, H, W, o_sp, res=xd, in_fmt=1, out_fmt=1, **kw2)
 
 
-@pytest.mark.parametrize("C,N,H,W", [(32, 2, 37, 70), (64, 1, 64, 130), (128, 1, 23, 45)])
+@pytest.mark.parametrize("C,N,H,W", [(32, 2, 37, 70), (64, 1, 64, 130), (128, 1, 23, 45),
+                                     # batches of small images (output at most 16 pixels wide, more than 256 plain tiles): folded tiles, 2 / 4 sub-tiles per MFMA row
+                                     (64, 40, 32, 32), (128, 40, 16, 16), (64, 45, 30, 27), (64, 70, 11, 13)])
 def test_conv3x3_s2_split_plane_input_planes4_output(C, N, H, W):
     """Stride-2 layer of the default data flow: input in split planes (raw block output) staged by LDS-DMA, output in planes of
-    4 channels -- equal to the [N][H][W][C] path bit for bit, in both output formats."""
+    4 channels -- equal to the [N][H][W][C] path bit for bit, in both output formats; the second output (SiLU of the value in split
+    planes, YondConvDesc.dst2) decodes to SiLU of the first."""
     from yond_public_amd.engine import _PackedConv
     g = torch.Generator().manual_seed(C + W)
     x = nhwc(torch.randn(N, C, H, W, generator=g))
@@ -359,20 +362,29 @@ def test_conv3x3_s2_split_plane_input_planes4_output(C, N, H, W):
     plan._conv(pc, to_sp(x), None, N, H, W, got, algo='split', in_fmt=1)
     gp4 = torch.empty(N * 2 * C * Ho * Wo, device=DEV)
     plan._conv(pc, to_sp(x), None, N, H, W, gp4, algo='split', in_fmt=1, out_fmt=2)
+    gp4b = torch.empty(N * 2 * C * Ho * Wo, device=DEV)
+    second = plan._new_sp('second', N, Ho, Wo, 2 * C)
+    plan._conv(pc, to_sp(x), None, N, H, W, gp4b, algo='split', in_fmt=1, out_fmt=2, dst2=second)
     torch.cuda.synchronize()
     assert torch.equal(got.cpu(), ref.cpu())
     assert torch.equal(from_p4(gp4, N, Ho, Wo, 2 * C), ref.cpu())
+    assert torch.equal(gp4b.cpu(), gp4.cpu())
+    val, pads = sp_decode(second, N, 2 * C, Ho, Wo)
+    assert not pads.view(torch.int16).any()
+    want = F.silu(nchw(ref.cpu()).double())
+    assert float((val - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
     z = F.conv2d(nchw(x).double(), w.double(), b.double(), stride=2, padding=1)
     assert report(f"stride-2 from split planes C{C}", nchw(got.cpu()), z) < 2e-5
 
 
-@pytest.mark.parametrize("c,h,w", [(64, 24, 40), (32, 19, 33), (128, 9, 35)])
-def test_decoder_gemm_split_plane_inputs(c, h, w):
+@pytest.mark.parametrize("c,h,w,N", [(64, 24, 40, 2), (32, 19, 33, 2), (128, 9, 35, 2),
+                                     # batches of small images (at most 16 pixels wide, more than 256 plain tiles): folded tiles, 2 / 4 sub-tiles per MFMA row
+                                     (64, 16, 16, 40), (128, 8, 8, 40), (64, 13, 11, 45), (64, 5, 7, 70)])
+def test_decoder_gemm_split_plane_inputs(c, h, w, N):
     """The decoder GEMM (ConvTranspose2d 2x2 + cat + 1x1 shortcut folded) with BOTH sources in split planes -- the
     low-resolution tensor and the skip tensor gathered at the sub-position -- and the output in either format."""
     from yond_public_amd.engine import _PackedConv
     g = torch.Generator().manual_seed(c + h)
-    N = 2
     cur = nhwc(torch.randn(N, 2 * c, h, w, generator=g))
     skip = nhwc(torch.randn(N, c, 2 * h, 2 * w, generator=g))
     wf = torch.randn(3 * c, c, 2, 2, generator=g) / (3 * c) ** 0.5        # ConvTranspose2d layout over [cur | skip]

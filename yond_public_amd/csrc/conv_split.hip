@@ -9,6 +9,8 @@ SPLIT_GROUP_HALF(SPLIT_EXTERN)
 SPLIT_GROUP_HALF128(SPLIT_EXTERN)
 SPLIT_GROUP_HALF_TALL(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD(SPLIT_EXTERN)
+SPLIT_GROUP_FOLD_S2(SPLIT_EXTERN)
+SPLIT_GROUP_FOLD_K1(SPLIT_EXTERN)
 SPLIT_GROUP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP_OSP(SPLIT_EXTERN)
@@ -205,6 +207,15 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.ksize == 1) {
         // the decoder GEMM: low-resolution input (C0) + skip tensor at the output resolution (C1), pixel-shuffle store
         if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W || osp || ip4) return YOND_EUNSUPPORTED;
+        if (isp && tn == 64 && d.Wo <= 16 && d.src1 && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
+            // input at most 16 pixels wide: 2 / 4 sub-tiles per MFMA row (conv_split_kernel.h, FOLD) when that saves a round of 256 workgroups
+            const int f = d.Wo <= 8 ? 4 : 2;
+            const long long subs = (long long)d.N * ((d.Ho + 7) / 8) * ((d.Wo + 32 / f - 1) / (32 / f));
+            const long long tiles_f = (long long)(d.Cout / 64) * ((subs + f - 1) / f), tiles = (long long)(d.Cout / 64) * ((d.Ho + 7) / 8) * d.N;
+            const bool fits = (long long)d.H * d.W * (d.C0 > 4 * d.C1 ? d.C0 : 4 * d.C1) * 4 * f < (1LL << 31);
+            if (fits && (tiles_f + 255) / 256 < (tiles + 255) / 256)
+                return f == 2 ? launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 2>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 4>(d, st);
+        }
         if (isp) return tn == 32 ? launch_split<1, 8, 32, 1, 2, 3, false, false, true, 2>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2>(d, st);
         if (tn == 32) return launch_split<1, 8, 32, 1, 2, 3, false, false, true>(d, st);    // level 1 -> 0: 32-channel output pixels
         return launch_split<1, 8, 64, 2, 2, 3, false, false, true>(d, st);
@@ -213,6 +224,17 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         if (d.Ho != (d.H + 1) / 2 || d.Wo != (d.W + 1) / 2 || d.pre_act) return YOND_EINVAL;
         if (osp || ip4 || (op4 && d.res)) return YOND_EUNSUPPORTED;
         // stride 2: 4 x 32 output pixels read 9 x 65 input pixels -- two weight buffers fit beside the two input images
+        if (isp && parts == 2 && d.Wo <= 16 && !d.src1 && !d.res && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
+            // output at most 16 pixels wide: 2 / 4 sub-tiles per MFMA row (conv_split_kernel.h, FOLD) when that saves a round of 256 workgroups
+            const int f = d.Wo <= 8 ? 4 : 2;
+            const long long subs = (long long)d.N * ((d.Ho + 3) / 4) * ((d.Wo + 32 / f - 1) / (32 / f));
+            const long long tiles_f = (long long)(d.Cout / 64) * ((subs + f - 1) / f), tiles = (long long)(d.Cout / 64) * ((d.Ho + 3) / 4) * d.N;
+            const bool fits = (long long)d.H * d.W * d.C0 * 4 * f < (1LL << 31);
+            if (fits && (tiles_f + 255) / 256 < (tiles + 255) / 256) {
+                if (f == 2) return d.dst2 ? launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true, 2>(d, st) : launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, false, 2>(d, st);
+                return d.dst2 ? launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true, 4>(d, st) : launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, false, 4>(d, st);
+            }
+        }
         if (isp && d.dst2) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true>(d, st);
         if (isp) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2>(d, st);
         return parts == 2 ? launch_split<2, 4, 64, 1, 2, 2, false>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false>(d, st);

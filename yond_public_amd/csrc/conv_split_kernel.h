@@ -71,8 +71,10 @@ struct SplitCfg {
     static constexpr int TAPS = K1 ? NPT : 9;
     static constexpr int IH = K1 ? TH : (TH - 1) * STRIDE + 3;
     // FOLD = 2 / 4 (images at most 16 / 8 pixels wide -- the deep levels of a batch of small blocks): the MFMA's 32 pixels are FOLD sub-tiles of 32 / FOLD
-    // columns side by side, each with its own halo columns: an LDS row = [1 + 16 + 1 | 1 + 16 + 1] units
-    static constexpr int IW = K1 ? 32 : (FOLD ? 32 + 2 * FOLD : 31 * STRIDE + 3);
+    // columns side by side, each with its own halo columns: an LDS row = [1 + 16 + 1 | 1 + 16 + 1] units (stride 2: a sub-tile's 2 w + 1 input
+    // columns and one unused column -- an even width keeps the even / odd column halves of the row aligned between sub-tiles)
+    static constexpr int FSUBW = FOLD ? (STRIDE == 2 ? 2 * (32 / FOLD) + 2 : 32 / FOLD + 2) : 0;       // input columns of a sub-tile's share of the LDS row
+    static constexpr int IW = K1 ? 32 : (FOLD ? FOLD * FSUBW : 31 * STRIDE + 3);
     static constexpr int HALF = (IW + 1) / 2;
     static constexpr int TWP = STRIDE == 2 ? 2 * HALF : IW;
     static constexpr int PLANE = IH * TWP * 4 + 4;                  // floats; the last 16 bytes take the staging items past the tile
@@ -93,7 +95,7 @@ struct SplitCfg {
     static constexpr int KEEP = WAHEAD == 2 ? NIN + NWT_MIN : NIN;  // memory operations that may stay in flight across a barrier
     static constexpr int W4_OFF = 2 * IN_FLOATS + NWB * W_FLOATS;   // floats: 4 x 32 weights of the fused output projection
     static constexpr int FILM_OFF = W4_OFF + (TN == 32 ? 128 : 0);  // floats: per wave and 32-channel block {scale[32], shift[32]} (split-plane epilogue)
-    static constexpr int FILM_FLOATS = 8 * NW * 64 * (FOLD ? FOLD : 1);     // (FOLD: every sub-tile may belong to another image)
+    static constexpr int FILM_FLOATS = 8 * NW * 64 * (FOLD && STRIDE == 1 ? FOLD : 1);     // (FOLD: every sub-tile may belong to another image; stride 2 never stores split planes)
     // h-only operands (PARTS 1) leave the transposed epilogue no consumed buffer large enough for its scratch (8 waves x 32 pixels x 36 floats):
     // their kernels use little LDS, so the scratch gets a region of its own behind everything else
     static constexpr int EP_FLOATS_C = 8 * 32 * 36;
@@ -110,7 +112,7 @@ struct SplitCfg {
     static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
     static_assert(!K1 || (STRIDE == 1 && PIX_ITEMS % NT == 0), "1x1 mode: whole chunks per pass of the staging threads");
     static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
-    static_assert(FOLD == 0 || ((FOLD == 2 || FOLD == 4) && STRIDE == 1 && !K1), "folded tiles: 3x3 stride-1 layers, two or four sub-tiles");
+    static_assert(FOLD == 0 || FOLD == 2 || FOLD == 4, "folded tiles: two or four sub-tiles");
 };
 
 // output rows m of a wave that read input row r (taps dy = r - m*stride in 0..2)
@@ -141,7 +143,8 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD>;
-    static_assert(!FOLD || (ISPM != 2 && OSP && !O4 && !D2 && !S2), "folded tiles: the split-plane data flow's 3x3 kernels (LDS-DMA or register-staged input, split-plane store)");
+    static_assert(!FOLD || (!O4 && !S2 && ((!K1 && STRIDE == 1 && ISPM != 2 && OSP) || (STRIDE == 2 && ISPM == 2) || (K1 && ISPM == 2))),
+                  "folded tiles: the split-plane data flow's kernels (3x3 stride 1: LDS-DMA or register-staged input, split-plane store; stride 2 and the decoder GEMM: register-staged split planes)");
     // split-plane input: ISPM 1 (ISP) by LDS-DMA, one step ahead -- the layers whose steps are long enough to cover the DMA's
     // latency; ISPM 2 (ISR) through the three register sets of the staging pipeline (a load has two steps to arrive), written to LDS
     // as whole 16-byte units with no arithmetic -- the stride-2 layers and the decoder GEMMs, whose steps hold 9-27 MFMAs per wave
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     const int li = lane & 31, lh = lane >> 5;
     // FOLD: lane li of a fragment = column li % FSW of sub-tile li / FSW; in the LDS row every sub-tile has its own two halo columns
     constexpr int FSW = FOLD ? 32 / FOLD : 32;
-    const int fsub = FOLD ? li / FSW : 0, fcol = FOLD ? li % FSW : li, flds = FOLD ? li + 2 * fsub : li;
+    const int fsub = FOLD ? li / FSW : 0, fcol = FOLD ? li % FSW : li, flds = (FOLD && !K1) ? li + (STRIDE == 2 ? 1 : 2) * fsub : li;     // (stride 2: position in the row's even-column half; the decoder GEMM has no halo)
     const int rg = wave % C::RG, cg = wave / C::RG;
 
     const int nct = d.Cout / TN;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
                 int nshift = 0;                                 // FOLD: byte distance of the sub-tile's image from sub-tile 0's (whose plane bases the DMA uses)
                 if constexpr (FOLD != 0) {
-                    const int sb = px / (FSW + 2), lx = px - (FSW + 2) * sb;
+                    const int sb = px / C::FSUBW, lx = px - C::FSUBW * sb;
                     const FGeo g = fold_geo(T.fu0 + sb);
                     gy = g.oy0 >= d.Ho ? -1 : g.oy0 - 1 + py;     // (past the last sub-tile: zeros)
                     gx = g.ox0 - 1 + lx;
@@ -311,21 +314,25 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             const int py = pix / C::IW, px = pix % C::IW;
             int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
             int nb = n * d.H * d.W;                                // the image's first pixel
+            int ushift = 0, ushift1 = 0;                           // ISR + FOLD: units from sub-tile 0's image's planes to the sub-tile's image's (src0, src1)
             if constexpr (FOLD != 0) {
-                const int sb = px / (FSW + 2), lx = px - (FSW + 2) * sb;
+                constexpr int SUBW = K1 ? FSW : C::FSUBW;
+                const int sb = px / SUBW, lx = px - SUBW * sb;
                 const FGeo g = fold_geo(T.fu0 + sb);
-                gy = g.oy0 >= d.Ho ? -1 : g.oy0 - 1 + py;         // (past the last sub-tile: zeros)
-                gx = g.ox0 - 1 + lx;
+                gy = g.oy0 >= d.Ho ? -1 : (K1 ? g.oy0 + py : g.oy0 * STRIDE - 1 + py);     // (past the last sub-tile: zeros)
+                gx = K1 ? g.ox0 + lx : g.ox0 * STRIDE - 1 + lx;
+                ushift1 = (g.n - n) * (d.C1 / 16) * 4 * PS1;
                 // the sub-tile's image: [N][H][W][C]: its pixels; planes of 4 channels: the plane base (load_src) is sub-tile 0's image's, C0/4 planes per image
                 nb = d.in_fmt == YOND_FMT_PLANES4 ? nb + (g.n - n) * (d.C0 / 4) * d.H * d.W : g.n * d.H * d.W;
+                ushift = (g.n - n) * (d.C0 / 16) * 4 * PS0;
             }
             const bool ok = it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
             T.goff[k] = ok ? (nb + gy * d.W + gx) : -1;
-            if constexpr (ISR) T.goff[k] = ok ? gy * d.W + gx : d.H * d.W;      // unit inside a plane (n is in the plane base); outside: the zero unit
+            if constexpr (ISR) T.goff[k] = ok ? gy * d.W + gx + ushift : d.H * d.W;      // unit inside a plane (n is in the plane base); outside: the zero unit
             if constexpr (K1) {
                 const int sp = k1_sp(T.ct, T.ct * TN);         // a channel tile never straddles two sub-positions (S2: dx = 0 here, + 1 unit for dx = 1)
                 T.goff1[k] = ok ? ((n * 2 * d.H + 2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1)) : -1;
-                if constexpr (ISR) T.goff1[k] = ok ? (2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1) : 4 * d.H * d.W;
+                if constexpr (ISR) T.goff1[k] = ok ? (2 * gy + (sp >> 1)) * (2 * d.W) + 2 * gx + (sp & 1) + ushift1 : 4 * d.H * d.W;
             }
         }
         }
@@ -947,7 +954,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     auto epilogue_direct = [&](const Tile& T) __attribute__((always_inline)) {      // (left to the inliner, the two call sites of a two-set kernel became real calls in one instantiation: the descriptor went to scratch memory, 13x slower)
         // lane = pixel: NHWC stores from here touch 32 lines with 32 bytes each; into PLANES OF 4 CHANNELS (out_fmt 2) the 32
         // pixels of a fragment are 512 contiguous bytes (K1: every other 16-byte unit of the pixel-shuffled row)
-        const int ox = T.ox0 + li;
+        const FGeo lg = lane_geo(T);
+        const int ox = lg.ox0;
         const bool col_ok = ox < d.Wo;
         const bool out_p4 = d.out_fmt == YOND_FMT_PLANES4;
         const int Hout = K1 ? 2 * d.Ho : d.Ho, Wout = K1 ? 2 * d.Wo : d.Wo;
@@ -955,7 +963,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         for (int nn = 0; nn < C::NW; ++nn) {
             const int cfull = T.ct * TN + (cg * C::NW + nn) * 32 + 4 * lh;
             const int sp = K1 ? k1_sp(T.ct, cfull) : 0, cbase = K1 ? k1_cb(T.ct, cfull) : cfull;     // K1: sub-position of the tile's channel block
-            const int eoff = (d.ebatch ? T.n * Cr : 0) + cbase;
+            const int eoff = (d.ebatch ? lg.n * Cr : 0) + cbase;
             f32x4 es[4], et[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -966,9 +974,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             f32x4 rr[MW][4];
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
-                const int oy = T.oy0 + rg * MW + m;
+                const int oy = lg.oy0 + rg * MW + m;
                 const bool ok = col_ok && oy < d.Ho;
-                const long long off = ok ? ((long long)(T.n * d.Ho + oy) * d.Wo + ox) * d.Cout + cbase : 0;   // masked lanes read element 0..
+                const long long off = ok ? ((long long)(lg.n * d.Ho + oy) * d.Wo + ox) * d.Cout + cbase : 0;   // masked lanes read element 0..
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -977,11 +985,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             }
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
-                const int oy = T.oy0 + rg * MW + m;
+                const int oy = lg.oy0 + rg * MW + m;
                 const bool ok = col_ok && oy < d.Ho;
                 const long long pixo = (long long)(K1 ? 2 * oy + (sp >> 1) : oy) * Wout + (K1 ? 2 * ox + (sp & 1) : ox);
-                float* op = out_p4 ? d.dst + (((long long)T.n * (Cr / 4) + cbase / 4) * Hout * Wout + pixo) * 4
-                                   : d.dst + ((long long)T.n * Hout * Wout + pixo) * Cr + cbase;
+                float* op = out_p4 ? d.dst + (((long long)lg.n * (Cr / 4) + cbase / 4) * Hout * Wout + pixo) * 4
+                                   : d.dst + ((long long)lg.n * Hout * Wout + pixo) * Cr + cbase;
                 const long long gstep = out_p4 ? 8LL * Hout * Wout : 8;              // elements from one 8-channel group to the next
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1008,7 +1016,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                                          (_Float16)((a[2] - (float)h[2]) * 2048.0f), (_Float16)((a[3] - (float)h[3]) * 2048.0f)};
                         const int c8 = cbase - 4 * lh + 8 * g;                          // first channel of the lane's unit
                         const size_t PS2 = (size_t)yond_sp_plane_units(Hout, Wout);
-                        char* pp = (char*)d.dst2 + ((size_t)(((T.n * (Cr / 16) + (c8 >> 4)) * 2 + ((c8 >> 3) & 1)) * 2) * PS2 + (size_t)pixo) * 16 + lh * 8;
+                        char* pp = (char*)d.dst2 + ((size_t)(((lg.n * (Cr / 16) + (c8 >> 4)) * 2 + ((c8 >> 3) & 1)) * 2) * PS2 + (size_t)pixo) * 16 + lh * 8;
                         if (ok) {
                             *(f16x4*)pp = h;
                             *(f16x4*)(pp + PS2 * 16) = l;
@@ -1160,7 +1168,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                                 if (flags == decltype(fcx)::value) epilogue_sp(fcx, IntC<-1>{}, cur);
                             }
                         });
-                } else if (K1 && d.out_fmt == YOND_FMT_PLANES4) {
+                } else if (K1 && (FOLD != 0 || d.out_fmt == YOND_FMT_PLANES4)) {
                     epilogue_direct(cur);                          // (planes of 4 channels: stored from the accumulator layout)
                 } else if constexpr (EP_FIT) {
                     float* scr = C::EP_OWN ? smem + C::EP_OFF : (EP_IN_W ? w0 : ibuf);
@@ -1285,6 +1293,12 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 #define SPLIT_GROUP_FOLD(X)                                                                             \
     X(1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 2) X(1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 2)         \
     X(1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 4) X(1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 4)
+// ... the decoder GEMMs (no halo: the sub-tiles lie side by side as the columns of one tile do)
+#define SPLIT_GROUP_FOLD_K1(X) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 2) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 4)
+// ... and the stride-2 layers of the flow (split planes in, planes of 4 channels out, with and without the second, split-plane output)
+#define SPLIT_GROUP_FOLD_S2(X)                                                                          \
+    X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true, 2) X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, false, 2)            \
+    X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true, 4) X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, false, 4)
 #define SPLIT_GROUP_D2(X) X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true)
 #define SPLIT_GROUP_WRES(X)                                                                             \
     X(1, 16, 32, 2, 2, 2, true, false, false, false, true) X(1, 16, 32, 2, 2, 2, false, false, false, true, true) \

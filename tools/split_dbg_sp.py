@@ -64,3 +64,15 @@ for _ in range(3):
     plan._conv(pc2, out, None, 1, h, w, nxt, algo='split', in_fmt=1, out_fmt=2)
 torch.cuda.synchronize()
 show("yond_split_debug_read_isp_k1s2", "stride 2: split-plane input through the register pipeline, planes-of-4 store")
+# the decoder GEMM of the level below (input c 2 channels at (h/2, w/2) + skip tensor c channels at (h, w) -> c channels at (h, w)): short steps
+# (three 16-channel pseudo-taps = 18 MFMAs per wave), register-staged split planes
+if Cc >= 64:
+    hl, wl = h // 2, w // 2
+    cur = plan._new_sp('cur', 1, hl, wl, 2 * Cc)
+    skip = plan._new_sp('skip', 1, 2 * hl, 2 * wl, Cc)
+    pcu = _PackedConv(plan.dev, torch.randn(3 * Cc, Cc, 2, 2, generator=g) / (3 * Cc) ** 0.5, torch.randn(Cc, generator=g), 1, 1, [2 * Cc, Cc], shuffle=True)
+    up = torch.empty(Cc * 4 * hl * wl, device='cuda')
+    for _ in range(3):
+        plan._conv(pcu, cur, skip, 1, hl, wl, up, algo='split', in_fmt=1, out_fmt=2)
+    torch.cuda.synchronize()
+    show("yond_split_debug_read_isp_k1s2", "decoder GEMM: split-plane inputs through the register pipeline, planes-of-4 pixel-shuffle store")

@@ -122,6 +122,25 @@ def test_conv3x3_split_plain(C, Co, N, H, W):
     assert report(f"split conv3x3 C{C}->{Co} {N}x{H}x{W}", got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("C,Co,N,H,W", [(64, 64, 70, 16, 16), (128, 128, 9, 8, 8), (64, 128, 5, 13, 11), (256, 256, 3, 6, 16)])
+def test_conv3x3_split_folded_tiles_nhwc(C, Co, N, H, W):
+    """The plain [N][H][W][C] 3x3 layer on a batch of images at most 16 pixels wide (training patches' deep levels): folded tiles -- two or
+    four sub-tiles, of one image or of several, share the MFMA's 32-pixel row.  Bias + LeakyReLU + residual against float64, and every image
+    of the batch BIT-EQUAL to the same image convolved alone (another grouping of the sub-tiles, the same arithmetic per pixel)."""
+    g = torch.Generator().manual_seed(C + H + N)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(Co, generator=g)
+    res = torch.randn(N, Co, H, W, generator=g)
+    xd, rd = nhwc(x).to(DEV), nhwc(res).to(DEV)
+    got = run_conv(w, b, 3, 1, [C], [xd], N, H, W, res=rd, post_act=2, slope=0.2, algo='split')
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.2) + res.double()
+    assert report(f"folded split conv3x3 C{C}->{Co} {N}x{H}x{W}", nchw(got), ref) < 2e-5
+    for n in (0, N // 2, N - 1):
+        one = run_conv(w, b, 3, 1, [C], [xd[n:n + 1].contiguous()], 1, H, W, res=rd[n:n + 1].contiguous(), post_act=2, slope=0.2, algo='split')
+        assert torch.equal(one[0], got[n]), n
+
+
 def test_conv3x3_split_accuracy_beside_fp32_kernels():
     """Error against float64 of the three 3x3 kernels on the same data, at unit scale and at magnitudes where the
     fp16 halves are subnormal (1e-6) or large (1e3): the split kernel must be no worse than 2x the fp32 direct

@@ -11,6 +11,7 @@ SPLIT_GROUP_HALF_TALL(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD_S2(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD_K1(SPLIT_EXTERN)
+SPLIT_GROUP_FOLD_NHWC(SPLIT_EXTERN)
 SPLIT_GROUP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP_OSP(SPLIT_EXTERN)
@@ -304,6 +305,17 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         // 12 x 32-pixel tiles, three rows per wave: 0.59 instead of 0.78 KiB of LDS fragments per MFMA, 1.5x the MFMA work per
         // step (and per barrier), and 94 / 188 / 376 / 752 rows fill 256 workgroups in whole rounds (1 / 2 / 4 / 8)
         const bool th12 = tiles12 >= 256;
+        if (parts == 2 && !d.pre_act && !d.src1 && !d.in_fmt && !d.out_fmt && !d.res_fmt && !d.out4_dst && !(d.ebatch && (d.escale || d.eshift)) && d.Wo <= 16 &&
+            yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
+            // the plain [N][H][W][C] layer on images at most 16 pixels wide (training patches' deep levels): folded 4-row tiles, as in the split-plane flow above
+            const int f = d.Wo <= 8 ? 4 : 2;
+            const long long subs = (long long)d.N * ((d.Ho + 3) / 4) * ((d.Wo + 32 / f - 1) / (32 / f));
+            const long long tiles_f = (long long)(d.Cout / 64) * ((subs + f - 1) / f), tiles8 = (long long)(d.Cout / 64) * ((d.Ho + 7) / 8) * d.N;
+            const double cost_plain = th12 ? 1.35 * (double)((tiles12 + 255) / 256) : (double)((tiles8 + 255) / 256);
+            const bool fits = (long long)d.N * d.H * d.W * (d.C0 > d.Cout ? d.C0 : d.Cout) < (1LL << 31);
+            if (fits && 0.667 * (double)((tiles_f + 255) / 256) < cost_plain)
+                return f == 2 ? launch_split<1, 4, 64, 1, 2, 3, false, false, false, 0, false, false, false, 2>(d, st) : launch_split<1, 4, 64, 1, 2, 3, false, false, false, 0, false, false, false, 4>(d, st);
+        }
         if (parts == 2 && th12) return d.pre_act ? launch_split<1, 12, 64, 3, 2, 2, true>(d, st) : launch_split<1, 12, 64, 3, 2, 2, false>(d, st);
         if (parts == 2) return d.pre_act ? launch_split<1, 8, 64, 2, 2, 3, true>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false>(d, st);
         if (th12) return d.pre_act ? launch_split<1, 12, 64, 3, 1, 2, true>(d, st) : launch_split<1, 12, 64, 3, 1, 2, false>(d, st);

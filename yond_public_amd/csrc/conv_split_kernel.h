@@ -143,8 +143,9 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD>;
-    static_assert(!FOLD || (!O4 && !S2 && ((!K1 && STRIDE == 1 && ISPM != 2 && OSP) || (STRIDE == 2 && ISPM == 2) || (K1 && ISPM == 2))),
-                  "folded tiles: the split-plane data flow's kernels (3x3 stride 1: LDS-DMA or register-staged input, split-plane store; stride 2 and the decoder GEMM: register-staged split planes)");
+    static_assert(!FOLD || (!O4 && !S2 && ((!K1 && STRIDE == 1 && ISPM != 2 && OSP) || (STRIDE == 2 && ISPM == 2) || (K1 && ISPM == 2) || (!K1 && STRIDE == 1 && ISPM == 0 && !OSP && !PRE))),
+                  "folded tiles: the split-plane data flow's kernels (3x3 stride 1: LDS-DMA or register-staged input, split-plane store; stride 2 and the decoder GEMM: register-staged split planes) "
+                  "and the plain [N][H][W][C] 3x3 layer (training, UNetSeeInDark)");
     // split-plane input: ISPM 1 (ISP) by LDS-DMA, one step ahead -- the layers whose steps are long enough to cover the DMA's
     // latency; ISPM 2 (ISR) through the three register sets of the staging pipeline (a load has two steps to arrive), written to LDS
     // as whole 16-byte units with no arithmetic -- the stride-2 layers and the decoder GEMMs, whose steps hold 9-27 MFMAs per wave
@@ -722,6 +723,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         }
         float* sw = scratch + wave * (32 * EPS);
         const int pj = lane >> 3, u = lane & 7;               // read-back: pixel pj + 8 j, channels 4 u .. 4 u + 3
+        FGeo jg[FOLD ? 4 : 1];                                // FOLD: (image, first row, column) of the read-back pixel pj + 8 j -- its sub-tile's geometry
+        if constexpr (FOLD != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                jg[j] = fold_geo(T.fu0 + (pj + 8 * j) / FSW);
+                jg[j].ox0 += (pj + 8 * j) % FSW;
+            }
+        }
         float ubv = 1.0f, bq = 0.0f;                          // OUT4: per-image maximum, bias of output component u & 3
         if constexpr (OUT4) {
             if (d.out4_ub) ubv = d.out4_ub[T.n];
@@ -776,8 +785,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;      // masked lanes read element 0..
-                        if constexpr (HAS_RES) rr[mm][j] = *(const f32x4*)(d.res + (ok ? rowoff[mm] + (long long)(pj + 8 * j) * pstep : 0));
+                        bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;      // masked lanes read element 0..
+                        long long off = rowoff[mm] + (long long)(pj + 8 * j) * pstep;
+                        if constexpr (FOLD != 0) {
+                            const int oyj = jg[j].oy0 + rg * MW + m0 + mm;
+                            ok = oyj < d.Ho && jg[j].ox0 < d.Wo;
+                            off = ((long long)(jg[j].n * d.Ho + oyj) * d.Wo + jg[j].ox0) * d.Cout + cb;
+                        }
+                        if constexpr (HAS_RES) rr[mm][j] = *(const f32x4*)(d.res + (ok ? off : 0));
                         else rr[mm][j] = zero4;
                     }
                 }
@@ -797,7 +812,13 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;
+                        bool ok = oy < d.Ho && T.ox0 + pj + 8 * j < d.Wo;
+                        long long soff = rowoff[mm] + (long long)(pj + 8 * j) * pstep;
+                        if constexpr (FOLD != 0) {
+                            const int oyj = jg[j].oy0 + rg * MW + m;
+                            ok = oyj < d.Ho && jg[j].ox0 < d.Wo;
+                            soff = ((long long)(jg[j].n * d.Ho + oyj) * d.Wo + jg[j].ox0) * d.Cout + cb;
+                        }
                         const f32x4 x = *(const f32x4*)(sw + (pj + 8 * j) * EPS + 4 * u);
                         f32x4 v;
 #pragma unroll
@@ -838,7 +859,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                             const long long gp = (long long)(T.n * d.Ho + oy) * d.Wo + T.ox0 + pj + 8 * j;
                             if (ok && u < 4) d.out4_dst[gp * 4 + cu] = t;
                         } else {
-                            if (ok) *(f32x4*)(d.dst + rowoff[mm] + (long long)(pj + 8 * j) * pstep) = v;
+                            if (ok) *(f32x4*)(d.dst + soff) = v;
                         }
                     }
                 }
@@ -1294,6 +1315,8 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
     X(1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 2) X(1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 2)         \
     X(1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 4) X(1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 4)
 // ... the decoder GEMMs (no halo: the sub-tiles lie side by side as the columns of one tile do)
+// ... the plain [N][H][W][C] layer (training's forward and data-gradient convolutions, UNetSeeInDark's deep stages)
+#define SPLIT_GROUP_FOLD_NHWC(X) X(1, 4, 64, 1, 2, 3, false, false, false, 0, false, false, false, 2) X(1, 4, 64, 1, 2, 3, false, false, false, 0, false, false, false, 4)
 #define SPLIT_GROUP_FOLD_K1(X) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 2) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 4)
 // ... and the stride-2 layers of the flow (split planes in, planes of 4 channels out, with and without the second, split-plane output)
 #define SPLIT_GROUP_FOLD_S2(X)                                                                          \

@@ -538,16 +538,23 @@ def test_conv3x3_s2(C, N, H, W):
 
 
 @pytest.mark.parametrize("C,N,H,W", [(32, 1, 16, 64), (64, 2, 32, 32), (32, 1, 18, 34), (128, 1, 7, 9), (32, 1, 2, 2),
-                                     (32, 1, 136, 544), (64, 1, 33, 65)])      # odd sizes; > 256 tiles
+                                     (32, 1, 136, 544), (64, 1, 33, 65),       # odd sizes; > 256 tiles
+                                     (64, 40, 32, 32), (128, 40, 16, 16), (64, 70, 11, 13)])    # batches of small images: folded tiles
 def test_conv3x3_s2_split(C, N, H, W):
-    """Stride-2 form of the split-operand kernel (algo 3), same tolerance as the fp32 kernel."""
+    """Stride-2 form of the split-operand kernel (algo 3), same tolerance as the fp32 kernel; an image of a batch is bit-equal to the
+    image convolved alone (folded tiles group sub-tiles of several images into one MFMA row)."""
     g = torch.Generator().manual_seed(C + W + 1)
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(2 * C, C, 3, 3, generator=g) / (3 * C ** 0.5)
     b = torch.randn(2 * C, generator=g)
-    got = nchw(run_conv(w, b, 3, 2, [C], [nhwc(x).to(DEV)], N, H, W, algo='split'))
+    xd = nhwc(x).to(DEV)
+    got = run_conv(w, b, 3, 2, [C], [xd], N, H, W, algo='split')
     ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
-    assert report(f"split conv3x3 s2 C{C} {N}x{H}x{W}", got, ref) < 2e-5
+    assert report(f"split conv3x3 s2 C{C} {N}x{H}x{W}", nchw(got), ref) < 2e-5
+    if N > 2:
+        for n in (0, N - 1):
+            one = run_conv(w, b, 3, 2, [C], [xd[n:n + 1].contiguous()], 1, H, W, algo='split')
+            assert torch.equal(one[0], got[n]), n
 
 
 @pytest.mark.parametrize("algo", [0, 'split'])

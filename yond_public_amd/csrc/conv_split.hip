@@ -238,6 +238,14 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         }
         if (isp && d.dst2) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true>(d, st);
         if (isp) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2>(d, st);
+        if (!isp && parts == 2 && d.Wo <= 16 && !d.src1 && !d.res && !d.in_fmt && !d.out_fmt && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
+            // the [N][H][W][C] form of the same (training's forward)
+            const int f = d.Wo <= 8 ? 4 : 2;
+            const long long subs = (long long)d.N * ((d.Ho + 3) / 4) * ((d.Wo + 32 / f - 1) / (32 / f));
+            const long long tiles_f = (long long)(d.Cout / 64) * ((subs + f - 1) / f), tiles = (long long)(d.Cout / 64) * ((d.Ho + 3) / 4) * d.N;
+            if ((tiles_f + 255) / 256 < (tiles + 255) / 256)
+                return f == 2 ? launch_split<2, 4, 64, 1, 2, 2, false, false, false, 0, false, false, false, 2>(d, st) : launch_split<2, 4, 64, 1, 2, 2, false, false, false, 0, false, false, false, 4>(d, st);
+        }
         return parts == 2 ? launch_split<2, 4, 64, 1, 2, 2, false>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false>(d, st);
     }
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;

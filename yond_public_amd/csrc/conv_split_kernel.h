@@ -143,7 +143,7 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0>
 __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD>;
-    static_assert(!FOLD || (!O4 && !S2 && ((!K1 && STRIDE == 1 && ISPM != 2 && OSP) || (STRIDE == 2 && ISPM == 2) || (K1 && ISPM == 2) || (!K1 && STRIDE == 1 && ISPM == 0 && !OSP && !PRE))),
+    static_assert(!FOLD || (!O4 && !S2 && ((!K1 && STRIDE == 1 && ISPM != 2 && OSP) || (STRIDE == 2 && (ISPM == 2 || (ISPM == 0 && !PRE && !D2))) || (K1 && ISPM == 2) || (!K1 && STRIDE == 1 && ISPM == 0 && !OSP && !PRE))),
                   "folded tiles: the split-plane data flow's kernels (3x3 stride 1: LDS-DMA or register-staged input, split-plane store; stride 2 and the decoder GEMM: register-staged split planes) "
                   "and the plain [N][H][W][C] 3x3 layer (training, UNetSeeInDark)");
     // split-plane input: ISPM 1 (ISP) by LDS-DMA, one step ahead -- the layers whose steps are long enough to cover the DMA's
@@ -1321,7 +1321,8 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 // ... and the stride-2 layers of the flow (split planes in, planes of 4 channels out, with and without the second, split-plane output)
 #define SPLIT_GROUP_FOLD_S2(X)                                                                          \
     X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true, 2) X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, false, 2)            \
-    X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true, 4) X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, false, 4)
+    X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true, 4) X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, false, 4)            \
+    X(2, 4, 64, 1, 2, 2, false, false, false, 0, false, false, false, 2) X(2, 4, 64, 1, 2, 2, false, false, false, 0, false, false, false, 4)
 #define SPLIT_GROUP_D2(X) X(2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true)
 #define SPLIT_GROUP_WRES(X)                                                                             \
     X(1, 16, 32, 2, 2, 2, true, false, false, false, true) X(1, 16, 32, 2, 2, 2, false, false, false, true, true) \

@@ -75,5 +75,4 @@ if Cc >= 64:
     for _ in range(3):
         plan._conv(pcu, cur, skip, 1, hl, wl, up, algo='split', in_fmt=1, out_fmt=2)
     torch.cuda.synchronize()
-    show("yond_split_debug_read_k1_wide" if (Cc % 128 == 0 and wl > 16) else "yond_split_debug_read_isp_k1s2",
-         "decoder GEMM: split-plane inputs (>= 128 channels: 128-column tiles by LDS-DMA; else through the register pipeline), planes-of-4 pixel-shuffle store")
+    show("yond_split_debug_read_isp_k1s2", "decoder GEMM: split-plane inputs through the register pipeline, planes-of-4 pixel-shuffle store")

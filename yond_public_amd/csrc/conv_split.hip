@@ -12,7 +12,6 @@ SPLIT_GROUP_FOLD(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD_S2(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD_K1(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD_NHWC(SPLIT_EXTERN)
-SPLIT_GROUP_K1_WIDE(SPLIT_EXTERN)
 SPLIT_GROUP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP_OSP(SPLIT_EXTERN)
@@ -39,7 +38,7 @@ extern "C" int yond_conv_split_supported(int ksize, int stride, int cin, int cou
 // ksize 1 (w = the re-indexed [4*cout][cin][1][1] matrix of a transposed convolution): [cout tile][step of 48 channels]
 // [chunk of 16][channel half][part][tn][8 halves].
 extern "C" int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst) {
-    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && ((parts == 1 && ksize == 3) || (parts == 2 && ksize == 1)))) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
+    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && parts == 1 && ksize == 3)) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
     _Float16* o = (_Float16*)dst;
     for (size_t i = 0, n = (size_t)cout * cin * ksize * ksize; i < n; ++i)
         if (!(fabsf(w[i]) <= 65504.0f)) return YOND_EUNSUPPORTED;          // its h half would be +-inf
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(256) void pack_split_weight_kernel(const float* __r
 
 extern "C" int yond_pack_conv_split_weight_dev_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst, int* status,
                                                    void* stream) {
-    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && ((parts == 1 && ksize == 3) || (parts == 2 && ksize == 1)))) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
+    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && parts == 1 && ksize == 3)) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
     if (ksize == 1 && cin % 48 != 0) return YOND_EINVAL;
     const int taps = ksize * ksize;
     const size_t ngroups = (size_t)cout * cin * taps * parts / 8;
@@ -181,10 +180,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     // h-only operands (algo 4) may be packed for 128-channel tiles: 3x3 stride-1 layers with plain tensors (conv_split_kernel.h, HALF128)
     const bool half128 = parts == 1 && d.tn == 128 && tn == 64 && d.ksize == 3 && d.stride == 1 && d.Cout % 128 == 0 && !d.in_fmt && !d.out_fmt &&
                          !d.res_fmt && !d.out4_dst && !d.dst2;
-    // the decoder GEMM of >= 128-channel output pixels may be packed for 128-column tiles: split-plane inputs by LDS-DMA (conv_split_kernel.h, K1 wide)
-    const bool k1wide = parts == 2 && d.tn == 128 && tn == 64 && d.ksize == 1 && d.shuffle == 1 && (d.Cout / 4) % 128 == 0 && d.in_fmt == YOND_FMT_SPLIT_PLANES &&
-                        d.out_fmt != YOND_FMT_SPLIT_PLANES && d.src1 && !d.res && !d.pre_act && !d.out4_dst && d.post_act != 1;
-    if (d.tn != tn && !half128 && !k1wide) return YOND_EINVAL;             // the layout the weights were packed for
+    if (d.tn != tn && !half128) return YOND_EINVAL;             // the layout the weights were packed for
     if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
     // tensor formats (include/yond_hip.h): split planes in (LDS-DMA staging) / out (stored from the accumulator layout), planes
     // of 4 channels for the float32 tensors that are read as residuals
@@ -212,7 +208,6 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.ksize == 1) {
         // the decoder GEMM: low-resolution input (C0) + skip tensor at the output resolution (C1), pixel-shuffle store
         if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W || osp || ip4) return YOND_EUNSUPPORTED;
-        if (k1wide) return launch_split<1, 8, 128, 2, 2, 2, false, false, true, 1>(d, st);
         if (isp && tn == 64 && d.Wo <= 16 && d.src1 && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
             // input at most 16 pixels wide: 2 / 4 sub-tiles per MFMA row (conv_split_kernel.h, FOLD) when that saves a round of 256 workgroups
             const int f = d.Wo <= 8 ? 4 : 2;

@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                                 if (flags == decltype(fcx)::value) epilogue_sp(fcx, IntC<-1>{}, cur);
                             }
                         });
-                } else if (K1 && (FOLD != 0 || TN == 128 || d.out_fmt == YOND_FMT_PLANES4)) {
+                } else if (K1 && (FOLD != 0 || d.out_fmt == YOND_FMT_PLANES4)) {
                     epilogue_direct(cur);                          // (planes of 4 channels: stored from the accumulator layout)
                 } else if constexpr (EP_FIT) {
                     float* scr = C::EP_OWN ? smem + C::EP_OFF : (EP_IN_W ? w0 : ibuf);
@@ -1315,8 +1315,6 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
     X(1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 2) X(1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 2)         \
     X(1, 4, 64, 1, 2, 3, false, false, false, true, true, false, false, 4) X(1, 4, 64, 1, 2, 3, true, false, false, false, true, false, false, 4)
 // ... the decoder GEMMs (no halo: the sub-tiles lie side by side as the columns of one tile do)
-// the decoder GEMM on 128-column tiles with LDS-DMA input: 36 MFMAs per wave and step instead of 18, no staging work (experiment: engine.K1_WIDE)
-#define SPLIT_GROUP_K1_WIDE(X) X(1, 8, 128, 2, 2, 2, false, false, true, 1)
 // ... the plain [N][H][W][C] layer (training's forward and data-gradient convolutions, UNetSeeInDark's deep stages)
 #define SPLIT_GROUP_FOLD_NHWC(X) X(1, 4, 64, 1, 2, 3, false, false, false, 0, false, false, false, 2) X(1, 4, 64, 1, 2, 3, false, false, false, 0, false, false, false, 4)
 #define SPLIT_GROUP_FOLD_K1(X) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 2) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 4)

@@ -49,10 +49,6 @@ FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue 
 FUSE_BLOCK0 = False                 # the two level-0 residual blocks as ONE launch each (csrc/block0_fused.hip: the tensor between the convolutions stays in
                                     # LDS).  Built, parity-tested, measured (round 5): 1.16 GB less HBM traffic per block and +1.0 % per forward -- level 0 is
                                     # bound by its vector work (SiLU + split three times per block), not by bytes: profiles/r05_experiments/README.md.  Off.
-K1_WIDE = False                     # the decoder GEMMs with >= 128-channel output pixels on 128-column tiles with LDS-DMA input (conv_split_kernel.h, K1 wide:
-                                    # 36 MFMAs per wave and step instead of 18, no staging work).  Built, bit-equal, measured (round 5): 149-151 us against
-                                    # 104-108 at 256 channels, 141 against 127-129 at 128 -- the step takes 8,900 cycles for twice the MFMAs of a 5,400-cycle
-                                    # step and the epilogue doubles (profiles/r05_experiments/README.md section 8).  Off.
 K1_SUB2 = True                      # the decoder GEMMs with two sub-positions per channel tile (YondConvDesc.shuffle 2)
 SP_CONV1_MIN_LEVEL = 3              # from this level down a stride-2 layer also stores SiLU(x) in split planes (YondConvDesc.dst2), so that the
                                     # next block's conv1 stages by LDS-DMA alone (there conv1 would repeat the SiLU + split per output-channel tile)
@@ -147,9 +143,8 @@ class _PackedConv:
             self._packed['wino'] = (tn, torch.from_numpy(packed).to(self._dev))
         return self._packed['wino']
 
-    def split(self, parts=2, wide=False):
-        """(tn, weights packed for the split-operand fp16-MFMA kernel) or None when the layer does not fit it.
-        wide: the decoder GEMM's 128-column packing (its own cache entry: the [N][H][W][C] path keeps the 64-column one)."""
+    def split(self, parts=2):
+        """(tn, weights packed for the split-operand fp16-MFMA kernel) or None when the layer does not fit it."""
         lib = L.load()
         if self.shuffle != (self.ksize == 1) or (self.shuffle and parts != 2):
             return None                     # ksize 1: the decoder's pixel-shuffle GEMM only (48-channel steps, >= 64 channels)
@@ -159,8 +154,6 @@ class _PackedConv:
         if parts == 1 and HALF_TN128 and tn == 64 and self.ksize == 3 and self.stride == 1 and self.gemm_n % 128 == 0:
             tn = 128                        # h-only operands: one accumulator per block leaves room for two blocks per wave (conv_split_kernel.h)
         key = ('split', parts)
-        if wide and self.shuffle and parts == 2 and tn == 64 and (self.gemm_n // 4) % 128 == 0:
-            tn, key = 128, ('split', parts, 128)
         if key not in self._packed:
             packed = np.empty(self._wp.size * parts // 2, np.float32)
             rc = lib.yond_pack_conv_split_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn, parts, _np_ptr(packed))
@@ -204,7 +197,7 @@ class _PackedUpSub2:
         self.wmax = float(np.abs(self._wp).max())
         self.macs_per_pixel = 2 * c * c * 4 + 2 * c * c * 4
 
-    def split(self, parts=2, wide=False):
+    def split(self, parts=2):
         return (64, self.wpk) if (self.ok and parts == 2) else None
 
     def wino(self):
@@ -381,8 +374,7 @@ class DenoiserPlan:
         fp16 = prec == 'fp16' or algo == 'fp16'
         wino = split = None
         if algo in ('split', 'half'):
-            # (the decoder GEMM of the split-plane flow on images too wide for folded tiles: 128-column tiles)
-            split = pc.split(2 if algo == 'split' else 1, wide=K1_WIDE and in_fmt == 1 and out_fmt != 1 and W > 16 and src1 is not None)
+            split = pc.split(2 if algo == 'split' else 1)
             if split is None and not fp16 and pc.ksize == 3:
                 wino = pc.wino()                     # 3x3 layers the split kernel does not take
         elif not fp16:

@@ -419,6 +419,17 @@ def test_decoder_gemm_split_plane_inputs(c, h, w, N):
     torch.cuda.synchronize()
     assert torch.equal(got.cpu(), ref.cpu())
     assert torch.equal(from_p4(gp4, N, 2 * h, 2 * w, c), ref.cpu())
+    if c >= 64 and w > 16:
+        # the second output (YondConvDesc.dst2): SiLU of the value in split planes, what the next block's conv1 stages by LDS-DMA
+        gp4b = torch.empty(N * c * 4 * h * w, device=DEV)
+        second = plan._new_sp('second', N, 2 * h, 2 * w, c)
+        plan._conv(pc, to_sp(cur), to_sp(skip), N, h, w, gp4b, algo='split', in_fmt=1, out_fmt=2, dst2=second)
+        torch.cuda.synchronize()
+        assert torch.equal(gp4b.cpu(), gp4.cpu())
+        val, pads = sp_decode(second, N, c, 2 * h, 2 * w)
+        assert not pads.view(torch.int16).any()
+        want = F.silu(nchw(ref.cpu()).double())
+        assert float((val - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
 
 
 def test_conv3x3_split_fused_12_row_tiles():

@@ -12,6 +12,7 @@ SPLIT_GROUP_FOLD(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD_S2(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD_K1(SPLIT_EXTERN)
 SPLIT_GROUP_FOLD_NHWC(SPLIT_EXTERN)
+SPLIT_GROUP_K1_D2(SPLIT_EXTERN)
 SPLIT_GROUP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP(SPLIT_EXTERN)
 SPLIT_GROUP_ISP_OSP(SPLIT_EXTERN)
@@ -190,7 +191,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.res_fmt != YOND_FMT_NHWC_F32 && !rp4) return YOND_EINVAL;
     if (isp && d.pre_act) return YOND_EUNSUPPORTED;             // the producer applied the activation
     // second output (SiLU in split planes): the stride-2 layers with split-plane input and planes-of-4 output
-    if (d.dst2 && !(parts == 2 && isp && op4 && d.ksize == 3 && d.stride == 2 && d.Cout % 16 == 0)) return YOND_EUNSUPPORTED;
+    if (d.dst2 && !(parts == 2 && isp && op4 && ((d.ksize == 3 && d.stride == 2 && d.Cout % 16 == 0) || (d.ksize == 1 && d.shuffle == 1 && tn == 64 && (d.Cout / 4) % 64 == 0)))) return YOND_EUNSUPPORTED;
     if (rp4 != (osp && d.res != nullptr)) return YOND_EUNSUPPORTED;   // a split-plane store reads its residual in planes of 4, nothing else does
     if (osp && d.res && !isp) return YOND_EUNSUPPORTED;              // ... and only conv2 of a block has one: split-plane input
     if (ip4 && (long long)d.N * (d.C0 > d.C1 ? d.C0 : d.C1) * d.H * d.W * (d.ksize == 1 ? 4 : 1) >= 0x7fffffffLL) return YOND_EUNSUPPORTED;   // 32-bit element offsets
@@ -208,7 +209,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (d.ksize == 1) {
         // the decoder GEMM: low-resolution input (C0) + skip tensor at the output resolution (C1), pixel-shuffle store
         if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W || osp || ip4) return YOND_EUNSUPPORTED;
-        if (isp && tn == 64 && d.Wo <= 16 && d.src1 && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
+        if (isp && tn == 64 && d.Wo <= 16 && d.src1 && !d.dst2 && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
             // input at most 16 pixels wide: 2 / 4 sub-tiles per MFMA row (conv_split_kernel.h, FOLD) when that saves a round of 256 workgroups
             const int f = d.Wo <= 8 ? 4 : 2;
             const long long subs = (long long)d.N * ((d.Ho + 7) / 8) * ((d.Wo + 32 / f - 1) / (32 / f));
@@ -217,6 +218,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
             if (fits && (tiles_f + 255) / 256 < (tiles + 255) / 256)
                 return f == 2 ? launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 2>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 4>(d, st);
         }
+        if (isp && d.dst2) return launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, true>(d, st);
         if (isp) return tn == 32 ? launch_split<1, 8, 32, 1, 2, 3, false, false, true, 2>(d, st) : launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2>(d, st);
         if (tn == 32) return launch_split<1, 8, 32, 1, 2, 3, false, false, true>(d, st);    // level 1 -> 0: 32-channel output pixels
         return launch_split<1, 8, 64, 2, 2, 3, false, false, true>(d, st);

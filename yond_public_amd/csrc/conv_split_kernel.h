@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     static_assert(ISPM == 0 || (!PRE && PARTS == 2), "split-plane input: the producer applied the activation; split precision only");
     static_assert(!OSP || (!O4 && !K1 && STRIDE == 1 && PARTS == 2), "split-plane output: 3x3 stride-1 layers at split precision");
     static_assert(!S2 || (K1 && ISPM == 2 && TN == 64), "two sub-positions per tile: the decoder GEMM with register-staged split planes");
-    static_assert(!D2 || (PARTS == 2 && !OSP && !O4 && !K1 && STRIDE == 2), "second output: the stride-2 layers at split precision");
+    static_assert(!D2 || (PARTS == 2 && !OSP && !O4 && ((!K1 && STRIDE == 2) || (K1 && ISPM == 2 && !S2 && TN == 64))), "second output: the stride-2 layers and the decoder GEMM at split precision");
     constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
     constexpr int NIN = ISP ? 0 : C::NIN;                    // register-staged 16-byte items per thread and step
     constexpr int NINA = NIN > 0 ? NIN : 1;                  // (array extents)
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                                 if (flags == decltype(fcx)::value) epilogue_sp(fcx, IntC<-1>{}, cur);
                             }
                         });
-                } else if (K1 && (FOLD != 0 || d.out_fmt == YOND_FMT_PLANES4)) {
+                } else if (K1 && (FOLD != 0 || D2 || d.out_fmt == YOND_FMT_PLANES4)) {
                     epilogue_direct(cur);                          // (planes of 4 channels: stored from the accumulator layout)
                 } else if constexpr (EP_FIT) {
                     float* scr = C::EP_OWN ? smem + C::EP_OFF : (EP_IN_W ? w0 : ibuf);
@@ -1317,6 +1317,8 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 // ... the decoder GEMMs (no halo: the sub-tiles lie side by side as the columns of one tile do)
 // ... the plain [N][H][W][C] layer (training's forward and data-gradient convolutions, UNetSeeInDark's deep stages)
 #define SPLIT_GROUP_FOLD_NHWC(X) X(1, 4, 64, 1, 2, 3, false, false, false, 0, false, false, false, 2) X(1, 4, 64, 1, 2, 3, false, false, false, 0, false, false, false, 4)
+// the decoder GEMM that also stores SiLU(value) in split planes (YondConvDesc.dst2: the next block's conv1 then stages by LDS-DMA alone)
+#define SPLIT_GROUP_K1_D2(X) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, true)
 #define SPLIT_GROUP_FOLD_K1(X) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 2) X(1, 8, 64, 2, 2, 3, false, false, true, 2, false, false, false, 4)
 // ... and the stride-2 layers of the flow (split planes in, planes of 4 channels out, with and without the second, split-plane output)
 #define SPLIT_GROUP_FOLD_S2(X)                                                                          \

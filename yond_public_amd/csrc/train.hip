@@ -11,6 +11,22 @@
 // the MFMA (one 4-byte load per operand and lane), partial sums are combined with float atomics.
 #include "common.h"
 
+// Zero-fill on the stream as a KERNEL, not hipMemsetAsync: the training step is replayed as a captured hipGraph, and the memset NODES of such a
+// graph did not reliably precede the kernels that accumulate (atomicAdd) onto the cleared buffers -- after an idle spell a replay now and then
+// summed onto whatever the buffer held (bias / FiLM gradients of 1e35, then NaN parameters: found with tools/probe/poison_run.py, which fills
+// every torch.empty with NaN).  Kernel nodes of one stream keep their order.
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned int* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 4;                                  // (every caller clears float / double arrays)
+    if (!n) return hipSuccess;
+    size_t nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)nb), dim3(256), 0, st, (unsigned int*)p, n);
+    return hipGetLastError();
+}
+
 struct WgradGeom {
     int N, H, W, Cin;          // X: [N][H][W][Cin]
     int Ho, Wo, Cout;          // dY: [N][Ho][Wo][Cout]
@@ -372,7 +388,7 @@ extern "C" int yond_conv_wgrad_ws_f32(const float* x, const float* dy, int N, in
     WgradGeom g{N, H, W, Cin, Ho, Wo, Cout, mode, stride, mode == 0 ? 9 : (mode == 1 ? 4 : 1), 0};
     hipStream_t st = (hipStream_t)stream;
     if (!ws) {                                                       // the atomics path sums into a zeroed output
-        hipError_t e = hipMemsetAsync(dw, 0, (size_t)g.taps * Cout * Cin * sizeof(float), st);
+        hipError_t e = zero_async(dw, (size_t)g.taps * Cout * Cin * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
     const bool two = Cout % 64 == 0;
@@ -436,7 +452,7 @@ __global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restric
 
 extern "C" int yond_colsum_f32(const float* dy, size_t npix, int C, float* db, void* stream) {
     if (!dy || !db || npix == 0 || C <= 0 || C % 32) return YOND_EINVAL;
-    hipError_t e = hipMemsetAsync(db, 0, (size_t)C * sizeof(float), (hipStream_t)stream);
+    hipError_t e = zero_async(db, (size_t)C * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     const int c4 = C / 4;
     if (C <= 256 && 256 % c4 == 0) {                         // C = 32, 64, 128, 256: the 16-byte form (thread = channel needs C <= 256)
@@ -531,8 +547,8 @@ extern "C" int yond_film_silu_bwd_f32(const float* z, const float* tk, const flo
                                       int N, size_t P, int C, void* stream) {
     if (!z || !tk || !tb || !dout || !dz || !dtk || !dtb || !film_silu_shape_ok(N, (long long)P, C)) return YOND_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dtk, 0, (size_t)N * C * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(dtb, 0, (size_t)N * C * sizeof(float), st);
+    hipError_t e = zero_async(dtk, (size_t)N * C * sizeof(float), st);
+    if (e == hipSuccess) e = zero_async(dtb, (size_t)N * C * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     const int ppw = 256 / (C / 4);
     size_t nb = (P + (size_t)ppw * 8 - 1) / ((size_t)ppw * 8);
@@ -884,7 +900,7 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ pred,
 
 extern "C" int yond_l1_loss_f32(const float* pred, const float* target, size_t n, double* loss_sum, float* grad, void* stream) {
     if (!pred || !target || !loss_sum || n == 0) return YOND_EINVAL;
-    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), (hipStream_t)stream);
+    hipError_t e = zero_async(loss_sum, sizeof(double), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     size_t nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;
@@ -919,7 +935,7 @@ __global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restric
 extern "C" int yond_charbonnier_loss_f32(const float* pred, const float* target, size_t n, double eps, double* loss_sum, float* grad,
                                          void* stream) {
     if (!pred || !target || !loss_sum || n == 0 || !(eps > 0.0)) return YOND_EINVAL;
-    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), (hipStream_t)stream);
+    hipError_t e = zero_async(loss_sum, sizeof(double), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     size_t nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;

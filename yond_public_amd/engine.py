@@ -50,6 +50,9 @@ FUSE_BLOCK0 = False                 # the two level-0 residual blocks as ONE lau
                                     # LDS).  Built, parity-tested, measured (round 5): 1.16 GB less HBM traffic per block and +1.0 % per forward -- level 0 is
                                     # bound by its vector work (SiLU + split three times per block), not by bytes: profiles/r05_experiments/README.md.  Off.
 K1_SUB2 = True                      # the decoder GEMMs with two sub-positions per channel tile (YondConvDesc.shuffle 2)
+K1_D2_LEVELS = (3,)                 # decoder levels whose GEMM also stores SiLU(x) in split planes for the block's conv1 (YondConvDesc.dst2), as the stride-2
+                                    # layers do from SP_CONV1_MIN_LEVEL down.  Measured per (GEMM + conv1) pair, two runs each (tools/layer_times.py, K1_D2_LEVELS=...):
+                                    # level 3 274 -> 254-262 us, level 2 302 -> 293-303, level 1 362 -> 357-361: kept where it is clear of the noise.  () = off
 SP_CONV1_MIN_LEVEL = 3              # from this level down a stride-2 layer also stores SiLU(x) in split planes (YondConvDesc.dst2), so that the
                                     # next block's conv1 stages by LDS-DMA alone (there conv1 would repeat the SiLU + split per output-channel tile)
 UNET_SP = True                      # UNetSeeInDark: the tensor between the two convolutions of a stage in split planes (LeakyReLU applied by the producer)
@@ -592,7 +595,10 @@ class DenoiserPlan:
                     # ConvT 2x2 s2 + the block's 1x1 shortcut over [up, skip] as one GEMM with a pixel-shuffle store
                     xs = self._new(N, 2 * h, 2 * w, cp)
                     up = blk['upsc2'] if (flow and K1_SUB2 and 'upsc2' in blk) else blk['upsc']
-                    self._conv(up, cur, skips[10 - i], N, h, w, xs, in_fmt=SP if flow else 0, out_fmt=xfmt)
+                    # (decoder level of block i = 9 - i; images too narrow for the unfolded GEMM keep the folded kernels, which have no second output)
+                    xsp = (self._new_sp(('xspd', i), N, 2 * h, 2 * w, cp)
+                           if (flow and not last and (9 - i) in K1_D2_LEVELS and up is blk['upsc'] and cp >= 64 and w > 16) else None)
+                    self._conv(up, cur, skips[10 - i], N, h, w, xs, in_fmt=SP if flow else 0, out_fmt=xfmt, dst2=xsp)
                     h, w = 2 * h, 2 * w
                     cur = xs
                 # z = conv2(SiLU(FiLM(conv1(SiLU(x))))) + x : the first SiLU runs in conv1's staging (x has other readers); the

@@ -215,8 +215,7 @@ __global__ __launch_bounds__(256) void film_kernel(const YondFilmDesc* __restric
     const YondFilmDesc d = descs[blockIdx.y];
     const int n = blockIdx.z;
     const int C = d.C;
-    const int row0 = blockIdx.x * 32;
-    if (row0 >= C) return;
+    if ((int)blockIdx.x * 32 >= C) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float tv = t[n];
     if (ub) tv = tv / ub[n];
@@ -233,6 +232,9 @@ __global__ __launch_bounds__(256) void film_kernel(const YondFilmDesc* __restric
         Wm = d.w_b;
     }
     __syncthreads();
+    // (a batch launches gridDim.x < 32 row tiles per (block, image): a workgroup then walks the tiles blockIdx.x, + gridDim.x, ... -- 32 workgroups
+    // per (block, image) of which at most C / 32 do anything were 9,216 workgroups at batch 32, 5 of 6 of them dead on arrival)
+    for (int row0 = blockIdx.x * 32; row0 < C; row0 += gridDim.x * 32) {
     // a wave owns 8 rows and walks them together: 8 independent loads per column step instead of 8 latency-bound passes
     float acc8[8];
 #pragma unroll
@@ -272,11 +274,12 @@ __global__ __launch_bounds__(256) void film_kernel(const YondFilmDesc* __restric
             }
         }
     }
+    }
 }
 
 extern "C" int yond_film_f32(const YondFilmDesc* descs, int nblocks, const float* t, const float* ub, int N, void* stream) {
     if (!descs || !t || nblocks <= 0 || N <= 0 || N > 65535 || nblocks > 65535) return YOND_EINVAL;
-    dim3 grid(1024 / 32, nblocks, N);
+    dim3 grid(N >= 8 ? (unsigned)yond_exp_long("YOND_FILM_GX", 8) : 1024 / 32, nblocks, N);      // (row tiles per (block, image): all 32 for a few images -- latency --, 8 for a batch)
     hipLaunchKernelGGL(film_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, descs, t, ub);
     YOND_LAUNCH_CHECK();
     hipLaunchKernelGGL(film_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, descs, t, ub);

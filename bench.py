@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--min-warmup-s", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (no sequential / fp32-mfma / parity legs)")
+    ap.add_argument("--group", type=int, default=4, help="cfg 3: SIDD images denoised together (one batch-(32 x group) forward per round); 1 = one image at a time")
     ap.add_argument("--sequential", action="store_true", help="time one frame at a time (IterDenoise) instead of the two-stream driver")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiments: no HIP events around the kernels (no roofline objects)")
     ap.add_argument("--precision", default=None, choices=["fp32", "fp32-mfma", "fp16"],
@@ -297,6 +298,18 @@ def sidd_eval_item(item, net, arch, P):
     return res
 
 
+def sidd_eval_group(items, net, arch, P):
+    """G images of YOND_SIDD.eval as one group (yond_public_amd/YOND_SIDD.py eval, --group): round 1 of the G images is ONE batch-(32 G)
+    forward, round 2 another; estimates, tables, t and the block metrics stay per image (per image the results are sidd_eval_item's, bit for
+    bit: tests/test_hip_eval.py)."""
+    ress = P.IterDenoiseGroup([(it['lr'], it['lr_full']) for it in items], net, arch, SIDD_PIPE)
+    for res, it in zip(ress, items):
+        if len(res['raw_dns']) != 2:
+            raise SystemExit(f"bench.py: the SIDD pipeline ran {len(res['raw_dns'])} pass(es), expected 2 (regs {res['regs']})")
+        res['metrics'] = [P.block_metrics(dn, it['hr']) for dn in res['raw_dns']]
+    return ress
+
+
 def timed_region(run_step, steps, sync, D, dev):
     """EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides; returns (the MAX over ranks of the
     elapsed time, every rank's time for its own K steps -- taken before the closing barrier -- in rank order)."""
@@ -325,6 +338,18 @@ def check_world(a, D):
     return gw
 
 
+def static_notes():
+    """NOT measured by the run that prints them: constants and provenance a reader of the line may want beside it."""
+    return {"not_measured_by_this_run": True,
+            "scaling": ("this line is one point; the 1/2/4/8-GPU curve is the driver's SCALE_rNN.json where it had a multi-GPU node.  The path "
+                        "shards by images with no data-path collective (DESIGN section 6)"),
+            "bare_loop_ceiling_of_split_products": {
+                "issued_frac": 0.60, "algorithmic_frac": 0.20, "in_kernel_mhz": 1690,
+                "what": ("a bare loop of the three MFMAs per fp32 product block and their LDS fragment reads (no global memory, no barriers) "
+                         "under the board's power cap, measured ONCE by a probe"),
+                "source": "tools/probe/mfma_shape_probe.hip, profiles/r05_experiments/mfma_shape_probe.txt"}}
+
+
 def stub_main(a):
     """Tests only (YOND_BENCH_STUB=1; tests/test_bench_launcher.py): the launcher, the rendezvous, the timed-region protocol
     (barriers, max over ranks, per-rank gather) and rank 0's line with the hot path replaced by a sleep, on gloo -- so that the
@@ -341,7 +366,7 @@ def stub_main(a):
         n_timed = a.steps * a.frames_per_step
         print(json.dumps({"metric": "STUB (no GPU work: launcher / rendezvous / reduction plumbing only)", "value": round(world * n_timed * mp / elapsed, 2),
                           "unit": "Bayer MP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-                          "data": "stub", "collectives": dict(D.STATS, world_size=gw,
+                          "data": "stub", "static_notes": static_notes(), "collectives": dict(D.STATS, world_size=gw,
                                                                per_rank_mp_per_s=[round(n_timed * mp / t, 2) for t in per_rank],
                                                                per_rank=[{"rank": r, "mp_per_s": round(n_timed * mp / t, 2), "in_kernel_mhz": None}
                                                                          for r, t in enumerate(per_rank)])}), flush=True)
@@ -424,6 +449,9 @@ def main(argv=None):
         elif stream_driver and not sequential:
             for last in P.denoise_stream((frames[i % len(frames)] for i in range(nframes)), net, arch, pipe):
                 pass
+        elif a.cfg == 3 and a.group > 1:
+            for i in range(0, nframes, a.group):
+                last = sidd_eval_group([frames[(i + j) % len(frames)] for j in range(min(a.group, nframes - i))], net, arch, P)[-1]
         else:
             for i in range(nframes):
                 last = one(frames[i % len(frames)])
@@ -526,9 +554,25 @@ def main(argv=None):
         el = D.max_over_ranks(time.perf_counter() - t1, dev)
         if len(r_it['raw_dns']) != 2:
             raise SystemExit(f"bench.py: the 'iter' leg ran {len(r_it['raw_dns'])} pass(es), expected 2 (regs {r_it['regs']})")
-        iter_leg = {"value": round(world * n_it * H * W / 1e6 / el, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el / n_it * 1e3, 3),
-                    "frames": n_it, "passes_per_frame": 2,
-                    "definition": "pipeline 'iter' (self NLE + denoise, collaborative NLE + denoise), one frame at a time, synchronised after every frame"}
+        seq_ms = el / n_it * 1e3
+        # ... and on the two-stream driver (pipeline._denoise_stream_chain_iter: frame k's collaborative estimate under another frame's network pass)
+        for _ in P.denoise_stream((frames[i % len(frames)] for i in range(4)), net, arch, pipe_it):
+            pass
+        torch.cuda.synchronize()
+        D.barrier()
+        t1 = time.perf_counter()
+        n_st = 24
+        for r_it in P.denoise_stream((frames[i % len(frames)] for i in range(n_st)), net, arch, pipe_it):
+            pass
+        torch.cuda.synchronize()
+        el = D.max_over_ranks(time.perf_counter() - t1, dev)
+        if len(r_it['raw_dns']) != 2:
+            raise SystemExit(f"bench.py: the streamed 'iter' leg ran {len(r_it['raw_dns'])} pass(es), expected 2 (regs {r_it['regs']})")
+        iter_leg = {"value": round(world * n_st * H * W / 1e6 / el, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el / n_st * 1e3, 3),
+                    "frames": n_st, "passes_per_frame": 2,
+                    "one_frame_at_a_time_ms_per_frame": round(seq_ms, 3),
+                    "definition": "pipeline 'iter' (self NLE + denoise, collaborative NLE + denoise: the reference's shipped default) through denoise_stream: frame k's "
+                                  "estimates on a second HIP stream under other frames' network passes; `one_frame_at_a_time_ms_per_frame`: IterDenoise, synchronised after every frame"}
 
     stage_prof, prof_all = [], []
     if not a.no_kernel_events:
@@ -573,10 +617,6 @@ def main(argv=None):
             roof["algorithm"] = ("direct 3x3, fp32 operands split into two fp16 halves when staged into LDS (22-23 significant "
                                  "bits), 3 v_mfma_f32_32x32x16_f16 per fp32 product block, fp32 accumulate")
             roof["mfma_issued_tflops"] = round(3.0 * ach, 2)
-            # what the chip can ISSUE of this pattern at all: a bare loop of the three MFMAs and their LDS fragment reads (no global memory,
-            # no barriers, random data, full occupancy) reaches 0.60 of the peak and drops the clock to 1.69 GHz doing it (power cap)
-            roof["bare_loop_ceiling"] = {"issued_frac": 0.60, "algorithmic_frac": 0.20, "in_kernel_mhz": 1690,
-                                         "source": "tools/probe/mfma_shape_probe.hip, profiles/r05_experiments/mfma_shape_probe.txt"}
             roof["mfma_issued_frac"] = round(3.0 * ach / PEAK_F16_MFMA_TFLOPS, 4)
         others = {t: {"launches": v[0], "avg_launch_ms": round(v[1] / v[0], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
                   for t, v in per.items() if t != dom and is33(t)}
@@ -659,22 +699,35 @@ def main(argv=None):
         # the region proper; the reference's log shows 5.1 s per image on its authors' GPU)
         try:
             it3 = sidd_items(2, dev)
-            sidd_eval_item(it3[0], net, arch, P)
+            G3 = max(1, a.group)
+            grp3 = [it3[j % 2] for j in range(G3)]
+            sidd_eval_group(grp3, net, arch, P)
             torch.cuda.synchronize()
             t3, n3 = time.perf_counter(), 0
             while n3 < 8 or time.perf_counter() - t3 < 1.0:
-                r3 = sidd_eval_item(it3[n3 % 2], net, arch, P)
-                n3 += 1
+                r3 = sidd_eval_group(grp3, net, arch, P)[-1]
+                n3 += G3
             torch.cuda.synchronize()
             el3 = time.perf_counter() - t3
+            # ... and one image at a time (the reference's loop shape; round 5's number)
+            sidd_eval_item(it3[0], net, arch, P)
+            torch.cuda.synchronize()
+            t31, n31 = time.perf_counter(), 0
+            while n31 < 4 or time.perf_counter() - t31 < 0.5:
+                sidd_eval_item(it3[n31 % 2], net, arch, P)
+                n31 += 1
+            torch.cuda.synchronize()
+            el31 = time.perf_counter() - t31
             others["cfg3_sidd_eval"] = {"images_per_s": round(n3 / el3, 2), "ms_per_image": round(el3 / n3 * 1e3, 3),
                                         "value": round(n3 * 256 * 8192 / 1e6 / el3, 2), "unit": "Bayer MP/s (denoised blocks: 2.097 MP per image)",
                                         "full_frame_mp_per_s": round(n3 * SIDD_FULL[0] * SIDD_FULL[1] / 1e6 / el3, 1), "images": n3,
                                         "psnr_iter0_iter1": [round(float(np.mean(m[0])), 3) for m in r3['metrics']],
                                         "reference_s_per_image": REF_SIDD_S_PER_IMAGE,
                                         "workload": f"configs[2]: SIDD-shaped synthetic items ({SIDD_FULL[0]}x{SIDD_FULL[1]} estimate frame + 32 blocks of 256x256), "
-                                                    "YOND_SIDD.eval's loop body (IterDenoise 'iter' with batch-32 forwards + block metrics), one image at a time"}
-            others["cfg3_sidd_eval"]["roofline"] = leg_roofline(plan, lambda: sidd_eval_item(it3[0], net, arch, P), torch.cuda.synchronize)
+                                                    f"YOND_SIDD.eval's loop body (IterDenoise 'iter' + block metrics), {G3} images per group: round 1 of a group is ONE "
+                                                    f"batch-{32 * G3} forward, round 2 another; estimates / tables / metrics per image",
+                                        "group": G3, "one_image_at_a_time_ms_per_image": round(el31 / n31 * 1e3, 3)}
+            others["cfg3_sidd_eval"]["roofline"] = leg_roofline(plan, lambda: sidd_eval_group(grp3, net, arch, P), torch.cuda.synchronize)
             del it3, r3
         except Exception as e:
             others["cfg3_sidd_eval"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -764,7 +817,8 @@ def main(argv=None):
         if a.batch:
             driver = f"IterDenoiseBatch: per-frame NLE, ONE batched forward of {a.batch} frames"
         elif a.cfg == 3:
-            driver = "YOND_SIDD.eval's loop body per image: IterDenoise (batch-32 forwards) + block metrics, one image at a time"
+            driver = (f"YOND_SIDD.eval's loop body: IterDenoiseGroup of {a.group} images (round 1 = ONE batch-{32 * a.group} forward, round 2 another; estimates, tables, "
+                      "block metrics per image)" if a.group > 1 else "YOND_SIDD.eval's loop body per image: IterDenoise (batch-32 forwards) + block metrics, one image at a time")
         elif stream_driver:
             driver = "denoise_stream: NLE of frame k+1 on a second HIP stream while the convolutions of frame k run"
         else:
@@ -818,8 +872,7 @@ def main(argv=None):
                                 per_rank_mp_per_s=[round(a.steps * F * H * W / 1e6 / t, 2) for t in per_rank_s],
                                 per_rank=[{"rank": r, "mp_per_s": round(a.steps * F * H * W / 1e6 / t, 2), "in_kernel_mhz": round(m, 1) if m else None}
                                           for r, (t, m) in enumerate(zip(per_rank_s, per_rank_mhz))]),
-            "scaling_measured": ("this line is one point; a 1/2/4/8-GPU curve exists only where the driver had a multi-GPU node -- none in rounds 1-4 "
-                                 "(SCALE_r0N.json: skipped).  The path shards by images with no data-path collective (DESIGN section 6)"),
+            "static_notes": static_notes(),
         }
         if world == 1 and not a.no_cpu_baseline and not a.batch:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline_and_parity(a, arch, dev, make_net)

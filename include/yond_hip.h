@@ -26,7 +26,7 @@ extern "C" {
 #define YOND_EUNSUPPORTED (-2) /* valid request the kernels do not cover (e.g. channel count) */
 
 /* Library / device probe.  Returns the ABI version (this header: YOND_ABI_VERSION; the loader refuses a mismatch). */
-#define YOND_ABI_VERSION 7
+#define YOND_ABI_VERSION 8
 int yond_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -554,31 +554,6 @@ int yond_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, d
  * of the caller's, e.g. a non-finite loss). */
 int yond_adam_step_dev_f32(float* p, const float* g, float* m, float* v, size_t n, double beta1, double beta2, double eps,
                            const float* hyp, const int* status, void* stream);
-
-/* K2f: a whole LEVEL-0 residual block of the guided U-Net (32 -> 32 -> 32 channels; archs/modules.py:186-196, archs/Unet.py:433, 461)
- * in ONE launch:   out = conv2( SiLU( conv1(SiLU(x)) * s1 + t1 ) ) * s2 + t2 + x.   The tensor between the two 3x3 convolutions never
- * leaves the chip (csrc/block0_fused.hip); split-operand arithmetic as yond_conv2d_f32 algo 3 (fp32-accurate products on the fp16 MFMA).
- *   x        block input, in_fmt YOND_FMT_PLANES4 ([N][8][H*W][4]) or YOND_FMT_NHWC_F32 ([N][H][W][32]); also the residual
- *   w1, w2   the two layers' weights as yond_pack_block0_weight_f32 lays them out (36,864 bytes each, device memory)
- *   s1..t2   [N][32] (ebatch != 0) or [32] float32 FiLM / bias vectors (the conv biases folded into t1 / t2 as yond_film_f32 does); NULL: 1 / 0
- *   dst      split planes (YOND_FMT_SPLIT_PLANES, raw values), or NULL with the fused output projection:
- *   out4_*   as in YondConvDesc: out4_dst[N][H][W][4] = (W4 . out + b4 + x4 / ub) * ub  (archs/Unet.py:463-468); the 32-channel tensor is not stored
- *   status   bit 0 set when a staged value leaves fp16's range (|a| > 65504) or is NaN. */
-typedef struct YondBlock0Desc {
-    const float* x;
-    int in_fmt, N, H, W;
-    const void *w1, *w2;
-    const float *s1, *t1, *s2, *t2;
-    int ebatch;
-    void* dst;
-    const float *out4_w, *out4_b, *out4_x, *out4_ub;
-    float* out4_dst;
-    int* status;
-} YondBlock0Desc;
-int yond_block0_fused_f32(const YondBlock0Desc* d /* host */, void* stream);
-/* Host-side packer: OIHW float32 [cout <= 32][cin <= 32][3][3] (host memory) -> 36,864 bytes (host memory) in the kernel's LDS order
- * [tap][part h, l][group of 8 input channels][32 output channels] x 8 halves; YOND_EUNSUPPORTED for a weight beyond fp16's range. */
-int yond_pack_block0_weight_f32(const float* w_oihw, int cout, int cin, void* out);
 
 /* Measurement aid (bench.py; not on the reference's path): one wave sleeps for `us` microseconds (<= 5 s) of wall time and
  * writes out[0] = elapsed shader cycles (s_memtime), out[1] = elapsed 100 MHz reference ticks (s_memrealtime): the clock

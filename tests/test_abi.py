@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # the ctypes prototype table covers the same set
     assert sorted(_lib.PROTOTYPES) == declared_symbols()
-    assert _lib.load().yond_abi_version() == 7
+    assert _lib.load().yond_abi_version() == 8
 
 
 def test_host_side_argument_checks_without_gpu():

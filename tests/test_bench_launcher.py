@@ -114,7 +114,7 @@ def test_cfg3_shortcut():
 def test_spawn_ranks_end_to_end_eight_gloo_ranks():
     """The same REAL launcher path at the width the scaling node has: `bench.py --gpus 8` starts eight ranks (gloo on CPU), the
     barriers / max over ranks / per-rank gather run over all eight, rank 0 alone prints the line, and the line says that no
-    hardware scaling curve stands behind it (`scaling_measured`)."""
+    hardware scaling curve stands behind it (`static_notes`: constants and provenance, marked as not measured by the run)."""
     import json
     r = _run_stub(["--gpus", "8", "--steps", "4", "--warmup", "1"], timeout=420)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -126,3 +126,4 @@ def test_spawn_ranks_end_to_end_eight_gloo_ranks():
     # rank 1 sleeps twice as long: value = 8 x the slowest rank's rate
     assert abs(out["value"] - 8 * min(c["per_rank_mp_per_s"])) <= 0.08 * out["value"]
     assert len(c["per_rank"]) == 8 and all("rank" in q and "mp_per_s" in q for q in c["per_rank"])
+    assert out["static_notes"]["not_measured_by_this_run"] is True and "SCALE_rNN" in out["static_notes"]["scaling"]

@@ -211,3 +211,31 @@ def test_prefetcher_orders_items_and_relays_errors():
     assert got == [5, 0, 3, 9, 1]
     assert [k for k, _ in Prefetcher(Slow(), [0, 1, 2, 3], 'cpu', workers=8, depth=1)] == [0, 1, 2, 3]
     assert list(Prefetcher(Slow(), [], 'cpu')) == []
+
+
+def test_prefetcher_look_ahead_is_gated_by_position():
+    """No worker starts position p before the consumer has taken p - depth: with one slow item (position 1) the other workers may
+    run at most `depth` positions past the consumer, and the slow position's worker is never starved of its turn."""
+    import threading
+    import time
+    from yond_public_amd.data import Prefetcher
+    started, lock = [], threading.Lock()
+
+    class Items:
+        def __len__(self):
+            return 40
+
+        def __getitem__(self, k):
+            with lock:
+                started.append(k)
+            if k == 1:
+                time.sleep(0.25)
+            return {'lr': np.zeros((1, 1), np.float32), 'name': str(k)}
+    pf = Prefetcher(Items(), list(range(40)), 'cpu', workers=4, depth=4)
+    seen = []
+    for k, _ in pf:
+        with lock:
+            ahead = max(started)
+        assert ahead < len(seen) + 1 + pf.depth, (ahead, len(seen))
+        seen.append(k)
+    assert seen == list(range(40))

@@ -728,6 +728,8 @@ def test_block0_fused_equals_the_two_launches(N, H, W, in_nhwc, out4):
     block (archs/modules.py:186-196); ragged tiles (H, W no multiples of 12 / 32), batch, both input formats, the zero pads untouched."""
     from yond_public_amd.engine import _PackedConv, DenoiserPlan
     from yond_public_amd import _lib as L
+    if not L.has("yond_block0_fused_f32"):
+        pytest.skip("the fused level-0 block (a measured no-go) exists only in experiment builds (python -m yond_public_amd.build --experiments)")
     C = 32
     g = torch.Generator().manual_seed(7 * H + W)
     x = torch.randn(N, C, H, W, generator=g)

@@ -53,6 +53,42 @@ def test_yond_sidd_eval_synthetic(tmp_path, monkeypatch):
     assert abs(red['psnr_last'] - np.mean(p1)) < 1e-9 and abs(red['ssim_last'] - np.mean(s1)) < 1e-12
 
 
+def test_grouped_images_equal_the_per_image_run_bit_for_bit(tmp_path, monkeypatch):
+    """YOND_SIDD.eval denoises `--group` images together (round 1 of the group = ONE batch-(32 G) forward, round 2 another): per image
+    the outputs of both rounds, the estimates and the logged metrics are those of the one-image IterDenoise, bit for bit -- three images of
+    different noise levels (a group of three = 96 blocks: other tile shapes / folded tiles than a batch of 32 takes), and the driver's
+    `--group 3` against `--group 1` on five images (groups of 3 + 2)."""
+    from yond_public_amd import YOND_SIDD as Y
+    from yond_public_amd import pipeline as P
+    monkeypatch.chdir(tmp_path)
+    trainer = Y.YOND_SIDD(['-f', RUNFILE, '-m', 'eval', '--synthetic', '5', '--group', '3'])
+    items = []
+    for j, (K, sg) in enumerate([(4.0, 6.0), (1.5, 3.0), (9.0, 14.0)]):
+        ds = Y.SyntheticSIDD(1, K=K, sigma=sg, full_hw=(1024, 1536))
+        ds._made = {}
+        d = ds[0]
+        items.append({k: (torch.from_numpy(np.ascontiguousarray(v)).to(DEV) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+    p = dict(trainer.pipe, wp=1023, bl=64, ratio=1, gain=1, sigma=0, scale=959.0)
+    singles = [trainer.IterDenoise(d, {'p': dict(p), 'img_id': i}) for i, d in enumerate(items)]
+    grouped = trainer.IterDenoiseGroup(items, [{'p': dict(p), 'img_id': i} for i in range(3)])
+    assert len({float(r['regs'][0][0]) for r in singles}) == 3                  # three different estimates
+    for a, b in zip(singles, grouped):
+        assert len(a['raw_dns']) == len(b['raw_dns']) == 2
+        for x, y in zip(a['raw_dns'], b['raw_dns']):
+            assert torch.equal(x, y)
+        assert [tuple(float(v) for v in r) for r in a['regs']] == [tuple(float(v) for v in r) for r in b['regs']]
+        assert [tuple(float(v) for v in r) for r in a['params']] == [tuple(float(v) for v in r) for r in b['params']]
+    # the driver: groups of 3 + 2 against one image at a time
+    red3 = trainer.eval(-1)
+    m3 = {k: dict(v) for k, v in trainer.metrics.items()}
+    trainer.parser.group = 1
+    red1 = trainer.eval(-1)
+    assert red1 == red3 and red3['count'] == 5
+    for k, v in trainer.metrics.items():
+        assert v['psnr'] == m3[k]['psnr'] and v['ssim'] == m3[k]['ssim']
+        assert [tuple(float(q) for q in r) for r in v['reg']] == [tuple(float(q) for q in r) for r in m3[k]['reg']]
+
+
 def test_yond_sidd_full_dn_runfile(tmp_path, monkeypatch):
     """A runfile with full_dn: True (the ELD / LRID / DND style of SURVEY 3.2) must run on the SIDD stack the dataset
     yields: the driver concatenates first, as YOND_SIDD.py:387-389 does."""

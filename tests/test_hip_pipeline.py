@@ -344,6 +344,39 @@ def test_denoise_stream_matches_iterdenoise():
         assert float((a_['raw_dns'][0] - b_['raw_dns'][0]).abs().max()) <= 5e-6      # two IterDenoise runs differ by up to 1e-6 themselves
 
 
+@pytest.mark.parametrize("weights", ["denoise", "procedural"])
+def test_denoise_stream_iter_matches_iterdenoise(weights):
+    """The reference's shipped mode (iter, max_iter 1; YOND_SIDD.py:419-472) on the two-stream driver: frame k's collaborative estimate and
+    parameter chain run on the side stream under another frame's network pass (pipeline._denoise_stream_chain_iter), round 2 is queued
+    speculatively -- and every frame must come out as IterDenoise returns it, both rounds.  With denoising weights every frame runs two
+    rounds; with procedural weights every frame's round 2 ends at the beta1 < 0 guard (:445-447, one output) -- the guard depends on the
+    network, so one stream cannot mix the two -- frames of two sizes, more frames than the driver's buffer ring holds."""
+    import yond_public_amd.pipeline as P
+    import yond_public_amd.archs as A
+    import yond_public_amd.synthetic as S
+    dev = torch.device('cuda:0')
+    arch = dict(name='GuidedResUnet', in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True, guided=True)
+    net = A.GuidedResUnet(dict(arch))
+    net.load_state_dict(S.denoising_state_dict(net, 0) if weights == "denoise" else S.procedural_state_dict(net, 0))
+    net = net.to(dev).eval()
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'iter', 'max_iter': 1, 'full_dn': True}
+    shapes = [(256, 320), (256, 320), (320, 448), (256, 320), (320, 448), (256, 320), (256, 320)]
+    frames = [torch.from_numpy(S.synth_noisy(h, w, 3.0 + i, 5.0 + 2 * i, 10 + i)[0]).to(dev) for i, (h, w) in enumerate(shapes)]
+    seq = [P.IterDenoise(f, net, arch, pipe) for f in frames]
+    assert P.STREAM_ITER
+    got = list(P.denoise_stream(iter(frames), net, arch, pipe))
+    one = list(P.denoise_stream(iter(frames[:1]), net, arch, pipe))                  # a single frame drains correctly
+    torch.cuda.synchronize()
+    assert len(got) == len(seq) and len(one) == 1
+    want_rounds = 2 if weights == "denoise" else 1
+    for a_, b_ in zip(got + one, seq + seq[:1]):
+        assert len(a_['raw_dns']) == len(b_['raw_dns']) == want_rounds and len(a_['regs']) == len(b_['regs']) == want_rounds
+        assert np.allclose(np.asarray(a_['regs'], np.float64), np.asarray(b_['regs'], np.float64), rtol=1e-9, atol=0)
+        assert np.allclose(np.asarray(a_['params'], np.float64), np.asarray(b_['params'], np.float64), rtol=1e-9, atol=0)
+        for x, y in zip(a_['raw_dns'], b_['raw_dns']):
+            assert float((x - y).abs().max()) <= 5e-6                    # (two IterDenoise runs differ by up to 1e-6 themselves: atomics in the moment sums)
+
+
 def test_cfg4_unet_batch8_full_size():
     """BASELINE cfg 4 at its real shape: UNetSeeInDark, batch 8 of 3000 x 4000 frames (packed, padded 1504 x 2016) in ONE
     forward; every item equals its batch-1 forward bit for bit (no cross-item coupling, deterministic tile arithmetic)."""

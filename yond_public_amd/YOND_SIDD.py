@@ -169,6 +169,33 @@ class YOND_SIDD:
         res['hr_raw'] = cat(data['hr']) if data.get('hr') is not None else None
         return res
 
+    def IterDenoiseGroup(self, datas, params_list):
+        """IterDenoise for several items at once (pipeline.IterDenoiseGroup): round 1 of the G images as ONE batch-(32 G) forward, round 2
+        likewise; every image keeps its own estimates, tables and t, and its result is IterDenoise's bit for bit.  The reference takes the
+        images one by one (:507-514); they are independent, and 32 blocks of 128 x 128 packed pixels leave the deep levels of a forward
+        (16 x 16 and 8 x 8 pixels) far too small for the chip."""
+        ress = P.IterDenoiseGroup([(d['lr'], d.get('lr_full')) for d in datas], self.net, self.arch, self.pipe, ps=[q['p'] for q in params_list],
+                                  device=self.device, log=(lambda s: log(s, self.logfile)) if self.parser.verbose else None, biaslut=self.biaslut,
+                                  ests=[{'root_dir': (getattr(self, 'dst', None) or {}).get('root_dir'), 'img_id': q.get('img_id'), 'name': d.get('name')}
+                                        for d, q in zip(datas, params_list)])
+        cat = lambda a: torch.cat(list(a), dim=-1) if isinstance(a, torch.Tensor) else np.concatenate(a, axis=-1)   # (:480-481)
+        for res, d in zip(ress, datas):
+            res['lr_raw'] = cat(d['lr'])
+            res['hr_raw'] = cat(d['hr']) if d.get('hr') is not None else None
+        return ress
+
+    def _groups(self, it):
+        """The prefetcher's items `group` at a time (consecutive items; the last group may be short)."""
+        G = max(1, int(getattr(self.parser, 'group', 1)))
+        batch = []
+        for k, data in it:
+            batch.append((k, data))
+            if len(batch) == G:
+                yield batch
+                batch = []
+        if batch:
+            yield batch
+
     def eval(self, epoch=-1):
         n_it = self.pipe['max_iter'] + 1 if self.pipe.get('iter') == 'iter' else 1
         sums = D.MetricSums(n_it)
@@ -186,25 +213,31 @@ class YOND_SIDD:
         # the items are read and uploaded by loader threads ahead of the GPU (the reference reads each in front of its IterDenoise,
         # :507-514): file reads, the float32 conversion and the 64 MB upload of the full frame overlap the previous images' kernels
         from .data import Prefetcher
-        for k, data in Prefetcher(self.dst_eval, mine, self.device, depth=self.parser.prefetch, workers=self.parser.loaders):
-            p['cfa'] = data.get('cfa', [[1, 2], [2, 3]])                                # YOND_SIDD.py:510
+        G = max(1, int(getattr(self.parser, 'group', 1)))
+        for batch in self._groups(Prefetcher(self.dst_eval, mine, self.device, depth=max(self.parser.prefetch, 2 * G), workers=self.parser.loaders)):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            res = self.IterDenoise(data, {'p': p, 'img_id': k})
-            psnrs, ssims = [], []
-            if res['hr_raw'] is not None:
-                hr = res['hr_raw'] if isinstance(res['hr_raw'], torch.Tensor) else torch.from_numpy(res['hr_raw']).to(self.device)
-                for dn in res['raw_dns']:
-                    ps, ss = P.block_metrics(dn, hr)                                   # :649-652 per 256x256 block
-                    psnrs.append(float(np.mean(ps)))
-                    ssims.append(float(np.mean(ss)))
-                sums.update(psnrs, ssims)        # iterations that did not run count -1 in their own meter (:644-647)
+            datas = [d for _, d in batch]
+            plist = [{'p': dict(p, cfa=d.get('cfa', [[1, 2], [2, 3]])), 'img_id': k} for k, d in batch]      # YOND_SIDD.py:510
+            if len(batch) == 1:
+                ress = [self.IterDenoise(datas[0], plist[0])]
+            else:
+                ress = self.IterDenoiseGroup(datas, plist)
+            for (k, data), res in zip(batch, ress):
+                psnrs, ssims = [], []
+                if res['hr_raw'] is not None:
+                    hr = res['hr_raw'] if isinstance(res['hr_raw'], torch.Tensor) else torch.from_numpy(res['hr_raw']).to(self.device)
+                    for dn in res['raw_dns']:
+                        ps, ss = P.block_metrics(dn, hr)                                   # :649-652 per 256x256 block
+                        psnrs.append(float(np.mean(ps)))
+                        ssims.append(float(np.mean(ss)))
+                    sums.update(psnrs, ssims)        # iterations that did not run count -1 in their own meter (:644-647)
+                self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
+                log(f"[rank {self.rank}] {data['name']}: PSNR={psnrs[-1] if psnrs else float('nan'):.2f}, "
+                    f"SSIM={ssims[-1] if ssims else float('nan'):.4f}", self.logfile)
             torch.cuda.synchronize()
-            t_path += time.perf_counter() - t1              # estimate + denoise (+ metrics) of this image
-            marks.append((time.perf_counter(), t_path))
-            self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
-            log(f"[rank {self.rank}] {data['name']}: PSNR={psnrs[-1] if psnrs else float('nan'):.2f}, "
-                f"SSIM={ssims[-1] if ssims else float('nan'):.4f}", self.logfile)
+            t_path += time.perf_counter() - t1              # estimate + denoise (+ metrics) of this group's images
+            marks.extend([(time.perf_counter(), t_path)] * len(batch))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         red = sums.reduce(self.device)                 # the ONE collective of the eval path (RCCL over xGMI)
@@ -246,14 +279,17 @@ class YOND_SIDD:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         from .data import Prefetcher
-        for k, data in Prefetcher(self.dst_eval, mine, self.device, depth=self.parser.prefetch, workers=self.parser.loaders):
-            p['cfa'] = data.get('cfa', [[1, 2], [2, 3]])
-            res = self.IterDenoise(data, {'p': p, 'img_id': k})
-            self.metrics.setdefault(data['name'], {})['reg_test'] = res['regs']                   # :597
-            first, last = res['raw_dns'][0].cpu().numpy(), res['raw_dns'][-1].cpu().numpy()
-            bench_init[k] = np.array(np.split(first, 32, axis=-1))                                # :612-613
-            bench_results[k] = np.array(np.split(last, 32, axis=-1))
-            log(f"[rank {self.rank}] {data['name']}: {len(res['raw_dns'])} round(s), regs {[tuple(float(v) for v in r) for r in res['regs']]}", self.logfile)
+        G = max(1, int(getattr(self.parser, 'group', 1)))
+        for batch in self._groups(Prefetcher(self.dst_eval, mine, self.device, depth=max(self.parser.prefetch, 2 * G), workers=self.parser.loaders)):
+            datas = [d for _, d in batch]
+            plist = [{'p': dict(p, cfa=d.get('cfa', [[1, 2], [2, 3]])), 'img_id': k} for k, d in batch]
+            ress = [self.IterDenoise(datas[0], plist[0])] if len(batch) == 1 else self.IterDenoiseGroup(datas, plist)
+            for (k, data), res in zip(batch, ress):
+                self.metrics.setdefault(data['name'], {})['reg_test'] = res['regs']                   # :597
+                first, last = res['raw_dns'][0].cpu().numpy(), res['raw_dns'][-1].cpu().numpy()
+                bench_init[k] = np.array(np.split(first, 32, axis=-1))                                # :612-613
+                bench_results[k] = np.array(np.split(last, 32, axis=-1))
+                log(f"[rank {self.rank}] {data['name']}: {len(res['raw_dns'])} round(s), regs {[tuple(float(v) for v in r) for r in res['regs']]}", self.logfile)
         torch.cuda.synchronize()
         dt = D.max_over_ranks(time.perf_counter() - t0, self.device)
         os.makedirs(f'npy/{self.method_name}', exist_ok=True)
@@ -282,7 +318,9 @@ class YONDParser:
                        "(40 = the SIDD validation set's size; each with a 3000 x 5328 frame for the round-1 estimate)")
         a.add_argument('--verbose', action='store_true', default=False)
         a.add_argument('--loaders', type=int, default=4, help="loader threads that read and upload the items ahead of the GPU")
-        a.add_argument('--prefetch', type=int, default=4, help="items the loader threads may be ahead of the GPU")
+        a.add_argument('--prefetch', type=int, default=4, help="items the loader threads may be ahead of the GPU (at least two groups)")
+        a.add_argument('--group', type=int, default=4, help="images denoised together: round 1 of a group is ONE batch-(32 x group) forward, round 2 another "
+                       "(per image the results are those of --group 1, bit for bit)")
         return a.parse_args(args)
 
 

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOND_HIP_LIB", os.path.join(_HERE, "libyond_hip.so"))   # override: experiments only
 _lib = None
-ABI_VERSION = 7                     # include/yond_hip.h YOND_ABI_VERSION
+ABI_VERSION = 8                     # include/yond_hip.h YOND_ABI_VERSION
 
 vp, i32, f32, f64, sz, i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_longlong
 
@@ -90,8 +90,6 @@ PROTOTYPES = {
     "yond_bias_lut_f64": [vp, i32, f64, f64, vp, vp],
     "yond_block_metrics_tiles": [i32, i32],
     "yond_block_metrics_f32": [vp, vp, i32, i32, i32, i32, vp, vp],
-    "yond_block0_fused_f32": [C.POINTER(YondBlock0Desc), vp],
-    "yond_pack_block0_weight_f32": [vp, i32, i32, vp],
     "yond_clock_probe": [f64, vp, vp],
     "yond_conv_wgrad_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "yond_conv_wgrad_ws_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp],
@@ -133,6 +131,8 @@ PROTOTYPES = {
 EXPERIMENT_PROTOTYPES = {
     "yond_box_stats_self_fused_f32": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
     "yond_box_stats_collab_fused_f32": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
+    "yond_block0_fused_f32": [C.POINTER(YondBlock0Desc), vp],          # the fused level-0 block (round 5: measured no-go)
+    "yond_pack_block0_weight_f32": [vp, i32, i32, vp],
 }
 _SIZE_T_RET = {"yond_select_ws_bytes", "yond_nle_ws_bytes", "yond_lut_ws_bytes", "yond_bias_lut_big_scratch", "yond_bias_points_scratch",
                "yond_conv_wgrad_ws_bytes", "yond_conv_wgrad_split_ws_bytes"}

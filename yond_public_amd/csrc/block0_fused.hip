@@ -23,7 +23,9 @@
 //   weights [layer][tap][part][kg][32 output channels] x 16 bytes.
 // Per tile: conv1 (32 items x 9 taps x 6 MFMAs) | barrier | epilogue 1 -> mid | barrier | conv2 (24 items: 12 rows x 2 halves, 3 per
 // wave) with the NEXT tile's input loads and this tile's residual loads in flight | epilogue 2 -> HBM | barrier | stage the next input.
+#ifdef YOND_EXPERIMENTS     // (a measured no-go, built into experiment libraries only: include/yond_hip_experiments.h)
 #include "common.h"
+#include "../../include/yond_hip_experiments.h"
 
 typedef _Float16 b0_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 b0_f16x4 __attribute__((ext_vector_type(4)));
@@ -520,3 +522,4 @@ extern "C" int yond_block0_fused_f32(const YondBlock0Desc* dp, void* stream) {
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
+#endif  // YOND_EXPERIMENTS

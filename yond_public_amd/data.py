@@ -309,14 +309,56 @@ def item_sizes(ds):
     return out
 
 
+class _PinnedPool:
+    """Pinned staging buffers shared by a Prefetcher's workers: (key, shape) -> buffers with the event of their last upload.  A buffer is handed
+    out again once that event has completed; buffers of shapes that have not been used lately are dropped when the pool would grow past `budget`
+    bytes (five SIDD frame sizes x per-worker double buffers had pinned ~2.5 GB of host memory)."""
+
+    def __init__(self, budget=1 << 30):
+        import threading
+        self.lock, self.bufs, self.bytes, self.budget, self.clock = threading.Lock(), {}, 0, int(budget), 0
+
+    def take(self, key, shape):
+        import torch
+        pk = (key, tuple(shape))
+        with self.lock:
+            self.clock += 1
+            lst = self.bufs.setdefault(pk, [])
+            for b in lst:
+                if not b['busy'] and (b['ev'] is None or b['ev'].query()):
+                    b['busy'], b['used'] = True, self.clock
+                    return b
+            need = 4
+            for d in shape:
+                need *= int(d)
+            if self.bytes + need > self.budget:                             # drop idle buffers of other shapes, least recently used first
+                idle = sorted(((b['used'], k2, b) for k2, l2 in self.bufs.items() if k2 != pk for b in l2
+                               if not b['busy'] and (b['ev'] is None or b['ev'].query())), key=lambda t: t[0])
+                for _, k2, b in idle:
+                    if self.bytes + need <= self.budget:
+                        break
+                    self.bufs[k2].remove(b)
+                    self.bytes -= b['t'].numel() * 4
+            b = {'t': torch.empty(tuple(shape), dtype=torch.float32).pin_memory(), 'ev': None, 'busy': True, 'used': self.clock}
+            lst.append(b)
+            self.bytes += need
+            return b
+
+    def give(self, b, ev):
+        with self.lock:
+            b['ev'], b['busy'] = ev, False
+
+
 class Prefetcher:
     """`for k, data in Prefetcher(ds, indices, device)`: the items `ds[k]` in the order of `indices`, read by `workers` background
     threads up to `depth` items ahead; every numpy array under the keys of `upload` arrives as a float32 DEVICE tensor (copied into
-    a reused pinned buffer, sent on the worker's own copy stream; the consumer's current stream is made to wait for the copy's event,
-    so no host synchronisation happens on the consumer's side).  Everything else in the item is passed through.  An exception in a
-    worker is re-raised at the item it belongs to."""
+    a reused pinned buffer of a pool the workers share, sent on the worker's own copy stream; the consumer's current stream is made to wait
+    for the copy's event, so no host synchronisation happens on the consumer's side).  Everything else in the item is passed through.  An
+    exception in a worker is re-raised at the item it belongs to.
+    The look-ahead is gated by POSITION: the worker of position p starts once p < consumed + depth.  (A counting semaphore lets workers that
+    have already delivered take every permit for positions beyond the one the consumer is blocked on, while that position's worker starves.)"""
 
-    def __init__(self, ds, indices, device, upload=('lr', 'hr', 'lr_full'), depth=4, workers=4):
+    def __init__(self, ds, indices, device, upload=('lr', 'hr', 'lr_full'), depth=4, workers=4, pinned_budget=1 << 30):
         import queue
         import threading
         import torch
@@ -324,8 +366,10 @@ class Prefetcher:
         self.workers = max(1, min(int(workers), len(self.indices) or 1))
         self.depth = max(self.workers, int(depth))
         self._slots = [queue.Queue(maxsize=1) for _ in self.indices]        # one-shot mailboxes, filled out of order, read in order
-        self._gate = threading.Semaphore(self.depth)                        # items loaded but not yet consumed
+        self._cv = threading.Condition()
+        self._consumed = 0                                                  # positions the consumer has taken
         self._stop = False
+        self._pool = _PinnedPool(pinned_budget)
         self._threads = [threading.Thread(target=self._work, args=(w,), daemon=True) for w in range(self.workers)]
         for t in self._threads:
             t.start()
@@ -333,12 +377,11 @@ class Prefetcher:
     def _work(self, w):
         import torch
         stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
-        pool = {}                                                           # (key, shape) -> [pinned buffer, event of its last copy] x 2
-        turn = {}
         for pos in range(w, len(self.indices), self.workers):
-            self._gate.acquire()
-            if self._stop:
-                return
+            with self._cv:
+                self._cv.wait_for(lambda: self._stop or pos < self._consumed + self.depth)
+                if self._stop:
+                    return
             k = self.indices[pos]
             try:
                 data = dict(self.ds[k])
@@ -350,21 +393,13 @@ class Prefetcher:
                     if stream is None:
                         data[key] = torch.from_numpy(np.ascontiguousarray(a, np.float32))
                         continue
-                    pk = (key, a.shape)
-                    bufs = pool.setdefault(pk, [])
-                    i = turn.get(pk, 0)
-                    turn[pk] = i + 1
-                    if len(bufs) < 2:
-                        bufs.append([torch.empty(a.shape, dtype=torch.float32).pin_memory(), None])
-                    buf = bufs[i % 2]
-                    if buf[1] is not None:
-                        buf[1].synchronize()                                # the buffer's previous upload has left it
-                    buf[0].numpy()[...] = a                                 # (converts to float32 on the way)
+                    buf = self._pool.take(key, a.shape)
+                    buf['t'].numpy()[...] = a                               # (converts to float32 on the way)
                     with torch.cuda.stream(stream):
-                        data[key] = buf[0].to(self.device, non_blocking=True)
+                        data[key] = buf['t'].to(self.device, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(stream)
-                    buf[1] = ev
+                    self._pool.give(buf, ev)
                 self._slots[pos].put((k, data, ev, None))
             except BaseException as e:                                      # noqa: BLE001 -- handed to the consumer
                 self._slots[pos].put((k, None, None, e))
@@ -374,7 +409,9 @@ class Prefetcher:
         try:
             for pos in range(len(self.indices)):
                 k, data, ev, err = self._slots[pos].get()
-                self._gate.release()
+                with self._cv:
+                    self._consumed = pos + 1
+                    self._cv.notify_all()
                 if err is not None:
                     raise err
                 if ev is not None:
@@ -385,6 +422,6 @@ class Prefetcher:
                             data[key].record_stream(cur)
                 yield k, data
         finally:
-            self._stop = True
-            for _ in self._threads:
-                self._gate.release()
+            with self._cv:
+                self._stop = True
+                self._cv.notify_all()

@@ -46,7 +46,8 @@ SPLIT_PLANES = True
 SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
 HALF_TN128 = True                   # fp16 path (precision='fp16', BASELINE cfg 5): 128-channel tiles for the 3x3 stride-1 layers with >= 128 output channels
 FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
-FUSE_BLOCK0 = False                 # the two level-0 residual blocks as ONE launch each (csrc/block0_fused.hip: the tensor between the convolutions stays in
+FUSE_BLOCK0 = False                 # EXPERIMENT BUILDS ONLY (YOND_HIP_LIB=tools/probe/libyond_exp.so; the product library does not export the entry point):
+                                    # the two level-0 residual blocks as ONE launch each (csrc/block0_fused.hip: the tensor between the convolutions stays in
                                     # LDS).  Built, parity-tested, measured (round 5): 1.16 GB less HBM traffic per block and +1.0 % per forward -- level 0 is
                                     # bound by its vector work (SiLU + split three times per block), not by bytes: profiles/r05_experiments/README.md.  Off.
 K1_SUB2 = True                      # the decoder GEMMs with two sub-positions per channel tile (YondConvDesc.shuffle 2)
@@ -214,7 +215,8 @@ class DenoiserPlan:
         self.lib = L.load()
         self.dev = torch.device(device)
         self.prof = None                           # list -> record (kernel tag, flops, start, end) HIP events per conv launch
-        self.status = torch.zeros(4, dtype=torch.int32, device=self.dev)     # range-guard words of the half-precision paths
+        self.status = torch.zeros(12, dtype=torch.int32, device=self.dev)    # range-guard words of the half-precision paths (0-2: pipeline wrappers, 3: the
+                                                                             # plugin surface, 4-11: the two-stream 'iter' driver's ring)
         self.status_slot = 0
         self.strict = False                        # True: every convolution on the fp32-input MFMA kernels (guard fallback)
         self.precision = getattr(module, 'precision', 'fp32')      # 'fp16': MFMA convolutions on the fp16 matrix path (cfg 5)
@@ -453,6 +455,8 @@ class DenoiserPlan:
         """A 32 -> 32 3x3 layer's weights in the fused level-0 kernel's LDS order (yond_pack_block0_weight_f32), cached on the layer."""
         w = getattr(pc, '_b0', None)
         if w is None:
+            if not L.has("yond_pack_block0_weight_f32"):
+                raise L.YondHipError("the fused level-0 block exists only in experiment builds of the library (python -m yond_public_amd.build --experiments)")
             if not (pc.ksize == 3 and pc.stride == 1 and pc.gemm_n == 32 and pc.cinp == 32 and len(pc.psplits) == 1):
                 return None
             host = np.zeros(9 * 2 * 4 * 32 * 8, np.float16)
@@ -597,7 +601,7 @@ class DenoiserPlan:
                     up = blk['upsc2'] if (flow and K1_SUB2 and 'upsc2' in blk) else blk['upsc']
                     # (decoder level of block i = 9 - i; images too narrow for the unfolded GEMM keep the folded kernels, which have no second output)
                     xsp = (self._new_sp(('xspd', i), N, 2 * h, 2 * w, cp)
-                           if (flow and not last and (9 - i) in K1_D2_LEVELS and up is blk['upsc'] and cp >= 64 and w > 16) else None)
+                           if (flow and not last and (9 - i) in K1_D2_LEVELS and up is blk['upsc'] and cp % 64 == 0 and w > 16) else None)     # (the dispatcher's second output: 64-wide tiles, conv_split.hip)
                     self._conv(up, cur, skips[10 - i], N, h, w, xs, in_fmt=SP if flow else 0, out_fmt=xfmt, dst2=xsp)
                     h, w = 2 * h, 2 * w
                     cur = xs

@@ -598,7 +598,7 @@ class _Guard:
     def __init__(self, plan, slot):
         self.plan, self.slot = plan, slot
         if not hasattr(plan, '_flag_host'):
-            plan._flag_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            plan._flag_host = torch.zeros(12, dtype=torch.int32).pin_memory()
         plan.begin_guard(slot)
 
     def arm(self, rerun):
@@ -925,35 +925,55 @@ CHAIN_SIDD = True                   # (False: the SIDD layout on the host-side c
 def _chain_denoise_blocks(blocks, net, arch, p, buf, guard_slot):
     """_chain_denoise for B blocks that share the round's parameter block and table: batched K1 -> ONE batch-B forward -> batched K4
     (YOND_SIDD.py:392-407 runs the blocks one by one with the same p and bias_func).  Returns ([B][H][W], guard)."""
+    outs, watch = _chain_denoise_blocks_group([blocks], net, arch, p, [buf], guard_slot)
+    return outs[0], watch
+
+
+def _chain_denoise_blocks_group(blocks_list, net, arch, p, bufs, guard_slot):
+    """The same for G images at once: image g's B blocks are stabilised with ITS parameter block and table (bufs[g]: one batched K1 per image
+    into its slice of the network input), the G x B blocks go through ONE forward (images are independent, YOND_SIDD.py:507-514; every block
+    carries its own maximum and its image's t -- the deep levels of a batch-32 forward of 128 x 128 blocks are 16 x 16 and 8 x 8 pixels and
+    leave most of the chip idle), one batched K4 per image.  Per block the kernels and their arguments are those of the one-image call:
+    the same bits.  Returns ([G] of [B][H][W], guard of the forward)."""
     lib = L.load()
-    B, H, W = blocks.shape
+    G = len(blocks_list)
+    B, H, W = blocks_list[0].shape
+    dev = blocks_list[0].device
     h, w = H // 2, W // 2
     scale = float(p['scale'])
     st = L.stream()
     p2d = get_p2d((1, 4, h, w), base=32)
     Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
-    x4 = torch.empty((B, Hp, Wp, 4), dtype=torch.float32, device=blocks.device)
-    img_max = torch.empty(B, dtype=torch.float32, device=blocks.device)
+    x4 = torch.empty((G * B, Hp, Wp, 4), dtype=torch.float32, device=dev)
+    img_max = torch.empty(G * B, dtype=torch.float32, device=dev)
     with _stage("vst_pack"):
-        L.check(lib.yond_pack_vst_norm_batch_dev_f32(L.ptr(blocks), B, H, W, L.ptr(x4), p2d[0], p2d[1], p2d[2], p2d[3], scale, L.ptr(buf.prm),
-                                                     L.ptr(buf.lut_ws), LUT_CAP, L.ptr(img_max), st), "yond_pack_vst_norm_batch_dev_f32")
-    plan = _plan_of(net, blocks.device)
-    t_dev = buf.t.expand(B).contiguous() if 'guided' in arch else None
+        for g, (blocks, buf) in enumerate(zip(blocks_list, bufs)):
+            L.check(lib.yond_pack_vst_norm_batch_dev_f32(L.ptr(blocks), B, H, W, L.ptr(x4[g * B:(g + 1) * B]), p2d[0], p2d[1], p2d[2], p2d[3], scale,
+                                                         L.ptr(buf.prm), L.ptr(buf.lut_ws), LUT_CAP, L.ptr(img_max[g * B:(g + 1) * B]), st),
+                    "yond_pack_vst_norm_batch_dev_f32")
+    plan = _plan_of(net, dev)
+    t_dev = None
+    if 'guided' in arch:
+        t_dev = (bufs[0].t.expand(B) if G == 1 else torch.cat([buf.t.expand(B) for buf in bufs])).contiguous()
 
     def forward_and_invert():
         y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
-        out = torch.empty((B, H, W), dtype=torch.float32, device=blocks.device)
+        outs = []
         with _stage("ivst_unpack"):
-            L.check(lib.yond_denorm_ivst_unpack_batch_dev_f32(L.ptr(y4), B, Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 1, scale, L.ptr(buf.prm),
-                                                              1, st), "yond_denorm_ivst_unpack_batch_dev_f32")
-        return out
+            for g, buf in enumerate(bufs):
+                out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+                L.check(lib.yond_denorm_ivst_unpack_batch_dev_f32(L.ptr(y4[g * B:(g + 1) * B]), B, Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 1, scale,
+                                                                  L.ptr(buf.prm), 1, st), "yond_denorm_ivst_unpack_batch_dev_f32")
+                outs.append(out)
+        return outs
 
     watch = _Guard(plan, guard_slot) if plan.uses_half_operands() else None
-    out = forward_and_invert()
+    outs = forward_and_invert()
     if watch is not None:
         watch.arm(forward_and_invert)
-    buf.prm_host.copy_(buf.prm, non_blocking=True)
-    return out, watch
+    for buf in bufs:
+        buf.prm_host.copy_(buf.prm, non_blocking=True)
+    return outs, watch
 
 
 def _iter_denoise_chain_sidd(blocks, lr_full, net, arch, pipe, p, log=None):
@@ -961,41 +981,70 @@ def _iter_denoise_chain_sidd(blocks, lr_full, net, arch, pipe, p, log=None):
     estimate on lr_full (or the blocks' concatenation, :340), the LUT grid from the blocks' maximum (:393), the 32 blocks through one
     batch-32 forward; round 2's collaborative estimate on the concatenations with the SIDD_256 re-tiling (:431); both rounds queued
     back to back, ONE synchronisation.  None when a round took a branch the chain leaves to the host-side path."""
+    return _iter_denoise_chain_sidd_group([(blocks, lr_full)], net, arch, pipe, p, log=log)[0]
+
+
+def _iter_denoise_chain_sidd_group(items, net, arch, pipe, p, log=None):
+    """_iter_denoise_chain_sidd for G images [(blocks, lr_full)] as ONE group: every image keeps its own estimates, parameter blocks and
+    tables (round 1: self estimate on its full frame; round 2: collaborative estimate on its own concatenations); round 1 of all G images is
+    ONE batch-(32 G) forward, round 2 likewise (speculatively for every image: whether an image's guard ends it after round 1, :445-447, is
+    read from its parameter block afterwards, as in the one-image chain); ONE synchronisation for the group.  Returns a list of G results
+    (None for an image that took a branch the chain leaves to the host-side path).  An image's result has the bits of its one-image call:
+    the group only changes which images share a launch (tests/test_hip_eval.py)."""
     two = pipe.get('iter', 'iter') == 'iter' and pipe.get('max_iter', 1) >= 1
     if two and pipe.get('max_iter', 1) > 1:
-        return None
-    blocks = blocks.contiguous()
-    lr_cat = torch.cat(list(blocks), dim=-1).contiguous()                              # :315
-    mx = _frame_max(lr_cat)                                                            # upper_bound = lr_raw.max() * (wp - bl), :393
-    b1 = _chain_buffers(blocks.device, 0)
-    _chain_estimate(lr_cat if lr_full is None else lr_full, None, 'self', pipe, p, b1, lr_max_dev=mx)
-    o1, g1 = _chain_denoise_blocks(blocks, net, arch, p, b1, 0)
-    out1 = torch.cat(list(o1), dim=-1).contiguous()                                    # :408
+        return [None] * len(items)
+    dev = items[0][0].device
+    G = len(items)
+    key = (lambda g, r: r) if G == 1 else (lambda g, r: ('group', g, r))       # (one image: the chain's two resident buffer sets)
+    st = []
+    for g, (blocks, lr_full) in enumerate(items):
+        blocks = blocks.contiguous()
+        lr_cat = torch.cat(list(blocks), dim=-1).contiguous()                              # :315
+        mx = _frame_max(lr_cat)                                                            # upper_bound = lr_raw.max() * (wp - bl), :393
+        b1 = _chain_buffers(dev, key(g, 0))
+        _chain_estimate(lr_cat if lr_full is None else lr_full, None, 'self', pipe, p, b1, lr_max_dev=mx)
+        st.append(dict(blocks=blocks, lr_cat=lr_cat, mx=mx, b1=b1))
+    o1, g1 = _chain_denoise_blocks_group([q['blocks'] for q in st], net, arch, p, [q['b1'] for q in st], 0)
+    for q, o in zip(st, o1):
+        q['out1'] = torch.cat(list(o), dim=-1).contiguous()                                # :408
     if two:
-        b2 = _chain_buffers(blocks.device, 1)
-        _chain_estimate(lr_cat, out1, 'collab', dict(pipe, collab_sidd256=pipe.get('collab_sidd256', True)), p, b2, lr_max_dev=mx)
-        o2, g2 = _chain_denoise_blocks(blocks, net, arch, p, b2, 1)
-        out2 = torch.cat(list(o2), dim=-1).contiguous()
+        pipe2 = dict(pipe, collab_sidd256=pipe.get('collab_sidd256', True))
+        for g, q in enumerate(st):
+            q['b2'] = _chain_buffers(dev, key(g, 1))
+            _chain_estimate(q['lr_cat'], q['out1'], 'collab', pipe2, p, q['b2'], lr_max_dev=q['mx'])
+        o2, g2 = _chain_denoise_blocks_group([q['blocks'] for q in st], net, arch, p, [q['b2'] for q in st], 1)
+        for q, o in zip(st, o2):
+            q['out2'] = torch.cat(list(o), dim=-1).contiguous()
     torch.cuda.current_stream().synchronize()
-    reg1, par1, fl1, info1 = _chain_result(b1)
-    if fl1 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE) or (g1 is not None and g1.tripped()):
-        return None
-    if log:
-        log(f"Self Est: K={par1[0]:.4f}, b={par1[1]:.4f} (beta1={reg1[0]:.3e}, beta2={reg1[1]:.3e})")
-    raw_dns, regs, params = [out1], [reg1], [par1]
-    if two:
-        reg2, par2, fl2, info2 = _chain_result(b2)
-        if fl2 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY):
-            return None
+    trip1 = g1 is not None and g1.tripped()
+    trip2 = two and g2 is not None and g2.tripped()
+    results = []
+    for g, q in enumerate(st):
+        tag = f"[image {g} of the group] " if G > 1 else ""
+        reg1, par1, fl1, info1 = _chain_result(q['b1'])
+        if fl1 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE) or trip1:
+            results.append(None)
+            continue
         if log:
-            log(f"Iter 1 Est: K={par2[0]:.4f}, sigma={par2[1]:.4f} (beta1={reg2[0]:.3e}, beta2={reg2[1]:.3e})")
-        if not (fl2 & PRM_ROUND_ABORTED):                # :445-447: beta1 < 0 ends the image after round 1
-            if fl2 & PRM_BAD_ESTIMATE or (g2 is not None and g2.tripped()):
-                return None
-            raw_dns.append(out2)
-            regs.append(reg2)
-            params.append(par2)
-    return dict(raw_dns=raw_dns, regs=regs, params=params, nle_info=info1)
+            log(f"{tag}Self Est: K={par1[0]:.4f}, b={par1[1]:.4f} (beta1={reg1[0]:.3e}, beta2={reg1[1]:.3e})")
+        raw_dns, regs, params = [q['out1']], [reg1], [par1]
+        if two:
+            reg2, par2, fl2, info2 = _chain_result(q['b2'])
+            if fl2 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY):
+                results.append(None)
+                continue
+            if log:
+                log(f"{tag}Iter 1 Est: K={par2[0]:.4f}, sigma={par2[1]:.4f} (beta1={reg2[0]:.3e}, beta2={reg2[1]:.3e})")
+            if not (fl2 & PRM_ROUND_ABORTED):                # :445-447: beta1 < 0 ends the image after round 1
+                if fl2 & PRM_BAD_ESTIMATE or trip2:
+                    results.append(None)
+                    continue
+                raw_dns.append(q['out2'])
+                regs.append(reg2)
+                params.append(par2)
+        results.append(dict(raw_dns=raw_dns, regs=regs, params=params, nle_info=info1))
+    return results
 
 
 def _frame_max(x):
@@ -1226,6 +1275,30 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
     return dict(raw_dns=raw_dns, regs=regs, params=params)
 
 
+def IterDenoiseGroup(items, net, arch, pipe, ps=None, device=None, log=None, biaslut=None, ests=None):
+    """`IterDenoise` for G images of the SIDD layout at once -- items: [(lr [32][256][256], lr_full or None)], ps / ests: per-image `p` / `est`
+    (or one for all).  Images are independent (YOND_SIDD.py:507-514 takes them one by one); here round 1 of the G images is ONE batch-(32 G)
+    forward and round 2 another, every image with its own estimates, tables and t: per image the result is IterDenoise's, bit for bit.
+    Images (or configurations) the grouped device chain does not cover go through IterDenoise one by one.  Returns the list of G results."""
+    G = len(items)
+    ps = list(ps) if isinstance(ps, (list, tuple)) else [ps] * G
+    ests = list(ests) if isinstance(ests, (list, tuple)) else [ests] * G
+    out = [None] * G
+    pp = [dict(q or default_params()) for q in ps]
+    dev_items = []
+    for lr, lf in items:
+        lr_c = _dev(lr, device)
+        dev_items.append((lr_c, None if lf is None else _dev(lf, lr_c.device)))
+    same_p = all({k: v for k, v in q.items() if k != 'cfa'} == {k: v for k, v in pp[0].items() if k != 'cfa'} for q in pp)
+    if G > 1 and same_p and all(chain_applies_sidd(lr_c, lf_c, net, arch, pipe, q, biaslut) and lr_c.shape == dev_items[0][0].shape
+                                 for (lr_c, lf_c), q in zip(dev_items, pp)):
+        out = _iter_denoise_chain_sidd_group(dev_items, net, arch, pipe, dict(pp[0]), log=log)
+    for g in range(G):
+        if out[g] is None:
+            out[g] = IterDenoise(items[g][0], net, arch, pipe, lr_full=items[g][1], p=ps[g], device=device, log=log, biaslut=biaslut, est=ests[g])
+    return out
+
+
 def IterDenoiseBatch(frames, net, arch, pipe, p=None, device=None):
     """`IterDenoise` for B equally sized full Bayer frames at once (BASELINE cfg 4: batch 8; pipe['full_dn']): every frame
     keeps its own noise-level estimate, bias LUT and VST constants -- the per-image steps of YOND_SIDD.py:341-356,
@@ -1292,6 +1365,12 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     Contract for device-tensor frames: frame k+1 is taken from the iterator BEFORE the network pass of frame k is queued
     and its estimate reads it on the side stream, so every frame handed in must stay UNMODIFIED until its own result has
     been yielded -- a producer that refills one buffer in place must hand in clones."""
+    chain_cfg = (DEVICE_CHAIN and pipe.get('bias_corr', 'pre') == 'pre' and 'simple' in str(pipe.get('est_type', 'simple')) and 'cal_est' not in pipe
+                 and pipe.get('full_est', True) and 'rot_cfa' not in (p or {}))
+    if pipe.get('full_dn', False) and pipe.get('iter', 'iter') == 'iter' and pipe.get('max_iter', 1) == 1 and chain_cfg and STREAM_ITER:
+        # the reference's shipped default (runfiles/YOND/*: iter, max_iter 1; control flow YOND_SIDD.py:419-472) on the two streams
+        yield from _denoise_stream_chain_iter(frames, net, arch, pipe, dict(p or default_params()), device)
+        return
     if pipe.get('iter', 'iter') != 'once' or not pipe.get('full_dn', False):
         for f in frames:
             yield IterDenoise(f, net, arch, pipe, p=p, device=device)
@@ -1407,6 +1486,104 @@ def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
         pending = (lr, out, buf, watch, fin)
     if pending is not None:
         yield release(pending)
+
+
+STREAM_ITER = True                  # (module attribute: False = 'iter' frames one at a time, for A/B)
+
+
+def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
+    """denoise_stream for pipe['iter'] == 'iter', max_iter 1 (YOND_SIDD.py:419-472) on the device chain.  Per frame k: E1 (self estimate +
+    parameter chain) -> D1 (K1, network, K4) -> E2 (collaborative estimate from (noisy, round-1 output) + guards + chain, :431-454) -> D2.
+    The main stream carries the network passes in the order D1(0), D1(1), D2(0), D1(2), D2(1), ...; the side stream runs E1(k+1) under D1(k)
+    and E2(k) under D2(k-1) -- E2(k) needs D1(k)'s output, so frame k's second pass is queued behind frame k+1's first, with frame k's
+    collaborative estimate in between on the other stream.  Round 2 is queued speculatively (whether :445-447 ends the image after round 1 is
+    read from its parameter block when the frame is yielded, as in _iter_denoise_chain); the host reads a frame's blocks two frames late.
+    Same kernels and arguments as IterDenoise, frame by frame: the same results (tests/test_hip_pipeline.py).  Frames handed in must stay
+    unmodified until their own result has been yielded (see denoise_stream)."""
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+    RING = 4                                                                  # frames whose buffers / guard words may be live at once
+
+    def bufs(k, r):
+        return _chain_buffers(main.device, ('iter-stream', k % RING, r))
+
+    def est1(lr, ready, k):
+        side.wait_event(ready)                                                # the frame as it stood when it was handed in
+        with torch.cuda.stream(side):
+            _chain_estimate(lr, None, 'self', pipe, p0, bufs(k, 0))
+            return side.record_event()
+
+    def est2(st, k):
+        b1, b2 = bufs(k, 0), bufs(k, 1)
+        side.wait_event(st['fin1'])                                           # round 1's output is complete
+        with torch.cuda.stream(side):
+            mx = torch.empty(1, dtype=torch.float32, device=main.device)
+            mx.copy_(b1.prm[PRM['frame_max']:PRM['frame_max'] + 1])           # float64 holding the float32 maximum -> float32
+            _chain_estimate(st['lr'], st['out1'], 'collab', pipe, p0, b2, lr_max_dev=mx)
+            st['mx'] = mx
+            return side.record_event()
+
+    def release(st, k):
+        st['fin2'].synchronize()
+        b1, b2 = bufs(k, 0), bufs(k, 1)
+        reg1, par1, fl1, info1 = _chain_result(b1)
+        reg2, par2, fl2, info2 = _chain_result(b2)
+        bad = bool(fl1 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE)) or (st['g1'] is not None and st['g1'].tripped())
+        bad = bad or bool(fl2 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY))
+        aborted = bool(fl2 & PRM_ROUND_ABORTED)                               # :445-447: beta1 < 0 ends the image after round 1
+        if not bad and not aborted:
+            bad = bool(fl2 & PRM_BAD_ESTIMATE) or (st['g2'] is not None and st['g2'].tripped())
+        if bad:                                                               # a branch the chain leaves to the host-side path
+            global DEVICE_CHAIN
+            DEVICE_CHAIN = False
+            try:
+                return IterDenoise(st['lr'], net, arch, pipe, p=p0)
+            finally:
+                DEVICE_CHAIN = True
+        raw_dns, regs, params = [st['out1']], [reg1], [par1]
+        if not aborted:
+            raw_dns.append(st['out2'])
+            regs.append(reg2)
+            params.append(par2)
+        return dict(raw_dns=raw_dns, regs=regs, params=params, nle_info=info1)
+
+    def round2(st, k):
+        main.wait_event(st['e2'])
+        st['out2'], st['g2'] = _chain_denoise(st['lr'], net, arch, p0, bufs(k, 1), 4 + 2 * (k % RING) + 1)
+        st['fin2'] = main.record_event()
+
+    it = iter(frames)
+    try:
+        f = _dev(next(it), device)
+    except StopIteration:
+        return
+    live = {}                                                                 # frame index -> its state
+    k = 0
+    live[0] = dict(lr=f)
+    live[0]['e1'] = est1(f, main.record_event(), 0)
+    while k in live:
+        st = live[k]
+        try:                               # take the next frame (and mark the main stream) BEFORE queuing this one's network
+            f_next = _dev(next(it), device)
+            ready = main.record_event()
+        except StopIteration:
+            f_next = None
+        main.wait_event(st['e1'])
+        st['out1'], st['g1'] = _chain_denoise(st['lr'], net, arch, p0, bufs(k, 0), 4 + 2 * (k % RING))       # D1(k)
+        st['fin1'] = main.record_event()
+        if f_next is not None:
+            live[k + 1] = dict(lr=f_next)
+            live[k + 1]['e1'] = est1(f_next, ready, k + 1)                     # E1(k+1): under D1(k)
+        st['e2'] = est2(st, k)                                                # E2(k): behind D1(k), under D2(k-1)
+        if k - 1 in live:
+            round2(live[k - 1], k - 1)                                        # D2(k-1)
+        if k - 2 in live:
+            yield release(live.pop(k - 2), k - 2)
+        k += 1
+    if k - 1 in live:
+        round2(live[k - 1], k - 1)
+    for j in sorted(live):
+        yield release(live.pop(j), j)
 
 
 _SIDE_STREAMS = {}

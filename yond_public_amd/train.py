@@ -599,7 +599,6 @@ class TrainStep:
         from . import distributed as D
         self.graph = bool(graph)
         self._graphs, self._seen = {}, {}
-        self._scale_checked = set()
         self.m = module
         self.dev = next(module.parameters()).device
         self.plan = _plan(self.dev)
@@ -949,15 +948,16 @@ class TrainStep:
                 if out is not None:
                     return out                               # (else: a range trip, nothing updated -- the eager path lowers the scale)
         if self.reducer is not None:
-            skey = (tuple(imgs_hr.shape), S)
-            if skey not in self._scale_checked:                  # the ranks all-reduce S-scaled gradients: S must agree (see __init__)
-                import torch.distributed as dist
-                t = torch.tensor([S, -S], dtype=torch.float64, device=self.dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                if float(t[0]) != S or float(t[1]) != -S:
-                    raise L.YondHipError(f"TrainStep: the ranks' loss scales differ (this rank {S:g}, maximum {float(t[0]):g}, minimum {-float(t[1]):g}): "
-                                         "give every rank the same local batch size or a fixed loss_scale")
-                self._scale_checked.add(skey)
+            # the ranks all-reduce S-scaled gradients: S must agree (see __init__).  Checked EVERY step, by every rank alike: the decision to
+            # check is itself collective (a check keyed on this rank's own batch shapes would be issued by one rank and skipped by another --
+            # exactly when their shapes differ, the case it exists for -- and mismatch the gradient all-reduces that follow)
+            import torch.distributed as dist
+            t = torch.tensor([S, -S], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t[0]) != S or float(t[1]) != -S:
+                raise L.YondHipError(f"TrainStep: the ranks' loss scales differ (this rank {S:g}, maximum {float(t[0]):g}, minimum {-float(t[1]):g}): "
+                                     "give every rank the same local batch size or a fixed loss_scale")
+        S0, auto0, clean0 = S, getattr(self, '_auto_scale', None), getattr(self, '_clean_steps', 0)    # the scale this step started with
         attempt = 0
         while True:
             pred, loss_sum = self._fwd_bwd(imgs_lr, imgs_hr, sigma, S)
@@ -979,6 +979,11 @@ class TrainStep:
                     # shortcut reads) is what cannot be lowered by the loss scale: those layers go back to the fp32-input MFMA
                     if self.reducer is not None:
                         self.reducer.finish()
+                    # ... and the trip was no gradient overflow: the retries' lowered scale (kept in _auto_scale, regrown x2 per 500 clean steps)
+                    # would leave dpred = S / n below fp16's normal range for thousands of steps -- back to the scale the step started with
+                    S = S0
+                    if self.loss_scale is None:
+                        self._auto_scale, self._clean_steps = auto0, clean0
                     attempt = 0
                     continue
                 raise L.YondHipError("TrainStep: an activation or gradient is NaN or left fp16's range (|a| > 65504) in the split-operand "

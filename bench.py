@@ -300,8 +300,7 @@ def sidd_eval_item(item, net, arch, P):
 
 def sidd_eval_group(items, net, arch, P):
     """G images of YOND_SIDD.eval as one group (yond_public_amd/YOND_SIDD.py eval, --group): round 1 of the G images is ONE batch-(32 G)
-    forward, round 2 another; estimates, tables, t and the block metrics stay per image (per image the results are sidd_eval_item's, bit for
-    bit: tests/test_hip_eval.py)."""
+    forward, round 2 another; estimates, tables, t and the block metrics stay per image (per image the results are sidd_eval_item's: tests/test_hip_eval.py)."""
     ress = P.IterDenoiseGroup([(it['lr'], it['lr_full']) for it in items], net, arch, SIDD_PIPE)
     for res, it in zip(ress, items):
         if len(res['raw_dns']) != 2:

@@ -172,7 +172,7 @@ typedef struct YondConvDesc {
        result silently wrong).  The caller zeroes it, reads it after the forward and falls back to the fp32-input MFMA
        kernels (algo 0 / 1).  Weights are checked by the packing functions (YOND_EUNSUPPORTED). */
     unsigned int* status;
-    /* Tensor formats (algo 3 only; 0 = [N][H][W][C] float32, the default everywhere).
+    /* Tensor formats (algo 3 and 4 only; 0 = [N][H][W][C] float32, the default everywhere).
        1 = SPLIT PLANES: what the consumer's LDS staging holds, stored once by the producer -- every value a (after the
        consumer's pre-activation, which the PRODUCER applies: post_act) as the half pair h = fp16(a), l = fp16((a - h) 2^11),
        laid out [N][C/16][channel half 0..1][part h, l][YOND_SP_PLANE_UNITS(H, W)] in units of 16 bytes = 8 consecutive
@@ -180,7 +180,11 @@ typedef struct YondConvDesc {
        zeroes once (producers never write it; consumers read conv zero padding from it).  A consumer (in_fmt 1: src0 and
        src1, pre_act must be 0) stages its input by LDS-DMA alone; a producer (out_fmt 1: dst, 3x3 stride 1, no res,
        no fused projection) stores from the accumulator layout without an LDS transpose.  Bit-identical to staging the
-       float32 tensor (the same split of the same float32 value). */
+       float32 tensor (the same split of the same float32 value).
+       With algo 4 (h-only operands: the fp16 path, BASELINE cfg 5) format 1 means H-ONLY PLANES: the h halves alone,
+       [N][C/16][channel half 0..1][YOND_SP_PLANE_UNITS(H, W)] units -- 2 bytes per element, the value every algo-4 consumer would have
+       rounded to when staging the float32 tensor; the same roles (3x3 stride-1 producers / consumers, the stride-2 layers, the decoder
+       GEMM with shuffle 1 or 2, dst2, the fused projection with split-plane input), the same zero pad, the same residual rule. */
     int in_fmt, out_fmt;
     /* 2 = PLANES OF 4 CHANNELS, float32 [N][C/4][H*W][4]: the format of the tensors that are read as RESIDUALS by a
        split-plane store (res_fmt 2 is required with out_fmt 1 and a residual, and only there): in the accumulator layout
@@ -209,8 +213,9 @@ typedef struct YondConvDesc {
 #define YOND_FMT_PLANES4 2
 /* 16-byte units per plane of a split-plane tensor: H*W pixels + at least one zero unit, rounded to 128 bytes */
 #define YOND_SP_PLANE_UNITS(H, W) ((((H) * (W)) + 8) / 8 * 8)
-/* bytes of a split-plane tensor of C channels (C a multiple of 16) */
+/* bytes of a split-plane tensor of C channels (C a multiple of 16); of an h-only tensor (algo 4): half of it */
 #define YOND_SP_BYTES(N, C, H, W) ((size_t)(N) * ((C) / 16) * 4 * (size_t)YOND_SP_PLANE_UNITS(H, W) * 16)
+#define YOND_HP_BYTES(N, C, H, W) ((size_t)(N) * ((C) / 16) * 2 * (size_t)YOND_SP_PLANE_UNITS(H, W) * 16)
 
 /* Tile configuration for a convolution (needed to pack weights): kc = channel chunk, tn = channel-tile width.
  * N, Ho, Wo (GEMM-M extent; 0 = unknown) let the library pick the tn that fills its persistent grid best. */

@@ -781,3 +781,151 @@ def test_block0_fused_equals_the_two_launches(N, H, W, in_nhwc, out4):
     big.view(-1)[5] = 1e6
     plan._block0(pc1, pc2, big, N, H, W, f, 0 if in_nhwc else 2, dst=plan._new_sp('o2', N, H, W, C))
     assert int(plan.status[0]) & 1
+
+
+# ---- the split-plane data flow on H-ONLY planes (descriptor algo 4 with in_fmt / out_fmt: the fp16 path, BASELINE cfg 5) -------------------
+def to_hp(x):
+    """[N][H][W][C] float32 (CPU) -> h-only planes [N][C/16][channel half][units][8 halves] (float32-typed buffer on the device): the halves
+    the plain-tensor h-only kernels round when they stage."""
+    from yond_public_amd.engine import sp_plane_units
+    N, H, W, C = x.shape
+    ps = sp_plane_units(H, W)
+    out = torch.zeros(N, C // 16, 2, ps, 8, dtype=torch.float16)
+    out[:, :, :, :H * W, :] = x.half().reshape(N, H * W, C // 16, 2, 8).permute(0, 2, 3, 1, 4)
+    return out.reshape(-1).view(torch.float32).to(DEV)
+
+
+def hp_decode(sp, N, C, H, W):
+    """h-only planes -> ([N][H][W][C] float16 (CPU), the pad units)."""
+    from yond_public_amd.engine import sp_plane_units
+    u = sp.cpu().view(torch.float16).reshape(N, C // 16, 2, sp_plane_units(H, W), 8)
+    return u[:, :, :, :H * W, :].permute(0, 3, 1, 2, 4).reshape(N, H, W, C), u[:, :, :, H * W:, :]
+
+
+@pytest.mark.parametrize("C,N,H,W", [(64, 2, 40, 70), (128, 1, 380, 100), (32, 2, 50, 75), (256, 1, 30, 61), (64, 5, 16, 16), (32, 1, 37, 70)])
+def test_half_plane_flow_block(C, N, H, W):
+    """The residual block in the formats of the fp16 path's data flow (round 6): x in float32 planes of 4 channels (conv1's staged input,
+    conv2's residual), tmp and out in H-ONLY planes (2 bytes per element).  The plain-tensor h-only kernels round every operand to half when
+    they stage it; here the producer stores the rounded value instead: tmp and out must be the half-rounding of what the [N][H][W][C] h-only
+    path computes, bit for bit, the zero pads untouched; every tile shape (8 / 12 / 16-row tiles, partial tiles, batch)."""
+    from yond_public_amd.engine import _PackedConv
+    g = torch.Generator().manual_seed(C + H)
+    x = nhwc(torch.randn(N, C, H, W, generator=g))
+    w1 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    es, et = torch.randn(N, C, generator=g).to(DEV), torch.randn(N, C, generator=g).to(DEV)
+    es2, et2 = torch.randn(N, C, generator=g).to(DEV), torch.randn(N, C, generator=g).to(DEV)
+    plan = bare_plan()
+    plan.status, plan.status_slot = torch.zeros(4, dtype=torch.int32, device=DEV), 0
+    pc1, pc2 = _PackedConv(plan.dev, w1, None, 3, 1, [C]), _PackedConv(plan.dev, w2, None, 3, 1, [C])
+    xd, xp = x.to(DEV), to_p4(x)
+    kw1 = dict(escale=es, eshift=et, ebatch=1, pre_act=1, post_act=1, algo='half')
+    kw2 = dict(escale=es2, eshift=et2, ebatch=1, algo='half')
+    t_ref = torch.empty(N, H, W, C, device=DEV)
+    o_ref = torch.empty(N, H, W, C, device=DEV)
+    plan._conv(pc1, xd, None, N, H, W, t_ref, **kw1)
+    plan._conv(pc2, t_ref, None, N, H, W, o_ref, res=xd, **kw2)
+    t_hp, o_hp = plan._new_sp('t', N, H, W, C, 1), plan._new_sp('o', N, H, W, C, 1)
+    plan._conv(pc1, xp, None, N, H, W, t_hp, in_fmt=2, out_fmt=1, **kw1)
+    plan._conv(pc2, t_hp, None, N, H, W, o_hp, res=xp, in_fmt=1, out_fmt=1, res_fmt=2, **kw2)
+    torch.cuda.synchronize()
+    for name, sp, ref in (("tmp", t_hp, t_ref), ("out", o_hp, o_ref)):
+        h, pads = hp_decode(sp, N, C, H, W)
+        assert not pads.view(torch.int16).any(), name
+        assert torch.equal(h.view(torch.int16), ref.cpu().half().view(torch.int16)), (name, float((h.float() - ref.cpu()).abs().max()))
+    assert int(plan.status[0]) == 0
+    z = F.conv2d(F.silu(nchw(x).double()), w1.double(), padding=1) * es.cpu().double()[:, :, None, None] + et.cpu().double()[:, :, None, None]
+    ref = F.conv2d(F.silu(z), w2.double(), padding=1) * es2.cpu().double()[:, :, None, None] + et2.cpu().double()[:, :, None, None] + nchw(x).double()
+    got = nchw(hp_decode(o_hp, N, C, H, W)[0].float())
+    assert report(f"residual block through h-only planes C{C} {H}x{W}", got, ref) <= 0.02 * max(1.0, float(ref.abs().max()))
+    # the last block's form: conv2 with the fused output projection reads tmp in h-only planes, its residual as [N][H][W][C]
+    if C == 32:
+        w4 = (torch.randn(4, C, generator=g) / C ** 0.5).to(DEV)
+        b4 = torch.randn(4, generator=g).to(DEV)
+        xin = torch.rand(N, H, W, 4, generator=g).to(DEV)
+        ub = (torch.rand(N, generator=g) + 0.5).to(DEV)
+        o4 = torch.full((N, H, W, 4), float('nan'), device=DEV)
+        plan._conv(pc2, t_hp, None, N, H, W, None, res=xd, in_fmt=1, out4=(w4, b4, xin, ub, o4), **kw2)
+        torch.cuda.synchronize()
+        u = ub.cpu().double()[:, None, None, None]
+        want = (torch.einsum('nhwc,qc->nhwq', o_ref.cpu().double(), w4.cpu().double()) + b4.cpu().double() + xin.cpu().double() / u) * u
+        assert report("h-only conv2 + fused output projection", o4.cpu(), want) <= 2e-5 * max(1.0, float(want.abs().max()))
+    # the range guard: a stored value beyond fp16's range is reported
+    big = x.clone()
+    big.view(-1)[3] = 3e6
+    plan._conv(pc1, to_p4(big), None, N, H, W, plan._new_sp('t2', N, H, W, C, 1), in_fmt=2, out_fmt=1, **kw1)
+    assert int(plan.status[0]) & 1
+
+
+@pytest.mark.parametrize("C,N,H,W", [(32, 2, 37, 70), (64, 1, 64, 130), (128, 1, 23, 45), (256, 1, 12, 33)])
+def test_conv3x3_s2_half_planes(C, N, H, W):
+    """Stride-2 layer of the fp16 path's flow: h-only planes in (through the register sets), float32 planes of 4 channels out -- the
+    plain-tensor h-only kernel's result bit for bit; the second output (YondConvDesc.dst2) holds half(SiLU(value)) in h-only planes."""
+    from yond_public_amd.engine import _PackedConv
+    g = torch.Generator().manual_seed(C + W)
+    x = nhwc(torch.randn(N, C, H, W, generator=g))
+    w = torch.randn(2 * C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(2 * C, generator=g)
+    plan = bare_plan()
+    pc = _PackedConv(plan.dev, w, b, 3, 2, [C])
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    ref = torch.empty(N, Ho, Wo, 2 * C, device=DEV)
+    plan._conv(pc, x.to(DEV), None, N, H, W, ref, algo='half')
+    gp4 = torch.empty(N * 2 * C * Ho * Wo, device=DEV)
+    plan._conv(pc, to_hp(x), None, N, H, W, gp4, algo='half', in_fmt=1, out_fmt=2)
+    gp4b = torch.empty(N * 2 * C * Ho * Wo, device=DEV)
+    second = plan._new_sp('second', N, Ho, Wo, 2 * C, 1)
+    plan._conv(pc, to_hp(x), None, N, H, W, gp4b, algo='half', in_fmt=1, out_fmt=2, dst2=second)
+    torch.cuda.synchronize()
+    assert torch.equal(from_p4(gp4, N, Ho, Wo, 2 * C), ref.cpu())
+    assert torch.equal(gp4b.cpu(), gp4.cpu())
+    val, pads = hp_decode(second, N, 2 * C, Ho, Wo)
+    assert not pads.view(torch.int16).any()
+    want = F.silu(ref.cpu().double())
+    assert float((val.double() - want).abs().max()) <= 2.0 ** -10 * max(1.0, float(want.abs().max()))
+    z = F.conv2d(nchw(x.half().float()).double(), w.half().double(), b.double(), stride=2, padding=1)
+    assert report(f"stride-2 from h-only planes C{C}", nchw(ref.cpu()), z) <= 2e-5 * max(1.0, float(z.abs().max()))
+
+
+@pytest.mark.parametrize("c,h,w,N", [(64, 24, 40, 2), (32, 19, 33, 2), (128, 9, 35, 2), (256, 7, 20, 1)])
+def test_decoder_gemm_half_planes(c, h, w, N):
+    """The decoder GEMM of the fp16 path's flow (ConvTranspose2d 2x2 + cat + 1x1 shortcut folded; archs/Unet.py:447-461): BOTH sources in
+    h-only planes, output as float32 planes of 4 channels or [N][H][W][C] (the last block's input) -- against the float64 layer on the
+    half-rounded operands (fp32 accumulate: 2e-5); the two output formats bit-equal; the second output = half(SiLU(value)); at 32 channels
+    the two-sub-positions-per-tile form (YondConvDesc.shuffle 2) bit-equal to the plain form."""
+    from yond_public_amd.engine import _PackedConv, _PackedUpSub2
+    g = torch.Generator().manual_seed(c + h)
+    cur = nhwc(torch.randn(N, 2 * c, h, w, generator=g))
+    skip = nhwc(torch.randn(N, c, 2 * h, 2 * w, generator=g))
+    wf = torch.randn(3 * c, c, 2, 2, generator=g) / (3 * c) ** 0.5        # ConvTranspose2d layout over [cur | skip]
+    bf = torch.randn(c, generator=g)
+    plan = bare_plan()
+    pc = _PackedConv(plan.dev, wf, bf, 1, 1, [2 * c, c], shuffle=True)
+    got = torch.empty(N, 2 * h, 2 * w, c, device=DEV)
+    plan._conv(pc, to_hp(cur), to_hp(skip), N, h, w, got, algo='half', in_fmt=1)
+    gp4 = torch.empty(N * c * 4 * h * w, device=DEV)
+    plan._conv(pc, to_hp(cur), to_hp(skip), N, h, w, gp4, algo='half', in_fmt=1, out_fmt=2)
+    torch.cuda.synchronize()
+    wq = wf.half().double()
+    ref = torch.einsum('nyxi,iojk->nyjxko', cur.half().double(), wq[:2 * c]).reshape(N, 2 * h, 2 * w, c)
+    ref += torch.einsum('nyjxki,iojk->nyjxko', skip.half().double().reshape(N, h, 2, w, 2, c), wq[2 * c:]).reshape(N, 2 * h, 2 * w, c)
+    ref += bf.double()
+    assert report(f"decoder GEMM from h-only planes c{c}", got.cpu(), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(from_p4(gp4, N, 2 * h, 2 * w, c), got.cpu())
+    if c >= 64:
+        gp4b = torch.empty(N * c * 4 * h * w, device=DEV)
+        second = plan._new_sp('second', N, 2 * h, 2 * w, c, 1)
+        plan._conv(pc, to_hp(cur), to_hp(skip), N, h, w, gp4b, algo='half', in_fmt=1, out_fmt=2, dst2=second)
+        torch.cuda.synchronize()
+        assert torch.equal(gp4b.cpu(), gp4.cpu())
+        val, pads = hp_decode(second, N, c, 2 * h, 2 * w)
+        assert not pads.view(torch.int16).any()
+        want = F.silu(got.cpu().double())
+        assert float((val.double() - want).abs().max()) <= 2.0 ** -10 * max(1.0, float(want.abs().max()))
+    if c == 32:
+        up2 = _PackedUpSub2(plan.dev, wf, bf, c)
+        assert up2.ok and up2.split(1) is not None
+        g2 = torch.empty(N * c * 4 * h * w, device=DEV)
+        plan._conv(up2, to_hp(cur), to_hp(skip), N, h, w, g2, algo='half', in_fmt=1, out_fmt=2)
+        torch.cuda.synchronize()
+        assert report("two sub-positions per tile, h-only", from_p4(g2, N, 2 * h, 2 * w, c), got.cpu()) <= 2e-6 * max(1.0, float(ref.abs().max()))

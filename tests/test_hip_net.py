@@ -54,6 +54,41 @@ def test_net_larger_frame_vs_oracle():
     assert report("net gru32 reloaded", y2.cpu().numpy(), ref2) <= 1e-4 * max(1.0, float(np.abs(ref2).max()))
 
 
+@pytest.mark.parametrize("aname,shape", [("gru32", (1, 4, 160, 224)), ("snr32", (2, 4, 96, 128)), ("gru32", (1, 4, 416, 672))])
+def test_net_fp16_path_split_plane_flow_equals_plain_tensors(aname, shape):
+    """The fp16 path's forward in the split-plane data flow on H-ONLY planes (engine.HALF_FLOW; round 6) against the same path on plain
+    float32 tensors: every operand is the same half-rounded value either way (the plain kernels round when they stage, the flow's producers
+    store the rounded value), so the two forwards differ only by the summation order of the layers that changed kernels (stride 2, decoder
+    GEMM: generic fp16 kernel -> split family) -- >= 70 dB on the [0, 1] output, and both >= 55 dB from the float32 reference."""
+    import yond_oracle as O
+    from yond_public_amd import engine as E
+    arch = dict(ARCHS[aname])
+    net, sd = make_net(arch, 9)
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(5)) * 0.9
+    t = torch.full((shape[0], 1, 1, 1), 0.05)
+    torch.set_num_threads(8)
+    ref = O.net_forward(arch, sd, x, t).numpy().astype(np.float64)
+    net.precision = 'fp16'
+    plan = net._get_plan(torch.device('cuda:0'))
+    assert E.HALF_FLOW and plan._sp_flow(shape[0], shape[2], shape[3])
+    with torch.no_grad():
+        y_flow = net(x.to('cuda:0'), t.to('cuda:0')).cpu().numpy().astype(np.float64)
+        E.HALF_FLOW = False
+        try:
+            assert not plan._sp_flow(shape[0], shape[2], shape[3])
+            y_plain = net(x.to('cuda:0'), t.to('cuda:0')).cpu().numpy().astype(np.float64)
+        finally:
+            E.HALF_FLOW = True
+    net.precision = 'fp32'
+    psnr = lambda a, b: 10 * np.log10(1.0 / max(float(np.mean((a - b) ** 2)), 1e-30))
+    print(f"[parity] {aname} {shape}: fp16 path, h-only flow vs plain tensors {psnr(y_flow, y_plain):.1f} dB; vs fp32 reference: flow {psnr(y_flow, ref):.1f} dB, "
+          f"plain {psnr(y_plain, ref):.1f} dB")
+    assert np.isfinite(y_flow).all()
+    assert psnr(y_flow, y_plain) >= 70.0
+    assert psnr(y_flow, ref) >= 55.0 and psnr(y_plain, ref) >= 55.0
+    assert psnr(y_flow, ref) >= psnr(y_plain, ref) - 1.0
+
+
 @pytest.mark.parametrize("aname", ["gru32", "snr32", "unet32"])
 def test_net_fp16_mfma_path_vs_fp32(aname):
     """BASELINE cfg 5: convolutions on the fp16 MFMA path (operands rounded to half at the matrix core, fp32

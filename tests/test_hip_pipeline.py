@@ -549,3 +549,9 @@ def test_full_cfg5_4000x6000_unclipped_matches_reference(golden):
     psnr = 10 * np.log10(1.0 / max(((got - ref) ** 2).mean(), 1e-30))
     print(f"[parity] cfg5 4000x6000 fp16-MFMA path vs the reference's output: PSNR {psnr:.1f} dB")
     assert psnr >= 55.0
+    # ... and the fp16 path denoises as well as the float32 path: PSNR against the CLEAN frame within 0.01 dB (north_star)
+    cl = np.asarray(clean, np.float64)
+    pc = lambda a: 10 * np.log10(1.0 / float(np.mean((np.clip(a.cpu().numpy().astype(np.float64), 0, 1) - np.clip(cl, 0, 1)) ** 2)))
+    p32, p16 = pc(res['raw_dns'][0]), pc(r16['raw_dns'][0])
+    print(f"[parity] cfg5 4000x6000 PSNR vs clean: fp32 path {p32:.4f} dB, fp16 path {p16:.4f} dB")
+    assert abs(p32 - p16) <= 0.01

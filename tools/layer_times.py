@@ -11,6 +11,8 @@ if os.environ.get("SP_CONV1_MIN_LEVEL"):            # A/B of the engine's data-f
     E.SP_CONV1_MIN_LEVEL = int(os.environ["SP_CONV1_MIN_LEVEL"])
 arch = dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True)
 net = A.GuidedResUnet(dict(arch)); net.load_state_dict(S.procedural_state_dict(net, 0)); net = net.to('cuda').eval()
+if os.environ.get("PRECISION"):                    # 'fp16': the BASELINE cfg 5 path (python tools/layer_times.py 1 2016 3008)
+    net.precision = os.environ["PRECISION"]
 plan = P._plan_of(net, torch.device('cuda'))
 B, Hh, Ww = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (1, 1504, 2016)
 x = torch.rand(B, Hh, Ww, 4, device='cuda'); t = torch.full((B,), 0.03, device='cuda'); ub = x.reshape(B, -1).max(1).values.contiguous()

@@ -171,7 +171,7 @@ class YOND_SIDD:
 
     def IterDenoiseGroup(self, datas, params_list):
         """IterDenoise for several items at once (pipeline.IterDenoiseGroup): round 1 of the G images as ONE batch-(32 G) forward, round 2
-        likewise; every image keeps its own estimates, tables and t, and its result is IterDenoise's bit for bit.  The reference takes the
+        likewise; every image keeps its own estimates, tables and t, and its result is IterDenoise's.  The reference takes the
         images one by one (:507-514); they are independent, and 32 blocks of 128 x 128 packed pixels leave the deep levels of a forward
         (16 x 16 and 8 x 8 pixels) far too small for the chip."""
         ress = P.IterDenoiseGroup([(d['lr'], d.get('lr_full')) for d in datas], self.net, self.arch, self.pipe, ps=[q['p'] for q in params_list],
@@ -320,7 +320,7 @@ class YONDParser:
         a.add_argument('--loaders', type=int, default=4, help="loader threads that read and upload the items ahead of the GPU")
         a.add_argument('--prefetch', type=int, default=4, help="items the loader threads may be ahead of the GPU (at least two groups)")
         a.add_argument('--group', type=int, default=4, help="images denoised together: round 1 of a group is ONE batch-(32 x group) forward, round 2 another "
-                       "(per image the results are those of --group 1, bit for bit)")
+                       "(per image the results are those of --group 1)")
         return a.parse_args(args)
 
 

@@ -637,14 +637,14 @@ extern "C" int yond_conv2d_f32(const YondConvDesc* dp, void* stream) {
     const YondConvDesc& d = *dp;
     hipStream_t st = (hipStream_t)stream;
     if (!d.src0 || !(d.dst || d.out4_dst) || !d.wpk || d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Ho <= 0 || d.Wo <= 0) return YOND_EINVAL;
-    if (d.out4_dst && (d.algo != 3 || !d.out4_w || d.Cout != 32 || d.stride != 1)) return YOND_EUNSUPPORTED;   // fused projection: conv_split.hip only
+    if (d.out4_dst && ((d.algo != 3 && d.algo != 4) || !d.out4_w || d.Cout != 32 || d.stride != 1)) return YOND_EUNSUPPORTED;   // fused projection: conv_split.hip only
     if (d.C1 > 0 && !d.src1) return YOND_EINVAL;
     if (d.shuffle < 0 || d.shuffle > 2) return YOND_EINVAL;
-    if (d.shuffle == 2 && d.algo != 3) return YOND_EUNSUPPORTED;               // two sub-positions per tile: the split-operand kernel only
+    if (d.shuffle == 2 && d.algo != 3 && d.algo != 4) return YOND_EUNSUPPORTED;   // two sub-positions per tile: the split-operand kernel only
     if ((long long)d.N * d.H * d.W > 0x7fffffffLL) return YOND_EUNSUPPORTED;    // 32-bit pixel offsets
     if (d.pre_act != 0 && d.pre_act != 1) return YOND_EINVAL;
     if (d.in_fmt < 0 || d.in_fmt > 2 || d.out_fmt < 0 || d.out_fmt > 2 || (d.res_fmt != 0 && d.res_fmt != 2)) return YOND_EINVAL;
-    if ((d.in_fmt || d.out_fmt || d.res_fmt) && d.algo != 3) return YOND_EUNSUPPORTED;       // other formats: the split-operand kernel only
+    if ((d.in_fmt || d.out_fmt || d.res_fmt) && d.algo != 3 && d.algo != 4) return YOND_EUNSUPPORTED;       // other formats: the split-operand kernel only (algo 4: h-only planes)
     if (d.algo == 1) return yond_conv_wino_dispatch(d, st);
     if (d.algo == 3 || d.algo == 4) return yond_conv_split_dispatch(d, st);
     if (d.algo != 0 && d.algo != 2 && d.algo != 5) return YOND_EINVAL;

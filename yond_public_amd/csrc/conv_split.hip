@@ -20,6 +20,14 @@ SPLIT_GROUP_ISP_K1S2(SPLIT_EXTERN)
 SPLIT_GROUP_K1_SUB2(SPLIT_EXTERN)
 SPLIT_GROUP_WRES(SPLIT_EXTERN)
 SPLIT_GROUP_D2(SPLIT_EXTERN)
+SPLIT_GROUP_H_OSP(SPLIT_EXTERN)
+SPLIT_GROUP_H_ISP_OSP(SPLIT_EXTERN)
+SPLIT_GROUP_H_ISP_O4(SPLIT_EXTERN)
+SPLIT_GROUP_H_K1S2(SPLIT_EXTERN)
+SPLIT_GROUP_H_D2(SPLIT_EXTERN)
+SPLIT_GROUP_H_SUB2(SPLIT_EXTERN)
+SPLIT_GROUP_H128_OSP(SPLIT_EXTERN)
+SPLIT_GROUP_H128_ISP_OSP(SPLIT_EXTERN)
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
 // ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has
@@ -167,31 +175,32 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         // zero-weight channels up to a multiple of 48], split-plane inputs
         const int Cr = d.Cout / 4;
         const int pad = d.C1 - 2 * Cr;
-        if (parts != 2 || d.ksize != 1 || d.stride != 1 || d.Cout % 128 || d.tn != 64 || d.C0 % 16 || pad < 0 || pad >= 48 || pad % 16 ||
+        if (d.ksize != 1 || d.stride != 1 || d.Cout % 128 || d.tn != 64 || d.C0 % 16 || pad < 0 || pad >= 48 || pad % 16 ||
             (d.C0 + d.C1) % 48 || d.in_fmt != YOND_FMT_SPLIT_PLANES || d.out_fmt == YOND_FMT_SPLIT_PLANES || d.res_fmt || d.pre_act || d.res ||
             d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W || !d.src1)
             return YOND_EUNSUPPORTED;
         const long long e0 = (long long)d.N * (d.C0 / 16) * 4 * YOND_SP_PLANE_UNITS(d.H, d.W) * 4;
         const long long e1 = (long long)d.N * (Cr / 16) * 4 * YOND_SP_PLANE_UNITS(2 * d.H, 2 * d.W) * 4;
         if (e0 >= 0x7fffffffLL || e1 >= 0x7fffffffLL) return YOND_EUNSUPPORTED;
+        if (parts == 1) return launch_split<1, 8, 64, 2, 1, 3, false, false, true, 2, false, true>(d, st);
         return launch_split<1, 8, 64, 2, 2, 3, false, false, true, 2, false, true>(d, st);
     }
     const int tn = yond_conv_split_supported(d.ksize, d.stride, d.C0 + d.C1, d.Cout);
     if (!tn || d.C0 % 16 != 0 || d.C1 % 16 != 0 || (d.shuffle != 0) != (d.ksize == 1)) return YOND_EUNSUPPORTED;
     // h-only operands (algo 4) may be packed for 128-channel tiles: 3x3 stride-1 layers with plain tensors (conv_split_kernel.h, HALF128)
-    const bool half128 = parts == 1 && d.tn == 128 && tn == 64 && d.ksize == 3 && d.stride == 1 && d.Cout % 128 == 0 && !d.in_fmt && !d.out_fmt &&
-                         !d.res_fmt && !d.out4_dst && !d.dst2;
+    const bool half128 = parts == 1 && d.tn == 128 && tn == 64 && d.ksize == 3 && d.stride == 1 && d.Cout % 128 == 0 && !d.out4_dst && !d.dst2 &&
+                         (d.out_fmt == YOND_FMT_SPLIT_PLANES || (!d.in_fmt && !d.out_fmt && !d.res_fmt));     // plain tensors, or a producer of the h-only flow
     if (d.tn != tn && !half128) return YOND_EINVAL;             // the layout the weights were packed for
     if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
     // tensor formats (include/yond_hip.h): split planes in (LDS-DMA staging) / out (stored from the accumulator layout), planes
     // of 4 channels for the float32 tensors that are read as residuals
     const bool isp = d.in_fmt == YOND_FMT_SPLIT_PLANES, osp = d.out_fmt == YOND_FMT_SPLIT_PLANES;
     const bool ip4 = d.in_fmt == YOND_FMT_PLANES4, op4 = d.out_fmt == YOND_FMT_PLANES4, rp4 = d.res_fmt == YOND_FMT_PLANES4;
-    if ((d.in_fmt || d.out_fmt || d.res_fmt) && parts != 2) return YOND_EUNSUPPORTED;
+    // (parts 1 -- the fp16 path: the same formats with H-ONLY planes, [n][C/16][channel half][units]: 2 bytes per element)
     if (d.res_fmt != YOND_FMT_NHWC_F32 && !rp4) return YOND_EINVAL;
     if (isp && d.pre_act) return YOND_EUNSUPPORTED;             // the producer applied the activation
     // second output (SiLU in split planes): the stride-2 layers with split-plane input and planes-of-4 output
-    if (d.dst2 && !(parts == 2 && isp && op4 && ((d.ksize == 3 && d.stride == 2 && d.Cout % 16 == 0) || (d.ksize == 1 && d.shuffle == 1 && tn == 64 && (d.Cout / 4) % 64 == 0)))) return YOND_EUNSUPPORTED;
+    if (d.dst2 && !(isp && op4 && ((d.ksize == 3 && d.stride == 2 && d.Cout % 16 == 0) || (d.ksize == 1 && d.shuffle == 1 && tn == 64 && (d.Cout / 4) % 64 == 0)))) return YOND_EUNSUPPORTED;
     if (rp4 != (osp && d.res != nullptr)) return YOND_EUNSUPPORTED;   // a split-plane store reads its residual in planes of 4, nothing else does
     if (osp && d.res && !isp) return YOND_EUNSUPPORTED;              // ... and only conv2 of a block has one: split-plane input
     if (ip4 && (long long)d.N * (d.C0 > d.C1 ? d.C0 : d.C1) * d.H * d.W * (d.ksize == 1 ? 4 : 1) >= 0x7fffffffLL) return YOND_EUNSUPPORTED;   // 32-bit element offsets
@@ -208,7 +217,13 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     }
     if (d.ksize == 1) {
         // the decoder GEMM: low-resolution input (C0) + skip tensor at the output resolution (C1), pixel-shuffle store
-        if (parts != 2 || d.pre_act || d.res || d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W || osp || ip4) return YOND_EUNSUPPORTED;
+        if (d.pre_act || d.res || d.out4_dst || d.post_act == 1 || d.Ho != d.H || d.Wo != d.W || osp || ip4) return YOND_EUNSUPPORTED;
+        if (parts == 1) {
+            // h-only operands: the decoder GEMM of the split-plane flow only (h-only planes in, planes of 4 channels out)
+            if (!isp || !d.src1) return YOND_EUNSUPPORTED;
+            if (d.dst2) return launch_split<1, 8, 64, 2, 1, 3, false, false, true, 2, false, false, true>(d, st);
+            return tn == 32 ? launch_split<1, 8, 32, 1, 1, 3, false, false, true, 2>(d, st) : launch_split<1, 8, 64, 2, 1, 3, false, false, true, 2>(d, st);
+        }
         if (isp && tn == 64 && d.Wo <= 16 && d.src1 && !d.dst2 && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
             // input at most 16 pixels wide: 2 / 4 sub-tiles per MFMA row (conv_split_kernel.h, FOLD) when that saves a round of 256 workgroups
             const int f = d.Wo <= 8 ? 4 : 2;
@@ -238,6 +253,10 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
                 return d.dst2 ? launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true, 4>(d, st) : launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, false, 4>(d, st);
             }
         }
+        if (isp && parts == 1) {
+            if (!op4) return YOND_EUNSUPPORTED;
+            return d.dst2 ? launch_split<2, 4, 64, 1, 1, 2, false, false, false, 2, false, false, true>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false, false, false, 2>(d, st);
+        }
         if (isp && d.dst2) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true>(d, st);
         if (isp) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2>(d, st);
         if (!isp && parts == 2 && d.Wo <= 16 && !d.src1 && !d.res && !d.in_fmt && !d.out_fmt && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
@@ -251,7 +270,7 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         return parts == 2 ? launch_split<2, 4, 64, 1, 2, 2, false>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false>(d, st);
     }
     if (d.Ho != d.H || d.Wo != d.W) return YOND_EINVAL;
-    if (d.out4_dst && (tn != 32 || parts != 2)) return YOND_EUNSUPPORTED;
+    if (d.out4_dst && (tn != 32 || (parts != 2 && !isp))) return YOND_EUNSUPPORTED;
     if (op4) return YOND_EUNSUPPORTED;                          // (3x3 stride-1 layers store [N][H][W][C] or split planes)
     // 12-row or 8-row tiles (64-channel kernels): 256 persistent workgroups walk the tiles in rounds, so a launch costs
     // rounds x rows per tile; a row of a 12-row tile is ~10 % cheaper (0.59 instead of 0.78 KiB of LDS fragments per MFMA, 1.5x the MFMA
@@ -269,6 +288,22 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     if (wres && isp && osp && !d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, false, false, false, true, true>(d, st);
     if (wres && isp && !osp && d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, false, true, false, true, false>(d, st);
     if (wres && !isp && osp && d.pre_act && !d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, true, false, false, false, true>(d, st);
+    if ((isp || osp) && parts == 1) {
+        // the flow on h-only planes: conv1 (float32 planes of 4 in, SiLU staged, h-only store), conv2 / deep conv1 (h-only in by LDS-DMA), the
+        // last convolution with the fused output projection
+        if (osp && d.out4_dst) return YOND_EUNSUPPORTED;
+        if (!isp && !(osp && d.pre_act)) return YOND_EUNSUPPORTED;
+        if (isp && !osp) return (d.out4_dst && tn == 32) ? launch_split<1, 16, 32, 2, 1, 3, false, true, false, true>(d, st) : YOND_EUNSUPPORTED;
+        if (half128) return isp ? launch_split<1, 8, 128, 2, 1, 3, false, false, false, true, true>(d, st) : launch_split<1, 8, 128, 2, 1, 3, true, false, false, false, true>(d, st);
+        if (isp) {
+            if (tn == 64 && tiles12 >= 256) return launch_split<1, 12, 64, 3, 1, 2, false, false, false, true, true>(d, st);
+            if (tn == 64) return launch_split<1, 8, 64, 2, 1, 3, false, false, false, true, true>(d, st);
+            return launch_split<1, 16, 32, 2, 1, 3, false, false, false, true, true>(d, st);
+        }
+        if (tn == 64 && tiles12 >= 256) return launch_split<1, 12, 64, 3, 1, 2, true, false, false, false, true>(d, st);
+        if (tn == 64) return launch_split<1, 8, 64, 2, 1, 3, true, false, false, false, true>(d, st);
+        return launch_split<1, 16, 32, 2, 1, 3, true, false, false, false, true>(d, st);
+    }
     if (isp || osp) {
         if (osp && d.out4_dst) return YOND_EUNSUPPORTED;
         // images at most 16 pixels wide (the deepest level of a batch of small blocks): a 32-pixel MFMA row would be half padding -- two

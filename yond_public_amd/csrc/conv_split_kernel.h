@@ -99,7 +99,7 @@ struct SplitCfg {
     // h-only operands (PARTS 1) leave the transposed epilogue no consumed buffer large enough for its scratch (8 waves x 32 pixels x 36 floats):
     // their kernels use little LDS, so the scratch gets a region of its own behind everything else
     static constexpr int EP_FLOATS_C = 8 * 32 * 36;
-    static constexpr bool EP_OWN = PARTS == 1 && STRIDE == 1 && !K1 && EP_FLOATS_C > (TN >= 64 ? W_FLOATS : IN_FLOATS);
+    static constexpr bool EP_OWN = PARTS == 1 && STRIDE == 1 && EP_FLOATS_C > ((TN >= 64 && !K1) ? W_FLOATS : IN_FLOATS);
     static constexpr int EP_OFF = FILM_OFF + FILM_FLOATS;
     static constexpr int SMEM_BYTES = (EP_OFF + (EP_OWN ? EP_FLOATS_C : 0)) * 4;  // (W4: the O4 instantiation only; FILM: the split-plane epilogue only)
     // input in SPLIT PLANES (YondConvDesc.in_fmt 1): a step's 2 x PARTS x NPT planes arrive by LDS-DMA alone, one 16-byte unit
@@ -150,22 +150,30 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // latency; ISPM 2 (ISR) through the three register sets of the staging pipeline (a load has two steps to arrive), written to LDS
     // as whole 16-byte units with no arithmetic -- the stride-2 layers and the decoder GEMMs, whose steps hold 9-27 MFMAs per wave
     constexpr bool ISP = ISPM == 1, ISR = ISPM == 2;
-    static_assert(ISPM == 0 || (!PRE && PARTS == 2), "split-plane input: the producer applied the activation; split precision only");
-    static_assert(!OSP || (!O4 && !K1 && STRIDE == 1 && PARTS == 2), "split-plane output: 3x3 stride-1 layers at split precision");
+    // (PARTS 1 -- the fp16 path, BASELINE cfg 5 -- runs the same data flow on H-ONLY planes: [n][C/16][channel half][H*W (+ zero pad)] units
+    // of 8 halves, i.e. 2 bytes per element; the operands are the halves the plain-tensor h-only kernels would have rounded when staging)
+    static_assert(ISPM == 0 || !PRE, "split-plane input: the producer applied the activation");
+    static_assert(!OSP || (!O4 && !K1 && STRIDE == 1), "split-plane output: 3x3 stride-1 layers");
     static_assert(!S2 || (K1 && ISPM == 2 && TN == 64), "two sub-positions per tile: the decoder GEMM with register-staged split planes");
-    static_assert(!D2 || (PARTS == 2 && !OSP && !O4 && ((!K1 && STRIDE == 2) || (K1 && ISPM == 2 && !S2 && TN == 64))), "second output: the stride-2 layers and the decoder GEMM at split precision");
+    static_assert(!D2 || (!OSP && !O4 && ((!K1 && STRIDE == 2) || (K1 && ISPM == 2 && !S2 && TN == 64))), "second output: the stride-2 layers and the decoder GEMM at split precision");
     constexpr int NACC = PARTS;                              // [0] h_w h_x ; [1] the two cross terms (carry the 2^11 scale)
-    constexpr int NIN = ISP ? 0 : C::NIN;                    // register-staged 16-byte items per thread and step
+    // register-staged 16-byte items: 4 per pixel and 16-channel chunk from float32 tensors (4 channels each); from split planes (ISR) one per
+    // plane = 2 PARTS per pixel (a whole unit of 8 halves)
+    constexpr int IPP = ISR ? 2 * PARTS : 4;
+    constexpr int PIX_ITEMS = C::IH * C::IW * IPP;            // staging items of one 16-channel chunk
+    constexpr int NITEM = C::NPT * PIX_ITEMS;                 // ... of a step
+    static_assert(!K1 || PIX_ITEMS % C::NT == 0, "1x1 mode: whole chunks per pass of the staging threads");
+    constexpr int NIN = ISP ? 0 : (NITEM + C::NT - 1) / C::NT;   // register-staged 16-byte items per thread and step
     constexpr int NINA = NIN > 0 ? NIN : 1;                  // (array extents)
     constexpr int NDI = ISP ? C::NDI : 0;                    // input LDS-DMAs per wave and step
     // (K1: a thread's items k and k + PIX_ITEMS / NT are the SAME pixel of different 16-channel chunks -- one offset serves both)
-    constexpr int KD = K1 ? C::PIX_ITEMS / C::NT : NIN;      // distinct pixels among a thread's register-staged items
+    constexpr int KD = K1 ? PIX_ITEMS / C::NT : NIN;      // distinct pixels among a thread's register-staged items
     // (LDS-DMA input: a slot's unit offset inside its plane depends on the slot's position in the plane only -- slots k and k + DPER
     // of a wave address the same units of different planes)
     constexpr int DPER = C::WPP / split_gcd(C::WPP, 8);
     constexpr int NG = ISP ? (NDI < DPER ? NDI : DPER) : KD;  // per-tile offsets a thread keeps
     constexpr int NOPS = C::NWT + NIN + NDI;                 // vector-memory instructions per thread and step
-    constexpr int KEEP = ISP ? (C::WAHEAD == 2 ? C::NWT_MIN : 0) : C::KEEP;
+    constexpr int KEEP = ISP ? (C::WAHEAD == 2 ? C::NWT_MIN : 0) : (C::WAHEAD == 2 ? NIN + C::NWT_MIN : NIN);   // memory operations that may stay in flight across a barrier
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -213,20 +221,20 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         if constexpr (S2) return (ct % cpb) * 32 + (cu & 31);
         return cu % Cr;
     };
-    const int my_sl = tid & 3;                               // the thread's 4-channel slot of a pixel (512 % 4 == 0)
+    const int my_sl = tid & (IPP - 1);                       // the thread's 4-channel slot of a pixel (512 % 4 == 0); ISR: its PLANE (channel half x part)
     const int my_plane = (my_sl >> 1) * PARTS * C::PLANE + (my_sl & 1) * 2;
 
     int in_lds[NINA];
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
         const int it = tid + k * C::NT;
-        const int pt = it / C::PIX_ITEMS;                   // pseudo-tap (K1; 0 otherwise)
-        const int pix = (it % C::PIX_ITEMS) / 4;
+        const int pt = it / PIX_ITEMS;                      // pseudo-tap (K1; 0 otherwise)
+        const int pix = (it % PIX_ITEMS) / IPP;
         const int py = pix / C::IW, px = pix % C::IW;
         const int lp = (STRIDE == 2) ? py * C::TWP + (px & 1) * C::HALF + (px >> 1) : py * C::TWP + px;
-        in_lds[k] = my_plane + (it < C::NITEM ? pt * 2 * PARTS * C::PLANE + lp * 4 : C::IH * C::TWP * 4);
-        // ISR: the thread's slot is a PLANE (channel half my_sl >> 1, part my_sl & 1) and the item a whole 16-byte unit
-        if constexpr (ISR) in_lds[k] = ((my_sl >> 1) * PARTS + (my_sl & 1)) * C::PLANE + (it < C::NITEM ? pt * 2 * PARTS * C::PLANE + lp * 4 : C::IH * C::TWP * 4);
+        in_lds[k] = my_plane + (it < NITEM ? pt * 2 * PARTS * C::PLANE + lp * 4 : C::IH * C::TWP * 4);
+        // ISR: the thread's slot is a PLANE (index my_sl = channel half x PARTS + part) and the item a whole 16-byte unit
+        if constexpr (ISR) in_lds[k] = my_sl * C::PLANE + (it < NITEM ? pt * 2 * PARTS * C::PLANE + lp * 4 : C::IH * C::TWP * 4);
     }
 
     struct Tile {
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 #pragma unroll
         for (int k = 0; k < KD; ++k) {
             const int it = tid_g + k * C::NT;
-            const int pix = (it % C::PIX_ITEMS) / 4;
+            const int pix = (it % PIX_ITEMS) / IPP;
             const int py = pix / C::IW, px = pix % C::IW;
             int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
             int nb = n * d.H * d.W;                                // the image's first pixel
@@ -322,12 +330,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 const FGeo g = fold_geo(T.fu0 + sb);
                 gy = g.oy0 >= d.Ho ? -1 : (K1 ? g.oy0 + py : g.oy0 * STRIDE - 1 + py);     // (past the last sub-tile: zeros)
                 gx = K1 ? g.ox0 + lx : g.ox0 * STRIDE - 1 + lx;
-                ushift1 = (g.n - n) * (d.C1 / 16) * 4 * PS1;
+                ushift1 = (g.n - n) * (d.C1 / 16) * (2 * PARTS) * PS1;
                 // the sub-tile's image: [N][H][W][C]: its pixels; planes of 4 channels: the plane base (load_src) is sub-tile 0's image's, C0/4 planes per image
                 nb = d.in_fmt == YOND_FMT_PLANES4 ? nb + (g.n - n) * (d.C0 / 4) * d.H * d.W : g.n * d.H * d.W;
-                ushift = (g.n - n) * (d.C0 / 16) * 4 * PS0;
+                ushift = (g.n - n) * (d.C0 / 16) * (2 * PARTS) * PS0;
             }
-            const bool ok = it < C::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            const bool ok = it < NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
             T.goff[k] = ok ? (nb + gy * d.W + gx) : -1;
             if constexpr (ISR) T.goff[k] = ok ? gy * d.W + gx + ushift : d.H * d.W;      // unit inside a plane (n is in the plane base); outside: the zero unit
             if constexpr (K1) {
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             if constexpr (ISR) {
                 // split planes: unit index inside the plane * 4 floats + the base of plane (n, chunk, channel half, part = the slot)
                 L.A[t] = 4;
-                L.B[t] = ((n * (Cs / 16) + cc / 16) * 4 + my_sl) * (L.hi[t] ? PS1 : PS0) * 4;
+                L.B[t] = ((n * (Cs / 16) + cc / 16) * (2 * PARTS) + my_sl) * (L.hi[t] ? PS1 : PS0) * 4;
             } else if (in_p4) {
                 const int hw = d.H * d.W * (L.hi[t] ? 4 : 1);
                 L.A[t] = 4;
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
     auto issue_load = [&](auto pc, auto kc, const Tile& T, const LoadSrc& L) {
         constexpr int P = decltype(pc)::value, k = decltype(kc)::value;
-        constexpr int t = K1 ? (k * C::NT) / C::PIX_ITEMS : 0;  // the item's chunk (K1: PIX_ITEMS is a multiple of the thread count)
+        constexpr int t = K1 ? (k * C::NT) / PIX_ITEMS : 0;  // the item's chunk (K1: PIX_ITEMS is a multiple of the thread count)
         constexpr int kd = k % KD;                             // (K1: the item's pixel)
         const bool ok = T.goff[kd] >= 0;                       // outside the image: read pixel 0, zeroed at the LDS write
         int po = T.goff[kd];
@@ -676,7 +684,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // tile, every wave of the CU at once): the loads of the first two rows are issued at the START of the tile's last step
     // and land under its MFMAs; a third row is requested when the epilogue begins, ahead of the first rows' arithmetic.
     constexpr bool RPF = ISP && !OSP && EP_FIT && !K1 && C::NW == 1;
-    constexpr int PFR = MW < 2 ? MW : 2;
+    constexpr int PFR = MW < 2 ? MW : (C::NW >= 2 ? 1 : 2);    // (two blocks per wave -- the h-only flow's 128-channel tiles: one prefetched row is what the registers hold)
     f32x4 prr[RPF ? PFR : 1][4];
     float pxq[RPF && O4 ? PFR : 1][4];
     auto res_addr = [&](const Tile& T, int m, int j) -> const float* {      // residual of pixel pj + 8 j of the wave's row m, channels 4 u ..
@@ -949,7 +957,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float y = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, acc[0][m][nn][4 * g + e]);
+                        float y = acc[0][m][nn][4 * g + e];
+                        if constexpr (PARTS == 2) y = fmaf(acc[1][m][nn][4 * g + e], 1.0f / 2048.0f, y);
                         y = fmaf(y, es[e], et[e]);
                         if constexpr (ACT == 2 || ACT < 0) y = y > 0.0f ? y : y * slope_eff;
                         if constexpr (ACT == 1) y = split_silu(y);
@@ -959,12 +968,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                     }
                     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                     const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    const f16x4 l = {(_Float16)((v[0] - (float)h[0]) * 2048.0f), (_Float16)((v[1] - (float)h[1]) * 2048.0f),
-                                     (_Float16)((v[2] - (float)h[2]) * 2048.0f), (_Float16)((v[3] - (float)h[3]) * 2048.0f)};
                     char* pp = pb + (size_t)(oy * d.Wo + ox) * 16;
-                    if (ok) {
-                        *(f16x4*)pp = h;
-                        *(f16x4*)(pp + (size_t)PSo * 16) = l;
+                    if (ok) *(f16x4*)pp = h;
+                    if constexpr (PARTS == 2) {
+                        const f16x4 l = {(_Float16)((v[0] - (float)h[0]) * 2048.0f), (_Float16)((v[1] - (float)h[1]) * 2048.0f),
+                                         (_Float16)((v[2] - (float)h[2]) * 2048.0f), (_Float16)((v[3] - (float)h[3]) * 2048.0f)};
+                        if (ok) *(f16x4*)(pp + (size_t)PSo * 16) = l;
                     }
                 }
             }
@@ -1033,14 +1042,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                         for (int e = 0; e < 4; ++e) a[e] = split_silu(v[e]);
                         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
                         const f16x4 h = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3]};
-                        const f16x4 l = {(_Float16)((a[0] - (float)h[0]) * 2048.0f), (_Float16)((a[1] - (float)h[1]) * 2048.0f),
-                                         (_Float16)((a[2] - (float)h[2]) * 2048.0f), (_Float16)((a[3] - (float)h[3]) * 2048.0f)};
                         const int c8 = cbase - 4 * lh + 8 * g;                          // first channel of the lane's unit
                         const size_t PS2 = (size_t)yond_sp_plane_units(Hout, Wout);
-                        char* pp = (char*)d.dst2 + ((size_t)(((lg.n * (Cr / 16) + (c8 >> 4)) * 2 + ((c8 >> 3) & 1)) * 2) * PS2 + (size_t)pixo) * 16 + lh * 8;
-                        if (ok) {
-                            *(f16x4*)pp = h;
-                            *(f16x4*)(pp + PS2 * 16) = l;
+                        char* pp = (char*)d.dst2 + ((size_t)(((lg.n * (Cr / 16) + (c8 >> 4)) * 2 + ((c8 >> 3) & 1)) * PARTS) * PS2 + (size_t)pixo) * 16 + lh * 8;
+                        if (ok) *(f16x4*)pp = h;
+                        if constexpr (PARTS == 2) {
+                            const f16x4 l = {(_Float16)((a[0] - (float)h[0]) * 2048.0f), (_Float16)((a[1] - (float)h[1]) * 2048.0f),
+                                             (_Float16)((a[2] - (float)h[2]) * 2048.0f), (_Float16)((a[3] - (float)h[3]) * 2048.0f)};
+                            if (ok) *(f16x4*)(pp + PS2 * 16) = l;
                         }
                     }
                 }
@@ -1329,5 +1338,27 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 #define SPLIT_GROUP_WRES(X)                                                                             \
     X(1, 16, 32, 2, 2, 2, true, false, false, false, true) X(1, 16, 32, 2, 2, 2, false, false, false, true, true) \
     X(1, 16, 32, 2, 2, 2, false, true, false, true, false)
+// ---- the split-plane data flow on H-ONLY planes (PARTS 1: the fp16 path, BASELINE cfg 5): block-internal and block-output tensors travel as
+// 2-byte halves [n][C/16][channel half][H*W (+ zero pad)] x 16-byte units
+// conv1 from the float32 block input (planes of 4 channels), SiLU in its staging, h-only store
+#define SPLIT_GROUP_H_OSP(X)                                                                            \
+    X(1, 12, 64, 3, 1, 2, true, false, false, false, true) X(1, 8, 64, 2, 1, 3, true, false, false, false, true) \
+    X(1, 16, 32, 2, 1, 3, true, false, false, false, true)
+// conv2 (h-only planes in by LDS-DMA, FiLM + float32 residual in planes of 4, h-only store) and conv1 of the levels whose producer stored SiLU(x)
+#define SPLIT_GROUP_H_ISP_OSP(X)                                                                        \
+    X(1, 12, 64, 3, 1, 2, false, false, false, true, true) X(1, 8, 64, 2, 1, 3, false, false, false, true, true) \
+    X(1, 16, 32, 2, 1, 3, false, false, false, true, true)
+// the last convolution with the fused output projection
+#define SPLIT_GROUP_H_ISP_O4(X) X(1, 16, 32, 2, 1, 3, false, true, false, true, false)
+// stride 2 and the decoder GEMMs: h-only planes through the register sets, planes of 4 channels (float32) out; with the second (h-only) output
+#define SPLIT_GROUP_H_K1S2(X)                                                                           \
+    X(1, 8, 32, 1, 1, 3, false, false, true, 2, false) X(1, 8, 64, 2, 1, 3, false, false, true, 2, false) \
+    X(2, 4, 64, 1, 1, 2, false, false, false, 2, false)
+#define SPLIT_GROUP_H_D2(X) X(2, 4, 64, 1, 1, 2, false, false, false, 2, false, false, true) X(1, 8, 64, 2, 1, 3, false, false, true, 2, false, false, true)
+#define SPLIT_GROUP_H_SUB2(X) X(1, 8, 64, 2, 1, 3, false, false, true, 2, false, true)
+// ... and 128-channel tiles for the flow's 3x3 layers with >= 128 output channels (one accumulator per block: a wave owns two blocks, as in HALF128)
+// (8-row tiles: the 12-row forms of these two spill 33 / 45 registers)
+#define SPLIT_GROUP_H128_OSP(X) X(1, 8, 128, 2, 1, 3, true, false, false, false, true)
+#define SPLIT_GROUP_H128_ISP_OSP(X) X(1, 8, 128, 2, 1, 3, false, false, false, true, true)
 #define SPLIT_INSTANTIATE(...) template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);
 #define SPLIT_EXTERN(...) extern template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);

@@ -44,6 +44,8 @@ WINO_DEFAULT = 'split'              # 'split': fp32-accurate split-operand fp16-
 # (Module attribute, not an environment switch: tools/ flip it for A/B runs.)
 SPLIT_PLANES = True
 SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
+HALF_FLOW = True                    # fp16 path: the whole forward in the split-plane data flow on H-ONLY planes (2 bytes per element; round 6)
+HALF_FLOW_TN128 = True              # ... its 3x3 layers with >= 128 output channels on 128-channel tiles (8 rows)
 HALF_TN128 = True                   # fp16 path (precision='fp16', BASELINE cfg 5): 128-channel tiles for the 3x3 stride-1 layers with >= 128 output channels
 FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
 FUSE_BLOCK0 = False                 # EXPERIMENT BUILDS ONLY (YOND_HIP_LIB=tools/probe/libyond_exp.so; the product library does not export the entry point):
@@ -147,17 +149,18 @@ class _PackedConv:
             self._packed['wino'] = (tn, torch.from_numpy(packed).to(self._dev))
         return self._packed['wino']
 
-    def split(self, parts=2):
-        """(tn, weights packed for the split-operand fp16-MFMA kernel) or None when the layer does not fit it."""
+    def split(self, parts=2, wide=True):
+        """(tn, weights packed for the split-operand fp16-MFMA kernel) or None when the layer does not fit it.
+        wide: h-only operands of a plain-tensor 3x3 layer may take 128-channel tiles (the split-plane flow's kernels do not)."""
         lib = L.load()
-        if self.shuffle != (self.ksize == 1) or (self.shuffle and parts != 2):
+        if self.shuffle != (self.ksize == 1):
             return None                     # ksize 1: the decoder's pixel-shuffle GEMM only (48-channel steps, >= 64 channels)
         tn = int(lib.yond_conv_split_supported(self.ksize, self.stride, self.cinp, self.gemm_n))
         if not tn:
             return None
-        if parts == 1 and HALF_TN128 and tn == 64 and self.ksize == 3 and self.stride == 1 and self.gemm_n % 128 == 0:
+        if parts == 1 and wide and HALF_TN128 and tn == 64 and self.ksize == 3 and self.stride == 1 and self.gemm_n % 128 == 0:
             tn = 128                        # h-only operands: one accumulator per block leaves room for two blocks per wave (conv_split_kernel.h)
-        key = ('split', parts)
+        key = ('split', parts) if tn != 128 else ('split', parts, 128)     # (train.py refreshes ('split', 2) in place every step)
         if key not in self._packed:
             packed = np.empty(self._wp.size * parts // 2, np.float32)
             rc = lib.yond_pack_conv_split_weight_f32(_np_ptr(self._wp), self.gemm_n, self.cinp, self.ksize, tn, parts, _np_ptr(packed))
@@ -188,10 +191,8 @@ class _PackedUpSub2:
                 m[dy, :, dx, :, :2 * c] = wc
                 m[dy, :, dx, :, 2 * c + dx * c:2 * c + (dx + 1) * c] = ws
         self._wp = np.ascontiguousarray(m.reshape(4 * c, k, 1, 1))
-        packed = np.empty(self._wp.size, np.float32)
-        rc = lib.yond_pack_conv_split_weight_f32(_np_ptr(self._wp), 4 * c, k, 1, 64, 2, _np_ptr(packed))
-        self.ok = rc == 0                                              # (-2: a weight outside fp16's range -> the plain form)
-        self.wpk = torch.from_numpy(packed).to(dev) if self.ok else None
+        self._dev, self._wpk = dev, {}
+        self.ok = self._pack(2) is not None                            # (-2: a weight outside fp16's range -> the plain form)
         b = torch.zeros(c, dtype=torch.float32)
         b[:] = b_f.detach().to('cpu', torch.float32)
         self.bias = b.to(dev)
@@ -201,8 +202,15 @@ class _PackedUpSub2:
         self.wmax = float(np.abs(self._wp).max())
         self.macs_per_pixel = 2 * c * c * 4 + 2 * c * c * 4
 
-    def split(self, parts=2):
-        return (64, self.wpk) if (self.ok and parts == 2) else None
+    def _pack(self, parts):
+        if parts not in self._wpk:
+            packed = np.empty(self._wp.size * parts // 2, np.float32)
+            rc = L.load().yond_pack_conv_split_weight_f32(_np_ptr(self._wp), self._wp.shape[0], self._wp.shape[1], 1, 64, parts, _np_ptr(packed))
+            self._wpk[parts] = torch.from_numpy(packed).to(self._dev) if rc == 0 else None
+        return self._wpk[parts]
+
+    def split(self, parts=2, wide=True):
+        return (64, self._pack(parts)) if (self.ok and self._pack(parts) is not None) else None
 
     def wino(self):
         return None
@@ -328,26 +336,30 @@ class DenoiserPlan:
         split precision, every 3x3 / stride-2 / decoder layer on the split-operand kernel, the output projection fused."""
         if not (SPLIT_PLANES and SP_FLOW) or getattr(self, 'strict', False) or getattr(self, 'conv_algo', WINO_DEFAULT) != 'split':
             return False
-        if getattr(self, 'precision', 'fp32') != 'fp32' or sp_plane_units(H, W) * 64 * 4 >= 2 ** 31:
+        prec = getattr(self, 'precision', 'fp32')
+        if prec not in ('fp32', 'fp16') or (prec == 'fp16' and not HALF_FLOW) or sp_plane_units(H, W) * 64 * 4 >= 2 ** 31:
             return False
+        parts = 2 if prec == 'fp32' else 1               # fp16 path (BASELINE cfg 5): the same flow on h-only planes, 2 bytes per element
         for i, blk in self.blocks.items():
             for k in ('conv1', 'conv2', 'pool', 'upsc'):
-                if k in blk and blk[k].split(2) is None:
+                if k in blk and blk[k].split(parts, wide=False) is None:
                     return False
-        return self._out4_fusable(self.blocks[9]['conv2'])
+        return self._out4_fusable(self.blocks[9]['conv2'], flow=True)
 
-    def _out4_fusable(self, pc):
-        """The 1x1 output projection can ride in the epilogue of the last 3x3 convolution: split kernel, one 32-channel tile."""
-        return (not getattr(self, 'strict', False) and getattr(self, 'conv_algo', WINO_DEFAULT) == 'split' and getattr(self, 'precision', 'fp32') == 'fp32'
-                and pc.ksize == 3 and pc.stride == 1 and pc.gemm_n == 32 and pc.split(2) is not None and FUSE_OUT4)
+    def _out4_fusable(self, pc, flow=False):
+        """The 1x1 output projection can ride in the epilogue of the last 3x3 convolution: split kernel, one 32-channel tile (on the fp16 path
+        only inside the split-plane flow: its h-only kernel with the projection takes h-only planes)."""
+        prec = getattr(self, 'precision', 'fp32')
+        return (not getattr(self, 'strict', False) and getattr(self, 'conv_algo', WINO_DEFAULT) == 'split' and (prec == 'fp32' or (prec == 'fp16' and flow))
+                and pc.ksize == 3 and pc.stride == 1 and pc.gemm_n == 32 and pc.split(2 if prec == 'fp32' else 1) is not None and FUSE_OUT4)
 
-    def _new_sp(self, key, N, H, W, Cc):
-        """A split-plane tensor [N][Cc/16][2][2][sp_plane_units(H, W)] x 16 bytes, kept per (key, shape) across forwards: the
-        zero units behind every plane are written once, here (producers never touch them)."""
+    def _new_sp(self, key, N, H, W, Cc, parts=2):
+        """A split-plane tensor [N][Cc/16][2][parts][sp_plane_units(H, W)] x 16 bytes, kept per (key, shape) across forwards: the
+        zero units behind every plane are written once, here (producers never touch them).  parts 1: h-only planes (the fp16 path)."""
         cache = self.__dict__.setdefault('_sp_cache', {})
-        k = (key, N, H, W, Cc)
+        k = (key, N, H, W, Cc, parts)
         if k not in cache:
-            cache[k] = torch.zeros(N * (Cc // 16) * 4 * sp_plane_units(H, W) * 4, dtype=torch.float32, device=self.dev)
+            cache[k] = torch.zeros(N * (Cc // 16) * 2 * parts * sp_plane_units(H, W) * 4, dtype=torch.float32, device=self.dev)
         return cache[k]
 
     def _conv(self, pc, src0, src1, N, H, W, dst, escale=None, eshift=None, ebatch=0, res=None, pre_act=0, post_act=0,
@@ -379,7 +391,10 @@ class DenoiserPlan:
         fp16 = prec == 'fp16' or algo == 'fp16'
         wino = split = None
         if algo in ('split', 'half'):
-            split = pc.split(2 if algo == 'split' else 1)
+            # (h-only operands: 128-channel tiles for plain tensors only; the decoder GEMM only inside the split-plane flow)
+            split = pc.split(2 if algo == 'split' else 1, wide=(not (in_fmt or out_fmt or res_fmt or dst2 is not None)) or (HALF_FLOW_TN128 and out_fmt == 1))
+            if algo == 'half' and pc.ksize == 1 and in_fmt != 1:
+                split = None
             if split is None and not fp16 and pc.ksize == 3:
                 wino = pc.wino()                     # 3x3 layers the split kernel does not take
         elif not fp16:
@@ -415,12 +430,12 @@ class DenoiserPlan:
             d.tile_order = self._tile_order
         clk = getattr(self, 'clk', None)             # bench.py: in-kernel clock of the split-operand launches (int64[2] on the device)
         d.clk = clk.data_ptr() if (clk is not None and d.algo in (3, 4)) else None
-        if (in_fmt or out_fmt or res_fmt) and d.algo != 3:
-            raise L.YondHipError("split-plane / 4-channel-plane tensors need the split-operand kernel (algo 3)")
+        if (in_fmt or out_fmt or res_fmt) and d.algo not in (3, 4):
+            raise L.YondHipError("split-plane / 4-channel-plane tensors need the split-operand kernel (algo 3, or 4 with h-only planes)")
         if out4 is not None:
             # (w [4][Cout], bias [4], network input NHWC4 or None, per-image maxima or None, destination NHWC4)
             w4, b4, x4, ub4, o4 = out4
-            if d.algo != 3:
+            if d.algo not in (3, 4):
                 raise L.YondHipError("fused output projection needs the split-operand 3x3 kernel")
             d.out4_w, d.out4_b = w4.data_ptr(), (b4.data_ptr() if b4 is not None else None)
             d.out4_x = x4.data_ptr() if x4 is not None else None
@@ -581,6 +596,7 @@ class DenoiserPlan:
             # so conv2, the stride-2 layers and the decoder GEMMs stage by LDS-DMA alone and every epilogue but the last stores
             # from the accumulator layout.  The last block keeps [N][H][W][C]: its conv2 carries the fused output projection.
             flow = self._sp_flow(N, H, W)
+            pt = 1 if (flow and getattr(self, 'precision', 'fp32') == 'fp16') else 2     # parts of the split-plane tensors: 1 = h-only planes (fp16 path)
             P4, SP = 2, 1
             a = self._new(N, H, W, nfp)
             L.check(lib.yond_conv_in_f32(L.ptr(x4), L.ptr(ub), N, H, W, nfp, L.ptr(self.conv_in_w), L.ptr(self.conv_in_b),
@@ -600,7 +616,7 @@ class DenoiserPlan:
                     xs = self._new(N, 2 * h, 2 * w, cp)
                     up = blk['upsc2'] if (flow and K1_SUB2 and 'upsc2' in blk) else blk['upsc']
                     # (decoder level of block i = 9 - i; images too narrow for the unfolded GEMM keep the folded kernels, which have no second output)
-                    xsp = (self._new_sp(('xspd', i), N, 2 * h, 2 * w, cp)
+                    xsp = (self._new_sp(('xspd', i), N, 2 * h, 2 * w, cp, pt)
                            if (flow and not last and (9 - i) in K1_D2_LEVELS and up is blk['upsc'] and cp % 64 == 0 and w > 16) else None)     # (the dispatcher's second output: 64-wide tiles, conv_split.hip)
                     self._conv(up, cur, skips[10 - i], N, h, w, xs, in_fmt=SP if flow else 0, out_fmt=xfmt, dst2=xsp)
                     h, w = 2 * h, 2 * w
@@ -612,17 +628,17 @@ class DenoiserPlan:
                 # conv2 stages them by LDS-DMA alone (the same bits again)
                 if flow and FUSE_BLOCK0 and h == H and cp == 32 and self._block0_weights(blk['conv1']) is not None and self._block0_weights(blk['conv2']) is not None:
                     # level 0: the whole block in one launch -- tmp never leaves the chip (csrc/block0_fused.hip)
-                    if last and self._out4_fusable(blk['conv2']):
+                    if last and self._out4_fusable(blk['conv2'], flow):
                         out4 = self._new(N, H, W, 4)
                         self._block0(blk['conv1'], blk['conv2'], cur, N, h, w, f, xfmt, out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4))
                         return out4
                     if not last:
-                        out = self._new_sp(('out', i), N, h, w, cp)
+                        out = self._new_sp(('out', i), N, h, w, cp, pt)
                         self._block0(blk['conv1'], blk['conv2'], cur, N, h, w, f, xfmt, dst=out)
                         cur = out
                         skips[i] = cur
                         nxt = self._new(N, h // 2, w // 2, blk['pool'].coutp)
-                        xsp = self._new_sp(('xsp', i + 1), N, h // 2, w // 2, blk['pool'].coutp) if (flow and i >= SP_CONV1_MIN_LEVEL) else None
+                        xsp = self._new_sp(('xsp', i + 1), N, h // 2, w // 2, blk['pool'].coutp, pt) if (flow and i >= SP_CONV1_MIN_LEVEL) else None
                         self._conv(blk['pool'], cur, None, N, h, w, nxt, in_fmt=SP, out_fmt=P4, dst2=xsp)
                         h, w = h // 2, w // 2
                         cur = nxt
@@ -630,7 +646,7 @@ class DenoiserPlan:
                 act_in_producer = self._split_pair(blk['conv1'], blk['conv2'])
                 sp = SP if (flow or (act_in_producer and SPLIT_PLANES and getattr(self, 'precision', 'fp32') == 'fp32'
                                       and sp_plane_units(h, w) * 64 < 2 ** 31)) else 0
-                tmp = self._new_sp(('tmp', i), N, h, w, cp) if sp else self._new(N, h, w, cp)
+                tmp = self._new_sp(('tmp', i), N, h, w, cp, pt) if sp else self._new(N, h, w, cp)
                 if xsp is not None and sp and act_in_producer:
                     # conv1's input as the producer of x stored it: SiLU applied, split -- staged by LDS-DMA alone
                     self._conv(blk['conv1'], xsp, None, N, h, w, tmp, escale=f[0], eshift=f[1], ebatch=1, pre_act=0, post_act=1,
@@ -640,14 +656,14 @@ class DenoiserPlan:
                                post_act=1 if act_in_producer else 0, in_fmt=xfmt, out_fmt=sp)
                 xsp = None
                 pre2 = 0 if act_in_producer else 1
-                if last and self._out4_fusable(blk['conv2']):
+                if last and self._out4_fusable(blk['conv2'], flow):
                     # the last block's output feeds only the 1x1 output projection: computed in this epilogue, never stored
                     out4 = self._new(N, H, W, 4)
                     self._conv(blk['conv2'], tmp, None, N, h, w, None, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2,
                                out4=(self.w_out, self.b_out, x4 if self.res else None, ub, out4), in_fmt=sp)
                     return out4
                 if flow:
-                    out = self._new_sp(('out', i), N, h, w, cp)
+                    out = self._new_sp(('out', i), N, h, w, cp, pt)
                     self._conv(blk['conv2'], tmp, None, N, h, w, out, escale=f[2], eshift=f[3], ebatch=1, res=cur, pre_act=pre2,
                                in_fmt=SP, out_fmt=SP, res_fmt=P4)
                 else:
@@ -657,7 +673,7 @@ class DenoiserPlan:
                 if i <= 4:
                     skips[i] = cur
                     nxt = self._new(N, h // 2, w // 2, blk['pool'].coutp)
-                    xsp = self._new_sp(('xsp', i + 1), N, h // 2, w // 2, blk['pool'].coutp) if (flow and i >= SP_CONV1_MIN_LEVEL) else None   # (level of block i + 1 = i)
+                    xsp = self._new_sp(('xsp', i + 1), N, h // 2, w // 2, blk['pool'].coutp, pt) if (flow and i >= SP_CONV1_MIN_LEVEL) else None   # (level of block i + 1 = i)
                     self._conv(blk['pool'], cur, None, N, h, w, nxt, in_fmt=SP if flow else 0, out_fmt=P4 if flow else 0, dst2=xsp)
                     h, w = h // 2, w // 2
                     cur = nxt

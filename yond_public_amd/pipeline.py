@@ -933,8 +933,8 @@ def _chain_denoise_blocks_group(blocks_list, net, arch, p, bufs, guard_slot):
     """The same for G images at once: image g's B blocks are stabilised with ITS parameter block and table (bufs[g]: one batched K1 per image
     into its slice of the network input), the G x B blocks go through ONE forward (images are independent, YOND_SIDD.py:507-514; every block
     carries its own maximum and its image's t -- the deep levels of a batch-32 forward of 128 x 128 blocks are 16 x 16 and 8 x 8 pixels and
-    leave most of the chip idle), one batched K4 per image.  Per block the kernels and their arguments are those of the one-image call:
-    the same bits.  Returns ([G] of [B][H][W], guard of the forward)."""
+    leave most of the chip idle), one batched K4 per image.  Per block the kernels and their arguments are those of the one-image call
+    (the forward of a block is bit-identical whatever batch it rides in: tests/test_hip_eval.py).  Returns ([G] of [B][H][W], guard of the forward)."""
     lib = L.load()
     G = len(blocks_list)
     B, H, W = blocks_list[0].shape
@@ -989,8 +989,9 @@ def _iter_denoise_chain_sidd_group(items, net, arch, pipe, p, log=None):
     tables (round 1: self estimate on its full frame; round 2: collaborative estimate on its own concatenations); round 1 of all G images is
     ONE batch-(32 G) forward, round 2 likewise (speculatively for every image: whether an image's guard ends it after round 1, :445-447, is
     read from its parameter block afterwards, as in the one-image chain); ONE synchronisation for the group.  Returns a list of G results
-    (None for an image that took a branch the chain leaves to the host-side path).  An image's result has the bits of its one-image call:
-    the group only changes which images share a launch (tests/test_hip_eval.py)."""
+    (None for an image that took a branch the chain leaves to the host-side path).  An image's result is that of its one-image call (the
+    group only changes which images share a launch; what differs is what two runs of ONE image differ by: the estimator's float64 moment
+    sums are accumulated with atomics -- tests/test_hip_eval.py)."""
     two = pipe.get('iter', 'iter') == 'iter' and pipe.get('max_iter', 1) >= 1
     if two and pipe.get('max_iter', 1) > 1:
         return [None] * len(items)
@@ -1278,7 +1279,8 @@ def IterDenoise(lr_raw, net, arch, pipe, lr_full=None, p=None, device=None, log=
 def IterDenoiseGroup(items, net, arch, pipe, ps=None, device=None, log=None, biaslut=None, ests=None):
     """`IterDenoise` for G images of the SIDD layout at once -- items: [(lr [32][256][256], lr_full or None)], ps / ests: per-image `p` / `est`
     (or one for all).  Images are independent (YOND_SIDD.py:507-514 takes them one by one); here round 1 of the G images is ONE batch-(32 G)
-    forward and round 2 another, every image with its own estimates, tables and t: per image the result is IterDenoise's, bit for bit.
+    forward and round 2 another, every image with its own estimates, tables and t: per image the result is IterDenoise's (the forward bit
+    for bit; the estimates to the rounding of their atomically accumulated sums, as between two IterDenoise runs).
     Images (or configurations) the grouped device chain does not cover go through IterDenoise one by one.  Returns the list of G results."""
     G = len(items)
     ps = list(ps) if isinstance(ps, (list, tuple)) else [ps] * G

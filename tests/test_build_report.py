@@ -31,6 +31,10 @@ def test_flow_kernels_do_not_spill():
     assert len(flow) >= 14
     bad = [r for r in flow if r.get("vgpr_spill", 0) or r.get("scratch", 0)]
     assert not bad, bad
+    # the fp16 path (BASELINE cfg 5) runs a guided net's whole forward on the flow's H-ONLY instantiations (PARTS 1: tests/test_hip_net.py
+    # asserts that its forward launches nothing else): every one of them is in `flow` above -- none spills
+    half_flow = [r for r in flow if (_args(r["name"]) + [0] * 13)[4] == 1]
+    assert len(half_flow) >= 15, len(half_flow)
     wg = [r for r in rep if "wgrad_split_kernel" in r["name"] or "wgrad_rows_kernel" in r["name"]]
     assert len(wg) >= 10 and not [r for r in wg if r.get("vgpr_spill", 0) or r.get("scratch", 0)], wg
     # the [N][H][W][C]-path instantiations (training forward / data gradients, UNetSeeInDark's unfused layers) keep a few spilled

@@ -72,7 +72,11 @@ def test_net_fp16_path_split_plane_flow_equals_plain_tensors(aname, shape):
     plan = net._get_plan(torch.device('cuda:0'))
     assert E.HALF_FLOW and plan._sp_flow(shape[0], shape[2], shape[3])
     with torch.no_grad():
+        plan.prof = []
         y_flow = net(x.to('cuda:0'), t.to('cuda:0')).cpu().numpy().astype(np.float64)
+        tags, plan.prof = [p[0] for p in plan.prof], None
+        # every MFMA convolution of the forward is an h-only launch of the split family (no generic kernel, no conversion inside a kernel)
+        assert len(tags) == 26 and all(tg.startswith("conv_split_kernel<") and tg.endswith(",1>") for tg in tags), tags
         E.HALF_FLOW = False
         try:
             assert not plan._sp_flow(shape[0], shape[2], shape[3])

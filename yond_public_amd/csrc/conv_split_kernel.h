@@ -1360,5 +1360,7 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 // (8-row tiles: the 12-row forms of these two spill 33 / 45 registers)
 #define SPLIT_GROUP_H128_OSP(X) X(1, 8, 128, 2, 1, 3, true, false, false, false, true)
 #define SPLIT_GROUP_H128_ISP_OSP(X) X(1, 8, 128, 2, 1, 3, false, false, false, true, true)
+// (resident weights for the 32 -> 32 layers, as SPLIT_GROUP_WRES, measured on this path in round 6: no gain -- its level 0 is bound by HBM bytes and the
+// SiLU arithmetic, not by the weight DMA -- and not built)
 #define SPLIT_INSTANTIATE(...) template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);
 #define SPLIT_EXTERN(...) extern template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);

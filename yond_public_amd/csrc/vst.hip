@@ -186,7 +186,10 @@ void pack_vst_chain_kernel(const float* __restrict__ bayer, int H, int W, float*
     const int ns = L.nseg;
     for (int i = 0; i < ns; ++i) {
         if (i + 1 < ns && L.seg_x[i + 1] == L.seg_x[i]) continue;
-        if (kept < 3) { rx[kept] = L.seg_x[i]; rv[kept] = L.seg_inv[i]; ra[kept] = L.seg_i[i]; rb[kept] = L.seg_i[i + 1]; }
+        // (constant indices after unrolling: a run-time index would put the four little arrays into scratch memory -- 16 bytes per lane)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (kept == j) { rx[j] = L.seg_x[i]; rv[j] = L.seg_inv[i]; ra[j] = L.seg_i[i]; rb[j] = L.seg_i[i + 1]; }
         ++kept;
     }
     if (lut_n < 2 || ns < 1 || kept > 3) {
@@ -202,10 +205,13 @@ void pack_vst_chain_kernel(const float* __restrict__ bayer, int H, int W, float*
     }
     // the kept runs in LDS, one 16-byte entry each: {start, 1 / step, first knot, last knot}; a run that is not there starts at +inf
     __shared__ f32x4 s_run[3];
-    if (threadIdx.x < 3) {
-        f32x4 e;
-        e[0] = rx[threadIdx.x]; e[1] = rv[threadIdx.x]; e[2] = __int_as_float(ra[threadIdx.x]); e[3] = __int_as_float(rb[threadIdx.x]);
-        s_run[threadIdx.x] = e;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            f32x4 e;
+            e[0] = rx[j]; e[1] = rv[j]; e[2] = __int_as_float(ra[j]); e[3] = __int_as_float(rb[j]);
+            s_run[j] = e;
+        }
     }
     const float fx1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rx[1])));
     const float fx2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rx[2])));

@@ -857,7 +857,9 @@ def test_half_plane_flow_block(C, N, H, W):
     assert int(plan.status[0]) & 1
 
 
-@pytest.mark.parametrize("C,N,H,W", [(32, 2, 37, 70), (64, 1, 64, 130), (128, 1, 23, 45), (256, 1, 12, 33)])
+@pytest.mark.parametrize("C,N,H,W", [(32, 2, 37, 70), (64, 1, 64, 130), (128, 1, 23, 45), (256, 1, 12, 33),
+                                     # enough tiles for the 8-row forms (two output rows per wave): 64-channel tiles, and 128-channel tiles where there is no second output
+                                     (32, 2, 250, 510), (64, 2, 256, 500), (128, 1, 130, 260)])
 def test_conv3x3_s2_half_planes(C, N, H, W):
     """Stride-2 layer of the fp16 path's flow: h-only planes in (through the register sets), float32 planes of 4 channels out -- the
     plain-tensor h-only kernel's result bit for bit; the second output (YondConvDesc.dst2) holds half(SiLU(value)) in h-only planes."""
@@ -887,7 +889,9 @@ def test_conv3x3_s2_half_planes(C, N, H, W):
     assert report(f"stride-2 from h-only planes C{C}", nchw(ref.cpu()), z) <= 2e-5 * max(1.0, float(z.abs().max()))
 
 
-@pytest.mark.parametrize("c,h,w,N", [(64, 24, 40, 2), (32, 19, 33, 2), (128, 9, 35, 2), (256, 7, 20, 1)])
+@pytest.mark.parametrize("c,h,w,N", [(64, 24, 40, 2), (32, 19, 33, 2), (128, 9, 35, 2), (256, 7, 20, 1),
+                                     # enough tiles for the 16-row form at 64 columns
+                                     (64, 200, 330, 1)])
 def test_decoder_gemm_half_planes(c, h, w, N):
     """The decoder GEMM of the fp16 path's flow (ConvTranspose2d 2x2 + cat + 1x1 shortcut folded; archs/Unet.py:447-461): BOTH sources in
     h-only planes, output as float32 planes of 4 channels or [N][H][W][C] (the last block's input) -- against the float64 layer on the

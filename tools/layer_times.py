@@ -7,6 +7,8 @@ from yond_public_amd import archs as A, synthetic as S, pipeline as P
 from yond_public_amd import engine as E
 if os.environ.get("K1_D2_LEVELS") is not None:
     E.K1_D2_LEVELS = tuple(int(v) for v in os.environ["K1_D2_LEVELS"].split(",") if v)
+if os.environ.get("K1_D2_LEVELS_HALF") is not None:
+    E.K1_D2_LEVELS_HALF = tuple(int(v) for v in os.environ["K1_D2_LEVELS_HALF"].split(",") if v)
 if os.environ.get("SP_CONV1_MIN_LEVEL"):            # A/B of the engine's data-flow constant (tools only)
     E.SP_CONV1_MIN_LEVEL = int(os.environ["SP_CONV1_MIN_LEVEL"])
 arch = dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True)

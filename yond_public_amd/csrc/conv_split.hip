@@ -28,6 +28,8 @@ SPLIT_GROUP_H_D2(SPLIT_EXTERN)
 SPLIT_GROUP_H_SUB2(SPLIT_EXTERN)
 SPLIT_GROUP_H128_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_H128_ISP_OSP(SPLIT_EXTERN)
+SPLIT_GROUP_H_S2_TALL(SPLIT_EXTERN)
+SPLIT_GROUP_H_K1_TALL(SPLIT_EXTERN)
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
 // ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has
@@ -47,7 +49,7 @@ extern "C" int yond_conv_split_supported(int ksize, int stride, int cin, int cou
 // ksize 1 (w = the re-indexed [4*cout][cin][1][1] matrix of a transposed convolution): [cout tile][step of 48 channels]
 // [chunk of 16][channel half][part][tn][8 halves].
 extern "C" int yond_pack_conv_split_weight_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst) {
-    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && parts == 1 && ksize == 3)) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
+    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && parts == 1)) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
     _Float16* o = (_Float16*)dst;
     for (size_t i = 0, n = (size_t)cout * cin * ksize * ksize; i < n; ++i)
         if (!(fabsf(w[i]) <= 65504.0f)) return YOND_EUNSUPPORTED;          // its h half would be +-inf
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void pack_split_weight_kernel(const float* __r
 
 extern "C" int yond_pack_conv_split_weight_dev_f32(const float* w, int cout, int cin, int ksize, int tn, int parts, float* dst, int* status,
                                                    void* stream) {
-    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && parts == 1 && ksize == 3)) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
+    if (!w || !dst || (ksize != 3 && ksize != 1) || (tn != 32 && tn != 64 && !(tn == 128 && parts == 1)) || cout % tn != 0 || cin % 16 != 0 || (parts != 1 && parts != 2)) return YOND_EINVAL;
     if (ksize == 1 && cin % 48 != 0) return YOND_EINVAL;
     const int taps = ksize * ksize;
     const size_t ngroups = (size_t)cout * cin * taps * parts / 8;
@@ -190,7 +192,12 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     // h-only operands (algo 4) may be packed for 128-channel tiles: 3x3 stride-1 layers with plain tensors (conv_split_kernel.h, HALF128)
     const bool half128 = parts == 1 && d.tn == 128 && tn == 64 && d.ksize == 3 && d.stride == 1 && d.Cout % 128 == 0 && !d.out4_dst && !d.dst2 &&
                          (d.out_fmt == YOND_FMT_SPLIT_PLANES || (!d.in_fmt && !d.out_fmt && !d.res_fmt));     // plain tensors, or a producer of the h-only flow
-    if (d.tn != tn && !half128) return YOND_EINVAL;             // the layout the weights were packed for
+    // ... and the flow's stride-2 layers on 128-channel tiles (h-only planes in, planes of 4 channels out)
+    const bool half128s2 = parts == 1 && d.tn == 128 && tn == 64 && d.ksize == 3 && d.stride == 2 && d.Cout % 128 == 0 && d.in_fmt == YOND_FMT_SPLIT_PLANES &&
+                           d.out_fmt == YOND_FMT_PLANES4;
+    // ... and its decoder GEMMs whose output pixels have >= 128 channels (a 128-column tile may not straddle two sub-positions)
+    const bool half128k1 = parts == 1 && d.tn == 128 && tn == 64 && d.ksize == 1 && d.shuffle == 1 && (d.Cout / 4) % 128 == 0 && d.in_fmt == YOND_FMT_SPLIT_PLANES && !d.dst2;
+    if (d.tn != tn && !half128 && !half128s2 && !half128k1) return YOND_EINVAL;             // the layout the weights were packed for
     if (d.post_act < 0 || d.post_act > 2) return YOND_EUNSUPPORTED;
     // tensor formats (include/yond_hip.h): split planes in (LDS-DMA staging) / out (stored from the accumulator layout), planes
     // of 4 channels for the float32 tensors that are read as residuals
@@ -221,7 +228,11 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         if (parts == 1) {
             // h-only operands: the decoder GEMM of the split-plane flow only (h-only planes in, planes of 4 channels out)
             if (!isp || !d.src1) return YOND_EUNSUPPORTED;
+            if (half128k1) return launch_split<1, 8, 128, 2, 1, 3, false, false, true, 2>(d, st);
             if (d.dst2) return launch_split<1, 8, 64, 2, 1, 3, false, false, true, 2, false, false, true>(d, st);
+            // 64 columns: 16-row tiles (four rows per wave share every weight fragment: 1.25 instead of 1.5 KiB of LDS fragments per MFMA) where they fill the workgroups
+            if (tn == 64 && op4 && (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 15) / 16) * d.N >= 256 && yond_exp_long("YOND_SPLIT_K1_TALL", 1) != 0)
+                return launch_split<1, 16, 64, 4, 1, 2, false, false, true, 2>(d, st);
             return tn == 32 ? launch_split<1, 8, 32, 1, 1, 3, false, false, true, 2>(d, st) : launch_split<1, 8, 64, 2, 1, 3, false, false, true, 2>(d, st);
         }
         if (isp && tn == 64 && d.Wo <= 16 && d.src1 && !d.dst2 && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {
@@ -255,6 +266,15 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         }
         if (isp && parts == 1) {
             if (!op4) return YOND_EUNSUPPORTED;
+            // 8-row tiles (two output rows per wave) where they fill the persistent workgroups: the 4-row form's steps are bound by LDS reads
+            // (2.0 KiB of fragments per MFMA with h-only operands; conv_split_kernel.h, SPLIT_GROUP_H_S2_TALL)
+            const long long tiles8 = (long long)(d.Cout / d.tn) * ((d.Wo + 31) / 32) * ((d.Ho + 7) / 8) * d.N;
+            const bool tall = tiles8 >= 256 && yond_exp_long("YOND_SPLIT_S2_TALL", 1) != 0;
+            if (half128s2) {
+                if (!tall) return YOND_EUNSUPPORTED;        // (the caller packs 64-channel tiles for small images)
+                return d.dst2 ? YOND_EUNSUPPORTED : launch_split<2, 8, 128, 2, 1, 2, false, false, false, 2>(d, st);
+            }
+            if (tall) return d.dst2 ? launch_split<2, 8, 64, 2, 1, 2, false, false, false, 2, false, false, true>(d, st) : launch_split<2, 8, 64, 2, 1, 2, false, false, false, 2>(d, st);
             return d.dst2 ? launch_split<2, 4, 64, 1, 1, 2, false, false, false, 2, false, false, true>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false, false, false, 2>(d, st);
         }
         if (isp && d.dst2) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true>(d, st);

@@ -349,7 +349,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
 
     // Three register sets: set s % 3 receives the loads of input(s+3) during step s and is split / written out as
     // input(s+3) during step s+2, so a load has two steps to arrive.
-    constexpr int NSET = MW >= 3 ? 2 : 3;                     // (three rows per wave: 96 accumulator registers leave room for two sets)
+    // (three rows per wave: 96 accumulator registers leave room for two sets; likewise the h-only stride-2 layer on 128-channel tiles -- 64 accumulator
+    // registers, two weight-fragment sets of two blocks: with three sets it spills five registers)
+    constexpr int NSET = (MW >= 3 || (STRIDE == 2 && PARTS == 1 && TN == 128)) ? 2 : 3;
     static_assert(NSET == 3 || C::WAHEAD == 1, "the two-set pipeline goes with two weight buffers");
     f32x4 vin[NSET][NINA];
     unsigned vin_ok[NSET] = {};
@@ -1362,5 +1364,17 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 #define SPLIT_GROUP_H128_ISP_OSP(X) X(1, 8, 128, 2, 1, 3, false, false, false, true, true)
 // (resident weights for the 32 -> 32 layers, as SPLIT_GROUP_WRES, measured on this path in round 6: no gain -- its level 0 is bound by HBM bytes and the
 // SiLU arithmetic, not by the weight DMA -- and not built)
+// ... and the flow's stride-2 layers on 8-row tiles, two output rows per wave, 64 or 128 channels: with h-only operands a fragment read from LDS feeds
+// ONE MFMA (not 1.5), and the 4-row form reads 2.0 KiB of fragments per MFMA where the CU's LDS delivers 1 KiB per MFMA slot -- its steps are
+// LDS-read bound (in-kernel stamps, profiles/r06_experiments).  Two rows per wave share every weight fragment and 1 of 6 pixel-row fragments
+// (1.33 KiB per MFMA), two channel blocks per wave share every pixel fragment (0.92); the h-only planes leave the LDS for the 17-row input image
+// (the 128-channel form with the second output spills 42 registers: not built -- those layers take the 64-channel form)
+#define SPLIT_GROUP_H_S2_TALL(X)                                                                        \
+    X(2, 8, 64, 2, 1, 2, false, false, false, 2, false) X(2, 8, 128, 2, 1, 2, false, false, false, 2, false) \
+    X(2, 8, 64, 2, 1, 2, false, false, false, 2, false, false, true)
+// ... and its decoder GEMMs: 16-row tiles (four rows per wave share every weight fragment), 128 GEMM columns where an output pixel has >= 128 channels
+// (two column blocks per wave share every pixel fragment): 1.5 KiB of LDS fragments per MFMA (8 rows x 64 columns) -> 1.25 (16 x 64) / 1.0 (8 x 128)
+// (16 rows x 128 columns spills 52 registers: not built)
+#define SPLIT_GROUP_H_K1_TALL(X) X(1, 16, 64, 4, 1, 2, false, false, true, 2, false) X(1, 8, 128, 2, 1, 3, false, false, true, 2, false)
 #define SPLIT_INSTANTIATE(...) template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);
 #define SPLIT_EXTERN(...) extern template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);

@@ -45,6 +45,8 @@ WINO_DEFAULT = 'split'              # 'split': fp32-accurate split-operand fp16-
 SPLIT_PLANES = True
 SP_FLOW = True                      # ... and the whole forward in the split-plane data flow (DenoiserPlan.forward_nhwc4)
 HALF_FLOW = True                    # fp16 path: the whole forward in the split-plane data flow on H-ONLY planes (2 bytes per element; round 6)
+HALF_K1_TN128 = True                # ... its decoder GEMMs with >= 128-channel output pixels (and no second output) on 128-column tiles
+HALF_S2_TN128 = True                # ... its stride-2 layers with >= 128 output channels (and no second output) on 8-row x 128-channel tiles
 HALF_FLOW_TN128 = True              # ... its 3x3 layers with >= 128 output channels on 128-channel tiles (8 rows)
 HALF_TN128 = True                   # fp16 path (precision='fp16', BASELINE cfg 5): 128-channel tiles for the 3x3 stride-1 layers with >= 128 output channels
 FUSE_OUT4 = True                    # the 1x1 output projection in the epilogue of the last 3x3 convolution
@@ -56,6 +58,7 @@ K1_SUB2 = True                      # the decoder GEMMs with two sub-positions p
 K1_D2_LEVELS = (3,)                 # decoder levels whose GEMM also stores SiLU(x) in split planes for the block's conv1 (YondConvDesc.dst2), as the stride-2
                                     # layers do from SP_CONV1_MIN_LEVEL down.  Measured per (GEMM + conv1) pair, two runs each (tools/layer_times.py, K1_D2_LEVELS=...):
                                     # level 3 274 -> 254-262 us, level 2 302 -> 293-303, level 1 362 -> 357-361: kept where it is clear of the noise.  () = off
+K1_D2_LEVELS_HALF = ()              # ... on the fp16 path's h-only flow: none (the GEMM takes its 128-column tile instead, which has no second output)
 SP_CONV1_MIN_LEVEL = 3              # from this level down a stride-2 layer also stores SiLU(x) in split planes (YondConvDesc.dst2), so that the
                                     # next block's conv1 stages by LDS-DMA alone (there conv1 would repeat the SiLU + split per output-channel tile)
 UNET_SP = True                      # UNetSeeInDark: the tensor between the two convolutions of a stage in split planes (LeakyReLU applied by the producer)
@@ -149,7 +152,7 @@ class _PackedConv:
             self._packed['wino'] = (tn, torch.from_numpy(packed).to(self._dev))
         return self._packed['wino']
 
-    def split(self, parts=2, wide=True):
+    def split(self, parts=2, wide=True, wide_s2=False):
         """(tn, weights packed for the split-operand fp16-MFMA kernel) or None when the layer does not fit it.
         wide: h-only operands of a plain-tensor 3x3 layer may take 128-channel tiles (the split-plane flow's kernels do not)."""
         lib = L.load()
@@ -160,6 +163,10 @@ class _PackedConv:
             return None
         if parts == 1 and wide and HALF_TN128 and tn == 64 and self.ksize == 3 and self.stride == 1 and self.gemm_n % 128 == 0:
             tn = 128                        # h-only operands: one accumulator per block leaves room for two blocks per wave (conv_split_kernel.h)
+        if parts == 1 and wide_s2 and tn == 64 and self.ksize == 3 and self.stride == 2 and self.gemm_n % 128 == 0:
+            tn = 128                        # ... the flow's stride-2 layers likewise (8-row tiles, two rows x two channel blocks per wave)
+        if parts == 1 and wide_s2 and tn == 64 and self.ksize == 1 and self.shuffle == 1 and (self.gemm_n // 4) % 128 == 0:
+            tn = 128                        # ... and its decoder GEMMs whose output pixels have >= 128 channels
         key = ('split', parts) if tn != 128 else ('split', parts, 128)     # (train.py refreshes ('split', 2) in place every step)
         if key not in self._packed:
             packed = np.empty(self._wp.size * parts // 2, np.float32)
@@ -209,7 +216,7 @@ class _PackedUpSub2:
             self._wpk[parts] = torch.from_numpy(packed).to(self._dev) if rc == 0 else None
         return self._wpk[parts]
 
-    def split(self, parts=2, wide=True):
+    def split(self, parts=2, wide=True, wide_s2=False):
         return (64, self._pack(parts)) if (self.ok and self._pack(parts) is not None) else None
 
     def wino(self):
@@ -392,7 +399,13 @@ class DenoiserPlan:
         wino = split = None
         if algo in ('split', 'half'):
             # (h-only operands: 128-channel tiles for plain tensors only; the decoder GEMM only inside the split-plane flow)
-            split = pc.split(2 if algo == 'split' else 1, wide=(not (in_fmt or out_fmt or res_fmt or dst2 is not None)) or (HALF_FLOW_TN128 and out_fmt == 1))
+            # (the stride-2 layers of the h-only flow: 128-channel tiles where 8-row tiles fill the 256 workgroups and there is no second output --
+            #  that instantiation spills)
+            ws2 = (HALF_S2_TN128 and algo == 'half' and pc.stride == 2 and in_fmt == 1 and out_fmt == 2 and dst2 is None
+                   and (pc.gemm_n // 128) * ((d.Wo + 31) // 32) * ((d.Ho + 7) // 8) * N >= 256)
+            ws2 = ws2 or (HALF_K1_TN128 and algo == 'half' and pc.ksize == 1 and in_fmt == 1 and dst2 is None)
+            split = pc.split(2 if algo == 'split' else 1, wide=(not (in_fmt or out_fmt or res_fmt or dst2 is not None)) or (HALF_FLOW_TN128 and out_fmt == 1),
+                             wide_s2=ws2)
             if algo == 'half' and pc.ksize == 1 and in_fmt != 1:
                 split = None
             if split is None and not fp16 and pc.ksize == 3:
@@ -617,7 +630,7 @@ class DenoiserPlan:
                     up = blk['upsc2'] if (flow and K1_SUB2 and 'upsc2' in blk) else blk['upsc']
                     # (decoder level of block i = 9 - i; images too narrow for the unfolded GEMM keep the folded kernels, which have no second output)
                     xsp = (self._new_sp(('xspd', i), N, 2 * h, 2 * w, cp, pt)
-                           if (flow and not last and (9 - i) in K1_D2_LEVELS and up is blk['upsc'] and cp % 64 == 0 and w > 16) else None)     # (the dispatcher's second output: 64-wide tiles, conv_split.hip)
+                           if (flow and not last and (9 - i) in (K1_D2_LEVELS if pt == 2 else K1_D2_LEVELS_HALF) and up is blk['upsc'] and cp % 64 == 0 and w > 16) else None)     # (the dispatcher's second output: 64-wide tiles, conv_split.hip)
                     self._conv(up, cur, skips[10 - i], N, h, w, xs, in_fmt=SP if flow else 0, out_fmt=xfmt, dst2=xsp)
                     h, w = 2 * h, 2 * w
                     cur = xs

@@ -802,7 +802,9 @@ def hp_decode(sp, N, C, H, W):
     return u[:, :, :, :H * W, :].permute(0, 3, 1, 2, 4).reshape(N, H, W, C), u[:, :, :, H * W:, :]
 
 
-@pytest.mark.parametrize("C,N,H,W", [(64, 2, 40, 70), (128, 1, 380, 100), (32, 2, 50, 75), (256, 1, 30, 61), (64, 5, 16, 16), (32, 1, 37, 70)])
+@pytest.mark.parametrize("C,N,H,W", [(64, 2, 40, 70), (128, 1, 380, 100), (32, 2, 50, 75), (256, 1, 30, 61), (64, 5, 16, 16), (32, 1, 37, 70),
+                                     # enough tiles for the four-rows-per-wave forms (16 x 32 pixels x 64 channels, 32 x 32 x 32)
+                                     (64, 1, 260, 520), (32, 1, 520, 530)])
 def test_half_plane_flow_block(C, N, H, W):
     """The residual block in the formats of the fp16 path's data flow (round 6): x in float32 planes of 4 channels (conv1's staged input,
     conv2's residual), tmp and out in H-ONLY planes (2 bytes per element).  The plain-tensor h-only kernels round every operand to half when

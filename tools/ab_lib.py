@@ -1,6 +1,6 @@
 """Same-process A/B of two builds of libyond_hip.so on one SNR-Net forward at the cfg-2 shape: per-launch HIP-event times of this
 build against another library (default tools/probe/libyond_hip_r3.so, round 3's), interleaved, plus the largest output difference.
-    python tools/ab_lib.py [other.so] [--unet]"""
+    python tools/ab_lib.py [other.so] [--unet] [--fp16]"""
 import ctypes as C
 import os
 import sys
@@ -26,11 +26,14 @@ else:
     arch = dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True)
     mk = A.GuidedResUnet
 net = mk(dict(arch)); net.load_state_dict(S.procedural_state_dict(net, 0)); net = net.to('cuda').eval()
+if "--fp16" in sys.argv:                             # the BASELINE cfg 5 path at its own shape
+    net.precision = 'fp16'
+HW = (2016, 3008) if "--fp16" in sys.argv else (1504, 2016)
 dev = torch.device('cuda')
 plans = {"new": E.DenoiserPlan(net, dev), "old": E.DenoiserPlan(net, dev)}
 plans["old"].lib = old
 torch.manual_seed(0)
-x = torch.rand(1, 1504, 2016, 4, device='cuda'); t = torch.full((1,), 0.03, device='cuda'); ub = x.reshape(1, -1).max(1).values.contiguous()
+x = torch.rand(1, HW[0], HW[1], 4, device='cuda'); t = torch.full((1,), 0.03, device='cuda'); ub = x.reshape(1, -1).max(1).values.contiguous()
 outs = {}
 for k, p in plans.items():
     for _ in range(3):

@@ -30,6 +30,7 @@ SPLIT_GROUP_H128_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_H128_ISP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_H_S2_TALL(SPLIT_EXTERN)
 SPLIT_GROUP_H_K1_TALL(SPLIT_EXTERN)
+SPLIT_GROUP_H_TALL4(SPLIT_EXTERN)
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
 // ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has
@@ -315,11 +316,17 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
         if (!isp && !(osp && d.pre_act)) return YOND_EUNSUPPORTED;
         if (isp && !osp) return (d.out4_dst && tn == 32) ? launch_split<1, 16, 32, 2, 1, 3, false, true, false, true>(d, st) : YOND_EUNSUPPORTED;
         if (half128) return isp ? launch_split<1, 8, 128, 2, 1, 3, false, false, false, true, true>(d, st) : launch_split<1, 8, 128, 2, 1, 3, true, false, false, false, true>(d, st);
+        // four rows per wave where such tiles fill the workgroups (0.75 KiB of LDS fragments per MFMA instead of 0.89 / 1.17)
+        const bool t4_64 = tn == 64 && (long long)(d.Cout / 64) * ((d.Wo + 31) / 32) * ((d.Ho + 15) / 16) * d.N >= 256;
+        const bool t4_32 = tn == 32 && (long long)((d.Wo + 31) / 32) * ((d.Ho + 31) / 32) * d.N >= 256;
         if (isp) {
+            if (t4_64) return launch_split<1, 16, 64, 4, 1, 2, false, false, false, true, true>(d, st);
+            if (t4_32) return launch_split<1, 32, 32, 4, 1, 2, false, false, false, true, true>(d, st);
             if (tn == 64 && tiles12 >= 256) return launch_split<1, 12, 64, 3, 1, 2, false, false, false, true, true>(d, st);
             if (tn == 64) return launch_split<1, 8, 64, 2, 1, 3, false, false, false, true, true>(d, st);
             return launch_split<1, 16, 32, 2, 1, 3, false, false, false, true, true>(d, st);
         }
+        if (t4_64) return launch_split<1, 16, 64, 4, 1, 2, true, false, false, false, true>(d, st);
         if (tn == 64 && tiles12 >= 256) return launch_split<1, 12, 64, 3, 1, 2, true, false, false, false, true>(d, st);
         if (tn == 64) return launch_split<1, 8, 64, 2, 1, 3, true, false, false, false, true>(d, st);
         return launch_split<1, 16, 32, 2, 1, 3, true, false, false, false, true>(d, st);

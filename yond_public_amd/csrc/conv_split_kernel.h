@@ -1376,5 +1376,10 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 // (two column blocks per wave share every pixel fragment): 1.5 KiB of LDS fragments per MFMA (8 rows x 64 columns) -> 1.25 (16 x 64) / 1.0 (8 x 128)
 // (16 rows x 128 columns spills 52 registers: not built)
 #define SPLIT_GROUP_H_K1_TALL(X) X(1, 16, 64, 4, 1, 2, false, false, true, 2, false) X(1, 8, 128, 2, 1, 3, false, false, true, 2, false)
+// ... and four rows per wave for its 32- and 64-channel 3x3 layers (every weight fragment serves four rows: 1.17 -> 0.75 and 0.89 -> 0.75 KiB of LDS
+// fragments per MFMA; the 32-row forms with register-staged input / the output projection spill 39 / 8 registers: not built)
+#define SPLIT_GROUP_H_TALL4(X)                                                                          \
+    X(1, 32, 32, 4, 1, 2, false, false, false, true, true)                                               \
+    X(1, 16, 64, 4, 1, 2, true, false, false, false, true) X(1, 16, 64, 4, 1, 2, false, false, false, true, true)
 #define SPLIT_INSTANTIATE(...) template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);
 #define SPLIT_EXTERN(...) extern template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);

@@ -629,11 +629,16 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             // each MFMA followed by a few of the vector instructions, then the LDS writes of a completed item.
             constexpr int nrd = (q + 2 < NQ ? PARTS : 0) + (wpre ? (K1 ? 1 : 3) * C::NW * PARTS : 0);
             if constexpr (nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
-            constexpr int nvalu = ISR ? 0 : (e_hi - e_lo) * (PRE ? 7 : 2) + nfin * (PARTS == 2 ? 22 : 6);
+            // The scheduler's VALU class (0x002) does not hold the transcendental instructions: v_exp_f32 / v_rcp_f32 of SiLU are class 0x400 and used to land
+            // where they might -- up to nine in one MFMA gap, 79 VALU + 7 of them behind the last MFMA of a level-0 step.  Each gap takes its share of them
+            // explicitly (round 6: the two level-0 conv1 launches -3 %, everything else unchanged, bit-identical; profiles/r06_experiments/sched_trans_ab.txt)
+            constexpr int ntr = (!ISR && PRE) ? (e_hi - e_lo) * 2 : 0;
+            constexpr int nvalu = ISR ? 0 : (e_hi - e_lo) * (PRE ? 5 : 2) + nfin * (PARTS == 2 ? 22 : 6);
             constexpr int vpm = (nvalu + nmf - 1) / nmf;
 #pragma unroll
             for (int i = 0; i < nmf; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if ((i * ntr) / nmf != ((i + 1) * ntr) / nmf) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
                 if constexpr (vpm > 0) __builtin_amdgcn_sched_group_barrier(0x002, vpm, 0);
             }
             if constexpr (wrep) __builtin_amdgcn_sched_group_barrier(0x100, C::NW * PARTS, 0);

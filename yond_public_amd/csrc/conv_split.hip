@@ -31,6 +31,10 @@ SPLIT_GROUP_H128_ISP_OSP(SPLIT_EXTERN)
 SPLIT_GROUP_H_S2_TALL(SPLIT_EXTERN)
 SPLIT_GROUP_H_K1_TALL(SPLIT_EXTERN)
 SPLIT_GROUP_H_TALL4(SPLIT_EXTERN)
+#ifdef YOND_EXPERIMENTS         // (round 6, measured no-gos: profiles/r06_experiments/README.md section 1b)
+SPLIT_GROUP_S2_W4(SPLIT_EXTERN)
+SPLIT_GROUP_S2_ROLES(SPLIT_EXTERN)
+#endif
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
 // ksize 1: the decoder's pixel-shuffle GEMM (cout = 4 sub-positions x channels of an output pixel; the descriptor has
@@ -278,6 +282,15 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
             if (tall) return d.dst2 ? launch_split<2, 8, 64, 2, 1, 2, false, false, false, 2, false, false, true>(d, st) : launch_split<2, 8, 64, 2, 1, 2, false, false, false, 2>(d, st);
             return d.dst2 ? launch_split<2, 4, 64, 1, 1, 2, false, false, false, 2, false, false, true>(d, st) : launch_split<2, 4, 64, 1, 1, 2, false, false, false, 2>(d, st);
         }
+#ifdef YOND_EXPERIMENTS
+        // round 6: two output rows per wave inside the same 4 x 32 x 64 tile (0.89 instead of 1.33 KiB of LDS fragments per MFMA) -- as eight waves in two roles
+        // (four multiply, four move the data) or as four waves, one per SIMD.  Both bit-identical, both 12-36 us SLOWER per launch: one multiplying wave per SIMD
+        // does not hide its own LDS latencies (profiles/r06_experiments/s2_*_ab.txt)
+        if (isp && parts == 2 && yond_exp_long("YOND_SPLIT_S2_ROLES", 0) != 0)
+            return d.dst2 ? launch_split<2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, true, 0, 8, 1>(d, st) : launch_split<2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, false, 0, 8, 1>(d, st);
+        if (isp && parts == 2 && yond_exp_long("YOND_SPLIT_S2_W4", 0) != 0)
+            return d.dst2 ? launch_split<2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, true, 0, 4>(d, st) : launch_split<2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, false, 0, 4>(d, st);
+#endif
         if (isp && d.dst2) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2, false, false, true>(d, st);
         if (isp) return launch_split<2, 4, 64, 1, 2, 2, false, false, false, 2>(d, st);
         if (!isp && parts == 2 && d.Wo <= 16 && !d.src1 && !d.res && !d.in_fmt && !d.out_fmt && yond_exp_long("YOND_SPLIT_FOLD", 1) != 0) {

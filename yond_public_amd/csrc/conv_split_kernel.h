@@ -60,9 +60,15 @@ extern "C" int SPLIT_DBG_READER(unsigned long long* host) {
 
 __host__ __device__ constexpr int yond_sp_plane_units(int H, int W) { return YOND_SP_PLANE_UNITS(H, W); }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool K1 = false, int FOLD = 0>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool K1 = false, int FOLD = 0, int NWAVE = 8, int ROLES = 0>
 struct SplitCfg {
-    static constexpr int NT = 512;
+    // NWAVE 8: 512-thread workgroups, two waves per SIMD (every shipped kernel but one); NWAVE 4 (round 6, the stride-2 layer of the split path): ONE wave per
+    // SIMD with twice the registers, so that a wave can own two output rows -- the only way to fewer LDS fragment reads per MFMA that fits the CU's 160 KB
+    static constexpr int NT = 64 * NWAVE;
+    // ROLES 1 (round 6, experiment): the first half of the waves (one per SIMD) only multiply -- they own the accumulators, two output rows each --, the second half
+    // only moves data: global loads, weight DMA, the staging writes.  The multiplying wave's instruction stream is then fragment reads + MFMAs alone
+    static constexpr int NWC = ROLES ? NWAVE / 2 : NWAVE;            // waves that hold accumulators
+    static constexpr int NTS = ROLES ? NT / 2 : NT;                  // threads that stage and issue the memory operations
     static constexpr int KC = 16;
     // K1: the decoder's 1x1 GEMM (ConvTranspose2d 2x2 + cat + 1x1 shortcut folded, engine.py) -- one tap, so a step takes
     // THREE consecutive 16-channel chunks as pseudo-taps (a short step is all overhead); no halo
@@ -82,23 +88,23 @@ struct SplitCfg {
     static constexpr int PIX_ITEMS = IH * IW * 4;                    // staging items of one 16-channel chunk
     static constexpr int W_FLOATS = TAPS * 2 * PARTS * TN * 4;
     static constexpr int RG = TH / MW;                              // row groups of waves
-    static constexpr int NCW = 8 / RG;                              // channel groups of waves
+    static constexpr int NCW = NWC / RG;                            // channel groups of waves
     static constexpr int NW = TN / 32 / NCW;                        // 32-channel blocks per wave
     static constexpr int NITEM = NPT * IH * IW * 4;                 // 16-byte (4-channel) staging items per step
     static constexpr int NIN = (NITEM + NT - 1) / NT;
     static constexpr int NWV = W_FLOATS / 4;
-    static constexpr int NWT = (NWV + NT - 1) / NT;
-    static constexpr int NWT_MIN = NWV / NT;                        // LDS-DMA instructions every wave issues per step
+    static constexpr int NWT = (NWV + NTS - 1) / NTS;
+    static constexpr int NWT_MIN = NWV / NTS;                       // LDS-DMA instructions every wave issues per step
     static constexpr int NOPS = NWT + NIN;                          // vector-memory instructions per thread and step
     static constexpr int WAHEAD = NWB - 1;                          // the LDS-DMA of step s fetches weights(s + WAHEAD)
     static constexpr bool LOADS_FIRST = WAHEAD == 2;                // order of a step's memory operations (see the step pipeline)
     static constexpr int KEEP = WAHEAD == 2 ? NIN + NWT_MIN : NIN;  // memory operations that may stay in flight across a barrier
     static constexpr int W4_OFF = 2 * IN_FLOATS + NWB * W_FLOATS;   // floats: 4 x 32 weights of the fused output projection
     static constexpr int FILM_OFF = W4_OFF + (TN == 32 ? 128 : 0);  // floats: per wave and 32-channel block {scale[32], shift[32]} (split-plane epilogue)
-    static constexpr int FILM_FLOATS = 8 * NW * 64 * (FOLD && STRIDE == 1 ? FOLD : 1);     // (FOLD: every sub-tile may belong to another image; stride 2 never stores split planes)
+    static constexpr int FILM_FLOATS = NWC * NW * 64 * (FOLD && STRIDE == 1 ? FOLD : 1);     // (FOLD: every sub-tile may belong to another image; stride 2 never stores split planes)
     // h-only operands (PARTS 1) leave the transposed epilogue no consumed buffer large enough for its scratch (8 waves x 32 pixels x 36 floats):
     // their kernels use little LDS, so the scratch gets a region of its own behind everything else
-    static constexpr int EP_FLOATS_C = 8 * 32 * 36;
+    static constexpr int EP_FLOATS_C = NWC * 32 * 36;
     static constexpr bool EP_OWN = PARTS == 1 && STRIDE == 1 && EP_FLOATS_C > ((TN >= 64 && !K1) ? W_FLOATS : IN_FLOATS);
     static constexpr int EP_OFF = FILM_OFF + FILM_FLOATS;
     static constexpr int SMEM_BYTES = (EP_OFF + (EP_OWN ? EP_FLOATS_C : 0)) * 4;  // (W4: the O4 instantiation only; FILM: the split-plane epilogue only)
@@ -108,10 +114,11 @@ struct SplitCfg {
     static constexpr int WPP = (UPP + 63) / 64;                     // wave-instructions per plane
     static constexpr int NPL = NPT * 2 * PARTS;                     // planes per step
     static constexpr int NDS = NPL * WPP;                           // DMA wave-slots per step
-    static constexpr int NDI = (NDS + 7) / 8;                       // ... per wave
+    static constexpr int NDI = (NDS + NWAVE - 1) / NWAVE;           // ... per wave
     static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
     static_assert(!K1 || (STRIDE == 1 && PIX_ITEMS % NT == 0), "1x1 mode: whole chunks per pass of the staging threads");
-    static_assert(RG * NCW == 8 && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
+    static_assert((NWAVE == 8 || NWAVE == 4) && RG * NCW == NWC && NW >= 1 && NW * NCW * 32 == TN, "wave grid does not cover the tile");
+    static_assert(!ROLES || (NWAVE == 8 && !K1 && FOLD == 0), "role split: eight waves, the 3x3 forms");
     static_assert(FOLD == 0 || FOLD == 2 || FOLD == 4, "folded tiles: two or four sub-tiles");
 };
 
@@ -140,9 +147,10 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 // (64-wide tile = 32 channels x two sub-positions) 6 / 11 / 22 steps where two tiles took 8 / 16 / 32.
 // D2 (stride 2): the layer also stores SiLU(value) in split planes (YondConvDesc.dst2), from the same epilogue loop -- an
 // instantiation of its own, so that the kernels without it keep their code and register allocation.
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0>
-__global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD>;
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0, int NWAVE = 8, int ROLES = 0>
+__global__ __launch_bounds__(64 * NWAVE) void conv_split_kernel(const YondConvDesc d) {
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD, NWAVE, ROLES>;
+    static_assert(!ROLES || (ISPM == 2 && !OSP && !O4 && !PRE), "role split: the register-staged split-plane input (stride 2)");
     static_assert(!FOLD || (!O4 && !S2 && ((!K1 && STRIDE == 1 && ISPM != 2 && OSP) || (STRIDE == 2 && (ISPM == 2 || (ISPM == 0 && !PRE && !D2))) || (K1 && ISPM == 2) || (!K1 && STRIDE == 1 && ISPM == 0 && !OSP && !PRE))),
                   "folded tiles: the split-plane data flow's kernels (3x3 stride 1: LDS-DMA or register-staged input, split-plane store; stride 2 and the decoder GEMM: register-staged split planes) "
                   "and the plain [N][H][W][C] 3x3 layer (training, UNetSeeInDark)");
@@ -162,21 +170,24 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     constexpr int IPP = ISR ? 2 * PARTS : 4;
     constexpr int PIX_ITEMS = C::IH * C::IW * IPP;            // staging items of one 16-channel chunk
     constexpr int NITEM = C::NPT * PIX_ITEMS;                 // ... of a step
-    static_assert(!K1 || PIX_ITEMS % C::NT == 0, "1x1 mode: whole chunks per pass of the staging threads");
-    constexpr int NIN = ISP ? 0 : (NITEM + C::NT - 1) / C::NT;   // register-staged 16-byte items per thread and step
+    static_assert(!K1 || PIX_ITEMS % C::NTS == 0, "1x1 mode: whole chunks per pass of the staging threads");
+    constexpr int NIN = ISP ? 0 : (NITEM + C::NTS - 1) / C::NTS;   // register-staged 16-byte items per (staging) thread and step
     constexpr int NINA = NIN > 0 ? NIN : 1;                  // (array extents)
     constexpr int NDI = ISP ? C::NDI : 0;                    // input LDS-DMAs per wave and step
     // (K1: a thread's items k and k + PIX_ITEMS / NT are the SAME pixel of different 16-channel chunks -- one offset serves both)
-    constexpr int KD = K1 ? PIX_ITEMS / C::NT : NIN;      // distinct pixels among a thread's register-staged items
+    constexpr int KD = K1 ? PIX_ITEMS / C::NTS : NIN;      // distinct pixels among a thread's register-staged items
     // (LDS-DMA input: a slot's unit offset inside its plane depends on the slot's position in the plane only -- slots k and k + DPER
     // of a wave address the same units of different planes)
-    constexpr int DPER = C::WPP / split_gcd(C::WPP, 8);
+    constexpr int DPER = C::WPP / split_gcd(C::WPP, NWAVE);
     constexpr int NG = ISP ? (NDI < DPER ? NDI : DPER) : KD;  // per-tile offsets a thread keeps
     constexpr int NOPS = C::NWT + NIN + NDI;                 // vector-memory instructions per thread and step
-    constexpr int KEEP = ISP ? (C::WAHEAD == 2 ? C::NWT_MIN : 0) : (C::WAHEAD == 2 ? NIN + C::NWT_MIN : NIN);   // memory operations that may stay in flight across a barrier
+    constexpr int KEEP = (ISP || ROLES) ? (C::WAHEAD == 2 ? C::NWT_MIN : 0) : (C::WAHEAD == 2 ? NIN + C::NWT_MIN : NIN);   // memory operations that may stay in flight across a barrier
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ROLES: the staging / memory work belongs to the second half of the workgroup (stid = its thread index there; the multiplying half never uses what it derives from it)
+    const int stid = ROLES ? tid - C::NTS : tid;
+    const bool consumer = !ROLES || __builtin_amdgcn_readfirstlane(wave) < C::NWC;
     const int li = lane & 31, lh = lane >> 5;
     // FOLD: lane li of a fragment = column li % FSW of sub-tile li / FSW; in the LDS row every sub-tile has its own two halo columns
     constexpr int FSW = FOLD ? 32 / FOLD : 32;
@@ -221,13 +232,13 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         if constexpr (S2) return (ct % cpb) * 32 + (cu & 31);
         return cu % Cr;
     };
-    const int my_sl = tid & (IPP - 1);                       // the thread's 4-channel slot of a pixel (512 % 4 == 0); ISR: its PLANE (channel half x part)
+    const int my_sl = stid & (IPP - 1);                       // the thread's 4-channel slot of a pixel (512 % 4 == 0); ISR: its PLANE (channel half x part)
     const int my_plane = (my_sl >> 1) * PARTS * C::PLANE + (my_sl & 1) * 2;
 
     int in_lds[NINA];
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
-        const int it = tid + k * C::NT;
+        const int it = stid + k * C::NTS;
         const int pt = it / PIX_ITEMS;                      // pseudo-tap (K1; 0 otherwise)
         const int pix = (it % PIX_ITEMS) / IPP;
         const int py = pix / C::IW, px = pix % C::IW;
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         if constexpr (ISP) {
 #pragma unroll
             for (int k = 0; k < NG; ++k) {
-                const int sid = k * 8 + wave_s;                 // DMA wave-slot: plane sid / WPP, units (sid % WPP) * 64 ...
+                const int sid = k * NWAVE + wave_s;             // DMA wave-slot: plane sid / WPP, units (sid % WPP) * 64 ...
                 const int q = (sid % C::WPP) * 64 + lane;       // the lane's unit of the plane's LDS image
                 const int py = q / C::TWP, rem = q % C::TWP;
                 const int px = STRIDE == 2 ? 2 * (rem % C::HALF) + rem / C::HALF : rem;      // stride 2: even columns first
@@ -314,11 +325,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         // ([N][H][W][C]-path instantiations -- training, UNetSeeInDark, the unfused first / last layers: the per-item pixel geometry is a
         // loop invariant that the compiler hoists out of the tile loop and then SPILLS (8-31 registers, reloaded at every tile); formed
         // from an opaque copy of the thread index it is recomputed per tile instead: a few integer operations per item)
-        int tid_g = tid;
+        int tid_g = stid;
         if constexpr (ISPM == 0 && !OSP && !K1) asm volatile("" : "+v"(tid_g));
 #pragma unroll
         for (int k = 0; k < KD; ++k) {
-            const int it = tid_g + k * C::NT;
+            const int it = tid_g + k * C::NTS;
             const int pix = (it % PIX_ITEMS) / IPP;
             const int py = pix / C::IW, px = pix % C::IW;
             int gy = K1 ? T.oy0 + py : T.oy0 * STRIDE - 1 + py, gx = K1 ? T.ox0 + px : T.ox0 * STRIDE - 1 + px;
@@ -351,7 +362,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // input(s+3) during step s+2, so a load has two steps to arrive.
     // (three rows per wave: 96 accumulator registers leave room for two sets; likewise the h-only stride-2 layer on 128-channel tiles -- 64 accumulator
     // registers, two weight-fragment sets of two blocks: with three sets it spills five registers)
-    constexpr int NSET = (MW >= 3 || (STRIDE == 2 && PARTS == 1 && TN == 128)) ? 2 : 3;
+    // (ROLES: ONE set -- the moving half loads input(s+1) and stages it within step s: it has nothing else to do while the other half multiplies, and a second set
+    // would not fit beside the accumulators: both roles' registers are allocated together)
+    constexpr int NSET = ROLES ? 1 : (MW >= 3 || (STRIDE == 2 && PARTS == 1 && TN == 128)) ? 2 : 3;
     static_assert(NSET == 3 || C::WAHEAD == 1, "the two-set pipeline goes with two weight buffers");
     f32x4 vin[NSET][NINA];
     unsigned vin_ok[NSET] = {};
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
     auto issue_load = [&](auto pc, auto kc, const Tile& T, const LoadSrc& L) {
         constexpr int P = decltype(pc)::value, k = decltype(kc)::value;
-        constexpr int t = K1 ? (k * C::NT) / PIX_ITEMS : 0;  // the item's chunk (K1: PIX_ITEMS is a multiple of the thread count)
+        constexpr int t = K1 ? (k * C::NTS) / PIX_ITEMS : 0;  // the item's chunk (K1: PIX_ITEMS is a multiple of the thread count)
         constexpr int kd = k % KD;                             // (K1: the item's pixel)
         const bool ok = T.goff[kd] >= 0;                       // outside the image: read pixel 0, zeroed at the LDS write
         int po = T.goff[kd];
@@ -425,11 +438,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         constexpr int k = decltype(kc)::value;
         if (wskip) return;
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)wbuf;
-        const int it = tid + k * C::NT;
+        const int it = stid + k * C::NTS;
         const int it_wave = __builtin_amdgcn_readfirstlane(it - lane);
         const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)it_wave * 16u);
         const unsigned voff = (unsigned)it * 16u;
-        if (C::NWV % C::NT == 0 || it_wave < C::NWV)
+        if (C::NWV % C::NTS == 0 || it_wave < C::NWV)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave), "v"(voff), "s"(wsrc) : "memory");
     };
     // ISP: the planes of a step's chunk(s), wave-uniform: [n][chunk][half][part][PS units]; DMA slot k of this wave moves the
@@ -454,7 +467,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     };
     auto issue_in_dma = [&](auto kc, const Tile& T, const InSrc& I, float* ob) {
         constexpr int k = decltype(kc)::value;
-        const int sid = k * 8 + wave_s;
+        const int sid = k * NWAVE + wave_s;
         const int plane = sid / C::WPP, wv = sid - plane * C::WPP;
         const int pt = plane / (2 * PARTS), pl = plane - pt * (2 * PARTS);
         const bool hi = K1 && ((I.hi >> pt) & 1u);
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // (the step's cursor arithmetic -- `prep`, which sets wsrc_s / ls_s and may decode the next tile -- runs after the
     // first groups of MFMAs have been issued; memory instructions and staging start at group Q0)
     const float* wsrc_s = nullptr;
-    const bool wave_hi = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    const bool wave_hi = NWAVE == 8 && __builtin_amdgcn_readfirstlane(wave) >= 4;       // (one wave per SIMD: no partner to arbitrate with)
     LoadSrc ls_s = {};
     InSrc is_s = {};
     int dbg_step = 0;
@@ -544,7 +557,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         // weight fragments of a column: two sets (the next column is fetched during the current one), or -- three rows per
         // wave, register budget -- ONE set, each dy refilled for the next column right behind its last use (two groups ahead
         // of its next use)
-        constexpr bool WINPLACE = MW >= 3;
+        constexpr bool WINPLACE = MW >= 3 || ROLES != 0;      // (ROLES: the register budget holds both roles)
         constexpr int WS = WINPLACE ? 1 : 2;
         f16x8 xr[XD][PARTS], wt[WS][3][C::NW][PARTS];
         auto loadX = [&](auto qc) {
@@ -595,7 +608,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             // one, which then runs alone and exposes its LDS latencies: the younger half leads for the first half instead
             if constexpr (q == 0) { if (wave_hi) __builtin_amdgcn_s_setprio(1); }
             if constexpr (q == NQ / 2) { if (wave_hi) __builtin_amdgcn_s_setprio(0); }
-            if constexpr (q == Q0 - 1) prep();
+            if constexpr (q == Q0 - 1 && !ROLES) prep();
             if constexpr (q == NQ / 4) SDBG(8);
             if constexpr (q == NQ / 2) SDBG(9);
             if constexpr (q == (3 * NQ) / 4) SDBG(10);
@@ -606,7 +619,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             // it goes into the first half of the step)
             constexpr int NQO = (ISP && C::WAHEAD == 1) ? (NQW + 1) / 2 : NQW;
             constexpr int qo = qq < NQO ? qq : NQO;
-            constexpr int o_lo = q >= Q0 ? (qo * NOPS + NQO - 1) / NQO : 0, o_hi = q >= Q0 ? ((qo + 1 < NQO ? qo + 1 : NQO) * NOPS + NQO - 1) / NQO : 0;
+            // (ROLES: the multiplying waves issue no memory operation and stage nothing)
+            constexpr int o_lo = (q >= Q0 && !ROLES) ? (qo * NOPS + NQO - 1) / NQO : 0, o_hi = (q >= Q0 && !ROLES) ? ((qo + 1 < NQO ? qo + 1 : NQO) * NOPS + NQO - 1) / NQO : 0;
             static_for<o_lo, o_hi>([&](auto oc) {
                 constexpr int o = decltype(oc)::value;
                 if constexpr (ISP) {
@@ -622,7 +636,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
                 }
             });
             // this group's share of the staging work (element tasks e_lo .. e_hi of the set loaded during the previous step)
-            constexpr int e_lo = q >= Q0 ? qq * NE / NQW : 0, e_hi = q >= Q0 ? (qq + 1) * NE / NQW : 0;
+            constexpr int e_lo = (q >= Q0 && !ROLES) ? qq * NE / NQW : 0, e_hi = (q >= Q0 && !ROLES) ? (qq + 1) * NE / NQW : 0;
             static_for<e_lo, e_hi>([&](auto ec) { stage_task(pc, ec, ob); });
             constexpr int nfin = (e_hi + 0) / 4 - (e_lo + 0) / 4;                     // items completed in this group
             // Issue order of the group: its LDS reads first (they are two groups / one column ahead of their use), then
@@ -658,7 +672,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // would otherwise apply the same SiLU once per output-channel tile (Cout / 64 times at the deeper levels)
     const bool silu_out = d.post_act == 1;
     constexpr int EPS = 36;                                   // floats per pixel of the scratch
-    constexpr int EP_FLOATS = 8 * 32 * EPS;                   // 36,864 bytes: one weight buffer (TN 64) or part of an input image
+    constexpr int EP_FLOATS = NWAVE * 32 * EPS;               // 36,864 bytes: one weight buffer (TN 64) or part of an input image
     // (stride 2: short steps, no residual -- measured slower with the transpose and its extra barrier: 211 vs 175 us at level 0)
     constexpr bool EP_IN_W = TN >= 64 && !K1;                 // scratch = the weight buffer just consumed; else the input image
     constexpr bool EP_FIT = STRIDE == 1 && (C::EP_OWN || EP_FLOATS <= (EP_IN_W ? C::W_FLOATS : C::IN_FLOATS));
@@ -1120,7 +1134,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     // prologue, in the steady-state order of the memory operations (DMA of a step before its loads):
     //   loads input(0) | DMA weights(0), loads input(1) | stage input(0) | DMA weights(1), loads input(2)
     const Cur c1 = adv(cs), c2 = adv(c1);
-    if constexpr (!ISP) load_all(IntC<0>{}, cs);
+    if constexpr (!ISP) { if (!ROLES || !consumer) load_all(IntC<0>{}, cs); }
     Cur cl, cw;                                 // cursors of the step's loads / weight DMA
     if constexpr (ISP) {
         // split-plane input: input(0), weights(0) (, weights(1)); step s issues the DMA of input(s+1) and of weights(s + WAHEAD)
@@ -1130,6 +1144,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         cl = c1;
         cw = C::WAHEAD == 2 ? c2 : c1;
         split_barrier_keep_loads<C::WAHEAD == 2 ? C::NWT_MIN : 0>();
+    } else if constexpr (ROLES != 0) {
+        if (!consumer) {
+            dma_all(cs, w0);
+            write_in(IntC<0>{}, ibuf);
+        }
+        cl = c1;
+        cw = c1;
+        split_barrier_keep_loads<0>();
     } else if constexpr (NSET == 2) {
         // two register sets (and two weight buffers): set s % 2 receives input(s+2) during step s, staged in step s+1
         dma_all(cs, w0);
@@ -1181,7 +1203,18 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
             wsrc_s = weight_src(ct_of(cw, cur.ct), cw.ch);
         };
         SDBG(1);
-        if (computes) mfma_stage(IntC<(S + 1) % NSET>{}, IntC<S>{}, ibuf, w0, obuf, C::WAHEAD == 2 ? w2 : w1, lt, prep);
+        if constexpr (ROLES != 0) {
+            if (consumer) {
+                if (computes) mfma_stage(IntC<0>{}, IntC<0>{}, ibuf, w0, obuf, w1, lt, prep);
+            } else {
+                // the moving half: the weight DMA of step s+1 and the loads of input(s+1), which it stages as soon as they arrive -- all of it under the other
+                // half's MFMAs of step s
+                prep();
+                static_for<0, C::NWT>([&](auto kc) { issue_dma(kc, wsrc_s, w1); });
+                static_for<0, NIN>([&](auto kc) { issue_load(IntC<0>{}, kc, lt, ls_s); });
+                write_in(IntC<0>{}, obuf);
+            }
+        } else if (computes) mfma_stage(IntC<(S + 1) % NSET>{}, IntC<S>{}, ibuf, w0, obuf, C::WAHEAD == 2 ? w2 : w1, lt, prep);
         SDBG(2);
         SDBG(3);
         split_barrier_keep_loads<KEEP>();                       // weights(s+1) have landed, input(s+1) is written
@@ -1189,7 +1222,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
         if (last_ch) {
             // scratch: weights(s) / input(s), which no wave reads any more; the barrier behind the epilogue keeps the next
             // step's DMA and staging writes (of OTHER waves) out of it until every wave has read its block back
-            if (computes) {
+            if (computes && consumer) {
                 if constexpr (OSP) {
                     // straight-line variants: the residual blocks' conv1 (FiLM + SiLU) and conv2 (FiLM + residual), a plain layer
                     // with LeakyReLU; the rest generic
@@ -1263,12 +1296,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const YondConvDesc d) {
     }
 }
 
-template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0>
+template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISP = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0, int NWAVE = 8, int ROLES = 0>
 int launch_split(const YondConvDesc& d, hipStream_t st) {
-    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD>;
+    using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD, NWAVE, ROLES>;
     static_assert(C::SMEM_BYTES <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP, S2, D2, FOLD>;
+    auto kern = conv_split_kernel<STRIDE, TH, TN, MW, PARTS, NWB, PRE, O4, K1, ISP, OSP, S2, D2, FOLD, NWAVE, ROLES>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -1280,7 +1313,7 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
     if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
     const int gmax = (int)yond_exp_long("YOND_SPLIT_GRID", 256);  // (experiment builds: fewer workgroups than CUs, leaving CUs to a side stream's kernels)
     const int grid = total < gmax ? (int)total : gmax;            // one persistent workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::SMEM_BYTES, st, d);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::SMEM_BYTES, st, d);
     YOND_LAUNCH_CHECK();
     return YOND_OK;
 }
@@ -1386,5 +1419,12 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 #define SPLIT_GROUP_H_TALL4(X)                                                                          \
     X(1, 32, 32, 4, 1, 2, false, false, false, true, true)                                               \
     X(1, 16, 64, 4, 1, 2, true, false, false, false, true) X(1, 16, 64, 4, 1, 2, false, false, false, true, true)
+// round 6, the split path's stride-2 layers with ONE wave per SIMD (256 threads): two output rows per wave (0.89 instead of 1.33 KiB of LDS fragments per MFMA) in the
+// same 4 x 32 x 64 tile and the same LDS
+#define SPLIT_GROUP_S2_W4(X)                                                                            \
+    X(2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, false, 0, 4) X(2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, true, 0, 4)
+// ... and with eight waves in two roles: four multiply (two output rows each), four move the data
+#define SPLIT_GROUP_S2_ROLES(X)                                                                         \
+    X(2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, false, 0, 8, 1) X(2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, true, 0, 8, 1)
 #define SPLIT_INSTANTIATE(...) template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);
 #define SPLIT_EXTERN(...) extern template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);

@@ -76,7 +76,7 @@ def parse_args(argv=None):
     if a.cfg == 3:
         a.mode = "iter"                                # the shipped SIDD runfile (runfiles/YOND/SIDD_simple+full_pre_grumix.yml)
         a.height, a.width = 256, 8192                  # the 32 blocks of an item side by side: the denoised Bayer pixels
-        a.frames_per_step = a.frames_per_step or 8
+        a.frames_per_step = a.frames_per_step or 16         # (four groups of four images: the two-stream driver overlaps consecutive groups)
         a.no_extras = True
     if a.cfg == 4:
         a.arch = 'UNetSeeInDark'
@@ -309,6 +309,24 @@ def sidd_eval_group(items, net, arch, P):
     return ress
 
 
+def sidd_eval_stream(items, group, net, arch, P):
+    """YOND_SIDD.eval's loop over `items` as the driver runs it: groups of `group` images, consecutive groups overlapped on two HIP streams
+    (pipeline.denoise_stream_groups), the block metrics of a finished group on a third.  Returns the last image's result."""
+    groups = [items[i:i + group] for i in range(0, len(items), group)]
+    met = {}
+
+    def finish(gi, ress):
+        met[gi] = [[P.block_metrics(dn, it['hr']) for dn in res['raw_dns']] for it, res in zip(groups[gi], ress)]
+    last = None
+    for gi, ress in enumerate(P.denoise_stream_groups(([(it['lr'], it['lr_full']) for it in g] for g in groups), net, arch, SIDD_PIPE, finish=finish)):
+        for res, m in zip(ress, met.pop(gi)):
+            if len(res['raw_dns']) != 2:
+                raise SystemExit(f"bench.py: the SIDD pipeline ran {len(res['raw_dns'])} pass(es), expected 2 (regs {res['regs']})")
+            res['metrics'] = m
+            last = res
+    return last
+
+
 def timed_region(run_step, steps, sync, D, dev):
     """EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides; returns (the MAX over ranks of the
     elapsed time, every rank's time for its own K steps -- taken before the closing barrier -- in rank order)."""
@@ -448,6 +466,8 @@ def main(argv=None):
         elif stream_driver and not sequential:
             for last in P.denoise_stream((frames[i % len(frames)] for i in range(nframes)), net, arch, pipe):
                 pass
+        elif a.cfg == 3 and a.group > 1 and not sequential and not a.sequential:
+            last = sidd_eval_stream([frames[i % len(frames)] for i in range(nframes)], a.group, net, arch, P)
         elif a.cfg == 3 and a.group > 1:
             for i in range(0, nframes, a.group):
                 last = sidd_eval_group([frames[(i + j) % len(frames)] for j in range(min(a.group, nframes - i))], net, arch, P)[-1]
@@ -700,14 +720,23 @@ def main(argv=None):
             it3 = sidd_items(2, dev)
             G3 = max(1, a.group)
             grp3 = [it3[j % 2] for j in range(G3)]
-            sidd_eval_group(grp3, net, arch, P)
+            sidd_eval_stream([it3[j % 2] for j in range(4 * G3)], G3, net, arch, P)
             torch.cuda.synchronize()
             t3, n3 = time.perf_counter(), 0
             while n3 < 8 or time.perf_counter() - t3 < 1.0:
-                r3 = sidd_eval_group(grp3, net, arch, P)[-1]
-                n3 += G3
+                r3 = sidd_eval_stream([it3[j % 2] for j in range(8 * G3)], G3, net, arch, P)
+                n3 += 8 * G3
             torch.cuda.synchronize()
             el3 = time.perf_counter() - t3
+            # ... one group at a time (synchronised after every group)
+            sidd_eval_group(grp3, net, arch, P)
+            torch.cuda.synchronize()
+            t3g, n3g = time.perf_counter(), 0
+            while n3g < 8 or time.perf_counter() - t3g < 0.5:
+                sidd_eval_group(grp3, net, arch, P)
+                n3g += G3
+            torch.cuda.synchronize()
+            el3g = time.perf_counter() - t3g
             # ... and one image at a time (the reference's loop shape; round 5's number)
             sidd_eval_item(it3[0], net, arch, P)
             torch.cuda.synchronize()
@@ -724,8 +753,9 @@ def main(argv=None):
                                         "reference_s_per_image": REF_SIDD_S_PER_IMAGE,
                                         "workload": f"configs[2]: SIDD-shaped synthetic items ({SIDD_FULL[0]}x{SIDD_FULL[1]} estimate frame + 32 blocks of 256x256), "
                                                     f"YOND_SIDD.eval's loop body (IterDenoise 'iter' + block metrics), {G3} images per group: round 1 of a group is ONE "
-                                                    f"batch-{32 * G3} forward, round 2 another; estimates / tables / metrics per image",
-                                        "group": G3, "one_image_at_a_time_ms_per_image": round(el31 / n31 * 1e3, 3)}
+                                                    f"batch-{32 * G3} forward, round 2 another; estimates / tables / metrics per image; consecutive groups overlapped on two HIP streams "
+                                                    "(pipeline.denoise_stream_groups), as yond_public_amd/YOND_SIDD.py eval runs them",
+                                        "group": G3, "one_group_at_a_time_ms_per_image": round(el3g / n3g * 1e3, 3), "one_image_at_a_time_ms_per_image": round(el31 / n31 * 1e3, 3)}
             others["cfg3_sidd_eval"]["roofline"] = leg_roofline(plan, lambda: sidd_eval_group(grp3, net, arch, P), torch.cuda.synchronize)
             del it3, r3
         except Exception as e:
@@ -816,8 +846,8 @@ def main(argv=None):
         if a.batch:
             driver = f"IterDenoiseBatch: per-frame NLE, ONE batched forward of {a.batch} frames"
         elif a.cfg == 3:
-            driver = (f"YOND_SIDD.eval's loop body: IterDenoiseGroup of {a.group} images (round 1 = ONE batch-{32 * a.group} forward, round 2 another; estimates, tables, "
-                      "block metrics per image)" if a.group > 1 else "YOND_SIDD.eval's loop body per image: IterDenoise (batch-32 forwards) + block metrics, one image at a time")
+            driver = (f"YOND_SIDD.eval's loop: groups of {a.group} images (round 1 = ONE batch-{32 * a.group} forward, round 2 another; estimates, tables, "
+                      "block metrics per image), consecutive groups overlapped on two HIP streams (denoise_stream_groups)" if a.group > 1 else "YOND_SIDD.eval's loop body per image: IterDenoise (batch-32 forwards) + block metrics, one image at a time")
         elif stream_driver:
             driver = "denoise_stream: NLE of frame k+1 on a second HIP stream while the convolutions of frame k run"
         else:

@@ -107,7 +107,7 @@ def test_cfg3_shortcut():
     sys.path.insert(0, ROOT)
     import bench
     a = bench.parse_args(["--cfg", "3"])
-    assert a.mode == "iter" and (a.height, a.width) == (256, 8192) and a.frames_per_step == 8
+    assert a.mode == "iter" and (a.height, a.width) == (256, 8192) and a.frames_per_step == 16 and a.group == 4
     assert bench.SIDD_PIPE['full_dn'] is False and bench.SIDD_PIPE['iter'] == 'iter' and bench.SIDD_FULL == (3000, 5328)
 
 

@@ -115,7 +115,8 @@ EVAL_WORKER = textwrap.dedent('''
         return 40.0 + 0.37 * k + it, 0.9 + 0.001 * k + 0.01 * it
 
     t = object.__new__(Y.YOND_SIDD)
-    t.parser = types.SimpleNamespace(prefetch=4, loaders=2, group=int(os.environ.get("YOND_GROUP", "4")), verbose=False)
+    t.parser = types.SimpleNamespace(prefetch=4, loaders=2, group=int(os.environ.get("YOND_GROUP", "4")), verbose=False, stream=False)   # (the two-stream form needs a GPU)
+    t.biaslut = None
     t.rank, t.local_rank, t.world = rank, local, world
     t.device = torch.device('cpu')
     t.pipe = {'iter': 'iter', 'max_iter': 1}

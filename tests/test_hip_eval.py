@@ -107,6 +107,65 @@ def test_grouped_images_equal_the_per_image_run(tmp_path, monkeypatch):
         np.testing.assert_allclose(np.asarray(v['reg'], np.float64), np.asarray(m3[k]['reg'], np.float64), rtol=1e-9, atol=0)
 
 
+def test_streamed_groups_equal_one_group_at_a_time(tmp_path, monkeypatch):
+    """pipeline.denoise_stream_groups -- consecutive groups of SIDD items overlapped on two HIP streams (group k+1's full-frame estimates under group k's
+    first pass, group k's collaborative estimates under group k-1's second), the `finish` callback (the driver's block metrics) on a third -- returns, image
+    by image, what IterDenoiseGroup returns one group at a time: seven images of four noise levels in groups of 3 + 3 + 1 (more groups than the buffer ring holds
+    would wrap it: nine groups of one image do), the metrics computed inside the callback equal to those computed afterwards; and YOND_SIDD.eval's
+    streamed loop equals its `--no-stream` loop."""
+    from yond_public_amd import YOND_SIDD as Y
+    from yond_public_amd import pipeline as P
+    monkeypatch.chdir(tmp_path)
+    trainer = Y.YOND_SIDD(['-f', RUNFILE, '-m', 'eval', '--synthetic', '9', '--group', '4'])
+    items = []
+    for j, (K, sg) in enumerate([(4.0, 6.0), (1.5, 3.0), (9.0, 14.0), (2.5, 9.0), (4.0, 6.0), (1.5, 3.0), (9.0, 14.0)]):
+        d = Y.SyntheticSIDD(1, K=K, sigma=sg, full_hw=(1024, 1536) if j % 2 else (768, 2048))[0]
+        items.append({k: (torch.from_numpy(np.ascontiguousarray(v)).to(DEV) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+    pipe = dict(trainer.pipe)
+    p = dict(pipe, wp=1023, bl=64, ratio=1, gain=1, sigma=0, scale=959.0)
+    pairs = [(d['lr'], d['lr_full']) for d in items]
+    hr = [torch.cat(list(d['hr']), dim=-1) for d in items]
+
+    def run(groups):
+        seen, out = {}, []
+
+        def finish(gi, ress):
+            seen[gi] = [[P.block_metrics(dn, hr[groups[gi][g]]) for dn in r['raw_dns']] for g, r in enumerate(ress)]
+        for gi, ress in enumerate(P.denoise_stream_groups(([pairs[i] for i in g] for g in groups), trainer.net, trainer.arch, pipe, p=p, finish=finish)):
+            assert len(ress) == len(groups[gi]) and gi in seen
+            for g, r in enumerate(ress):
+                again = [P.block_metrics(dn, hr[groups[gi][g]]) for dn in r['raw_dns']]
+                for (a0, a1), (b0, b1) in zip(seen[gi][g], again):
+                    assert np.array_equal(a0, b0) and np.array_equal(a1, b1)
+                out.append(r)
+        return out
+    want = []
+    for g in ([0, 1, 2], [3, 4, 5], [6]):
+        want += P.IterDenoiseGroup([pairs[i] for i in g], trainer.net, trainer.arch, pipe, ps=p)
+    for groups in ([[0, 1, 2], [3, 4, 5], [6]], [[i % 7] for i in range(9)]):
+        got = run(groups)
+        order = [i for g in groups for i in g]
+        assert len(got) == len(order)
+        for r, i in zip(got, order):
+            w = want[i]
+            assert len(r['raw_dns']) == len(w['raw_dns']) == 2
+            for it in range(2):
+                assert report(f"streamed groups {len(groups)}: image {i} round {it}", r['raw_dns'][it].cpu().numpy(), w['raw_dns'][it].cpu().numpy()) <= 5e-6
+            np.testing.assert_allclose(np.asarray(r['regs'], np.float64), np.asarray(w['regs'], np.float64), rtol=1e-9, atol=0)
+    # the driver: streamed against one group at a time
+    assert P.STREAM_GROUPS and trainer.parser.stream
+    red_s = trainer.eval(-1)
+    m_s = {k: dict(v) for k, v in trainer.metrics.items()}
+    trainer.parser.stream = False
+    red_g = trainer.eval(-1)
+    assert red_s['count'] == red_g['count'] == 9
+    for key in red_g:
+        assert abs(red_g[key] - red_s[key]) <= 1e-5 * max(1.0, abs(red_g[key])), key
+    for k, v in trainer.metrics.items():
+        np.testing.assert_allclose(v['psnr'], m_s[k]['psnr'], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(v['ssim'], m_s[k]['ssim'], rtol=0, atol=1e-6)
+
+
 def test_yond_sidd_full_dn_runfile(tmp_path, monkeypatch):
     """A runfile with full_dn: True (the ELD / LRID / DND style of SURVEY 3.2) must run on the SIDD stack the dataset
     yields: the driver concatenates first, as YOND_SIDD.py:387-389 does."""

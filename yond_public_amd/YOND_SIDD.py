@@ -214,7 +214,51 @@ class YOND_SIDD:
         # :507-514): file reads, the float32 conversion and the 64 MB upload of the full frame overlap the previous images' kernels
         from .data import Prefetcher
         G = max(1, int(getattr(self.parser, 'group', 1)))
-        for batch in self._groups(Prefetcher(self.dst_eval, mine, self.device, depth=max(self.parser.prefetch, 2 * G), workers=self.parser.loaders)):
+        pf = Prefetcher(self.dst_eval, mine, self.device, depth=max(self.parser.prefetch, 3 * G), workers=self.parser.loaders)
+        est_type = str(self.pipe.get('est_type', 'simple'))
+        streamed = (P.STREAM_GROUPS and getattr(self.parser, 'stream', True) and self.pipe.get('iter') == 'iter' and self.pipe.get('max_iter', 1) == 1
+                    and 'simple' in est_type and 'cal_est' not in self.pipe and 'rot_cfa' not in p and self.biaslut is None)
+
+        def metrics_of(data, res):
+            psnrs, ssims = [], []
+            hr_raw = data.get('hr')
+            if hr_raw is not None:
+                hr = torch.cat(list(hr_raw), dim=-1) if isinstance(hr_raw, torch.Tensor) else torch.from_numpy(np.concatenate(hr_raw, axis=-1)).to(self.device)
+                for dn in res['raw_dns']:
+                    ps, ss = P.block_metrics(dn, hr)                                   # :649-652 per 256x256 block
+                    psnrs.append(float(np.mean(ps)))
+                    ssims.append(float(np.mean(ss)))
+            return psnrs, ssims
+
+        def account(data, res, psnrs, ssims):
+            if psnrs:
+                sums.update(psnrs, ssims)            # iterations that did not run count -1 in their own meter (:644-647)
+            self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
+            log(f"[rank {self.rank}] {data['name']}: PSNR={psnrs[-1] if psnrs else float('nan'):.2f}, "
+                f"SSIM={ssims[-1] if ssims else float('nan'):.4f}", self.logfile)
+
+        if streamed:
+            # consecutive groups overlapped on two HIP streams (pipeline.denoise_stream_groups): group k+1's full-frame estimates under group k's first
+            # pass, group k's collaborative estimates under group k-1's second; the block metrics of a finished group on a third stream
+            batches, done = {}, {}
+
+            def groups():
+                for gi, batch in enumerate(self._groups(pf)):
+                    batches[gi] = batch
+                    yield [(d['lr'], d.get('lr_full')) for _, d in batch]
+
+            def finish(gi, ress):
+                done[gi] = [metrics_of(d, r) for (_, d), r in zip(batches[gi], ress)]
+
+            for gi, ress in enumerate(P.denoise_stream_groups(groups(), self.net, self.arch, self.pipe, p=dict(p, cfa=[[1, 2], [2, 3]]), device=self.device,
+                                                             log=(lambda s: log(s, self.logfile)) if self.parser.verbose else None, finish=finish)):
+                batch = batches.pop(gi)
+                for (k, data), res, (psnrs, ssims) in zip(batch, ress, done.pop(gi)):
+                    account(data, res, psnrs, ssims)
+                t_path = time.perf_counter() - t0          # (groups overlap: the path IS the wall clock here)
+                marks.extend([(time.perf_counter(), t_path)] * len(batch))
+        else:
+          for batch in self._groups(pf):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             datas = [d for _, d in batch]
@@ -224,17 +268,8 @@ class YOND_SIDD:
             else:
                 ress = self.IterDenoiseGroup(datas, plist)
             for (k, data), res in zip(batch, ress):
-                psnrs, ssims = [], []
-                if res['hr_raw'] is not None:
-                    hr = res['hr_raw'] if isinstance(res['hr_raw'], torch.Tensor) else torch.from_numpy(res['hr_raw']).to(self.device)
-                    for dn in res['raw_dns']:
-                        ps, ss = P.block_metrics(dn, hr)                                   # :649-652 per 256x256 block
-                        psnrs.append(float(np.mean(ps)))
-                        ssims.append(float(np.mean(ss)))
-                    sums.update(psnrs, ssims)        # iterations that did not run count -1 in their own meter (:644-647)
-                self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
-                log(f"[rank {self.rank}] {data['name']}: PSNR={psnrs[-1] if psnrs else float('nan'):.2f}, "
-                    f"SSIM={ssims[-1] if ssims else float('nan'):.4f}", self.logfile)
+                psnrs, ssims = metrics_of(data, res)
+                account(data, res, psnrs, ssims)
             torch.cuda.synchronize()
             t_path += time.perf_counter() - t1              # estimate + denoise (+ metrics) of this group's images
             marks.extend([(time.perf_counter(), t_path)] * len(batch))
@@ -319,6 +354,7 @@ class YONDParser:
         a.add_argument('--verbose', action='store_true', default=False)
         a.add_argument('--loaders', type=int, default=4, help="loader threads that read and upload the items ahead of the GPU")
         a.add_argument('--prefetch', type=int, default=4, help="items the loader threads may be ahead of the GPU (at least two groups)")
+        a.add_argument('--no-stream', dest='stream', action='store_false', default=True, help="one group at a time instead of consecutive groups overlapped on two HIP streams")
         a.add_argument('--group', type=int, default=4, help="images denoised together: round 1 of a group is ONE batch-(32 x group) forward, round 2 another "
                        "(per image the results are those of --group 1)")
         return a.parse_args(args)

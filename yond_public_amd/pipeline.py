@@ -1301,6 +1301,140 @@ def IterDenoiseGroup(items, net, arch, pipe, ps=None, device=None, log=None, bia
     return out
 
 
+def denoise_stream_groups(groups, net, arch, pipe, p=None, device=None, log=None, biaslut=None, finish=None):
+    """`IterDenoiseGroup` over a SEQUENCE of groups of SIDD-layout items with consecutive groups overlapped on two HIP streams (the shipped SIDD
+    mode: iter, max_iter 1, block-wise denoising, est_type 'simple'): the main stream carries the batched network passes in the order D1(0), D1(1),
+    D2(0), D1(2), D2(1), ...; the side stream runs group k+1's self estimates (one 16 MP frame per image) under D1(k) and group k's collaborative
+    estimates + guards + parameter chains under D2(k-1).  groups: an iterable of lists [(lr [32][256][256], lr_full or None), ...]; yields one
+    list of results per group, two groups late.  finish(group index, results): an optional callback run on the SIDE stream behind the group's last
+    pass (the evaluation driver's block metrics: their host reads then wait for that group only, not for the passes queued since).
+    Per image the result is IterDenoise's (tests/test_hip_eval.py); a group the device chain does not cover, and an image whose parameter block carries a
+    flag the chain leaves to the host, go through IterDenoiseGroup / IterDenoise when they are yielded.  Items must stay unmodified until yielded."""
+    p0 = dict(p or default_params())
+    two = pipe.get('iter', 'iter') == 'iter' and pipe.get('max_iter', 1) == 1
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+    RING = 4
+    pipe2 = dict(pipe, collab_sidd256=pipe.get('collab_sidd256', True))
+
+    def usable(items):
+        return (two and STREAM_GROUPS and len(items) >= 1 and all(chain_applies_sidd(lr, lf, net, arch, pipe, p0, biaslut) and lr.shape == items[0][0].shape
+                                                                   for lr, lf in items))
+
+    def bufs(k, g, r):
+        return _chain_buffers(main.device, ('group-stream', k % RING, g, r))
+
+    def est1(st, k, ready):
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            for g, (blocks, lr_full) in enumerate(st['items']):
+                lr_cat = torch.cat(list(blocks), dim=-1).contiguous()                          # :315
+                mx = _frame_max(lr_cat)                                                        # :393
+                _chain_estimate(lr_cat if lr_full is None else lr_full, None, 'self', pipe, p0, bufs(k, g, 0), lr_max_dev=mx)
+                st['lr_cat'].append(lr_cat)
+                st['mx'].append(mx)
+            return side.record_event()
+
+    def est2(st, k):
+        side.wait_event(st['fin1'])
+        with torch.cuda.stream(side):
+            for g in range(len(st['items'])):
+                _chain_estimate(st['lr_cat'][g], st['out1'][g], 'collab', pipe2, p0, bufs(k, g, 1), lr_max_dev=st['mx'][g])
+            return side.record_event()
+
+    def round_(st, k, r):
+        G = len(st['items'])
+        outs, watch = _chain_denoise_blocks_group([it[0] for it in st['items']], net, arch, p0, [bufs(k, g, r) for g in range(G)], 4 + 2 * (k % RING) + r)
+        return [torch.cat(list(o), dim=-1).contiguous() for o in outs], watch, main.record_event()
+
+    def release(st, k):
+        items = st['items']
+        redone = not st['chain']
+        if not st['chain']:
+            res = IterDenoiseGroup(items, net, arch, pipe, ps=p0, log=log, biaslut=biaslut)
+        else:
+            st['fin2'].synchronize()
+            trip1 = st['g1'] is not None and st['g1'].tripped()
+            trip2 = st['g2'] is not None and st['g2'].tripped()
+            res = []
+            for g in range(len(items)):
+                reg1, par1, fl1, info1 = _chain_result(bufs(k, g, 0))
+                reg2, par2, fl2, info2 = _chain_result(bufs(k, g, 1))
+                bad = bool(fl1 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE)) or trip1 or bool(fl2 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY))
+                aborted = bool(fl2 & PRM_ROUND_ABORTED)                       # :445-447
+                if not bad and not aborted:
+                    bad = bool(fl2 & PRM_BAD_ESTIMATE) or trip2
+                if bad:
+                    res.append(IterDenoise(items[g][0], net, arch, pipe, lr_full=items[g][1], p=p0, log=log, biaslut=biaslut))
+                    redone = True
+                    continue
+                raw_dns, regs, params = [st['out1'][g]], [reg1], [par1]
+                if not aborted:
+                    raw_dns.append(st['out2'][g])
+                    regs.append(reg2)
+                    params.append(par2)
+                res.append(dict(raw_dns=raw_dns, regs=regs, params=params, nle_info=info1))
+        if finish is not None:
+            # on a stream of its own: the host has just waited for this group's last pass, and a host read inside `finish` must not wait for the estimates and
+            # passes of the groups queued since
+            aux = _side_stream(main.device, 'aux')
+            if redone:
+                aux.wait_stream(main)                  # (a group or an image recomputed just now, on the main stream)
+            with torch.cuda.stream(aux):
+                finish(k, res)
+        return res
+
+    it = iter(groups)
+
+    def take():
+        try:
+            raw = next(it)
+        except StopIteration:
+            return None
+        items = []
+        for lr, lf in raw:
+            lr_c = _dev(lr, device).contiguous()
+            items.append((lr_c, None if lf is None else _dev(lf, lr_c.device)))
+        return dict(items=items, lr_cat=[], mx=[], chain=usable(items), g1=None, g2=None)
+
+    live = {}
+    nxt = take()
+    k = 0
+    if nxt is not None:
+        live[0] = nxt
+        if nxt['chain']:
+            nxt['e1'] = est1(nxt, 0, main.record_event())
+    while k in live:
+        st = live[k]
+        nxt = take()                                  # (and mark the main stream) BEFORE queuing this group's network
+        ready = main.record_event()
+        if st['chain']:
+            main.wait_event(st['e1'])
+            st['out1'], st['g1'], st['fin1'] = round_(st, k, 0)                # D1(k)
+        if nxt is not None:
+            live[k + 1] = nxt
+            if nxt['chain']:
+                nxt['e1'] = est1(nxt, k + 1, ready)                            # E1(k+1): under D1(k)
+        if st['chain']:
+            st['e2'] = est2(st, k)                                             # E2(k): behind D1(k), under D2(k-1)
+        if k - 1 in live and live[k - 1]['chain']:
+            prev = live[k - 1]
+            main.wait_event(prev['e2'])
+            prev['out2'], prev['g2'], prev['fin2'] = round_(prev, k - 1, 1)    # D2(k-1)
+        if k - 2 in live:
+            yield release(live.pop(k - 2), k - 2)
+        k += 1
+    if k - 1 in live and live[k - 1]['chain']:
+        prev = live[k - 1]
+        main.wait_event(prev['e2'])
+        prev['out2'], prev['g2'], prev['fin2'] = round_(prev, k - 1, 1)
+    for j in sorted(live):
+        yield release(live.pop(j), j)
+
+
+STREAM_GROUPS = True                # (module attribute: False = the evaluation drivers take one group at a time, for A/B)
+
+
 def IterDenoiseBatch(frames, net, arch, pipe, p=None, device=None):
     """`IterDenoise` for B equally sized full Bayer frames at once (BASELINE cfg 4: batch 8; pipe['full_dn']): every frame
     keeps its own noise-level estimate, bias LUT and VST constants -- the per-image steps of YOND_SIDD.py:341-356,
@@ -1591,8 +1725,8 @@ def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
 _SIDE_STREAMS = {}
 
 
-def _side_stream(dev):
-    key = str(dev)
+def _side_stream(dev, which='side'):
+    key = (str(dev), which)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SIDE_STREAMS[key]

@@ -87,7 +87,7 @@ def parse_args(argv=None):
     a.precision = a.precision or 'fp32'
     a.height, a.width = a.height or 3000, a.width or 4000
     if not a.frames_per_step:
-        a.frames_per_step = a.batch if a.batch else (24 if a.mode == "once" else 12)
+        a.frames_per_step = 3 * a.batch if a.batch else (24 if a.mode == "once" else 12)     # (batches: three per step -- the stream driver overlaps consecutive batches)
         if a.cfg == 5:
             a.frames_per_step = 12
     if a.batch and a.frames_per_step % a.batch:
@@ -327,6 +327,18 @@ def sidd_eval_stream(items, group, net, arch, P):
     return last
 
 
+def batch_stream(frames, B, net, arch, pipe, P):
+    """cfg 4's loop: B frames per forward, the B estimators of batch k+1 on a second HIP stream under the batched network pass of batch k
+    (pipeline.denoise_stream_batches).  Returns the LAST batch in IterDenoiseBatch's shape (raw_dns [[B][H][W]], regs [[B]], params [[B]])."""
+    import torch
+    last = []
+    for r in P.denoise_stream_batches(frames, B, net, arch, pipe):
+        last.append(r)
+        if len(last) > B:
+            last.pop(0)
+    return dict(raw_dns=[torch.stack([r['raw_dns'][0] for r in last])], regs=[[r['regs'][0] for r in last]], params=[[r['params'][0] for r in last]])
+
+
 def timed_region(run_step, steps, sync, D, dev):
     """EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides; returns (the MAX over ranks of the
     elapsed time, every rank's time for its own K steps -- taken before the closing barrier -- in rank order)."""
@@ -460,7 +472,9 @@ def main(argv=None):
     def run(nframes, sequential=False):
         """nframes passes of the hot path over the resident frames (cycled)."""
         last = None
-        if a.batch:
+        if a.batch and not sequential and not a.sequential and a.mode == "once":
+            last = batch_stream((frames[i % len(frames)] for i in range(nframes // a.batch * a.batch)), a.batch, net, arch, pipe, P)
+        elif a.batch:
             for b in range(nframes // a.batch):
                 last = P.IterDenoiseBatch([frames[(b * a.batch + j) % len(frames)] for j in range(a.batch)], net, arch, pipe)
         elif stream_driver and not sequential:
@@ -696,16 +710,26 @@ def main(argv=None):
         net4.load_state_dict(S.denoising_state_dict(net4, 0))
         net4 = net4.to(dev).eval()
         batch8 = [frames[j % len(frames)] for j in range(8)]
-        P.IterDenoiseBatch(batch8, net4, arch4, pipe)
+        batch_stream((batch8[j % 8] for j in range(16)), 8, net4, arch4, pipe, P)
         torch.cuda.synchronize()
         t4, n4 = time.perf_counter(), 0
-        while n4 < 2 or time.perf_counter() - t4 < 1.0:
-            r4 = P.IterDenoiseBatch(batch8, net4, arch4, pipe)
-            torch.cuda.synchronize()
-            n4 += 1
+        while n4 < 3 or time.perf_counter() - t4 < 1.0:
+            r4 = batch_stream((batch8[j % 8] for j in range(24)), 8, net4, arch4, pipe, P)
+            n4 += 3
+        torch.cuda.synchronize()
         el4 = time.perf_counter() - t4
+        P.IterDenoiseBatch(batch8, net4, arch4, pipe)
+        torch.cuda.synchronize()
+        t4b, n4b = time.perf_counter(), 0
+        while n4b < 2 or time.perf_counter() - t4b < 0.5:
+            P.IterDenoiseBatch(batch8, net4, arch4, pipe)
+            torch.cuda.synchronize()
+            n4b += 1
+        el4b = time.perf_counter() - t4b
         others["cfg4_unet_batch8"] = {"value": round(n4 * 8 * H * W / 1e6 / el4, 2), "unit": "Bayer MP/s", "ms_per_frame": round(el4 / (n4 * 8) * 1e3, 3),
-                                      "frames": n4 * 8, "workload": f"configs[3]: UNetSeeInDark(nf=32), {H}x{W} frames, per-frame NLE, ONE batched forward of 8"}
+                                      "frames": n4 * 8, "one_batch_at_a_time_ms_per_frame": round(el4b / (n4b * 8) * 1e3, 3),
+                                      "workload": f"configs[3]: UNetSeeInDark(nf=32), {H}x{W} frames, per-frame NLE, ONE batched forward of 8; the estimators of batch k+1 on a "
+                                                  "second HIP stream under the forward of batch k (pipeline.denoise_stream_batches)"}
         try:
             others["cfg4_unet_batch8"]["roofline"] = leg_roofline(P._plan_of(net4, dev), lambda: P.IterDenoiseBatch(batch8, net4, arch4, pipe),
                                                                   torch.cuda.synchronize)
@@ -844,7 +868,8 @@ def main(argv=None):
         mp = H * W / 1e6
         cfg_idx = {2: 1, 3: 2, 4: 3, 5: 4}[a.cfg]
         if a.batch:
-            driver = f"IterDenoiseBatch: per-frame NLE, ONE batched forward of {a.batch} frames"
+            driver = (f"denoise_stream_batches: per-frame NLE, ONE batched forward of {a.batch} frames, the estimators of batch k+1 on a second HIP stream under the forward of batch k"
+                      if (a.mode == "once" and not a.sequential) else f"IterDenoiseBatch: per-frame NLE, ONE batched forward of {a.batch} frames")
         elif a.cfg == 3:
             driver = (f"YOND_SIDD.eval's loop: groups of {a.group} images (round 1 = ONE batch-{32 * a.group} forward, round 2 another; estimates, tables, "
                       "block metrics per image), consecutive groups overlapped on two HIP streams (denoise_stream_groups)" if a.group > 1 else "YOND_SIDD.eval's loop body per image: IterDenoise (batch-32 forwards) + block metrics, one image at a time")

@@ -50,7 +50,7 @@ def test_config_shortcuts():
     sys.path.insert(0, ROOT)
     import bench
     a = bench.parse_args(["--cfg", "4"])
-    assert a.arch == "UNetSeeInDark" and a.batch == 8 and a.frames_per_step == 8 and (a.height, a.width) == (3000, 4000)
+    assert a.arch == "UNetSeeInDark" and a.batch == 8 and a.frames_per_step == 24 and (a.height, a.width) == (3000, 4000)
     a = bench.parse_args(["--cfg", "5"])
     assert a.precision == "fp16" and (a.height, a.width) == (4000, 6000)
     a = bench.parse_args([])

@@ -193,6 +193,29 @@ def test_yond_sidd_full_dn_runfile(tmp_path, monkeypatch):
         np.testing.assert_allclose(m['reg'][it][0], ref['regs'][it][0], rtol=2e-5)
 
 
+def test_streamed_batches_equal_iterdenoise():
+    """pipeline.denoise_stream_batches (cfg 4's driver: B frames per forward, the estimators of batch k+1 on a second HIP stream under the forward of
+    batch k): every frame comes out as IterDenoise returns it -- seven frames in batches of 3 + 3 + 1, UNetSeeInDark and the guided net."""
+    import yond_oracle as O
+    from yond_public_amd import archs as A
+    from yond_public_amd import pipeline as P
+    pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'max_iter': 1, 'full_dn': True}
+    for aname, seed in (("unet32", 82), ("gru32", 9)):
+        arch = ARCHS[aname]
+        net = getattr(A, arch['name'])(dict(arch))
+        net.load_state_dict(O.denoising_state_dict(arch, seed))
+        net = net.to(DEV).eval()
+        frames = [torch.from_numpy(O.synth_noisy(192, 320, 2.0 + i, 4.0 + 3 * i, 40 + i)[0]).to(DEV) for i in range(7)]
+        want = [P.IterDenoise(f, net, arch, pipe) for f in frames]
+        got = list(P.denoise_stream_batches(iter(frames), 3, net, arch, pipe))
+        assert len(got) == 7
+        for i, (r, w) in enumerate(zip(got, want)):
+            assert len(r['raw_dns']) == 1
+            assert report(f"{aname}: streamed batches, frame {i}", r['raw_dns'][0].cpu().numpy(), w['raw_dns'][0].cpu().numpy()) <= 5e-6
+            np.testing.assert_allclose(np.asarray(r['regs'], np.float64), np.asarray(w['regs'], np.float64), rtol=1e-9, atol=0)
+            np.testing.assert_allclose(np.asarray(r['params'], np.float64), np.asarray(w['params'], np.float64), rtol=1e-9, atol=0)
+
+
 def test_iter_denoise_batch_equals_per_frame():
     """BASELINE cfg 4 driver: B frames with their own estimates through ONE batched forward per round give, frame by
     frame, IterDenoise's result (UNetSeeInDark and the guided net; two rounds)."""

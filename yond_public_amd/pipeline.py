@@ -853,6 +853,48 @@ def _chain_denoise(lr, net, arch, p, buf, guard_slot):
     return out, watch
 
 
+def _chain_denoise_frames(frames, net, arch, p, bufs, guard_slot):
+    """_chain_denoise for B equally sized full frames, each with ITS parameter block and table (bufs[b]): K1 per frame into its slice of ONE network
+    input -> one batch-B forward (every item with its own maximum and t) -> K4 per frame.  Returns ([B] of [H][W], guard)."""
+    lib = L.load()
+    B = len(frames)
+    H, W = frames[0].shape
+    dev = frames[0].device
+    h, w = H // 2, W // 2
+    scale = float(p['scale'])
+    st = L.stream()
+    p2d = get_p2d((1, 4, h, w), base=32)
+    Hp, Wp = h + p2d[2] + p2d[3], w + p2d[0] + p2d[1]
+    x4 = torch.empty((B, Hp, Wp, 4), dtype=torch.float32, device=dev)
+    img_max = torch.empty(B, dtype=torch.float32, device=dev)
+    k1 = lib.yond_pack_vst_norm_chain_f32 if CHAIN_K1 else lib.yond_pack_vst_norm_dev_f32
+    with _stage("vst_pack"):
+        for b, (lr, buf) in enumerate(zip(frames, bufs)):
+            L.check(k1(L.ptr(lr), H, W, L.ptr(x4[b]), p2d[0], p2d[1], p2d[2], p2d[3], scale, L.ptr(buf.prm), L.ptr(buf.lut_ws), LUT_CAP,
+                       L.ptr(img_max[b:b + 1]), st), "yond_pack_vst_norm_chain_f32")
+    plan = _plan_of(net, dev)
+    t_dev = torch.cat([buf.t for buf in bufs]).contiguous() if 'guided' in arch else None
+
+    def forward_and_invert():
+        y4 = plan.forward_nhwc4(x4, t_dev, ub=img_max)
+        outs = []
+        with _stage("ivst_unpack"):
+            for b, buf in enumerate(bufs):
+                out = torch.empty((H, W), dtype=torch.float32, device=dev)
+                L.check(lib.yond_denorm_ivst_unpack_dev_f32(L.ptr(y4[b]), Hp, Wp, p2d[2], p2d[0], h, w, L.ptr(out), 1, scale, L.ptr(buf.prm), 1, st),
+                        "yond_denorm_ivst_unpack_dev_f32")
+                outs.append(out)
+        return outs
+
+    watch = _Guard(plan, guard_slot) if plan.uses_half_operands() else None
+    outs = forward_and_invert()
+    if watch is not None:
+        watch.arm(forward_and_invert)
+    for buf in bufs:
+        buf.prm_host.copy_(buf.prm, non_blocking=True)
+    return outs, watch
+
+
 def _chain_round(lr, hr, mode, net, arch, pipe, p, slot, lr_max_dev=None, vst_type='exact'):
     """One round of IterDenoise for a bare frame, queued without any host synchronisation:
     estimator (self / collab) -> yond_frame_params_f64 -> bias LUT -> table -> K1 -> network -> K4.
@@ -1433,6 +1475,88 @@ def denoise_stream_groups(groups, net, arch, pipe, p=None, device=None, log=None
 
 
 STREAM_GROUPS = True                # (module attribute: False = the evaluation drivers take one group at a time, for A/B)
+
+
+def denoise_stream_batches(frames, B, net, arch, pipe, p=None, device=None):
+    """`IterDenoiseBatch` over a sequence of equally sized full Bayer frames, B per forward (BASELINE cfg 4), with the estimators of batch k+1 -- B self
+    estimates and parameter chains -- on the side stream under the batched network pass of batch k (pipe['iter'] == 'once', the device chain's
+    configurations; anything else: IterDenoiseBatch batch by batch).  Yields one dict per FRAME (raw_dns, regs, params), a batch late.  Per frame the
+    result is IterDenoise's (tests/test_hip_eval.py).  Frames must stay unmodified until yielded."""
+    p0 = dict(p or default_params())
+    it = iter(frames)
+
+    def take():
+        out = []
+        for f in it:
+            out.append(_dev(f, device))
+            if len(out) == B:
+                break
+        return out
+
+    chain_cfg = (DEVICE_CHAIN and STREAM_GROUPS and pipe.get('iter', 'iter') == 'once' and pipe.get('full_dn', False) and pipe.get('bias_corr', 'pre') == 'pre'
+                 and 'simple' in str(pipe.get('est_type', 'simple')) and 'cal_est' not in pipe and pipe.get('full_est', True) and 'rot_cfa' not in p0)
+    if not chain_cfg:
+        while True:
+            batch = take()
+            if not batch:
+                return
+            r = IterDenoiseBatch(batch, net, arch, pipe, p=p0, device=device)
+            for b in range(len(batch)):
+                yield dict(raw_dns=[rd[b] for rd in r['raw_dns']], regs=[rg[b] for rg in r['regs']], params=[pr[b] for pr in r['params']])
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+    RING = 3
+
+    def bufs(k, b):
+        return _chain_buffers(main.device, ('batch-stream', k % RING, b))
+
+    def estimate(batch, k, ready):
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            for b, lr in enumerate(batch):
+                _chain_estimate(lr, None, 'self', pipe, p0, bufs(k, b))
+            return side.record_event()
+
+    def release(item, k):
+        batch, outs, watch, fin = item
+        fin.synchronize()
+        trip = watch is not None and watch.tripped()
+        res = []
+        for b, lr in enumerate(batch):
+            reg, par, flags, info = _chain_result(bufs(k, b))
+            if flags & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE) or trip:
+                global DEVICE_CHAIN
+                DEVICE_CHAIN = False
+                try:
+                    res.append(IterDenoise(lr, net, arch, pipe, p=p0))
+                finally:
+                    DEVICE_CHAIN = True
+            else:
+                res.append(dict(raw_dns=[outs[b]], regs=[reg], params=[par], nle_info=info))
+        return res
+
+    batch = take()
+    if not batch:
+        return
+    k = 0
+    est = estimate(batch, 0, main.record_event())
+    pending = None
+    while batch:
+        nxt = take()                                   # (and mark the main stream) BEFORE queuing this batch's network
+        ready = main.record_event()
+        main.wait_event(est)
+        outs, watch = _chain_denoise_frames(batch, net, arch, p0, [bufs(k, b) for b in range(len(batch))], 4 + (k % RING))
+        fin = main.record_event()
+        cur = (batch, outs, watch, fin)
+        if nxt:
+            est = estimate(nxt, k + 1, ready)
+        if pending is not None:
+            yield from release(*pending)
+        pending = (cur, k)
+        batch = nxt
+        k += 1
+    if pending is not None:
+        yield from release(*pending)
 
 
 def IterDenoiseBatch(frames, net, arch, pipe, p=None, device=None):

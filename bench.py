@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (no sequential / fp32-mfma / parity legs)")
     ap.add_argument("--group", type=int, default=4, help="cfg 3: SIDD images denoised together (one batch-(32 x group) forward per round); 1 = one image at a time")
+    ap.add_argument("--lanes", type=int, default=0, help="A/B: HIP streams the network passes of consecutive frames alternate between (pipeline.STREAM_LANES; 0 = its default)")
     ap.add_argument("--sequential", action="store_true", help="time one frame at a time (IterDenoise) instead of the two-stream driver")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiments: no HIP events around the kernels (no roofline objects)")
     ap.add_argument("--precision", default=None, choices=["fp32", "fp32-mfma", "fp16"],
@@ -425,6 +426,8 @@ def main(argv=None):
     rank, local, world = D.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    if a.lanes:
+        P.STREAM_LANES = a.lanes
     group_world = check_world(a, D)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -874,7 +877,9 @@ def main(argv=None):
             driver = (f"YOND_SIDD.eval's loop: groups of {a.group} images (round 1 = ONE batch-{32 * a.group} forward, round 2 another; estimates, tables, "
                       "block metrics per image), consecutive groups overlapped on two HIP streams (denoise_stream_groups)" if a.group > 1 else "YOND_SIDD.eval's loop body per image: IterDenoise (batch-32 forwards) + block metrics, one image at a time")
         elif stream_driver:
-            driver = "denoise_stream: NLE of frame k+1 on a second HIP stream while the convolutions of frame k run"
+            driver = ("denoise_stream: NLE of frame k+1 on a side HIP stream while the convolutions of frame k run" +
+                      (f"; the network passes of consecutive frames alternate between {P.STREAM_LANES} streams (a launch's last, partly filled round of persistent "
+                       "workgroups and the gaps between dependent launches are covered by the other frame's launches)" if (P.STREAM_LANES > 1 and a.mode == "once") else ""))
         else:
             driver = "IterDenoise, one frame at a time"
         out = {

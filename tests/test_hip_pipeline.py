@@ -330,9 +330,22 @@ def test_denoise_stream_matches_iterdenoise():
     net.load_state_dict(S.procedural_state_dict(net, 0))
     net = net.to(dev).eval()
     pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'max_iter': 1, 'full_dn': True}
-    frames = [torch.from_numpy(S.synth_noisy(256, 320, 3.0 + i, 5.0 + 2 * i, 10 + i)[0]).to(dev) for i in range(4)]
+    # round 6: the network passes of consecutive frames alternate between two streams (pipeline.STREAM_LANES), each lane with its own split-plane
+    # tensors -- frames of two sizes, more of them than the driver's ring of parameter blocks (4) holds, and a one-frame sequence that must drain
+    shapes = [(256, 320), (256, 320), (320, 448), (256, 320), (320, 448), (256, 320), (256, 320)]
+    frames = [torch.from_numpy(S.synth_noisy(h, w, 3.0 + i, 5.0 + 2 * i, 10 + i)[0]).to(dev) for i, (h, w) in enumerate(shapes)]
     seq = [P.IterDenoise(f, net, arch, pipe) for f in frames]
+    assert P.STREAM_LANES == 2
     got = list(P.denoise_stream(iter(frames), net, arch, pipe))
+    one = list(P.denoise_stream(iter(frames[:1]), net, arch, pipe))
+    assert len(one) == 1 and float((one[0]['raw_dns'][0] - seq[0]['raw_dns'][0]).abs().max()) <= 5e-6
+    P.STREAM_LANES = 1                                            # (every pass on the main stream, as before)
+    try:
+        got1 = list(P.denoise_stream(iter(frames), net, arch, pipe))
+    finally:
+        P.STREAM_LANES = 2
+    for a_, b_ in zip(got1, seq):
+        assert float((a_['raw_dns'][0] - b_['raw_dns'][0]).abs().max()) <= 5e-6
     got_host = list(P.denoise_stream((f.cpu().numpy() for f in frames), net, arch, pipe, device=dev))    # host arrays are uploaded in order
     torch.cuda.synchronize()
     assert len(got) == len(seq) == len(got_host)

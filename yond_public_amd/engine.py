@@ -364,7 +364,7 @@ class DenoiserPlan:
         """A split-plane tensor [N][Cc/16][2][parts][sp_plane_units(H, W)] x 16 bytes, kept per (key, shape) across forwards: the
         zero units behind every plane are written once, here (producers never touch them).  parts 1: h-only planes (the fp16 path)."""
         cache = self.__dict__.setdefault('_sp_cache', {})
-        k = (key, N, H, W, Cc, parts)
+        k = (key, N, H, W, Cc, parts, getattr(self, 'lane', 0))              # (lane: the forwards of two frames in flight on two streams keep their own tensors)
         if k not in cache:
             cache[k] = torch.zeros(N * (Cc // 16) * 2 * parts * sp_plane_units(H, W) * 4, dtype=torch.float32, device=self.dev)
         return cache[k]
@@ -528,7 +528,7 @@ class DenoiserPlan:
 
     def _film(self, t_dev, ub, N):
         """All nine blocks' (scale, shift) epilogue vectors in one launch."""
-        key = N
+        key = (N, getattr(self, 'lane', 0))
         if key not in self._film_cache:
             fp = self._film_params
             outs, descs = {}, (L.YondFilmDesc * len(self._film_spec))()

@@ -1692,16 +1692,27 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
         yield release(pending)
 
 
+STREAM_LANES = 2                    # network passes in flight on as many HIP streams (1: every pass on the main stream, as rounds 3-5 had it)
+
+
 def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
     """denoise_stream on the device chain: frame k+1's estimator AND its whole parameter chain (beta -> K, sigma, t, knots ->
     bias LUT -> table) run on the side stream under the convolutions of frame k -- no host round trip anywhere; the host reads
-    a frame's parameter block one frame late, when it yields the result.  A frame whose block carries a flag (no flat area,
-    table capacity, K <= 0) or whose range guard tripped is recomputed on the host-side chain before it is yielded."""
+    a frame's parameter block late, when it yields the result.  A frame whose block carries a flag (no flat area,
+    table capacity, K <= 0) or whose range guard tripped is recomputed on the host-side chain before it is yielded.
+    Round 6: the network passes of consecutive frames alternate between STREAM_LANES streams (each lane with its own split-plane tensors and
+    FiLM vectors, engine `lane`): the persistent workgroups of frame k+1's launch take the CUs that the last, partly filled round of frame k's
+    launch leaves idle (5,922 level-0 tiles = 23.1 rounds of 256) and the gap between two dependent launches of one stream is covered by the
+    other's.  Same kernels, same arguments, same results; a frame is yielded STREAM_LANES frames late."""
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
+    NL = max(1, int(STREAM_LANES))
+    lanes = [main] + [_side_stream(main.device, f'net{j}') for j in range(1, NL)]
+    RING = NL + 2                                                # a frame's buffers rest until it has been yielded: estimate, NL passes in flight, one read
+    plan = _plan_of(net, main.device)
 
     def estimate(lr, ready, slot):
-        buf = _chain_buffers(lr.device, 2 + slot % 3)            # three sets: a frame's buffers rest until two frames later
+        buf = _chain_buffers(lr.device, ('once-stream', slot % RING))
         side.wait_event(ready)                                   # the frame as it stood when it was handed in
         with torch.cuda.stream(side):
             _chain_estimate(lr, None, 'self', pipe, p0, buf)
@@ -1719,6 +1730,8 @@ def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
                 return IterDenoise(lr, net, arch, pipe, p=p0)
             finally:
                 DEVICE_CHAIN = True
+        if out.device.type == 'cuda':
+            out.record_stream(main)                              # (allocated on its lane's stream, handed to the caller's)
         return dict(raw_dns=[out], regs=[reg], params=[par], nle_info=info)
 
     it = iter(frames)
@@ -1728,24 +1741,33 @@ def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
         return
     k_frame = 0
     nxt = estimate(f, main.record_event(), k_frame)
-    pending = None
-    while nxt is not None:
-        lr, buf, est_done = nxt
-        try:                               # take the next frame (and mark the main stream) BEFORE queuing this one's network
-            f_next = _dev(next(it), device)
-            ready = main.record_event()
-        except StopIteration:
-            f_next = None
-        main.wait_event(est_done)
-        out, watch = _chain_denoise(lr, net, arch, p0, buf, k_frame % 3)
-        fin = main.record_event()
-        k_frame += 1
-        nxt = estimate(f_next, ready, k_frame) if f_next is not None else None
-        if pending is not None:
-            yield release(pending)
-        pending = (lr, out, buf, watch, fin)
-    if pending is not None:
-        yield release(pending)
+    pending = []
+    try:
+        while nxt is not None:
+            lr, buf, est_done = nxt
+            try:                               # take the next frame (and mark the main stream) BEFORE queuing this one's network
+                f_next = _dev(next(it), device)
+                ready = main.record_event()
+            except StopIteration:
+                f_next = None
+            lane = lanes[k_frame % NL]
+            lane.wait_event(est_done)          # (and, through the estimate's own wait, the frame as the main stream uploaded it)
+            plan.lane = k_frame % NL
+            with torch.cuda.stream(lane):
+                out, watch = _chain_denoise(lr, net, arch, p0, buf, 4 + k_frame % RING)
+                fin = lane.record_event()
+            plan.lane = 0
+            k_frame += 1
+            nxt = estimate(f_next, ready, k_frame) if f_next is not None else None
+            pending.append((lr, out, buf, watch, fin))
+            if len(pending) > NL:              # (NL passes stay queued behind the one the host waits for)
+                yield release(pending.pop(0))
+        while pending:
+            yield release(pending.pop(0))
+    finally:
+        plan.lane = 0
+        for ln in lanes[1:]:
+            main.wait_stream(ln)               # (the caller's stream continues behind everything queued here)
 
 
 STREAM_ITER = True                  # (module attribute: False = 'iter' frames one at a time, for A/B)

@@ -68,6 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (no sequential / fp32-mfma / parity legs)")
     ap.add_argument("--group", type=int, default=4, help="cfg 3: SIDD images denoised together (one batch-(32 x group) forward per round); 1 = one image at a time")
     ap.add_argument("--lanes", type=int, default=0, help="A/B: HIP streams the network passes of consecutive frames alternate between (pipeline.STREAM_LANES; 0 = its default)")
+    ap.add_argument("--lane-pipelines", type=int, default=-1, help="A/B: 1 = every frame's whole chain on one lane (pipeline.LANE_PIPELINES / _ONCE), 0 = estimates on the side stream")
     ap.add_argument("--sequential", action="store_true", help="time one frame at a time (IterDenoise) instead of the two-stream driver")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiments: no HIP events around the kernels (no roofline objects)")
     ap.add_argument("--precision", default=None, choices=["fp32", "fp32-mfma", "fp16"],
@@ -428,6 +429,8 @@ def main(argv=None):
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     if a.lanes:
         P.STREAM_LANES = a.lanes
+    if a.lane_pipelines >= 0:
+        P.LANE_PIPELINES = P.LANE_PIPELINES_ONCE = bool(a.lane_pipelines)
     group_world = check_world(a, D)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -460,7 +463,7 @@ def main(argv=None):
     pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': a.mode, 'max_iter': 1, 'full_dn': True,
             'collab_sidd256': False}
     n_pass = 2 if a.mode == "iter" else 1
-    stream_driver = a.mode == "once" and not a.sequential and not a.batch
+    stream_driver = not a.sequential and not a.batch and a.cfg != 3
     F = a.frames_per_step
 
     def one(frame, netx=None):
@@ -876,10 +879,14 @@ def main(argv=None):
         elif a.cfg == 3:
             driver = (f"YOND_SIDD.eval's loop: groups of {a.group} images (round 1 = ONE batch-{32 * a.group} forward, round 2 another; estimates, tables, "
                       "block metrics per image), consecutive groups overlapped on two HIP streams (denoise_stream_groups)" if a.group > 1 else "YOND_SIDD.eval's loop body per image: IterDenoise (batch-32 forwards) + block metrics, one image at a time")
+        elif stream_driver and a.mode == "iter":
+            driver = (f"denoise_stream: {P.STREAM_LANES} independent in-order lanes (HIP streams), frame k's whole chain (self NLE, pass 1, collaborative NLE, pass 2) on lane k mod "
+                      f"{P.STREAM_LANES}: one lane's estimators run under the other's network pass" if (P.STREAM_LANES > 1 and P.LANE_PIPELINES) else
+                      "denoise_stream: first and second passes interleaved on the main stream, estimators on a side stream")
         elif stream_driver:
             driver = ("denoise_stream: NLE of frame k+1 on a side HIP stream while the convolutions of frame k run" +
                       (f"; the network passes of consecutive frames alternate between {P.STREAM_LANES} streams (a launch's last, partly filled round of persistent "
-                       "workgroups and the gaps between dependent launches are covered by the other frame's launches)" if (P.STREAM_LANES > 1 and a.mode == "once") else ""))
+                       "workgroups and the gaps between dependent launches are covered by the other frame's launches)" if P.STREAM_LANES > 1 else ""))
         else:
             driver = "IterDenoise, one frame at a time"
         out = {

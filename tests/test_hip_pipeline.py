@@ -379,10 +379,22 @@ def test_denoise_stream_iter_matches_iterdenoise(weights):
     assert P.STREAM_ITER
     got = list(P.denoise_stream(iter(frames), net, arch, pipe))
     one = list(P.denoise_stream(iter(frames[:1]), net, arch, pipe))                  # a single frame drains correctly
+    # round 6: second passes on a lane of their own (default); every frame's whole chain on one of two lanes (LANE_PIPELINES); one stream (STREAM_LANES 1)
+    assert P.STREAM_LANES == 2 and not P.LANE_PIPELINES
+    P.LANE_PIPELINES = True
+    try:
+        got_lp = list(P.denoise_stream(iter(frames), net, arch, pipe))
+    finally:
+        P.LANE_PIPELINES = False
+    P.STREAM_LANES = 1
+    try:
+        got_1 = list(P.denoise_stream(iter(frames), net, arch, pipe))
+    finally:
+        P.STREAM_LANES = 2
     torch.cuda.synchronize()
-    assert len(got) == len(seq) and len(one) == 1
+    assert len(got) == len(got_lp) == len(got_1) == len(seq) and len(one) == 1
     want_rounds = 2 if weights == "denoise" else 1
-    for a_, b_ in zip(got + one, seq + seq[:1]):
+    for a_, b_ in zip(got + one + got_lp + got_1, seq + seq[:1] + seq + seq):
         assert len(a_['raw_dns']) == len(b_['raw_dns']) == want_rounds and len(a_['regs']) == len(b_['regs']) == want_rounds
         assert np.allclose(np.asarray(a_['regs'], np.float64), np.asarray(b_['regs'], np.float64), rtol=1e-9, atol=0)
         assert np.allclose(np.asarray(a_['params'], np.float64), np.asarray(b_['params'], np.float64), rtol=1e-9, atol=0)

@@ -1384,10 +1384,25 @@ def denoise_stream_groups(groups, net, arch, pipe, p=None, device=None, log=None
                 _chain_estimate(st['lr_cat'][g], st['out1'][g], 'collab', pipe2, p0, bufs(k, g, 1), lr_max_dev=st['mx'][g])
             return side.record_event()
 
-    def round_(st, k, r):
+    lane2 = _side_stream(main.device, 'net1') if STREAM_LANES > 1 else main     # second passes on a stream of their own: D2(k-1) beside D1(k)
+    plan = _plan_of(net, main.device)
+
+    def round_(st, k, r, wait):
         G = len(st['items'])
-        outs, watch = _chain_denoise_blocks_group([it[0] for it in st['items']], net, arch, p0, [bufs(k, g, r) for g in range(G)], 4 + 2 * (k % RING) + r)
-        return [torch.cat(list(o), dim=-1).contiguous() for o in outs], watch, main.record_event()
+        lane = lane2 if r else main
+        lane.wait_event(wait)
+        plan.lane = 0 if lane is main else 1
+        try:
+            with torch.cuda.stream(lane):
+                outs, watch = _chain_denoise_blocks_group([it[0] for it in st['items']], net, arch, p0, [bufs(k, g, r) for g in range(G)], 4 + 2 * (k % RING) + r)
+                cat = [torch.cat(list(o), dim=-1).contiguous() for o in outs]
+                fin = lane.record_event()
+        finally:
+            plan.lane = 0
+        if lane is not main:
+            for c in cat:
+                c.record_stream(main)
+        return cat, watch, fin
 
     def release(st, k):
         items = st['items']
@@ -1451,8 +1466,7 @@ def denoise_stream_groups(groups, net, arch, pipe, p=None, device=None, log=None
         nxt = take()                                  # (and mark the main stream) BEFORE queuing this group's network
         ready = main.record_event()
         if st['chain']:
-            main.wait_event(st['e1'])
-            st['out1'], st['g1'], st['fin1'] = round_(st, k, 0)                # D1(k)
+            st['out1'], st['g1'], st['fin1'] = round_(st, k, 0, st['e1'])      # D1(k)
         if nxt is not None:
             live[k + 1] = nxt
             if nxt['chain']:
@@ -1461,17 +1475,17 @@ def denoise_stream_groups(groups, net, arch, pipe, p=None, device=None, log=None
             st['e2'] = est2(st, k)                                             # E2(k): behind D1(k), under D2(k-1)
         if k - 1 in live and live[k - 1]['chain']:
             prev = live[k - 1]
-            main.wait_event(prev['e2'])
-            prev['out2'], prev['g2'], prev['fin2'] = round_(prev, k - 1, 1)    # D2(k-1)
+            prev['out2'], prev['g2'], prev['fin2'] = round_(prev, k - 1, 1, prev['e2'])    # D2(k-1)
         if k - 2 in live:
             yield release(live.pop(k - 2), k - 2)
         k += 1
     if k - 1 in live and live[k - 1]['chain']:
         prev = live[k - 1]
-        main.wait_event(prev['e2'])
-        prev['out2'], prev['g2'], prev['fin2'] = round_(prev, k - 1, 1)
+        prev['out2'], prev['g2'], prev['fin2'] = round_(prev, k - 1, 1, prev['e2'])
     for j in sorted(live):
         yield release(live.pop(j), j)
+    if lane2 is not main:
+        main.wait_stream(lane2)
 
 
 STREAM_GROUPS = True                # (module attribute: False = the evaluation drivers take one group at a time, for A/B)
@@ -1505,7 +1519,10 @@ def denoise_stream_batches(frames, B, net, arch, pipe, p=None, device=None):
                 yield dict(raw_dns=[rd[b] for rd in r['raw_dns']], regs=[rg[b] for rg in r['regs']], params=[pr[b] for pr in r['params']])
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
-    RING = 3
+    NL = max(1, int(STREAM_LANES))                     # batched passes of consecutive batches alternate between NL streams (see _denoise_stream_chain)
+    lanes = [main] + [_side_stream(main.device, f'net{j}') for j in range(1, NL)]
+    plan = _plan_of(net, main.device)
+    RING = NL + 2
 
     def bufs(k, b):
         return _chain_buffers(main.device, ('batch-stream', k % RING, b))
@@ -1540,23 +1557,34 @@ def denoise_stream_batches(frames, B, net, arch, pipe, p=None, device=None):
         return
     k = 0
     est = estimate(batch, 0, main.record_event())
-    pending = None
+    pending = []
     while batch:
         nxt = take()                                   # (and mark the main stream) BEFORE queuing this batch's network
         ready = main.record_event()
-        main.wait_event(est)
-        outs, watch = _chain_denoise_frames(batch, net, arch, p0, [bufs(k, b) for b in range(len(batch))], 4 + (k % RING))
-        fin = main.record_event()
+        lane = lanes[k % NL]
+        lane.wait_event(est)
+        plan.lane = k % NL
+        try:
+            with torch.cuda.stream(lane):
+                outs, watch = _chain_denoise_frames(batch, net, arch, p0, [bufs(k, b) for b in range(len(batch))], 4 + (k % RING))
+                fin = lane.record_event()
+        finally:
+            plan.lane = 0
+        if lane is not main:
+            for o in outs:
+                o.record_stream(main)
         cur = (batch, outs, watch, fin)
         if nxt:
             est = estimate(nxt, k + 1, ready)
-        if pending is not None:
-            yield from release(*pending)
-        pending = (cur, k)
+        pending.append((cur, k))
+        if len(pending) > NL:
+            yield from release(*pending.pop(0))
         batch = nxt
         k += 1
-    if pending is not None:
-        yield from release(*pending)
+    while pending:
+        yield from release(*pending.pop(0))
+    for ln in lanes[1:]:
+        main.wait_stream(ln)
 
 
 def IterDenoiseBatch(frames, net, arch, pipe, p=None, device=None):
@@ -1704,6 +1732,9 @@ def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
     FiLM vectors, engine `lane`): the persistent workgroups of frame k+1's launch take the CUs that the last, partly filled round of frame k's
     launch leaves idle (5,922 level-0 tiles = 23.1 rounds of 256) and the gap between two dependent launches of one stream is covered by the
     other's.  Same kernels, same arguments, same results; a frame is yielded STREAM_LANES frames late."""
+    if STREAM_LANES > 1 and LANE_PIPELINES_ONCE:
+        yield from _denoise_lanes(frames, net, arch, pipe, p0, device, 1)
+        return
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
     NL = max(1, int(STREAM_LANES))
@@ -1770,18 +1801,107 @@ def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
             main.wait_stream(ln)               # (the caller's stream continues behind everything queued here)
 
 
+LANE_PIPELINES_ONCE = False         # A/B: 'once' as independent lane pipelines too (no side stream)
+LANE_PIPELINES = False              # 'iter' with STREAM_LANES > 1: every frame's whole chain on ONE lane (False, the default: first passes on the main stream, second passes on a lane, estimates on the side stream -- measured equal or 1 % faster)
+
+
+def _denoise_lanes(frames, net, arch, pipe, p0, device, rounds):
+    """STREAM_LANES independent in-order pipelines: frame k's whole chain -- E1 (self estimate + parameter chain) -> D1 (K1, network, K4) and, for
+    rounds == 2 (pipe['iter'] == 'iter', max_iter 1; YOND_SIDD.py:419-472), E2 (collaborative estimate from (noisy, round-1 output) + guards + chain)
+    -> D2 -- is queued on lane k mod STREAM_LANES, with no event between the lanes: one lane's estimators (latency-bound, a few workgroups) run under the
+    other's network pass, and the other's launches cover a launch's last, partly filled round of persistent workgroups and the gaps between dependent
+    launches.  Each lane has its own split-plane tensors and FiLM vectors (engine `lane`), each frame its own parameter blocks (a ring).  Round 2 is
+    queued speculatively as in _iter_denoise_chain; a frame is yielded STREAM_LANES frames late.  Same kernels and arguments as IterDenoise."""
+    main = torch.cuda.current_stream()
+    NL = max(1, int(STREAM_LANES))
+    lanes = [main] + [_side_stream(main.device, f'net{j}') for j in range(1, NL)]
+    RING = NL + 2
+    plan = _plan_of(net, main.device)
+
+    def bufs(k, r):
+        return _chain_buffers(main.device, ('lanes', k % RING, r))
+
+    def release(st, k):
+        st['fin'].synchronize()
+        reg1, par1, fl1, info1 = _chain_result(bufs(k, 0))
+        bad = bool(fl1 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE)) or (st['g1'] is not None and st['g1'].tripped())
+        aborted = False
+        if rounds == 2:
+            reg2, par2, fl2, info2 = _chain_result(bufs(k, 1))
+            bad = bad or bool(fl2 & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY))
+            aborted = bool(fl2 & PRM_ROUND_ABORTED)                           # :445-447: beta1 < 0 ends the image after round 1
+            if not bad and not aborted:
+                bad = bool(fl2 & PRM_BAD_ESTIMATE) or (st['g2'] is not None and st['g2'].tripped())
+        if bad:                                                               # a branch the chain leaves to the host-side path
+            global DEVICE_CHAIN
+            DEVICE_CHAIN = False
+            try:
+                return IterDenoise(st['lr'], net, arch, pipe, p=p0)
+            finally:
+                DEVICE_CHAIN = True
+        raw_dns, regs, params = [st['out1']], [reg1], [par1]
+        if rounds == 2 and not aborted:
+            raw_dns.append(st['out2'])
+            regs.append(reg2)
+            params.append(par2)
+        return dict(raw_dns=raw_dns, regs=regs, params=params, nle_info=info1)
+
+    pending = []
+    k = 0
+    try:
+        for f in frames:
+            lr = _dev(f, device)                                              # (a host array is uploaded on the main stream)
+            lane = lanes[k % NL]
+            if lane is not main:
+                lane.wait_event(main.record_event())                          # the frame as it stood when it was handed in
+            st = dict(lr=lr, g2=None)
+            plan.lane = k % NL
+            try:
+                with torch.cuda.stream(lane):
+                    b1 = bufs(k, 0)
+                    _chain_estimate(lr, None, 'self', pipe, p0, b1)                                              # E1
+                    st['out1'], st['g1'] = _chain_denoise(lr, net, arch, p0, b1, 4 + 2 * (k % RING))           # D1
+                    if rounds == 2:
+                        mx = torch.empty(1, dtype=torch.float32, device=main.device)
+                        mx.copy_(b1.prm[PRM['frame_max']:PRM['frame_max'] + 1])                                  # float64 holding the float32 maximum -> float32
+                        _chain_estimate(lr, st['out1'], 'collab', pipe, p0, bufs(k, 1), lr_max_dev=mx)           # E2
+                        st['mx'] = mx
+                        st['out2'], st['g2'] = _chain_denoise(lr, net, arch, p0, bufs(k, 1), 4 + 2 * (k % RING) + 1)    # D2
+                    st['fin'] = lane.record_event()
+            finally:
+                plan.lane = 0
+            if lane is not main:
+                for key in ('out1', 'out2'):
+                    if key in st:
+                        st[key].record_stream(main)                           # (allocated on the lane's stream, handed to the caller's)
+            pending.append((st, k))
+            k += 1
+            if len(pending) > NL:
+                yield release(*pending.pop(0))
+        while pending:
+            yield release(*pending.pop(0))
+    finally:
+        plan.lane = 0
+        for ln in lanes[1:]:
+            main.wait_stream(ln)
+
+
 STREAM_ITER = True                  # (module attribute: False = 'iter' frames one at a time, for A/B)
 
 
 def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
     """denoise_stream for pipe['iter'] == 'iter', max_iter 1 (YOND_SIDD.py:419-472) on the device chain.  Per frame k: E1 (self estimate +
     parameter chain) -> D1 (K1, network, K4) -> E2 (collaborative estimate from (noisy, round-1 output) + guards + chain, :431-454) -> D2.
-    The main stream carries the network passes in the order D1(0), D1(1), D2(0), D1(2), D2(1), ...; the side stream runs E1(k+1) under D1(k)
-    and E2(k) under D2(k-1) -- E2(k) needs D1(k)'s output, so frame k's second pass is queued behind frame k+1's first, with frame k's
-    collaborative estimate in between on the other stream.  Round 2 is queued speculatively (whether :445-447 ends the image after round 1 is
+    The network passes are queued in the order D1(0), D1(1), D2(0), D1(2), D2(1), ... -- first passes on the main stream, second passes on a
+    lane of their own (STREAM_LANES > 1: D2(k-1) runs beside D1(k), each covering the other's launch tails and gaps; engine `lane` 1 = its own
+    split-plane tensors); the side stream runs E1(k+1) under D1(k) and E2(k) under D2(k-1) -- E2(k) needs D1(k)'s output, so frame k's second
+    pass is queued behind frame k+1's first, with frame k's collaborative estimate in between on the other stream.  Round 2 is queued speculatively (whether :445-447 ends the image after round 1 is
     read from its parameter block when the frame is yielded, as in _iter_denoise_chain); the host reads a frame's blocks two frames late.
     Same kernels and arguments as IterDenoise, frame by frame: the same results (tests/test_hip_pipeline.py).  Frames handed in must stay
     unmodified until their own result has been yielded (see denoise_stream)."""
+    if STREAM_LANES > 1 and LANE_PIPELINES:
+        yield from _denoise_lanes(frames, net, arch, pipe, p0, device, 2)
+        return
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
     RING = 4                                                                  # frames whose buffers / guard words may be live at once
@@ -1829,10 +1949,20 @@ def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
             params.append(par2)
         return dict(raw_dns=raw_dns, regs=regs, params=params, nle_info=info1)
 
+    lane2 = _side_stream(main.device, 'net1') if STREAM_LANES > 1 else main     # second passes on a stream of their own: D2(k-1) beside D1(k)
+    plan = _plan_of(net, main.device)
+
     def round2(st, k):
-        main.wait_event(st['e2'])
-        st['out2'], st['g2'] = _chain_denoise(st['lr'], net, arch, p0, bufs(k, 1), 4 + 2 * (k % RING) + 1)
-        st['fin2'] = main.record_event()
+        lane2.wait_event(st['e2'])
+        plan.lane = 0 if lane2 is main else 1
+        try:
+            with torch.cuda.stream(lane2):
+                st['out2'], st['g2'] = _chain_denoise(st['lr'], net, arch, p0, bufs(k, 1), 4 + 2 * (k % RING) + 1)
+                st['fin2'] = lane2.record_event()
+        finally:
+            plan.lane = 0
+        if lane2 is not main:
+            st['out2'].record_stream(main)                                    # (allocated on the lane's stream, handed to the caller's)
 
     it = iter(frames)
     try:
@@ -1866,6 +1996,8 @@ def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
         round2(live[k - 1], k - 1)
     for j in sorted(live):
         yield release(live.pop(j), j)
+    if lane2 is not main:
+        main.wait_stream(lane2)
 
 
 _SIDE_STREAMS = {}

@@ -540,6 +540,28 @@ def main(argv=None):
                                "timed region (YondConvDesc.clk); hwmon_mhz / socket_power_w: sysfs hwmon of the busiest card, 50 ms "
                                "samples during the timed region")
     prof, plan.prof = plan.prof or [], None
+    # With the network passes of two frames on two lanes (pipeline.STREAM_LANES) the persistent workgroups of one lane's launch take the CUs as the other
+    # lane's launch retires them: a launch's wall duration between its events then includes its wait for the other lane's workgroups and is no longer its
+    # cost.  The roofline object therefore comes from the SAME job run on one lane right behind the timed region (>= 2 steps, the same event pairs); the
+    # timed region's own wall durations stay beside it (`timed_region_wall`).
+    prof_wall = None
+    if prof and P.STREAM_LANES > 1 and not a.sequential:
+        prof_wall = prof
+        lanes_was, P.STREAM_LANES = P.STREAM_LANES, 1
+        try:
+            run(F)                                          # (lane 0 alone: its clocks and caches as they will be measured)
+            torch.cuda.synchronize()
+            plan.prof = []
+            t_r = time.perf_counter()
+            n_roof = 0
+            while n_roof < 2 or time.perf_counter() - t_r < 0.5:
+                run(F)
+                n_roof += 1
+            torch.cuda.synchronize()
+            one_lane_ms_per_frame = (time.perf_counter() - t_r) / (n_roof * F) * 1e3
+        finally:
+            P.STREAM_LANES = lanes_was
+        prof, plan.prof = plan.prof or [], None
     plan.prof_only = None
     plan.prof_every = 1
     n_timed = a.steps * F
@@ -644,6 +666,15 @@ def main(argv=None):
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK, 4), "traffic": pmc_traffic(dom), "launches": n,
                 "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
+        if prof_wall is not None:
+            wall = [e0.elapsed_time(e1) for tag, _, e0, e1 in prof_wall if tag == dom]
+            roof["measured"] = (f"HIP events on the launch stream around the 3x3 stride-1 launches of every 4th forward while the timed region's job ({F} frames per step, {n_roof} steps) ran on ONE "
+                                "lane right behind the timed region; rocprofv3 counterpart: profiles/r06_bench_once_one_lane_kernel_stats.csv (bench.py --lanes 1)")
+            roof["one_lane_ms_per_frame"] = round(one_lane_ms_per_frame, 3)
+            roof["timed_region_wall"] = {"launches": len(wall), "avg_launch_ms": round(sum(wall) / max(len(wall), 1), 4),
+                                         "note": f"the timed region runs the network passes of consecutive frames on {P.STREAM_LANES} lanes: the persistent workgroups of one lane's launch take "
+                                                 "the CUs as the other lane's launch retires them, so the time between a launch's events there includes its wait for the other lane's "
+                                                 "workgroups (rocprofv3 of the default command shows the same durations: profiles/r06_bench_once_kernel_stats.csv)"}
         if dom.startswith("conv_wino_kernel"):
             # Winograd F(2x2,3x3) issues 16 multiplications per patch where the direct algorithm has 36: `achieved`
             # counts the ALGORITHMIC flops of the convolution; the flops the MFMA unit really executes are 16/36 of that

@@ -51,6 +51,7 @@ def _plan(dev):
     plan.status = torch.zeros(4, dtype=torch.int32, device=plan.dev)
     plan.status_slot = 0
     plan.gen = 0                     # bumped whenever a buffer the step's launches point at is replaced: captured steps are then stale
+    plan.wgrad_stream = torch.cuda.Stream(device=plan.dev) if plan.dev.type == 'cuda' else None      # the weight gradients' lane (_lane)
     return plan
 
 
@@ -191,6 +192,41 @@ def _wgrad(plan, x, dy, mode, stride, taps, with_bias=False, oihw=False):
     return dw
 
 
+WGRAD_LANE = True                    # a layer's weight (and bias) gradient on a second HIP stream beside its data gradient: fork / join inside every backward,
+                                     # so the captured step has two branches per layer -- one kernel's launch gap and partly filled last round under the other's work
+
+
+class _lane:
+    """`with _lane(plan):` -- the launches inside go to the plan's second stream, ordered behind everything queued on the current one so far (fork);
+    `_join(plan)` orders the current stream behind them.  Every backward that forks joins before it returns: autograd sees finished tensors, the
+    allocator's per-stream pools stay safe (a block of the lane's pool is only handed out again on the lane, behind the next fork), and a stream
+    capture ends with the lane joined."""
+
+    def __init__(self, plan):
+        self.on = WGRAD_LANE and plan.dev.type == 'cuda' and getattr(plan, 'wgrad_stream', None) is not None
+        self.plan = plan
+
+    def __enter__(self):
+        if self.on:
+            side = self.plan.wgrad_stream
+            side.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+            self.plan.lane_open = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def _join(plan):
+    if getattr(plan, 'lane_open', False):
+        torch.cuda.current_stream().wait_stream(plan.wgrad_stream)
+        plan.lane_open = False
+
+
 def _colsum(plan, dy):
     c = dy.shape[-1]
     db = torch.empty(c, dtype=torch.float32, device=dy.device)
@@ -220,13 +256,14 @@ class _Conv3x3(torch.autograd.Function):
         dy = dy.contiguous()
         N, H, W, cin_p = x.shape
         cout, cin = w.shape[0], w.shape[1]
-        if WGRAD_BIAS:
-            dw, db = _wgrad(plan, x, dy, 0, stride, 9, with_bias=True, oihw=True)
-            dw = dw if (dw.shape[0] == cout and dw.shape[1] == cin) else dw[:cout, :cin].contiguous()
-        else:
-            dw, db = _wgrad(plan, x, dy, 0, stride, 9), _colsum(plan, dy)
-            dw = dw[:, :cout, :cin].permute(1, 2, 0).reshape(cout, cin, 3, 3)
-        db = db[:cout]
+        with _lane(plan):
+            if WGRAD_BIAS:
+                dw, db = _wgrad(plan, x, dy, 0, stride, 9, with_bias=True, oihw=True)
+                dw = dw if (dw.shape[0] == cout and dw.shape[1] == cin) else dw[:cout, :cin].contiguous()
+            else:
+                dw, db = _wgrad(plan, x, dy, 0, stride, 9), _colsum(plan, dy)
+                dw = dw[:, :cout, :cin].permute(1, 2, 0).reshape(cout, cin, 3, 3)
+            db = db[:cout]
         dx = None
         if ctx.need_dx:
             g = dy
@@ -237,6 +274,7 @@ class _Conv3x3(torch.autograd.Function):
             dx = _conv_fwd(plan, w, None, 3, 1, [cout], [g], N, H, W, role='dgrad',
                            xf=lambda t: t.flip(2, 3).transpose(0, 1).contiguous())          # [cin][cout][2-ky][2-kx]
             dx = _pad_c(dx[..., :cin], cin_p) if dx.shape[-1] != cin_p else dx
+        _join(plan)
         return dx, dw, db, None, None, None, (dy if ctx.has_res else None)
 
 
@@ -263,13 +301,17 @@ class _Conv3x3Cat(torch.autograd.Function):
         N, H, W, _ = dy.shape
         cout, c1 = w.shape[0], w.shape[1] - c0
         dws, dxs = [], []
+        with _lane(plan):
+            for x, lo, c in ((x0, 0, c0), (x1, c0, c1)):
+                dws.append(_wgrad(plan, x, dy, 0, 1, 9)[:, :cout, :c].permute(1, 2, 0).reshape(cout, c, 3, 3))
+            db = _colsum(plan, dy)[:cout]
+            dw = torch.cat(dws, 1)
         for x, lo, c in ((x0, 0, c0), (x1, c0, c1)):
-            dws.append(_wgrad(plan, x, dy, 0, 1, 9)[:, :cout, :c].permute(1, 2, 0).reshape(cout, c, 3, 3))
             dx = _conv_fwd(plan, w, None, 3, 1, [cout], [dy], N, H, W, role=('dgrad', lo),
                            xf=lambda t, lo=lo, c=c: t[:, lo:lo + c].flip(2, 3).transpose(0, 1).contiguous())    # [c][cout][2-ky][2-kx]
             dxs.append(dx if dx.shape[-1] == x.shape[-1] else _pad_c(dx[..., :c], x.shape[-1]))
-        db = _colsum(plan, dy)[:cout]
-        return dxs[0], dxs[1], torch.cat(dws, 1), db, None, None
+        _join(plan)
+        return dxs[0], dxs[1], dw, db, None, None
 
 
 def _gemm_split(plan, srcs, P, n_p, n_real, sn_lo, sn_hi, nblk, bias, y, ldy, shuffle=0, H=0, W=0):
@@ -339,29 +381,35 @@ class _Conv1x1(torch.autograd.Function):
             dws, dxs, off = [], [], 0
             srcs = [x.view(shape[0], shape[1], shape[2], x.shape[-1]) for x in srcs]    # (the forward may have run on the flat view)
             xf, dyf = [_flat32(x) for x in srcs], _flat32(dy)                       # (the weight gradient's rows: 32 pixels wide)
+            with _lane(plan):
+                for x, xw, c in zip(srcs, xf, splits):
+                    dws.append(_wgrad(plan, xw, dyf, 2, 1, 1)[0, :cout, :c])
+                dw = torch.cat(dws, 1)[:, :, None, None]
+                db = _colsum(plan, dy)[:cout]
             for x, xw, c in zip(srcs, xf, splits):
-                dws.append(_wgrad(plan, xw, dyf, 2, 1, 1)[0, :cout, :c])
                 dx = torch.empty_like(x)                                            # dx[p][ci] = sum_co dy[p][co] w[co][off + ci]
                 _gemm_split(plan, [(dy, w.data_ptr() + 4 * off, w.shape[1], 0, n_p, n_p, _BIG, cout)], P, x.shape[-1], c, 1, 0, _BIG, None,
                             dx, x.shape[-1])
                 dxs.append(dx)
                 off += c
-            dw = torch.cat(dws, 1)[:, :, None, None]
-            db = _colsum(plan, dy)[:cout]
+            _join(plan)
             return dxs[0], (dxs[1] if ctx.two else None), dw, db, None
         dy = _flat32(dy.contiguous()) if srcs[0].shape[:3] != shape[:3] else dy.contiguous()      # (the geometry the forward ran in)
         N, H, W, _ = dy.shape
         cout = w.shape[0]
         dws, dxs, off = [], [], 0
+        with _lane(plan):
+            for x, s in zip(srcs, splits):
+                dws.append(_wgrad(plan, x, dy, 2, 1, 1)[0, :cout, :s])
+            dw = torch.cat(dws, 1)[:, :, None, None]
+            db = _colsum(plan, dy)[:cout]
         for x, s in zip(srcs, splits):
-            dws.append(_wgrad(plan, x, dy, 2, 1, 1)[0, :cout, :s])
             dx = _conv_fwd(plan, w, None, 1, 1, [cout], [dy], N, H, W, role=('dgrad', off),
                            xf=lambda t, off=off, s=s: t[:, off:off + s, 0, 0].t().contiguous()[:, :, None, None])   # [s][cout][1][1]
             dx = dx if dx.shape[-1] == x.shape[-1] else _pad_c(dx[..., :s], x.shape[-1])
             dxs.append(dx.view(shape[0], shape[1], shape[2], dx.shape[-1]))
             off += s
-        dw = torch.cat(dws, 1)[:, :, None, None]
-        db = _colsum(plan, dy)[:cout]
+        _join(plan)
         return dxs[0], (dxs[1] if ctx.two else None), dw, db, None
 
 
@@ -556,8 +604,9 @@ class _ConvT2x2(torch.autograd.Function):
         N, H, W, cin_p = x.shape
         cin, cout = w.shape[0], w.shape[1]
         cop = dy.shape[-1]
-        dw = _wgrad(plan, x, dy, 1, 2, 4)[:, :cout, :cin].permute(2, 1, 0).reshape(cin, cout, 2, 2)     # [tap][co][ci] -> [ci][co][dy][dx]
-        db = _colsum(plan, dy)[:cout]
+        with _lane(plan):
+            dw = _wgrad(plan, x, dy, 1, 2, 4)[:, :cout, :cin].permute(2, 1, 0).reshape(cin, cout, 2, 2)     # [tap][co][ci] -> [ci][co][dy][dx]
+            db = _colsum(plan, dy)[:cout]
         # adjoint: dx[y][x][ci] = sum_{dy,dx,co} g[2y+dy][2x+dx][co] W[ci][co][dy][dx] = a 1x1 GEMM on the pixel-unshuffled gradient
         gu = dy.reshape(N, H, 2, W, 2, cop).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, 4 * cop).contiguous()
 
@@ -568,10 +617,12 @@ class _ConvT2x2(torch.autograd.Function):
         if _use_gemm(plan, 4 * cop):                         # dx[p][ci] = sum_{j, co} gu[p][j cop + co] w[ci][co][j]
             dx = torch.empty((N, H, W, cin_p), dtype=torch.float32, device=dy.device)
             _gemm_split(plan, [(gu, w.data_ptr(), 4, 1, 4 * cop, 4 * cop, cop, cout)], N * H * W, cin_p, cin, 4 * cout, 0, _BIG, None, dx, cin_p)
+            _join(plan)
             return dx, dw, db, None
         guf = _flat32(gu)                                    # (a 1x1 GEMM: narrow images as 32-pixel rows)
         dx = _conv_fwd(plan, w, None, 1, 1, [4 * cop], [guf], guf.shape[0], guf.shape[1], guf.shape[2], role='dgrad', xf=xf)
         dx = dx if dx.shape[-1] == cin_p else _pad_c(dx[..., :cin], cin_p)
+        _join(plan)
         return dx.view(N, H, W, dx.shape[-1]), dw, db, None
 
 

@@ -34,6 +34,7 @@ SPLIT_GROUP_H_TALL4(SPLIT_EXTERN)
 #ifdef YOND_EXPERIMENTS         // (round 6, measured no-gos: profiles/r06_experiments/README.md section 1b)
 SPLIT_GROUP_S2_W4(SPLIT_EXTERN)
 SPLIT_GROUP_S2_ROLES(SPLIT_EXTERN)
+SPLIT_GROUP_WRES_W4(SPLIT_EXTERN)
 #endif
 
 // the channel-tile width the split kernel uses for a layer (0: not supported)
@@ -319,6 +320,14 @@ int yond_conv_split_dispatch(const YondConvDesc& d, hipStream_t st) {
     }
     // 32 -> 32 channels: two weight slices in all -- on two buffers they stay resident in LDS (conv_split_kernel.h, wres)
     const bool wres = parts == 2 && tn == 32 && d.Cout == 32 && d.C0 + d.C1 == 32 && yond_exp_long("YOND_SPLIT_WRES", 1) != 0;
+#ifdef YOND_EXPERIMENTS
+    // round 6, measured no-go: level 0 as half-size workgroups (four waves, 8-row tiles, 80 KB of LDS), two per CU -- meant to put one workgroup's epilogue and first
+    // loads under the other's MFMAs; same-box A/B: conv1 +2-7 %, conv2 +-0, the last convolution -4 %, the frame 2 % slower (profiles/r06_experiments/README.md, section 6)
+    const bool w4 = wres && (long long)((d.Wo + 31) / 32) * ((d.Ho + 7) / 8) * d.N >= 2048 && yond_exp_long("YOND_SPLIT_L0_W4", 0) != 0;
+    if (w4 && isp && osp && !d.out4_dst) return launch_split<1, 8, 32, 2, 2, 2, false, false, false, true, true, false, false, 0, 4>(d, st);
+    if (w4 && isp && !osp && d.out4_dst) return launch_split<1, 8, 32, 2, 2, 2, false, true, false, true, false, false, false, 0, 4>(d, st);
+    if (w4 && !isp && osp && d.pre_act && !d.out4_dst) return launch_split<1, 8, 32, 2, 2, 2, true, false, false, false, true, false, false, 0, 4>(d, st);
+#endif
     if (wres && isp && osp && !d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, false, false, false, true, true>(d, st);
     if (wres && isp && !osp && d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, false, true, false, true, false>(d, st);
     if (wres && !isp && osp && d.pre_act && !d.out4_dst) return launch_split<1, 16, 32, 2, 2, 2, true, false, false, false, true>(d, st);

@@ -100,8 +100,10 @@ struct SplitCfg {
     static constexpr bool LOADS_FIRST = WAHEAD == 2;                // order of a step's memory operations (see the step pipeline)
     static constexpr int KEEP = WAHEAD == 2 ? NIN + NWT_MIN : NIN;  // memory operations that may stay in flight across a barrier
     static constexpr int W4_OFF = 2 * IN_FLOATS + NWB * W_FLOATS;   // floats: 4 x 32 weights of the fused output projection
-    static constexpr int FILM_OFF = W4_OFF + (TN == 32 ? 128 : 0);  // floats: per wave and 32-channel block {scale[32], shift[32]} (split-plane epilogue)
-    static constexpr int FILM_FLOATS = NWC * NW * 64 * (FOLD && STRIDE == 1 ? FOLD : 1);     // (FOLD: every sub-tile may belong to another image; stride 2 never stores split planes)
+    // (the projection's weights -- O4 -- and the FiLM vectors -- OSP -- share one region: no kernel has both)
+    static constexpr int FILM_OFF = W4_OFF;                         // floats: per wave and 32-channel block {scale[32], shift[32]} (split-plane epilogue)
+    static constexpr int FILM_FLOATS_ = NWC * NW * 64 * (FOLD && STRIDE == 1 ? FOLD : 1);     // (FOLD: every sub-tile may belong to another image; stride 2 never stores split planes)
+    static constexpr int FILM_FLOATS = (TN == 32 && FILM_FLOATS_ < 128) ? 128 : FILM_FLOATS_;
     // h-only operands (PARTS 1) leave the transposed epilogue no consumed buffer large enough for its scratch (8 waves x 32 pixels x 36 floats):
     // their kernels use little LDS, so the scratch gets a region of its own behind everything else
     static constexpr int EP_FLOATS_C = NWC * 32 * 36;
@@ -148,7 +150,7 @@ __device__ __forceinline__ void split_barrier_keep_loads() { asm volatile("s_wai
 // D2 (stride 2): the layer also stores SiLU(value) in split planes (YondConvDesc.dst2), from the same epilogue loop -- an
 // instantiation of its own, so that the kernels without it keep their code and register allocation.
 template <int STRIDE, int TH, int TN, int MW, int PARTS, int NWB, bool PRE, bool O4 = false, bool K1 = false, int ISPM = 0, bool OSP = false, bool S2 = false, bool D2 = false, int FOLD = 0, int NWAVE = 8, int ROLES = 0>
-__global__ __launch_bounds__(64 * NWAVE) void conv_split_kernel(const YondConvDesc d) {
+__global__ __launch_bounds__(64 * NWAVE, (NWAVE == 4 && STRIDE == 1) ? 2 : 1) void conv_split_kernel(const YondConvDesc d) {    // (four waves at stride 1: two workgroups per CU, 256 registers per wave)
     using C = SplitCfg<STRIDE, TH, TN, MW, PARTS, NWB, K1, FOLD, NWAVE, ROLES>;
     static_assert(!ROLES || (ISPM == 2 && !OSP && !O4 && !PRE), "role split: the register-staged split-plane input (stride 2)");
     static_assert(!FOLD || (!O4 && !S2 && ((!K1 && STRIDE == 1 && ISPM != 2 && OSP) || (STRIDE == 2 && (ISPM == 2 || (ISPM == 0 && !PRE && !D2))) || (K1 && ISPM == 2) || (!K1 && STRIDE == 1 && ISPM == 0 && !OSP && !PRE))),
@@ -1311,7 +1313,9 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
     const long long total = FOLD ? (long long)(d.Cout / TN) * (((long long)d.N * ((d.Ho + TH - 1) / TH) * ((d.Wo + FSWL - 1) / FSWL) + FOLD - 1) / (FOLD ? FOLD : 1))
                                  : (long long)(d.Cout / TN) * ((d.Wo + 31) / 32) * ((d.Ho + TH - 1) / TH) * d.N;
     if (total > 0x7fffffffLL) return YOND_EUNSUPPORTED;
-    const int gmax = (int)yond_exp_long("YOND_SPLIT_GRID", 256);  // (experiment builds: fewer workgroups than CUs, leaving CUs to a side stream's kernels)
+    // (four-wave workgroups whose LDS fits twice into a CU: two persistent workgroups per CU -- one's epilogue and prologue under the other's MFMAs)
+    constexpr int PER_CU = (NWAVE == 4 && C::SMEM_BYTES <= 80 * 1024) ? 2 : 1;
+    const int gmax = (int)yond_exp_long("YOND_SPLIT_GRID", 256) * PER_CU;  // (experiment builds: fewer workgroups than CUs, leaving CUs to a side stream's kernels)
     const int grid = total < gmax ? (int)total : gmax;            // one persistent workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::SMEM_BYTES, st, d);
     YOND_LAUNCH_CHECK();
@@ -1426,5 +1430,12 @@ int launch_split(const YondConvDesc& d, hipStream_t st) {
 // ... and with eight waves in two roles: four multiply (two output rows each), four move the data
 #define SPLIT_GROUP_S2_ROLES(X)                                                                         \
     X(2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, false, 0, 8, 1) X(2, 4, 64, 2, 2, 2, false, false, false, 2, false, false, true, 0, 8, 1)
+// round 6, level 0 (32 -> 32 channels, resident weights): HALF-SIZE workgroups -- four waves (one per SIMD) on 8 x 32-pixel tiles, 80 KB of LDS, TWO per CU (512
+// persistent workgroups): a level-0 tile has two 16-channel steps and a full epilogue, and with one workgroup per CU nothing runs under its epilogue, its first
+// loads and its barriers (stamps: ~19 k cycles per tile for ~7 k of matrix pipe); two independent workgroups were meant to drift apart and fill each other's gaps.
+// Measured (same box): conv1 2-7 % SLOWER, conv2 equal, the last convolution 4 % faster, the frame 2 % slower -- experiment builds only
+#define SPLIT_GROUP_WRES_W4(X)                                                                          \
+    X(1, 8, 32, 2, 2, 2, true, false, false, false, true, false, false, 0, 4) X(1, 8, 32, 2, 2, 2, false, false, false, true, true, false, false, 0, 4) \
+    X(1, 8, 32, 2, 2, 2, false, true, false, true, false, false, false, 0, 4)
 #define SPLIT_INSTANTIATE(...) template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);
 #define SPLIT_EXTERN(...) extern template int launch_split<__VA_ARGS__>(const YondConvDesc&, hipStream_t);

@@ -408,6 +408,11 @@ def _small_full_runfile(tmp_path, src, root_dir, nf=8, **dst_over):
     return str(f)
 
 
+def P_stream_applies(drv):
+    from yond_public_amd import pipeline as P
+    return P.stream_applies(drv.pipe, drv.pipe, drv.biaslut)
+
+
 def test_yond_any_full_frame_driver(tmp_path, monkeypatch):
     """N3: the `YOND_any`-style driver (README.md:38-47; runfiles/YOND/ANY_simple+full_pre_grumix.yml) on a directory of raw-DN
     `.npy` Bayer frames: black / white level and the ratio list from the runfile, whole-frame `iter` denoising, whole-frame
@@ -428,9 +433,22 @@ def test_yond_any_full_frame_driver(tmp_path, monkeypatch):
     rf = _small_full_runfile(tmp_path, "ANY_simple+full_pre_grumix.yml", frames, H=H, W=W, ratio_list=[2])
     drv = Y.YOND_Full(['-f', rf, '-m', 'eval'])
     assert type(drv.dst_eval).__name__ == 'Any_Dataset' and len(drv.dst_eval) == 2
+    assert Y.STREAM_EVAL and P_stream_applies(drv)                # (round 6: eval() feeds pipeline.denoise_stream -- per-frame parameter dicts, two lanes)
     res = drv.eval(-1)
     red = res['x2']
     assert red['count'] == 2
+    streamed = {k: dict(v) for k, v in drv.metrics.items()}
+    Y.STREAM_EVAL = False                                         # ... and one frame at a time: the same numbers
+    try:
+        res1 = drv.eval(-1)
+    finally:
+        Y.STREAM_EVAL = True
+    assert abs(res1['x2']['psnr_last'] - red['psnr_last']) < 2e-3
+    for k, m1 in drv.metrics.items():
+        assert len(m1['reg']) == len(streamed[k]['reg'])
+        np.testing.assert_allclose(np.asarray(m1['reg'][0], np.float64), np.asarray(streamed[k]['reg'][0], np.float64), rtol=1e-9)
+        assert abs(m1['psnr'][-1] - streamed[k]['psnr'][-1]) < 2e-3
+    drv.metrics = streamed
     arch = dict(drv.arch)
     sd = O.denoising_state_dict(arch, 0)
     torch.set_num_threads(8)

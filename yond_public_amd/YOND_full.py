@@ -28,6 +28,8 @@ from . import pipeline as P
 from . import synthetic as S
 from .YOND_SIDD import YONDParser, log
 
+STREAM_EVAL = True                 # eval(): frames through pipeline.denoise_stream (False: IterDenoise one frame at a time, synchronised after every frame)
+
 
 class SyntheticFrames:
     """Stand-in when the runfile's root_dir holds no frames: low-light Poisson-Gaussian frames of the runfile's size."""
@@ -127,14 +129,15 @@ class YOND_Full:
             torch.cuda.synchronize()
             t0, t_path, npix = time.perf_counter(), 0.0, 0
             from .data import Prefetcher                     # loader threads read / convert / upload the frames ahead of the GPU
-            for k, data in Prefetcher(ds, mine, self.device, upload=('lr', 'hr'), depth=getattr(self.parser, 'prefetch', 4),
-                                      workers=getattr(self.parser, 'loaders', 4)):
+            loader = Prefetcher(ds, mine, self.device, upload=('lr', 'hr'), depth=getattr(self.parser, 'prefetch', 4), workers=getattr(self.parser, 'loaders', 4))
+
+            def params_of(data):
                 p = dict(self.pipe)
                 p.update({'wp': wp, 'bl': bl, 'ratio': data.get('ratio', 1), 'gain': 1, 'sigma': 0})           # YOND_SIDD.py:503-505
                 p['scale'] = (p['wp'] - p['bl']) / p['ratio']
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                res = self.IterDenoise(data, {'p': p, 'img_id': k})
+                return p
+
+            def account(k, data, res):
                 psnrs, ssims = [], []
                 if data.get('hr') is not None:
                     hr = data['hr'] if isinstance(data['hr'], torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data['hr'], np.float32)).to(self.device)
@@ -144,12 +147,36 @@ class YOND_Full:
                         psnrs.append(float(np.mean(ps)))
                         ssims.append(float(np.mean(ss)))
                     sums.update(psnrs, ssims)
-                torch.cuda.synchronize()
-                t_path += time.perf_counter() - t1
-                npix += int(np.prod(tuple(data['lr'].shape)))
                 self.metrics[data['name']] = {'psnr': psnrs, 'ssim': ssims, 'reg': res['regs']}
                 log(f"[rank {self.rank}] {data['name']}: " + (f"PSNR={psnrs[-1]:.2f}, SSIM={ssims[-1]:.4f}" if psnrs else "denoised (no reference frame)")
                     + f", K={res['params'][-1][0]:.3f}, sigma={res['params'][-1][1]:.3f}", self.logfile)
+
+            streamed = STREAM_EVAL and getattr(self.parser, 'stream', True) and not self.parser.verbose and P.stream_applies(self.pipe, self.pipe, self.biaslut)
+            if streamed:
+                # pipeline.denoise_stream: the estimator of the next frame on a side stream, the network passes of consecutive frames on two lanes -- every
+                # frame's result is IterDenoise's (tests/test_hip_pipeline.py); results arrive a few frames late, in order
+                queue = []
+
+                def feed():
+                    for k, data in loader:
+                        queue.append((k, data))
+                        yield data['lr'], params_of(data)
+                t1 = time.perf_counter()
+                for res in P.denoise_stream(feed(), self.net, self.arch, self.pipe, device=self.device):
+                    k, data = queue.pop(0)
+                    account(k, data, res)
+                    npix += int(np.prod(tuple(data['lr'].shape)))
+                torch.cuda.synchronize()
+                t_path += time.perf_counter() - t1           # (includes what the loop waited for its loader threads)
+            else:
+                for k, data in loader:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    res = self.IterDenoise(data, {'p': params_of(data), 'img_id': k})
+                    account(k, data, res)
+                    torch.cuda.synchronize()
+                    t_path += time.perf_counter() - t1
+                    npix += int(np.prod(tuple(data['lr'].shape)))
             torch.cuda.synchronize()
             dt = D.max_over_ranks(time.perf_counter() - t0, self.device)
             red = sums.reduce(self.device)
@@ -161,7 +188,8 @@ class YOND_Full:
                         log(f"Iter{it}: PSNR={red[f'psnr_iter{it}']:.2f}, SSIM={red[f'ssim_iter{it}']:.4f}", self.logfile)
                     log(f"Iter_last: PSNR={red['psnr_last']:.2f}, SSIM={red['ssim_last']:.4f}", self.logfile)
                 log(f"{len(ds)} frames on {self.world} GPU(s) in {dt:.2f} s (rank 0: {t_path / max(len(mine), 1) * 1e3:.1f} ms per frame in "
-                    f"IterDenoise + metrics = {npix / 1e6 / max(t_path, 1e-9):.0f} Bayer MP/s; the rest is data loading)", self.logfile)
+                    + ("denoise_stream + metrics, waits for the loader threads included" if streamed else "IterDenoise + metrics")
+                    + f" = {npix / 1e6 / max(t_path, 1e-9):.0f} Bayer MP/s" + ("" if streamed else "; the rest is data loading") + ")", self.logfile)
         if self.rank == 0:
             log(f"collectives: backend={D.STATS['backend']}, all_reduce={D.STATS['all_reduce']}, barrier={D.STATS['barrier']}", self.logfile)
         return results

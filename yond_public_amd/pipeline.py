@@ -1643,6 +1643,15 @@ def IterDenoiseBatch(frames, net, arch, pipe, p=None, device=None):
     return dict(raw_dns=raw_dns, regs=all_regs, params=all_params, alive=alive)
 
 
+def stream_applies(pipe, p=None, biaslut=None):
+    """True when denoise_stream runs one of its device-chain drivers for this configuration (full-frame denoising, bias_corr 'pre' with the 1-D LUT,
+    est_type 'simple', 'once' or the shipped 'iter' with max_iter 1) -- the configurations in which `frames` may carry per-frame parameter dicts."""
+    ok = (DEVICE_CHAIN and bool(pipe.get('full_dn', False)) and pipe.get('bias_corr', 'pre') == 'pre' and 'simple' in str(pipe.get('est_type', 'simple'))
+          and 'cal_est' not in pipe and pipe.get('full_est', True) and 'rot_cfa' not in (p or {}) and biaslut is None)
+    mode = pipe.get('iter', 'iter')
+    return ok and (mode == 'once' or (mode == 'iter' and pipe.get('max_iter', 1) == 1 and STREAM_ITER))
+
+
 def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     """`IterDenoise` over a sequence of full Bayer frames with the two phases of consecutive frames overlapped
     (pipe['iter'] == 'once', pipe['full_dn']): the noise-level estimation of frame k+1 -- memory / latency bound kernels
@@ -1652,7 +1661,9 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
     Any other mode falls back to IterDenoise.
     Contract for device-tensor frames: frame k+1 is taken from the iterator BEFORE the network pass of frame k is queued
     and its estimate reads it on the side stream, so every frame handed in must stay UNMODIFIED until its own result has
-    been yielded -- a producer that refills one buffer in place must hand in clones."""
+    been yielded -- a producer that refills one buffer in place must hand in clones.
+    An element of `frames` may be a pair (frame, p): a frame with its own parameter dict (wp / bl / ratio / scale: the evaluation drivers' items) --
+    in the configurations `stream_applies` names."""
     chain_cfg = (DEVICE_CHAIN and pipe.get('bias_corr', 'pre') == 'pre' and 'simple' in str(pipe.get('est_type', 'simple')) and 'cal_est' not in pipe
                  and pipe.get('full_est', True) and 'rot_cfa' not in (p or {}))
     if pipe.get('full_dn', False) and pipe.get('iter', 'iter') == 'iter' and pipe.get('max_iter', 1) == 1 and chain_cfg and STREAM_ITER:
@@ -1661,12 +1672,19 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
         return
     if pipe.get('iter', 'iter') != 'once' or not pipe.get('full_dn', False):
         for f in frames:
-            yield IterDenoise(f, net, arch, pipe, p=p, device=device)
+            f, pk = f if isinstance(f, tuple) else (f, p)
+            yield IterDenoise(f, net, arch, pipe, p=pk, device=device)
         return
     p0 = dict(p or default_params())
     if DEVICE_CHAIN and pipe.get('bias_corr', 'pre') == 'pre' and 'simple' in str(pipe.get('est_type', 'simple')) and 'cal_est' not in pipe:
         yield from _denoise_stream_chain(frames, net, arch, pipe, p0, device)
         return
+
+    def _plain(item):
+        if isinstance(item, tuple):
+            raise L.YondHipError("denoise_stream: per-frame parameter dicts need a configuration of the device chain (pipeline.stream_applies)")
+        return item
+    frames = (_plain(f) for f in frames)
     k = pipe.get('k', 29)
     bias_corr = pipe.get('bias_corr', 'pre')
     if bias_corr == 'none':
@@ -1720,6 +1738,18 @@ def denoise_stream(frames, net, arch, pipe, p=None, device=None):
         yield release(pending)
 
 
+def _frame_item(item, p0, device):
+    """An element of a stream driver's `frames`: a frame, or (frame, p) -- a frame with ITS OWN parameter dict (the evaluation drivers: wp / bl / ratio /
+    scale per item, YOND_SIDD.py:503-505).  Returns (device frame, p)."""
+    if isinstance(item, tuple):
+        f, pk = item
+        pk = dict(pk)
+        if 'rot_cfa' in pk:
+            raise L.YondHipError("denoise_stream: a frame with rot_cfa goes through IterDenoise (the stream drivers run the device chain)")
+        return _dev(f, device), pk
+    return _dev(item, device), p0
+
+
 STREAM_LANES = 2                    # network passes in flight on as many HIP streams (1: every pass on the main stream, as rounds 3-5 had it)
 
 
@@ -1742,23 +1772,24 @@ def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
     RING = NL + 2                                                # a frame's buffers rest until it has been yielded: estimate, NL passes in flight, one read
     plan = _plan_of(net, main.device)
 
-    def estimate(lr, ready, slot):
+    def estimate(item, ready, slot):
+        lr, pk = item
         buf = _chain_buffers(lr.device, ('once-stream', slot % RING))
         side.wait_event(ready)                                   # the frame as it stood when it was handed in
         with torch.cuda.stream(side):
-            _chain_estimate(lr, None, 'self', pipe, p0, buf)
+            _chain_estimate(lr, None, 'self', pipe, pk, buf)
             done = side.record_event()
-        return lr, buf, done
+        return lr, pk, buf, done
 
     def release(item):
-        lr, out, buf, watch, fin = item
+        lr, pk, out, buf, watch, fin = item
         fin.synchronize()
         reg, par, flags, info = _chain_result(buf)
         if flags & (PRM_NO_FLAT_AREA | PRM_LUT_CAPACITY | PRM_BAD_ESTIMATE) or (watch is not None and watch.tripped()):
             global DEVICE_CHAIN
             DEVICE_CHAIN = False
             try:
-                return IterDenoise(lr, net, arch, pipe, p=p0)
+                return IterDenoise(lr, net, arch, pipe, p=pk)
             finally:
                 DEVICE_CHAIN = True
         if out.device.type == 'cuda':
@@ -1767,7 +1798,7 @@ def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
 
     it = iter(frames)
     try:
-        f = _dev(next(it), device)
+        f = _frame_item(next(it), p0, device)
     except StopIteration:
         return
     k_frame = 0
@@ -1775,9 +1806,9 @@ def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
     pending = []
     try:
         while nxt is not None:
-            lr, buf, est_done = nxt
+            lr, pk, buf, est_done = nxt
             try:                               # take the next frame (and mark the main stream) BEFORE queuing this one's network
-                f_next = _dev(next(it), device)
+                f_next = _frame_item(next(it), p0, device)
                 ready = main.record_event()
             except StopIteration:
                 f_next = None
@@ -1785,12 +1816,12 @@ def _denoise_stream_chain(frames, net, arch, pipe, p0, device):
             lane.wait_event(est_done)          # (and, through the estimate's own wait, the frame as the main stream uploaded it)
             plan.lane = k_frame % NL
             with torch.cuda.stream(lane):
-                out, watch = _chain_denoise(lr, net, arch, p0, buf, 4 + k_frame % RING)
+                out, watch = _chain_denoise(lr, net, arch, pk, buf, 4 + k_frame % RING)
                 fin = lane.record_event()
             plan.lane = 0
             k_frame += 1
             nxt = estimate(f_next, ready, k_frame) if f_next is not None else None
-            pending.append((lr, out, buf, watch, fin))
+            pending.append((lr, pk, out, buf, watch, fin))
             if len(pending) > NL:              # (NL passes stay queued behind the one the host waits for)
                 yield release(pending.pop(0))
         while pending:
@@ -1836,7 +1867,7 @@ def _denoise_lanes(frames, net, arch, pipe, p0, device, rounds):
             global DEVICE_CHAIN
             DEVICE_CHAIN = False
             try:
-                return IterDenoise(st['lr'], net, arch, pipe, p=p0)
+                return IterDenoise(st['lr'], net, arch, pipe, p=st['p'])
             finally:
                 DEVICE_CHAIN = True
         raw_dns, regs, params = [st['out1']], [reg1], [par1]
@@ -1850,23 +1881,23 @@ def _denoise_lanes(frames, net, arch, pipe, p0, device, rounds):
     k = 0
     try:
         for f in frames:
-            lr = _dev(f, device)                                              # (a host array is uploaded on the main stream)
+            lr, pk = _frame_item(f, p0, device)                               # (a host array is uploaded on the main stream)
             lane = lanes[k % NL]
             if lane is not main:
                 lane.wait_event(main.record_event())                          # the frame as it stood when it was handed in
-            st = dict(lr=lr, g2=None)
+            st = dict(lr=lr, p=pk, g2=None)
             plan.lane = k % NL
             try:
                 with torch.cuda.stream(lane):
                     b1 = bufs(k, 0)
-                    _chain_estimate(lr, None, 'self', pipe, p0, b1)                                              # E1
-                    st['out1'], st['g1'] = _chain_denoise(lr, net, arch, p0, b1, 4 + 2 * (k % RING))           # D1
+                    _chain_estimate(lr, None, 'self', pipe, pk, b1)                                              # E1
+                    st['out1'], st['g1'] = _chain_denoise(lr, net, arch, pk, b1, 4 + 2 * (k % RING))           # D1
                     if rounds == 2:
                         mx = torch.empty(1, dtype=torch.float32, device=main.device)
                         mx.copy_(b1.prm[PRM['frame_max']:PRM['frame_max'] + 1])                                  # float64 holding the float32 maximum -> float32
-                        _chain_estimate(lr, st['out1'], 'collab', pipe, p0, bufs(k, 1), lr_max_dev=mx)           # E2
+                        _chain_estimate(lr, st['out1'], 'collab', pipe, pk, bufs(k, 1), lr_max_dev=mx)           # E2
                         st['mx'] = mx
-                        st['out2'], st['g2'] = _chain_denoise(lr, net, arch, p0, bufs(k, 1), 4 + 2 * (k % RING) + 1)    # D2
+                        st['out2'], st['g2'] = _chain_denoise(lr, net, arch, pk, bufs(k, 1), 4 + 2 * (k % RING) + 1)    # D2
                     st['fin'] = lane.record_event()
             finally:
                 plan.lane = 0
@@ -1909,10 +1940,10 @@ def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
     def bufs(k, r):
         return _chain_buffers(main.device, ('iter-stream', k % RING, r))
 
-    def est1(lr, ready, k):
+    def est1(lr, pk, ready, k):
         side.wait_event(ready)                                                # the frame as it stood when it was handed in
         with torch.cuda.stream(side):
-            _chain_estimate(lr, None, 'self', pipe, p0, bufs(k, 0))
+            _chain_estimate(lr, None, 'self', pipe, pk, bufs(k, 0))
             return side.record_event()
 
     def est2(st, k):
@@ -1921,7 +1952,7 @@ def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
         with torch.cuda.stream(side):
             mx = torch.empty(1, dtype=torch.float32, device=main.device)
             mx.copy_(b1.prm[PRM['frame_max']:PRM['frame_max'] + 1])           # float64 holding the float32 maximum -> float32
-            _chain_estimate(st['lr'], st['out1'], 'collab', pipe, p0, b2, lr_max_dev=mx)
+            _chain_estimate(st['lr'], st['out1'], 'collab', pipe, st['p'], b2, lr_max_dev=mx)
             st['mx'] = mx
             return side.record_event()
 
@@ -1939,7 +1970,7 @@ def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
             global DEVICE_CHAIN
             DEVICE_CHAIN = False
             try:
-                return IterDenoise(st['lr'], net, arch, pipe, p=p0)
+                return IterDenoise(st['lr'], net, arch, pipe, p=st['p'])
             finally:
                 DEVICE_CHAIN = True
         raw_dns, regs, params = [st['out1']], [reg1], [par1]
@@ -1957,7 +1988,7 @@ def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
         plan.lane = 0 if lane2 is main else 1
         try:
             with torch.cuda.stream(lane2):
-                st['out2'], st['g2'] = _chain_denoise(st['lr'], net, arch, p0, bufs(k, 1), 4 + 2 * (k % RING) + 1)
+                st['out2'], st['g2'] = _chain_denoise(st['lr'], net, arch, st['p'], bufs(k, 1), 4 + 2 * (k % RING) + 1)
                 st['fin2'] = lane2.record_event()
         finally:
             plan.lane = 0
@@ -1966,26 +1997,26 @@ def _denoise_stream_chain_iter(frames, net, arch, pipe, p0, device):
 
     it = iter(frames)
     try:
-        f = _dev(next(it), device)
+        f, fp = _frame_item(next(it), p0, device)
     except StopIteration:
         return
     live = {}                                                                 # frame index -> its state
     k = 0
-    live[0] = dict(lr=f)
-    live[0]['e1'] = est1(f, main.record_event(), 0)
+    live[0] = dict(lr=f, p=fp)
+    live[0]['e1'] = est1(f, fp, main.record_event(), 0)
     while k in live:
         st = live[k]
         try:                               # take the next frame (and mark the main stream) BEFORE queuing this one's network
-            f_next = _dev(next(it), device)
+            f_next, p_next = _frame_item(next(it), p0, device)
             ready = main.record_event()
         except StopIteration:
             f_next = None
         main.wait_event(st['e1'])
-        st['out1'], st['g1'] = _chain_denoise(st['lr'], net, arch, p0, bufs(k, 0), 4 + 2 * (k % RING))       # D1(k)
+        st['out1'], st['g1'] = _chain_denoise(st['lr'], net, arch, st['p'], bufs(k, 0), 4 + 2 * (k % RING))       # D1(k)
         st['fin1'] = main.record_event()
         if f_next is not None:
-            live[k + 1] = dict(lr=f_next)
-            live[k + 1]['e1'] = est1(f_next, ready, k + 1)                     # E1(k+1): under D1(k)
+            live[k + 1] = dict(lr=f_next, p=p_next)
+            live[k + 1]['e1'] = est1(f_next, p_next, ready, k + 1)                     # E1(k+1): under D1(k)
         st['e2'] = est2(st, k)                                                # E2(k): behind D1(k), under D2(k-1)
         if k - 1 in live:
             round2(live[k - 1], k - 1)                                        # D2(k-1)

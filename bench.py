@@ -669,12 +669,12 @@ def main(argv=None):
         if prof_wall is not None:
             wall = [e0.elapsed_time(e1) for tag, _, e0, e1 in prof_wall if tag == dom]
             roof["measured"] = (f"HIP events on the launch stream around the 3x3 stride-1 launches of every 4th forward while the timed region's job ({F} frames per step, {n_roof} steps) ran on ONE "
-                                "lane right behind the timed region; rocprofv3 counterpart: profiles/r06_bench_once_one_lane_kernel_stats.csv (bench.py --lanes 1)")
+                                f"lane right behind the timed region; rocprofv3 counterpart: profiles/r06_bench_{'cfg5' if a.cfg == 5 else 'once'}_one_lane_kernel_stats.csv (bench.py --lanes 1)")
             roof["one_lane_ms_per_frame"] = round(one_lane_ms_per_frame, 3)
             roof["timed_region_wall"] = {"launches": len(wall), "avg_launch_ms": round(sum(wall) / max(len(wall), 1), 4),
                                          "note": f"the timed region runs the network passes of consecutive frames on {P.STREAM_LANES} lanes: the persistent workgroups of one lane's launch take "
                                                  "the CUs as the other lane's launch retires them, so the time between a launch's events there includes its wait for the other lane's "
-                                                 "workgroups (rocprofv3 of the default command shows the same durations: profiles/r06_bench_once_kernel_stats.csv)"}
+                                                 f"workgroups (rocprofv3 of the default command shows the same durations: profiles/r06_bench_{'cfg5' if a.cfg == 5 else 'once'}_kernel_stats.csv)"}
         if dom.startswith("conv_wino_kernel"):
             # Winograd F(2x2,3x3) issues 16 multiplications per patch where the direct algorithm has 36: `achieved`
             # counts the ALGORITHMIC flops of the convolution; the flops the MFMA unit really executes are 16/36 of that

@@ -637,15 +637,18 @@ def main(argv=None):
 
     stage_prof, prof_all = [], []
     if not a.no_kernel_events:
-        plan.prof = []
-        P.PROF = []
-        if a.batch:
-            run(a.batch)
-        else:
-            one(last_frame)
-        torch.cuda.synchronize()
-        prof_all, plan.prof = plan.prof, None
-        stage_prof, P.PROF = P.PROF, None
+        passes = []                                  # three instrumented passes, the one with the median stage total is reported (a pass whose stage
+        for _ in range(3):                           # holds an allocator refill -- a host gap between two event records -- is not the stage's time)
+            plan.prof = []
+            P.PROF = []
+            if a.batch:
+                run(a.batch)
+            else:
+                one(last_frame)
+            torch.cuda.synchronize()
+            passes.append((sum(e0.elapsed_time(e1) for _, e0, e1 in P.PROF), plan.prof, P.PROF))
+            plan.prof, P.PROF = None, None
+        _, prof_all, stage_prof = sorted(passes, key=lambda t: t[0])[1]
     inst_frames = a.batch or 1
 
     # dominant kernel: the 3x3 stride-1 convolution kernel that takes the most time (18 launches per forward, 91 % of the
@@ -711,7 +714,7 @@ def main(argv=None):
         roof_hbm = {"stage": "VST+NLE (K1, K4, K5-K7)", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBPS, 4), "algorithmic_bytes_per_bayer_px": bpp, "ms_per_frame": round(tot_ms, 4),
                     "stage_ms_per_frame": {k: round(v / inst_frames, 4) for k, v in stage_ms.items()},
-                    "measured": "HIP events, one instrumented pass after the timed region"}
+                    "measured": "HIP events, the median of three instrumented passes after the timed region"}
     conv_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof_all) / inst_frames
     conv_fl = sum(fl for _, fl, _, _ in prof_all) / inst_frames
 
@@ -954,7 +957,7 @@ def main(argv=None):
             "roofline_vst_nle": roof_hbm,
             "conv_stack": {"ms_per_frame": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
                            "share_of_frame": round(conv_ms / (elapsed / n_timed * 1e3), 3) if conv_ms else None,
-                           "measured": "HIP events around every convolution launch, one instrumented pass after the timed region"},
+                           "measured": "HIP events around every convolution launch, the median of three instrumented passes after the timed region"},
             "psnr_vs_clean_db": {"denoised": round(red["psnr_last"], 3), "noisy_input": round(10 * np.log10(1.0 / mse_in), 3)},
             "estimated_K_sigma": [[round(float(v), 4) for v in pr] for pr in (res['params'] if not a.batch else res['params'][-1])],
             **({"images_per_s": round(world * n_timed / elapsed, 2), "ms_per_image": round(elapsed / n_timed * 1e3, 3),

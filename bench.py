@@ -676,8 +676,9 @@ def main(argv=None):
             roof["one_lane_ms_per_frame"] = round(one_lane_ms_per_frame, 3)
             roof["timed_region_wall"] = {"launches": len(wall), "avg_launch_ms": round(sum(wall) / max(len(wall), 1), 4),
                                          "note": f"the timed region runs the network passes of consecutive frames on {P.STREAM_LANES} lanes: the persistent workgroups of one lane's launch take "
-                                                 "the CUs as the other lane's launch retires them, so the time between a launch's events there includes its wait for the other lane's "
-                                                 f"workgroups (rocprofv3 of the default command shows the same durations: profiles/r06_bench_{'cfg5' if a.cfg == 5 else 'once'}_kernel_stats.csv)"}
+                                                 "the CUs as the other lane's launch retires them, so the time between a launch's HIP events there includes its wait in the hardware queue "
+                                                 "for the other lane's workgroups; rocprofv3's begin / end timestamps of the default command -- the launch's own execution -- stay within ~3 % of "
+                                                 f"the one-lane durations (profiles/r06_bench_{'cfg5' if a.cfg == 5 else 'once'}_kernel_stats.csv beside ..._one_lane_kernel_stats.csv)"}
         if dom.startswith("conv_wino_kernel"):
             # Winograd F(2x2,3x3) issues 16 multiplications per patch where the direct algorithm has 36: `achieved`
             # counts the ALGORITHMIC flops of the convolution; the flops the MFMA unit really executes are 16/36 of that

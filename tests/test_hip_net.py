@@ -227,3 +227,36 @@ def test_unet_split_plane_pairs_bit_identical():
         E.UNET_SP = saved
     torch.cuda.synchronize()
     assert bool(torch.isfinite(a).all()) and torch.equal(a, b), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_two_lanes_forward_concurrently_bit_equal(precision):
+    """Round 6: the stream drivers run the network passes of consecutive frames on two HIP streams, each engine `lane` with its own split-plane
+    tensors and FiLM vectors (DenoiserPlan.lane).  Two DIFFERENT inputs with different noise levels queued on the two lanes without any
+    synchronisation between them must each come out bit for bit as when forwarded alone -- several times over, so that the lanes' persistent
+    tensors (whose zero padding is written once) are reused."""
+    from yond_public_amd import pipeline as P
+    arch = dict(name='GuidedResUnet', guided=True, in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True)
+    net, _ = make_net(arch, 9)
+    net.precision = precision
+    plan = P._plan_of(net, torch.device(DEV))
+    g = torch.Generator().manual_seed(5)
+    xa = torch.rand((1, 96, 160, 4), generator=g).to(DEV)
+    xb = (torch.rand((1, 96, 160, 4), generator=g) * 0.5).to(DEV)
+    ta, tb = torch.tensor([0.02], device=DEV), torch.tensor([0.07], device=DEV)
+    alone_a = plan.forward_nhwc4(xa, ta).clone()
+    alone_b = plan.forward_nhwc4(xb, tb).clone()
+    torch.cuda.synchronize()
+    assert float((alone_a - alone_b).abs().max()) > 1e-3
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    for rep in range(3):
+        side.wait_stream(main)
+        plan.lane = 1
+        with torch.cuda.stream(side):
+            yb = plan.forward_nhwc4(xb, tb)
+        plan.lane = 0
+        ya = plan.forward_nhwc4(xa, ta)
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, alone_a) and torch.equal(yb, alone_b), f"repetition {rep}"
+    assert plan.lane == 0

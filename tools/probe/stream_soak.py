@@ -20,7 +20,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 dev = torch.device('cuda:0')
 arch = dict(name='GuidedResUnet', in_nc=4, out_nc=4, nf=32, nframes=1, res=True, norm=True, guided=True)
 net = A.GuidedResUnet(dict(arch)); net.load_state_dict(S.procedural_state_dict(net, 0)); net = net.to(dev).eval()
-pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': 'once', 'max_iter': 1, 'full_dn': True}
+pipe = {'k': 29, 'vst_type': 'exact', 'bias_corr': 'pre', 'iter': os.environ.get('MODE', 'once'), 'max_iter': 1, 'full_dn': True}     # MODE=iter: the shipped two-round mode
+if os.environ.get('WEIGHTS') == 'denoise':
+    net.load_state_dict(S.denoising_state_dict(net, 0)); net = net.to(dev).eval()        # (round 2 then runs; with procedural weights it ends at the beta1 < 0 guard)
 kinds = [torch.from_numpy(S.synth_noisy(h, w, 3.0 + i, 5.0 + 2 * i, 10 + i)[0]).to(dev) for i, (h, w) in enumerate([(256, 320), (512, 768), (256, 320), (384, 512), (512, 768)])]
 ref = [P.IterDenoise(f, net, arch, pipe) for f in kinds]
 torch.cuda.synchronize()
@@ -36,10 +38,11 @@ def gen():
 worst = 0.0
 for i, r in enumerate(P.denoise_stream(gen(), net, arch, pipe)):
     k = order[i]
-    d = float((r['raw_dns'][0] - ref[k]['raw_dns'][0]).abs().max())
+    assert len(r['raw_dns']) == len(ref[k]['raw_dns'])
+    d = max(float((a_ - b_).abs().max()) for a_, b_ in zip(r['raw_dns'], ref[k]['raw_dns']))
     dr = float(np.abs(np.asarray(r['regs'], np.float64) / np.asarray(ref[k]['regs'], np.float64) - 1.0).max())
     worst = max(worst, d)
-    if not (d <= 5e-6 and dr <= 1e-9):
+    if not (d <= 5e-6 and dr <= (1e-9 if pipe['iter'] == 'once' else 3e-4)):
         print(f"frame {i} (content {k}): output differs from IterDenoise's by {d:g}, estimate by {dr:g} (relative)")
         sys.exit(1)
 print(f"{n} frames through denoise_stream: every one equal to its IterDenoise result (largest difference {worst:.3g}; max |output| {max(float(q['raw_dns'][0].abs().max()) for q in ref):.3g}, dtype {ref[0]['raw_dns'][0].dtype})")

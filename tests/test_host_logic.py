@@ -92,3 +92,27 @@ def test_fit_from_moments_rank_deficient_is_minimum_norm():
     ref1 = np.linalg.pinv(np.array([[0.3, 1.0]])) @ np.array([2e-4])
     np.testing.assert_allclose(P._fit_from_moments(one, one), ref1, rtol=1e-9)
     assert np.all(P._fit_from_moments(np.zeros(5), np.zeros(5)) == 0)
+
+
+def test_stream_applies_and_frame_items():
+    """Host logic of the stream drivers (round 6): which configurations pipeline.denoise_stream runs on its device-chain drivers -- the ones whose
+    `frames` may carry per-frame parameter dicts -- and how an element of `frames` is read (no GPU: CPU tensors without a device are refused)."""
+    import pytest
+    import torch
+    from yond_public_amd import pipeline as P
+    from yond_public_amd import _lib as L
+    once = {'k': 29, 'bias_corr': 'pre', 'iter': 'once', 'full_dn': True}
+    assert P.stream_applies(once) and P.stream_applies(dict(once, iter='iter', max_iter=1))
+    assert not P.stream_applies(dict(once, iter='iter', max_iter=2))                  # only the shipped single re-estimation is streamed
+    assert not P.stream_applies(dict(once, full_dn=False))                            # block-wise denoising: the SIDD group driver's job
+    assert not P.stream_applies(dict(once, bias_corr='post'))
+    assert not P.stream_applies(dict(once, est_type='ours'))
+    assert not P.stream_applies(dict(once, cal_est='foi'))
+    assert not P.stream_applies(once, p={'rot_cfa': 1})
+    assert not P.stream_applies(once, biaslut=object())                               # the 2-D LUT goes through IterDenoise
+    p0 = {'wp': 1023, 'bl': 64}
+    with pytest.raises(L.YondHipError):
+        P._frame_item((torch.zeros(4, 4), {'rot_cfa': 2}), p0, None)
+    with pytest.raises(L.YondHipError):
+        P._frame_item(torch.zeros(4, 4), p0, None)                                    # a CPU tensor and no device: no CPU fallback
+    assert P.STREAM_LANES == 2 and not P.LANE_PIPELINES and not P.LANE_PIPELINES_ONCE

@@ -949,6 +949,8 @@ def main(argv=None):
                        "weights": {"denoising": "synthetic.denoising_state_dict (analytic 3x3 box-mean path + eps-scaled procedural weights)",
                                    "procedural": "synthetic.procedural_state_dict (seeded random)"}[a.weights]},
             "gfx_clock": sclk_res,
+            "hbm_gb": {"peak_allocated": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2), "peak_reserved": round(torch.cuda.max_memory_reserved(dev) / 1e9, 2),
+                       "note": "torch's caching allocator on rank 0 over the whole run (every leg of this line); the library allocates nothing itself"},
             "roofline": roof,
             "sequential": seq,
             "iter_pipeline": iter_leg,
